@@ -1,0 +1,199 @@
+"""Weight containers for the airfe front end.
+
+The reference keeps its weights inside ONNX files that TensorRT turns into
+``*.engine`` caches on first run (``src/plnet.cpp:24-196,587-643``,
+``src/super_point.cpp:18-85``, ``src/light_glue.cpp:20-106``,
+``src/super_glue.cpp:20-120``).  Our equivalent is a flat *pack* file: named
+fp32 tensors in PyTorch ``state_dict`` naming and layout.  ``libairfe.so`` reads
+the pack at ``airfe_create`` time and re-packs the tensors into its MFMA slab
+layout (≙ engine build); nothing here knows about the device layout.
+
+Five of the six ONNX files are absent from the reference checkout
+(``.MISSING_LARGE_BLOBS``), so this module also owns the *synthetic* weight
+generator used for throughput runs and HIP-vs-oracle parity (same tensors on
+both sides).  Shapes follow the public SuperPoint / LightGlue / SuperGlue
+definitions (marked UNVERIFIED-UPSTREAM there).
+
+Pack file format (little endian)::
+
+    char[8]  magic  = b"AIRFEPK1"
+    u32      count
+    count x { u32 name_len; char name[name_len]; u32 ndim; u32 dims[ndim];
+              f32 data[prod(dims)] }
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+MAGIC = b"AIRFEPK1"
+
+Spec = List[Tuple[str, Tuple[int, ...]]]
+
+
+# --------------------------------------------------------------------------- specs
+def superpoint_spec() -> Spec:
+    """SuperPoint v1 VGG encoder + detector/descriptor heads."""
+    chans = [("conv1a", 1, 64), ("conv1b", 64, 64), ("conv2a", 64, 64), ("conv2b", 64, 64),
+             ("conv3a", 64, 128), ("conv3b", 128, 128), ("conv4a", 128, 128), ("conv4b", 128, 128),
+             ("convPa", 128, 256), ("convDa", 128, 256)]
+    spec: Spec = []
+    for name, cin, cout in chans:
+        spec.append((f"{name}.weight", (cout, cin, 3, 3)))
+        spec.append((f"{name}.bias", (cout,)))
+    spec += [("convPb.weight", (65, 256, 1, 1)), ("convPb.bias", (65,)),
+             ("convDb.weight", (256, 256, 1, 1)), ("convDb.bias", (256,))]
+    return spec
+
+
+LG_LAYERS = 9
+LG_DIM = 256
+LG_HEADS = 4
+
+
+def lightglue_spec(n_layers: int = LG_LAYERS) -> Spec:
+    """LightGlue (SuperPoint flavour) — SURVEY.md C.2."""
+    d = LG_DIM
+    spec: Spec = [("posenc.Wr.weight", (32, 2))]
+    for i in range(n_layers):
+        s = f"transformers.{i}.self_attn"
+        spec += [(f"{s}.Wqkv.weight", (3 * d, d)), (f"{s}.Wqkv.bias", (3 * d,)),
+                 (f"{s}.out_proj.weight", (d, d)), (f"{s}.out_proj.bias", (d,)),
+                 (f"{s}.ffn.0.weight", (2 * d, 2 * d)), (f"{s}.ffn.0.bias", (2 * d,)),
+                 (f"{s}.ffn.1.weight", (2 * d,)), (f"{s}.ffn.1.bias", (2 * d,)),
+                 (f"{s}.ffn.3.weight", (d, 2 * d)), (f"{s}.ffn.3.bias", (d,))]
+        c = f"transformers.{i}.cross_attn"
+        spec += [(f"{c}.to_qk.weight", (d, d)), (f"{c}.to_qk.bias", (d,)),
+                 (f"{c}.to_v.weight", (d, d)), (f"{c}.to_v.bias", (d,)),
+                 (f"{c}.to_out.weight", (d, d)), (f"{c}.to_out.bias", (d,)),
+                 (f"{c}.ffn.0.weight", (2 * d, 2 * d)), (f"{c}.ffn.0.bias", (2 * d,)),
+                 (f"{c}.ffn.1.weight", (2 * d,)), (f"{c}.ffn.1.bias", (2 * d,)),
+                 (f"{c}.ffn.3.weight", (d, 2 * d)), (f"{c}.ffn.3.bias", (d,))]
+    # only the last layer's assignment head is evaluated at inference (no early exit)
+    a = f"log_assignment.{n_layers - 1}"
+    spec += [(f"{a}.matchability.weight", (1, d)), (f"{a}.matchability.bias", (1,)),
+             (f"{a}.final_proj.weight", (d, d)), (f"{a}.final_proj.bias", (d,))]
+    return spec
+
+
+SG_LAYERS = 18
+
+
+def superglue_spec(n_layers: int = SG_LAYERS) -> Spec:
+    """SuperGlue — SURVEY.md C.3.  BatchNorm is stored folded (inference form)."""
+    d = 256
+    spec: Spec = []
+    enc = [3, 32, 64, 128, 256, d]
+    for i in range(len(enc) - 1):
+        spec += [(f"kenc.encoder.{i}.weight", (enc[i + 1], enc[i])), (f"kenc.encoder.{i}.bias", (enc[i + 1],))]
+    for i in range(n_layers):
+        g = f"gnn.layers.{i}"
+        for p in ("attn.proj.0", "attn.proj.1", "attn.proj.2", "attn.merge"):
+            spec += [(f"{g}.{p}.weight", (d, d)), (f"{g}.{p}.bias", (d,))]
+        spec += [(f"{g}.mlp.0.weight", (2 * d, 2 * d)), (f"{g}.mlp.0.bias", (2 * d,)),
+                 (f"{g}.mlp.3.weight", (d, 2 * d)), (f"{g}.mlp.3.bias", (d,))]
+    spec += [("final_proj.weight", (d, d)), ("final_proj.bias", (d,)), ("bin_score", (1,))]
+    return spec
+
+
+def plnet_s1_spec() -> Spec:
+    """PLNet stage-1 LOI head, shapes decoded from output/plnet_s1.onnx."""
+    return [("fc2.0.weight", (128, 496)), ("fc2.0.bias", (128,)),
+            ("fc2.2.weight", (128, 128)), ("fc2.2.bias", (128,)),
+            ("fc2.4.weight", (128, 128)), ("fc2.4.bias", (128,)),
+            ("fc2_res.0.weight", (128, 240)), ("fc2_res.0.bias", (128,)),
+            ("fc2_head.weight", (2, 128)), ("fc2_head.bias", (2,))]
+
+
+# ----------------------------------------------------------------------- synthetic
+def _fan_in(shape: Tuple[int, ...]) -> int:
+    n = 1
+    for s in shape[1:]:
+        n *= s
+    return max(n, 1)
+
+
+def synthetic(spec: Spec, seed: int = 1234, gain: float = 1.0) -> Dict[str, np.ndarray]:
+    """Seeded He-uniform weights, small uniform biases; LayerNorm gains near 1."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in spec:
+        if name.endswith(".bias"):
+            w = rng.uniform(-0.05, 0.05, size=shape)
+        elif len(shape) == 1:  # LayerNorm weight / scalar parameters
+            w = rng.uniform(0.9, 1.1, size=shape)
+        else:
+            bound = gain * np.sqrt(6.0 / _fan_in(shape))
+            w = rng.uniform(-bound, bound, size=shape)
+        out[name] = w.astype(np.float32)
+    return out
+
+
+def synthetic_superpoint(seed: int = 1234) -> Dict[str, np.ndarray]:
+    w = synthetic(superpoint_spec(), seed)
+    # Make the heat map look like a trained detector's: strong dustbin, peaky logits.
+    rng = np.random.default_rng(seed + 1)
+    w["convPb.weight"] = (w["convPb.weight"] * 6.0).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, size=(65,)).astype(np.float32)
+    b[64] = 4.0
+    w["convPb.bias"] = b
+    return w
+
+
+def synthetic_lightglue(seed: int = 1234, n_layers: int = LG_LAYERS) -> Dict[str, np.ndarray]:
+    w = synthetic(lightglue_spec(n_layers), seed + 10, gain=0.6)
+    rng = np.random.default_rng(seed + 11)
+    # upstream init: normal(0, gamma^-2), gamma = 1
+    w["posenc.Wr.weight"] = rng.normal(0.0, 1.0, size=(32, 2)).astype(np.float32)
+    return w
+
+
+def synthetic_superglue(seed: int = 1234, n_layers: int = SG_LAYERS) -> Dict[str, np.ndarray]:
+    w = synthetic(superglue_spec(n_layers), seed + 20, gain=0.6)
+    w["bin_score"] = np.array([1.0], dtype=np.float32)
+    return w
+
+
+def synthetic_plnet_s1(seed: int = 1234) -> Dict[str, np.ndarray]:
+    return synthetic(plnet_s1_spec(), seed + 30)
+
+
+# ---------------------------------------------------------------------------- packs
+def save_pack(path: str, tensors: Dict[str, np.ndarray]) -> None:
+    with open(path, "wb") as f:
+        f.write(MAGIC)
+        f.write(struct.pack("<I", len(tensors)))
+        for name, arr in tensors.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            nb = name.encode()
+            f.write(struct.pack("<I", len(nb)))
+            f.write(nb)
+            f.write(struct.pack("<I", a.ndim))
+            f.write(struct.pack(f"<{a.ndim}I", *a.shape))
+            f.write(a.tobytes())
+
+
+def load_pack(path: str) -> Dict[str, np.ndarray]:
+    out: Dict[str, np.ndarray] = {}
+    with open(path, "rb") as f:
+        if f.read(8) != MAGIC:
+            raise ValueError(f"{path}: not an airfe weight pack")
+        (count,) = struct.unpack("<I", f.read(4))
+        for _ in range(count):
+            (nl,) = struct.unpack("<I", f.read(4))
+            name = f.read(nl).decode()
+            (nd,) = struct.unpack("<I", f.read(4))
+            dims = struct.unpack(f"<{nd}I", f.read(4 * nd)) if nd else ()
+            n = int(np.prod(dims)) if nd else 1
+            out[name] = np.frombuffer(f.read(4 * n), dtype="<f4").reshape(dims).copy()
+    return out
+
+
+def check_spec(tensors: Dict[str, np.ndarray], spec: Spec) -> None:
+    for name, shape in spec:
+        if name not in tensors:
+            raise KeyError(f"weight pack is missing tensor {name!r}")
+        if tuple(tensors[name].shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {tensors[name].shape} != expected {shape}")

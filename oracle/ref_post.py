@@ -1,0 +1,317 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product (airslam_amd/).
+
+numpy restatement of every CPU routine on the reference's detect/match path.
+Each function cites the reference file:line it follows (paths under
+/root/reference).  Arithmetic is carried out in float32 op by op wherever the
+C++ does float arithmetic, so results match the C++ up to FMA contraction.
+
+PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for
+this path, and cannot be compiled here (TensorRT, OpenCV,
+Eigen absent).  These restatements are pinned only by reading the code.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F = np.float32
+
+
+# ------------------------------------------------------------------ pre-process
+def _resize_coeffs(dsize: int, ssize: int):
+    """OpenCV 4.x resize() INTER_LINEAR coefficient table for 8-bit images
+    (imgproc/src/resize.cpp: `fx = (float)((dx+0.5)*scale_x - 0.5)`, edge clamps,
+    `saturate_cast<short>(cbuf[k]*INTER_RESIZE_COEF_SCALE)` with scale 2048)."""
+    scale = float(ssize) / float(dsize)
+    d = np.arange(dsize, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(F)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(F)).astype(F)
+    lo = s < 0
+    f[lo] = 0
+    s[lo] = 0
+    hi = s >= ssize - 1
+    f[hi] = 0
+    s[hi] = ssize - 1
+    a0 = np.rint((F(1.0) - f) * F(2048.0)).astype(np.int64)   # cvRound: half to even
+    a1 = np.rint(f * F(2048.0)).astype(np.int64)
+    s1 = np.minimum(s + 1, ssize - 1)
+    return s, s1, a0, a1
+
+
+def resize_linear_u8(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """cv::resize(src, dst, Size(dw, dh)) for CV_8UC1, default INTER_LINEAR, as called at
+    src/plnet.cpp:258 and src/super_point.cpp:116 (fixed-point path: HResizeLinear with
+    11-bit coefficients, VResizeLinear `(((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2`)."""
+    sh, sw = src.shape
+    if sw == dw and sh == dh:
+        return src.copy()
+    xs, xs1, xa0, xa1 = _resize_coeffs(dw, sw)
+    ys, ys1, yb0, yb1 = _resize_coeffs(dh, sh)
+    s = src.astype(np.int64)
+    hp = s[:, xs] * xa0[None, :] + s[:, xs1] * xa1[None, :]            # [sh, dw]
+    r0 = hp[ys, :]
+    r1 = hp[ys1, :]
+    out = (((yb0[:, None] * (r0 >> 4)) >> 16) + ((yb1[:, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def process_image(image: np.ndarray, rw: int = 512, rh: int = 512):
+    """PLNet::process_image src/plnet.cpp:246-270 (≡ SuperPoint src/super_point.cpp:111-116,146-165):
+    resize to 512x512, `float(px) / 255.0` (double division, stored as float)."""
+    h, w = image.shape
+    w_scale = F(F(w) / F(rw))
+    h_scale = F(F(h) / F(rh))
+    r = resize_linear_u8(image, rw, rh)
+    x = (r.astype(np.float64) / 255.0).astype(F)
+    return x, w_scale, h_scale
+
+
+# ------------------------------------------------------------------ model-side NMS
+def simple_nms(scores: np.ndarray, radius: int) -> np.ndarray:
+    """SuperPoint `simple_nms` (public SuperGluePretrainedNetwork models/superpoint.py); believed
+    to be baked into superpoint_v1_sim_int32.onnx / plnet_s0.onnx (UNVERIFIED-UPSTREAM; the C++
+    does no NMS: src/plnet.cpp:309-355).  radius 0 disables it."""
+    if radius <= 0:
+        return scores.copy()
+
+    def max_pool(x):
+        h, w = x.shape
+        k = 2 * radius + 1
+        p = np.full((h + 2 * radius, w + 2 * radius), -np.inf, dtype=x.dtype)
+        p[radius:radius + h, radius:radius + w] = x
+        # separable sliding max
+        t = p[:, 0:w].copy()
+        for i in range(1, k):
+            np.maximum(t, p[:, i:i + w], out=t)
+        o = t[0:h].copy()
+        for i in range(1, k):
+            np.maximum(o, t[i:i + h], out=o)
+        return o
+
+    zeros = np.zeros_like(scores)
+    max_mask = scores == max_pool(scores)
+    for _ in range(2):
+        supp_mask = max_pool(max_mask.astype(scores.dtype)) > 0
+        supp_scores = np.where(supp_mask, zeros, scores)
+        new_max_mask = supp_scores == max_pool(supp_scores)
+        max_mask = max_mask | (new_max_mask & (~supp_mask))
+    return np.where(max_mask, scores, zeros)
+
+
+# ------------------------------------------------------------------ keypoint decode
+def detect_point(heat: np.ndarray, threshold: float, border: int, top_k: int):
+    """PLNet::detect_point src/plnet.cpp:309-355 ≡ SuperPoint::detect_point src/super_point.cpp:174-217.
+    Upper border bound is INCLUSIVE (x > w-border rejects).  If more than top_k candidates: sorted by
+    score descending (std::sort, unstable → we fix ties by ascending raster index);
+    otherwise raster order, unsorted."""
+    h, w = heat.shape
+    flat = heat.reshape(-1)
+    idx = np.nonzero(~(flat < F(threshold)))[0]
+    y = idx // w
+    x = idx - y * w
+    keep = ~((x < border) | (x > w - border) | (y < border) | (y > h - border))
+    idx, x, y = idx[keep], x[keep], y[keep]
+    s = flat[idx]
+    if idx.size > top_k:
+        order = np.argsort(-s.astype(np.float64), kind="stable")[:top_k]
+        idx, x, y, s = idx[order], x[order], y[order], s[order]
+    return s.astype(F), x.astype(F), y.astype(F)
+
+
+def _clip(v, mx):
+    return np.maximum(0, np.minimum(v, mx - 1))
+
+
+def extract_descriptors(desc_chw: np.ndarray, xs: np.ndarray, ys: np.ndarray, s: int = 8) -> np.ndarray:
+    """PLNet::extract_descriptors src/plnet.cpp:369-417 ≡ src/super_point.cpp:224-272.
+    desc_chw: [256, h, w] float32.  Returns [N, 256] (row n = Eigen column n rows 3..258)."""
+    c, h, w = desc_chw.shape
+    sx = F(2.0 / (w * s - s // 2 - 0.5))
+    bx = F((1 - s) / (w * s - s // 2 - 0.5) - 1)
+    sy = F(2.0 / (h * s - s // 2 - 0.5))
+    by = F((1 - s) / (h * s - s // 2 - 0.5) - 1)
+    kx = (xs.astype(F) * sx + bx).astype(F)
+    ky = (ys.astype(F) * sy + by).astype(F)
+    kx = ((kx + F(1)) * F(0.5)).astype(F)
+    ky = ((ky + F(1)) * F(0.5)).astype(F)
+    ix = (kx * F(w - 1)).astype(F)
+    iy = (ky * F(h - 1)).astype(F)
+    ix_nw = _clip(np.floor(ix).astype(np.int64), w)
+    iy_nw = _clip(np.floor(iy).astype(np.int64), h)
+    ix_ne = _clip(ix_nw + 1, w)
+    iy_ne = _clip(iy_nw, h)
+    ix_sw = _clip(ix_nw, w)
+    iy_sw = _clip(iy_nw + 1, h)
+    ix_se = _clip(ix_nw + 1, w)
+    iy_se = _clip(iy_nw + 1, h)
+    nw = ((ix_se.astype(F) - ix) * (iy_se.astype(F) - iy)).astype(F)
+    ne = ((ix - ix_sw.astype(F)) * (iy_sw.astype(F) - iy)).astype(F)
+    sw_ = ((ix_ne.astype(F) - ix) * (iy - iy_ne.astype(F))).astype(F)
+    se = ((ix - ix_nw.astype(F)) * (iy - iy_nw.astype(F))).astype(F)
+    d = desc_chw
+    v = (d[:, iy_nw, ix_nw] * nw[None]).astype(F)
+    v = (v + (d[:, iy_ne, ix_ne] * ne[None]).astype(F)).astype(F)
+    v = (v + (d[:, iy_sw, ix_sw] * sw_[None]).astype(F)).astype(F)
+    v = (v + (d[:, iy_se, ix_se] * se[None]).astype(F)).astype(F)      # [256, N]
+    nrm = np.sqrt(np.sum((v * v).astype(F), axis=0, dtype=F)).astype(F)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        v = (v / nrm[None]).astype(F)                                  # Eigen normalize(): no epsilon
+    return np.ascontiguousarray(v.T)
+
+
+def keypoints_decoder(heat, desc_chw, threshold, border, top_k, w_scale=F(1), h_scale=F(1)):
+    """PLNet::keypoints_decoder src/plnet.cpp:419-423 + rescale :574-575 (≡ super_point.cpp:274-282).
+    Returns feat [N, 259] float32; row n = [score, x*w_scale, y*h_scale, d0..d255]
+    (byte-identical to column n of the reference's Eigen::Matrix<float,259,Dynamic>)."""
+    s, x, y = detect_point(heat, threshold, border, top_k)
+    d = extract_descriptors(desc_chw, x, y, 8)
+    feat = np.empty((s.size, 259), dtype=F)
+    feat[:, 0] = s
+    feat[:, 1] = (x * F(w_scale)).astype(F)
+    feat[:, 2] = (y * F(h_scale)).astype(F)
+    feat[:, 3:] = d
+    return feat
+
+
+# ------------------------------------------------------------------ PLNet line path
+def wireframe_matcher(iskeep, idx_min, idx_max, jn: int = 300):
+    """PLNet::wireframe_matcher src/plnet.cpp:272-307.  Inputs flattened [3*128*128] float32.
+    Returns (is_keep_index [M1], inverse [M1], unique_pairs [M2,2] as (max,min))."""
+    keep = np.nonzero(iskeep.reshape(-1) > 0)[0]
+    a = idx_min.reshape(-1)[keep].astype(np.int64)     # (int) cast truncates; values are whole
+    b = idx_max.reshape(-1)[keep].astype(np.int64)
+    code = a * jn + b
+    _, first_pos, inv = np.unique(code, return_index=True, return_inverse=True)
+    order = np.argsort(first_pos, kind="stable")       # unique ids in first-seen order
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    inverse = rank[inv]
+    pairs = np.empty((order.size, 2), dtype=np.int64)
+    ucode = code[first_pos[order]]
+    pairs[:, 0] = ucode % jn       # (j, i) = (max, min)  plnet.cpp:301
+    pairs[:, 1] = ucode // jn
+    return keep.astype(np.int64), inverse.astype(np.int64), pairs
+
+
+def line_filter(lines_adjusted, scores_line, border, line_threshold, line_length_threshold,
+                rw: int = 512, rh: int = 512):
+    """process_output src/plnet.cpp:519-558.  Returns (lines [L,4] float64 in 512-space, junction_map bool [rh,rw])."""
+    jmap = np.zeros((rh, rw), dtype=bool)
+    border = max(border, 0)
+    thr2 = F(F(line_length_threshold) * F(line_length_threshold))
+    out = []
+    for i in range(lines_adjusted.shape[0]):
+        if scores_line[i] < 0.5:
+            continue
+        x1 = F(lines_adjusted[i, 0] * F(4)); y1 = F(lines_adjusted[i, 1] * F(4))
+        x2 = F(lines_adjusted[i, 2] * F(4)); y2 = F(lines_adjusted[i, 3] * F(4))
+        xi1 = int(np.float64(x1) + 0.1); yi1 = int(np.float64(y1) + 0.1)
+        xi2 = int(np.float64(x2) + 0.1); yi2 = int(np.float64(y2) + 0.1)
+        p1 = (xi1 > border) and (xi1 < rw - border) and (yi1 > border) and (yi1 < rh - border)
+        p2 = (xi2 > border) and (xi2 < rw - border) and (yi2 > border) and (yi2 < rh - border)
+        jmap[yi1, xi1] = p1
+        jmap[yi2, xi2] = p2
+        if scores_line[i] < F(line_threshold):
+            continue
+        l2 = F(F((x2 - x1) * (x2 - x1)) + F((y2 - y1) * (y2 - y1)))
+        if l2 < thr2:
+            continue
+        out.append((float(x1), float(y1), float(x2), float(y2)))
+    return np.array(out, dtype=np.float64).reshape(-1, 4), jmap
+
+
+def junction_detector(heat, desc_chw, jmap, border, w_scale=F(1), h_scale=F(1)):
+    """PLNet::junction_detector src/plnet.cpp:425-448 (+ rescale :569-570): raster scan, upper bound EXCLUSIVE."""
+    h, w = heat.shape
+    border = max(border, 0)
+    m = np.zeros_like(jmap)
+    m[border:h - border, border:w - border] = jmap[border:h - border, border:w - border]
+    ys, xs = np.nonzero(m)
+    s = heat[ys, xs].astype(F)
+    d = extract_descriptors(desc_chw, xs.astype(F), ys.astype(F), 8)
+    feat = np.empty((s.size, 259), dtype=F)
+    feat[:, 0] = s
+    feat[:, 1] = (xs.astype(F) * F(w_scale)).astype(F)
+    feat[:, 2] = (ys.astype(F) * F(h_scale)).astype(F)
+    feat[:, 3:] = d
+    return feat
+
+
+def rescale_lines(lines512: np.ndarray, w_scale, h_scale) -> np.ndarray:
+    """src/plnet.cpp:577-582: Vector4d *= float scale (double * float → double)."""
+    out = lines512.astype(np.float64).copy()
+    out[:, 0] *= float(F(w_scale)); out[:, 2] *= float(F(w_scale))
+    out[:, 1] *= float(F(h_scale)); out[:, 3] *= float(F(h_scale))
+    return out
+
+
+# ------------------------------------------------------------------ matcher glue
+def normalize_keypoints(feat: np.ndarray, width: int, height: int, scale: float) -> np.ndarray:
+    """PointMatcher::NormalizeKeypoints src/point_matcher.cc:39-48.  feat [N,259]; integer width/2."""
+    out = feat.copy()
+    l_inv = F(1.0 / max(width, height) * float(F(scale)))
+    out[:, 1] = ((feat[:, 1] - F(width // 2)) * l_inv).astype(F)
+    out[:, 2] = ((feat[:, 2] - F(height // 2)) * l_inv).astype(F)
+    return out
+
+
+def filter_matches(scores: np.ndarray, threshold: float = 0.1):
+    """filter_matches src/light_glue.cpp:214-266: strict '>' from -FLT_MAX (first max wins), mutual check,
+    exp(max) > threshold, ascending row order.  Returns (idx [K,2] int32, score [K] float32)."""
+    n0, n1 = scores.shape
+    if n0 == 0 or n1 == 0:
+        return np.zeros((0, 2), np.int32), np.zeros((0,), F)
+    rcol = np.argmax(scores, axis=1)           # np.argmax returns the first maximum
+    rval = scores[np.arange(n0), rcol]
+    crow = np.argmax(scores, axis=0)
+    rows = np.arange(n0)
+    mutual = crow[rcol] == rows
+    e = np.exp(rval.astype(F)).astype(F)
+    ok = mutual & (e > F(threshold))
+    idx = np.stack([rows[ok], rcol[ok]], axis=1).astype(np.int32)
+    return idx, e[ok].astype(F)
+
+
+def superglue_decode(scores: np.ndarray, threshold: float = 0.2):
+    """decode src/super_glue.cpp:339-367 on scores [h,w] (h=N0+1, w=N1+1): uses rows 0..h-2, cols 0..w-2."""
+    h, w = scores.shape
+    inner = scores[:h - 1, :w - 1]
+    if inner.size == 0:
+        return (np.zeros(h - 1, np.int32), np.zeros(w - 1, np.int32),
+                np.zeros(h - 1, np.float64), np.zeros(w - 1, np.float64))
+    idx0 = np.argmax(inner, axis=1); max0 = inner[np.arange(h - 1), idx0]
+    idx1 = np.argmax(inner, axis=0)
+    mutual0 = idx1[idx0] == np.arange(h - 1)
+    mutual1 = idx0[idx1] == np.arange(w - 1)
+    ms0 = np.where(mutual0, np.exp(max0.astype(F)).astype(F), F(0)).astype(F)
+    ms1 = np.where(mutual1, ms0[idx1], F(0)).astype(F)
+    valid0 = mutual0 & (ms0 > F(threshold))
+    valid1 = mutual1 & valid0[idx1]
+    i0 = np.where(valid0, idx0, -1).astype(np.int32)
+    i1 = np.where(valid1, idx1, -1).astype(np.int32)
+    return i0, i1, ms0.astype(np.float64), ms1.astype(np.float64)
+
+
+def superglue_matches(i0, i1, ms0, ms1):
+    """PointMatcher::MatchingPoints superglue branch src/point_matcher.cc:82-91 → list of (q, t, dist)."""
+    out = []
+    for i in range(len(i0)):
+        if 0 <= i0[i] < len(i1) and i1[i0[i]] == i:
+            out.append((i, int(i0[i]), 1.0 - (ms0[i] + ms1[i0[i]]) / 2.0))
+    return out
+
+
+def log_optimal_transport(scores: np.ndarray, alpha: float = 2.3457, iters: int = 100) -> np.ndarray:
+    """Dead-code CPU Sinkhorn src/super_glue.cpp:369-435 (float32, sequential sums replaced by
+    float32 logsumexp-free direct exp sums exactly as the C++ does: no max subtraction)."""
+    m, n = scores.shape
+    c = np.full((m + 1, n + 1), F(alpha), dtype=F)
+    c[:m, :n] = scores
+    norm = F(-np.log(F(m + n)))
+    log_mu = np.full(m + 1, norm, dtype=F); log_mu[m] = F(np.log(F(n)) + norm)
+    log_nu = np.full(n + 1, norm, dtype=F); log_nu[n] = F(np.log(F(m)) + norm)
+    u = np.zeros(m + 1, dtype=F); v = np.zeros(n + 1, dtype=F)
+    for _ in range(iters):
+        u = (log_mu - np.log(np.sum(np.exp(c + v[None, :]), axis=1, dtype=F))).astype(F)
+        v = (log_nu - np.log(np.sum(np.exp(c + u[:, None]), axis=0, dtype=F))).astype(F)
+    return (c + u[:, None] + v[None, :] - norm).astype(F)
