@@ -1,0 +1,81 @@
+"""ctypes binding of libairfe.so (include/airfe.h).  No fallback: if the HIP library is missing or no GPU is
+visible the product path raises — there is no CPU implementation behind this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libairfe.so")
+
+
+class Cfg(C.Structure):
+    _fields_ = [
+        ("device", C.c_int), ("precision", C.c_int), ("max_batch", C.c_int), ("enc_chunk", C.c_int),
+        ("max_keypoints", C.c_int), ("keypoint_threshold", C.c_float), ("remove_borders", C.c_int),
+        ("nms_radius", C.c_int), ("line_threshold", C.c_float), ("line_length_threshold", C.c_float),
+        ("matcher", C.c_int), ("image_width", C.c_int), ("image_height", C.c_int), ("sinkhorn_iters", C.c_int),
+        ("superpoint_pack", C.c_char_p), ("plnet_s1_pack", C.c_char_p), ("lightglue_pack", C.c_char_p),
+        ("superglue_pack", C.c_char_p),
+    ]
+
+
+class Stage0(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "juncs_pred", "lines_pred", "iskeep", "idx_junc_to_end_min", "idx_junc_to_end_max",
+        "loi_features", "loi_features_thin", "loi_features_aux")]
+
+
+# name -> (restype, argtypes); every symbol include/airfe.h declares
+SIGNATURES = {
+    "airfe_default_cfg": (None, [C.POINTER(Cfg)]),
+    "airfe_create": (C.c_int, [C.POINTER(Cfg), C.POINTER(C.c_void_p)]),
+    "airfe_destroy": (None, [C.c_void_p]),
+    "airfe_last_error": (C.c_char_p, [C.c_void_p]),
+    "airfe_detect_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                      C.POINTER(C.c_int)]),
+    "airfe_detect_plnet": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Stage0), C.c_void_p,
+                                     C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p,
+                                     C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "airfe_match_lightglue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.POINTER(C.c_int)]),
+    "airfe_match_superglue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "airfe_detect_points_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "airfe_match_lightglue_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                  C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "airfe_stereo_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "airfe_sync": (C.c_int, [C.c_void_p]),
+    "airfe_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "airfe_profile_stages": (C.c_int, []),
+    "airfe_profile_stage_name": (C.c_char_p, [C.c_int]),
+    "airfe_profile_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "airfe_debug_detector_maps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "airfe_debug_lightglue_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "airfe_debug_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "airfe_debug_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_void_p]),
+    "airfe_debug_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m airslam_amd.build` "
+                "(hipcc, gfx950).  airslam_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)      # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib

@@ -1,0 +1,250 @@
+"""Host-side mirror of the reference's front-end interface on top of the libairfe.so C ABI.
+
+`FeatureDetector.Detect` and `PointMatcher.MatchingPoints` keep the names, argument meaning and error behaviour
+of include/feature_detector.h:8-31 and include/point_matcher.h:8-24 (bool / match-count returns, printed
+messages, early-outs); feature matrices are numpy [259, N] float32 in the reference's Eigen orientation
+(column = keypoint), stored Fortran-contiguous so they are byte-identical to Eigen's column-major buffer.
+
+torch is used only as plumbing for the device-resident batch entry points (`Context.*_dev`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import tempfile
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib, weights as W
+
+FEAT = 259
+
+
+def _pack_arg(x, tmpfiles) -> Optional[bytes]:
+    if x is None:
+        return None
+    if isinstance(x, (str, bytes, os.PathLike)):
+        return os.fsencode(x)
+    f = tempfile.NamedTemporaryFile(suffix=".airfe", delete=False)
+    f.close()
+    W.save_pack(f.name, x)
+    tmpfiles.append(f.name)
+    return f.name.encode()
+
+
+class AirfeError(RuntimeError):
+    pass
+
+
+class Context:
+    """One airfe_ctx: one device, one stream, one calling thread."""
+
+    def __init__(self, superpoint=None, lightglue=None, superglue=None, plnet_s1=None, **cfg):
+        self._l = _lib.lib()
+        c = _lib.Cfg()
+        self._l.airfe_default_cfg(C.byref(c))
+        for k, v in cfg.items():
+            if not hasattr(c, k):
+                raise TypeError(f"unknown airfe_cfg field {k!r}")
+            setattr(c, k, v)
+        tmp = []
+        try:
+            c.superpoint_pack = _pack_arg(superpoint, tmp)
+            c.lightglue_pack = _pack_arg(lightglue, tmp)
+            c.superglue_pack = _pack_arg(superglue, tmp)
+            c.plnet_s1_pack = _pack_arg(plnet_s1, tmp)
+            h = C.c_void_p()
+            rc = self._l.airfe_create(C.byref(c), C.byref(h))
+            if rc != 0:
+                raise AirfeError((self._l.airfe_last_error(None) or b"airfe_create failed").decode())
+        finally:
+            for t in tmp:
+                os.unlink(t)
+        self._h = h
+        self.cfg = c
+        self.max_keypoints = c.max_keypoints
+        self.np_rows = (c.max_keypoints + 63) // 64 * 64
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.airfe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise AirfeError(f"{what}: {(self._l.airfe_last_error(self._h) or b'').decode()}")
+
+    # ---------------------------------------------------------------- host, batch-1 (≙ reference infer())
+    def detect_points(self, gray: np.ndarray) -> np.ndarray:
+        """-> [n, 259] float32 rows (score, x, y, desc).  Raises on an empty image."""
+        gray = np.asarray(gray)
+        if gray.ndim != 2 or gray.dtype != np.uint8:
+            raise TypeError("expected a 2-D uint8 image")
+        if gray.size == 0:
+            raise AirfeError("empty image")
+        if gray.strides[1] != 1:
+            gray = np.ascontiguousarray(gray)
+        cap = self.np_rows
+        feat = np.empty((cap, FEAT), dtype=np.float32)
+        n = C.c_int(0)
+        self._chk(self._l.airfe_detect_points(self._h, gray.ctypes.data, gray.shape[0], gray.shape[1], gray.strides[0],
+                                              feat.ctypes.data, cap, C.byref(n)), "airfe_detect_points")
+        return feat[:n.value].copy()
+
+    def match_lightglue(self, f0: np.ndarray, f1: np.ndarray):
+        """f0/f1: [n, 258] rows (normalised x, y, desc) -> (idx [k,2] int32, score [k] float32)."""
+        f0 = np.ascontiguousarray(f0, dtype=np.float32)
+        f1 = np.ascontiguousarray(f1, dtype=np.float32)
+        cap = self.np_rows
+        idx = np.empty((cap, 2), dtype=np.int32)
+        sc = np.empty((cap,), dtype=np.float32)
+        n = C.c_int(0)
+        self._chk(self._l.airfe_match_lightglue(self._h, f0.ctypes.data, f0.shape[0], f1.ctypes.data, f1.shape[0],
+                                                idx.ctypes.data, sc.ctypes.data, cap, C.byref(n)), "airfe_match_lightglue")
+        return idx[:n.value].copy(), sc[:n.value].copy()
+
+    def lightglue_scores(self, f0: np.ndarray, f1: np.ndarray) -> np.ndarray:
+        f0 = np.ascontiguousarray(f0, dtype=np.float32)
+        f1 = np.ascontiguousarray(f1, dtype=np.float32)
+        out = np.empty((f0.shape[0], f1.shape[0]), dtype=np.float32)
+        self._chk(self._l.airfe_debug_lightglue_scores(self._h, f0.ctypes.data, f0.shape[0], f1.ctypes.data, f1.shape[0],
+                                                       out.ctypes.data), "airfe_debug_lightglue_scores")
+        return out
+
+    def detector_maps(self, b: int = 1):
+        heat = np.empty((b, 512, 512), np.float32)
+        nms = np.empty((b, 512, 512), np.float32)
+        desc = np.empty((b, 64, 64, 256), np.float32)
+        self._chk(self._l.airfe_debug_detector_maps(self._h, b, heat.ctypes.data, nms.ctypes.data, desc.ctypes.data),
+                  "airfe_debug_detector_maps")
+        return heat, nms, desc
+
+    def debug_preprocess(self, gray):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        out = np.empty((512, 512), np.float32)
+        self._chk(self._l.airfe_debug_preprocess(self._h, gray.ctypes.data, gray.shape[0], gray.shape[1], gray.strides[0],
+                                                 out.ctypes.data), "airfe_debug_preprocess")
+        return out
+
+    def debug_conv3x3(self, x, w, b, pool=False):
+        x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32); b = np.ascontiguousarray(b, np.float32)
+        bb, cin, hh, ww = x.shape
+        cout = w.shape[0]
+        ho, wo = (hh // 2, ww // 2) if pool else (hh, ww)
+        y = np.empty((bb, cout, ho, wo), np.float32)
+        self._chk(self._l.airfe_debug_conv3x3(self._h, x.ctypes.data, bb, cin, hh, ww, w.ctypes.data, b.ctypes.data, cout,
+                                              int(pool), y.ctypes.data), "airfe_debug_conv3x3")
+        return y
+
+    def debug_gemm(self, x, w, b, relu=False):
+        x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32); b = np.ascontiguousarray(b, np.float32)
+        m, k = x.shape
+        n = w.shape[0]
+        y = np.empty((m, n), np.float32)
+        self._chk(self._l.airfe_debug_gemm(self._h, x.ctypes.data, m, k, w.ctypes.data, b.ctypes.data, n, int(relu),
+                                           y.ctypes.data), "airfe_debug_gemm")
+        return y
+
+    # ---------------------------------------------------------------- device-resident batch (torch plumbing)
+    def detect_batch_dev(self, gray_t, feat_t, n_t, stream=None):
+        b, h, w = gray_t.shape
+        self._chk(self._l.airfe_detect_points_batch_dev(self._h, gray_t.data_ptr(), b, h, w, gray_t.stride(1),
+                                                        gray_t.stride(0), feat_t.data_ptr(), feat_t.shape[1],
+                                                        n_t.data_ptr(), self._stream(stream)), "airfe_detect_points_batch_dev")
+
+    def match_lightglue_batch_dev(self, f0_t, n0_t, f1_t, n1_t, idx_t, score_t, nm_t, stream=None):
+        self._chk(self._l.airfe_match_lightglue_batch_dev(self._h, f0_t.data_ptr(), n0_t.data_ptr(), f1_t.data_ptr(),
+                                                          n1_t.data_ptr(), f0_t.shape[0], f0_t.shape[1], idx_t.data_ptr(),
+                                                          score_t.data_ptr(), idx_t.shape[1], nm_t.data_ptr(), self._stream(stream)),
+                  "airfe_match_lightglue_batch_dev")
+
+    def stereo_batch_dev(self, left_t, right_t, featL, featR, nL, nR, idx_t, score_t, nm_t, stream=None):
+        b, h, w = left_t.shape
+        self._chk(self._l.airfe_stereo_batch_dev(self._h, left_t.data_ptr(), right_t.data_ptr(), b, h, w, left_t.stride(1),
+                                                 left_t.stride(0), featL.data_ptr(), featR.data_ptr(), featL.shape[1],
+                                                 nL.data_ptr(), nR.data_ptr(), idx_t.data_ptr(), score_t.data_ptr(),
+                                                 idx_t.shape[1], nm_t.data_ptr(), self._stream(stream)), "airfe_stereo_batch_dev")
+
+    def _stream(self, stream):
+        # the ctx runs on its own non-blocking stream: order it after whatever torch queued on ITS streams
+        if stream is None:
+            import torch
+            torch.cuda.synchronize()
+        return stream
+
+    def profile(self, on: bool):
+        self._chk(self._l.airfe_profile_enable(self._h, int(on)), "airfe_profile_enable")
+
+    def profile_read(self):
+        n = self._l.airfe_profile_stages()
+        ms = (C.c_double * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)(); la = (C.c_int * n)()
+        self._chk(self._l.airfe_profile_read(self._h, ms, fl, by, la), "airfe_profile_read")
+        return {self._l.airfe_profile_stage_name(i).decode(): dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=la[i])
+                for i in range(n)}
+
+    def sync(self):
+        self._chk(self._l.airfe_sync(self._h), "airfe_sync")
+
+
+# ------------------------------------------------------------------------------------ reference-shaped façade
+class FeatureDetector:
+    """Mirror of FeatureDetector (include/feature_detector.h:8-31, src/feature_detector.cc)."""
+
+    def __init__(self, ctx: Context):
+        self._ctx = ctx
+
+    def Detect(self, image: np.ndarray):
+        """Detect(cv::Mat&, Eigen::Matrix<float,259,Dynamic>&) -> (ok, features [259, N])."""
+        try:
+            f = self._ctx.detect_points(image)
+        except (AirfeError, TypeError):
+            print("Failed when extracting point features !")     # feature_detector.cc:46-48
+            return False, np.zeros((FEAT, 0), np.float32, order="F")
+        return True, np.asfortranarray(f.T)
+
+    def DetectStereo(self, left: np.ndarray, right: np.ndarray):
+        okl, fl = self.Detect(left)
+        okr, fr = self.Detect(right)
+        ok = okl & okr                                            # feature_detector.cc:74-80
+        if not ok:
+            print("Failed when extracting point features !")
+        return ok, fl, fr
+
+
+class PointMatcher:
+    """Mirror of PointMatcher (include/point_matcher.h:8-24, src/point_matcher.cc).  The F-matrix RANSAC of
+    MatchingPoints (cv::findFundamentalMat, :95-104) stays in the reference's own code and is not part of this path."""
+
+    def __init__(self, ctx: Context, image_width: int, image_height: int, matcher: int = 0):
+        self._ctx = ctx
+        self.image_width, self.image_height, self.matcher = image_width, image_height, matcher
+
+    @staticmethod
+    def NormalizeKeypoints(features: np.ndarray, width: int, height: int, scale: float) -> np.ndarray:
+        """point_matcher.cc:39-48 on a [259, N] matrix."""
+        out = np.array(features, dtype=np.float32, order="F", copy=True)
+        l_inv = np.float32(1.0 / max(width, height) * float(np.float32(scale)))
+        out[1] = (features[1] - np.float32(width // 2)) * l_inv
+        out[2] = (features[2] - np.float32(height // 2)) * l_inv
+        return out
+
+    def MatchingPoints(self, features0: np.ndarray, features1: np.ndarray):
+        """-> (count, matches) with matches = list of (queryIdx, trainIdx, distance) ≙ cv::DMatch."""
+        if features0.shape[1] < 1 or features1.shape[1] < 1:
+            return 0, []                                          # point_matcher.cc:53-55
+        scale = 0.7 if self.matcher else 0.5
+        n0 = self.NormalizeKeypoints(features0, self.image_width, self.image_height, scale)
+        n1 = self.NormalizeKeypoints(features1, self.image_width, self.image_height, scale)
+        if self.matcher == 0:
+            idx, sc = self._ctx.match_lightglue(np.ascontiguousarray(n0[1:].T), np.ascontiguousarray(n1[1:].T))
+            matches = [(int(i), int(j), float(np.float32(1.0) - s)) for (i, j), s in zip(idx, sc)]
+        else:
+            raise AirfeError("SuperGlue matcher is not available in this build")
+        return len(matches), matches

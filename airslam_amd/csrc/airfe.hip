@@ -1,0 +1,901 @@
+// airfe — host side of libairfe.so: context, weight-pack loading and slab packing (≙ TensorRT engine
+// build, src/plnet.cpp:24-196), persistent device arena (replaces the per-call BufferManager of
+// 3rdparty/tensorrtbuffer/include/buffers.h:237-417) and the detect / match pipelines behind the C ABI.
+#include "../../include/airfe.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "common.h"
+
+using namespace airfe;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Tensor {
+  std::vector<int> dims;
+  std::vector<float> data;
+};
+typedef std::map<std::string, Tensor> Pack;
+
+bool load_pack(const char* path, Pack& out, std::string& err) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { err = std::string("cannot open weight pack ") + path; return false; }
+  char magic[8];
+  uint32_t count = 0;
+  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "AIRFEPK1", 8) == 0 && fread(&count, 4, 1, f) == 1;
+  for (uint32_t i = 0; ok && i < count; ++i) {
+    uint32_t nl = 0, nd = 0;
+    ok = fread(&nl, 4, 1, f) == 1 && nl < 4096;
+    if (!ok) break;
+    std::string name(nl, '\0');
+    ok = fread(&name[0], 1, nl, f) == nl && fread(&nd, 4, 1, f) == 1 && nd <= 8;
+    if (!ok) break;
+    Tensor t;
+    size_t n = 1;
+    for (uint32_t d = 0; d < nd; ++d) {
+      uint32_t v = 0;
+      ok = ok && fread(&v, 4, 1, f) == 1;
+      t.dims.push_back((int)v);
+      n *= v;
+    }
+    if (!ok) break;
+    t.data.resize(n);
+    ok = fread(t.data.data(), 4, n, f) == n;
+    out[name] = std::move(t);
+  }
+  fclose(f);
+  if (!ok) err = std::string("malformed weight pack ") + path;
+  return ok;
+}
+
+// ---- 2-byte conversions (round to nearest even) on the host
+uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+uint16_t f2h(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  int32_t e = (int32_t)((x >> 23) & 0xFF) - 127 + 15;
+  uint32_t m = x & 0x7FFFFFu;
+  if (((x >> 23) & 0xFF) == 0xFF) return (uint16_t)(sign | 0x7C00u | (m ? 0x200u : 0));
+  if (e >= 31) return (uint16_t)(sign | 0x7C00u);
+  if (e <= 0) {
+    if (e < -10) return (uint16_t)sign;
+    m |= 0x800000u;
+    const int shift = 14 - e;
+    uint32_t r = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+  }
+  uint32_t r = ((uint32_t)e << 10) | (m >> 13);
+  const uint32_t rem = m & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+  return (uint16_t)(sign | r);
+}
+inline uint16_t cvt2(float f, int prec) { return prec == 1 ? f2h(f) : f2bf(f); }
+float h2f(uint16_t h) {
+  const uint32_t s = (uint32_t)(h & 0x8000u) << 16;
+  int e = (h >> 10) & 31;
+  uint32_t m = h & 0x3FFu;
+  uint32_t u;
+  if (e == 0) {
+    if (!m) u = s;
+    else {
+      e = 1;
+      while (!(m & 0x400u)) { m <<= 1; --e; }
+      m &= 0x3FFu;
+      u = s | ((uint32_t)(e + 112) << 23) | (m << 13);
+    }
+  } else if (e == 31) u = s | 0x7F800000u | (m << 13);
+  else u = s | ((uint32_t)(e + 112) << 23) | (m << 13);
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline float back2(uint16_t v, int prec) {
+  if (prec == 1) return h2f(v);
+  uint32_t u = (uint32_t)v << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// ---- slab packer: [cbt][nslab] slabs of [64 rows][64 k], rows in MFMA order, swz128 chunk swizzle
+std::vector<uint16_t> pack_slabs(int cbt, int nslab, int prec, const std::function<float(int, int, int)>& get) {
+  std::vector<uint16_t> out((size_t)cbt * nslab * 4096, 0);
+  for (int cb = 0; cb < cbt; ++cb)
+    for (int s = 0; s < nslab; ++s) {
+      uint16_t* slab = out.data() + ((size_t)cb * nslab + s) * 4096;
+      for (int rr = 0; rr < 64; ++rr) {
+        const int feat = cb * 64 + slab_row_to_feature(rr);
+        for (int k = 0; k < 64; ++k) {
+          const int byte = rr * 128 + ((((k >> 3) ^ ((rr >> 1) & 7))) << 4) + (k & 7) * 2;
+          slab[byte >> 1] = cvt2(get(feat, s, k), prec);
+        }
+      }
+    }
+  return out;
+}
+
+struct ConvW { uint16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; };
+struct LinW { uint16_t* w = nullptr; float* b = nullptr; int K = 0, N = 0, cbt = 0; };
+struct LgLayer {
+  LinW qk, v, out, ffn0, ffn3, cqk, cv, cout, cffn0, cffn3;
+  float *ln_g = nullptr, *ln_b = nullptr, *cln_g = nullptr, *cln_b = nullptr;
+};
+
+}  // namespace
+
+struct airfe_ctx {
+  airfe_cfg cfg;
+  std::string err;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  int prec = 0;
+  int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
+  bool has_sp = false, has_lg = false;
+
+  // detector weights
+  float *c1a_w = nullptr, *c1a_b = nullptr;
+  ConvW c1b, c2a, c2b, c3a, c3b, c4a, c4b, cPa, cDa;
+  LinW cPb, cDb;
+  // detector arena
+  float* img32 = nullptr;
+  uint16_t *a1a = nullptr, *a1b = nullptr, *a2a = nullptr, *a2b = nullptr, *a3a = nullptr, *a3b = nullptr, *a4a = nullptr,
+           *a4b = nullptr, *aPa = nullptr, *aDa = nullptr;
+  float *logits = nullptr, *heat = nullptr, *heat_nms = nullptr, *nms_tmp = nullptr, *desc = nullptr;
+  int *xtab = nullptr, *ytab = nullptr;
+  float* lut = nullptr;
+  int tab_w = -1, tab_h = -1;
+  // host-API staging
+  uint8_t* st_img = nullptr; size_t st_img_bytes = 0;
+  float *st_feat0 = nullptr, *st_feat1 = nullptr, *st_score = nullptr;
+  int *st_n0 = nullptr, *st_n1 = nullptr, *st_nm = nullptr;
+  int32_t* st_idx = nullptr;
+  float* st_scores_full = nullptr;
+
+  // LightGlue
+  std::vector<LgLayer> lg;
+  LinW lg_final;
+  float *lg_wr = nullptr, *lg_mw = nullptr;
+  float lg_mb = 0.f;
+  float *x32 = nullptr, *rot_cos = nullptr, *rot_sin = nullptr, *zbuf = nullptr, *simbuf = nullptr, *rowlse = nullptr,
+        *collse = nullptr, *rowval = nullptr;
+  uint16_t *xb = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *ob = nullptr, *msg = nullptr, *hb = nullptr,
+           *mdb = nullptr;
+  int *lens = nullptr, *rowarg = nullptr, *colarg = nullptr;
+
+  // per-stage hipEvent timers (airfe_profile_*): events are recorded on the launch stream only
+  struct Mark { int stage; hipEvent_t a, b; double flops, bytes; };
+  bool prof_on = false;
+  std::vector<Mark> marks;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+enum Stage {
+  ST_PREPROCESS = 0, ST_CONV1A, ST_CONV3X3_C64, ST_CONV3X3_C128, ST_HEAD_GEMM, ST_HEAD_ELTWISE, ST_NMS, ST_SELECT,
+  ST_SAMPLE, ST_LG_PREPARE, ST_LG_GEMM, ST_LG_ATTENTION, ST_LG_LNGELU, ST_LG_ASSIGN, ST_COUNT
+};
+static const char* kStageNames[ST_COUNT] = {
+  "preprocess", "conv1a", "conv3x3_cin64", "conv3x3_cin128", "head_gemm", "head_eltwise", "simple_nms", "select_topk",
+  "sample_desc", "lg_prepare", "lg_gemm", "lg_attention", "lg_ln_gelu", "lg_assign"};
+
+struct ProfScope {
+  airfe_ctx* c; hipStream_t st; bool on; airfe_ctx::Mark m;
+  ProfScope(airfe_ctx* c_, int stage, hipStream_t st_, double flops, double bytes) : c(c_), st(st_), on(c_->prof_on) {
+    if (!on) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+      else (void)hipEventCreate(&e);
+      return e;
+    };
+    m.stage = stage; m.flops = flops; m.bytes = bytes; m.a = get(); m.b = get();
+    (void)hipEventRecord(m.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(m.b, st);
+    c->marks.push_back(m);
+  }
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                         \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                             \
+      g_err = (ctx)->err;                                                                         \
+      return 1;                                                                                   \
+    }                                                                                             \
+  } while (0)
+
+int fail(airfe_ctx* c, const std::string& m) {
+  if (c) c->err = m;
+  g_err = m;
+  return 1;
+}
+
+template <class T>
+T* dalloc(airfe_ctx* c, size_t n, bool zero = true) {
+  void* p = nullptr;
+  if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+  if (zero) (void)hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T));
+  c->allocs.push_back(p);
+  return reinterpret_cast<T*>(p);
+}
+template <class T>
+T* dupload(airfe_ctx* c, const std::vector<T>& v) {
+  T* p = dalloc<T>(c, v.size(), false);
+  if (p && !v.empty()) (void)hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  return p;
+}
+
+const Tensor* need(const Pack& p, const std::string& name, std::string& err) {
+  auto it = p.find(name);
+  if (it == p.end()) { err = "weight pack is missing tensor " + name; return nullptr; }
+  return &it->second;
+}
+
+bool make_conv(airfe_ctx* c, const Pack& p, const std::string& name, int cin, int cout, ConvW& out, std::string& err) {
+  const Tensor* w = need(p, name + ".weight", err);
+  const Tensor* b = need(p, name + ".bias", err);
+  if (!w || !b) return false;
+  if ((int)w->data.size() != cout * cin * 9 || (int)b->data.size() != cout) { err = name + ": unexpected shape"; return false; }
+  const int nci = cin / 64;
+  const float* wd = w->data.data();
+  auto slabs = pack_slabs(cout / 64, 9 * nci, c->prec, [&](int feat, int s, int k) {
+    const int tap = s / nci, cc = s % nci, ci = cc * 64 + k;
+    return wd[((size_t)feat * cin + ci) * 9 + tap];
+  });
+  out.w = dupload(c, slabs);
+  out.b = dupload(c, b->data);
+  out.cin = cin;
+  out.cout = cout;
+  return out.w && out.b;
+}
+
+// Linear y = W x + b with W [N][K] row-major; `src_row(feature)` lets callers permute / select output rows
+bool make_linear(airfe_ctx* c, const float* W, const float* bias, int K, int N, LinW& out, float scale = 1.f,
+                 const std::function<int(int)>* src_row = nullptr) {
+  const int Kp = (K + 63) / 64 * 64, cbt = (N + 63) / 64;
+  auto slabs = pack_slabs(cbt, Kp / 64, c->prec, [&](int feat, int s, int k) {
+    const int kk = s * 64 + k;
+    if (feat >= N || kk >= K) return 0.f;
+    const int r = src_row ? (*src_row)(feat) : feat;
+    return W[(size_t)r * K + kk] * scale;
+  });
+  std::vector<float> bp((size_t)cbt * 64, 0.f);
+  for (int f = 0; f < N; ++f) bp[f] = bias[src_row ? (*src_row)(f) : f] * scale;
+  out.w = dupload(c, slabs);
+  out.b = dupload(c, bp);
+  out.K = Kp;
+  out.N = N;
+  out.cbt = cbt;
+  return out.w && out.b;
+}
+
+bool make_linear_named(airfe_ctx* c, const Pack& p, const std::string& name, int K, int N, LinW& out, std::string& err,
+                       float scale = 1.f) {
+  const Tensor* w = need(p, name + ".weight", err);
+  const Tensor* b = need(p, name + ".bias", err);
+  if (!w || !b) return false;
+  if ((int)w->data.size() != N * K || (int)b->data.size() != N) { err = name + ": unexpected shape"; return false; }
+  return make_linear(c, w->data.data(), b->data.data(), K, N, out, scale);
+}
+
+// OpenCV resize() INTER_LINEAR coefficient table (imgproc/src/resize.cpp) -> [d][4] = s0, s1, a0, a1
+std::vector<int> resize_table(int dsize, int ssize) {
+  std::vector<int> t((size_t)dsize * 4);
+  const double scale = (double)ssize / dsize;
+  for (int d = 0; d < dsize; ++d) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    t[d * 4 + 0] = s;
+    t[d * 4 + 1] = std::min(s + 1, ssize - 1);
+    t[d * 4 + 2] = (int)lrintf((1.f - f) * 2048.f);
+    t[d * 4 + 3] = (int)lrintf(f * 2048.f);
+  }
+  return t;
+}
+
+int load_superpoint(airfe_ctx* c, const char* path) {
+  Pack p;
+  std::string err;
+  if (!load_pack(path, p, err)) return fail(c, err);
+  const Tensor* w1 = need(p, "conv1a.weight", err);
+  const Tensor* b1 = need(p, "conv1a.bias", err);
+  if (!w1 || !b1 || w1->data.size() != 64 * 9) return fail(c, err.empty() ? "conv1a: unexpected shape" : err);
+  c->c1a_w = dupload(c, w1->data);
+  c->c1a_b = dupload(c, b1->data);
+  bool ok = make_conv(c, p, "conv1b", 64, 64, c->c1b, err) && make_conv(c, p, "conv2a", 64, 64, c->c2a, err) &&
+            make_conv(c, p, "conv2b", 64, 64, c->c2b, err) && make_conv(c, p, "conv3a", 64, 128, c->c3a, err) &&
+            make_conv(c, p, "conv3b", 128, 128, c->c3b, err) && make_conv(c, p, "conv4a", 128, 128, c->c4a, err) &&
+            make_conv(c, p, "conv4b", 128, 128, c->c4b, err) && make_conv(c, p, "convPa", 128, 256, c->cPa, err) &&
+            make_conv(c, p, "convDa", 128, 256, c->cDa, err) &&
+            make_linear_named(c, p, "convPb", 256, 65, c->cPb, err) && make_linear_named(c, p, "convDb", 256, 256, c->cDb, err);
+  if (!ok) return fail(c, err.empty() ? "device allocation failed while packing SuperPoint weights" : err);
+
+  const int B = c->Bmax, ch = c->chunk, R = AIRFE_INTERNAL_SIZE;
+  c->img32 = dalloc<float>(c, (size_t)ch * (R + 2) * (R + 2));
+  c->a1a = dalloc<uint16_t>(c, (size_t)ch * (R + 2) * (R + 2) * 64);
+  c->a1b = dalloc<uint16_t>(c, (size_t)ch * (R / 2 + 2) * (R / 2 + 2) * 64);
+  c->a2a = dalloc<uint16_t>(c, (size_t)ch * (R / 2 + 2) * (R / 2 + 2) * 64);
+  c->a2b = dalloc<uint16_t>(c, (size_t)B * (R / 4 + 2) * (R / 4 + 2) * 64);
+  c->a3a = dalloc<uint16_t>(c, (size_t)B * (R / 4 + 2) * (R / 4 + 2) * 128);
+  c->a3b = dalloc<uint16_t>(c, (size_t)B * (R / 8 + 2) * (R / 8 + 2) * 128);
+  c->a4a = dalloc<uint16_t>(c, (size_t)B * (R / 8 + 2) * (R / 8 + 2) * 128);
+  c->a4b = dalloc<uint16_t>(c, (size_t)B * (R / 8 + 2) * (R / 8 + 2) * 128);
+  const size_t cells = (size_t)B * (R / 8) * (R / 8);
+  c->aPa = dalloc<uint16_t>(c, cells * 256);
+  c->aDa = dalloc<uint16_t>(c, cells * 256);
+  c->logits = dalloc<float>(c, cells * 72);
+  c->desc = dalloc<float>(c, cells * 256);
+  c->heat = dalloc<float>(c, (size_t)B * R * R);
+  c->heat_nms = dalloc<float>(c, (size_t)B * R * R);
+  c->nms_tmp = dalloc<float>(c, (size_t)4 * B * R * R);
+  c->xtab = dalloc<int>(c, (size_t)R * 4);
+  c->ytab = dalloc<int>(c, (size_t)R * 4);
+  std::vector<float> lut(256);
+  for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);
+  c->lut = dupload(c, lut);
+  if (!c->img32 || !c->a1a || !c->a1b || !c->a2a || !c->a2b || !c->a3a || !c->a3b || !c->a4a || !c->a4b || !c->aPa ||
+      !c->aDa || !c->logits || !c->desc || !c->heat || !c->heat_nms || !c->nms_tmp || !c->xtab || !c->ytab || !c->lut)
+    return fail(c, "device allocation failed (detector arena)");
+  c->has_sp = true;
+  return 0;
+}
+
+int load_lightglue(airfe_ctx* c, const char* path) {
+  Pack p;
+  std::string err;
+  if (!load_pack(path, p, err)) return fail(c, err);
+  int L = 0;
+  while (p.count("transformers." + std::to_string(L) + ".self_attn.Wqkv.weight")) ++L;
+  if (L == 0) return fail(c, "LightGlue pack has no transformer layers");
+  const Tensor* wr = need(p, "posenc.Wr.weight", err);
+  if (!wr || wr->data.size() != 64) return fail(c, "posenc.Wr.weight missing or wrong shape");
+  c->lg_wr = dupload(c, wr->data);
+  c->lg.resize(L);
+  bool ok = true;
+  for (int i = 0; i < L && ok; ++i) {
+    LgLayer& l = c->lg[i];
+    const std::string s = "transformers." + std::to_string(i) + ".self_attn";
+    const std::string x = "transformers." + std::to_string(i) + ".cross_attn";
+    const Tensor* wqkv = need(p, s + ".Wqkv.weight", err);
+    const Tensor* bqkv = need(p, s + ".Wqkv.bias", err);
+    if (!wqkv || !bqkv || wqkv->data.size() != 768 * 256) { ok = false; break; }
+    // Wqkv output index = h*192 + d*3 + {q,k,v}  (qkv.unflatten(-1,(H,-1,3)))  ->  [q(h,d) | k(h,d)] and v(h,d)
+    std::function<int(int)> qk_row = [](int f) { const int sel = f >> 8, hd = f & 255; return (hd >> 6) * 192 + (hd & 63) * 3 + sel; };
+    std::function<int(int)> v_row = [](int f) { return (f >> 6) * 192 + (f & 63) * 3 + 2; };
+    ok = ok && make_linear(c, wqkv->data.data(), bqkv->data.data(), 256, 512, l.qk, 1.f, &qk_row);
+    ok = ok && make_linear(c, wqkv->data.data(), bqkv->data.data(), 256, 256, l.v, 1.f, &v_row);
+    ok = ok && make_linear_named(c, p, s + ".out_proj", 256, 256, l.out, err);
+    ok = ok && make_linear_named(c, p, s + ".ffn.0", 512, 512, l.ffn0, err);
+    ok = ok && make_linear_named(c, p, s + ".ffn.3", 512, 256, l.ffn3, err);
+    ok = ok && make_linear_named(c, p, x + ".to_qk", 256, 256, l.cqk, err);
+    ok = ok && make_linear_named(c, p, x + ".to_v", 256, 256, l.cv, err);
+    ok = ok && make_linear_named(c, p, x + ".to_out", 256, 256, l.cout, err);
+    ok = ok && make_linear_named(c, p, x + ".ffn.0", 512, 512, l.cffn0, err);
+    ok = ok && make_linear_named(c, p, x + ".ffn.3", 512, 256, l.cffn3, err);
+    const Tensor *g1 = need(p, s + ".ffn.1.weight", err), *b1 = need(p, s + ".ffn.1.bias", err);
+    const Tensor *g2 = need(p, x + ".ffn.1.weight", err), *b2 = need(p, x + ".ffn.1.bias", err);
+    if (!g1 || !b1 || !g2 || !b2) { ok = false; break; }
+    l.ln_g = dupload(c, g1->data); l.ln_b = dupload(c, b1->data);
+    l.cln_g = dupload(c, g2->data); l.cln_b = dupload(c, b2->data);
+  }
+  const std::string a = "log_assignment." + std::to_string(L - 1);
+  ok = ok && make_linear_named(c, p, a + ".final_proj", 256, 256, c->lg_final, err, 0.25f /* d^-1/4, d = 256 */);
+  const Tensor *mw = need(p, a + ".matchability.weight", err), *mb = need(p, a + ".matchability.bias", err);
+  if (!ok || !mw || !mb) return fail(c, err.empty() ? "LightGlue weight packing failed" : err);
+  c->lg_mw = dupload(c, mw->data);
+  c->lg_mb = mb->data[0];
+
+  const int S = 2 * c->Pmax, Np = c->Np;
+  const size_t M = (size_t)S * Np;
+  c->x32 = dalloc<float>(c, M * 256);
+  c->xb = dalloc<uint16_t>(c, M * 256);
+  c->qb = dalloc<uint16_t>(c, M * 256);
+  c->kb = dalloc<uint16_t>(c, M * 256);
+  c->vtb = dalloc<uint16_t>(c, M * 256);
+  c->ob = dalloc<uint16_t>(c, M * 256);
+  c->msg = dalloc<uint16_t>(c, M * 256);
+  c->hb = dalloc<uint16_t>(c, M * 512);
+  c->mdb = dalloc<uint16_t>(c, M * 256);
+  c->rot_cos = dalloc<float>(c, M * 32);
+  c->rot_sin = dalloc<float>(c, M * 32);
+  c->zbuf = dalloc<float>(c, M);
+  c->lens = dalloc<int>(c, S);
+  c->simbuf = dalloc<float>(c, (size_t)c->Pmax * Np * Np);
+  c->st_scores_full = dalloc<float>(c, (size_t)Np * Np);
+  c->rowlse = dalloc<float>(c, (size_t)c->Pmax * Np);
+  c->collse = dalloc<float>(c, (size_t)c->Pmax * Np);
+  c->rowval = dalloc<float>(c, (size_t)c->Pmax * Np);
+  c->rowarg = dalloc<int>(c, (size_t)c->Pmax * Np);
+  c->colarg = dalloc<int>(c, (size_t)c->Pmax * Np);
+  if (!c->x32 || !c->xb || !c->qb || !c->kb || !c->vtb || !c->ob || !c->msg || !c->hb || !c->mdb || !c->rot_cos ||
+      !c->rot_sin || !c->zbuf || !c->lens || !c->simbuf || !c->rowlse || !c->collse || !c->rowval || !c->rowarg ||
+      !c->colarg || !c->st_scores_full)
+    return fail(c, "device allocation failed (matcher arena)");
+  c->has_lg = true;
+  return 0;
+}
+
+int ensure_tables(airfe_ctx* c, int h, int w) {
+  if (c->tab_w == w && c->tab_h == h) return 0;
+  const auto xt = resize_table(AIRFE_INTERNAL_SIZE, w), yt = resize_table(AIRFE_INTERNAL_SIZE, h);
+  HIPCHK(c, hipMemcpyAsync(c->xtab, xt.data(), xt.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->ytab, yt.data(), yt.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // host vectors go out of scope
+  c->tab_w = w;
+  c->tab_h = h;
+  return 0;
+}
+
+void run_conv(airfe_ctx* c, const ConvW& w, const uint16_t* x, uint16_t* y, int B, int H, int W, int pool, int out_pad,
+              hipStream_t st) {
+  ConvArgs a;
+  a.X = x; a.Wp = w.w; a.bias = w.b; a.Y = y;
+  a.B = B; a.H = H; a.W = W; a.CIN = w.cin; a.COUT = w.cout;
+  a.pool = pool; a.out_pad = out_pad; a.relu = 1;
+  const double px = (double)B * H * W;
+  const double ob = px / (pool ? 4 : 1) * w.cout * 2;
+  ProfScope ps(c, w.cin == 64 ? ST_CONV3X3_C64 : ST_CONV3X3_C128, st, 2.0 * px * w.cin * w.cout * 9,
+               px * w.cin * 2 + ob + 9.0 * w.cin * w.cout * 2);
+  launch_conv3x3(c->prec, a, st);
+}
+
+int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat,
+               int cap, int* d_n, hipStream_t st) {
+  if (!c->has_sp) return fail(c, "detector weights were not loaded (cfg.superpoint_pack)");
+  if (B < 1 || B > c->Bmax) return fail(c, "batch exceeds cfg.max_batch");
+  if (h < 1 || w < 1) return fail(c, "empty image");
+  if (cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
+  if (ensure_tables(c, h, w)) return 1;
+  const int R = AIRFE_INTERNAL_SIZE;
+  for (int c0 = 0; c0 < B; c0 += c->chunk) {
+    const int cb = std::min(c->chunk, B - c0);
+    {
+      ProfScope ps(c, ST_PREPROCESS, st, 0, (double)cb * ((double)h * w + (double)R * R * 4));
+      launch_preprocess(d_gray + (size_t)c0 * img_stride, cb, h, w, stride, img_stride, c->xtab, c->ytab, c->lut, c->img32, R, R, st);
+    }
+    {
+      ProfScope ps(c, ST_CONV1A, st, 2.0 * cb * R * R * 9 * 64, (double)cb * R * R * (4 + 128));
+      launch_conv1a(c->prec, c->img32, c->c1a_w, c->c1a_b, c->a1a, cb, R, R, st);
+    }
+    run_conv(c, c->c1b, c->a1a, c->a1b, cb, R, R, 1, 1, st);
+    run_conv(c, c->c2a, c->a1b, c->a2a, cb, R / 2, R / 2, 0, 1, st);
+    run_conv(c, c->c2b, c->a2a, c->a2b + (size_t)c0 * (R / 4 + 2) * (R / 4 + 2) * 64, cb, R / 2, R / 2, 1, 1, st);
+  }
+  run_conv(c, c->c3a, c->a2b, c->a3a, B, R / 4, R / 4, 0, 1, st);
+  run_conv(c, c->c3b, c->a3a, c->a3b, B, R / 4, R / 4, 1, 1, st);
+  run_conv(c, c->c4a, c->a3b, c->a4a, B, R / 8, R / 8, 0, 1, st);
+  run_conv(c, c->c4b, c->a4a, c->a4b, B, R / 8, R / 8, 0, 1, st);
+  run_conv(c, c->cPa, c->a4b, c->aPa, B, R / 8, R / 8, 0, 0, st);
+  run_conv(c, c->cDa, c->a4b, c->aDa, B, R / 8, R / 8, 0, 0, st);
+  const int cells = B * (R / 8) * (R / 8);
+  {
+    GemmArgs g;
+    g.X1 = c->aPa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cPb.w; g.bias = c->cPb.b;
+    g.M = cells; g.N = 65; g.cb_total = c->cPb.cbt; g.epi = EPI_STORE_F32; g.out = c->logits; g.ldo = 72;
+    { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 288)); launch_gemm(c->prec, 256, false, g, st); }
+    { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * (260 + 256)); launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st); }
+  }
+  {
+    GemmArgs g;
+    g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b;
+    g.M = cells; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
+    { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024)); launch_gemm(c->prec, 256, false, g, st); }
+    { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * 2048); launch_l2norm256(c->desc, cells, st); }
+  }
+  const float* hsel = c->heat;
+  if (c->cfg.nms_radius > 0) {
+    ProfScope ps(c, ST_NMS, st, 0, (double)B * R * R * 8);
+    launch_simple_nms(c->heat, c->heat_nms, c->nms_tmp, B, R, R, c->cfg.nms_radius, st);
+    hsel = c->heat_nms;
+  }
+  {
+    ProfScope ps(c, ST_SELECT, st, 0, (double)B * R * R * 4);
+    launch_select_topk(hsel, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cfg.max_keypoints, cap, d_feat,
+                       d_n, st);
+  }
+  {
+    ProfScope ps(c, ST_SAMPLE, st, 0, (double)B * c->cfg.max_keypoints * (4096 + 1036));
+    launch_sample_desc(c->desc, B, R / 8, R / 8, d_feat, d_n, cap, (float)w / (float)R, (float)h / (float)R, st);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1, const uint16_t* x2, int ld2, int M,
+                int epi, int act, void* out, int ldo, hipStream_t st, bool trans = false, void* out2 = nullptr,
+                float* x32 = nullptr, const float* rc = nullptr, const float* rs = nullptr) {
+  GemmArgs g;
+  g.X1 = x1; g.ld1 = ld1; g.K1 = K1; g.X2 = x2; g.ld2 = ld2;
+  g.Wp = w.w; g.bias = w.b; g.M = M; g.N = w.N; g.cb_total = w.cbt;
+  g.epi = epi; g.act = act; g.out = out; g.out2 = out2; g.ldo = ldo; g.x32 = x32;
+  g.rot_cos = rc; g.rot_sin = rs; g.Np = c->Np; g.H = 4;
+  ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * w.K * w.N, (double)M * (w.K + w.N) * 2 + (double)w.K * w.N * 2);
+  launch_gemm(c->prec, w.K, trans, g, st);
+}
+
+void lg_ffn(airfe_ctx* c, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st) {
+  run_linear(c, f0, c->xb, 256, 256, c->msg, 256, M, EPI_STORE, ACT_NONE, c->hb, 512, st);
+  { ProfScope ps(c, ST_LG_LNGELU, st, 0, (double)M * 2048); launch_ln_gelu(c->prec, c->hb, g, b, M, st); }
+  run_linear(c, f3, c->hb, 512, 512, nullptr, 0, M, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
+}
+
+// LightGlue forward on B pairs whose feature rows live on the device
+int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1, const int* n1, int B, int cap, int ld,
+                  int kp_off, int normalize, int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, float* scores_out,
+                  hipStream_t st) {
+  if (!c->has_lg) return fail(c, "LightGlue weights were not loaded (cfg.lightglue_pack)");
+  if (B < 1 || B > c->Pmax) return fail(c, "pair batch exceeds cfg.max_batch / 2");
+  if (cap > c->Np) return fail(c, "feature capacity exceeds the matcher arena (max_keypoints)");
+  const int S = 2 * B, Np = c->Np, M = S * Np;
+  LgPrepArgs pa;
+  pa.f0 = f0; pa.f1 = f1; pa.n0 = n0; pa.n1 = n1; pa.ld = ld; pa.kp_off = kp_off; pa.normalize = normalize;
+  // PointMatcher::NormalizeKeypoints (src/point_matcher.cc:39-48): integer width/2, L_inv = 1.0/max(w,h)*scale
+  pa.cx = (float)(c->cfg.image_width / 2);
+  pa.cy = (float)(c->cfg.image_height / 2);
+  pa.linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.5f);
+  pa.wr = c->lg_wr; pa.B = B; pa.cap = cap; pa.Np = Np;
+  pa.x32 = c->x32; pa.xb = c->xb; pa.rot_cos = c->rot_cos; pa.rot_sin = c->rot_sin; pa.lens = c->lens;
+  { ProfScope ps(c, ST_LG_PREPARE, st, 0, (double)M * (1036 + 1536 + 256)); launch_lg_prepare(c->prec, pa, st); }
+  for (const LgLayer& l : c->lg) {
+    // ---- self block
+    run_linear(c, l.qk, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS, ACT_NONE, c->qb, 0, st, false, c->kb, nullptr, c->rot_cos, c->rot_sin);
+    run_linear(c, l.v, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
+    { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
+    run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, M, EPI_STORE, ACT_NONE, c->msg, 256, st);
+    lg_ffn(c, l.ffn0, l.ln_g, l.ln_b, l.ffn3, M, st);
+    // ---- cross block (one shared projection for q and k; the two sides swap roles)
+    run_linear(c, l.cqk, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS, ACT_NONE, c->qb, 0, st);
+    run_linear(c, l.cv, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
+    { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
+    run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, M, EPI_STORE, ACT_NONE, c->msg, 256, st);
+    lg_ffn(c, l.cffn0, l.cln_g, l.cln_b, l.cffn3, M, st);
+  }
+  run_linear(c, c->lg_final, c->xb, 256, 256, nullptr, 0, M, EPI_STORE, ACT_NONE, c->mdb, 256, st);
+  ProfScope ps(c, ST_LG_ASSIGN, st, 2.0 * B * Np * (double)Np * 256, (double)B * Np * Np * 4 * 6);
+  launch_rowdot256(c->x32, c->lg_mw, c->lg_mb, c->zbuf, M, st);
+  launch_sim(c->prec, c->mdb, c->simbuf, B, Np, st);
+  launch_lg_assign(c->simbuf, c->zbuf, c->lens, B, Np, mcap, 0.1f, c->rowlse, c->collse, scores_out, c->rowarg, c->rowval,
+                   c->colarg, d_idx, d_score, d_nmatch, st);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int ensure_stage_img(airfe_ctx* c, size_t bytes) {
+  if (bytes <= c->st_img_bytes) return 0;
+  void* p = nullptr;
+  HIPCHK(c, hipMalloc(&p, bytes));
+  c->allocs.push_back(p);
+  c->st_img = reinterpret_cast<uint8_t*>(p);
+  c->st_img_bytes = bytes;
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================================== C ABI
+extern "C" {
+
+void airfe_default_cfg(airfe_cfg* cfg) {
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->device = 0;
+  cfg->precision = 0;
+  cfg->max_batch = 2;
+  cfg->enc_chunk = 4;
+  cfg->max_keypoints = 400;        // configs/visual_odometry/vo_euroc.yaml:3-5
+  cfg->keypoint_threshold = 0.004f;
+  cfg->remove_borders = 4;
+  cfg->nms_radius = 4;
+  cfg->line_threshold = 0.75f;
+  cfg->line_length_threshold = 50.f;
+  cfg->matcher = 0;
+  cfg->image_width = 752;
+  cfg->image_height = 480;
+  cfg->sinkhorn_iters = 100;
+}
+
+const char* airfe_last_error(const airfe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, "airfe_create: null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(nullptr, "airfe_create: no HIP device visible (the product path has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, "airfe_create: bad device ordinal");
+  if (cfg->max_keypoints < 1 || cfg->max_keypoints > 1024) return fail(nullptr, "airfe_create: max_keypoints must be 1..1024");
+  if (cfg->precision != 0 && cfg->precision != 1) return fail(nullptr, "airfe_create: precision must be 0 (bf16) or 1 (fp16)");
+  if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, "airfe_create: hipSetDevice failed");
+  airfe_ctx* c = new airfe_ctx();
+  c->cfg = *cfg;
+  c->prec = cfg->precision;
+  c->Bmax = std::max(cfg->max_batch, 1);
+  c->chunk = std::min(std::max(cfg->enc_chunk, 1), c->Bmax);
+  c->Pmax = c->Bmax;
+  c->Np = (cfg->max_keypoints + 63) / 64 * 64;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return fail(nullptr, "airfe_create: stream creation failed");
+  }
+  int rc = 0;
+  if (cfg->superpoint_pack) rc = load_superpoint(c, cfg->superpoint_pack);
+  if (!rc && cfg->lightglue_pack) rc = load_lightglue(c, cfg->lightglue_pack);
+  if (!rc) {
+    const size_t capf = (size_t)c->Np * AIRFE_FEAT_DIM;
+    c->st_feat0 = dalloc<float>(c, capf);
+    c->st_feat1 = dalloc<float>(c, capf);
+    c->st_score = dalloc<float>(c, c->Np);
+    c->st_idx = dalloc<int32_t>(c, (size_t)c->Np * 2);
+    c->st_n0 = dalloc<int>(c, 1);
+    c->st_n1 = dalloc<int>(c, 1);
+    c->st_nm = dalloc<int>(c, 1);
+    if (!c->st_feat0 || !c->st_feat1 || !c->st_score || !c->st_idx || !c->st_n0 || !c->st_n1 || !c->st_nm)
+      rc = fail(c, "device allocation failed (staging)");
+  }
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(c, "device error during weight upload");
+  if (rc) {
+    g_err = c->err;
+    airfe_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return 0;
+}
+
+void airfe_destroy(airfe_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (void* p : c->allocs) (void)hipFree(p);
+  for (auto& m : c->marks) { (void)hipEventDestroy(m.a); (void)hipEventDestroy(m.b); }
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int airfe_profile_enable(airfe_ctx* c, int on) {
+  if (!c) return 1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto& m : c->marks) { c->ev_pool.push_back(m.a); c->ev_pool.push_back(m.b); }
+  c->marks.clear();
+  c->prof_on = on != 0;
+  return 0;
+}
+
+int airfe_profile_stages(void) { return ST_COUNT; }
+const char* airfe_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+
+int airfe_profile_read(airfe_ctx* c, double* ms, double* flops, double* bytes, int* launches) {
+  if (!c) return 1;
+  HIPCHK(c, hipDeviceSynchronize());
+  for (int i = 0; i < ST_COUNT; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
+  for (auto& m : c->marks) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, m.a, m.b) == hipSuccess) {
+      ms[m.stage] += t; flops[m.stage] += m.flops; bytes[m.stage] += m.bytes; launches[m.stage] += 1;
+    }
+    c->ev_pool.push_back(m.a); c->ev_pool.push_back(m.b);
+  }
+  c->marks.clear();
+  return 0;
+}
+
+int airfe_sync(airfe_ctx* c) {
+  if (!c) return 1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int airfe_detect_points_batch_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride,
+                                  float* d_feat, int cap, int* d_n, void* stream) {
+  if (!c) return 1;
+  return detect_dev(c, d_gray, B, h, w, stride, img_stride, d_feat, cap, d_n, stream ? (hipStream_t)stream : c->stream);
+}
+
+int airfe_detect_points(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, float* feat, int cap, int* n) {
+  if (!c) return 1;
+  if (!gray || h < 1 || w < 1) return fail(c, "empty image");     // plnet.cpp:247
+  if (cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
+  const size_t bytes = (size_t)h * stride;
+  if (ensure_stage_img(c, bytes)) return 1;
+  HIPCHK(c, hipMemcpyAsync(c->st_img, gray, bytes, hipMemcpyHostToDevice, c->stream));
+  if (detect_dev(c, c->st_img, 1, h, w, stride, bytes, c->st_feat0, c->Np, c->st_n0, c->stream)) return 1;
+  int nn = 0;
+  HIPCHK(c, hipMemcpyAsync(&nn, c->st_n0, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (nn > 0) HIPCHK(c, hipMemcpy(feat, c->st_feat0, (size_t)nn * AIRFE_FEAT_DIM * 4, hipMemcpyDeviceToHost));
+  *n = nn;
+  return 0;
+}
+
+int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_nms, float* desc) {
+  if (!c || !c->has_sp || B > c->Bmax) return 1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t R = AIRFE_INTERNAL_SIZE;
+  if (heat_raw) HIPCHK(c, hipMemcpy(heat_raw, c->heat, (size_t)B * R * R * 4, hipMemcpyDeviceToHost));
+  if (heat_nms) HIPCHK(c, hipMemcpy(heat_nms, c->cfg.nms_radius > 0 ? c->heat_nms : c->heat, (size_t)B * R * R * 4, hipMemcpyDeviceToHost));
+  if (desc) HIPCHK(c, hipMemcpy(desc, c->desc, (size_t)B * 64 * 64 * 256 * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+static int lg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx, float* score, int cap,
+                   int* nmatch, float* scores_full) {
+  if (!c) return 1;
+  if (n0 < 1 || n1 < 1) { if (nmatch) *nmatch = 0; return 0; }   // point_matcher.cc:53-55
+  if (n0 > c->cfg.max_keypoints || n1 > c->cfg.max_keypoints) return fail(c, "keypoint count exceeds max_keypoints");
+  HIPCHK(c, hipMemcpyAsync(c->st_feat0, f0, (size_t)n0 * 258 * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_feat1, f1, (size_t)n1 * 258 * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_n0, &n0, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_n1, &n1, 4, hipMemcpyHostToDevice, c->stream));
+  if (lightglue_dev(c, c->st_feat0, c->st_n0, c->st_feat1, c->st_n1, 1, c->Np, 258, 0, 0, c->st_idx, c->st_score, c->Np,
+                    c->st_nm, scores_full ? c->st_scores_full : nullptr, c->stream))
+    return 1;
+  int nm = 0;
+  HIPCHK(c, hipMemcpyAsync(&nm, c->st_nm, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (idx && score) {
+    nm = std::min(nm, cap);
+    if (nm > 0) {
+      HIPCHK(c, hipMemcpy(idx, c->st_idx, (size_t)nm * 8, hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(score, c->st_score, (size_t)nm * 4, hipMemcpyDeviceToHost));
+    }
+  }
+  if (nmatch) *nmatch = nm;
+  if (scores_full)
+    for (int i = 0; i < n0; ++i)
+      HIPCHK(c, hipMemcpy(scores_full + (size_t)i * n1, c->st_scores_full + (size_t)i * c->Np, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int airfe_match_lightglue(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx, float* score,
+                          int cap, int* nmatch) {
+  return lg_host(c, f0, n0, f1, n1, idx, score, cap, nmatch, nullptr);
+}
+
+int airfe_debug_lightglue_scores(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, float* scores) {
+  return lg_host(c, f0, n0, f1, n1, nullptr, nullptr, 0, nullptr, scores);
+}
+
+int airfe_match_lightglue_batch_dev(airfe_ctx* c, const float* d_f0, const int* d_n0, const float* d_f1, const int* d_n1,
+                                    int B, int cap, int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, void* stream) {
+  if (!c) return 1;
+  return lightglue_dev(c, d_f0, d_n0, d_f1, d_n1, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr,
+                       stream ? (hipStream_t)stream : c->stream);
+}
+
+int airfe_stereo_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
+                           size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, int32_t* d_idx,
+                           float* d_score, int mcap, int* d_nmatch, void* stream) {
+  if (!c) return 1;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  if (detect_dev(c, d_left, B, h, w, stride, img_stride, d_featL, cap, d_nL, st)) return 1;
+  if (detect_dev(c, d_right, B, h, w, stride, img_stride, d_featR, cap, d_nR, st)) return 1;
+  return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
+}
+
+// ---- not built yet in this revision: report loudly instead of pretending
+int airfe_detect_plnet(airfe_ctx* c, const uint8_t*, int, int, int, const airfe_plnet_stage0*, float*, int, int*, double*,
+                       int, int*, float*, int, int*, int) {
+  return fail(c, "airfe_detect_plnet: not implemented in this build");
+}
+int airfe_match_superglue(airfe_ctx* c, const float*, int, const float*, int, int32_t*, int32_t*, double*, double*) {
+  return fail(c, "airfe_match_superglue: not implemented in this build");
+}
+
+// ---- kernel-level test hooks ------------------------------------------------------------------------------
+int airfe_debug_preprocess(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, float* out) {
+  if (!c || !c->has_sp) return fail(c, "debug_preprocess: detector not loaded");
+  const size_t bytes = (size_t)h * stride;
+  if (ensure_stage_img(c, bytes) || ensure_tables(c, h, w)) return 1;
+  const int R = AIRFE_INTERNAL_SIZE;
+  HIPCHK(c, hipMemcpyAsync(c->st_img, gray, bytes, hipMemcpyHostToDevice, c->stream));
+  launch_preprocess(c->st_img, 1, h, w, stride, bytes, c->xtab, c->ytab, c->lut, c->img32, R, R, c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy2D(out, (size_t)R * 4, c->img32 + (R + 2) + 1, (size_t)(R + 2) * 4, (size_t)R * 4, R, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int airfe_debug_conv3x3(airfe_ctx* c, const float* x, int B, int cin, int H, int W, const float* w, const float* b, int cout,
+                        int pool, float* y) {
+  if (!c) return 1;
+  if ((cin != 64 && cin != 128) || cout % 64 || W % 16 || H % 16) return fail(c, "debug_conv3x3: unsupported shape");
+  const int prec = c->prec;
+  std::vector<uint16_t> xin((size_t)B * (H + 2) * (W + 2) * cin, 0);
+  for (int bb = 0; bb < B; ++bb)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int yy = 0; yy < H; ++yy)
+        for (int xx = 0; xx < W; ++xx)
+          xin[(((size_t)bb * (H + 2) + yy + 1) * (W + 2) + xx + 1) * cin + ci] = cvt2(x[(((size_t)bb * cin + ci) * H + yy) * W + xx], prec);
+  const int nci = cin / 64;
+  auto slabs = pack_slabs(cout / 64, 9 * nci, prec, [&](int feat, int s, int k) {
+    const int tap = s / nci, cc = s % nci, ci = cc * 64 + k;
+    return w[((size_t)feat * cin + ci) * 9 + tap];
+  });
+  const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+  uint16_t *dx = nullptr, *dw = nullptr, *dy = nullptr;
+  float* db = nullptr;
+  const size_t ybytes = (size_t)B * (Ho + 2) * (Wo + 2) * cout * 2;
+  HIPCHK(c, hipMalloc((void**)&dx, xin.size() * 2));
+  HIPCHK(c, hipMalloc((void**)&dw, slabs.size() * 2));
+  HIPCHK(c, hipMalloc((void**)&dy, ybytes));
+  HIPCHK(c, hipMalloc((void**)&db, (size_t)cout * 4));
+  HIPCHK(c, hipMemcpy(dx, xin.data(), xin.size() * 2, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dw, slabs.data(), slabs.size() * 2, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(db, b, (size_t)cout * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemset(dy, 0, ybytes));
+  ConvArgs a;
+  a.X = dx; a.Wp = dw; a.bias = db; a.Y = dy; a.B = B; a.H = H; a.W = W; a.CIN = cin; a.COUT = cout;
+  a.pool = pool; a.out_pad = 1; a.relu = 1;
+  launch_conv3x3(prec, a, c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<uint16_t> yo(ybytes / 2);
+  HIPCHK(c, hipMemcpy(yo.data(), dy, ybytes, hipMemcpyDeviceToHost));
+  for (int bb = 0; bb < B; ++bb)
+    for (int co = 0; co < cout; ++co)
+      for (int yy = 0; yy < Ho; ++yy)
+        for (int xx = 0; xx < Wo; ++xx)
+          y[(((size_t)bb * cout + co) * Ho + yy) * Wo + xx] = back2(yo[(((size_t)bb * (Ho + 2) + yy + 1) * (Wo + 2) + xx + 1) * cout + co], prec);
+  (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db);
+  return 0;
+}
+
+int airfe_debug_gemm(airfe_ctx* c, const float* x, int M, int K, const float* w, const float* b, int N, int relu, float* y) {
+  if (!c) return 1;
+  if (K != 128 && K != 256 && K != 512) return fail(c, "debug_gemm: K must be 128, 256 or 512");
+  const int prec = c->prec, Mp = (M + 127) / 128 * 128, Np8 = (N + 7) / 8 * 8;
+  std::vector<uint16_t> xin((size_t)Mp * K, 0);
+  for (size_t i = 0; i < (size_t)M * K; ++i) xin[i] = cvt2(x[i], prec);
+  airfe_ctx tmp;   // only as an allocation list holder
+  tmp.prec = prec;
+  LinW lw;
+  if (!make_linear(&tmp, w, b, K, N, lw)) return fail(c, "debug_gemm: allocation failed");
+  uint16_t* dx = dupload(&tmp, xin);
+  float* dy = dalloc<float>(&tmp, (size_t)Mp * Np8);
+  int rc = 0;
+  if (!dx || !dy) rc = fail(c, "debug_gemm: allocation failed");
+  if (!rc) {
+    GemmArgs g;
+    g.X1 = dx; g.ld1 = K; g.K1 = K; g.Wp = lw.w; g.bias = lw.b; g.M = Mp; g.N = N; g.cb_total = lw.cbt;
+    g.epi = EPI_STORE_F32; g.act = relu ? ACT_RELU : ACT_NONE; g.out = dy; g.ldo = Np8;
+    launch_gemm(prec, K, false, g, c->stream);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, "debug_gemm: kernel failed");
+  }
+  if (!rc) {
+    std::vector<float> yo((size_t)Mp * Np8);
+    (void)hipMemcpy(yo.data(), dy, yo.size() * 4, hipMemcpyDeviceToHost);
+    for (int m = 0; m < M; ++m)
+      for (int n = 0; n < N; ++n) y[(size_t)m * N + n] = yo[(size_t)m * Np8 + n];
+  }
+  for (void* p : tmp.allocs) (void)hipFree(p);
+  return rc;
+}
+
+}  // extern "C"

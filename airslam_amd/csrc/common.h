@@ -1,0 +1,102 @@
+// airfe — shared device/host helpers for the gfx950 front-end kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace airfe {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---------------------------------------------------------------------------------------------
+// Precision traits: 2-byte storage type + the 16x16x32 MFMA that consumes it (fp32 accumulate).
+// Storage in HBM/LDS is always raw uint16_t bits; these only give meaning to the bits.
+struct PBF16 {
+  using vec8 = bf16x8;
+  static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float f) {
+    __bf16 h = static_cast<__bf16>(f);
+    return __builtin_bit_cast(uint16_t, h);
+  }
+  static __device__ __forceinline__ float to_f32(uint16_t u) {
+    return __builtin_bit_cast(float, (uint32_t)u << 16);
+  }
+};
+struct PF16 {
+  using vec8 = f16x8;
+  static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float f) {
+    _Float16 h = static_cast<_Float16>(f);
+    return __builtin_bit_cast(uint16_t, h);
+  }
+  static __device__ __forceinline__ float to_f32(uint16_t u) {
+    return static_cast<float>(__builtin_bit_cast(_Float16, u));
+  }
+};
+
+template <class P>
+__device__ __forceinline__ uint4 pack8(const float* v) {
+  uint4 r;
+  r.x = (uint32_t)P::from_f32(v[0]) | ((uint32_t)P::from_f32(v[1]) << 16);
+  r.y = (uint32_t)P::from_f32(v[2]) | ((uint32_t)P::from_f32(v[3]) << 16);
+  r.z = (uint32_t)P::from_f32(v[4]) | ((uint32_t)P::from_f32(v[5]) << 16);
+  r.w = (uint32_t)P::from_f32(v[6]) | ((uint32_t)P::from_f32(v[7]) << 16);
+  return r;
+}
+template <class P>
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  uint2 r;
+  r.x = (uint32_t)P::from_f32(a) | ((uint32_t)P::from_f32(b) << 16);
+  r.y = (uint32_t)P::from_f32(c) | ((uint32_t)P::from_f32(d) << 16);
+  return r;
+}
+template <class P>
+__device__ __forceinline__ void unpack8(uint4 u, float* v) {
+  v[0] = P::to_f32(u.x & 0xFFFF); v[1] = P::to_f32(u.x >> 16);
+  v[2] = P::to_f32(u.y & 0xFFFF); v[3] = P::to_f32(u.y >> 16);
+  v[4] = P::to_f32(u.z & 0xFFFF); v[5] = P::to_f32(u.z >> 16);
+  v[6] = P::to_f32(u.w & 0xFFFF); v[7] = P::to_f32(u.w >> 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS swizzles (16-byte chunk index XOR) that keep ds_read_b128 MFMA-fragment reads conflict-free.
+//   row pitch 128 B (64 two-byte channels): two rows share one 256-B bank row
+//   row pitch >= 256 B                    : each row starts a bank row
+__device__ __forceinline__ int swz128(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int swz256(int row) { return row & 15; }
+
+// Weight slab: [64 rows][64 k] two-byte elements = 8 KiB, pitch 128 B, swz128.  Slab row (t,i)
+// (MFMA tile t = 0..3, fragment row i = 0..15) holds output feature
+//     co = (t>>1)*32 + (i>>2)*8 + (t&1)*4 + (i&3)
+// so that after the swapped-operand MFMA (A = weights, B = activations) lane (j, g = lane>>4)
+// owns features tp*32 + g*8 .. +8 of token/pixel j for tp = 0,1  ->  two 16-byte stores.
+constexpr int SLAB_BYTES = 8192;
+
+__host__ __device__ inline int slab_row_to_feature(int rr) {
+  int t = rr >> 4, i = rr & 15;
+  return (t >> 1) * 32 + (i >> 2) * 8 + (t & 1) * 4 + (i & 3);
+}
+
+template <class P>
+__device__ __forceinline__ typename P::vec8 lds_frag(const char* base, int byte_off) {
+  uint4 u = *reinterpret_cast<const uint4*>(base + byte_off);
+  return __builtin_bit_cast(typename P::vec8, u);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+}  // namespace airfe

@@ -1,0 +1,107 @@
+// airfe — host-callable launch wrappers for every gfx950 kernel of the front end.
+// All pointers are device pointers; `prec` selects the 2-byte storage type (0 = bf16, 1 = fp16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace airfe {
+
+enum Epi {
+  EPI_STORE = 0,      // bias (+act) -> 2-byte [M][ldo]
+  EPI_STORE_F32 = 1,  // bias        -> fp32  [M][ldo], only features < N
+  EPI_RESID = 2,      // x32[M][ldo] += bias + acc ; out = 2-byte copy of x32
+  EPI_HEADS = 3,      // bias (+rotary) -> 2-byte head-major [S][H][Np][64]; feature/256 selects out/out2
+  EPI_HEADS_T = 4,    // (TRANS kernels) bias -> 2-byte [S][H][64][Np]
+};
+enum Act { ACT_NONE = 0, ACT_RELU = 1 };
+
+struct GemmArgs {
+  const uint16_t* X1 = nullptr;  // rows [M][ld1], first K1 input features
+  const uint16_t* X2 = nullptr;  // rows [M][ld2], remaining K-K1 features (cat(x, msg) inputs)
+  int ld1 = 0, ld2 = 0, K1 = 0;
+  const uint16_t* Wp = nullptr;  // slabs [N/64][K/64][8 KiB]
+  const float* bias = nullptr;   // [>= cb_total*64], natural feature order
+  int M = 0;                     // rows, multiple of the block's row tile
+  int N = 0;                     // valid output features
+  int cb_total = 0;              // ceil(N/64)
+  int epi = EPI_STORE;
+  int act = ACT_NONE;
+  void* out = nullptr;
+  void* out2 = nullptr;
+  int ldo = 0;
+  float* x32 = nullptr;
+  const float* rot_cos = nullptr;  // [M][32] (rotary on when non-null)
+  const float* rot_sin = nullptr;
+  int Np = 0, H = 4;
+};
+
+// out[M][N] = X[M][K] * W^T ; K in {128,256,512}; trans => EPI_HEADS_T (operand roles swapped)
+void launch_gemm(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st);
+
+struct ConvArgs {
+  const uint16_t* X = nullptr;  // [B][H+2][W+2][CIN], zero border
+  const uint16_t* Wp = nullptr; // slabs [COUT/64][9][CIN/64][8 KiB]
+  const float* bias = nullptr;
+  uint16_t* Y = nullptr;        // [B][Ho+2][Wo+2][COUT] (out_pad=1) or [B][Ho][Wo][COUT] (out_pad=0)
+  int B = 0, H = 0, W = 0, CIN = 0, COUT = 0;
+  int pool = 0;                 // fused 2x2 max-pool
+  int out_pad = 1;
+  int relu = 1;
+};
+void launch_conv3x3(int prec, const ConvArgs& a, hipStream_t st);
+
+// conv1a: fp32 image [B][H+2][W+2] (zero border) -> 2-byte [B][H+2][W+2][64], 3x3, Cin=1, ReLU
+void launch_conv1a(int prec, const float* img, const float* w /*[64][9]*/, const float* bias, uint16_t* out,
+                   int B, int H, int W, hipStream_t st);
+
+// cv::resize(INTER_LINEAR, 8-bit fixed point) + /255 -> fp32 [B][RH+2][RW+2] interior
+void launch_preprocess(const uint8_t* src, int B, int h, int w, int stride, size_t img_stride,
+                       const int* xtab /*[RW][4]: x0,x1,a0,a1*/, const int* ytab /*[RH][4]*/, const float* lut /*[256]*/,
+                       float* out, int RH, int RW, hipStream_t st);
+
+// ---- detector heads -----------------------------------------------------------------------
+// logits fp32 [B*HC*WC][ldl] (65 valid) -> heat fp32 [B][HC*8][WC*8]
+void launch_softmax_d2s(const float* logits, int ldl, float* heat, int B, int HC, int WC, hipStream_t st);
+// in-place channel L2 normalisation of fp32 [rows][256]
+void launch_l2norm256(float* d, int rows, hipStream_t st);
+// SuperPoint simple_nms(radius) on fp32 [B][H][W]; tmp: 3 maps of the same size
+void launch_simple_nms(const float* heat, float* out, float* tmp, int B, int H, int W, int radius, hipStream_t st);
+// threshold + border + top-K (score desc, raster asc) / raster order when count <= K
+//   feat [B][cap][259] rows: score,x,y written (x,y in 512-space, unscaled); n_out [B]
+void launch_select_topk(const float* heat, int B, int H, int W, float thr, int border, int topk, int cap,
+                        float* feat, int* n_out, hipStream_t st);
+// bilinear descriptor sampling + L2 norm (plnet.cpp:369-417), then x,y *= (w_scale,h_scale)
+//   desc fp32 [B][HC][WC][256]
+void launch_sample_desc(const float* desc, int B, int HC, int WC, float* feat, const int* n, int cap,
+                        float w_scale, float h_scale, hipStream_t st);
+
+// ---- LightGlue ------------------------------------------------------------------------------
+struct LgPrepArgs {
+  const float* f0; const float* f1;   // [B][cap][ld] feature rows (ld = 259: score,x,y,desc ; ld = 258: x,y,desc)
+  const int* n0; const int* n1;       // [B]
+  int ld, kp_off;                     // kp_off: column of x
+  int normalize;                      // apply PointMatcher::NormalizeKeypoints (point_matcher.cc:39-48)
+  float cx, cy, linv;                 // width/2, height/2 (integer division), scale/max(w,h)
+  const float* wr;                    // posenc.Wr.weight [32][2]
+  int B, cap, Np;
+  float* x32; uint16_t* xb;           // [2B][Np][256]
+  float* rot_cos; float* rot_sin;     // [2B][Np][32]
+  int* lens;                          // [2B]
+};
+void launch_lg_prepare(int prec, const LgPrepArgs& a, hipStream_t st);
+// flash attention over head-major Q,K [S][H][Np][64] and Vt [S][H][64][Np]; cross => kv sequence s^1
+void launch_attention(int prec, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O /*[S][Np][256]*/,
+                      const int* lens, int S, int H, int Np, int cross, float scale, hipStream_t st);
+// in-place LayerNorm(512, eps) + exact GELU on 2-byte [M][512]
+void launch_ln_gelu(int prec, uint16_t* h, const float* gamma, const float* beta, int M, hipStream_t st);
+// z[M] = logsigmoid-ready matchability: dot(x32[m], w) + b
+void launch_rowdot256(const float* x32, const float* w, float b, float* z, int M, hipStream_t st);
+// sim[b][i][j] = md[2b][i] . md[2b+1][j]  (fp32 [B][Np][Np])
+void launch_sim(int prec, const uint16_t* md, float* sim, int B, int Np, hipStream_t st);
+// LightGlue assignment + filter_matches (light_glue.cpp:214-266) fully on device
+//   scores_out (optional) [B][Np][Np] log-assignment; idx [B][cap][2], score [B][cap], nmatch [B]
+void launch_lg_assign(const float* sim, const float* z, const int* lens, int B, int Np, int cap, float thr,
+                      float* rowlse, float* collse, float* scores_out, int* rowarg, float* rowval, int* colarg,
+                      int32_t* idx, float* score, int* nmatch, hipStream_t st);
+
+}  // namespace airfe

@@ -1,0 +1,394 @@
+// airfe — image-side kernels: cv::resize-compatible pre-process, conv1a (Cin = 1), detector heads
+// (softmax-65 + depth-to-space, descriptor L2 norm, simple_nms), exact top-K keypoint selection and
+// bilinear descriptor sampling.  All HBM-bound; written for coalesced 16-byte lanes.
+#include "common.h"
+#include "kernels.h"
+
+namespace airfe {
+
+// =============================================================================== pre-process
+// cv::resize(INTER_LINEAR) 8-bit fixed-point path + `float(px)/255.0`
+// (reference: src/plnet.cpp:246-270, src/super_point.cpp:111-116,146-165).
+__global__ void preprocess_kernel(const uint8_t* __restrict__ src, int stride, size_t img_stride,
+                                  const int4* __restrict__ xtab, const int4* __restrict__ ytab,
+                                  const float* __restrict__ lut, float* __restrict__ out, int RH, int RW) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= RW) return;
+  const int4 xt = xtab[x], yt = ytab[y];
+  const uint8_t* s = src + (size_t)b * img_stride;
+  const uint8_t* r0 = s + (size_t)yt.x * stride;
+  const uint8_t* r1 = s + (size_t)yt.y * stride;
+  const int h0 = (int)r0[xt.x] * xt.z + (int)r0[xt.y] * xt.w;
+  const int h1 = (int)r1[xt.x] * xt.z + (int)r1[xt.y] * xt.w;
+  int v = (((yt.z * (h0 >> 4)) >> 16) + ((yt.w * (h1 >> 4)) >> 16) + 2) >> 2;
+  v = min(max(v, 0), 255);
+  out[((size_t)b * (RH + 2) + y + 1) * (RW + 2) + x + 1] = lut[v];
+}
+
+void launch_preprocess(const uint8_t* src, int B, int h, int w, int stride, size_t img_stride, const int* xtab,
+                       const int* ytab, const float* lut, float* out, int RH, int RW, hipStream_t st) {
+  (void)h; (void)w;
+  dim3 grid((RW + 255) / 256, RH, B);
+  hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, st, src, stride, img_stride,
+                     reinterpret_cast<const int4*>(xtab), reinterpret_cast<const int4*>(ytab), lut, out, RH, RW);
+}
+
+// =============================================================================== conv1a
+// Cin = 1: K = 9 is hopeless as a GEMM (AI ~ 9 F/B) -> fp32 VALU, 8 output channels per thread,
+// 8 consecutive threads write the 128 contiguous bytes of one pixel.
+template <class P>
+__global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, uint16_t* __restrict__ out,
+                                                     int B, int H, int W) {
+  const int cg = threadIdx.x & 7;
+  float wr[8][9], br[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    br[c] = bias[cg * 8 + c];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[c][k] = w[(cg * 8 + c) * 9 + k];
+  }
+  const long total = (long)B * H * W;
+  const long step = ((long)gridDim.x * blockDim.x) >> 3;
+  for (long pix = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; pix < total; pix += step) {
+    const int b = (int)(pix / ((long)H * W));
+    const int rem = (int)(pix - (long)b * H * W);
+    const int y = rem / W, x = rem - y * W;
+    const float* ip = img + ((size_t)b * (H + 2) + y) * (W + 2) + x;
+    float in[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) in[ky * 3 + kx] = ip[(size_t)ky * (W + 2) + kx];
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float s = br[c];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s = fmaf(wr[c][k], in[k], s);
+      v[c] = fmaxf(s, 0.f);
+    }
+    *reinterpret_cast<uint4*>(out + (((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + cg * 8) = pack8<P>(v);
+  }
+}
+
+void launch_conv1a(int prec, const float* img, const float* w, const float* bias, uint16_t* out, int B, int H, int W,
+                   hipStream_t st) {
+  const long total = (long)B * H * W;
+  long blocks = (total * 8 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (prec == 1)
+    hipLaunchKernelGGL(conv1a_kernel<PF16>, dim3((unsigned)blocks), dim3(256), 0, st, img, w, bias, out, B, H, W);
+  else
+    hipLaunchKernelGGL(conv1a_kernel<PBF16>, dim3((unsigned)blocks), dim3(256), 0, st, img, w, bias, out, B, H, W);
+}
+
+// =============================================================================== detector head
+// softmax over 65 logits, drop the dustbin, 8x8 depth-to-space (SuperPoint head)
+__global__ void softmax_d2s_kernel(const float* __restrict__ logits, int ldl, float* __restrict__ heat, int ncell,
+                                   int HC, int WC) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= ncell) return;
+  const float* l = logits + (size_t)cell * ldl;
+  float v[65];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 64; i += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(l + i);
+    v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+  }
+  v[64] = l[64];
+#pragma unroll
+  for (int i = 0; i < 65; ++i) mx = fmaxf(mx, v[i]);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 65; ++i) { v[i] = expf(v[i] - mx); sum += v[i]; }
+  const float inv = 1.0f / sum;
+  const int b = cell / (HC * WC), rem = cell - b * HC * WC;
+  const int cy = rem / WC, cx = rem - cy * WC;
+  float* o = heat + ((size_t)b * HC * 8 + (size_t)cy * 8) * (WC * 8) + cx * 8;
+#pragma unroll
+  for (int dy = 0; dy < 8; ++dy) {
+    float* r = o + (size_t)dy * (WC * 8);
+    *reinterpret_cast<float4*>(r) = make_float4(v[dy * 8] * inv, v[dy * 8 + 1] * inv, v[dy * 8 + 2] * inv, v[dy * 8 + 3] * inv);
+    *reinterpret_cast<float4*>(r + 4) = make_float4(v[dy * 8 + 4] * inv, v[dy * 8 + 5] * inv, v[dy * 8 + 6] * inv, v[dy * 8 + 7] * inv);
+  }
+}
+
+void launch_softmax_d2s(const float* logits, int ldl, float* heat, int B, int HC, int WC, hipStream_t st) {
+  const int ncell = B * HC * WC;
+  hipLaunchKernelGGL(softmax_d2s_kernel, dim3((ncell + 127) / 128), dim3(128), 0, st, logits, ldl, heat, ncell, HC, WC);
+}
+
+// F.normalize(dim=channel): one wave per 256-channel row
+__global__ void l2norm256_kernel(float* __restrict__ d, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float4* p = reinterpret_cast<float4*>(d + (size_t)row * 256) + lane;
+  float4 v = *p;
+  const float ss = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+  *p = v;
+}
+
+void launch_l2norm256(float* d, int rows, hipStream_t st) {
+  hipLaunchKernelGGL(l2norm256_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, d, rows);
+}
+
+// =============================================================================== simple_nms
+// Upstream SuperPoint simple_nms: 5 max-pools of (2r+1)^2 with mask logic, done as separable passes.
+__global__ void nms_poolh_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int r) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const size_t base = ((size_t)blockIdx.z * H + y) * W;
+  float m = -INFINITY;
+  for (int dx = -r; dx <= r; ++dx) {
+    const int xx = x + dx;
+    if (xx >= 0 && xx < W) m = fmaxf(m, in[base + xx]);
+  }
+  out[base + x] = m;
+}
+
+// mode 0: M = (S == pv)
+// mode 1: SUPP = pv > 0 ; SS = SUPP ? 0 : S
+// mode 2: M |= (SS == pv) & !SUPP
+// mode 3: like 2, and OUT = M ? S : 0
+__global__ void nms_poolv_kernel(const float* __restrict__ A, const float* __restrict__ S, float* __restrict__ M,
+                                 float* __restrict__ SS, float* __restrict__ SUPP, float* __restrict__ OUT, int H, int W,
+                                 int r, int mode) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const size_t img = (size_t)blockIdx.z * H * W;
+  float pv = -INFINITY;
+  for (int dy = -r; dy <= r; ++dy) {
+    const int yy = y + dy;
+    if (yy >= 0 && yy < H) pv = fmaxf(pv, A[img + (size_t)yy * W + x]);
+  }
+  const size_t i = img + (size_t)y * W + x;
+  if (mode == 0) {
+    M[i] = (S[i] == pv) ? 1.f : 0.f;
+  } else if (mode == 1) {
+    const bool sp = pv > 0.f;
+    SUPP[i] = sp ? 1.f : 0.f;
+    SS[i] = sp ? 0.f : S[i];
+  } else {
+    const bool nm = (SS[i] == pv);
+    const bool m = (M[i] > 0.f) || (nm && !(SUPP[i] > 0.f));
+    M[i] = m ? 1.f : 0.f;
+    if (mode == 3) OUT[i] = m ? S[i] : 0.f;
+  }
+}
+
+void launch_simple_nms(const float* heat, float* out, float* tmp, int B, int H, int W, int radius, hipStream_t st) {
+  const size_t n = (size_t)B * H * W;
+  float *A = tmp, *M = tmp + n, *SS = tmp + 2 * n, *SUPP = tmp + 3 * n;
+  dim3 grid((W + 255) / 256, H, B), blk(256);
+  hipLaunchKernelGGL(nms_poolh_kernel, grid, blk, 0, st, heat, A, H, W, radius);
+  hipLaunchKernelGGL(nms_poolv_kernel, grid, blk, 0, st, A, heat, M, SS, SUPP, out, H, W, radius, 0);
+  for (int it = 0; it < 2; ++it) {
+    hipLaunchKernelGGL(nms_poolh_kernel, grid, blk, 0, st, M, A, H, W, radius);
+    hipLaunchKernelGGL(nms_poolv_kernel, grid, blk, 0, st, A, heat, M, SS, SUPP, out, H, W, radius, 1);
+    hipLaunchKernelGGL(nms_poolh_kernel, grid, blk, 0, st, SS, A, H, W, radius);
+    hipLaunchKernelGGL(nms_poolv_kernel, grid, blk, 0, st, A, heat, M, SS, SUPP, out, H, W, radius, it == 1 ? 3 : 2);
+  }
+}
+
+// =============================================================================== top-K selection
+// detect_point (src/plnet.cpp:309-355): candidates = score >= thr inside the (inclusive) border box.
+//   count <= K : all candidates in RASTER order (unsorted)
+//   count >  K : top K by score descending; ties by ascending raster index
+// One 1024-thread workgroup per image.  Exact: MSB radix select on the 49-bit key
+// (score_bits << 18 | (2^18-1 - idx)) then a bitonic sort of the <= 1024 survivors in LDS.
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 kp_key(const float* hm, int i, int W, int H, float thr, int border) {
+  const float s = hm[i];
+  if (s < thr) return 0ull;
+  const int y = i / W, x = i - y * W;
+  if (x < border || x > W - border || y < border || y > H - border) return 0ull;
+  return (1ull << 49) | ((u64)__float_as_uint(s) << 18) | (u64)(0x3FFFF - i);
+}
+
+__global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restrict__ heat, int H, int W, float thr,
+                                                           int border, int topk, int cap, float* __restrict__ feat,
+                                                           int* __restrict__ n_out) {
+  __shared__ unsigned hist[2048];
+  __shared__ u64 sk[1024];
+  __shared__ unsigned wsum[16];
+  __shared__ u64 s_prefix;
+  __shared__ unsigned s_remaining, s_cnt, s_done;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int N = H * W;
+  const float* hm = heat + (size_t)b * N;
+
+  u64 prefix = 0;          // determined high bits of the K-th largest key (bit 49 = valid flag, always 1)
+  unsigned remaining = (unsigned)topk;
+  bool take_all = false;
+  const int shifts[5] = {38, 27, 16, 5, 0};
+  const int nbits[5] = {11, 11, 11, 11, 5};
+  for (int pass = 0; pass < 5; ++pass) {
+    for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+    __syncthreads();
+    const int sh = shifts[pass];
+    const u64 himask = ~((1ull << (sh + nbits[pass])) - 1ull);   // bits above this digit
+    const unsigned dmask = (1u << nbits[pass]) - 1u;
+    for (int i = tid; i < N; i += 1024) {
+      const u64 k = kp_key(hm, i, W, H, thr, border);
+      if (k && ((k & himask) == ((prefix | (1ull << 49)) & himask))) atomicAdd(&hist[(unsigned)(k >> sh) & dmask], 1u);
+    }
+    __syncthreads();
+    // suffix scan from the top bin: thread t owns bins (2047-2t) and (2046-2t)
+    const unsigned h0 = hist[2047 - 2 * tid], h1 = hist[2046 - 2 * tid];
+    unsigned v = h0 + h1, incl = v;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned woff = 0, tot = 0;
+    for (int w2 = 0; w2 < 16; ++w2) {
+      const unsigned t = wsum[w2];
+      if (w2 < wv) woff += t;
+      tot += t;
+    }
+    incl += woff;
+    const unsigned excl = incl - v;
+    if (pass == 0 && tot <= (unsigned)topk) take_all = true;   // uniform: every thread sees the same tot
+    if (!take_all) {
+      // the bin where the cumulative count (from the top) first reaches `remaining`
+      if (excl < remaining && remaining <= excl + h0) {
+        s_prefix = prefix | ((u64)(2047 - 2 * tid) << sh);
+        s_remaining = remaining - excl;
+        s_done = (h0 == remaining - excl) ? 1u : 0u;
+      } else if (excl + h0 < remaining && remaining <= incl) {
+        s_prefix = prefix | ((u64)(2046 - 2 * tid) << sh);
+        s_remaining = remaining - excl - h0;
+        s_done = (h1 == remaining - excl - h0) ? 1u : 0u;
+      }
+    }
+    __syncthreads();
+    if (take_all) break;
+    prefix = s_prefix;
+    remaining = s_remaining;
+    const bool done = s_done != 0;
+    __syncthreads();
+    if (done) break;   // every key under this prefix is selected; lower bits of the threshold stay 0
+  }
+
+  // ---- collect survivors into LDS
+  const u64 T = prefix | (1ull << 49);
+  if (tid == 0) s_cnt = 0;
+  sk[tid] = ~0ull;
+  __syncthreads();
+  for (int i = tid; i < N; i += 1024) {
+    const u64 k = kp_key(hm, i, W, H, thr, border);
+    if (k && (take_all || k >= T)) {
+      const unsigned slot = atomicAdd(&s_cnt, 1u);
+      if (slot < 1024) {
+        if (take_all) sk[slot] = ((u64)i << 32) | (u64)(unsigned)((k >> 18) & 0xFFFFFFFFull);   // ascending raster
+        else sk[slot] = ~k;                                                                    // descending key
+      }
+    }
+  }
+  __syncthreads();
+  const int n = min((int)s_cnt, min(topk, 1024));
+  // ---- bitonic sort (ascending) of 1024 keys
+  for (int k2 = 2; k2 <= 1024; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      const int p = tid ^ j;
+      if (p > tid) {
+        const u64 a = sk[tid], c = sk[p];
+        const bool up = (tid & k2) == 0;
+        if ((a > c) == up) { sk[tid] = c; sk[p] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < n) {
+    const u64 e = sk[tid];
+    int idx;
+    unsigned sb;
+    if (take_all) { idx = (int)(e >> 32); sb = (unsigned)(e & 0xFFFFFFFFull); }
+    else { const u64 k = ~e; idx = 0x3FFFF - (int)(k & 0x3FFFFull); sb = (unsigned)((k >> 18) & 0xFFFFFFFFull); }
+    const int y = idx / W, x = idx - y * W;
+    float* f = feat + ((size_t)b * cap + tid) * 259;
+    f[0] = __uint_as_float(sb);
+    f[1] = (float)x;
+    f[2] = (float)y;
+  }
+  if (tid == 0) n_out[b] = n;
+}
+
+void launch_select_topk(const float* heat, int B, int H, int W, float thr, int border, int topk, int cap, float* feat,
+                        int* n_out, hipStream_t st) {
+  hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(1024), 0, st, heat, H, W, thr, border, topk, cap, feat, n_out);
+}
+
+// =============================================================================== descriptor sampling
+// extract_descriptors (src/plnet.cpp:369-417 == src/super_point.cpp:224-272) on a dense NHWC fp32 map,
+// one wave per keypoint (lane = 4 channels, 1 KiB coalesced row reads), then the final rescale
+// (plnet.cpp:574-575).  _rn intrinsics keep hipcc from contracting the reference's mul/add pairs.
+__device__ __forceinline__ int clipi(int v, int mx) { return v < 0 ? 0 : min(v, mx - 1); }
+
+__global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restrict__ desc, int HC, int WC,
+                                                          float* __restrict__ feat, const int* __restrict__ n, int cap,
+                                                          float sx, float bx, float sy, float by, float w_scale,
+                                                          float h_scale) {
+  const int b = blockIdx.y, k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= n[b]) return;
+  float* f = feat + ((size_t)b * cap + k) * 259;
+  const float x = f[1], y = f[2];
+  float kx = __fadd_rn(__fmul_rn(x, sx), bx), ky = __fadd_rn(__fmul_rn(y, sy), by);
+  kx = __fmul_rn(__fadd_rn(kx, 1.0f), 0.5f);
+  ky = __fmul_rn(__fadd_rn(ky, 1.0f), 0.5f);
+  const float ix = __fmul_rn(kx, (float)(WC - 1)), iy = __fmul_rn(ky, (float)(HC - 1));
+  const int ix_nw = clipi((int)floorf(ix), WC), iy_nw = clipi((int)floorf(iy), HC);
+  const int ix_ne = clipi(ix_nw + 1, WC), iy_ne = clipi(iy_nw, HC);
+  const int ix_sw = clipi(ix_nw, WC), iy_sw = clipi(iy_nw + 1, HC);
+  const int ix_se = clipi(ix_nw + 1, WC), iy_se = clipi(iy_nw + 1, HC);
+  const float nw = __fmul_rn(__fsub_rn((float)ix_se, ix), __fsub_rn((float)iy_se, iy));
+  const float ne = __fmul_rn(__fsub_rn(ix, (float)ix_sw), __fsub_rn((float)iy_sw, iy));
+  const float sw = __fmul_rn(__fsub_rn((float)ix_ne, ix), __fsub_rn(iy, (float)iy_ne));
+  const float se = __fmul_rn(__fsub_rn(ix, (float)ix_nw), __fsub_rn(iy, (float)iy_nw));
+  const float* d = desc + (size_t)b * HC * WC * 256 + lane * 4;
+  const float4 a0 = *reinterpret_cast<const float4*>(d + ((size_t)iy_nw * WC + ix_nw) * 256);
+  const float4 a1 = *reinterpret_cast<const float4*>(d + ((size_t)iy_ne * WC + ix_ne) * 256);
+  const float4 a2 = *reinterpret_cast<const float4*>(d + ((size_t)iy_sw * WC + ix_sw) * 256);
+  const float4 a3 = *reinterpret_cast<const float4*>(d + ((size_t)iy_se * WC + ix_se) * 256);
+  float v[4];
+  const float n0[4] = {a0.x, a0.y, a0.z, a0.w}, n1[4] = {a1.x, a1.y, a1.z, a1.w};
+  const float n2[4] = {a2.x, a2.y, a2.z, a2.w}, n3[4] = {a3.x, a3.y, a3.z, a3.w};
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float t = __fmul_rn(n0[j], nw);
+    t = __fadd_rn(t, __fmul_rn(n1[j], ne));
+    t = __fadd_rn(t, __fmul_rn(n2[j], sw));
+    t = __fadd_rn(t, __fmul_rn(n3[j], se));
+    v[j] = t;
+    ss = __fadd_rn(ss, __fmul_rn(t, t));
+  }
+  ss = wave_sum(ss);
+  const float nrm = sqrtf(ss);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) f[3 + lane * 4 + j] = v[j] / nrm;
+  if (lane == 0) {
+    f[1] = __fmul_rn(x, w_scale);
+    f[2] = __fmul_rn(y, h_scale);
+  }
+}
+
+void launch_sample_desc(const float* desc, int B, int HC, int WC, float* feat, const int* n, int cap, float w_scale,
+                        float h_scale, hipStream_t st) {
+  const int s = 8;
+  const float sx = (float)(2.0 / (WC * s - s / 2 - 0.5)), bx = (float)((1 - s) / (WC * s - s / 2 - 0.5) - 1);
+  const float sy = (float)(2.0 / (HC * s - s / 2 - 0.5)), by = (float)((1 - s) / (HC * s - s / 2 - 0.5) - 1);
+  hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4, B), dim3(256), 0, st, desc, HC, WC, feat, n, cap, sx, bx,
+                     sy, by, w_scale, h_scale);
+}
+
+}  // namespace airfe

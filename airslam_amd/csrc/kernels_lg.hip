@@ -1,0 +1,449 @@
+// airfe — matcher kernels shared by LightGlue / SuperGlue: token preparation (+ Fourier positional
+// encoding), flash attention on MFMA (d_head = 64), LayerNorm+GELU, similarity GEMM, and the
+// LightGlue log-assignment + on-device filter_matches (src/light_glue.cpp:214-266).
+#include "common.h"
+#include "kernels.h"
+
+namespace airfe {
+
+// =============================================================================== prepare
+// Builds the residual stream from the 259/258-float feature rows (the reference's process_input,
+// src/light_glue.cpp:172-212, plus PointMatcher::NormalizeKeypoints, src/point_matcher.cc:39-48).
+template <class P>
+__global__ __launch_bounds__(256) void lg_prepare_kernel(LgPrepArgs a) {
+  const int s = blockIdx.y, n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= a.Np) return;
+  const int b = s >> 1, side = s & 1;
+  const int len = side ? a.n1[b] : a.n0[b];
+  if (n == 0 && lane == 0) a.lens[s] = len;
+  const size_t row = (size_t)s * a.Np + n;
+  float* x32 = a.x32 + row * 256;
+  uint16_t* xb = a.xb + row * 256;
+  if (n < len) {
+    const float* f = (side ? a.f1 : a.f0) + ((size_t)b * a.cap + n) * a.ld;
+    float kx = f[a.kp_off], ky = f[a.kp_off + 1];
+    if (a.normalize) {
+      kx = __fmul_rn(__fsub_rn(kx, a.cx), a.linv);
+      ky = __fmul_rn(__fsub_rn(ky, a.cy), a.linv);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = lane + 64 * j;
+      const float v = f[a.kp_off + 2 + c];
+      x32[c] = v;
+      xb[c] = P::from_f32(v);
+    }
+    if (lane < 32) {
+      const float pr = a.wr[lane * 2] * kx + a.wr[lane * 2 + 1] * ky;
+      a.rot_cos[row * 32 + lane] = cosf(pr);
+      a.rot_sin[row * 32 + lane] = sinf(pr);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = lane + 64 * j;
+      x32[c] = 0.f;
+      xb[c] = 0;
+    }
+    if (lane < 32) {
+      a.rot_cos[row * 32 + lane] = 1.f;
+      a.rot_sin[row * 32 + lane] = 0.f;
+    }
+  }
+}
+
+void launch_lg_prepare(int prec, const LgPrepArgs& a, hipStream_t st) {
+  dim3 grid((a.Np + 3) / 4, 2 * a.B);
+  if (prec == 1) hipLaunchKernelGGL(lg_prepare_kernel<PF16>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(lg_prepare_kernel<PBF16>, grid, dim3(256), 0, st, a);
+}
+
+// =============================================================================== attention
+// Flash attention, one (sequence, head, 128-query block) per workgroup; each wave owns 32 queries.
+// Swapped products keep the softmax row-local to a lane group:
+//   S^T = K . Q^T   (A = K rows from LDS, B = Q fragments in VGPRs)  -> lane (q = lane&15, g) holds 4 keys/tile
+//   O^T = V^T . P^T (A = V^T rows from LDS, B = P packed straight from the S^T accumulators, no shuffles)
+template <class P>
+__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K,
+                                                        const uint16_t* __restrict__ Vt, uint16_t* __restrict__ O,
+                                                        const int* __restrict__ lens, int H, int Np, int cross,
+                                                        float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int s = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int skv = cross ? (s ^ 1) : s;
+  const int len_kv = lens[skv];
+  const uint16_t* Qh = Q + ((size_t)s * H + h) * Np * 64;
+  const uint16_t* Kh = K + ((size_t)skv * H + h) * Np * 64;
+  const uint16_t* Vh = Vt + ((size_t)skv * H + h) * 64 * Np;
+
+  typename P::vec8 qf[2][2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int row = min(q0 + qt * 16 + l15, Np - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 u = *reinterpret_cast<const uint4*>(Qh + (size_t)row * 64 + ks * 32 + g * 8);
+      qf[qt][ks] = __builtin_bit_cast(typename P::vec8, u);
+    }
+  }
+
+  const int nkv = (len_kv + 63) >> 6;
+  float m_i[2] = {-INFINITY, -INFINITY}, l_i[2] = {0.f, 0.f};
+  f32x4 o[2][4];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: 512 16-byte chunks per tile, two per thread
+  const int c0 = tid, c1 = tid + 256;
+  const int r0 = c0 >> 3, r1 = c1 >> 3, cc0 = c0 & 7, cc1 = c1 & 7;
+  const int d0 = r0 * 128 + ((cc0 ^ swz128(r0)) << 4), d1 = r1 * 128 + ((cc1 ^ swz128(r1)) << 4);
+  uint4 pk0, pk1, pv0, pv1;
+  auto load_tile = [&](int kt) {
+    pk0 = *reinterpret_cast<const uint4*>(Kh + ((size_t)kt * 64 + r0) * 64 + cc0 * 8);
+    pk1 = *reinterpret_cast<const uint4*>(Kh + ((size_t)kt * 64 + r1) * 64 + cc1 * 8);
+    pv0 = *reinterpret_cast<const uint4*>(Vh + (size_t)r0 * Np + kt * 64 + cc0 * 8);
+    pv1 = *reinterpret_cast<const uint4*>(Vh + (size_t)r1 * Np + kt * 64 + cc1 * 8);
+  };
+  auto write_tile = [&](int buf) {
+    char* kb = smem + buf * 16384;
+    char* vb = kb + 8192;
+    *reinterpret_cast<uint4*>(kb + d0) = pk0;
+    *reinterpret_cast<uint4*>(kb + d1) = pk1;
+    *reinterpret_cast<uint4*>(vb + d0) = pv0;
+    *reinterpret_cast<uint4*>(vb + d1) = pv1;
+  };
+  if (nkv > 0) {
+    load_tile(0);
+    write_tile(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nkv; ++kt) {
+    if (kt + 1 < nkv) load_tile(kt + 1);
+    const char* kb = smem + (kt & 1) * 16384;
+    const char* vb = kb + 8192;
+
+    f32x4 st[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int kti = 0; kti < 4; ++kti) st[qt][kti] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kti = 0; kti < 4; ++kti) {
+      const int kr = kti * 16 + l15;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const typename P::vec8 kf = lds_frag<P>(kb, kr * 128 + (((ks * 4 + g) ^ swz128(kr)) << 4));
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) st[qt][kti] = P::mfma(kf, qf[qt][ks], st[qt][kti]);
+      }
+    }
+    typename P::vec8 pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kti = 0; kti < 4; ++kti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 64 + kti * 16 + g * 4 + r;
+          float v = st[qt][kti][r] * scale_log2e;
+          if (key >= len_kv) v = -INFINITY;
+          st[qt][kti][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_i[qt], mx);
+      const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = exp2f(m_i[qt] - m_safe);
+      float ps = 0.f;
+#pragma unroll
+      for (int kti = 0; kti < 4; ++kti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(st[qt][kti][r] - m_safe);
+          st[qt][kti][r] = p;
+          ps += p;
+        }
+      l_i[qt] = l_i[qt] * alpha + ps;
+      m_i[qt] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[qt][dt] *= alpha;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        float pv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          pv[e] = st[qt][2 * kk][e];
+          pv[4 + e] = st[qt][2 * kk + 1][e];
+        }
+        pf[qt][kk] = __builtin_bit_cast(typename P::vec8, pack8<P>(pv));
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int dr = dt * 16 + l15;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ca = kk * 4 + (g >> 1), cbk = ca + 2;
+        const uint2 va = *reinterpret_cast<const uint2*>(vb + dr * 128 + ((ca ^ swz128(dr)) << 4) + (g & 1) * 8);
+        const uint2 vb2 = *reinterpret_cast<const uint2*>(vb + dr * 128 + ((cbk ^ swz128(dr)) << 4) + (g & 1) * 8);
+        const uint4 u = make_uint4(va.x, va.y, vb2.x, vb2.y);
+        const typename P::vec8 vf = __builtin_bit_cast(typename P::vec8, u);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) o[qt][dt] = P::mfma(vf, pf[qt][kk], o[qt][dt]);
+      }
+    }
+    if (kt + 1 < nkv) write_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = l_i[qt];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+    const int q = q0 + qt * 16 + l15;
+    if (q < Np) {
+      uint16_t* orow = O + ((size_t)s * Np + q) * (H * 64) + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<uint2*>(orow + dt * 16 + g * 4) =
+            pack4<P>(o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv);
+    }
+  }
+}
+
+void launch_attention(int prec, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, const int* lens,
+                      int S, int H, int Np, int cross, float scale, hipStream_t st) {
+  dim3 grid((Np + 127) / 128, H, S);
+  const float sl = scale * 1.4426950408889634f;
+  if (prec == 1) hipLaunchKernelGGL(attention_kernel<PF16>, grid, dim3(256), 0, st, Q, K, Vt, O, lens, H, Np, cross, sl);
+  else hipLaunchKernelGGL(attention_kernel<PBF16>, grid, dim3(256), 0, st, Q, K, Vt, O, lens, H, Np, cross, sl);
+}
+
+// =============================================================================== LayerNorm + GELU
+template <class P>
+__global__ __launch_bounds__(256) void ln_gelu_kernel(uint16_t* __restrict__ h, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int M) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  uint4* p = reinterpret_cast<uint4*>(h + (size_t)row * 512) + lane;
+  float v[8];
+  unpack8<P>(*p, v);
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sum += v[e];
+  const float mean = wave_sum(sum) * (1.0f / 512.0f);
+  float var = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; var += d * d; }
+  var = wave_sum(var) * (1.0f / 512.0f);
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = lane * 8 + e;
+    const float y = (v[e] - mean) * rstd * gamma[c] + beta[c];
+    v[e] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752f));
+  }
+  *p = pack8<P>(v);
+}
+
+void launch_ln_gelu(int prec, uint16_t* h, const float* gamma, const float* beta, int M, hipStream_t st) {
+  dim3 grid((M + 3) / 4);
+  if (prec == 1) hipLaunchKernelGGL(ln_gelu_kernel<PF16>, grid, dim3(256), 0, st, h, gamma, beta, M);
+  else hipLaunchKernelGGL(ln_gelu_kernel<PBF16>, grid, dim3(256), 0, st, h, gamma, beta, M);
+}
+
+// =============================================================================== matchability
+__global__ void rowdot256_kernel(const float* __restrict__ x32, const float* __restrict__ w, float b,
+                                 float* __restrict__ z, int M) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float4 x = *(reinterpret_cast<const float4*>(x32 + (size_t)row * 256) + lane);
+  const float4 ww = *(reinterpret_cast<const float4*>(w) + lane);
+  const float d = wave_sum(x.x * ww.x + x.y * ww.y + x.z * ww.z + x.w * ww.w);
+  if (lane == 0) z[row] = d + b;
+}
+
+void launch_rowdot256(const float* x32, const float* w, float b, float* z, int M, hipStream_t st) {
+  hipLaunchKernelGGL(rowdot256_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x32, w, b, z, M);
+}
+
+// =============================================================================== similarity
+// sim[b][i][j] = md[2b][i] . md[2b+1][j], K = 256; each wave a 16 x 64 tile, fragments straight from L2.
+template <class P>
+__global__ __launch_bounds__(256) void sim_kernel(const uint16_t* __restrict__ md, float* __restrict__ sim, int Np) {
+  const int b = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+  const int i0 = (blockIdx.x * 4 + wave) * 16, j0 = blockIdx.y * 64;
+  if (i0 >= Np) return;
+  const uint16_t* A = md + ((size_t)(2 * b) * Np + i0 + l15) * 256;
+  const uint16_t* Bm = md + ((size_t)(2 * b + 1) * Np + j0 + l15) * 256;
+  f32x4 acc[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const uint4 ua = *reinterpret_cast<const uint4*>(A + ks * 32 + g * 8);
+    const typename P::vec8 af = __builtin_bit_cast(typename P::vec8, ua);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const uint4 ub = *reinterpret_cast<const uint4*>(Bm + (size_t)jt * 16 * 256 + ks * 32 + g * 8);
+      acc[jt] = P::mfma(af, __builtin_bit_cast(typename P::vec8, ub), acc[jt]);
+    }
+  }
+  float* out = sim + ((size_t)b * Np + i0) * Np + j0;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(size_t)(g * 4 + r) * Np + jt * 16 + l15] = acc[jt][r];
+}
+
+void launch_sim(int prec, const uint16_t* md, float* sim, int B, int Np, hipStream_t st) {
+  dim3 grid((Np / 16 + 3) / 4, Np / 64, B);
+  if (prec == 1) hipLaunchKernelGGL(sim_kernel<PF16>, grid, dim3(256), 0, st, md, sim, Np);
+  else hipLaunchKernelGGL(sim_kernel<PBF16>, grid, dim3(256), 0, st, md, sim, Np);
+}
+
+// =============================================================================== assignment + filter
+__device__ __forceinline__ float logsigmoidf(float z) { return fminf(z, 0.f) - log1pf(expf(-fabsf(z))); }
+
+// wave per row: log-sum-exp over j < n1
+__global__ void lg_rowlse_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np,
+                                 float* __restrict__ rowlse) {
+  const int b = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
+  if (i >= n0) return;
+  const float* r = sim + ((size_t)b * Np + i) * Np;
+  float mx = -INFINITY;
+  for (int j = lane; j < n1; j += 64) mx = fmaxf(mx, r[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < n1; j += 64) s += expf(r[j] - mx);
+  s = wave_sum(s);
+  if (lane == 0) rowlse[(size_t)b * Np + i] = mx + logf(s);
+}
+
+// thread per column: log-sum-exp over i < n0 (coalesced across the block's columns)
+__global__ void lg_collse_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np,
+                                 float* __restrict__ collse) {
+  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
+  if (j >= n1) return;
+  const float* c = sim + (size_t)b * Np * Np + j;
+  float mx = -INFINITY;
+  for (int i = 0; i < n0; ++i) mx = fmaxf(mx, c[(size_t)i * Np]);
+  float s = 0.f;
+  for (int i = 0; i < n0; ++i) s += expf(c[(size_t)i * Np] - mx);
+  collse[(size_t)b * Np + j] = mx + logf(s);
+}
+
+__device__ __forceinline__ float lg_score(float sv, float rl, float cl, float c0, float c1) {
+  return ((sv - rl) + (sv - cl)) + (c0 + c1);
+}
+
+// wave per row: scores (optionally materialised) + row arg-max, first maximum wins
+__global__ void lg_rowarg_kernel(const float* __restrict__ sim, const float* __restrict__ z, const int* __restrict__ lens,
+                                 int Np, const float* __restrict__ rowlse, const float* __restrict__ collse,
+                                 float* __restrict__ scores_out, int* __restrict__ rowarg, float* __restrict__ rowval) {
+  const int b = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
+  if (i >= n0) return;
+  const float* r = sim + ((size_t)b * Np + i) * Np;
+  const float rl = rowlse[(size_t)b * Np + i];
+  const float c0 = logsigmoidf(z[(size_t)(2 * b) * Np + i]);
+  const float* z1 = z + (size_t)(2 * b + 1) * Np;
+  const float* cl = collse + (size_t)b * Np;
+  float best = -INFINITY;
+  int bj = 0x7FFFFFFF;
+  for (int j = lane; j < n1; j += 64) {
+    const float sc = lg_score(r[j], rl, cl[j], c0, logsigmoidf(z1[j]));
+    if (scores_out) scores_out[((size_t)b * Np + i) * Np + j] = sc;
+    if (sc > best) { best = sc; bj = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int oj = __shfl_xor(bj, o);
+    if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+  }
+  if (lane == 0) {
+    rowarg[(size_t)b * Np + i] = (bj == 0x7FFFFFFF) ? 0 : bj;
+    rowval[(size_t)b * Np + i] = best;
+  }
+}
+
+// thread per column: column arg-max over rows, strict '>' (first maximum wins)
+__global__ void lg_colarg_kernel(const float* __restrict__ sim, const float* __restrict__ z, const int* __restrict__ lens,
+                                 int Np, const float* __restrict__ rowlse, const float* __restrict__ collse,
+                                 int* __restrict__ colarg) {
+  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
+  if (j >= n1) return;
+  const float* c = sim + (size_t)b * Np * Np + j;
+  const float cl = collse[(size_t)b * Np + j];
+  const float c1 = logsigmoidf(z[(size_t)(2 * b + 1) * Np + j]);
+  const float* z0 = z + (size_t)(2 * b) * Np;
+  const float* rl = rowlse + (size_t)b * Np;
+  float best = -INFINITY;
+  int bi = 0;
+  for (int i = 0; i < n0; ++i) {
+    const float sc = lg_score(c[(size_t)i * Np], rl[i], cl, logsigmoidf(z0[i]), c1);
+    if (sc > best) { best = sc; bi = i; }
+  }
+  colarg[(size_t)b * Np + j] = bi;
+}
+
+// one 1024-thread workgroup per pair: mutual check + exp(score) > thr, ordered compaction (ascending row)
+__global__ __launch_bounds__(1024) void lg_filter_kernel(const int* __restrict__ lens, int Np, int cap, float thr,
+                                                         const int* __restrict__ rowarg, const float* __restrict__ rowval,
+                                                         const int* __restrict__ colarg, int32_t* __restrict__ idx,
+                                                         float* __restrict__ score, int* __restrict__ nmatch) {
+  __shared__ unsigned wsum[16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n0 = lens[2 * b];
+  bool ok = false;
+  int col = 0;
+  float e = 0.f;
+  if (tid < n0) {
+    col = rowarg[(size_t)b * Np + tid];
+    e = expf(rowval[(size_t)b * Np + tid]);
+    ok = (colarg[(size_t)b * Np + col] == tid) && (e > thr);
+  }
+  const unsigned long long bal = __ballot(ok);
+  const unsigned before = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wsum[wv] = __popcll(bal);
+  __syncthreads();
+  unsigned off = 0, tot = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wv) off += wsum[w];
+    tot += wsum[w];
+  }
+  const unsigned slot = off + before;
+  if (ok && slot < (unsigned)cap) {
+    idx[((size_t)b * cap + slot) * 2] = tid;
+    idx[((size_t)b * cap + slot) * 2 + 1] = col;
+    score[(size_t)b * cap + slot] = e;
+  }
+  if (tid == 0) nmatch[b] = min((int)tot, cap);
+}
+
+void launch_lg_assign(const float* sim, const float* z, const int* lens, int B, int Np, int cap, float thr, float* rowlse,
+                      float* collse, float* scores_out, int* rowarg, float* rowval, int* colarg, int32_t* idx,
+                      float* score, int* nmatch, hipStream_t st) {
+  hipLaunchKernelGGL(lg_rowlse_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, sim, lens, Np, rowlse);
+  hipLaunchKernelGGL(lg_collse_kernel, dim3((Np + 63) / 64, B), dim3(64), 0, st, sim, lens, Np, collse);
+  hipLaunchKernelGGL(lg_rowarg_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, sim, z, lens, Np, rowlse, collse,
+                     scores_out, rowarg, rowval);
+  hipLaunchKernelGGL(lg_colarg_kernel, dim3((Np + 63) / 64, B), dim3(64), 0, st, sim, z, lens, Np, rowlse, collse, colarg);
+  hipLaunchKernelGGL(lg_filter_kernel, dim3(B), dim3(1024), 0, st, lens, Np, cap, thr, rowarg, rowval, colarg, idx, score,
+                     nmatch);
+}
+
+}  // namespace airfe

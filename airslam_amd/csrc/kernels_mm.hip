@@ -1,0 +1,383 @@
+// airfe — MFMA kernels: implicit-GEMM 3x3 convolution (NHWC, LDS-staged halo tile) and the dense
+// "X-stationary" GEMM used by 1x1 convs and every Linear/Conv1d of the matchers.
+//
+// Both kernels use the same scheme (gfx950, wave64, v_mfma_f32_16x16x32_{bf16,f16}):
+//   * the activation tile (halo'ed pixels x CIN, or BM rows x K) is staged ONCE into LDS with a
+//     16-byte-chunk XOR swizzle so every ds_read_b128 fragment read is bank-conflict free;
+//   * weights stream through a double-buffered 8 KiB slab ([64 features][64 k], pre-swizzled on
+//     the host so staging is a linear copy), one barrier per slab, next slab prefetched in VGPRs;
+//   * operands are SWAPPED (A = weight rows, B = pixels/tokens): the accumulator of lane
+//     (j = lane&15, g = lane>>4) then holds 8 contiguous output features of pixel j per tile pair,
+//     i.e. the epilogue (bias, ReLU, 2x2 max-pool, rotary, residual, ...) works on whole feature
+//     runs of one pixel and stores 16-byte vectors.
+#include "common.h"
+#include "kernels.h"
+
+namespace airfe {
+
+template <int CIN>
+__device__ __forceinline__ int swz_pix(int p) {
+  if constexpr (CIN == 64) return swz128(p);
+  else return swz256(p);
+}
+
+// ================================================================================== conv 3x3
+template <class P, int CIN, int MR, bool POOL>
+__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int tiles_x, int tiles_y, int cb_per_block) {
+  constexpr int TH = 4 * MR, TW = 16, PH = TH + 2, PW = TW + 2;
+  constexpr int PIXB = CIN * 2, CPP = CIN / 8, NS = 9 * (CIN / 64);
+  constexpr int TILE_BYTES = PH * PW * PIXB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;
+  char* ws = smem + TILE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int bid = blockIdx.x;
+  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = bid / (tiles_x * tiles_y);
+  const int H = a.H, W = a.W, COUT = a.COUT;
+
+  // ---- stage the halo tile (input has a zero border, so no bounds tests)
+  const size_t in_row = (size_t)(W + 2) * PIXB;
+  const char* xin = (const char*)a.X + ((size_t)b * (H + 2) + (size_t)ty * TH) * in_row + (size_t)tx * TW * PIXB;
+  for (int q = tid; q < PH * PW * CPP; q += 256) {
+    const int p = q / CPP, c = q % CPP;
+    const int pr = p / PW, pc = p % PW;
+    const uint4 v = *reinterpret_cast<const uint4*>(xin + (size_t)pr * in_row + pc * PIXB + c * 16);
+    *reinterpret_cast<uint4*>(xs + p * PIXB + ((c ^ swz_pix<CIN>(p)) << 4)) = v;
+  }
+
+  const int cb0 = blockIdx.y * cb_per_block;
+  const int total = cb_per_block * NS;
+  const uint4* wsrc = reinterpret_cast<const uint4*>(a.Wp) + (size_t)cb0 * NS * 512;
+  uint4 pre0 = wsrc[tid], pre1 = wsrc[256 + tid];
+  reinterpret_cast<uint4*>(ws)[tid] = pre0;
+  reinterpret_cast<uint4*>(ws)[256 + tid] = pre1;
+  __syncthreads();
+
+  f32x4 acc[MR][4];
+  const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+  const int opad = a.out_pad;
+
+  for (int it = 0; it < total; ++it) {
+    const int s = it % NS;
+    if (s == 0) {
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (it + 1 < total) {
+      pre0 = wsrc[(size_t)(it + 1) * 512 + tid];
+      pre1 = wsrc[(size_t)(it + 1) * 512 + 256 + tid];
+    }
+    const int tap = s / (CIN / 64), cc = s % (CIN / 64);
+    const int dy = tap / 3, dx = tap % 3;
+    const char* wb = ws + (it & 1) * SLAB_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      typename P::vec8 af[4], bf[MR];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int rr = t * 16 + l15;
+        af[t] = lds_frag<P>(wb, rr * 128 + (((ks * 4 + g) ^ swz128(rr)) << 4));
+      }
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const int p = (wave * MR + m + dy) * PW + l15 + dx;
+        const int c = cc * 8 + ks * 4 + g;
+        bf[m] = lds_frag<P>(xs, p * PIXB + ((c ^ swz_pix<CIN>(p)) << 4));
+      }
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = P::mfma(af[t], bf[m], acc[m][t]);
+    }
+    if (it + 1 < total) {
+      char* wn = ws + ((it + 1) & 1) * SLAB_BYTES;
+      reinterpret_cast<uint4*>(wn)[tid] = pre0;
+      reinterpret_cast<uint4*>(wn)[256 + tid] = pre1;
+    }
+    if (s == NS - 1) {
+      // ---- epilogue for cout block cb: bias, ReLU, optional 2x2 max-pool, 16-byte stores
+      const int cb = cb0 + it / NS;
+      const size_t orow = (size_t)(Wo + 2 * opad) * COUT;
+      uint16_t* ybase = a.Y + (size_t)b * (Ho + 2 * opad) * orow;
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        const int co0 = cb * 64 + tp * 32 + g * 8;
+        float bias[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias[e] = a.bias[co0 + e];
+        if constexpr (!POOL) {
+#pragma unroll
+          for (int m = 0; m < MR; ++m) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = acc[m][2 * tp][e] + bias[e];
+              v[4 + e] = acc[m][2 * tp + 1][e] + bias[4 + e];
+            }
+            if (a.relu) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            const int y = ty * TH + wave * MR + m, x = tx * TW + l15;
+            *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * COUT + co0) = pack8<P>(v);
+          }
+        } else {
+#pragma unroll
+          for (int mp = 0; mp < MR / 2; ++mp) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = fmaxf(acc[2 * mp][2 * tp][e], acc[2 * mp + 1][2 * tp][e]);
+              v[4 + e] = fmaxf(acc[2 * mp][2 * tp + 1][e], acc[2 * mp + 1][2 * tp + 1][e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[e] = fmaxf(v[e], __shfl_xor(v[e], 1));
+              v[e] += bias[e];
+              if (a.relu) v[e] = fmaxf(v[e], 0.f);
+            }
+            if ((l15 & 1) == 0) {
+              const int y = (ty * TH + wave * MR) / 2 + mp, x = (tx * TW + l15) / 2;
+              *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * COUT + co0) = pack8<P>(v);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <class P, int CIN, int MR, bool POOL>
+static void conv_launch_t(const ConvArgs& a, hipStream_t st) {
+  constexpr int TH = 4 * MR;
+  constexpr int LDS = (TH + 2) * 18 * CIN * 2 + 2 * SLAB_BYTES;
+  static bool attr_done = false;
+  auto kfn = conv3x3_kernel<P, CIN, MR, POOL>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  const int tiles_x = a.W / 16, tiles_y = a.H / TH;
+  const int cbt = a.COUT / 64;
+  const long blocks = (long)tiles_x * tiles_y * a.B;
+  const int gy = (blocks >= 2048) ? 1 : cbt;
+  dim3 grid((unsigned)blocks, (unsigned)gy);
+  hipLaunchKernelGGL(kfn, grid, dim3(256), LDS, st, a, tiles_x, tiles_y, cbt / gy);
+}
+
+template <class P>
+static void conv_launch_p(const ConvArgs& a, hipStream_t st) {
+  if (a.CIN == 64) {
+    if (a.pool) conv_launch_t<P, 64, 4, true>(a, st); else conv_launch_t<P, 64, 4, false>(a, st);
+  } else {
+    if (a.pool) conv_launch_t<P, 128, 2, true>(a, st); else conv_launch_t<P, 128, 2, false>(a, st);
+  }
+}
+
+void launch_conv3x3(int prec, const ConvArgs& a, hipStream_t st) {
+  if (prec == 1) conv_launch_p<PF16>(a, st); else conv_launch_p<PBF16>(a, st);
+}
+
+// ================================================================================== dense GEMM
+template <class P>
+__device__ __forceinline__ void gemm_store_run(const GemmArgs& a, int row, int co0, float* v) {
+  // v[0..7] = features co0..co0+7 of row `row`, bias not yet added
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] += a.bias[co0 + e];
+  if (a.act == ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  switch (a.epi) {
+    case EPI_STORE: {
+      if (co0 < a.ldo)
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.out) + (size_t)row * a.ldo + co0) = pack8<P>(v);
+      break;
+    }
+    case EPI_STORE_F32: {
+      if (co0 < a.ldo) {
+        float* o = reinterpret_cast<float*>(a.out) + (size_t)row * a.ldo + co0;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      break;
+    }
+    case EPI_RESID: {
+      float* xr = a.x32 + (size_t)row * a.ldo + co0;
+      float4 r0 = *reinterpret_cast<float4*>(xr), r1 = *reinterpret_cast<float4*>(xr + 4);
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+      v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      *reinterpret_cast<float4*>(xr) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(xr + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.out) + (size_t)row * a.ldo + co0) = pack8<P>(v);
+      break;
+    }
+    case EPI_HEADS: {
+      const int s = row / a.Np, n = row - s * a.Np;
+      const int sel = co0 >> 8, cw = co0 & 255, h = cw >> 6, d = cw & 63;
+      if (a.rot_cos) {
+        const float4 c = *reinterpret_cast<const float4*>(a.rot_cos + (size_t)row * 32 + (d >> 1));
+        const float4 sn = *reinterpret_cast<const float4*>(a.rot_sin + (size_t)row * 32 + (d >> 1));
+        const float cs[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x0 = v[2 * i], x1 = v[2 * i + 1];
+          v[2 * i] = x0 * cs[i] - x1 * ss[i];
+          v[2 * i + 1] = x1 * cs[i] + x0 * ss[i];
+        }
+      }
+      uint16_t* o = reinterpret_cast<uint16_t*>(sel ? a.out2 : a.out) + (((size_t)s * a.H + h) * a.Np + n) * 64 + d;
+      *reinterpret_cast<uint4*>(o) = pack8<P>(v);
+      break;
+    }
+    default: break;
+  }
+}
+
+template <class P, int K, int MR, bool TRANS>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a, int cb_per_block) {
+  constexpr int BM = 64 * MR, ROWB = K * 2, CPR = K / 8, NS = K / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;
+  char* ws = smem + BM * ROWB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * BM;
+
+  for (int q = tid; q < BM * CPR; q += 256) {
+    const int r = q / CPR, c = q % CPR;
+    const int kk = c * 8;
+    const uint16_t* src = (kk < a.K1) ? a.X1 + (size_t)(m0 + r) * a.ld1 + kk
+                                      : a.X2 + (size_t)(m0 + r) * a.ld2 + (kk - a.K1);
+    const uint4 v = *reinterpret_cast<const uint4*>(src);
+    *reinterpret_cast<uint4*>(xs + r * ROWB + ((c ^ swz256(r)) << 4)) = v;
+  }
+
+  const int cb0 = blockIdx.y * cb_per_block;
+  const int total = cb_per_block * NS;
+  const uint4* wsrc = reinterpret_cast<const uint4*>(a.Wp) + (size_t)cb0 * NS * 512;
+  uint4 pre0 = wsrc[tid], pre1 = wsrc[256 + tid];
+  reinterpret_cast<uint4*>(ws)[tid] = pre0;
+  reinterpret_cast<uint4*>(ws)[256 + tid] = pre1;
+  __syncthreads();
+
+  f32x4 acc[MR][4];
+  for (int it = 0; it < total; ++it) {
+    const int s = it % NS;
+    if (s == 0) {
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (it + 1 < total) {
+      pre0 = wsrc[(size_t)(it + 1) * 512 + tid];
+      pre1 = wsrc[(size_t)(it + 1) * 512 + 256 + tid];
+    }
+    const char* wb = ws + (it & 1) * SLAB_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      typename P::vec8 wf[4], xf[MR];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int rr = t * 16 + l15;
+        wf[t] = lds_frag<P>(wb, rr * 128 + (((ks * 4 + g) ^ swz128(rr)) << 4));
+      }
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const int r = (wave * MR + m) * 16 + l15;
+        const int c = s * 8 + ks * 4 + g;
+        xf[m] = lds_frag<P>(xs, r * ROWB + ((c ^ swz256(r)) << 4));
+      }
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if constexpr (TRANS) acc[m][t] = P::mfma(xf[m], wf[t], acc[m][t]);
+          else acc[m][t] = P::mfma(wf[t], xf[m], acc[m][t]);
+        }
+    }
+    if (it + 1 < total) {
+      char* wn = ws + ((it + 1) & 1) * SLAB_BYTES;
+      reinterpret_cast<uint4*>(wn)[tid] = pre0;
+      reinterpret_cast<uint4*>(wn)[256 + tid] = pre1;
+    }
+    if (s == NS - 1) {
+      const int cb = cb0 + it / NS;
+      if constexpr (!TRANS) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          const int row = m0 + (wave * MR + m) * 16 + l15;
+#pragma unroll
+          for (int tp = 0; tp < 2; ++tp) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = acc[m][2 * tp][e];
+              v[4 + e] = acc[m][2 * tp + 1][e];
+            }
+            gemm_store_run<P>(a, row, cb * 64 + tp * 32 + g * 8, v);
+          }
+        }
+      } else {
+        // transposed store: lane (feature row l15 of tile t, g) holds tokens g*4..g*4+3 of m-tile m
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int co = cb * 64 + slab_row_to_feature(t * 16 + l15);
+          const float bv = a.bias[co];
+          const int h = co >> 6, d = co & 63;
+#pragma unroll
+          for (int m = 0; m < MR; ++m) {
+            const int row0 = m0 + (wave * MR + m) * 16 + g * 4;
+            const int sq = row0 / a.Np, n = row0 - sq * a.Np;
+            uint16_t* o = reinterpret_cast<uint16_t*>(a.out) + (((size_t)sq * a.H + h) * 64 + d) * a.Np + n;
+            *reinterpret_cast<uint2*>(o) = pack4<P>(acc[m][t][0] + bv, acc[m][t][1] + bv, acc[m][t][2] + bv, acc[m][t][3] + bv);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <class P, int K, int MR, bool TRANS>
+static void gemm_launch_t(const GemmArgs& a, hipStream_t st) {
+  constexpr int BM = 64 * MR;
+  constexpr int LDS = BM * K * 2 + 2 * SLAB_BYTES;
+  static bool attr_done = false;
+  auto kfn = gemm_kernel<P, K, MR, TRANS>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  const int mb = a.M / BM;
+  // split the feature blocks over grid.y when there are few row blocks, to fill 256 CUs
+  int gy = 1;
+  if (mb < 512) {
+    gy = a.cb_total;
+    while (gy > 1 && (long)mb * gy > 4096) gy >>= 1;
+    while (a.cb_total % gy) --gy;
+  }
+  dim3 grid((unsigned)mb, (unsigned)gy);
+  hipLaunchKernelGGL(kfn, grid, dim3(256), LDS, st, a, a.cb_total / gy);
+}
+
+template <class P>
+static void gemm_launch_p(int K, bool trans, const GemmArgs& a, hipStream_t st) {
+  if (K == 512) {
+    if (trans) gemm_launch_t<P, 512, 1, true>(a, st); else gemm_launch_t<P, 512, 1, false>(a, st);
+  } else if (K == 256) {
+    if (trans) gemm_launch_t<P, 256, 2, true>(a, st); else gemm_launch_t<P, 256, 2, false>(a, st);
+  } else {
+    if (trans) gemm_launch_t<P, 128, 2, true>(a, st); else gemm_launch_t<P, 128, 2, false>(a, st);
+  }
+}
+
+void launch_gemm(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st) {
+  if (prec == 1) gemm_launch_p<PF16>(K, trans, a, st); else gemm_launch_p<PBF16>(K, trans, a, st);
+}
+
+}  // namespace airfe

@@ -1,0 +1,138 @@
+/* airfe — C ABI of the MI355X-native per-frame front end (feature detect + match) for AirSLAM.
+ *
+ * This header is the drop-in boundary: every entry point names the reference interface it
+ * replaces (paths under the AirSLAM checkout).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - return value: 0 = ok, non-zero = failure (airfe_last_error() gives the text); never throws.
+ *   - one ctx = one HIP stream = one calling thread (the reference wrappers are not re-entrant either:
+ *     include/plnet.h:38-63, include/light_glue.h:39-47).
+ *   - feature rows are 259 contiguous floats [score, x, y, d0..d255]: byte-identical to one COLUMN of the
+ *     reference's column-major Eigen::Matrix<float,259,Dynamic> (include/feature_detector.h:8-31), so the
+ *     C++ shim does features.resize(259,n) + one memcpy.
+ *   - *_dev entry points take DEVICE pointers and an optional hipStream_t (NULL = the ctx stream); they are
+ *     asynchronous.  They have no reference counterpart (the reference is batch-1, host buffers only).
+ */
+#ifndef AIRFE_H_
+#define AIRFE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIRFE_FEAT_DIM 259
+#define AIRFE_INTERNAL_SIZE 512 /* reference resizes every image to 512x512: src/plnet.cpp:17-18,258 */
+
+typedef struct airfe_ctx airfe_ctx;
+
+/* Mirrors the knobs of PLNetConfig / SuperPointConfig / PointMatcherConfig (include/read_configs.h:9-103). */
+typedef struct airfe_cfg {
+  int device;                  /* HIP device ordinal */
+  int precision;               /* 0 = bf16 storage (default), 1 = fp16 storage; accumulation is always fp32 */
+  int max_batch;               /* images per detect batch / 2x pairs per match batch the arena is sized for */
+  int enc_chunk;               /* images per pass through the full-resolution conv layers (cache blocking) */
+  int max_keypoints;           /* plnet.max_keypoints        (<= 1024, light_glue.cpp:52) */
+  float keypoint_threshold;    /* plnet.keypoint_threshold */
+  int remove_borders;          /* plnet.remove_borders */
+  int nms_radius;              /* SuperPoint simple_nms radius inside the model graph (4 upstream; 0 = off) */
+  float line_threshold;        /* plnet.line_threshold */
+  float line_length_threshold; /* plnet.line_length_threshold */
+  int matcher;                 /* point_matcher.matcher: 0 = LightGlue, 1 = SuperGlue */
+  int image_width;             /* point_matcher.image_width / image_height (NormalizeKeypoints) */
+  int image_height;
+  int sinkhorn_iters;          /* SuperGlue: iterations baked into the exported graph (100 upstream) */
+  const char* superpoint_pack; /* weight packs (airslam_amd/weights.py format); NULL = that model is unavailable */
+  const char* plnet_s1_pack;
+  const char* lightglue_pack;
+  const char* superglue_pack;
+} airfe_cfg;
+
+void airfe_default_cfg(airfe_cfg* cfg);
+
+/* ≙ the build() calls made by FeatureDetector / PointMatcher constructors
+ *   (src/feature_detector.cc:7-34, src/point_matcher.cc:6-37): loads + packs weights, allocates the
+ *   persistent device arena (replaces the per-infer cudaMalloc of 3rdparty/tensorrtbuffer, buffers.h:253-271). */
+int airfe_create(const airfe_cfg* cfg, airfe_ctx** out);
+void airfe_destroy(airfe_ctx* ctx);
+const char* airfe_last_error(const airfe_ctx* ctx); /* ctx may be NULL (creation errors) */
+
+/* ≙ SuperPoint::infer (src/super_point.cpp:103-144).  gray: h x w uint8, `stride` bytes per row
+ *   (cv::Mat::step).  feat: caller buffer [cap][259]; *n receives the keypoint count (<= max_keypoints).
+ *   x,y are in ORIGINAL image pixels.  Fails (non-zero) on an empty image, like the reference returns false. */
+int airfe_detect_points(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int stride, float* feat, int cap, int* n);
+
+/* ≙ PLNet::infer (src/plnet.cpp:221-244).  Point branch as above.  Line branch: the stage-0 line tensors
+ *   (Appendix A.1 contract) are supplied by the caller because plnet_s0.onnx is absent from the reference
+ *   checkout; everything downstream of them (wireframe_matcher :272-307, stage-1 LOI head :468-514,
+ *   line/junction filter :519-558, junction_detector :425-448, rescale :569-582) runs on the device.
+ *   lines: [capL][4] doubles (x1,y1,x2,y2) original pixels (std::vector<Eigen::Vector4d> layout);
+ *   junc: [capJ][259].  stage0 may be NULL -> no lines/junctions (counts 0). */
+typedef struct airfe_plnet_stage0 {
+  const float* juncs_pred;          /* [300][2]        */
+  const float* lines_pred;          /* [3*128*128][4]  */
+  const float* iskeep;              /* [3*128*128]     */
+  const float* idx_junc_to_end_min; /* [3*128*128]     */
+  const float* idx_junc_to_end_max; /* [3*128*128]     */
+  const float* loi_features;        /* [128][128][128] CHW */
+  const float* loi_features_thin;   /* [4][128][128]   */
+  const float* loi_features_aux;    /* [4][128][128]   */
+} airfe_plnet_stage0;
+int airfe_detect_plnet(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int stride, const airfe_plnet_stage0* stage0,
+                       float* feat, int cap, int* n, double* lines, int capL, int* nlines, float* junc, int capJ,
+                       int* njunc, int want_junctions);
+
+/* ≙ SuperPointLightGlue::infer (src/light_glue.cpp:120-170).  f0/f1: [n][258] rows = (x,y already normalised by
+ *   PointMatcher::NormalizeKeypoints, d0..d255) — the contiguous temporary Eigen makes for bottomRows(258)
+ *   at src/point_matcher.cc:67.  idx: [cap][2] (row-major, ascending in idx0), score = exp(log score). */
+int airfe_match_lightglue(airfe_ctx* ctx, const float* f0, int n0, const float* f1, int n1, int32_t* idx, float* score,
+                          int cap, int* nmatch);
+
+/* ≙ SuperGlue::infer (src/super_glue.cpp:136-197).  f0/f1: [n][259] rows with normalised x,y.
+ *   idx0 [n0], idx1 [n1] (-1 = unmatched), ms0 [n0], ms1 [n1] doubles (decode, src/super_glue.cpp:339-367). */
+int airfe_match_superglue(airfe_ctx* ctx, const float* f0, int n0, const float* f1, int n1, int32_t* idx0, int32_t* idx1,
+                          double* ms0, double* ms1);
+
+/* ---- device-resident batch pipeline (NEW: no reference counterpart) ------------------------------------ */
+/* d_gray: [B] images, image b at d_gray + b*img_stride, rows `stride` bytes apart.  d_feat [B][cap][259], d_n [B]. */
+int airfe_detect_points_batch_dev(airfe_ctx* ctx, const uint8_t* d_gray, int B, int h, int w, int stride,
+                                  size_t img_stride, float* d_feat, int cap, int* d_n, void* stream);
+/* LightGlue on B pairs of device feature matrices (259-float rows, ORIGINAL pixel coords; NormalizeKeypoints with
+ *   cfg.image_width/height is applied on the device exactly as src/point_matcher.cc:39-48 does on the host).
+ *   d_idx [B][mcap][2], d_score [B][mcap], d_nmatch [B]. */
+int airfe_match_lightglue_batch_dev(airfe_ctx* ctx, const float* d_f0, const int* d_n0, const float* d_f1, const int* d_n1,
+                                    int B, int cap, int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, void* stream);
+/* One "stereo detect+match pair" x B (≙ map_builder.cc:85-86: Detect(L,R) + MatchingPoints(L,R)). */
+int airfe_stereo_batch_dev(airfe_ctx* ctx, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
+                           size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR,
+                           int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, void* stream);
+int airfe_sync(airfe_ctx* ctx);
+
+/* ---- per-stage hipEvent timers (measurement; SURVEY.md §5 "tracing") ----------------------------------- */
+/* enable/disable + reset; while enabled every kernel group is bracketed by events on its launch stream */
+int airfe_profile_enable(airfe_ctx* ctx, int on);
+int airfe_profile_stages(void);
+const char* airfe_profile_stage_name(int i);
+/* synchronises, then sums per stage: elapsed ms, algorithmic FLOPs, algorithmic bytes, launch groups; resets */
+int airfe_profile_read(airfe_ctx* ctx, double* ms, double* flops, double* bytes, int* launches);
+
+/* ---- inspection hooks used by the parity tests ------------------------------------------------------ */
+/* after a detect call with B images: copy internal maps to HOST buffers (NULL = skip).
+ *   heat_raw/heat_nms [B][512][512]; desc [B][64][64][256] (NHWC, channel-normalised). */
+int airfe_debug_detector_maps(airfe_ctx* ctx, int B, float* heat_raw, float* heat_nms, float* desc);
+/* run LightGlue on one HOST pair (258-float rows) and return the full log-assignment scores [n0][n1] */
+int airfe_debug_lightglue_scores(airfe_ctx* ctx, const float* f0, int n0, const float* f1, int n1, float* scores);
+/* kernel-level checks on HOST fp32 tensors (test only): NCHW conv3x3(+ReLU, optional 2x2 max-pool) and
+ *   y[M][N] = x[M][K] w[N][K]^T + b through the same MFMA kernels the pipelines use. */
+/* the pre-process alone (cv::resize + /255, src/plnet.cpp:246-270): HOST gray image -> HOST fp32 [512][512] */
+int airfe_debug_preprocess(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int stride, float* out);
+int airfe_debug_conv3x3(airfe_ctx* ctx, const float* x, int B, int cin, int H, int W, const float* w, const float* b,
+                        int cout, int pool, float* y);
+int airfe_debug_gemm(airfe_ctx* ctx, const float* x, int M, int K, const float* w, const float* b, int N, int relu, float* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIRFE_H_ */

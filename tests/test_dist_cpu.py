@@ -1,0 +1,71 @@
+"""world_size-2 gloo test of the only exchange on the path: the match gather to rank 0."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from airslam_amd import dist as adist
+    r, w, _ = adist.init_from_env("gloo")
+    rng = np.random.default_rng(rank)
+    b, cap = 3, 16
+    nm = torch.tensor(rng.integers(0, cap, b), dtype=torch.int32)
+    idx = torch.tensor(rng.integers(0, 400, (b, cap, 2)), dtype=torch.int32)
+    sc = torch.tensor(rng.random((b, cap)), dtype=torch.float32)
+    out = adist.gather_matches(idx, sc, nm, dst=0)
+    lo, hi = adist.shard_range(10, r, w)
+    mx = adist.max_over_ranks(float(rank + 1), torch.device("cpu"))
+    if r == 0:
+        gi, gs, gn = out
+        q.put((gi.numpy(), gs.numpy(), gn.numpy(), (lo, hi), mx))
+    else:
+        assert out is None
+        q.put(((lo, hi), mx))
+    torch.distributed.destroy_process_group()
+
+
+def test_gather_matches_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = [r for r in res if len(r) == 5][0]
+    other = [r for r in res if len(r) == 2][0]
+    gi, gs, gn, rng0, mx = full
+    assert gi.shape == (6, 16, 2) and gs.shape == (6, 16) and gn.shape == (6,)
+    for rank in range(2):
+        rng = np.random.default_rng(rank)
+        nm = rng.integers(0, 16, 3); idx = rng.integers(0, 400, (3, 16, 2)); sc = rng.random((3, 16)).astype(np.float32)
+        np.testing.assert_array_equal(gn[rank * 3:(rank + 1) * 3], nm)
+        np.testing.assert_array_equal(gi[rank * 3:(rank + 1) * 3], idx)
+        np.testing.assert_array_equal(gs[rank * 3:(rank + 1) * 3], sc)
+    assert rng0 == (0, 5) and other[0] == (5, 10) and mx == 2.0 and other[1] == 2.0
+
+
+def test_shard_range_covers_everything():
+    from airslam_amd import dist as adist
+    for n in (1, 7, 8, 64, 200):
+        for w in (1, 2, 4, 8):
+            spans = [adist.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

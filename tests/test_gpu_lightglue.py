@@ -1,0 +1,106 @@
+"""LightGlue parity on the GPU (C ABI) vs the CPU oracle; filter_matches is checked bit-exact on the device's
+own score matrix."""
+import numpy as np
+import pytest
+
+from gpu_common import context, diag
+from oracle import ref_nets, ref_post
+
+pytestmark = pytest.mark.gpu
+
+
+def _features(n, seed, w=752, h=480):
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 256)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    xy = np.stack([rng.uniform(4, w - 4, n), rng.uniform(4, h - 4, n)], 1).astype(np.float32)
+    f = np.zeros((n, 259), np.float32)
+    f[:, 0] = rng.uniform(0.01, 1, n)
+    f[:, 1:3] = xy
+    f[:, 3:] = d
+    return f
+
+
+def _pair(n0, n1, seed):
+    f0 = _features(n0, seed)
+    f1 = _features(n1, seed + 1)
+    k = min(n0, n1) // 2                      # plant true correspondences so that matches exist
+    rng = np.random.default_rng(seed + 2)
+    f1[:k, 3:] = f0[:k, 3:] + 0.05 * rng.normal(size=(k, 256)).astype(np.float32)
+    f1[:k, 3:] /= np.linalg.norm(f1[:k, 3:], axis=1, keepdims=True)
+    f1[:k, 1] = f0[:k, 1] - 12
+    f1[:k, 2] = f0[:k, 2]
+    n0f = ref_post.normalize_keypoints(f0, 752, 480, 0.5)
+    n1f = ref_post.normalize_keypoints(f1, 752, 480, 0.5)
+    return f0, f1, np.ascontiguousarray(n0f[:, 1:]), np.ascontiguousarray(n1f[:, 1:])
+
+
+@pytest.mark.parametrize("n0,n1", [(400, 400), (317, 400), (64, 65), (1, 5), (2, 1)])
+def test_lightglue_scores_vs_oracle(n0, n1):
+    ctx, _, lg = context("lg", max_batch=4)
+    _, _, a, b = _pair(n0, n1, n0 * 3 + n1)
+    s = ctx.lightglue_scores(a, b)
+    ref = ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
+    err = np.abs(s - ref)
+    idx, sc = ctx.match_lightglue(a, b)
+    ridx, rsc = ref_post.filter_matches(ref, 0.1)
+    # filter_matches on the DEVICE scores must be reproduced exactly (index work)
+    didx, dsc = ref_post.filter_matches(s, 0.1)
+    agree = len(set(map(tuple, idx)) & set(map(tuple, ridx))) / max(len(ridx), 1)
+    diag(f"lg_scores_{n0}_{n1}", max_err=err.max(), mean_err=err.mean(), ref_absmax=np.abs(ref).max(), n_dev=len(idx),
+         n_ref=len(ridx), match_agreement=agree, nan=int(np.isnan(s).sum()))
+    assert not np.isnan(s).any()
+    np.testing.assert_array_equal(idx, didx)
+    np.testing.assert_allclose(sc, dsc, rtol=2e-6)
+    assert err.max() <= 0.05 * max(1.0, np.abs(ref).mean()), "log-assignment scores drifted from the fp32 oracle"
+    if len(ridx) >= 10:
+        assert agree >= 0.9
+
+
+def test_lightglue_layer_states_drift():
+    """Where precision goes: score error with 1, 3, 9 layers (diagnostic, loose bound)."""
+    from airslam_amd import weights
+    from airslam_amd import api
+    _, _, a, b = _pair(200, 180, 77)
+    out = {}
+    for L in (1, 3):
+        w = weights.synthetic_lightglue(1234, n_layers=L)
+        ctx = api.Context(lightglue=w, max_batch=2)
+        s = ctx.lightglue_scores(a, b)
+        ref = ref_nets.lightglue_forward(w, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:], n_layers=L)
+        out[f"L{L}_max_err"] = float(np.abs(s - ref).max())
+        ctx.close()
+    diag("lg_layers", **out)
+    assert out["L1_max_err"] < 0.05
+
+
+def test_match_batch_dev_equals_host_path():
+    import torch
+    from airslam_amd import api
+    ctx, _, lg = context("lg", max_batch=4)
+    pairs = [_pair(400, 380, 5), _pair(120, 400, 9)]
+    f0 = torch.zeros((2, 400, 259)); f1 = torch.zeros((2, 400, 259))
+    n0 = torch.tensor([400, 120], dtype=torch.int32); n1 = torch.tensor([380, 400], dtype=torch.int32)
+    for i, (a, b, _, _) in enumerate(pairs):
+        f0[i, :a.shape[0]] = torch.from_numpy(a); f1[i, :b.shape[0]] = torch.from_numpy(b)
+    f0, f1, n0, n1 = f0.cuda(), f1.cuda(), n0.cuda(), n1.cuda()
+    idx = torch.zeros((2, 400, 2), dtype=torch.int32, device="cuda")
+    sc = torch.zeros((2, 400), dtype=torch.float32, device="cuda")
+    nm = torch.zeros((2,), dtype=torch.int32, device="cuda")
+    ctx.match_lightglue_batch_dev(f0, n0, f1, n1, idx, sc, nm)
+    ctx.sync()
+    pm = api.PointMatcher(ctx, 752, 480, 0)
+    for i, (a, b, _, _) in enumerate(pairs):
+        cnt, matches = pm.MatchingPoints(np.asfortranarray(a.T), np.asfortranarray(b.T))
+        k = int(nm[i])
+        assert k == cnt
+        got = idx[i, :k].cpu().numpy()
+        assert [tuple(g) for g in got] == [(m[0], m[1]) for m in matches]
+        np.testing.assert_allclose(1.0 - sc[i, :k].cpu().numpy(), [m[2] for m in matches], atol=1e-6)
+
+
+def test_matching_points_early_out():
+    from airslam_amd import api
+    ctx, _, _ = context("lg", max_batch=4)
+    pm = api.PointMatcher(ctx, 752, 480, 0)
+    assert pm.MatchingPoints(np.zeros((259, 0), np.float32), np.zeros((259, 7), np.float32)) == (0, [])

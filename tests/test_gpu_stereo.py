@@ -1,0 +1,54 @@
+"""The benchmarked unit: B stereo pairs = 2x detect + 1x LightGlue match, device-resident (airfe_stereo_batch_dev)."""
+import numpy as np
+import pytest
+
+from airslam_amd import synth
+from gpu_common import context, diag
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stereo_batch_consistent_with_single_calls():
+    import torch
+    from airslam_amd import api
+    ctx, _, _ = context("splg", max_batch=4, enc_chunk=2)
+    B = 3
+    ls, rs = synth.stereo_batch(B, 480, 752, 21)
+    L, R = torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda()
+    fl = torch.zeros((B, 400, 259), device="cuda"); fr = torch.zeros((B, 400, 259), device="cuda")
+    nl = torch.zeros((B,), dtype=torch.int32, device="cuda"); nr = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    idx = torch.zeros((B, 400, 2), dtype=torch.int32, device="cuda")
+    sc = torch.zeros((B, 400), device="cuda"); nm = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    ctx.stereo_batch_dev(L, R, fl, fr, nl, nr, idx, sc, nm)
+    ctx.sync()
+    det, pm = api.FeatureDetector(ctx), api.PointMatcher(ctx, 752, 480, 0)
+    counts = []
+    for b in range(B):
+        ok, f0, f1 = det.DetectStereo(ls[b], rs[b])
+        assert ok
+        np.testing.assert_array_equal(fl[b, :f0.shape[1]].cpu().numpy(), f0.T)
+        np.testing.assert_array_equal(fr[b, :f1.shape[1]].cpu().numpy(), f1.T)
+        cnt, matches = pm.MatchingPoints(f0, f1)
+        k = int(nm[b])
+        counts.append((int(nl[b]), int(nr[b]), k))
+        assert k == cnt
+        assert [tuple(g) for g in idx[b, :k].cpu().numpy()] == [(m[0], m[1]) for m in matches]
+    diag("stereo_counts", counts=str(counts))
+
+
+def test_stereo_is_deterministic():
+    import torch
+    ctx, _, _ = context("splg", max_batch=4, enc_chunk=2)
+    ls, rs = synth.stereo_batch(2, 480, 752, 33)
+    L, R = torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda()
+    outs = []
+    for _ in range(2):
+        fl = torch.zeros((2, 400, 259), device="cuda"); fr = torch.zeros((2, 400, 259), device="cuda")
+        nl = torch.zeros((2,), dtype=torch.int32, device="cuda"); nr = torch.zeros((2,), dtype=torch.int32, device="cuda")
+        idx = torch.zeros((2, 400, 2), dtype=torch.int32, device="cuda")
+        sc = torch.zeros((2, 400), device="cuda"); nm = torch.zeros((2,), dtype=torch.int32, device="cuda")
+        ctx.stereo_batch_dev(L, R, fl, fr, nl, nr, idx, sc, nm)
+        ctx.sync()
+        outs.append((fl.cpu().numpy(), idx.cpu().numpy(), nm.cpu().numpy()))
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)

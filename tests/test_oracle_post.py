@@ -1,0 +1,173 @@
+"""The numpy restatements of the reference's CPU routines against slow literal transcriptions of the C++ loops
+(small sizes) and against their defining properties."""
+import numpy as np
+import pytest
+
+from oracle import ref_post as rp
+
+
+def _detect_point_loops(heat, thr, border, top_k):
+    """Literal transcription of src/plnet.cpp:309-355 with the SURVEY B.1 tie rule."""
+    h, w = heat.shape
+    cand = []
+    for i in range(h * w):
+        s = heat.flat[i]
+        if s < np.float32(thr):
+            continue
+        y = i // w
+        x = i - y * w
+        if x < border or x > w - border or y < border or y > h - border:
+            continue
+        cand.append((float(s), i, x, y))
+    if len(cand) > top_k:
+        cand.sort(key=lambda c: (-c[0], c[1]))
+        cand = cand[:top_k]
+    return (np.array([c[0] for c in cand], np.float32), np.array([c[2] for c in cand], np.float32),
+            np.array([c[3] for c in cand], np.float32))
+
+
+@pytest.mark.parametrize("seed,top_k", [(0, 50), (1, 5000), (2, 1)])
+def test_detect_point(seed, top_k):
+    rng = np.random.default_rng(seed)
+    heat = (rng.random((40, 48)) ** 6).astype(np.float32)
+    heat[5, 7] = heat[9, 9] = heat[20, 30] = 0.9          # exact ties
+    a = rp.detect_point(heat, 0.05, 4, top_k)
+    b = _detect_point_loops(heat, 0.05, 4, top_k)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+
+
+def test_detect_point_border_inclusive_upper():
+    heat = np.zeros((32, 32), np.float32)
+    heat[28, 28] = 1.0      # x == w - border -> kept (upper bound inclusive, plnet.cpp:332)
+    heat[29, 10] = 1.0      # y > h - border -> dropped
+    heat[3, 10] = 1.0       # y < border -> dropped
+    s, x, y = rp.detect_point(heat, 0.5, 4, 10)
+    assert list(zip(x, y)) == [(28.0, 28.0)]
+
+
+def test_extract_descriptors_matches_loops():
+    rng = np.random.default_rng(3)
+    d = rng.normal(size=(256, 8, 8)).astype(np.float32)
+    xs = np.array([0, 5, 31.0, 63, 62, 17], np.float32)
+    ys = np.array([0, 63, 2.0, 63, 1, 40], np.float32)
+    out = rp.extract_descriptors(d, xs, ys, 8)
+    # literal loop (double precision reference of the same formula) for a loose cross-check
+    h = w = 8
+    s = 8
+    for j in range(len(xs)):
+        sx = 2.0 / (w * s - s // 2 - 0.5); bx = (1 - s) / (w * s - s // 2 - 0.5) - 1
+        ix = ((xs[j] * sx + bx) + 1) * 0.5 * (w - 1)
+        iy = ((ys[j] * sx + bx) + 1) * 0.5 * (h - 1)
+        x0 = min(max(int(np.floor(ix)), 0), w - 1); y0 = min(max(int(np.floor(iy)), 0), h - 1)
+        x1 = min(x0 + 1, w - 1); y1 = min(y0 + 1, h - 1)
+        v = (d[:, y0, x0] * (x1 - ix) * (y1 - iy) + d[:, y0, x1] * (ix - x0) * (y1 - iy)
+             + d[:, y1, x0] * (x1 - ix) * (iy - y0) + d[:, y1, x1] * (ix - x0) * (iy - y0))
+        n = np.linalg.norm(v)
+        if n > 0:
+            np.testing.assert_allclose(out[j], v / n, atol=2e-5)
+    # far edge (ix == w-1): clamped neighbours collapse every weight to 0 -> 0/0, exactly as the C++ would
+    # (SURVEY.md B.2); with remove_borders >= 1 at 512x512 this never happens in the pipeline
+    edge = np.array([False, True, False, True, False, False])
+    assert np.isnan(out[edge]).all()
+    assert np.allclose(np.linalg.norm(out[~edge], axis=1), 1, atol=1e-5)
+
+
+def test_resize_identity_and_range():
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, size=(512, 512), dtype=np.uint8)
+    np.testing.assert_array_equal(rp.resize_linear_u8(img, 512, 512), img)
+    src = rng.integers(0, 256, size=(480, 752), dtype=np.uint8)
+    out = rp.resize_linear_u8(src, 512, 512)
+    assert out.shape == (512, 512) and out.dtype == np.uint8
+    const = np.full((480, 752), 137, np.uint8)
+    np.testing.assert_array_equal(rp.resize_linear_u8(const, 512, 512), np.full((512, 512), 137, np.uint8))
+    # within +-1 grey level of float bilinear interpolation with half-pixel centres
+    yy = np.clip((np.arange(512) + 0.5) * 480 / 512 - 0.5, 0, 479); xx = np.clip((np.arange(512) + 0.5) * 752 / 512 - 0.5, 0, 751)
+    y0 = np.floor(yy).astype(int); x0 = np.floor(xx).astype(int)
+    y1 = np.minimum(y0 + 1, 479); x1 = np.minimum(x0 + 1, 751)
+    fy = (yy - y0)[:, None]; fx = (xx - x0)[None, :]
+    s = src.astype(np.float64)
+    ref = (s[y0][:, x0] * (1 - fx) + s[y0][:, x1] * fx) * (1 - fy) + (s[y1][:, x0] * (1 - fx) + s[y1][:, x1] * fx) * fy
+    assert np.abs(out.astype(np.float64) - ref).max() <= 1.0
+
+
+def test_wireframe_matcher_matches_loops():
+    rng = np.random.default_rng(5)
+    n = 3 * 16 * 16
+    iskeep = (rng.random(n) < 0.2).astype(np.float32)
+    a = rng.integers(0, 12, n); b = rng.integers(0, 12, n)
+    mn, mx = np.minimum(a, b).astype(np.float32), np.maximum(a, b).astype(np.float32)
+    keep, inv, pairs = rp.wireframe_matcher(iskeep, mn, mx)
+    # literal transcription of src/plnet.cpp:272-307
+    k2 = [i for i in range(n) if iskeep[i] > 0]
+    table = {}
+    inv2 = []
+    for i in k2:
+        key = (int(mn[i]), int(mx[i]))
+        if key not in table:
+            table[key] = len(table) + 1
+        inv2.append(table[key] - 1)
+    pairs2 = [None] * len(table)
+    for (x, y), v in table.items():
+        pairs2[v - 1] = (y, x)
+    np.testing.assert_array_equal(keep, k2)
+    np.testing.assert_array_equal(inv, inv2)
+    np.testing.assert_array_equal(pairs, np.array(pairs2))
+
+
+def test_filter_matches_matches_loops():
+    rng = np.random.default_rng(6)
+    sc = np.log(rng.random((37, 29)).astype(np.float32) ** 3 + 1e-9).astype(np.float32)
+    sc[3, 4] = sc[3, 9] = 0.0          # tie in a row: first column wins
+    idx, val = rp.filter_matches(sc, 0.1)
+    # literal transcription of src/light_glue.cpp:214-266
+    rmax = []
+    for r in range(sc.shape[0]):
+        best, bc = -np.inf, 0
+        for c in range(sc.shape[1]):
+            if sc[r, c] > best:
+                best, bc = sc[r, c], c
+        rmax.append((bc, best))
+    cmax = []
+    for c in range(sc.shape[1]):
+        best, br = -np.inf, 0
+        for r in range(sc.shape[0]):
+            if sc[r, c] > best:
+                best, br = sc[r, c], r
+        cmax.append(br)
+    exp = [(r, rmax[r][0], np.exp(np.float32(rmax[r][1]))) for r in range(sc.shape[0])
+           if cmax[rmax[r][0]] == r and np.exp(np.float32(rmax[r][1])) > 0.1]
+    assert [tuple(i) for i in idx] == [(e[0], e[1]) for e in exp]
+    np.testing.assert_allclose(val, [e[2] for e in exp], rtol=1e-6)
+    assert np.all(np.diff(idx[:, 0]) > 0)
+
+
+def test_superglue_decode_properties():
+    rng = np.random.default_rng(7)
+    z = np.log(rng.random((21, 18)).astype(np.float32) + 1e-6).astype(np.float32)
+    i0, i1, m0, m1 = rp.superglue_decode(z)
+    assert i0.shape == (20,) and i1.shape == (17,)
+    for i, j in enumerate(i0):
+        if j >= 0:
+            assert i1[j] == i and m0[i] > 0.2
+    assert np.all((i0 >= -1) & (i0 < 17))
+
+
+def test_sinkhorn_marginals():
+    rng = np.random.default_rng(8)
+    s = rng.normal(size=(12, 9)).astype(np.float32)
+    z = rp.log_optimal_transport(s, 1.0, 100)
+    p = np.exp(z.astype(np.float64))
+    # rows of the coupling sum to the prescribed marginals (x (m+n) after the -norm shift)
+    np.testing.assert_allclose(p[:12].sum(1), 1.0, atol=1e-3)
+    np.testing.assert_allclose(p[:, :9].sum(0), 1.0, atol=1e-3)
+
+
+def test_normalize_keypoints_integer_halves():
+    f = np.zeros((3, 259), np.float32)
+    f[:, 1] = [0, 376, 751]; f[:, 2] = [0, 240, 479]
+    o = rp.normalize_keypoints(f, 752, 480, 0.5)
+    linv = np.float32(1.0 / 752 * 0.5)
+    np.testing.assert_array_equal(o[:, 1], (f[:, 1] - 376) * linv)
+    np.testing.assert_array_equal(o[:, 2], (f[:, 2] - 240) * linv)
