@@ -289,7 +289,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restri
     if (k && (take_all || k >= T)) {
       const unsigned slot = atomicAdd(&s_cnt, 1u);
       if (slot < 1024) {
-        if (take_all) sk[slot] = ((u64)i << 32) | (u64)(unsigned)((k >> 18) & 0xFFFFFFFFull);   // ascending raster
+        if (take_all) sk[slot] = ((u64)i << 32) | (u64)(unsigned)((k >> 18) & 0x7FFFFFFFull);   // ascending raster
         else sk[slot] = ~k;                                                                    // descending key
       }
     }
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restri
     int idx;
     unsigned sb;
     if (take_all) { idx = (int)(e >> 32); sb = (unsigned)(e & 0xFFFFFFFFull); }
-    else { const u64 k = ~e; idx = 0x3FFFF - (int)(k & 0x3FFFFull); sb = (unsigned)((k >> 18) & 0xFFFFFFFFull); }
+    else { const u64 k = ~e; idx = 0x3FFFF - (int)(k & 0x3FFFFull); sb = (unsigned)((k >> 18) & 0x7FFFFFFFull); }
     const int y = idx / W, x = idx - y * W;
     float* f = feat + ((size_t)b * cap + tid) * 259;
     f[0] = __uint_as_float(sb);

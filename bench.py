@@ -29,7 +29,7 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp):
     the host cores, on a bounded sample of the same workload."""
     from airslam_amd import synth
     from oracle import ref_nets, ref_post
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads than this only adds sync overhead at batch 1
     t0 = time.perf_counter()
     for i in range(n_pairs):
         left, right = synth.stereo_pair(h, w, 100 + i)

@@ -48,7 +48,22 @@ def test_detector_network_vs_oracle():
     diag("detector_maps", heat_max_err=herr.max(), heat_mean_err=herr.mean(), heat_max=oh.max(), desc_cos_max=cd.max(),
          desc_cos_mean=cd.mean(), n_kpts=feat.shape[0], heat_sum_dev=float(heat[0].sum()), heat_sum_ref=float(oh.sum()))
     assert cd.max() <= 1e-3, "dense descriptors: cosine distance above the north-star tolerance"
-    assert herr.max() <= 0.02 * max(oh.max(), 1e-3) + 2e-3
+    # heat = softmax of logits of magnitude ~10: a 2-byte activation error d shows up as a RELATIVE heat error ~d.
+    # bf16 (8-bit mantissa) is allowed 5 % of the peak here; fp16 storage (test below) must be ~8x tighter.
+    assert herr.max() <= 0.05 * max(oh.max(), 1e-3) + 2e-3
+
+
+def test_detector_network_fp16_storage_is_tighter():
+    ctx, sp, _ = context("sp", precision=1, **CFG)
+    img = synth.gabor_image(480, 752, 0)
+    ctx.detect_points(img)
+    heat, nms, desc = ctx.detector_maps(1)
+    oh, od, ws, hs = _oracle_maps(sp, img)
+    herr = np.abs(heat[0] - oh)
+    cd = cosine_dist(desc[0].reshape(-1, 256), od.transpose(1, 2, 0).reshape(-1, 256))
+    diag("detector_maps_fp16", heat_max_err=herr.max(), heat_mean_err=herr.mean(), desc_cos_max=cd.max())
+    assert cd.max() <= 1e-4
+    assert herr.max() <= 0.01 * max(oh.max(), 1e-3) + 1e-3
 
 
 def test_nms_and_decode_bit_exact_on_device_maps():
