@@ -118,6 +118,65 @@ class Context:
                                                        out.ctypes.data), "airfe_debug_lightglue_scores")
         return out
 
+    @staticmethod
+    def _stage0(s0):
+        """dict of numpy arrays (synth.plnet_stage0_lines layout) -> (_lib.Stage0, keep-alive list)"""
+        st = _lib.Stage0()
+        keep = []
+        for name, _ in _lib.Stage0._fields_:
+            a = np.ascontiguousarray(s0[name], dtype=np.float32)
+            keep.append(a)
+            setattr(st, name, a.ctypes.data)
+        return st, keep
+
+    def detect_plnet(self, gray: np.ndarray, stage0=None, want_junctions: bool = False, cap_lines: int = 16384,
+                     cap_junc: int = 2048):
+        """≙ PLNet::infer -> (feat [n,259], lines [L,4] float64, junctions [K,259])."""
+        gray = np.asarray(gray)
+        if gray.ndim != 2 or gray.dtype != np.uint8 or gray.size == 0:
+            raise AirfeError("empty image")
+        if gray.strides[1] != 1:
+            gray = np.ascontiguousarray(gray)
+        cap = self.np_rows
+        feat = np.empty((cap, FEAT), np.float32)
+        lines = np.empty((cap_lines, 4), np.float64)
+        junc = np.empty((cap_junc, FEAT), np.float32)
+        n, nl, nj = C.c_int(0), C.c_int(0), C.c_int(0)
+        st, keep = (self._stage0(stage0) if stage0 is not None else (None, None))
+        self._chk(self._l.airfe_detect_plnet(self._h, gray.ctypes.data, gray.shape[0], gray.shape[1], gray.strides[0],
+                                             C.byref(st) if st is not None else None, feat.ctypes.data, cap, C.byref(n),
+                                             lines.ctypes.data, cap_lines, C.byref(nl), junc.ctypes.data, cap_junc,
+                                             C.byref(nj), int(want_junctions)), "airfe_detect_plnet")
+        return feat[:n.value].copy(), lines[:nl.value].copy(), junc[:nj.value].copy()
+
+    def debug_plnet_s1(self, stage0, cap: int = 16384):
+        st, keep = self._stage0(stage0)
+        la = np.empty((cap, 4), np.float32)
+        sc = np.empty((cap,), np.float32)
+        m2 = C.c_int(0)
+        self._chk(self._l.airfe_debug_plnet_s1(self._h, C.byref(st), la.ctypes.data, sc.ctypes.data, cap, C.byref(m2)),
+                  "airfe_debug_plnet_s1")
+        return la[:m2.value].copy(), sc[:m2.value].copy()
+
+    def match_superglue(self, f0: np.ndarray, f1: np.ndarray):
+        """f0/f1: [n, 259] rows (score, normalised x, y, desc) -> (indices0, indices1, mscores0, mscores1)."""
+        f0 = np.ascontiguousarray(f0, dtype=np.float32)
+        f1 = np.ascontiguousarray(f1, dtype=np.float32)
+        i0 = np.empty((f0.shape[0],), np.int32); i1 = np.empty((f1.shape[0],), np.int32)
+        m0 = np.empty((f0.shape[0],), np.float64); m1 = np.empty((f1.shape[0],), np.float64)
+        self._chk(self._l.airfe_match_superglue(self._h, f0.ctypes.data, f0.shape[0], f1.ctypes.data, f1.shape[0],
+                                                i0.ctypes.data, i1.ctypes.data, m0.ctypes.data, m1.ctypes.data),
+                  "airfe_match_superglue")
+        return i0, i1, m0, m1
+
+    def superglue_scores(self, f0: np.ndarray, f1: np.ndarray) -> np.ndarray:
+        f0 = np.ascontiguousarray(f0, dtype=np.float32)
+        f1 = np.ascontiguousarray(f1, dtype=np.float32)
+        out = np.empty((f0.shape[0] + 1, f1.shape[0] + 1), dtype=np.float32)
+        self._chk(self._l.airfe_debug_superglue_scores(self._h, f0.ctypes.data, f0.shape[0], f1.ctypes.data, f1.shape[0],
+                                                       out.ctypes.data), "airfe_debug_superglue_scores")
+        return out
+
     def detector_maps(self, b: int = 1):
         heat = np.empty((b, 512, 512), np.float32)
         nms = np.empty((b, 512, 512), np.float32)
@@ -209,6 +268,17 @@ class FeatureDetector:
             return False, np.zeros((FEAT, 0), np.float32, order="F")
         return True, np.asfortranarray(f.T)
 
+    def DetectLines(self, image: np.ndarray, stage0, lines: list, junction_detection: bool = False):
+        """Detect(image, features, lines[, junctions]) (feature_detector.cc:52-69) -> (ok, features, junctions).
+        `lines` is APPENDED to, never cleared — exactly like the reference (plnet.cpp:544)."""
+        try:
+            f, l, j = self._ctx.detect_plnet(image, stage0, want_junctions=junction_detection)
+        except (AirfeError, TypeError):
+            print("Failed when extracting point features !")
+            return False, np.zeros((FEAT, 0), np.float32, order="F"), np.zeros((FEAT, 0), np.float32, order="F")
+        lines.extend(tuple(r) for r in l)
+        return True, np.asfortranarray(f.T), np.asfortranarray(j.T)
+
     def DetectStereo(self, left: np.ndarray, right: np.ndarray):
         okl, fl = self.Detect(left)
         okr, fr = self.Detect(right)
@@ -246,5 +316,9 @@ class PointMatcher:
             idx, sc = self._ctx.match_lightglue(np.ascontiguousarray(n0[1:].T), np.ascontiguousarray(n1[1:].T))
             matches = [(int(i), int(j), float(np.float32(1.0) - s)) for (i, j), s in zip(idx, sc)]
         else:
-            raise AirfeError("SuperGlue matcher is not available in this build")
+            i0, i1, m0, m1 = self._ctx.match_superglue(np.ascontiguousarray(n0.T), np.ascontiguousarray(n1.T))
+            matches = []
+            for i in range(len(i0)):                              # point_matcher.cc:82-91
+                if 0 <= i0[i] < len(i1) and i1[i0[i]] == i:
+                    matches.append((i, int(i0[i]), float(np.float32(1.0 - (m0[i] + m1[i0[i]]) / 2.0))))
         return len(matches), matches

@@ -141,6 +141,10 @@ struct LgLayer {
   LinW qk, v, out, ffn0, ffn3, cqk, cv, cout, cffn0, cffn3;
   float *ln_g = nullptr, *ln_b = nullptr, *cln_g = nullptr, *cln_b = nullptr;
 };
+struct SgLayer { LinW qk, v, merge, mlp0, mlp3; };
+constexpr int LINE_CAP = 16384;     // unique candidate lines per image (the reference's TensorRT profile allows 50000)
+constexpr int KEEP_CAP = 3 * 128 * 128;
+constexpr int JUNC_CAP = 2048;
 
 }  // namespace
 
@@ -182,6 +186,27 @@ struct airfe_ctx {
   uint16_t *xb = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *ob = nullptr, *msg = nullptr, *hb = nullptr,
            *mdb = nullptr;
   int *lens = nullptr, *rowarg = nullptr, *colarg = nullptr;
+  bool has_arena = false;
+
+  // SuperGlue
+  bool has_sg = false;
+  std::vector<SgLayer> sg;
+  LinW sg_final;
+  float sg_alpha = 1.f;
+  const float* sg_kenc[10] = {nullptr};
+  int Lz = 0;
+  float *sg_u = nullptr, *sg_v = nullptr, *sg_Z = nullptr, *sg_max0 = nullptr, *sg_ms0 = nullptr, *sg_ms1 = nullptr;
+  int *sg_idx0 = nullptr, *sg_idx1 = nullptr;
+  int32_t *sg_out0 = nullptr, *sg_out1 = nullptr;
+
+  // PLNet stage 1 + line path
+  bool has_s1 = false;
+  const float* s1_w[11] = {nullptr};
+  int *wf_table = nullptr, *wf_keep = nullptr, *wf_pairs = nullptr, *wf_rep = nullptr, *wf_counts = nullptr;
+  float *s1_la = nullptr, *s1_sc = nullptr, *s0_stage = nullptr, *junc_feat = nullptr;
+  unsigned char* jmap = nullptr;
+  double* d_lines = nullptr;
+  int *d_nlines = nullptr, *d_njunc = nullptr;
 
   // per-stage hipEvent timers (airfe_profile_*): events are recorded on the launch stream only
   struct Mark { int stage; hipEvent_t a, b; double flops, bytes; };
@@ -277,13 +302,14 @@ bool make_conv(airfe_ctx* c, const Pack& p, const std::string& name, int cin, in
 
 // Linear y = W x + b with W [N][K] row-major; `src_row(feature)` lets callers permute / select output rows
 bool make_linear(airfe_ctx* c, const float* W, const float* bias, int K, int N, LinW& out, float scale = 1.f,
-                 const std::function<int(int)>* src_row = nullptr) {
+                 const std::function<int(int)>* src_row = nullptr, const std::function<int(int)>* src_col = nullptr) {
   const int Kp = (K + 63) / 64 * 64, cbt = (N + 63) / 64;
   auto slabs = pack_slabs(cbt, Kp / 64, c->prec, [&](int feat, int s, int k) {
     const int kk = s * 64 + k;
     if (feat >= N || kk >= K) return 0.f;
     const int r = src_row ? (*src_row)(feat) : feat;
-    return W[(size_t)r * K + kk] * scale;
+    const int cc = src_col ? (*src_col)(kk) : kk;
+    return W[(size_t)r * K + cc] * scale;
   });
   std::vector<float> bp((size_t)cbt * 64, 0.f);
   for (int f = 0; f < N; ++f) bp[f] = bias[src_row ? (*src_row)(f) : f] * scale;
@@ -369,6 +395,8 @@ int load_superpoint(airfe_ctx* c, const char* path) {
   return 0;
 }
 
+int alloc_matcher_arena(airfe_ctx* c);
+
 int load_lightglue(airfe_ctx* c, const char* path) {
   Pack p;
   std::string err;
@@ -413,7 +441,13 @@ int load_lightglue(airfe_ctx* c, const char* path) {
   if (!ok || !mw || !mb) return fail(c, err.empty() ? "LightGlue weight packing failed" : err);
   c->lg_mw = dupload(c, mw->data);
   c->lg_mb = mb->data[0];
+  if (alloc_matcher_arena(c)) return 1;
+  c->has_lg = true;
+  return 0;
+}
 
+int alloc_matcher_arena(airfe_ctx* c) {
+  if (c->has_arena) return 0;
   const int S = 2 * c->Pmax, Np = c->Np;
   const size_t M = (size_t)S * Np;
   c->x32 = dalloc<float>(c, M * 256);
@@ -440,7 +474,113 @@ int load_lightglue(airfe_ctx* c, const char* path) {
       !c->rot_sin || !c->zbuf || !c->lens || !c->simbuf || !c->rowlse || !c->collse || !c->rowval || !c->rowarg ||
       !c->colarg || !c->st_scores_full)
     return fail(c, "device allocation failed (matcher arena)");
-  c->has_lg = true;
+  c->has_arena = true;
+  return 0;
+}
+
+// y = W x + b stored transposed [K][N] fp32 for the thread-per-neuron VALU kernels
+float* upload_transposed(airfe_ctx* c, const Tensor& w, int N, int K) {
+  std::vector<float> t((size_t)N * K);
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) t[(size_t)k * N + n] = w.data[(size_t)n * K + k];
+  return dupload(c, t);
+}
+
+int load_superglue(airfe_ctx* c, const char* path) {
+  Pack p;
+  std::string err;
+  if (!load_pack(path, p, err)) return fail(c, err);
+  int L = 0;
+  while (p.count("gnn.layers." + std::to_string(L) + ".attn.merge.weight")) ++L;
+  if (L == 0) return fail(c, "SuperGlue pack has no GNN layers");
+  const int enc[6] = {3, 32, 64, 128, 256, 256};
+  for (int i = 0; i < 5; ++i) {
+    const Tensor* w = need(p, "kenc.encoder." + std::to_string(i) + ".weight", err);
+    const Tensor* b = need(p, "kenc.encoder." + std::to_string(i) + ".bias", err);
+    if (!w || !b || (int)w->data.size() != enc[i] * enc[i + 1]) return fail(c, err.empty() ? "kenc: unexpected shape" : err);
+    c->sg_kenc[2 * i] = upload_transposed(c, *w, enc[i + 1], enc[i]);
+    c->sg_kenc[2 * i + 1] = dupload(c, b->data);
+  }
+  // MultiHeadedAttention views channels as (dim, heads): channel = d*4 + h  ->  our head-major h*64 + d
+  std::function<int(int)> hm = [](int f) { return (f & 63) * 4 + (f >> 6); };
+  c->sg.resize(L);
+  bool ok = true;
+  for (int i = 0; i < L && ok; ++i) {
+    SgLayer& l = c->sg[i];
+    const std::string g = "gnn.layers." + std::to_string(i);
+    const Tensor *wq = need(p, g + ".attn.proj.0.weight", err), *bq = need(p, g + ".attn.proj.0.bias", err);
+    const Tensor *wk = need(p, g + ".attn.proj.1.weight", err), *bk = need(p, g + ".attn.proj.1.bias", err);
+    const Tensor *wv = need(p, g + ".attn.proj.2.weight", err), *bv = need(p, g + ".attn.proj.2.bias", err);
+    const Tensor *wm = need(p, g + ".attn.merge.weight", err), *bm = need(p, g + ".attn.merge.bias", err);
+    if (!wq || !bq || !wk || !bk || !wv || !bv || !wm || !bm) { ok = false; break; }
+    std::vector<float> wqk(512 * 256), bqk(512);
+    for (int f = 0; f < 256; ++f) {
+      memcpy(&wqk[(size_t)f * 256], &wq->data[(size_t)hm(f) * 256], 1024);
+      memcpy(&wqk[(size_t)(256 + f) * 256], &wk->data[(size_t)hm(f) * 256], 1024);
+      bqk[f] = bq->data[hm(f)];
+      bqk[256 + f] = bk->data[hm(f)];
+    }
+    ok = ok && make_linear(c, wqk.data(), bqk.data(), 256, 512, l.qk);
+    ok = ok && make_linear(c, wv->data.data(), bv->data.data(), 256, 256, l.v, 1.f, &hm);
+    ok = ok && make_linear(c, wm->data.data(), bm->data.data(), 256, 256, l.merge, 1.f, nullptr, &hm);
+    ok = ok && make_linear_named(c, p, g + ".mlp.0", 512, 512, l.mlp0, err);
+    ok = ok && make_linear_named(c, p, g + ".mlp.3", 512, 256, l.mlp3, err);
+  }
+  ok = ok && make_linear_named(c, p, "final_proj", 256, 256, c->sg_final, err, 0.25f /* scores / 256^.5 split over both sides */);
+  const Tensor* bs = need(p, "bin_score", err);
+  if (!ok || !bs) return fail(c, err.empty() ? "SuperGlue weight packing failed" : err);
+  c->sg_alpha = bs->data[0];
+  if (alloc_matcher_arena(c)) return 1;
+  const int P = c->Pmax;
+  c->Lz = c->Np + 64;
+  const size_t pl = (size_t)P * c->Lz;
+  c->sg_u = dalloc<float>(c, pl); c->sg_v = dalloc<float>(c, pl); c->sg_Z = dalloc<float>(c, pl * c->Lz);
+  c->sg_max0 = dalloc<float>(c, pl); c->sg_ms0 = dalloc<float>(c, pl); c->sg_ms1 = dalloc<float>(c, pl);
+  c->sg_idx0 = dalloc<int>(c, pl); c->sg_idx1 = dalloc<int>(c, pl);
+  c->sg_out0 = dalloc<int32_t>(c, pl); c->sg_out1 = dalloc<int32_t>(c, pl);
+  if (!c->sg_u || !c->sg_v || !c->sg_Z || !c->sg_max0 || !c->sg_ms0 || !c->sg_ms1 || !c->sg_idx0 || !c->sg_idx1 ||
+      !c->sg_out0 || !c->sg_out1)
+    return fail(c, "device allocation failed (SuperGlue arena)");
+  c->has_sg = true;
+  return 0;
+}
+
+int load_plnet_s1(airfe_ctx* c, const char* path) {
+  Pack p;
+  std::string err;
+  if (!load_pack(path, p, err)) return fail(c, err);
+  struct L { const char* name; int n, k; } ls[4] = {{"fc2.0", 128, 496}, {"fc2.2", 128, 128}, {"fc2.4", 128, 128}, {"fc2_res.0", 128, 240}};
+  for (int i = 0; i < 4; ++i) {
+    const Tensor* w = need(p, std::string(ls[i].name) + ".weight", err);
+    const Tensor* b = need(p, std::string(ls[i].name) + ".bias", err);
+    if (!w || !b || (int)w->data.size() != ls[i].n * ls[i].k) return fail(c, err.empty() ? "plnet_s1: unexpected shape" : err);
+    c->s1_w[2 * i] = upload_transposed(c, *w, ls[i].n, ls[i].k);
+    c->s1_w[2 * i + 1] = dupload(c, b->data);
+  }
+  const Tensor *wh = need(p, "fc2_head.weight", err), *bh = need(p, "fc2_head.bias", err), *tt = need(p, "sample_t", err);
+  if (!wh || !bh || !tt || wh->data.size() != 256 || tt->data.size() != 30) return fail(c, err.empty() ? "plnet_s1 head: unexpected shape" : err);
+  c->s1_w[8] = dupload(c, wh->data);
+  c->s1_w[9] = dupload(c, bh->data);
+  c->s1_w[10] = dupload(c, tt->data);
+  std::vector<int> tab(300 * 300, 0x7FFFFFFF);
+  c->wf_table = dupload(c, tab);
+  c->wf_keep = dalloc<int>(c, KEEP_CAP);
+  c->wf_pairs = dalloc<int>(c, (size_t)LINE_CAP * 2);
+  c->wf_rep = dalloc<int>(c, LINE_CAP);
+  c->wf_counts = dalloc<int>(c, 2);
+  c->s1_la = dalloc<float>(c, (size_t)LINE_CAP * 4);
+  c->s1_sc = dalloc<float>(c, LINE_CAP);
+  c->s0_stage = dalloc<float>(c, 600 + (size_t)KEEP_CAP * 7 + 128 * 128 * 128 + 2 * 4 * 128 * 128);
+  c->jmap = dalloc<unsigned char>(c, (size_t)AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE);
+  c->d_lines = dalloc<double>(c, (size_t)LINE_CAP * 4);
+  c->d_nlines = dalloc<int>(c, 1);
+  c->d_njunc = dalloc<int>(c, 1);
+  c->junc_feat = dalloc<float>(c, (size_t)JUNC_CAP * AIRFE_FEAT_DIM);
+  for (int i = 0; i < 11; ++i) if (!c->s1_w[i]) return fail(c, "device allocation failed (plnet_s1 weights)");
+  if (!c->wf_table || !c->wf_keep || !c->wf_pairs || !c->wf_rep || !c->wf_counts || !c->s1_la || !c->s1_sc || !c->s0_stage ||
+      !c->jmap || !c->d_lines || !c->d_nlines || !c->d_njunc || !c->junc_feat)
+    return fail(c, "device allocation failed (line path arena)");
+  c->has_s1 = true;
   return 0;
 }
 
@@ -589,6 +729,40 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   return 0;
 }
 
+// SuperGlue forward on B pairs of device feature matrices (259-float rows) -> decode outputs [B][Lz]
+int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1, const int* n1, int B, int cap, int normalize,
+                  hipStream_t st) {
+  if (!c->has_sg) return fail(c, "SuperGlue weights were not loaded (cfg.superglue_pack)");
+  if (B < 1 || B > c->Pmax) return fail(c, "pair batch exceeds cfg.max_batch");
+  if (cap > c->Np) return fail(c, "feature capacity exceeds the matcher arena (max_keypoints)");
+  const int S = 2 * B, Np = c->Np, M = S * Np;
+  const float cx = (float)(c->cfg.image_width / 2), cy = (float)(c->cfg.image_height / 2);
+  const float linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.7f);   // point_matcher.cc:58
+  launch_sg_prepare(c->prec, f0, f1, n0, n1, AIRFE_FEAT_DIM, normalize, cx, cy, linv, c->sg_kenc, B, cap, Np, c->x32, c->xb,
+                    c->lens, st);
+  int li = 0;
+  for (const SgLayer& l : c->sg) {
+    const int cross = li & 1;      // names = ['self','cross'] * 9
+    ++li;
+    run_linear(c, l.qk, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS, ACT_NONE, c->qb, 0, st, false, c->kb);
+    run_linear(c, l.v, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
+    {
+      ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048);
+      launch_attention(c->prec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, cross, 0.125f, st);
+    }
+    run_linear(c, l.merge, c->ob, 256, 256, nullptr, 0, M, EPI_STORE, ACT_NONE, c->msg, 256, st);
+    run_linear(c, l.mlp0, c->xb, 256, 256, c->msg, 256, M, EPI_STORE, ACT_RELU, c->hb, 512, st);
+    run_linear(c, l.mlp3, c->hb, 512, 512, nullptr, 0, M, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
+  }
+  run_linear(c, c->sg_final, c->xb, 256, 256, nullptr, 0, M, EPI_STORE, ACT_NONE, c->mdb, 256, st);
+  launch_sim(c->prec, c->mdb, c->simbuf, B, Np, st);
+  launch_sg_sinkhorn(c->simbuf, c->lens, B, Np, c->Lz, c->sg_alpha, c->cfg.sinkhorn_iters, c->sg_u, c->sg_v, c->sg_Z, st);
+  launch_sg_decode(c->sg_Z, c->lens, B, Np, c->Lz, 0.2f, c->sg_idx0, c->sg_max0, c->sg_idx1, c->sg_out0, c->sg_out1, c->sg_ms0,
+                   c->sg_ms1, st);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int ensure_stage_img(airfe_ctx* c, size_t bytes) {
   if (bytes <= c->st_img_bytes) return 0;
   void* p = nullptr;
@@ -648,6 +822,8 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   int rc = 0;
   if (cfg->superpoint_pack) rc = load_superpoint(c, cfg->superpoint_pack);
   if (!rc && cfg->lightglue_pack) rc = load_lightglue(c, cfg->lightglue_pack);
+  if (!rc && cfg->superglue_pack) rc = load_superglue(c, cfg->superglue_pack);
+  if (!rc && cfg->plnet_s1_pack) rc = load_plnet_s1(c, cfg->plnet_s1_pack);
   if (!rc) {
     const size_t capf = (size_t)c->Np * AIRFE_FEAT_DIM;
     c->st_feat0 = dalloc<float>(c, capf);
@@ -801,13 +977,117 @@ int airfe_stereo_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d
   return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
 }
 
-// ---- not built yet in this revision: report loudly instead of pretending
-int airfe_detect_plnet(airfe_ctx* c, const uint8_t*, int, int, int, const airfe_plnet_stage0*, float*, int, int*, double*,
-                       int, int*, float*, int, int*, int) {
-  return fail(c, "airfe_detect_plnet: not implemented in this build");
+int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, const airfe_plnet_stage0* s0, float* feat,
+                       int cap, int* n, double* lines, int capL, int* nlines, float* junc, int capJ, int* njunc,
+                       int want_junctions) {
+  if (!c) return 1;
+  if (nlines) *nlines = 0;
+  if (njunc) *njunc = 0;
+  if (airfe_detect_points(c, gray, h, w, stride, feat, cap, n)) return 1;      // point branch: plnet.cpp:560
+  if (!s0) return 0;
+  if (!c->has_s1) return fail(c, "PLNet stage-1 weights were not loaded (cfg.plnet_s1_pack)");
+  hipStream_t st = c->stream;
+  const int R = AIRFE_INTERNAL_SIZE, NP = KEEP_CAP;
+  float* d = c->s0_stage;
+  float *d_juncs = d, *d_lp = d + 600, *d_keep = d_lp + (size_t)NP * 4, *d_min = d_keep + NP, *d_max = d_min + NP;
+  float *d_loi = d_max + NP, *d_thin = d_loi + 128 * 128 * 128, *d_aux = d_thin + 4 * 128 * 128;
+  HIPCHK(c, hipMemcpyAsync(d_juncs, s0->juncs_pred, 600 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_lp, s0->lines_pred, (size_t)NP * 16, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_keep, s0->iskeep, (size_t)NP * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_min, s0->idx_junc_to_end_min, (size_t)NP * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_max, s0->idx_junc_to_end_max, (size_t)NP * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_loi, s0->loi_features, (size_t)128 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_thin, s0->loi_features_thin, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_aux, s0->loi_features_aux, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemsetAsync(c->jmap, 0, (size_t)R * R, st));
+  const float ws = (float)w / (float)R, hs = (float)h / (float)R;
+  launch_wireframe(d_keep, d_min, d_max, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, LINE_CAP, c->wf_counts, st);
+  launch_plnet_s1(d_juncs, d_lp, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, d_loi, d_thin, d_aux, c->s1_w, c->s1_la,
+                  c->s1_sc, LINE_CAP, st);
+  launch_line_filter(c->s1_la, c->s1_sc, c->wf_counts, c->cfg.remove_borders, c->cfg.line_threshold,
+                     c->cfg.line_length_threshold, ws, hs, R, c->jmap, c->d_lines, LINE_CAP, c->d_nlines, st);
+  int nl = 0, nj = 0;
+  HIPCHK(c, hipMemcpyAsync(&nl, c->d_nlines, 4, hipMemcpyDeviceToHost, st));
+  if (want_junctions) {
+    const float* hsel = c->cfg.nms_radius > 0 ? c->heat_nms : c->heat;
+    launch_junction_scan(c->jmap, hsel, R, c->cfg.remove_borders, c->junc_feat, JUNC_CAP, c->d_njunc, st);
+    launch_sample_desc(c->desc, 1, R / 8, R / 8, c->junc_feat, c->d_njunc, JUNC_CAP, ws, hs, st);
+    HIPCHK(c, hipMemcpyAsync(&nj, c->d_njunc, 4, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(c, hipStreamSynchronize(st));
+  nl = std::min(nl, capL);
+  nj = std::min(nj, capJ);
+  if (nl > 0 && lines) HIPCHK(c, hipMemcpy(lines, c->d_lines, (size_t)nl * 32, hipMemcpyDeviceToHost));
+  if (nj > 0 && junc) HIPCHK(c, hipMemcpy(junc, c->junc_feat, (size_t)nj * AIRFE_FEAT_DIM * 4, hipMemcpyDeviceToHost));
+  if (nlines) *nlines = nl;
+  if (njunc) *njunc = nj;
+  return 0;
 }
-int airfe_match_superglue(airfe_ctx* c, const float*, int, const float*, int, int32_t*, int32_t*, double*, double*) {
-  return fail(c, "airfe_match_superglue: not implemented in this build");
+
+/* stage-1 alone on HOST stage-0 tensors: lines_adjusted [M2][4] + scores_line [M2] (parity vs the real plnet_s1.onnx) */
+int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* lines_adjusted, float* scores_line, int cap, int* m2) {
+  if (!c || !c->has_s1 || !s0) return fail(c, "debug_plnet_s1: stage-1 not loaded");
+  hipStream_t st = c->stream;
+  const int NP = KEEP_CAP;
+  float* d = c->s0_stage;
+  float *d_juncs = d, *d_lp = d + 600, *d_keep = d_lp + (size_t)NP * 4, *d_min = d_keep + NP, *d_max = d_min + NP;
+  float *d_loi = d_max + NP, *d_thin = d_loi + 128 * 128 * 128, *d_aux = d_thin + 4 * 128 * 128;
+  HIPCHK(c, hipMemcpyAsync(d_juncs, s0->juncs_pred, 600 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_lp, s0->lines_pred, (size_t)NP * 16, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_keep, s0->iskeep, (size_t)NP * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_min, s0->idx_junc_to_end_min, (size_t)NP * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_max, s0->idx_junc_to_end_max, (size_t)NP * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_loi, s0->loi_features, (size_t)128 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_thin, s0->loi_features_thin, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_aux, s0->loi_features_aux, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+  launch_wireframe(d_keep, d_min, d_max, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, LINE_CAP, c->wf_counts, st);
+  launch_plnet_s1(d_juncs, d_lp, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, d_loi, d_thin, d_aux, c->s1_w, c->s1_la,
+                  c->s1_sc, LINE_CAP, st);
+  int cnt[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(cnt, c->wf_counts, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  const int k = std::min(cnt[1], cap);
+  if (k > 0) {
+    HIPCHK(c, hipMemcpy(lines_adjusted, c->s1_la, (size_t)k * 16, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(scores_line, c->s1_sc, (size_t)k * 4, hipMemcpyDeviceToHost));
+  }
+  *m2 = k;
+  return 0;
+}
+
+static int sg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx0, int32_t* idx1, double* ms0,
+                   double* ms1, float* scores_full) {
+  if (!c) return 1;
+  if (n0 < 1 || n1 < 1) return fail(c, "airfe_match_superglue: empty input (MatchingPoints early-outs before calling infer)");
+  if (n0 > c->cfg.max_keypoints || n1 > c->cfg.max_keypoints) return fail(c, "keypoint count exceeds max_keypoints");
+  HIPCHK(c, hipMemcpyAsync(c->st_feat0, f0, (size_t)n0 * 259 * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_feat1, f1, (size_t)n1 * 259 * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_n0, &n0, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_n1, &n1, 4, hipMemcpyHostToDevice, c->stream));
+  if (superglue_dev(c, c->st_feat0, c->st_n0, c->st_feat1, c->st_n1, 1, c->Np, 0, c->stream)) return 1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (idx0) {
+    std::vector<float> m0(n0), m1(n1);
+    HIPCHK(c, hipMemcpy(idx0, c->sg_out0, (size_t)n0 * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(idx1, c->sg_out1, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(m0.data(), c->sg_ms0, (size_t)n0 * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(m1.data(), c->sg_ms1, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n0; ++i) ms0[i] = (double)m0[i];      // VectorXd filled from float vectors: super_glue.cpp:464-469
+    for (int j = 0; j < n1; ++j) ms1[j] = (double)m1[j];
+  }
+  if (scores_full)
+    HIPCHK(c, hipMemcpy2D(scores_full, (size_t)(n1 + 1) * 4, c->sg_Z, (size_t)c->Lz * 4, (size_t)(n1 + 1) * 4, n0 + 1, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int airfe_match_superglue(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx0, int32_t* idx1,
+                          double* ms0, double* ms1) {
+  return sg_host(c, f0, n0, f1, n1, idx0, idx1, ms0, ms1, nullptr);
+}
+
+/* full SuperGlue output `scores` [n0+1][n1+1] (binding A.5) for one HOST pair */
+int airfe_debug_superglue_scores(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, float* scores) {
+  return sg_host(c, f0, n0, f1, n1, nullptr, nullptr, nullptr, nullptr, scores);
 }
 
 // ---- kernel-level test hooks ------------------------------------------------------------------------------

@@ -104,4 +104,29 @@ void launch_lg_assign(const float* sim, const float* z, const int* lens, int B, 
                       float* rowlse, float* collse, float* scores_out, int* rowarg, float* rowval, int* colarg,
                       int32_t* idx, float* score, int* nmatch, hipStream_t st);
 
+// ---- PLNet line path (src/plnet.cpp:272-307, 468-558) -------------------------------------------------------
+// table: [jn*jn] ints pre-filled with INT_MAX (left clean by the kernel); counts[0] = M1 kept, counts[1] = M2 unique
+void launch_wireframe(const float* iskeep, const float* imin, const float* imax, int n, int jn, int* table, int* keep,
+                      int* pairs, int* rep, int cap, int* counts, hipStream_t st);
+// w: 11 device pointers {W0t[496][128], b0, W2t, b2, W4t, b4, Wrt[240][128], br, Wh[2][128], bh, t[30]}
+void launch_plnet_s1(const float* juncs, const float* lines_pred, const int* keep, const int* pairs, const int* rep,
+                     const int* counts, const float* loi, const float* thin, const float* aux, const float* const* w,
+                     float* lines_adjusted, float* scores_line, int cap_lines, hipStream_t st);
+void launch_line_filter(const float* la, const float* sc, const int* counts, int border, float line_thr, float len_thr,
+                        float w_scale, float h_scale, int R, unsigned char* jmap, double* lines_out, int capL, int* nlines,
+                        hipStream_t st);
+void launch_junction_scan(const unsigned char* jmap, const float* heat, int R, int border, float* feat, int cap, int* n_out,
+                          hipStream_t st);
+
+// ---- SuperGlue ----------------------------------------------------------------------------------------------
+// w: 10 device pointers {W0t[3][32], b0, W1t[32][64], b1, W2t[64][128], b2, W3t[128][256], b3, W4t[256][256], b4}
+void launch_sg_prepare(int prec, const float* f0, const float* f1, const int* n0, const int* n1, int ld, int normalize,
+                       float cx, float cy, float linv, const float* const* w, int B, int cap, int Np, float* x32,
+                       uint16_t* xb, int* lens, hipStream_t st);
+// u, v: [B][Lz]; Z: [B][Lz][Lz] log-assignment incl. dustbins (rows 0..n0, cols 0..n1)
+void launch_sg_sinkhorn(const float* sim, const int* lens, int B, int Np, int Lz, float alpha, int iters, float* u, float* v,
+                        float* Z, hipStream_t st);
+void launch_sg_decode(const float* Z, const int* lens, int B, int Np, int Lz, float thr, int* idx0, float* max0, int* idx1,
+                      int32_t* out0, int32_t* out1, float* ms0, float* ms1, hipStream_t st);
+
 }  // namespace airfe

@@ -1,0 +1,501 @@
+// airfe — PLNet line path (wireframe_matcher, stage-1 LOI head, line/junction filter) and the SuperGlue-specific
+// pieces (keypoint encoder, log-domain Sinkhorn, decode).  Small, irregular, fp32: VALU + LDS, no MFMA.
+#include "common.h"
+#include "kernels.h"
+
+namespace airfe {
+
+// block-wide exclusive scan of one unsigned per thread (1024 threads); returns exclusive prefix, *total = sum
+__device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* wsum /*[16] LDS*/, unsigned* total) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  __syncthreads();            // protect wsum from the previous use
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  unsigned off = 0, tot = 0;
+  for (int w = 0; w < 16; ++w) {
+    const unsigned t = wsum[w];
+    if (w < wv) off += t;
+    tot += t;
+  }
+  *total = tot;
+  return off + incl - v;
+}
+
+// =============================================================================== wireframe_matcher
+// src/plnet.cpp:272-307 on the device.  keep = raster-ordered indices with iskeep > 0; unique (min,max) junction pairs
+// get ids in FIRST-SEEN order; rep[u] = position (in keep) of the first proposal of unique line u — which is also the
+// `perm` the stage-1 graph rebuilds with its reversed ScatterElements (oracle/onnx_run.py).
+__global__ __launch_bounds__(1024) void wireframe_kernel(const float* __restrict__ iskeep, const float* __restrict__ imin,
+                                                         const float* __restrict__ imax, int n, int jn, int* table,
+                                                         int* __restrict__ keep, int* __restrict__ pairs,
+                                                         int* __restrict__ rep, int cap, int* __restrict__ counts) {
+  __shared__ unsigned wsum[16];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = tid * per, hi = min(lo + per, n);
+  unsigned cnt = 0;
+  for (int i = lo; i < hi; ++i) cnt += iskeep[i] > 0.f;
+  unsigned m1;
+  unsigned off = block_excl_scan_1024(cnt, wsum, &m1);
+  for (int i = lo; i < hi; ++i)
+    if (iskeep[i] > 0.f) { if (off < (unsigned)cap) keep[off] = i; ++off; }
+  m1 = min(m1, (unsigned)cap);
+  __syncthreads();
+  for (unsigned k = tid; k < m1; k += 1024) {
+    const int i = keep[k];
+    const int a = (int)imin[i], b = (int)imax[i];
+    if (a >= 0 && a < jn && b >= 0 && b < jn) atomicMin(&table[a * jn + b], (int)k);
+  }
+  __syncthreads();
+  const int per2 = ((int)m1 + 1023) / 1024;
+  const int lo2 = tid * per2, hi2 = min(lo2 + per2, (int)m1);
+  unsigned c2 = 0;
+  for (int k = lo2; k < hi2; ++k) {
+    const int i = keep[k];
+    const int a = (int)imin[i], b = (int)imax[i];
+    c2 += (a >= 0 && a < jn && b >= 0 && b < jn) && __hip_atomic_load(&table[a * jn + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k;
+  }
+  unsigned m2;
+  unsigned off2 = block_excl_scan_1024(c2, wsum, &m2);
+  for (int k = lo2; k < hi2; ++k) {
+    const int i = keep[k];
+    const int a = (int)imin[i], b = (int)imax[i];
+    if ((a >= 0 && a < jn && b >= 0 && b < jn) && __hip_atomic_load(&table[a * jn + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k) {
+      rep[off2] = k;
+      pairs[off2 * 2] = b;          // (max, min): plnet.cpp:301
+      pairs[off2 * 2 + 1] = a;
+      ++off2;
+    }
+  }
+  __syncthreads();
+  for (unsigned k = tid; k < m1; k += 1024) {      // leave the table clean for the next call
+    const int i = keep[k];
+    const int a = (int)imin[i], b = (int)imax[i];
+    if (a >= 0 && a < jn && b >= 0 && b < jn) table[a * jn + b] = 0x7FFFFFFF;
+  }
+  if (tid == 0) { counts[0] = (int)m1; counts[1] = (int)m2; }
+}
+
+void launch_wireframe(const float* iskeep, const float* imin, const float* imax, int n, int jn, int* table, int* keep,
+                      int* pairs, int* rep, int cap, int* counts, hipStream_t st) {
+  hipLaunchKernelGGL(wireframe_kernel, dim3(1), dim3(1024), 0, st, iskeep, imin, imax, n, jn, table, keep, pairs, rep, cap, counts);
+}
+
+// =============================================================================== stage-1 LOI head
+// plnet_s1.onnx restated (oracle/ref_nets.py::plnet_s1_forward), fp32 throughout.
+__device__ __forceinline__ float bil_chw(const float* __restrict__ f, int H, int W, float x, float y) {
+  const float px = x - 0.5f, py = y - 0.5f;
+  const float x0 = fminf(fmaxf(floorf(px), 0.f), (float)(W - 1)), y0 = fminf(fmaxf(floorf(py), 0.f), (float)(H - 1));
+  const float x1 = fminf(fmaxf(x0 + 1.f, 0.f), (float)(W - 1)), y1 = fminf(fmaxf(y0 + 1.f, 0.f), (float)(H - 1));
+  const int x0i = (int)x0, y0i = (int)y0, x1i = (int)x1, y1i = (int)y1;
+  return f[y0i * W + x0i] * (y1 - py) * (x1 - px) + f[y1i * W + x0i] * (py - y0) * (x1 - px) +
+         f[y0i * W + x1i] * (y1 - py) * (px - x0) + f[y1i * W + x1i] * (py - y0) * (px - x0);
+}
+
+constexpr int S1_LT = 8;   // lines per workgroup
+
+template <int K>
+__device__ __forceinline__ void s1_dense(const float* __restrict__ wt /*[K][128]*/, const float* __restrict__ bias,
+                                         const float* xin /*LDS [LT][ldx]*/, int ldx, float* out /*[LT]*/, int n) {
+  float acc[S1_LT];
+#pragma unroll
+  for (int l = 0; l < S1_LT; ++l) acc[l] = bias[n];
+  for (int k = 0; k < K; ++k) {
+    const float w = wt[k * 128 + n];
+#pragma unroll
+    for (int l = 0; l < S1_LT; ++l) acc[l] = fmaf(w, xin[l * ldx + k], acc[l]);
+  }
+#pragma unroll
+  for (int l = 0; l < S1_LT; ++l) out[l] = acc[l];
+}
+
+struct S1Weights {
+  const float *w0t, *b0, *w2t, *b2, *w4t, *b4, *wrt, *br, *wh, *bh, *tt;   // *t = transposed [K][128]; wh [2][128]
+};
+
+__global__ __launch_bounds__(128) void plnet_s1_kernel(const float* __restrict__ juncs, const float* __restrict__ lines_pred,
+                                                       const int* __restrict__ keep, const int* __restrict__ pairs,
+                                                       const int* __restrict__ rep, const int* __restrict__ counts,
+                                                       const float* __restrict__ loi, const float* __restrict__ thin,
+                                                       const float* __restrict__ aux, S1Weights w,
+                                                       float* __restrict__ lines_adjusted, float* __restrict__ scores_line) {
+  __shared__ float xs[S1_LT][496];
+  __shared__ float h0[S1_LT][128], h1[S1_LT][128];
+  __shared__ float la[S1_LT][4], li[S1_LT][4];
+  const int m2 = counts[1];
+  const int l0 = blockIdx.x * S1_LT, tid = threadIdx.x;
+  if (l0 >= m2) return;
+  if (tid < S1_LT * 4) {
+    const int l = tid >> 2, c = tid & 3, u = min(l0 + l, m2 - 1);
+    const int j = pairs[u * 2 + (c >> 1)];
+    const float v = juncs[j * 2 + (c & 1)];
+    la[l][c] = v;
+    li[l][c] = lines_pred[(size_t)keep[rep[u]] * 4 + c];
+    if (l0 + l < m2) lines_adjusted[(size_t)(l0 + l) * 4 + c] = v;
+  }
+  __syncthreads();
+  for (int l = 0; l < S1_LT; ++l) {
+    xs[l][tid] = bil_chw(loi + (size_t)tid * 128 * 128, 128, 128, la[l][0], la[l][1]);
+    xs[l][128 + tid] = bil_chw(loi + (size_t)tid * 128 * 128, 128, 128, la[l][2], la[l][3]);
+    if (tid < 120) {
+      const int c = tid / 30, j = tid - c * 30;
+      const float t = w.tt[j], t1 = 1.0f - t;
+      xs[l][256 + tid] = bil_chw(thin + (size_t)c * 128 * 128, 128, 128, la[l][0] * t + la[l][2] * t1, la[l][1] * t + la[l][3] * t1);
+      xs[l][376 + tid] = bil_chw(aux + (size_t)c * 128 * 128, 128, 128, li[l][0] * t + li[l][2] * t1, li[l][1] * t + li[l][3] * t1);
+    }
+  }
+  __syncthreads();
+  float o[S1_LT], r[S1_LT];
+  s1_dense<496>(w.w0t, w.b0, &xs[0][0], 496, o, tid);
+#pragma unroll
+  for (int l = 0; l < S1_LT; ++l) h0[l][tid] = fmaxf(o[l], 0.f);
+  s1_dense<240>(w.wrt, w.br, &xs[0][256], 496, r, tid);
+  __syncthreads();
+  s1_dense<128>(w.w2t, w.b2, &h0[0][0], 128, o, tid);
+#pragma unroll
+  for (int l = 0; l < S1_LT; ++l) h1[l][tid] = fmaxf(o[l], 0.f);
+  __syncthreads();
+  s1_dense<128>(w.w4t, w.b4, &h1[0][0], 128, o, tid);
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < S1_LT; ++l) h0[l][tid] = o[l] + fmaxf(r[l], 0.f);
+  __syncthreads();
+  if (tid < S1_LT * 2) {
+    const int l = tid >> 1, c = tid & 1;
+    float z = w.bh[c];
+    for (int k = 0; k < 128; ++k) z = fmaf(w.wh[c * 128 + k], h0[l][k], z);
+    h1[l][c] = z;
+  }
+  __syncthreads();
+  if (tid < S1_LT && l0 + tid < m2) {
+    const float z0 = h1[tid][0], z1 = h1[tid][1], m = fmaxf(z0, z1);
+    const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+    scores_line[l0 + tid] = e1 / (e0 + e1);
+  }
+}
+
+void launch_plnet_s1(const float* juncs, const float* lines_pred, const int* keep, const int* pairs, const int* rep,
+                     const int* counts, const float* loi, const float* thin, const float* aux, const float* const* w,
+                     float* lines_adjusted, float* scores_line, int cap_lines, hipStream_t st) {
+  S1Weights sw{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10]};
+  hipLaunchKernelGGL(plnet_s1_kernel, dim3((cap_lines + S1_LT - 1) / S1_LT), dim3(128), 0, st, juncs, lines_pred, keep, pairs, rep,
+                     counts, loi, thin, aux, sw, lines_adjusted, scores_line);
+}
+
+// =============================================================================== line filter + junction map
+// src/plnet.cpp:519-558 (+ rescale :577-582).  junction_map[y][x] = p_valid(x,y) is a pure function of the pixel,
+// so the sequential "assignment, not OR" of the reference is order-independent; lines are emitted in ascending i.
+__global__ __launch_bounds__(1024) void line_filter_kernel(const float* __restrict__ la, const float* __restrict__ sc,
+                                                           const int* __restrict__ counts, int border, float line_thr,
+                                                           float len_thr, float w_scale, float h_scale, int R,
+                                                           unsigned char* __restrict__ jmap, double* __restrict__ lines_out,
+                                                           int capL, int* __restrict__ nlines) {
+  __shared__ unsigned wsum[16];
+  const int tid = threadIdx.x, m2 = counts[1];
+  const int per = (m2 + 1023) / 1024, lo = tid * per, hi = min(lo + per, m2);
+  const float thr2 = __fmul_rn(len_thr, len_thr);
+  border = max(border, 0);
+  unsigned cnt = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    unsigned off = 0, tot = 0;
+    if (pass == 1) off = block_excl_scan_1024(cnt, wsum, &tot);
+    for (int i = lo; i < hi; ++i) {
+      const float s = sc[i];
+      if (s < 0.5f) continue;
+      const float x1 = __fmul_rn(la[i * 4], 4.f), y1 = __fmul_rn(la[i * 4 + 1], 4.f);
+      const float x2 = __fmul_rn(la[i * 4 + 2], 4.f), y2 = __fmul_rn(la[i * 4 + 3], 4.f);
+      if (pass == 0) {
+        const int xi1 = (int)((double)x1 + 0.1), yi1 = (int)((double)y1 + 0.1);
+        const int xi2 = (int)((double)x2 + 0.1), yi2 = (int)((double)y2 + 0.1);
+        const bool p1 = xi1 > border && xi1 < R - border && yi1 > border && yi1 < R - border;
+        const bool p2 = xi2 > border && xi2 < R - border && yi2 > border && yi2 < R - border;
+        if (xi1 >= 0 && xi1 < R && yi1 >= 0 && yi1 < R) jmap[yi1 * R + xi1] = p1;
+        if (xi2 >= 0 && xi2 < R && yi2 >= 0 && yi2 < R) jmap[yi2 * R + xi2] = p2;
+      }
+      if (s < line_thr) continue;
+      const float dx = __fsub_rn(x2, x1), dy = __fsub_rn(y2, y1);
+      const float l2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+      if (l2 < thr2) continue;
+      if (pass == 0) ++cnt;
+      else {
+        if (off < (unsigned)capL) {
+          lines_out[(size_t)off * 4 + 0] = (double)x1 * (double)w_scale;
+          lines_out[(size_t)off * 4 + 1] = (double)y1 * (double)h_scale;
+          lines_out[(size_t)off * 4 + 2] = (double)x2 * (double)w_scale;
+          lines_out[(size_t)off * 4 + 3] = (double)y2 * (double)h_scale;
+        }
+        ++off;
+      }
+    }
+    if (pass == 1 && tid == 0) *nlines = min((int)tot, capL);
+  }
+}
+
+void launch_line_filter(const float* la, const float* sc, const int* counts, int border, float line_thr, float len_thr,
+                        float w_scale, float h_scale, int R, unsigned char* jmap, double* lines_out, int capL, int* nlines,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(line_filter_kernel, dim3(1), dim3(1024), 0, st, la, sc, counts, border, line_thr, len_thr, w_scale,
+                     h_scale, R, jmap, lines_out, capL, nlines);
+}
+
+// junction_detector (src/plnet.cpp:425-448): raster scan of the junction map inside [border, R-border) (EXCLUSIVE upper)
+__global__ __launch_bounds__(1024) void junction_scan_kernel(const unsigned char* __restrict__ jmap,
+                                                             const float* __restrict__ heat, int R, int border,
+                                                             float* __restrict__ feat, int cap, int* __restrict__ n_out) {
+  __shared__ unsigned wsum[16];
+  const int tid = threadIdx.x, N = R * R;
+  const int per = (N + 1023) / 1024, lo = tid * per, hi = min(lo + per, N);
+  border = max(border, 0);
+  unsigned cnt = 0;
+  for (int i = lo; i < hi; ++i) {
+    const int y = i / R, x = i - y * R;
+    cnt += jmap[i] && x >= border && x < R - border && y >= border && y < R - border;
+  }
+  unsigned tot;
+  unsigned off = block_excl_scan_1024(cnt, wsum, &tot);
+  for (int i = lo; i < hi; ++i) {
+    const int y = i / R, x = i - y * R;
+    if (jmap[i] && x >= border && x < R - border && y >= border && y < R - border) {
+      if (off < (unsigned)cap) {
+        float* f = feat + (size_t)off * 259;
+        f[0] = heat[i];
+        f[1] = (float)x;
+        f[2] = (float)y;
+      }
+      ++off;
+    }
+  }
+  if (tid == 0) *n_out = min((int)tot, cap);
+}
+
+void launch_junction_scan(const unsigned char* jmap, const float* heat, int R, int border, float* feat, int cap, int* n_out,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(junction_scan_kernel, dim3(1), dim3(1024), 0, st, jmap, heat, R, border, feat, cap, n_out);
+}
+
+// =============================================================================== SuperGlue: keypoint encoder
+// KeypointEncoder MLP [3,32,64,128,256,256] (Conv1d k=1, BN folded, ReLU) on (x, y, score), added to the descriptor.
+// process_input layout: src/super_glue.cpp:199-246.  4 keypoints per 256-thread workgroup, weights transposed [K][N].
+constexpr int KE_LT = 4;
+
+template <int K, int N>
+__device__ __forceinline__ void ke_layer(const float* __restrict__ wt, const float* __restrict__ b, const float* in, int ldi,
+                                         float* out, int ldo, bool relu) {
+  const int n = threadIdx.x;
+  if (n < N) {
+    float acc[KE_LT];
+#pragma unroll
+    for (int l = 0; l < KE_LT; ++l) acc[l] = b[n];
+    for (int k = 0; k < K; ++k) {
+      const float w = wt[k * N + n];
+#pragma unroll
+      for (int l = 0; l < KE_LT; ++l) acc[l] = fmaf(w, in[l * ldi + k], acc[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < KE_LT; ++l) out[l * ldo + n] = relu ? fmaxf(acc[l], 0.f) : acc[l];
+  }
+}
+
+struct SgPrepArgs {
+  const float* f0; const float* f1; const int* n0; const int* n1;
+  int ld, normalize; float cx, cy, linv;
+  const float* w[10];   // w0t,b0,...,w4t,b4
+  int B, cap, Np;
+  float* x32; uint16_t* xb; int* lens;
+};
+
+template <class P>
+__global__ __launch_bounds__(256) void sg_prepare_kernel(SgPrepArgs a) {
+  __shared__ float bufa[KE_LT][256], bufb[KE_LT][256];
+  const int s = blockIdx.y, n0r = blockIdx.x * KE_LT, tid = threadIdx.x;
+  const int b = s >> 1, side = s & 1;
+  const int len = side ? a.n1[b] : a.n0[b];
+  if (blockIdx.x == 0 && tid == 0) a.lens[s] = len;
+  const float* fbase = (side ? a.f1 : a.f0) + (size_t)b * a.cap * a.ld;
+  if (tid < KE_LT * 3) {
+    const int l = tid / 3, c = tid - l * 3, n = n0r + l;
+    float v = 0.f;
+    if (n < len) {
+      const float* f = fbase + (size_t)n * a.ld;
+      if (c == 2) v = f[0];                                     // score
+      else {
+        v = f[1 + c];
+        if (a.normalize) v = __fmul_rn(__fsub_rn(v, c == 0 ? a.cx : a.cy), a.linv);
+      }
+    }
+    bufa[l][c] = v;
+  }
+  __syncthreads();
+  ke_layer<3, 32>(a.w[0], a.w[1], &bufa[0][0], 256, &bufb[0][0], 256, true);
+  __syncthreads();
+  ke_layer<32, 64>(a.w[2], a.w[3], &bufb[0][0], 256, &bufa[0][0], 256, true);
+  __syncthreads();
+  ke_layer<64, 128>(a.w[4], a.w[5], &bufa[0][0], 256, &bufb[0][0], 256, true);
+  __syncthreads();
+  ke_layer<128, 256>(a.w[6], a.w[7], &bufb[0][0], 256, &bufa[0][0], 256, true);
+  __syncthreads();
+  ke_layer<256, 256>(a.w[8], a.w[9], &bufa[0][0], 256, &bufb[0][0], 256, false);
+  __syncthreads();
+  for (int l = 0; l < KE_LT; ++l) {
+    const int n = n0r + l;
+    if (n >= a.Np) break;
+    const size_t row = (size_t)s * a.Np + n;
+    float v = 0.f;
+    if (n < len) v = fbase[(size_t)n * a.ld + 3 + tid] + bufb[l][tid];
+    a.x32[row * 256 + tid] = v;
+    a.xb[row * 256 + tid] = P::from_f32(v);
+  }
+}
+
+void launch_sg_prepare(int prec, const float* f0, const float* f1, const int* n0, const int* n1, int ld, int normalize,
+                       float cx, float cy, float linv, const float* const* w, int B, int cap, int Np, float* x32,
+                       uint16_t* xb, int* lens, hipStream_t st) {
+  SgPrepArgs a;
+  a.f0 = f0; a.f1 = f1; a.n0 = n0; a.n1 = n1; a.ld = ld; a.normalize = normalize; a.cx = cx; a.cy = cy; a.linv = linv;
+  for (int i = 0; i < 10; ++i) a.w[i] = w[i];
+  a.B = B; a.cap = cap; a.Np = Np; a.x32 = x32; a.xb = xb; a.lens = lens;
+  dim3 grid((Np + KE_LT - 1) / KE_LT, 2 * B);
+  if (prec == 1) hipLaunchKernelGGL(sg_prepare_kernel<PF16>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(sg_prepare_kernel<PBF16>, grid, dim3(256), 0, st, a);
+}
+
+// =============================================================================== SuperGlue: Sinkhorn
+// log_optimal_transport (public SuperGlue; cf. the reference's CPU copy src/super_glue.cpp:369-435).
+// Couplings are never materialised: C[i][j] = sim[i][j] inside, alpha on the dustbin row/column.
+__device__ __forceinline__ float sg_coupling(const float* __restrict__ sim, int Np, int n0, int n1, float alpha, int i, int j) {
+  return (i < n0 && j < n1) ? sim[(size_t)i * Np + j] : alpha;
+}
+
+// wave per row: u[i] = log_mu[i] - logsumexp_j(C[i][j] + v[j]), i in [0, n0]
+__global__ void sg_sinkhorn_row_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np, int Lz, float alpha,
+                                       float* __restrict__ u, const float* __restrict__ v) {
+  const int b = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
+  if (i > n0) return;
+  const float* S = sim + (size_t)b * Np * Np;
+  const float* vb = v + (size_t)b * Lz;
+  float mx = -INFINITY;
+  for (int j = lane; j <= n1; j += 64) mx = fmaxf(mx, sg_coupling(S, Np, n0, n1, alpha, i, j) + vb[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j <= n1; j += 64) s += expf(sg_coupling(S, Np, n0, n1, alpha, i, j) + vb[j] - mx);
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float norm = -logf((float)(n0 + n1));
+    const float log_mu = (i < n0) ? norm : logf((float)n1) + norm;
+    u[(size_t)b * Lz + i] = log_mu - (mx + logf(s));
+  }
+}
+
+// thread per column: v[j] = log_nu[j] - logsumexp_i(C[i][j] + u[i]), j in [0, n1]
+__global__ void sg_sinkhorn_col_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np, int Lz, float alpha,
+                                       const float* __restrict__ u, float* __restrict__ v) {
+  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
+  if (j > n1) return;
+  const float* S = sim + (size_t)b * Np * Np;
+  const float* ub = u + (size_t)b * Lz;
+  float mx = -INFINITY;
+  for (int i = 0; i <= n0; ++i) mx = fmaxf(mx, sg_coupling(S, Np, n0, n1, alpha, i, j) + ub[i]);
+  float s = 0.f;
+  for (int i = 0; i <= n0; ++i) s += expf(sg_coupling(S, Np, n0, n1, alpha, i, j) + ub[i] - mx);
+  const float norm = -logf((float)(n0 + n1));
+  const float log_nu = (j < n1) ? norm : logf((float)n0) + norm;
+  v[(size_t)b * Lz + j] = log_nu - (mx + logf(s));
+}
+
+// Z = C + u + v - norm  ->  scores [b][Lz][Lz] (row stride Lz), rows 0..n0, cols 0..n1
+__global__ void sg_scores_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np, int Lz, float alpha,
+                                 const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ Z) {
+  const int b = blockIdx.z, i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
+  if (i > n0 || j > n1) return;
+  const float norm = -logf((float)(n0 + n1));
+  Z[((size_t)b * Lz + i) * Lz + j] =
+      sg_coupling(sim + (size_t)b * Np * Np, Np, n0, n1, alpha, i, j) + u[(size_t)b * Lz + i] + v[(size_t)b * Lz + j] - norm;
+}
+
+void launch_sg_sinkhorn(const float* sim, const int* lens, int B, int Np, int Lz, float alpha, int iters, float* u, float* v,
+                        float* Z, hipStream_t st) {
+  (void)hipMemsetAsync(u, 0, (size_t)B * Lz * 4, st);
+  (void)hipMemsetAsync(v, 0, (size_t)B * Lz * 4, st);
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL(sg_sinkhorn_row_kernel, dim3((Np + 1 + 3) / 4, B), dim3(256), 0, st, sim, lens, Np, Lz, alpha, u, v);
+    hipLaunchKernelGGL(sg_sinkhorn_col_kernel, dim3((Np + 1 + 63) / 64, B), dim3(64), 0, st, sim, lens, Np, Lz, alpha, u, v);
+  }
+  hipLaunchKernelGGL(sg_scores_kernel, dim3((Np + 1 + 63) / 64, Np + 1, B), dim3(64), 0, st, sim, lens, Np, Lz, alpha, u, v, Z);
+}
+
+// =============================================================================== SuperGlue: decode
+// decode (src/super_glue.cpp:339-367) on Z: inner block rows < n0, cols < n1; strict '<' => first maximum wins.
+__global__ void sg_rowmax_kernel(const float* __restrict__ Z, const int* __restrict__ lens, int Lz, int* __restrict__ idx0,
+                                 float* __restrict__ max0) {
+  const int b = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
+  if (i >= n0) return;
+  const float* r = Z + ((size_t)b * Lz + i) * Lz;
+  float best = -INFINITY;
+  int bj = 0x7FFFFFFF;
+  for (int j = lane; j < n1; j += 64) { const float v = r[j]; if (v > best) { best = v; bj = j; } }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int oj = __shfl_xor(bj, o);
+    if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+  }
+  if (lane == 0) { idx0[(size_t)b * Lz + i] = (bj == 0x7FFFFFFF) ? 0 : bj; max0[(size_t)b * Lz + i] = best; }
+}
+
+__global__ void sg_colmax_kernel(const float* __restrict__ Z, const int* __restrict__ lens, int Lz, int* __restrict__ idx1) {
+  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
+  if (j >= n1) return;
+  const float* c = Z + (size_t)b * Lz * Lz + j;
+  float best = -INFINITY;
+  int bi = 0;
+  for (int i = 0; i < n0; ++i) { const float v = c[(size_t)i * Lz]; if (v > best) { best = v; bi = i; } }
+  idx1[(size_t)b * Lz + j] = bi;
+}
+
+__global__ __launch_bounds__(1024) void sg_decode_kernel(const int* __restrict__ lens, int Lz, const int* __restrict__ idx0,
+                                                         const float* __restrict__ max0, const int* __restrict__ idx1,
+                                                         float thr, int32_t* __restrict__ out0, int32_t* __restrict__ out1,
+                                                         float* __restrict__ ms0, float* __restrict__ ms1) {
+  __shared__ float s_ms0[1024];
+  __shared__ unsigned char s_valid0[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
+  const int* i0 = idx0 + (size_t)b * Lz;
+  const int* i1 = idx1 + (size_t)b * Lz;
+  if (tid < n0) {
+    const bool mutual = i1[i0[tid]] == tid;
+    const float m = mutual ? expf(max0[(size_t)b * Lz + tid]) : 0.f;
+    const bool valid = mutual && m > thr;
+    s_ms0[tid] = m;
+    s_valid0[tid] = valid;
+    ms0[(size_t)b * Lz + tid] = m;
+    out0[(size_t)b * Lz + tid] = valid ? i0[tid] : -1;
+  }
+  __syncthreads();
+  if (tid < n1) {
+    const int r = i1[tid];
+    const bool mutual = i0[r] == tid;
+    ms1[(size_t)b * Lz + tid] = mutual ? s_ms0[r] : 0.f;
+    out1[(size_t)b * Lz + tid] = (mutual && s_valid0[r]) ? r : -1;
+  }
+}
+
+void launch_sg_decode(const float* Z, const int* lens, int B, int Np, int Lz, float thr, int* idx0, float* max0, int* idx1,
+                      int32_t* out0, int32_t* out1, float* ms0, float* ms1, hipStream_t st) {
+  hipLaunchKernelGGL(sg_rowmax_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, Z, lens, Lz, idx0, max0);
+  hipLaunchKernelGGL(sg_colmax_kernel, dim3((Np + 63) / 64, B), dim3(64), 0, st, Z, lens, Lz, idx1);
+  hipLaunchKernelGGL(sg_decode_kernel, dim3(B), dim3(1024), 0, st, lens, Lz, idx0, max0, idx1, thr, out0, out1, ms0, ms1);
+}
+
+}  // namespace airfe

@@ -104,7 +104,18 @@ def plnet_s1_spec() -> Spec:
             ("fc2.2.weight", (128, 128)), ("fc2.2.bias", (128,)),
             ("fc2.4.weight", (128, 128)), ("fc2.4.bias", (128,)),
             ("fc2_res.0.weight", (128, 240)), ("fc2_res.0.bias", (128,)),
-            ("fc2_head.weight", (2, 128)), ("fc2_head.bias", (2,))]
+            ("fc2_head.weight", (2, 128)), ("fc2_head.bias", (2,)),
+            # the graph's [1,1,30] constant `linspace(0,1,32)[1:-1]` (torch fp32 values, NOT (j+1)/31 rounded)
+            ("sample_t", (30,))]
+
+
+def linspace_t() -> np.ndarray:
+    """torch.linspace(0, 1, 32)[1:-1] in fp32, bit-exact (matches initializer onnx::Mul_1141 of plnet_s1.onnx)."""
+    step = np.float32(np.float32(1.0) / np.float32(31))
+    i = np.arange(32)
+    v = np.where(i < 16, (step * i.astype(np.float32)).astype(np.float32),
+                 (np.float32(1) - step * (31 - i).astype(np.float32)).astype(np.float32))
+    return v[1:-1].astype(np.float32)
 
 
 # ----------------------------------------------------------------------- synthetic
@@ -157,7 +168,9 @@ def synthetic_superglue(seed: int = 1234, n_layers: int = SG_LAYERS) -> Dict[str
 
 
 def synthetic_plnet_s1(seed: int = 1234) -> Dict[str, np.ndarray]:
-    return synthetic(plnet_s1_spec(), seed + 30)
+    w = synthetic(plnet_s1_spec(), seed + 30)
+    w["sample_t"] = linspace_t()
+    return w
 
 
 # ---------------------------------------------------------------------------- packs

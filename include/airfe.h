@@ -126,6 +126,11 @@ int airfe_debug_detector_maps(airfe_ctx* ctx, int B, float* heat_raw, float* hea
 int airfe_debug_lightglue_scores(airfe_ctx* ctx, const float* f0, int n0, const float* f1, int n1, float* scores);
 /* kernel-level checks on HOST fp32 tensors (test only): NCHW conv3x3(+ReLU, optional 2x2 max-pool) and
  *   y[M][N] = x[M][K] w[N][K]^T + b through the same MFMA kernels the pipelines use. */
+/* SuperGlue on one HOST pair ([n][259] rows, normalised x,y): the engine's `scores` output [n0+1][n1+1] */
+int airfe_debug_superglue_scores(airfe_ctx* ctx, const float* f0, int n0, const float* f1, int n1, float* scores);
+/* wireframe_matcher + stage-1 LOI head alone: lines_adjusted [cap][4], scores_line [cap], *m2 = unique lines */
+int airfe_debug_plnet_s1(airfe_ctx* ctx, const airfe_plnet_stage0* stage0, float* lines_adjusted, float* scores_line,
+                         int cap, int* m2);
 /* the pre-process alone (cv::resize + /255, src/plnet.cpp:246-270): HOST gray image -> HOST fp32 [512][512] */
 int airfe_debug_preprocess(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int stride, float* out);
 int airfe_debug_conv3x3(airfe_ctx* ctx, const float* x, int B, int cin, int H, int W, const float* w, const float* b,

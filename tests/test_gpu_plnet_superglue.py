@@ -1,0 +1,123 @@
+"""PLNet line path and SuperGlue on the GPU (C ABI) vs the oracle.  The stage-1 LOI head runs the REAL weights of
+output/plnet_s1.onnx (tests/golden/plnet_s1.airfe) and is compared with the golden outputs of the real graph."""
+import os
+
+import numpy as np
+import pytest
+
+from airslam_amd import api, synth, weights
+from conftest import GOLDEN
+from gpu_common import diag
+from oracle import ref_nets, ref_post
+
+pytestmark = pytest.mark.gpu
+_C = {}
+
+
+def _ctx_plnet():
+    if "p" not in _C:
+        _C["p"] = api.Context(superpoint=weights.synthetic_superpoint(1234), plnet_s1=os.path.join(GOLDEN, "plnet_s1.airfe"),
+                              max_batch=2, enc_chunk=2)
+    return _C["p"]
+
+
+@pytest.mark.parametrize("seed,nl", [(5, 300), (6, 1500), (7, 40), (8, 1)])
+def test_stage1_real_weights_vs_real_onnx_golden(seed, nl):
+    ctx = _ctx_plnet()
+    g = np.load(os.path.join(GOLDEN, "plnet_s1_golden.npz"))
+    s0 = synth.plnet_stage0_lines(seed, n_lines=nl)
+    la, sc = ctx.debug_plnet_s1(s0)
+    ref_la, ref_sc = g[f"s{seed}_n{nl}_lines_adjusted"], g[f"s{seed}_n{nl}_scores_line"]
+    diag(f"plnet_s1_{seed}_{nl}", m2_dev=la.shape[0], m2_ref=ref_la.shape[0],
+         score_err=float(np.abs(sc - ref_sc).max()) if la.shape[0] == ref_la.shape[0] else -1.0)
+    assert la.shape == ref_la.shape
+    np.testing.assert_array_equal(la, ref_la)                      # wireframe dedup + junction gather: index work, exact
+    np.testing.assert_allclose(sc, ref_sc, atol=5e-6, rtol=0)      # fp32 LOI pooling + MLP + softmax
+
+
+def test_no_kept_lines():
+    ctx = _ctx_plnet()
+    s0 = synth.plnet_stage0_lines(9, n_lines=1)
+    s0["iskeep"][:] = 0
+    la, sc = ctx.debug_plnet_s1(s0)
+    assert la.shape == (0, 4) and sc.shape == (0,)
+
+
+@pytest.mark.parametrize("seed,nl,lt,ll", [(5, 300, 0.75, 50.0), (6, 1500, 0.5, 10.0), (11, 3000, 0.2, 0.0)])
+def test_plnet_infer_lines_and_junctions(seed, nl, lt, ll):
+    ctx = api.Context(superpoint=weights.synthetic_superpoint(1234), plnet_s1=os.path.join(GOLDEN, "plnet_s1.airfe"),
+                      max_batch=2, enc_chunk=2, line_threshold=lt, line_length_threshold=ll)
+    img = synth.gabor_image(480, 752, seed)
+    s0 = synth.plnet_stage0_lines(seed, n_lines=nl)
+    feat, lines, junc = ctx.detect_plnet(img, s0, want_junctions=True)
+    heat, nms, desc = ctx.detector_maps(1)
+    ws, hs = np.float32(752 / 512), np.float32(480 / 512)
+    # oracle on the device's own stage-1 outputs (index / byte work must be exact)
+    la, sc = ctx.debug_plnet_s1(s0)
+    ref_lines, jmap = ref_post.line_filter(la, sc, 4, lt, ll)
+    ref_lines = ref_post.rescale_lines(ref_lines, ws, hs)
+    ref_junc = ref_post.junction_detector(nms[0], np.ascontiguousarray(desc[0].transpose(2, 0, 1)), jmap, 4, ws, hs)
+    diag(f"plnet_lines_{seed}", n_lines=lines.shape[0], n_ref=ref_lines.shape[0], n_junc=junc.shape[0], n_junc_ref=ref_junc.shape[0])
+    assert lines.shape == ref_lines.shape and lines.shape[0] > 0
+    np.testing.assert_array_equal(lines, ref_lines)
+    assert junc.shape == ref_junc.shape and junc.shape[0] > 0
+    np.testing.assert_array_equal(junc[:, :3], ref_junc[:, :3])
+    np.testing.assert_allclose(junc[:, 3:], ref_junc[:, 3:], atol=2e-6, rtol=0)
+    # the point branch is the same detector
+    np.testing.assert_array_equal(feat, ctx.detect_points(img))
+    # lines are appended, never cleared (plnet.cpp:544)
+    det = api.FeatureDetector(ctx)
+    acc = [(0.0, 0.0, 1.0, 1.0)]
+    ok, f, j = det.DetectLines(img, s0, acc, junction_detection=False)
+    assert ok and len(acc) == 1 + lines.shape[0] and j.shape == (259, 0)
+    ctx.close()
+
+
+def _features(n, seed):
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 256)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    f = np.zeros((n, 259), np.float32)
+    f[:, 0] = rng.uniform(0.01, 1, n)
+    f[:, 1] = rng.uniform(4, 748, n); f[:, 2] = rng.uniform(4, 476, n)
+    f[:, 3:] = d
+    return f
+
+
+@pytest.mark.parametrize("n0,n1,layers,iters", [(300, 280, 4, 20), (64, 65, 18, 100), (1, 3, 2, 5), (400, 400, 18, 100)])
+def test_superglue_vs_oracle(n0, n1, layers, iters):
+    w = weights.synthetic_superglue(1234, n_layers=layers)
+    ctx = api.Context(superglue=w, matcher=1, max_batch=2, sinkhorn_iters=iters)
+    f0 = ref_post.normalize_keypoints(_features(n0, n0 + layers), 752, 480, 0.7)
+    f1 = ref_post.normalize_keypoints(_features(n1, n1 + 7), 752, 480, 0.7)
+    z = ctx.superglue_scores(f0, f1)
+    ref = ref_nets.superglue_forward(w, f0[:, 1:3], f0[:, 0], f0[:, 3:], f1[:, 1:3], f1[:, 0], f1[:, 3:], n_layers=layers, iters=iters)
+    err = np.abs(z - ref)
+    i0, i1, m0, m1 = ctx.match_superglue(f0, f1)
+    d0, d1, dm0, dm1 = ref_post.superglue_decode(z, 0.2)          # decode on the DEVICE scores: exact index work
+    diag(f"sg_{n0}_{n1}_{layers}", max_err=err.max(), mean_err=err.mean(), ref_absmax=np.abs(ref).max(),
+         n_valid=int((i0 >= 0).sum()), nan=int(np.isnan(z).sum()))
+    assert not np.isnan(z).any()
+    np.testing.assert_array_equal(i0, d0)
+    np.testing.assert_array_equal(i1, d1)
+    np.testing.assert_allclose(m0, dm0, rtol=2e-6)
+    np.testing.assert_allclose(m1, dm1, rtol=2e-6)
+    assert err.max() <= 0.05 * max(1.0, np.abs(ref).mean())
+    # marginals: exp(Z) rows/cols sum to the prescribed masses after `iters` iterations (column step is last)
+    p = np.exp(z.astype(np.float64))
+    np.testing.assert_allclose(p[:, :n1].sum(0), 1.0, atol=2e-3)
+    ctx.close()
+
+
+def test_matching_points_superglue_branch():
+    w = weights.synthetic_superglue(1234, n_layers=2)
+    ctx = api.Context(superglue=w, matcher=1, max_batch=2, sinkhorn_iters=20)
+    pm = api.PointMatcher(ctx, 752, 480, 1)
+    a, b = _features(50, 1), _features(60, 2)
+    cnt, matches = pm.MatchingPoints(np.asfortranarray(a.T), np.asfortranarray(b.T))
+    na, nb = ref_post.normalize_keypoints(a, 752, 480, 0.7), ref_post.normalize_keypoints(b, 752, 480, 0.7)
+    z = ctx.superglue_scores(na, nb)
+    ref = ref_post.superglue_matches(*ref_post.superglue_decode(z, 0.2))
+    assert cnt == len(ref)
+    assert [(m[0], m[1]) for m in matches] == [(r[0], r[1]) for r in ref]
+    ctx.close()

@@ -26,6 +26,9 @@ CASES = [(5, 300), (6, 1500), (7, 40), (8, 1)]
 def main():
     m = onnx_lite.load(ONNX)
     w = {k: v for k, v in m.initializers.items() if k.startswith("fc2")}
+    w["sample_t"] = m.initializers["onnx::Mul_1141"].reshape(-1)
+    assert np.array_equal(w["sample_t"], weights.linspace_t())
+    assert np.array_equal(m.initializers["onnx::Mul_1142"].reshape(-1), np.float32(1) - w["sample_t"])
     weights.check_spec(w, weights.plnet_s1_spec())
     gd = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gd, exist_ok=True)
