@@ -32,7 +32,8 @@ def test_stage1_real_weights_vs_real_onnx_golden(seed, nl):
          score_err=float(np.abs(sc - ref_sc).max()) if la.shape[0] == ref_la.shape[0] else -1.0)
     assert la.shape == ref_la.shape
     np.testing.assert_array_equal(la, ref_la)                      # wireframe dedup + junction gather: index work, exact
-    np.testing.assert_allclose(sc, ref_sc, atol=5e-6, rtol=0)      # fp32 LOI pooling + MLP + softmax
+    # fp32 LOI pooling + 496-long fp32 dot products (fmaf order differs from the interpreter's BLAS) + softmax
+    np.testing.assert_allclose(sc, ref_sc, atol=5e-5, rtol=0)
 
 
 def test_no_kept_lines():
