@@ -168,6 +168,8 @@ struct airfe_ctx {
   float *logits = nullptr, *heat = nullptr, *heat_nms = nullptr, *nms_tmp = nullptr, *desc = nullptr;
   int *xtab = nullptr, *ytab = nullptr;
   float* lut = nullptr;
+  unsigned long long* cand = nullptr;   // [Bmax][512*512] detect_point candidate keys
+  int* cand_cnt = nullptr;
   int tab_w = -1, tab_h = -1;
   // host-API staging
   uint8_t* st_img = nullptr; size_t st_img_bytes = 0;
@@ -382,14 +384,18 @@ int load_superpoint(airfe_ctx* c, const char* path) {
   c->desc = dalloc<float>(c, cells * 256);
   c->heat = dalloc<float>(c, (size_t)B * R * R);
   c->heat_nms = dalloc<float>(c, (size_t)B * R * R);
-  c->nms_tmp = dalloc<float>(c, (size_t)4 * B * R * R);
+  const bool multipass_nms = c->cfg.nms_radius > 0 && c->cfg.nms_radius != 4;
+  c->nms_tmp = dalloc<float>(c, multipass_nms ? (size_t)4 * B * R * R : 1);
+  c->cand = dalloc<unsigned long long>(c, (size_t)B * R * R, false);
+  c->cand_cnt = dalloc<int>(c, B);
   c->xtab = dalloc<int>(c, (size_t)R * 4);
   c->ytab = dalloc<int>(c, (size_t)R * 4);
   std::vector<float> lut(256);
   for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);
   c->lut = dupload(c, lut);
   if (!c->img32 || !c->a1a || !c->a1b || !c->a2a || !c->a2b || !c->a3a || !c->a3b || !c->a4a || !c->a4b || !c->aPa ||
-      !c->aDa || !c->logits || !c->desc || !c->heat || !c->heat_nms || !c->nms_tmp || !c->xtab || !c->ytab || !c->lut)
+      !c->aDa || !c->logits || !c->desc || !c->heat || !c->heat_nms || !c->nms_tmp || !c->xtab || !c->ytab || !c->lut ||
+      !c->cand || !c->cand_cnt)
     return fail(c, "device allocation failed (detector arena)");
   c->has_sp = true;
   return 0;
@@ -651,16 +657,22 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
     { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024)); launch_gemm(c->prec, 256, false, g, st); }
     { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * 2048); launch_l2norm256(c->desc, cells, st); }
   }
-  const float* hsel = c->heat;
-  if (c->cfg.nms_radius > 0) {
+  const int ccap = R * R;
+  {
     ProfScope ps(c, ST_NMS, st, 0, (double)B * R * R * 8);
-    launch_simple_nms(c->heat, c->heat_nms, c->nms_tmp, B, R, R, c->cfg.nms_radius, st);
-    hsel = c->heat_nms;
+    if (c->cfg.nms_radius == 4) {
+      launch_nms4_candidates(c->heat, c->heat_nms, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand,
+                             c->cand_cnt, ccap, st);
+    } else if (c->cfg.nms_radius > 0) {
+      launch_simple_nms(c->heat, c->heat_nms, c->nms_tmp, B, R, R, c->cfg.nms_radius, st);
+      launch_candidates(c->heat_nms, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
+    } else {
+      launch_candidates(c->heat, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
+    }
   }
   {
-    ProfScope ps(c, ST_SELECT, st, 0, (double)B * R * R * 4);
-    launch_select_topk(hsel, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cfg.max_keypoints, cap, d_feat,
-                       d_n, st);
+    ProfScope ps(c, ST_SELECT, st, 0, (double)B * 8192 * 8);
+    launch_select_list(c->cand, c->cand_cnt, ccap, B, R, c->cfg.max_keypoints, cap, d_feat, d_n, st);
   }
   {
     ProfScope ps(c, ST_SAMPLE, st, 0, (double)B * c->cfg.max_keypoints * (4096 + 1036));

@@ -66,9 +66,16 @@ void launch_softmax_d2s(const float* logits, int ldl, float* heat, int B, int HC
 void launch_l2norm256(float* d, int rows, hipStream_t st);
 // SuperPoint simple_nms(radius) on fp32 [B][H][W]; tmp: 3 maps of the same size
 void launch_simple_nms(const float* heat, float* out, float* tmp, int B, int H, int W, int radius, hipStream_t st);
-// threshold + border + top-K (score desc, raster asc) / raster order when count <= K
+// fused simple_nms(4) in LDS: out = NMS'd map, and the detect_point candidates (score >= thr inside the border box)
+// are appended to cand [B][cand_cap] (49-bit keys) / cand_cnt [B]
+void launch_nms4_candidates(const float* heat, float* out, int B, int H, int W, float thr, int border,
+                            unsigned long long* cand, int* cand_cnt, int cand_cap, hipStream_t st);
+// candidates from a finished map (NMS off, or radius != 4 through the multi-pass launch_simple_nms)
+void launch_candidates(const float* heat, int B, int H, int W, float thr, int border, unsigned long long* cand,
+                       int* cand_cnt, int cand_cap, hipStream_t st);
+// exact top-K (score desc, raster asc) / raster order when count <= K, on the candidate list
 //   feat [B][cap][259] rows: score,x,y written (x,y in 512-space, unscaled); n_out [B]
-void launch_select_topk(const float* heat, int B, int H, int W, float thr, int border, int topk, int cap,
+void launch_select_list(const unsigned long long* cand, const int* cand_cnt, int cand_cap, int B, int W, int topk, int cap,
                         float* feat, int* n_out, hipStream_t st);
 // bilinear descriptor sampling + L2 norm (plnet.cpp:369-417), then x,y *= (w_scale,h_scale)
 //   desc fp32 [B][HC][WC][256]

@@ -194,140 +194,6 @@ void launch_simple_nms(const float* heat, float* out, float* tmp, int B, int H, 
   }
 }
 
-// =============================================================================== top-K selection
-// detect_point (src/plnet.cpp:309-355): candidates = score >= thr inside the (inclusive) border box.
-//   count <= K : all candidates in RASTER order (unsorted)
-//   count >  K : top K by score descending; ties by ascending raster index
-// One 1024-thread workgroup per image.  Exact: MSB radix select on the 49-bit key
-// (score_bits << 18 | (2^18-1 - idx)) then a bitonic sort of the <= 1024 survivors in LDS.
-typedef unsigned long long u64;
-
-__device__ __forceinline__ u64 kp_key(const float* hm, int i, int W, int H, float thr, int border) {
-  const float s = hm[i];
-  if (s < thr) return 0ull;
-  const int y = i / W, x = i - y * W;
-  if (x < border || x > W - border || y < border || y > H - border) return 0ull;
-  return (1ull << 49) | ((u64)__float_as_uint(s) << 18) | (u64)(0x3FFFF - i);
-}
-
-__global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restrict__ heat, int H, int W, float thr,
-                                                           int border, int topk, int cap, float* __restrict__ feat,
-                                                           int* __restrict__ n_out) {
-  __shared__ unsigned hist[2048];
-  __shared__ u64 sk[1024];
-  __shared__ unsigned wsum[16];
-  __shared__ u64 s_prefix;
-  __shared__ unsigned s_remaining, s_cnt, s_done;
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int N = H * W;
-  const float* hm = heat + (size_t)b * N;
-
-  u64 prefix = 0;          // determined high bits of the K-th largest key (bit 49 = valid flag, always 1)
-  unsigned remaining = (unsigned)topk;
-  bool take_all = false;
-  const int shifts[5] = {38, 27, 16, 5, 0};
-  const int nbits[5] = {11, 11, 11, 11, 5};
-  for (int pass = 0; pass < 5; ++pass) {
-    for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
-    __syncthreads();
-    const int sh = shifts[pass];
-    const u64 himask = ~((1ull << (sh + nbits[pass])) - 1ull);   // bits above this digit
-    const unsigned dmask = (1u << nbits[pass]) - 1u;
-    for (int i = tid; i < N; i += 1024) {
-      const u64 k = kp_key(hm, i, W, H, thr, border);
-      if (k && ((k & himask) == ((prefix | (1ull << 49)) & himask))) atomicAdd(&hist[(unsigned)(k >> sh) & dmask], 1u);
-    }
-    __syncthreads();
-    // suffix scan from the top bin: thread t owns bins (2047-2t) and (2046-2t)
-    const unsigned h0 = hist[2047 - 2 * tid], h1 = hist[2046 - 2 * tid];
-    unsigned v = h0 + h1, incl = v;
-    const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned t = __shfl_up(incl, o);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    unsigned woff = 0, tot = 0;
-    for (int w2 = 0; w2 < 16; ++w2) {
-      const unsigned t = wsum[w2];
-      if (w2 < wv) woff += t;
-      tot += t;
-    }
-    incl += woff;
-    const unsigned excl = incl - v;
-    if (pass == 0 && tot <= (unsigned)topk) take_all = true;   // uniform: every thread sees the same tot
-    if (!take_all) {
-      // the bin where the cumulative count (from the top) first reaches `remaining`
-      if (excl < remaining && remaining <= excl + h0) {
-        s_prefix = prefix | ((u64)(2047 - 2 * tid) << sh);
-        s_remaining = remaining - excl;
-        s_done = (h0 == remaining - excl) ? 1u : 0u;
-      } else if (excl + h0 < remaining && remaining <= incl) {
-        s_prefix = prefix | ((u64)(2046 - 2 * tid) << sh);
-        s_remaining = remaining - excl - h0;
-        s_done = (h1 == remaining - excl - h0) ? 1u : 0u;
-      }
-    }
-    __syncthreads();
-    if (take_all) break;
-    prefix = s_prefix;
-    remaining = s_remaining;
-    const bool done = s_done != 0;
-    __syncthreads();
-    if (done) break;   // every key under this prefix is selected; lower bits of the threshold stay 0
-  }
-
-  // ---- collect survivors into LDS
-  const u64 T = prefix | (1ull << 49);
-  if (tid == 0) s_cnt = 0;
-  sk[tid] = ~0ull;
-  __syncthreads();
-  for (int i = tid; i < N; i += 1024) {
-    const u64 k = kp_key(hm, i, W, H, thr, border);
-    if (k && (take_all || k >= T)) {
-      const unsigned slot = atomicAdd(&s_cnt, 1u);
-      if (slot < 1024) {
-        if (take_all) sk[slot] = ((u64)i << 32) | (u64)(unsigned)((k >> 18) & 0x7FFFFFFFull);   // ascending raster
-        else sk[slot] = ~k;                                                                    // descending key
-      }
-    }
-  }
-  __syncthreads();
-  const int n = min((int)s_cnt, min(topk, 1024));
-  // ---- bitonic sort (ascending) of 1024 keys
-  for (int k2 = 2; k2 <= 1024; k2 <<= 1) {
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      const int p = tid ^ j;
-      if (p > tid) {
-        const u64 a = sk[tid], c = sk[p];
-        const bool up = (tid & k2) == 0;
-        if ((a > c) == up) { sk[tid] = c; sk[p] = a; }
-      }
-      __syncthreads();
-    }
-  }
-  if (tid < n) {
-    const u64 e = sk[tid];
-    int idx;
-    unsigned sb;
-    if (take_all) { idx = (int)(e >> 32); sb = (unsigned)(e & 0xFFFFFFFFull); }
-    else { const u64 k = ~e; idx = 0x3FFFF - (int)(k & 0x3FFFFull); sb = (unsigned)((k >> 18) & 0x7FFFFFFFull); }
-    const int y = idx / W, x = idx - y * W;
-    float* f = feat + ((size_t)b * cap + tid) * 259;
-    f[0] = __uint_as_float(sb);
-    f[1] = (float)x;
-    f[2] = (float)y;
-  }
-  if (tid == 0) n_out[b] = n;
-}
-
-void launch_select_topk(const float* heat, int B, int H, int W, float thr, int border, int topk, int cap, float* feat,
-                        int* n_out, hipStream_t st) {
-  hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(1024), 0, st, heat, H, W, thr, border, topk, cap, feat, n_out);
-}
-
 // =============================================================================== descriptor sampling
 // extract_descriptors (src/plnet.cpp:369-417 == src/super_point.cpp:224-272) on a dense NHWC fp32 map,
 // one wave per keypoint (lane = 4 channels, 1 KiB coalesced row reads), then the final rescale

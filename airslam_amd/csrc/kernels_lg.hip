@@ -229,6 +229,19 @@ void launch_attention(int prec, const uint16_t* Q, const uint16_t* K, const uint
 }
 
 // =============================================================================== LayerNorm + GELU
+// exact-erf GELU 0.5 y (1 + erf(y / sqrt 2)) with a branch-free erf: Abramowitz & Stegun 7.1.26, |err| <= 1.5e-7
+// (far below the 2-byte storage the result is rounded to), instead of libm's branchy erff (9 divergent branches/row).
+__device__ __forceinline__ float gelu_exact(float y) {
+  const float x = fabsf(y) * 0.70710678118654752f;
+  const float t = 1.0f / fmaf(0.3275911f, x, 1.0f);
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erfa = 1.0f - poly * t * __expf(-x * x);
+  return 0.5f * y * (1.0f + copysignf(erfa, y));
+}
+
 template <class P>
 __global__ __launch_bounds__(256) void ln_gelu_kernel(uint16_t* __restrict__ h, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int M) {
@@ -246,11 +259,14 @@ __global__ __launch_bounds__(256) void ln_gelu_kernel(uint16_t* __restrict__ h, 
   for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; var += d * d; }
   var = wave_sum(var) * (1.0f / 512.0f);
   const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma + lane * 8), g1 = *reinterpret_cast<const float4*>(gamma + lane * 8 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(beta + lane * 8), b1 = *reinterpret_cast<const float4*>(beta + lane * 8 + 4);
+  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const int c = lane * 8 + e;
-    const float y = (v[e] - mean) * rstd * gamma[c] + beta[c];
-    v[e] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752f));
+    const float y = (v[e] - mean) * rstd * gg[e] + bb[e];
+    v[e] = gelu_exact(y);
   }
   *p = pack8<P>(v);
 }

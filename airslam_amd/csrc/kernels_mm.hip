@@ -355,12 +355,11 @@ static void gemm_launch_t(const GemmArgs& a, hipStream_t st) {
   }
   const int mb = a.M / BM;
   // split the feature blocks over grid.y when there are few row blocks, to fill 256 CUs
+  // Every workgroup re-stages its X tile, so split the feature blocks over grid.y only as far as needed to put
+  // one resident wave of workgroups on the 256 CUs (2 per CU when the tile leaves room for two).
+  const int target = 256 * ((LDS <= 80 * 1024) ? 2 : 1);
   int gy = 1;
-  if (mb < 512) {
-    gy = a.cb_total;
-    while (gy > 1 && (long)mb * gy > 4096) gy >>= 1;
-    while (a.cb_total % gy) --gy;
-  }
+  while (gy < a.cb_total && (mb * gy < target || a.cb_total % gy)) ++gy;
   dim3 grid((unsigned)mb, (unsigned)gy);
   hipLaunchKernelGGL(kfn, grid, dim3(256), LDS, st, a, a.cb_total / gy);
 }
@@ -368,7 +367,7 @@ static void gemm_launch_t(const GemmArgs& a, hipStream_t st) {
 template <class P>
 static void gemm_launch_p(int K, bool trans, const GemmArgs& a, hipStream_t st) {
   if (K == 512) {
-    if (trans) gemm_launch_t<P, 512, 1, true>(a, st); else gemm_launch_t<P, 512, 1, false>(a, st);
+    if (trans) gemm_launch_t<P, 512, 2, true>(a, st); else gemm_launch_t<P, 512, 2, false>(a, st);
   } else if (K == 256) {
     if (trans) gemm_launch_t<P, 256, 2, true>(a, st); else gemm_launch_t<P, 256, 2, false>(a, st);
   } else {

@@ -1,0 +1,279 @@
+// airfe — keypoint selection: fused simple_nms (radius 4) in LDS that also emits the compact candidate list, and the
+// exact top-K (detect_point, src/plnet.cpp:309-355) on that list.  HBM traffic: heat read once, NMS map written once,
+// a few thousand 8-byte candidates per image instead of ten 1 MB map passes + six full-map select passes.
+#include "common.h"
+#include "kernels.h"
+
+namespace airfe {
+
+typedef unsigned long long u64;
+
+// candidate key: valid bit | score bits (scores >= 0) | inverted raster index  => descending key order is
+// "score descending, then raster index ascending" (the tie rule of SURVEY.md B.1)
+__device__ __forceinline__ u64 make_key(float s, int idx) {
+  return (1ull << 49) | ((u64)(__float_as_uint(s) & 0x7FFFFFFFu) << 18) | (u64)(0x3FFFF - idx);
+}
+__device__ __forceinline__ bool in_border_box(int x, int y, int W, int H, int border) {
+  return !(x < border || x > W - border || y < border || y > H - border);      // upper bound INCLUSIVE (plnet.cpp:332)
+}
+
+// =============================================================================== fused simple_nms, radius 4
+constexpr int NT = 48;             // output tile
+constexpr int NH = 20;             // halo = 5 dependent 9x9 max-pools x radius 4
+constexpr int NR = NT + 2 * NH;    // 88: region held in LDS
+constexpr int NP = NR + 1;         // row pitch (odd => column walks are bank-conflict free)
+constexpr int NSTRIP = NR / 8;     // 11 strips of 8
+
+__device__ __forceinline__ void max9_of16(const float* x, float* o) {
+  float a[15], b[13], c[9];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) a[i] = fmaxf(x[i], x[i + 1]);
+#pragma unroll
+  for (int i = 0; i < 13; ++i) b[i] = fmaxf(a[i], a[i + 2]);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) c[i] = fmaxf(b[i], b[i + 4]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = fmaxf(c[i], x[i + 8]);       // max over x[i .. i+8]
+}
+
+template <class F>
+__device__ __forceinline__ void nms_hpass(F in, float* T) {
+  for (int s = threadIdx.x; s < NR * NSTRIP; s += 256) {
+    const int r = s % NR, c0 = (s / NR) * 8;
+    float x[16], o[8];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int cc = c0 - 4 + k;
+      x[k] = (cc >= 0 && cc < NR) ? in(r, cc) : -INFINITY;
+    }
+    max9_of16(x, o);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) T[r * NP + c0 + i] = o[i];
+  }
+}
+
+template <class G>
+__device__ __forceinline__ void nms_vpass(const float* T, G out) {
+  for (int s = threadIdx.x; s < NR * NSTRIP; s += 256) {
+    const int c = s % NR, r0 = (s / NR) * 8;
+    float x[16], o[8];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int rr = r0 - 4 + k;
+      x[k] = (rr >= 0 && rr < NR) ? T[rr * NP + c] : -INFINITY;
+    }
+    max9_of16(x, o);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out(r0 + i, c, o[i]);
+  }
+}
+
+// public SuperPoint simple_nms(scores, 4) on fp32 [B][H][W], + candidate emission for detect_point
+__global__ __launch_bounds__(256) void nms4_fused_kernel(const float* __restrict__ heat, float* __restrict__ out, int H, int W,
+                                                         int tiles_x, float thr, int border, u64* __restrict__ cand,
+                                                         int* __restrict__ cand_cnt, int cand_cap) {
+  extern __shared__ __attribute__((aligned(16))) char nms_smem[];
+  float* S = reinterpret_cast<float*>(nms_smem);
+  float* T = S + NR * NP;
+  unsigned char* M = reinterpret_cast<unsigned char*>(T + NR * NP);
+  unsigned char* P = M + NR * NP;
+  const int b = blockIdx.y, tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int gy0 = ty * NT - NH, gx0 = tx * NT - NH;
+  const float* hm = heat + (size_t)b * H * W;
+  for (int i = threadIdx.x; i < NR * NR; i += 256) {
+    const int r = i / NR, c = i - r * NR, gy = gy0 + r, gx = gx0 + c;
+    S[r * NP + c] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? hm[(size_t)gy * W + gx] : -INFINITY;
+  }
+  __syncthreads();
+  auto inimg = [&](int r, int c) { const int gy = gy0 + r, gx = gx0 + c; return gy >= 0 && gy < H && gx >= 0 && gx < W; };
+  // max_mask = scores == max_pool(scores)
+  nms_hpass([&](int r, int c) { return S[r * NP + c]; }, T);
+  __syncthreads();
+  nms_vpass(T, [&](int r, int c, float m) { M[r * NP + c] = inimg(r, c) && (S[r * NP + c] == m); });
+  __syncthreads();
+  for (int it = 0; it < 2; ++it) {
+    // supp_mask = max_pool(max_mask) > 0
+    nms_hpass([&](int r, int c) { return M[r * NP + c] ? 1.f : 0.f; }, T);
+    __syncthreads();
+    nms_vpass(T, [&](int r, int c, float m) { P[r * NP + c] = m > 0.f; });
+    __syncthreads();
+    // supp_scores = where(supp_mask, 0, scores); new_max_mask = supp_scores == max_pool(supp_scores)
+    nms_hpass([&](int r, int c) { return P[r * NP + c] ? 0.f : S[r * NP + c]; }, T);
+    __syncthreads();
+    nms_vpass(T, [&](int r, int c, float m) {
+      const bool p = P[r * NP + c];
+      const float ss = p ? 0.f : S[r * NP + c];
+      if (inimg(r, c) && !p && ss == m) M[r * NP + c] = 1;     // max_mask | (new_max_mask & ~supp_mask)
+    });
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < NT * NT; i += 256) {
+    const int r = i / NT + NH, c = i % NT + NH, gy = gy0 + r, gx = gx0 + c;
+    if (gy < H && gx < W) {
+      const float v = M[r * NP + c] ? S[r * NP + c] : 0.f;
+      const int idx = gy * W + gx;
+      out[(size_t)b * H * W + idx] = v;
+      if (!(v < thr) && in_border_box(gx, gy, W, H, border)) {
+        const int slot = atomicAdd(&cand_cnt[b], 1);
+        if (slot < cand_cap) cand[(size_t)b * cand_cap + slot] = make_key(v, idx);
+      }
+    }
+  }
+}
+
+void launch_nms4_candidates(const float* heat, float* out, int B, int H, int W, float thr, int border, u64* cand,
+                            int* cand_cnt, int cand_cap, hipStream_t st) {
+  const int tiles_x = (W + NT - 1) / NT, tiles_y = (H + NT - 1) / NT;
+  constexpr int LDS = NR * NP * (2 * (int)sizeof(float) + 2);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms4_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  (void)hipMemsetAsync(cand_cnt, 0, (size_t)B * sizeof(int), st);
+  hipLaunchKernelGGL(nms4_fused_kernel, dim3(tiles_x * tiles_y, B), dim3(256), LDS, st, heat, out, H, W, tiles_x, thr, border,
+                     cand, cand_cnt, cand_cap);
+}
+
+// plain threshold + border compaction of a heat map into the candidate list (NMS off, or after the multi-pass NMS)
+__global__ __launch_bounds__(256) void candidates_kernel(const float* __restrict__ heat, int H, int W, float thr, int border,
+                                                         u64* __restrict__ cand, int* __restrict__ cand_cnt, int cand_cap) {
+  const int b = blockIdx.y, N = H * W;
+  const float* hm = heat + (size_t)b * N;
+  for (int i0 = (blockIdx.x * 256 + threadIdx.x) * 4; i0 < N; i0 += gridDim.x * 256 * 4) {
+    const float4 v4 = *reinterpret_cast<const float4*>(hm + i0);
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k;
+      if (!(v[k] < thr)) {
+        const int y = i / W, x = i - y * W;
+        if (in_border_box(x, y, W, H, border)) {
+          const int slot = atomicAdd(&cand_cnt[b], 1);
+          if (slot < cand_cap) cand[(size_t)b * cand_cap + slot] = make_key(v[k], i);
+        }
+      }
+    }
+  }
+}
+
+void launch_candidates(const float* heat, int B, int H, int W, float thr, int border, u64* cand, int* cand_cnt, int cand_cap,
+                       hipStream_t st) {
+  (void)hipMemsetAsync(cand_cnt, 0, (size_t)B * sizeof(int), st);
+  hipLaunchKernelGGL(candidates_kernel, dim3(64, B), dim3(256), 0, st, heat, H, W, thr, border, cand, cand_cnt, cand_cap);
+}
+
+// =============================================================================== exact top-K on the candidate list
+// count <= K : all candidates in RASTER order (unsorted by score)       (plnet.cpp:348-353)
+// count >  K : top K by key descending = score descending, ties by ascending raster index
+// One 1024-thread workgroup per image: MSB radix select on the 49-bit key, then a bitonic sort of <= 1024 survivors.
+__global__ __launch_bounds__(1024) void select_list_kernel(const u64* __restrict__ cand, const int* __restrict__ cand_cnt,
+                                                           int cand_cap, int W, int topk, int cap, float* __restrict__ feat,
+                                                           int* __restrict__ n_out) {
+  __shared__ unsigned hist[2048];
+  __shared__ u64 sk[1024];
+  __shared__ unsigned wsum[16];
+  __shared__ u64 s_prefix;
+  __shared__ unsigned s_remaining, s_cnt, s_done;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int N = min(cand_cnt[b], cand_cap);
+  const u64* keys = cand + (size_t)b * cand_cap;
+
+  u64 prefix = 0;
+  unsigned remaining = (unsigned)topk;
+  const bool take_all = N <= topk;
+  if (!take_all) {
+    const int shifts[5] = {38, 27, 16, 5, 0};
+    const int nbits[5] = {11, 11, 11, 11, 5};
+    for (int pass = 0; pass < 5; ++pass) {
+      for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+      __syncthreads();
+      const int sh = shifts[pass];
+      const u64 himask = ~((1ull << (sh + nbits[pass])) - 1ull);
+      const unsigned dmask = (1u << nbits[pass]) - 1u;
+      const u64 want = (prefix | (1ull << 49)) & himask;
+      for (int i = tid; i < N; i += 1024) {
+        const u64 k = keys[i];
+        if ((k & himask) == want) atomicAdd(&hist[(unsigned)(k >> sh) & dmask], 1u);
+      }
+      __syncthreads();
+      const unsigned h0 = hist[2047 - 2 * tid], h1 = hist[2046 - 2 * tid];
+      const unsigned v = h0 + h1;
+      unsigned incl = v;
+      const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      if (lane == 63) wsum[wv] = incl;
+      __syncthreads();
+      unsigned woff = 0;
+      for (int w2 = 0; w2 < wv; ++w2) woff += wsum[w2];
+      incl += woff;
+      const unsigned excl = incl - v;
+      if (excl < remaining && remaining <= excl + h0) {
+        s_prefix = prefix | ((u64)(2047 - 2 * tid) << sh);
+        s_remaining = remaining - excl;
+        s_done = (h0 == remaining - excl) ? 1u : 0u;
+      } else if (excl + h0 < remaining && remaining <= incl) {
+        s_prefix = prefix | ((u64)(2046 - 2 * tid) << sh);
+        s_remaining = remaining - excl - h0;
+        s_done = (h1 == remaining - excl - h0) ? 1u : 0u;
+      }
+      __syncthreads();
+      prefix = s_prefix;
+      remaining = s_remaining;
+      const bool done = s_done != 0;
+      __syncthreads();
+      if (done) break;       // every key under this prefix is selected; the lower threshold bits stay 0
+    }
+  }
+  const u64 T = prefix | (1ull << 49);
+  if (tid == 0) s_cnt = 0;
+  sk[tid] = ~0ull;
+  __syncthreads();
+  for (int i = tid; i < N; i += 1024) {
+    const u64 k = keys[i];
+    if (take_all || k >= T) {
+      const unsigned slot = atomicAdd(&s_cnt, 1u);
+      if (slot < 1024) {
+        const u64 idx = 0x3FFFFull - (k & 0x3FFFFull);
+        sk[slot] = take_all ? ((idx << 32) | ((k >> 18) & 0x7FFFFFFFull)) : ~k;      // raster asc / key desc
+      }
+    }
+  }
+  __syncthreads();
+  const int n = min((int)s_cnt, min(topk, 1024));
+  for (int k2 = 2; k2 <= 1024; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      const int p = tid ^ j;
+      if (p > tid) {
+        const u64 a = sk[tid], c = sk[p];
+        const bool up = (tid & k2) == 0;
+        if ((a > c) == up) { sk[tid] = c; sk[p] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < n) {
+    const u64 e = sk[tid];
+    int idx;
+    unsigned sb;
+    if (take_all) { idx = (int)(e >> 32); sb = (unsigned)(e & 0x7FFFFFFFull); }
+    else { const u64 k = ~e; idx = 0x3FFFF - (int)(k & 0x3FFFFull); sb = (unsigned)((k >> 18) & 0x7FFFFFFFull); }
+    const int y = idx / W, x = idx - y * W;
+    float* f = feat + ((size_t)b * cap + tid) * 259;
+    f[0] = __uint_as_float(sb);
+    f[1] = (float)x;
+    f[2] = (float)y;
+  }
+  if (tid == 0) n_out[b] = n;
+}
+
+void launch_select_list(const u64* cand, const int* cand_cnt, int cand_cap, int B, int W, int topk, int cap, float* feat,
+                        int* n_out, hipStream_t st) {
+  hipLaunchKernelGGL(select_list_kernel, dim3(B), dim3(1024), 0, st, cand, cand_cnt, cand_cap, W, topk, cap, feat, n_out);
+}
+
+}  // namespace airfe
