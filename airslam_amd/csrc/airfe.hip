@@ -306,14 +306,15 @@ bool make_conv(airfe_ctx* c, const Pack& p, const std::string& name, int cin, in
 bool make_linear(airfe_ctx* c, const float* W, const float* bias, int K, int N, LinW& out, float scale = 1.f,
                  const std::function<int(int)>* src_row = nullptr, const std::function<int(int)>* src_col = nullptr) {
   const int Kp = (K + 63) / 64 * 64, cbt = (N + 63) / 64;
-  auto slabs = pack_slabs(cbt, Kp / 64, c->prec, [&](int feat, int s, int k) {
+  const int cbp = (cbt + 1) & ~1;        // the GEMM consumes feature blocks in pairs (128-feature tiles): pad with zeros
+  auto slabs = pack_slabs(cbp, Kp / 64, c->prec, [&](int feat, int s, int k) {
     const int kk = s * 64 + k;
     if (feat >= N || kk >= K) return 0.f;
     const int r = src_row ? (*src_row)(feat) : feat;
     const int cc = src_col ? (*src_col)(kk) : kk;
     return W[(size_t)r * K + cc] * scale;
   });
-  std::vector<float> bp((size_t)cbt * 64, 0.f);
+  std::vector<float> bp((size_t)cbp * 64, 0.f);
   for (int f = 0; f < N; ++f) bp[f] = bias[src_row ? (*src_row)(f) : f] * scale;
   out.w = dupload(c, slabs);
   out.b = dupload(c, bp);

@@ -238,103 +238,124 @@ __device__ __forceinline__ void gemm_store_run(const GemmArgs& a, int row, int c
   }
 }
 
-template <class P, int K, int MR, bool TRANS>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a, int cb_per_block) {
-  constexpr int BM = 64 * MR, ROWB = K * 2, CPR = K / 8, NS = K / 64;
+// Tile: 128 rows x 128 features per accumulation, K streamed in 64-wide chunks.  Both operands go through a
+// double-buffered LDS stage (X chunk [128][64] + two weight slabs = 32 KiB per stage) with the next chunk prefetched
+// into VGPRs while the current one feeds 32 MFMAs per wave.  A workgroup walks ALL its feature-block pairs for one row
+// tile in a single continuous (pair, k-chunk) stream, so the pipeline never drains between output tiles; X chunks are
+// re-read from L2 per pair (the 64-128 KiB row tile is L2-resident), which keeps every load overlapped with MFMAs —
+// the earlier "X-stationary" version staged the whole row tile up front and spent 70 % of its wave cycles waiting.
+template <class P, bool TRANS>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a, int K, int pairs_per_block) {
+  constexpr int STAGE = 32768;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* xs = smem;
-  char* ws = smem + BM * ROWB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * BM;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * 128;
+  const int NS = K >> 6;
+  const int pair0 = blockIdx.y * pairs_per_block;
+  const int total = pairs_per_block * NS;
 
-  for (int q = tid; q < BM * CPR; q += 256) {
-    const int r = q / CPR, c = q % CPR;
-    const int kk = c * 8;
-    const uint16_t* src = (kk < a.K1) ? a.X1 + (size_t)(m0 + r) * a.ld1 + kk
-                                      : a.X2 + (size_t)(m0 + r) * a.ld2 + (kk - a.K1);
-    const uint4 v = *reinterpret_cast<const uint4*>(src);
-    *reinterpret_cast<uint4*>(xs + r * ROWB + ((c ^ swz256(r)) << 4)) = v;
+  // per-thread staging coordinates: X chunk = 1024 16-byte pieces; thread t owns piece (t & 7) of rows (t >> 3) + 32 i
+  const int xr = tid >> 3, xc = tid & 7;
+  const int xdst0 = xr * 128 + ((xc ^ swz128(xr)) << 4);       // rows 32 apart share the swizzle (32 % 16 == 0)
+  const uint16_t* xp1 = a.X1 + (size_t)(m0 + xr) * a.ld1 + xc * 8;
+  const uint16_t* xp2 = a.X2 ? a.X2 + (size_t)(m0 + xr) * a.ld2 + xc * 8 : xp1;
+  uint4 px0, px1, px2, px3, pw0, pw1, pw2, pw3;   // named, not arrays: hipcc put the arrays in scratch
+  const int K1 = a.K1, ld1 = a.ld1, ld2 = a.ld2;
+  const uint4* wbase = reinterpret_cast<const uint4*>(a.Wp) + tid;
+#define AIRFE_LOAD_CHUNK(IT)                                                                                  \
+  {                                                                                                           \
+    const int pr_ = pair0 + (IT) / NS, s_ = (IT) % NS, k0_ = s_ * 64;                                         \
+    const bool first_ = k0_ < K1; /* K1 is a multiple of 64: the whole chunk is on one side */                \
+    const uint16_t* src_ = first_ ? xp1 + k0_ : xp2 + (k0_ - K1);                                             \
+    const size_t rstep_ = (size_t)32 * (first_ ? ld1 : ld2);                                                  \
+    px0 = *reinterpret_cast<const uint4*>(src_);                                                              \
+    px1 = *reinterpret_cast<const uint4*>(src_ + rstep_);                                                     \
+    px2 = *reinterpret_cast<const uint4*>(src_ + 2 * rstep_);                                                 \
+    px3 = *reinterpret_cast<const uint4*>(src_ + 3 * rstep_);                                                 \
+    const uint4* w0_ = wbase + ((size_t)(2 * pr_) * NS + s_) * 512;                                           \
+    pw0 = w0_[0]; pw1 = w0_[256]; pw2 = w0_[(size_t)NS * 512]; pw3 = w0_[(size_t)NS * 512 + 256];             \
   }
-
-  const int cb0 = blockIdx.y * cb_per_block;
-  const int total = cb_per_block * NS;
-  const uint4* wsrc = reinterpret_cast<const uint4*>(a.Wp) + (size_t)cb0 * NS * 512;
-  uint4 pre0 = wsrc[tid], pre1 = wsrc[256 + tid];
-  reinterpret_cast<uint4*>(ws)[tid] = pre0;
-  reinterpret_cast<uint4*>(ws)[256 + tid] = pre1;
+#define AIRFE_STORE_CHUNK(BUF)                                                                                \
+  {                                                                                                           \
+    char* xb_ = smem + (BUF) * STAGE;                                                                         \
+    uint4* wb_ = reinterpret_cast<uint4*>(xb_ + 16384);                                                       \
+    *reinterpret_cast<uint4*>(xb_ + xdst0) = px0;                                                             \
+    *reinterpret_cast<uint4*>(xb_ + xdst0 + 4096) = px1;                                                      \
+    *reinterpret_cast<uint4*>(xb_ + xdst0 + 8192) = px2;                                                      \
+    *reinterpret_cast<uint4*>(xb_ + xdst0 + 12288) = px3;                                                     \
+    wb_[tid] = pw0; wb_[256 + tid] = pw1; wb_[512 + tid] = pw2; wb_[768 + tid] = pw3;                         \
+  }
+  AIRFE_LOAD_CHUNK(0)
+  AIRFE_STORE_CHUNK(0)
   __syncthreads();
 
-  f32x4 acc[MR][4];
+  f32x4 acc[4][4];
   for (int it = 0; it < total; ++it) {
     const int s = it % NS;
     if (s == 0) {
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (it + 1 < total) {
-      pre0 = wsrc[(size_t)(it + 1) * 512 + tid];
-      pre1 = wsrc[(size_t)(it + 1) * 512 + 256 + tid];
-    }
-    const char* wb = ws + (it & 1) * SLAB_BYTES;
+    if (it + 1 < total) AIRFE_LOAD_CHUNK(it + 1)
+    const char* xb = smem + (it & 1) * STAGE;
+    const char* wb = xb + 16384 + wn * SLAB_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      typename P::vec8 wf[4], xf[MR];
+      typename P::vec8 wf[4], xf[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int rr = t * 16 + l15;
         wf[t] = lds_frag<P>(wb, rr * 128 + (((ks * 4 + g) ^ swz128(rr)) << 4));
       }
 #pragma unroll
-      for (int m = 0; m < MR; ++m) {
-        const int r = (wave * MR + m) * 16 + l15;
-        const int c = s * 8 + ks * 4 + g;
-        xf[m] = lds_frag<P>(xs, r * ROWB + ((c ^ swz256(r)) << 4));
+      for (int m = 0; m < 4; ++m) {
+        const int r = wm * 64 + m * 16 + l15;
+        xf[m] = lds_frag<P>(xb, r * 128 + (((ks * 4 + g) ^ swz128(r)) << 4));
       }
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           if constexpr (TRANS) acc[m][t] = P::mfma(xf[m], wf[t], acc[m][t]);
           else acc[m][t] = P::mfma(wf[t], xf[m], acc[m][t]);
         }
     }
-    if (it + 1 < total) {
-      char* wn = ws + ((it + 1) & 1) * SLAB_BYTES;
-      reinterpret_cast<uint4*>(wn)[tid] = pre0;
-      reinterpret_cast<uint4*>(wn)[256 + tid] = pre1;
-    }
+    if (it + 1 < total) AIRFE_STORE_CHUNK((it + 1) & 1)
     if (s == NS - 1) {
-      const int cb = cb0 + it / NS;
-      if constexpr (!TRANS) {
+      const int cb = 2 * (pair0 + it / NS) + wn;
+      if (cb < a.cb_total) {
+        if constexpr (!TRANS) {
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {
-          const int row = m0 + (wave * MR + m) * 16 + l15;
+          for (int m = 0; m < 4; ++m) {
+            const int row = m0 + wm * 64 + m * 16 + l15;
 #pragma unroll
-          for (int tp = 0; tp < 2; ++tp) {
-            float v[8];
+            for (int tp = 0; tp < 2; ++tp) {
+              float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[e] = acc[m][2 * tp][e];
-              v[4 + e] = acc[m][2 * tp + 1][e];
+              for (int e = 0; e < 4; ++e) {
+                v[e] = acc[m][2 * tp][e];
+                v[4 + e] = acc[m][2 * tp + 1][e];
+              }
+              gemm_store_run<P>(a, row, cb * 64 + tp * 32 + g * 8, v);
             }
-            gemm_store_run<P>(a, row, cb * 64 + tp * 32 + g * 8, v);
           }
-        }
-      } else {
-        // transposed store: lane (feature row l15 of tile t, g) holds tokens g*4..g*4+3 of m-tile m
+        } else {
+          // transposed store: lane (feature row l15 of tile t, g) holds tokens g*4..g*4+3 of m-tile m
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int co = cb * 64 + slab_row_to_feature(t * 16 + l15);
-          const float bv = a.bias[co];
-          const int h = co >> 6, d = co & 63;
+          for (int t = 0; t < 4; ++t) {
+            const int co = cb * 64 + slab_row_to_feature(t * 16 + l15);
+            const float bv = a.bias[co];
+            const int h = co >> 6, d = co & 63;
 #pragma unroll
-          for (int m = 0; m < MR; ++m) {
-            const int row0 = m0 + (wave * MR + m) * 16 + g * 4;
-            const int sq = row0 / a.Np, n = row0 - sq * a.Np;
-            uint16_t* o = reinterpret_cast<uint16_t*>(a.out) + (((size_t)sq * a.H + h) * 64 + d) * a.Np + n;
-            *reinterpret_cast<uint2*>(o) = pack4<P>(acc[m][t][0] + bv, acc[m][t][1] + bv, acc[m][t][2] + bv, acc[m][t][3] + bv);
+            for (int m = 0; m < 4; ++m) {
+              const int row0 = m0 + wm * 64 + m * 16 + g * 4;
+              const int sq = row0 / a.Np, n = row0 - sq * a.Np;
+              uint16_t* o = reinterpret_cast<uint16_t*>(a.out) + (((size_t)sq * a.H + h) * 64 + d) * a.Np + n;
+              *reinterpret_cast<uint2*>(o) = pack4<P>(acc[m][t][0] + bv, acc[m][t][1] + bv, acc[m][t][2] + bv, acc[m][t][3] + bv);
+            }
           }
         }
       }
@@ -343,40 +364,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a, int cb_per_block)
   }
 }
 
-template <class P, int K, int MR, bool TRANS>
-static void gemm_launch_t(const GemmArgs& a, hipStream_t st) {
-  constexpr int BM = 64 * MR;
-  constexpr int LDS = BM * K * 2 + 2 * SLAB_BYTES;
+template <class P, bool TRANS>
+static void gemm_launch_t(int K, const GemmArgs& a, hipStream_t st) {
+  constexpr int LDS = 2 * 32768;
   static bool attr_done = false;
-  auto kfn = gemm_kernel<P, K, MR, TRANS>;
+  auto kfn = gemm_kernel<P, TRANS>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
-  const int mb = a.M / BM;
-  // split the feature blocks over grid.y when there are few row blocks, to fill 256 CUs
-  // Every workgroup re-stages its X tile, so split the feature blocks over grid.y only as far as needed to put
-  // one resident wave of workgroups on the 256 CUs (2 per CU when the tile leaves room for two).
-  const int target = 256 * ((LDS <= 80 * 1024) ? 2 : 1);
+  const int mb = a.M / 128;
+  const int npairs = (a.cb_total + 1) / 2;      // the weight buffer is packed with an even number of feature blocks
+  // split the feature-block pairs over grid.y only as far as needed to keep two workgroups per CU resident
   int gy = 1;
-  while (gy < a.cb_total && (mb * gy < target || a.cb_total % gy)) ++gy;
+  while (gy < npairs && (mb * gy < 512 || npairs % gy)) ++gy;
   dim3 grid((unsigned)mb, (unsigned)gy);
-  hipLaunchKernelGGL(kfn, grid, dim3(256), LDS, st, a, a.cb_total / gy);
-}
-
-template <class P>
-static void gemm_launch_p(int K, bool trans, const GemmArgs& a, hipStream_t st) {
-  if (K == 512) {
-    if (trans) gemm_launch_t<P, 512, 2, true>(a, st); else gemm_launch_t<P, 512, 2, false>(a, st);
-  } else if (K == 256) {
-    if (trans) gemm_launch_t<P, 256, 2, true>(a, st); else gemm_launch_t<P, 256, 2, false>(a, st);
-  } else {
-    if (trans) gemm_launch_t<P, 128, 2, true>(a, st); else gemm_launch_t<P, 128, 2, false>(a, st);
-  }
+  hipLaunchKernelGGL(kfn, grid, dim3(256), LDS, st, a, K, npairs / gy);
 }
 
 void launch_gemm(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st) {
-  if (prec == 1) gemm_launch_p<PF16>(K, trans, a, st); else gemm_launch_p<PBF16>(K, trans, a, st);
+  if (prec == 1) {
+    if (trans) gemm_launch_t<PF16, true>(K, a, st); else gemm_launch_t<PF16, false>(K, a, st);
+  } else {
+    if (trans) gemm_launch_t<PBF16, true>(K, a, st); else gemm_launch_t<PBF16, false>(K, a, st);
+  }
 }
 
 }  // namespace airfe
