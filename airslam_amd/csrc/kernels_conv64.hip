@@ -1,0 +1,194 @@
+// airfe — weight-stationary persistent 3x3 convolution for the 64 -> 64 channel layers (conv1b, conv2a, conv2b:
+// 29 of the encoder's 44.5 GFLOP per image).
+//
+// Why a second conv kernel: rocprofv3 PMCs on the generic slab-streaming kernel (kernels_mm.hip) showed its waves
+// parked 35-53 % of the time (one barrier per 8 KiB weight slab, weights re-streamed from L2 for every 256-pixel
+// tile, tile staging not overlapped).  For Cin = Cout = 64 the whole filter bank is only 72 KiB of 2-byte data:
+//   * each wave keeps ALL 9 taps x 64 x 64 weights as MFMA A-fragments in registers (288 VGPRs; one wave per SIMD has
+//     the full 512-entry file) -> no weight traffic and no LDS weight reads inside the loop at all;
+//   * workgroups are persistent (one per CU) and walk 16x16-pixel tiles; the NEXT tile's halo'ed input (18x18x64 ch =
+//     40.5 KiB) is fetched with global_load_lds (LDS-DMA, no VGPRs, swizzle applied on the source address) into the
+//     other half of a double buffer while the current tile feeds 288 MFMAs per wave;
+//   * exactly one barrier per tile; LDS read traffic drops to the 4 pixel fragments per 16 MFMAs.
+#include "common.h"
+#include "kernels.h"
+
+namespace airfe {
+
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+
+constexpr int C64_TILE_BYTES = 18 * 18 * 128;     // 41472
+constexpr int C64_CHUNKS = 18 * 18 * 8;           // 2592 sixteen-byte pieces
+
+template <class P, bool POOL, int WREG_TAPS>
+__global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, W = a.W;
+  const size_t in_row = (size_t)(W + 2) * 128;
+  const size_t in_img = (size_t)(H + 2) * in_row;
+
+  // ---- weights: taps [0, WREG_TAPS) live in registers as MFMA A fragments, the rest stay resident in LDS behind the two
+  // input buffers (no per-slab barrier either way: they are loaded exactly once per workgroup)
+  constexpr int WT = WREG_TAPS > 0 ? WREG_TAPS : 1;
+  typename P::vec8 wreg[WT][2][4];
+  char* wlds = smem + 2 * C64_TILE_BYTES;
+  {
+    const char* wp = reinterpret_cast<const char*>(a.Wp);
+#pragma unroll
+    for (int tap = 0; tap < WREG_TAPS; ++tap)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int rr = t * 16 + l15;
+          const uint4 u = *reinterpret_cast<const uint4*>(wp + tap * SLAB_BYTES + rr * 128 + (((ks * 4 + g) ^ swz128(rr)) << 4));
+          wreg[tap][ks][t] = __builtin_bit_cast(typename P::vec8, u);
+        }
+    for (int q = tid; q < (9 - WREG_TAPS) * 512; q += 256)
+      reinterpret_cast<uint4*>(wlds)[q] = reinterpret_cast<const uint4*>(wp + WREG_TAPS * SLAB_BYTES)[q];
+  }
+  float bias[2][8];
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[tp][e] = a.bias[tp * 32 + g * 8 + e];
+
+  const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+  const int opad = a.out_pad;
+  const size_t orow = (size_t)(Wo + 2 * opad) * 64;
+  const int per_img = tiles_x * tiles_y;
+
+  // LDS-DMA of one halo tile: piece q' = j*256 + tid lands at LDS byte q'*16 (wave-uniform base + lane*16);
+  // the piece that belongs there is channel chunk c = c' ^ swz(p) of pixel p = q'/8  (swizzle on the SOURCE side)
+  auto stage = [&](int tile, int buf) {
+    const int b = tile / per_img, rem = tile - b * per_img;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const char* xin = reinterpret_cast<const char*>(a.X) + (size_t)b * in_img + (size_t)ty * 16 * in_row + (size_t)tx * 16 * 128;
+    char* dst = smem + buf * C64_TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      const int q = j * 256 + tid;
+      if (q < C64_CHUNKS) {
+        const int p = q >> 3, c = (q & 7) ^ swz128(p);
+        const int pr = p / 18, pc = p - pr * 18;
+        __builtin_amdgcn_global_load_lds((gas_ptr)(xin + (size_t)pr * in_row + pc * 128 + c * 16),
+                                         (las_ptr)(dst + (j * 256 + wave * 64) * 16), 16, 0, 0);
+      }
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) stage(tile, 0);
+  __syncthreads();
+
+  for (int i = 0; tile < ntiles; ++i, tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < ntiles) stage(next, (i + 1) & 1);
+    const char* xs = smem + (i & 1) * C64_TILE_BYTES;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        typename P::vec8 bf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int p = (wave * 4 + m + dy) * 18 + l15 + dx;
+          bf[m] = lds_frag<P>(xs, p * 128 + (((ks * 4 + g) ^ swz128(p)) << 4));
+        }
+        typename P::vec8 af[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (tap < WREG_TAPS) af[t] = wreg[tap < WREG_TAPS ? tap : 0][ks][t];
+          else {
+            const int rr = t * 16 + l15;
+            af[t] = lds_frag<P>(wlds, (tap - WREG_TAPS) * SLAB_BYTES + rr * 128 + (((ks * 4 + g) ^ swz128(rr)) << 4));
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[m][t] = P::mfma(af[t], bf[m], acc[m][t]);
+      }
+    }
+
+    // ---- epilogue: bias, ReLU, optional 2x2 max-pool, 16-byte stores (same mapping as conv3x3_kernel)
+    const int b = tile / per_img, rem = tile - b * per_img;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    uint16_t* ybase = a.Y + (size_t)b * (Ho + 2 * opad) * orow;
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      const int co0 = tp * 32 + g * 8;
+      if constexpr (!POOL) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = fmaxf(acc[m][2 * tp][e] + bias[tp][e], 0.f);
+            v[4 + e] = fmaxf(acc[m][2 * tp + 1][e] + bias[tp][4 + e], 0.f);
+          }
+          const int y = ty * 16 + wave * 4 + m, x = tx * 16 + l15;
+          *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * 64 + co0) = pack8<P>(v);
+        }
+      } else {
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = fmaxf(acc[2 * mp][2 * tp][e], acc[2 * mp + 1][2 * tp][e]);
+            v[4 + e] = fmaxf(acc[2 * mp][2 * tp + 1][e], acc[2 * mp + 1][2 * tp + 1][e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] = fmaxf(v[e], __shfl_xor(v[e], 1));
+            v[e] = fmaxf(v[e] + bias[tp][e], 0.f);
+          }
+          if ((l15 & 1) == 0) {
+            const int y = (ty * 16 + wave * 4) / 2 + mp, x = (tx * 16 + l15) / 2;
+            *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * 64 + co0) = pack8<P>(v);
+          }
+        }
+      }
+    }
+    __syncthreads();      // next tile's LDS-DMA has landed (vmcnt(0) before the barrier) and this buffer is free again
+  }
+}
+
+constexpr int C64_WREG_TAPS = 0;     // taps kept in registers (0 = all nine filter taps resident in LDS)
+
+template <class P, bool POOL>
+static void conv64ws_launch_t(const ConvArgs& a, hipStream_t st) {
+  constexpr int LDS = 2 * C64_TILE_BYTES + (9 - C64_WREG_TAPS) * SLAB_BYTES;
+  static bool attr_done = false;
+  auto kfn = conv64ws_kernel<P, POOL, C64_WREG_TAPS>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  const int tiles_x = a.W / 16, tiles_y = a.H / 16;
+  const int ntiles = tiles_x * tiles_y * a.B;
+  const int grid = ntiles < 256 ? ntiles : 256;
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), LDS, st, a, tiles_x, tiles_y, ntiles);
+}
+
+// requires CIN == COUT == 64, relu, H % 16 == 0, W % 16 == 0
+void launch_conv64ws(int prec, const ConvArgs& a, hipStream_t st) {
+  if (prec == 1) {
+    if (a.pool) conv64ws_launch_t<PF16, true>(a, st); else conv64ws_launch_t<PF16, false>(a, st);
+  } else {
+    if (a.pool) conv64ws_launch_t<PBF16, true>(a, st); else conv64ws_launch_t<PBF16, false>(a, st);
+  }
+}
+
+}  // namespace airfe

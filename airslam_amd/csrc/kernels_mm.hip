@@ -179,6 +179,10 @@ static void conv_launch_p(const ConvArgs& a, hipStream_t st) {
 }
 
 void launch_conv3x3(int prec, const ConvArgs& a, hipStream_t st) {
+  if (a.CIN == 64 && a.COUT == 64 && a.relu && (a.H % 16) == 0 && (a.W % 16) == 0) {
+    launch_conv64ws(prec, a, st);      // weight-stationary persistent kernel (kernels_conv64.hip)
+    return;
+  }
   if (prec == 1) conv_launch_p<PF16>(a, st); else conv_launch_p<PBF16>(a, st);
 }
 
