@@ -18,6 +18,18 @@ namespace airfe {
 typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* las_ptr;
 
+// LDS-DMA issued from inline asm so that hipcc does not see it: with the builtin the compiler inserts `s_waitcnt vmcnt(0)`
+// before the very next ds_read (it cannot prove the DMA target and the tile being read are different buffers), which
+// serialises the prefetch with the compute it is meant to overlap.  The wait is placed by hand before the tile barrier.
+// (M0 = wave-uniform LDS byte address; data lands at M0 + lane*16.  Recipe: cdna_hip_programming.md §5.7.)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_off)
+               : "memory");
+}
+
 constexpr int C64_TILE_BYTES = 18 * 18 * 128;     // 41472
 constexpr int C64_CHUNKS = 18 * 18 * 8;           // 2592 sixteen-byte pieces
 
@@ -63,25 +75,26 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
 
   // LDS-DMA of one halo tile: piece q' = j*256 + tid lands at LDS byte q'*16 (wave-uniform base + lane*16);
   // the piece that belongs there is channel chunk c = c' ^ swz(p) of pixel p = q'/8  (swizzle on the SOURCE side)
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(las_ptr)smem);
   auto stage = [&](int tile, int buf) {
     const int b = tile / per_img, rem = tile - b * per_img;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const char* xin = reinterpret_cast<const char*>(a.X) + (size_t)b * in_img + (size_t)ty * 16 * in_row + (size_t)tx * 16 * 128;
-    char* dst = smem + buf * C64_TILE_BYTES;
+    const unsigned dst = lds_base + buf * C64_TILE_BYTES + wave * 1024;
 #pragma unroll
     for (int j = 0; j < 11; ++j) {
       const int q = j * 256 + tid;
       if (q < C64_CHUNKS) {
         const int p = q >> 3, c = (q & 7) ^ swz128(p);
         const int pr = p / 18, pc = p - pr * 18;
-        __builtin_amdgcn_global_load_lds((gas_ptr)(xin + (size_t)pr * in_row + pc * 128 + c * 16),
-                                         (las_ptr)(dst + (j * 256 + wave * 64) * 16), 16, 0, 0);
+        glds16(xin + (size_t)pr * in_row + pc * 128 + c * 16, dst + j * 4096);
       }
     }
   };
 
   int tile = blockIdx.x;
   if (tile < ntiles) stage(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int i = 0; tile < ntiles; ++i, tile += gridDim.x) {
@@ -161,7 +174,8 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
         }
       }
     }
-    __syncthreads();      // next tile's LDS-DMA has landed (vmcnt(0) before the barrier) and this buffer is free again
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile's LDS-DMA has landed
+    __syncthreads();                                   // ... everyone's has, and the buffer just read is free again
   }
 }
 
