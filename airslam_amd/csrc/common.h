@@ -88,6 +88,26 @@ __device__ __forceinline__ typename P::vec8 lds_frag(const char* base, int byte_
   return __builtin_bit_cast(typename P::vec8, u);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Full-line epilogue stores.  After the swapped-operand MFMA, lane (j = lane&15, g = lane>>4) holds two 16-byte
+// chunks of pixel/row j: A = bytes [g*16, +16) and B = bytes [64 + g*16, +16) of that pixel's 128-byte feature run.
+// Storing A then B makes every store instruction touch 16 different 128-byte lines, half a line each (measured:
+// the conv epilogue alone ran at ~1 TB/s).  One DPP row-rotate by 8 swaps chunks between lanes j and j^8 so that
+//   r1 of lane j goes to pixel (j & 7)     at byte (j < 8 ? 0 : 64) + g*16
+//   r2 of lane j goes to pixel 8 + (j & 7) at the same byte offset
+// i.e. each store instruction now writes 8 complete 128-byte lines.
+__device__ __forceinline__ uint32_t dpp_ror8(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128 /* row_ror:8 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ void line_exchange(uint4& a, uint4& b, int l15) {
+  const bool lo = l15 < 8;
+  const uint4 x = lo ? b : a;
+  uint4 y;
+  y.x = dpp_ror8(x.x); y.y = dpp_ror8(x.y); y.z = dpp_ror8(x.z); y.w = dpp_ror8(x.w);
+  if (lo) b = y; else { a = y; }
+}
+// after line_exchange: for lanes >= 8 `a` holds the partner pixel's B chunk and `b` its own B; see call sites
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -75,22 +75,42 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
 
   // LDS-DMA of one halo tile: piece q' = j*256 + tid lands at LDS byte q'*16 (wave-uniform base + lane*16);
   // the piece that belongs there is channel chunk c = c' ^ swz(p) of pixel p = q'/8  (swizzle on the SOURCE side)
+  // loop-invariant per-thread offsets, computed ONCE (PMCs showed 2.8 VALU instructions per MFMA when the swizzled LDS
+  // addresses and the DMA source addresses were re-derived inside the tile loop)
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(las_ptr)smem);
+  int goff[11];
+#pragma unroll
+  for (int j = 0; j < 11; ++j) {
+    const int q = min(j * 256 + tid, C64_CHUNKS - 1);
+    const int p = q >> 3, c = (q & 7) ^ swz128(p);
+    const int pr = p / 18, pc = p - pr * 18;
+    goff[j] = pr * (int)in_row + pc * 128 + c * 16;
+  }
+  const bool last_piece = 10 * 256 + tid < C64_CHUNKS;
   auto stage = [&](int tile, int buf) {
     const int b = tile / per_img, rem = tile - b * per_img;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const char* xin = reinterpret_cast<const char*>(a.X) + (size_t)b * in_img + (size_t)ty * 16 * in_row + (size_t)tx * 16 * 128;
     const unsigned dst = lds_base + buf * C64_TILE_BYTES + wave * 1024;
 #pragma unroll
-    for (int j = 0; j < 11; ++j) {
-      const int q = j * 256 + tid;
-      if (q < C64_CHUNKS) {
-        const int p = q >> 3, c = (q & 7) ^ swz128(p);
-        const int pr = p / 18, pc = p - pr * 18;
-        glds16(xin + (size_t)pr * in_row + pc * 128 + c * 16, dst + j * 4096);
-      }
-    }
+    for (int j = 0; j < 10; ++j) glds16(xin + goff[j], dst + j * 4096);
+    if (last_piece) glds16(xin + goff[10], dst + 10 * 4096);
   };
+  // fragment read offsets inside a tile buffer: pixel rows wave*4 + {0..5}, column shifts {0,1,2}; ks = 1 is XOR 64
+  int boff[6][3];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int p = (wave * 4 + r) * 18 + l15 + dx;
+      boff[r][dx] = p * 128 + ((g ^ swz128(p)) << 4);
+    }
+  int aoff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int rr = t * 16 + l15;
+    aoff[t] = 2 * C64_TILE_BYTES + rr * 128 + ((g ^ swz128(rr)) << 4);
+  }
 
   int tile = blockIdx.x;
   if (tile < ntiles) stage(tile, 0);
@@ -100,78 +120,78 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
   for (int i = 0; tile < ntiles; ++i, tile += gridDim.x) {
     const int next = tile + gridDim.x;
     if (next < ntiles) stage(next, (i + 1) & 1);
-    const char* xs = smem + (i & 1) * C64_TILE_BYTES;
 
     f32x4 acc[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 18 k-steps (9 taps x 2 half-channel groups), software-pipelined by hand: the fragments of step s+1 are requested
+    // BEFORE the 16 MFMAs of step s, so with one wave per SIMD the LDS latency hides under ~256 MFMA cycles
+    typename P::vec8 af[2][4], bf[2][4];
+    const int xoff = (i & 1) * C64_TILE_BYTES;
+    auto load_step = [&](int step, int set) {
+      const int tap = step >> 1, ks = step & 1;
+      const int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
+      for (int m = 0; m < 4; ++m) bf[set][m] = lds_frag<P>(smem, (boff[m + dy][dx] ^ (ks << 6)) + xoff);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        typename P::vec8 bf[4];
+      for (int t = 0; t < 4; ++t) af[set][t] = lds_frag<P>(smem, (aoff[t] ^ (ks << 6)) + tap * SLAB_BYTES);
+    };
+    load_step(0, 0);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int p = (wave * 4 + m + dy) * 18 + l15 + dx;
-          bf[m] = lds_frag<P>(xs, p * 128 + (((ks * 4 + g) ^ swz128(p)) << 4));
-        }
-        typename P::vec8 af[4];
+    for (int step = 0; step < 18; ++step) {
+      if (step + 1 < 18) load_step(step + 1, (step + 1) & 1);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (tap < WREG_TAPS) af[t] = wreg[tap < WREG_TAPS ? tap : 0][ks][t];
-          else {
-            const int rr = t * 16 + l15;
-            af[t] = lds_frag<P>(wlds, (tap - WREG_TAPS) * SLAB_BYTES + rr * 128 + (((ks * 4 + g) ^ swz128(rr)) << 4));
-          }
-        }
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[m][t] = P::mfma(af[t], bf[m], acc[m][t]);
-      }
+        for (int t = 0; t < 4; ++t) acc[m][t] = P::mfma(af[step & 1][t], bf[step & 1][m], acc[m][t]);
     }
 
     // ---- epilogue: bias, ReLU, optional 2x2 max-pool, 16-byte stores (same mapping as conv3x3_kernel)
     const int b = tile / per_img, rem = tile - b * per_img;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     uint16_t* ybase = a.Y + (size_t)b * (Ho + 2 * opad) * orow;
+    if constexpr (!POOL) {
 #pragma unroll
-    for (int tp = 0; tp < 2; ++tp) {
-      const int co0 = tp * 32 + g * 8;
-      if constexpr (!POOL) {
+      for (int m = 0; m < 4; ++m) {
+        float v0[8], v1[8];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = fmaxf(acc[m][2 * tp][e] + bias[tp][e], 0.f);
-            v[4 + e] = fmaxf(acc[m][2 * tp + 1][e] + bias[tp][4 + e], 0.f);
-          }
-          const int y = ty * 16 + wave * 4 + m, x = tx * 16 + l15;
-          *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * 64 + co0) = pack8<P>(v);
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = fmaxf(acc[m][0][e] + bias[0][e], 0.f);
+          v0[4 + e] = fmaxf(acc[m][1][e] + bias[0][4 + e], 0.f);
+          v1[e] = fmaxf(acc[m][2][e] + bias[1][e], 0.f);
+          v1[4 + e] = fmaxf(acc[m][3][e] + bias[1][4 + e], 0.f);
         }
-      } else {
+        uint4 r1 = pack8<P>(v0), r2 = pack8<P>(v1);
+        line_exchange(r1, r2, l15);                      // full 128-byte lines per store instruction (common.h)
+        const int y = ty * 16 + wave * 4 + m, x = tx * 16 + (l15 & 7);
+        char* o = reinterpret_cast<char*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * 64) + (l15 < 8 ? 0 : 64) + g * 16;
+        *reinterpret_cast<uint4*>(o) = r1;
+        *reinterpret_cast<uint4*>(o + 8 * 128) = r2;
+      }
+    } else {
 #pragma unroll
-        for (int mp = 0; mp < 2; ++mp) {
-          float v[8];
+      for (int mp = 0; mp < 2; ++mp) {
+        float v0[8], v1[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = fmaxf(acc[2 * mp][2 * tp][e], acc[2 * mp + 1][2 * tp][e]);
-            v[4 + e] = fmaxf(acc[2 * mp][2 * tp + 1][e], acc[2 * mp + 1][2 * tp + 1][e]);
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            v[e] = fmaxf(v[e], __shfl_xor(v[e], 1));
-            v[e] = fmaxf(v[e] + bias[tp][e], 0.f);
-          }
-          if ((l15 & 1) == 0) {
-            const int y = (ty * 16 + wave * 4) / 2 + mp, x = (tx * 16 + l15) / 2;
-            *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * 64 + co0) = pack8<P>(v);
-          }
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = fmaxf(acc[2 * mp][0][e], acc[2 * mp + 1][0][e]);
+          v0[4 + e] = fmaxf(acc[2 * mp][1][e], acc[2 * mp + 1][1][e]);
+          v1[e] = fmaxf(acc[2 * mp][2][e], acc[2 * mp + 1][2][e]);
+          v1[4 + e] = fmaxf(acc[2 * mp][3][e], acc[2 * mp + 1][3][e]);
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v0[e] = fmaxf(fmaxf(v0[e], __shfl_xor(v0[e], 1)) + bias[0][e], 0.f);
+          v1[e] = fmaxf(fmaxf(v1[e], __shfl_xor(v1[e], 1)) + bias[1][e], 0.f);
+        }
+        // both lanes of a pair hold the pooled pixel: the even lane stores its first 64 bytes, the odd lane the rest,
+        // so ONE store instruction writes 8 complete 128-byte lines
+        const uint4 r = (l15 & 1) ? pack8<P>(v1) : pack8<P>(v0);
+        const int y = (ty * 16 + wave * 4) / 2 + mp, x = tx * 8 + (l15 >> 1);
+        char* o = reinterpret_cast<char*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * 64) + (l15 & 1) * 64 + g * 16;
+        *reinterpret_cast<uint4*>(o) = r;
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile's LDS-DMA has landed

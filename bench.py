@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=752)
     ap.add_argument("--max-keypoints", type=int, default=400)
-    ap.add_argument("--chunk", type=int, default=4)
+    ap.add_argument("--chunk", type=int, default=32, help="images per pass through the full-resolution conv layers")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--cpu-pairs", type=int, default=3, help="CPU-baseline sample size (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
