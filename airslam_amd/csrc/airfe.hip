@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -156,6 +157,7 @@ struct airfe_ctx {
   int prec = 0;
   int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
   bool has_sp = false, has_lg = false;
+  bool fuse_conv1a = false;      // AIRFE_FUSE_CONV1A=1: experimental conv1a-in-conv1b fusion (correct, not yet faster)
 
   // detector weights
   float *c1a_w = nullptr, *c1a_b = nullptr;
@@ -629,11 +631,23 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
       ProfScope ps(c, ST_PREPROCESS, st, 0, (double)cb * ((double)h * w + (double)R * R * 4));
       launch_preprocess(d_gray + (size_t)c0 * img_stride, cb, h, w, stride, img_stride, c->xtab, c->ytab, c->lut, c->img32, R, R, st);
     }
-    {
-      ProfScope ps(c, ST_CONV1A, st, 2.0 * cb * R * R * 9 * 64, (double)cb * R * R * (4 + 128));
-      launch_conv1a(c->prec, c->img32, c->c1a_w, c->c1a_b, c->a1a, cb, R, R, st);
+    if (c->fuse_conv1a) {
+      // conv1a (Cin = 1) fused into the persistent conv1b kernel: its 64-channel full-resolution output never
+      // reaches HBM (kernels_conv64.hip).  FLOPs/bytes below are the algorithmic ones of conv1a + conv1b.
+      ConvArgs a;
+      a.Wp = c->c1b.w; a.bias = c->c1b.b; a.Y = c->a1b; a.B = cb; a.H = R; a.W = R; a.CIN = 64; a.COUT = 64;
+      a.pool = 1; a.out_pad = 1; a.relu = 1;
+      a.img = c->img32; a.w1a = c->c1a_w; a.b1a = c->c1a_b;
+      const double px = (double)cb * R * R;
+      ProfScope ps(c, ST_CONV3X3_C64, st, 2.0 * px * 9 * 64 + 2.0 * px * 64 * 64 * 9, px * 4 + px / 4 * 128 + 9.0 * 64 * 64 * 2);
+      launch_conv64ws(c->prec, a, st);
+    } else {
+      {
+        ProfScope ps(c, ST_CONV1A, st, 2.0 * cb * R * R * 9 * 64, (double)cb * R * R * (4 + 128));
+        launch_conv1a(c->prec, c->img32, c->c1a_w, c->c1a_b, c->a1a, cb, R, R, st);
+      }
+      run_conv(c, c->c1b, c->a1a, c->a1b, cb, R, R, 1, 1, st);
     }
-    run_conv(c, c->c1b, c->a1a, c->a1b, cb, R, R, 1, 1, st);
     run_conv(c, c->c2a, c->a1b, c->a2a, cb, R / 2, R / 2, 0, 1, st);
     run_conv(c, c->c2b, c->a2a, c->a2b + (size_t)c0 * (R / 4 + 2) * (R / 4 + 2) * 64, cb, R / 2, R / 2, 1, 1, st);
   }
@@ -828,6 +842,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   c->chunk = std::min(std::max(cfg->enc_chunk, 1), c->Bmax);
   c->Pmax = c->Bmax;
   c->Np = (cfg->max_keypoints + 63) / 64 * 64;
+  c->fuse_conv1a = getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) != 0;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return fail(nullptr, "airfe_create: stream creation failed");

@@ -30,10 +30,19 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_off) {
                : "memory");
 }
 
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_off)
+               : "memory");
+}
+
+constexpr int C64_PATCH = 20 * 20;                 // fused conv1a: fp32 image patch per tile (halo 2)
 constexpr int C64_TILE_BYTES = 18 * 18 * 128;     // 41472
 constexpr int C64_CHUNKS = 18 * 18 * 8;           // 2592 sixteen-byte pieces
 
-template <class P, bool POOL, int WREG_TAPS>
+template <class P, bool POOL, int WREG_TAPS, bool FUSE1A>
 __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
@@ -112,14 +121,102 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
     aoff[t] = 2 * C64_TILE_BYTES + rr * 128 + ((g ^ swz128(rr)) << 4);
   }
 
+  // ---- fused conv1a (Cin = 1): the 18x18x64 input tile of conv1b is COMPUTED here from a 20x20 image patch instead of
+  // being read back from HBM (33.5 MB/image of intermediate traffic and one kernel disappear).  K = 9 taps are padded
+  // to one 32-wide fp16 MFMA step: lanes g=0 carry taps 0..7, g=1 tap 8, g=2,3 zeros.
+  [[maybe_unused]] f16x8 w1[4];
+  [[maybe_unused]] float bias1[2][8];
+  [[maybe_unused]] const unsigned pbase = lds_base + 2 * C64_TILE_BYTES + 9 * SLAB_BYTES;
+  [[maybe_unused]] const float* pbuf = reinterpret_cast<const float*>(smem + 2 * C64_TILE_BYTES + 9 * SLAB_BYTES);
+  if constexpr (FUSE1A) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int co = slab_row_to_feature(t * 16 + l15);
+      f16x8 w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = g * 8 + e;
+        w[e] = (_Float16)(k < 9 ? a.w1a[co * 9 + k] : 0.f);
+      }
+      w1[t] = w;
+    }
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias1[tp][e] = a.b1a[tp * 32 + g * 8 + e];
+  }
+  // 20x20 fp32 patch of tile `t` -> pbuf[buf] by 4-byte LDS-DMA (image buffer has a 1-pixel zero border; rows/cols that
+  // fall outside even that are clamped: they only feed halo pixels that lie outside the image and are forced to 0)
+  auto stage_patch = [&](int t, int buf) {
+    const int b = t / per_img, rem = t - b * per_img;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const float* img = a.img + (size_t)b * (H + 2) * (W + 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = j * 256 + tid;
+      if (q < C64_PATCH) {
+        const int r = q / 20, cc = q - r * 20;
+        const int gy = min(max(ty * 16 - 1 + r, 0), H + 1), gx = min(max(tx * 16 - 1 + cc, 0), W + 1);
+        glds4(img + (size_t)gy * (W + 2) + gx, pbase + buf * (C64_PATCH * 4) + (j * 256 + wave * 64) * 4);
+      }
+    }
+  };
+  auto produce = [&](int t, int buf, int xbuf) {
+    const int b = t / per_img, rem = t - b * per_img;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    (void)b;
+    const float* pb = pbuf + buf * C64_PATCH;
+    for (int k = wave; k < 21; k += 4) {
+      const int p = k * 16 + l15, pc_ = min(p, 323);
+      const int py = pc_ / 18, px = pc_ - py * 18;
+      f16x8 bfr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bfr[e] = (_Float16)0.f;
+      if (g == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bfr[e] = (_Float16)pb[(py + e / 3) * 20 + px + e % 3];
+      } else if (g == 1) {
+        bfr[0] = (_Float16)pb[(py + 2) * 20 + px + 2];
+      }
+      f32x4 c1[4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) c1[tt] = PF16::mfma(w1[tt], bfr, f32x4{0.f, 0.f, 0.f, 0.f});
+      const int gy = ty * 16 - 1 + py, gx = tx * 16 - 1 + px;
+      const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      if (p < 324) {
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = inside ? fmaxf(c1[2 * tp][e] + bias1[tp][e], 0.f) : 0.f;
+            v[4 + e] = inside ? fmaxf(c1[2 * tp + 1][e] + bias1[tp][4 + e], 0.f) : 0.f;
+          }
+          *reinterpret_cast<uint4*>(smem + xbuf * C64_TILE_BYTES + p * 128 + (((tp * 4 + g) ^ swz128(p)) << 4)) = pack8<P>(v);
+        }
+      }
+    }
+  };
+
   int tile = blockIdx.x;
-  if (tile < ntiles) stage(tile, 0);
+  if constexpr (FUSE1A) {
+    if (tile < ntiles) stage_patch(tile, 0);
+  } else {
+    if (tile < ntiles) stage(tile, 0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int i = 0; tile < ntiles; ++i, tile += gridDim.x) {
     const int next = tile + gridDim.x;
-    if (next < ntiles) stage(next, (i + 1) & 1);
+    if constexpr (FUSE1A) {
+      if (next < ntiles) stage_patch(next, (i + 1) & 1);
+      produce(tile, i & 1, i & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();          // conv1a tile complete (all waves) and the next patch has landed
+    } else {
+      if (next < ntiles) stage(next, (i + 1) & 1);
+    }
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -148,6 +245,13 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
         for (int t = 0; t < 4; ++t) acc[m][t] = P::mfma(af[step & 1][t], bf[step & 1][m], acc[m][t]);
     }
 
+    // The wait for the next tile's LDS-DMA sits HERE, before this tile's output stores are issued: vmcnt also counts
+    // stores, and waiting behind them exposed a full HBM write latency per tile (ablation: the kernel took 2.4 ms/step
+    // with neither MFMAs nor DMA).  Now the stores get the whole next tile to retire.
+    if constexpr (!FUSE1A) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile's LDS-DMA has landed
+      __syncthreads();                                   // ... everyone's has, and the buffer just read is free again
+    }
     // ---- epilogue: bias, ReLU, optional 2x2 max-pool, 16-byte stores (same mapping as conv3x3_kernel)
     const int b = tile / per_img, rem = tile - b * per_img;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
@@ -194,18 +298,17 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
         *reinterpret_cast<uint4*>(o) = r;
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile's LDS-DMA has landed
-    __syncthreads();                                   // ... everyone's has, and the buffer just read is free again
+
   }
 }
 
 constexpr int C64_WREG_TAPS = 0;     // taps kept in registers (0 = all nine filter taps resident in LDS)
 
-template <class P, bool POOL>
+template <class P, bool POOL, bool FUSE1A>
 static void conv64ws_launch_t(const ConvArgs& a, hipStream_t st) {
-  constexpr int LDS = 2 * C64_TILE_BYTES + (9 - C64_WREG_TAPS) * SLAB_BYTES;
+  constexpr int LDS = 2 * C64_TILE_BYTES + (9 - C64_WREG_TAPS) * SLAB_BYTES + (FUSE1A ? 2 * C64_PATCH * 4 : 0);
   static bool attr_done = false;
-  auto kfn = conv64ws_kernel<P, POOL, C64_WREG_TAPS>;
+  auto kfn = conv64ws_kernel<P, POOL, C64_WREG_TAPS, FUSE1A>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
@@ -216,12 +319,17 @@ static void conv64ws_launch_t(const ConvArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), LDS, st, a, tiles_x, tiles_y, ntiles);
 }
 
-// requires CIN == COUT == 64, relu, H % 16 == 0, W % 16 == 0
+// requires CIN == COUT == 64, relu, H % 16 == 0, W % 16 == 0.  a.img != nullptr selects the fused conv1a+conv1b form
+// (input = fp32 image [B][H+2][W+2] with zero border, a.w1a [64][9], a.b1a [64]; always followed by the 2x2 max-pool).
 void launch_conv64ws(int prec, const ConvArgs& a, hipStream_t st) {
+  if (a.img) {
+    if (prec == 1) conv64ws_launch_t<PF16, true, true>(a, st); else conv64ws_launch_t<PBF16, true, true>(a, st);
+    return;
+  }
   if (prec == 1) {
-    if (a.pool) conv64ws_launch_t<PF16, true>(a, st); else conv64ws_launch_t<PF16, false>(a, st);
+    if (a.pool) conv64ws_launch_t<PF16, true, false>(a, st); else conv64ws_launch_t<PF16, false, false>(a, st);
   } else {
-    if (a.pool) conv64ws_launch_t<PBF16, true>(a, st); else conv64ws_launch_t<PBF16, false>(a, st);
+    if (a.pool) conv64ws_launch_t<PBF16, true, false>(a, st); else conv64ws_launch_t<PBF16, false, false>(a, st);
   }
 }
 
