@@ -308,7 +308,7 @@ bool make_conv(airfe_ctx* c, const Pack& p, const std::string& name, int cin, in
 bool make_linear(airfe_ctx* c, const float* W, const float* bias, int K, int N, LinW& out, float scale = 1.f,
                  const std::function<int(int)>* src_row = nullptr, const std::function<int(int)>* src_col = nullptr) {
   const int Kp = (K + 63) / 64 * 64, cbt = (N + 63) / 64;
-  const int cbp = (cbt + 1) & ~1;        // the GEMM consumes feature blocks in pairs (128-feature tiles): pad with zeros
+  const int cbp = (cbt + 3) & ~3;        // the GEMMs consume feature blocks in pairs / quads (128- / 256-feature tiles): zero pad
   auto slabs = pack_slabs(cbp, Kp / 64, c->prec, [&](int feat, int s, int k) {
     const int kk = s * 64 + k;
     if (feat >= N || kk >= K) return 0.f;

@@ -37,6 +37,8 @@ struct GemmArgs {
 
 // out[M][N] = X[M][K] * W^T ; K in {128,256,512}; trans => EPI_HEADS_T (operand roles swapped)
 void launch_gemm(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st);
+// M % 256 == 0: 256x128 tile, 8 waves, three-stage LDS-DMA ring (launch_gemm dispatches to it for large M)
+void launch_gemm8(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st);
 
 struct ConvArgs {
   const uint16_t* X = nullptr;  // [B][H+2][W+2][CIN], zero border

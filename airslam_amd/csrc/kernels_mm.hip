@@ -387,6 +387,10 @@ static void gemm_launch_t(int K, const GemmArgs& a, hipStream_t st) {
 }
 
 void launch_gemm(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st) {
+  if (a.M % 256 == 0 && a.M >= 4096) {       // large-M path: 8-wave, 3-stage LDS-DMA ring (kernels_gemm8.hip)
+    launch_gemm8(prec, K, trans, a, st);
+    return;
+  }
   if (prec == 1) {
     if (trans) gemm_launch_t<PF16, true>(K, a, st); else gemm_launch_t<PF16, false>(K, a, st);
   } else {
