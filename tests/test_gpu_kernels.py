@@ -36,7 +36,10 @@ def test_conv3x3(cin, cout, pool, B, H, W):
 
 
 @pytest.mark.parametrize("K,N,M,relu", [(256, 256, 128, False), (256, 65, 200, False), (512, 512, 64, True),
-                                        (512, 256, 300, False), (128, 128, 128, False), (256, 768, 1000, False)])
+                                        (512, 256, 300, False), (128, 128, 128, False), (256, 768, 1000, False),
+                                        # M >= 4096 and M % 256 == 0 -> the 8-wave LDS-DMA kernel (kernels_gemm8.hip)
+                                        (256, 512, 4096, False), (512, 256, 4352, True), (256, 65, 4096, False),
+                                        (128, 320, 8192, False)])
 def test_gemm(K, N, M, relu):
     ctx, _, _ = context("sp")
     rng = np.random.default_rng(K + N + M)

@@ -104,3 +104,31 @@ def test_matching_points_early_out():
     ctx, _, _ = context("lg", max_batch=4)
     pm = api.PointMatcher(ctx, 752, 480, 0)
     assert pm.MatchingPoints(np.zeros((259, 0), np.float32), np.zeros((259, 7), np.float32)) == (0, [])
+
+
+def test_large_batch_uses_gemm8_and_agrees_with_single_pair_path():
+    """8 pairs -> M = 16 x 448 = 7168 rows: the linears go through the 8-wave LDS-DMA GEMM (kernels_gemm8.hip);
+    a single pair (M = 896) goes through the 4-wave kernel.  Same K-order accumulation => same matches."""
+    import torch
+    from airslam_amd import api
+    ctx, _, lg = context("lg", max_batch=8)
+    B = 8
+    pairs = [_pair(400 - 7 * i, 390 - 11 * i, 40 + i) for i in range(B)]
+    f0 = torch.zeros((B, 400, 259)); f1 = torch.zeros((B, 400, 259))
+    n0 = torch.tensor([p[0].shape[0] for p in pairs], dtype=torch.int32)
+    n1 = torch.tensor([p[1].shape[0] for p in pairs], dtype=torch.int32)
+    for i, (a, b, _, _) in enumerate(pairs):
+        f0[i, :a.shape[0]] = torch.from_numpy(a); f1[i, :b.shape[0]] = torch.from_numpy(b)
+    f0, f1, n0, n1 = f0.cuda(), f1.cuda(), n0.cuda(), n1.cuda()
+    idx = torch.zeros((B, 400, 2), dtype=torch.int32, device="cuda")
+    sc = torch.zeros((B, 400), dtype=torch.float32, device="cuda")
+    nm = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    ctx.match_lightglue_batch_dev(f0, n0, f1, n1, idx, sc, nm)
+    ctx.sync()
+    pm = api.PointMatcher(ctx, 752, 480, 0)
+    for i, (a, b, _, _) in enumerate(pairs):
+        cnt, matches = pm.MatchingPoints(np.asfortranarray(a.T), np.asfortranarray(b.T))
+        k = int(nm[i])
+        assert k == cnt
+        assert [tuple(g) for g in idx[i, :k].cpu().numpy()] == [(m[0], m[1]) for m in matches]
+        np.testing.assert_allclose(1.0 - sc[i, :k].cpu().numpy(), [m[2] for m in matches], atol=1e-5)
