@@ -206,14 +206,21 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (FUSE1A) {
+    // pipeline prologue: patch(1) in flight, conv1a tile(0) produced, both visible before the loop
+    if (tile < ntiles) {
+      if (tile + (int)gridDim.x < ntiles) stage_patch(tile + gridDim.x, 1);
+      produce(tile, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 
   for (int i = 0; tile < ntiles; ++i, tile += gridDim.x) {
     const int next = tile + gridDim.x;
     if constexpr (FUSE1A) {
-      if (next < ntiles) stage_patch(next, (i + 1) & 1);
-      produce(tile, i & 1, i & 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();          // conv1a tile complete (all waves) and the next patch has landed
+      // patch(i+2) -> pbuf[i&1] (consumed by produce(i) one iteration ago); it has the whole MFMA phase to land
+      if (next + (int)gridDim.x < ntiles) stage_patch(next + gridDim.x, i & 1);
     } else {
       if (next < ntiles) stage(next, (i + 1) & 1);
     }
@@ -248,10 +255,13 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
     // The wait for the next tile's LDS-DMA sits HERE, before this tile's output stores are issued: vmcnt also counts
     // stores, and waiting behind them exposed a full HBM write latency per tile (ablation: the kernel took 2.4 ms/step
     // with neither MFMAs nor DMA).  Now the stores get the whole next tile to retire.
-    if constexpr (!FUSE1A) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile's LDS-DMA has landed
-      __syncthreads();                                   // ... everyone's has, and the buffer just read is free again
+    if constexpr (FUSE1A) {
+      // conv1a of the NEXT tile goes into the other buffer right behind this tile's MFMAs (its patch landed an iteration
+      // ago); then one wait + barrier covers "next input tile complete", "patch(i+2) landed" and "this buffer is free"
+      if (next < ntiles) produce(next, (i + 1) & 1, (i + 1) & 1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile's LDS-DMA has landed
+    __syncthreads();                                   // ... everyone's has, and the buffer just read is free again
     // ---- epilogue: bias, ReLU, optional 2x2 max-pool, 16-byte stores (same mapping as conv3x3_kernel)
     const int b = tile / per_img, rem = tile - b * per_img;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;

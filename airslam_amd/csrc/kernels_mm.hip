@@ -183,6 +183,10 @@ void launch_conv3x3(int prec, const ConvArgs& a, hipStream_t st) {
     launch_conv64ws(prec, a, st);      // weight-stationary persistent kernel (kernels_conv64.hip)
     return;
   }
+  if (a.CIN == 128 && (a.COUT % 128) == 0 && (a.H % 8) == 0 && (a.W % 16) == 0) {
+    launch_conv128ws(prec, a, st);     // persistent tap-streamed kernel (kernels_conv128.hip)
+    return;
+  }
   if (prec == 1) conv_launch_p<PF16>(a, st); else conv_launch_p<PBF16>(a, st);
 }
 
