@@ -43,7 +43,7 @@ constexpr int C64_TILE_BYTES = 18 * 18 * 128;     // 41472
 constexpr int C64_CHUNKS = 18 * 18 * 8;           // 2592 sixteen-byte pieces
 
 template <class P, bool POOL, int WREG_TAPS, bool FUSE1A>
-__global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int ntiles) {
+__global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int ntiles, int cb0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
   typename P::vec8 wreg[WT][2][4];
   char* wlds = smem + 2 * C64_TILE_BYTES;
   {
-    const char* wp = reinterpret_cast<const char*>(a.Wp);
+    const char* wp = reinterpret_cast<const char*>(a.Wp) + (size_t)cb0 * 9 * SLAB_BYTES;   // 64 output channels per pass
 #pragma unroll
     for (int tap = 0; tap < WREG_TAPS; ++tap)
 #pragma unroll
@@ -75,11 +75,11 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
 #pragma unroll
   for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias[tp][e] = a.bias[tp * 32 + g * 8 + e];
+    for (int e = 0; e < 8; ++e) bias[tp][e] = a.bias[cb0 * 64 + tp * 32 + g * 8 + e];
 
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
   const int opad = a.out_pad;
-  const size_t orow = (size_t)(Wo + 2 * opad) * 64;
+  const size_t orow = (size_t)(Wo + 2 * opad) * a.COUT;
   const int per_img = tiles_x * tiles_y;
 
   // LDS-DMA of one halo tile: piece q' = j*256 + tid lands at LDS byte q'*16 (wave-uniform base + lane*16);
@@ -280,9 +280,9 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
         uint4 r1 = pack8<P>(v0), r2 = pack8<P>(v1);
         line_exchange(r1, r2, l15);                      // full 128-byte lines per store instruction (common.h)
         const int y = ty * 16 + wave * 4 + m, x = tx * 16 + (l15 & 7);
-        char* o = reinterpret_cast<char*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * 64) + (l15 < 8 ? 0 : 64) + g * 16;
+        char* o = reinterpret_cast<char*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * a.COUT + cb0 * 64) + (l15 < 8 ? 0 : 64) + g * 16;
         *reinterpret_cast<uint4*>(o) = r1;
-        *reinterpret_cast<uint4*>(o + 8 * 128) = r2;
+        *reinterpret_cast<uint4*>(o + 8 * a.COUT * 2) = r2;
       }
     } else {
 #pragma unroll
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void conv64ws_kernel(ConvArgs a, int tiles_
         // so ONE store instruction writes 8 complete 128-byte lines
         const uint4 r = (l15 & 1) ? pack8<P>(v1) : pack8<P>(v0);
         const int y = (ty * 16 + wave * 4) / 2 + mp, x = tx * 8 + (l15 >> 1);
-        char* o = reinterpret_cast<char*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * 64) + (l15 & 1) * 64 + g * 16;
+        char* o = reinterpret_cast<char*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * a.COUT + cb0 * 64) + (l15 & 1) * 64 + g * 16;
         *reinterpret_cast<uint4*>(o) = r;
       }
     }
@@ -326,7 +326,7 @@ static void conv64ws_launch_t(const ConvArgs& a, hipStream_t st) {
   const int tiles_x = a.W / 16, tiles_y = a.H / 16;
   const int ntiles = tiles_x * tiles_y * a.B;
   const int grid = ntiles < 256 ? ntiles : 256;
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), LDS, st, a, tiles_x, tiles_y, ntiles);
+  for (int cb0 = 0; cb0 < a.COUT / 64; ++cb0) hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), LDS, st, a, tiles_x, tiles_y, ntiles, cb0);
 }
 
 // requires CIN == COUT == 64, relu, H % 16 == 0, W % 16 == 0.  a.img != nullptr selects the fused conv1a+conv1b form
