@@ -157,7 +157,7 @@ struct airfe_ctx {
   int prec = 0;
   int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
   bool has_sp = false, has_lg = false;
-  bool fuse_conv1a = false;      // AIRFE_FUSE_CONV1A=1: experimental conv1a-in-conv1b fusion (correct, not yet faster)
+  bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
 
   // detector weights
   float *c1a_w = nullptr, *c1a_b = nullptr;
@@ -633,14 +633,14 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
     }
     if (c->fuse_conv1a) {
       // conv1a (Cin = 1) fused into the persistent conv1b kernel: its 64-channel full-resolution output never
-      // reaches HBM (kernels_conv64.hip).  FLOPs/bytes below are the algorithmic ones of conv1a + conv1b.
+      // reaches HBM (kernels_conv64r.hip).  FLOPs/bytes below are the algorithmic ones of conv1a + conv1b.
       ConvArgs a;
       a.Wp = c->c1b.w; a.bias = c->c1b.b; a.Y = c->a1b; a.B = cb; a.H = R; a.W = R; a.CIN = 64; a.COUT = 64;
       a.pool = 1; a.out_pad = 1; a.relu = 1;
       a.img = c->img32; a.w1a = c->c1a_w; a.b1a = c->c1a_b;
       const double px = (double)cb * R * R;
       ProfScope ps(c, ST_CONV3X3_C64, st, 2.0 * px * 9 * 64 + 2.0 * px * 64 * 64 * 9, px * 4 + px / 4 * 128 + 9.0 * 64 * 64 * 2);
-      launch_conv64ws(c->prec, a, st);
+      launch_conv64r(c->prec, a, st);
     } else {
       {
         ProfScope ps(c, ST_CONV1A, st, 2.0 * cb * R * R * 9 * 64, (double)cb * R * R * (4 + 128));
@@ -842,7 +842,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   c->chunk = std::min(std::max(cfg->enc_chunk, 1), c->Bmax);
   c->Pmax = c->Bmax;
   c->Np = (cfg->max_keypoints + 63) / 64 * 64;
-  c->fuse_conv1a = getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) != 0;
+  c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return fail(nullptr, "airfe_create: stream creation failed");

@@ -8,6 +8,10 @@ namespace airfe {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
 
 // ---------------------------------------------------------------------------------------------
 // Precision traits: 2-byte storage type + the 16x16x32 MFMA that consumes it (fp32 accumulate).
@@ -20,6 +24,9 @@ struct PBF16 {
   static __device__ __forceinline__ uint16_t from_f32(float f) {
     __bf16 h = static_cast<__bf16>(f);
     return __builtin_bit_cast(uint16_t, h);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {   // one v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
   }
   static __device__ __forceinline__ float to_f32(uint16_t u) {
     return __builtin_bit_cast(float, (uint32_t)u << 16);
@@ -34,6 +41,9 @@ struct PF16 {
     _Float16 h = static_cast<_Float16>(f);
     return __builtin_bit_cast(uint16_t, h);
   }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {   // one v_cvt_pk_f16_f32 (round to nearest even)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
+  }
   static __device__ __forceinline__ float to_f32(uint16_t u) {
     return static_cast<float>(__builtin_bit_cast(_Float16, u));
   }
@@ -42,17 +52,25 @@ struct PF16 {
 template <class P>
 __device__ __forceinline__ uint4 pack8(const float* v) {
   uint4 r;
-  r.x = (uint32_t)P::from_f32(v[0]) | ((uint32_t)P::from_f32(v[1]) << 16);
-  r.y = (uint32_t)P::from_f32(v[2]) | ((uint32_t)P::from_f32(v[3]) << 16);
-  r.z = (uint32_t)P::from_f32(v[4]) | ((uint32_t)P::from_f32(v[5]) << 16);
-  r.w = (uint32_t)P::from_f32(v[6]) | ((uint32_t)P::from_f32(v[7]) << 16);
+  r.x = P::pack2(v[0], v[1]);
+  r.y = P::pack2(v[2], v[3]);
+  r.z = P::pack2(v[4], v[5]);
+  r.w = P::pack2(v[6], v[7]);
   return r;
+}
+// ReLU on packed 2-byte floats (bf16 and fp16 alike): as signed 16-bit integers every negative float is negative, so
+// one v_pk_max_i16 against 0 per PAIR replaces two fp32 max (+ canonicalisation) per value; -0 becomes +0.
+__device__ __forceinline__ uint32_t relu_packed(uint32_t u) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), s16x2{0, 0}));
+}
+__device__ __forceinline__ uint4 relu_packed(uint4 u) {
+  return uint4{relu_packed(u.x), relu_packed(u.y), relu_packed(u.z), relu_packed(u.w)};
 }
 template <class P>
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   uint2 r;
-  r.x = (uint32_t)P::from_f32(a) | ((uint32_t)P::from_f32(b) << 16);
-  r.y = (uint32_t)P::from_f32(c) | ((uint32_t)P::from_f32(d) << 16);
+  r.x = P::pack2(a, b);
+  r.y = P::pack2(c, d);
   return r;
 }
 template <class P>

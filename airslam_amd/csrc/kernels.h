@@ -49,14 +49,14 @@ struct ConvArgs {
   int pool = 0;                 // fused 2x2 max-pool
   int out_pad = 1;
   int relu = 1;
-  // fused conv1a -> conv1b (launch_conv64ws only): fp32 image [B][H+2][W+2], conv1a weights [64][9] and bias [64]
+  // fused conv1a -> conv1b (launch_conv64r only): fp32 image [B][H+2][W+2], conv1a weights [64][9] and bias [64]
   const float* img = nullptr;
   const float* w1a = nullptr;
   const float* b1a = nullptr;
 };
 void launch_conv3x3(int prec, const ConvArgs& a, hipStream_t st);
 // persistent weight-stationary variant for CIN == COUT == 64 (launch_conv3x3 dispatches to it)
-void launch_conv64ws(int prec, const ConvArgs& a, hipStream_t st);
+void launch_conv64r(int prec, const ConvArgs& a, hipStream_t st);
 // persistent tap-streamed variant for CIN == 128, COUT % 128 == 0 (launch_conv3x3 dispatches to it)
 void launch_conv128ws(int prec, const ConvArgs& a, hipStream_t st);
 

@@ -1,0 +1,330 @@
+// airfe — persistent 3x3 convolution for the 64-input-channel layers (conv1b, conv2a, conv2b, conv3a) with the filter
+// bank RESIDENT IN REGISTERS, 64 output channels per pass.
+//
+// Why: in the LDS-resident form (weights + pixels both fetched from LDS, wave tile 64 pixels x 64 couts) a wave issues
+// 8 ds_read_b128 per 16 MFMAs; four waves then need 576 KiB of LDS reads per 16x16 tile = 4608 cycles at 128 B/clk, exactly
+// the 4608 MFMA cycles of the tile: the LDS pipe and the matrix pipe were co-limiting and the kernel sat at ~45 % of the
+// MFMA peak.  Here the four waves of a workgroup are a 2 x 2 grid (pixel rows 0-7 / 8-15  x  couts 0-31 / 32-63):
+//   * a wave's share of the filters is 9 taps x 64 cin x 32 cout = 36 A-fragments = 144 VGPRs, loaded ONCE per workgroup;
+//   * pixel fragments are fetched once per (column shift, channel half) and reused by all three filter rows:
+//     10 ds_read_b128 per 48 MFMAs -> 240 KiB of LDS reads per tile (2.4x less), the kernel becomes MFMA-bound;
+//   * LDS now only holds the double-buffered halo tile (2 x 40.5 KiB), filled one tile ahead by LDS-DMA.
+#include "common.h"
+#include "kernels.h"
+
+namespace airfe {
+
+typedef __attribute__((address_space(3))) void* las_ptr64r;
+
+__device__ __forceinline__ void c64r_glds4(const void* gsrc, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_off)
+               : "memory");
+}
+
+__device__ __forceinline__ void c64r_glds16(const void* gsrc, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_off)
+               : "memory");
+}
+
+constexpr int C64R_TILE_STRIDE = 21 * 16 * 128;    // 43008: buffer pitch, padded to 21 whole groups of 16 pixels (fused conv1a)
+constexpr int C64R_PIECES = 18 * 18 * 8;           // 2592 sixteen-byte pieces
+constexpr int C64R_PATCH = 20 * 20;                // fused conv1a: fp32 image patch per tile (halo 2)
+
+template <class P, bool POOL, bool FUSE1A>
+__global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x, int tiles_y, int ntiles, int cb0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave >> 1, ch = wave & 1;             // pixel-row half, cout half of this wave
+  const int H = a.H, W = a.W, COUT = a.COUT;
+  const size_t in_row = (size_t)(W + 2) * 128;
+  const size_t in_img = (size_t)(H + 2) * in_row;
+  const int per_img = tiles_x * tiles_y;
+
+  // ---- filters: slab rows (2*ch + tt)*16 + l15 of every tap, both channel halves, as MFMA A fragments
+  typename P::vec8 wreg[9][2][2];
+  {
+    const char* wp = reinterpret_cast<const char*>(a.Wp) + (size_t)cb0 * 9 * SLAB_BYTES;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int rr = (2 * ch + tt) * 16 + l15;
+          const uint4 u = *reinterpret_cast<const uint4*>(wp + tap * SLAB_BYTES + rr * 128 + (((ks * 4 + g) ^ swz128(rr)) << 4));
+          wreg[tap][ks][tt] = __builtin_bit_cast(typename P::vec8, u);
+        }
+  }
+  float bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = a.bias[cb0 * 64 + ch * 32 + g * 8 + e];
+
+  const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+  const int opad = a.out_pad;
+  const size_t orow = (size_t)(Wo + 2 * opad) * COUT;
+
+  // ---- loop-invariant offsets: LDS-DMA piece q = j*256 + tid lands at LDS byte q*16; it is channel chunk
+  // (q&7) ^ swz(pixel) of pixel q>>3 (the swizzle is applied on the SOURCE address)
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(las_ptr64r)smem);
+  int goff[11];
+#pragma unroll
+  for (int j = 0; j < 11; ++j) {
+    const int q = min(j * 256 + tid, C64R_PIECES - 1);
+    const int p = q >> 3, c = (q & 7) ^ swz128(p);
+    const int pr = p / 18, pc = p - pr * 18;
+    goff[j] = pr * (int)in_row + pc * 128 + c * 16;
+  }
+  const bool last_piece = 10 * 256 + tid < C64R_PIECES;
+  auto stage = [&](int tile, int buf) {
+    const int b = tile / per_img, rem = tile - b * per_img;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const char* xin = reinterpret_cast<const char*>(a.X) + (size_t)b * in_img + (size_t)ty * 16 * in_row + (size_t)tx * 16 * 128;
+    const unsigned dst = lds_base + buf * C64R_TILE_STRIDE + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) c64r_glds16(xin + goff[j], dst + j * 4096);
+    if (last_piece) c64r_glds16(xin + goff[10], dst + 10 * 4096);
+  };
+  // pixel fragments: tile rows ph*8 + {0..9}, column shifts {0,1,2}; channel half ks = 1 is XOR 64
+  int boff[10][3];
+#pragma unroll
+  for (int r = 0; r < 10; ++r)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int p = (ph * 8 + r) * 18 + l15 + dx;
+      boff[r][dx] = p * 128 + ((g ^ swz128(p)) << 4);
+    }
+
+  // ---- fused conv1a (Cin = 1, FUSE1A): the 18x18x64 input tile of conv1b is COMPUTED here from a 20x20 patch of the
+  // fp32 image instead of being read back from HBM: conv1a's 32 MiB/image of output never exists (conv1b alone is at
+  // the HBM ridge: 458 flop/byte).  conv1a runs on the matrix pipe too, as one 32-wide fp16 k-step: lane group g = 0..2
+  // carries filter row dy = g (3 taps in k slots g*8 + {0,1,2}), g = 3 carries a constant 1 against the bias, so that
+  // the epilogue is just ReLU + pack; halo pixels outside the image get an all-zero B column -> exact 0.
+  [[maybe_unused]] f16x8 w1[4];
+  [[maybe_unused]] const unsigned pbase = lds_base + 2 * C64R_TILE_STRIDE;
+  [[maybe_unused]] const float* pbuf = reinterpret_cast<const float*>(smem + 2 * C64R_TILE_STRIDE);
+  if constexpr (FUSE1A) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int co = slab_row_to_feature(t * 16 + l15);
+      f16x8 w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] = (_Float16)0.f;
+      if (g < 3) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) w[e] = (_Float16)a.w1a[co * 9 + g * 3 + e];
+      } else {
+        w[0] = (_Float16)a.b1a[co];
+      }
+      w1[t] = w;
+    }
+  }
+  // 20x20 fp32 patch of tile t -> pbuf[buf] by 4-byte LDS-DMA.  The image buffer has a 1-pixel zero border; rows/cols
+  // beyond even that are clamped: they only feed halo pixels outside the image, which are forced to 0 anyway.
+  auto stage_patch = [&](int t, int buf) {
+    const int b = t / per_img, rem = t - b * per_img;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const float* img = a.img + (size_t)b * (H + 2) * (W + 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = j * 256 + tid;
+      if (q < C64R_PATCH) {
+        const int r = q / 20, cc = q - r * 20;
+        const int gy = min(max(ty * 16 - 1 + r, 0), H + 1), gx = min(max(tx * 16 - 1 + cc, 0), W + 1);
+        c64r_glds4(img + (size_t)gy * (W + 2) + gx, pbase + buf * (C64R_PATCH * 4) + (j * 256 + wave * 64) * 4);
+      }
+    }
+  };
+  // conv1a + ReLU of one tile = 21 groups of 16 halo pixels; wave w owns groups w, w+4, ..  (the sixth slot of every wave
+  // is group 20: four identical copies, cheaper than a wave-divergent tail).  Everything that does not depend on the tile
+  // is hoisted; the per-group work is branch-free so that it can be scheduled INTO the main MFMA loop (one group per combo).
+  [[maybe_unused]] int prd[6], pwr[6], pyx[6];
+  if constexpr (FUSE1A) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int k = min(wave + 4 * j, 20);
+      const int p = k * 16 + l15, pc = min(p, 323);              // p >= 324 (group 20, lanes 4..15): lands in the pad rows
+      const int py = pc / 18, px = pc - py * 18;
+      prd[j] = ((py + min(g, 2)) * 20 + px) * 4;
+      pwr[j] = p * 128 + ((g ^ swz128(p)) << 4);
+      pyx[j] = (py << 8) | px;
+    }
+  }
+  struct Taps { float q0, q1, q2; };
+  auto prod_load = [&](int j, int buf) {
+    const float* q = reinterpret_cast<const float*>(smem + 2 * C64R_TILE_STRIDE + buf * (C64R_PATCH * 4) + prd[j]);
+    return Taps{q[0], q[1], q[2]};
+  };
+  auto prod_finish = [&](int j, const Taps& tp3, int ty, int tx, int xbuf) {
+    const int gy = ty * 16 - 1 + (pyx[j] >> 8), gx = tx * 16 - 1 + (pyx[j] & 255);
+    const float m = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? 1.f : 0.f;
+    const bool taps = g < 3;
+    f16x8 bfr;
+    bfr[0] = (_Float16)((taps ? tp3.q0 : 1.f) * m);
+    bfr[1] = (_Float16)((taps ? tp3.q1 : 0.f) * m);
+    bfr[2] = (_Float16)((taps ? tp3.q2 : 0.f) * m);
+#pragma unroll
+    for (int e = 3; e < 8; ++e) bfr[e] = (_Float16)0.f;
+    f32x4 c1[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) c1[tt] = PF16::mfma(w1[tt], bfr, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = c1[2 * tp][e];
+        v[4 + e] = c1[2 * tp + 1][e];
+      }
+      *reinterpret_cast<uint4*>(smem + xbuf * C64R_TILE_STRIDE + (pwr[j] ^ (tp << 6))) = relu_packed(pack8<P>(v));
+    }
+  };
+  auto tile_xy = [&](int t, int& ty, int& tx) {
+    const int rem = t % per_img;
+    ty = rem / tiles_x;
+    tx = rem - ty * tiles_x;
+  };
+
+  int tile = blockIdx.x;
+  if constexpr (FUSE1A) {
+    if (tile < ntiles) stage_patch(tile, 0);
+  } else {
+    if (tile < ntiles) stage(tile, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if constexpr (FUSE1A) {
+    // pipeline prologue: patch(1) in flight, conv1a of tile(0) produced, both visible before the loop
+    if (tile < ntiles) {
+      if (tile + (int)gridDim.x < ntiles) stage_patch(tile + gridDim.x, 1);
+      int ty0, tx0;
+      tile_xy(tile, ty0, tx0);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) prod_finish(j, prod_load(j, 0), ty0, tx0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  for (int i = 0; tile < ntiles; ++i, tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if constexpr (FUSE1A) {
+      // patch(i+2) -> pbuf[i&1] (consumed by produce one iteration ago); it has the whole MFMA phase to land
+      if (next + (int)gridDim.x < ntiles) stage_patch(next + gridDim.x, i & 1);
+    } else {
+      if (next < ntiles) stage(next, (i + 1) & 1);
+    }
+
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 6 combos (column shift dx, channel half ks); the 10 pixel-row fragments of combo c+1 are requested before the
+    // 48 MFMAs (3 filter rows x 8 pixel rows x 2 cout tiles) of combo c
+    typename P::vec8 bf[2][10];
+    const int xoff = (i & 1) * C64R_TILE_STRIDE;
+    [[maybe_unused]] int nty = 0, ntx = 0;
+    if constexpr (FUSE1A) tile_xy(next < ntiles ? next : tile, nty, ntx);   // past the end: harmless rewrite of a dead buffer
+    auto load_combo = [&](int c, int set) {
+      const int dx = c >> 1, ks = c & 1;
+#pragma unroll
+      for (int r = 0; r < 10; ++r) bf[set][r] = lds_frag<P>(smem, (boff[r][dx] ^ (ks << 6)) + xoff);
+    };
+    load_combo(0, 0);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      if (c + 1 < 6) load_combo(c + 1, (c + 1) & 1);
+      [[maybe_unused]] Taps taps{};
+      if constexpr (FUSE1A) taps = prod_load(c, (i + 1) & 1);   // conv1a of the NEXT tile, group c (its patch landed an iteration ago)
+      const int dx = c >> 1, ks = c & 1;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[m][t] = P::mfma(wreg[dy * 3 + dx][ks][t], bf[c & 1][m + dy], acc[m][t]);
+      if constexpr (FUSE1A) prod_finish(c, taps, nty, ntx, (i + 1) & 1);
+    }
+
+    // wait for the next tile's LDS-DMA BEFORE this tile's stores are issued (vmcnt counts stores too), then one barrier:
+    // "next tile complete" and "the buffer just read is free"
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- epilogue: bias, ReLU, optional 2x2 max-pool; a lane owns 8 contiguous couts (16 bytes) of its pixel
+    const int b = tile / per_img, rem = tile - b * per_img;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    uint16_t* ybase = a.Y + (size_t)b * (Ho + 2 * opad) * orow + cb0 * 64 + ch * 32 + g * 8;
+    if constexpr (!POOL) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[m][0][e] + bias[e];
+          v[4 + e] = acc[m][1][e] + bias[4 + e];
+        }
+        const int y = ty * 16 + ph * 8 + m, x = tx * 16 + l15;
+        *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * COUT) = relu_packed(pack8<P>(v));
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float v[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m0 = (2 * q + h) * 2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[h][e] = fmaxf(acc[m0][0][e], acc[m0 + 1][0][e]);
+            v[h][4 + e] = fmaxf(acc[m0][1][e], acc[m0 + 1][1][e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[h][e] = fmaxf(v[h][e], __shfl_xor(v[h][e], 1)) + bias[e];
+        }
+        // both lanes of a column pair hold both pooled rows: the even lane stores row 2q, the odd lane row 2q + 1
+        const uint4 r = relu_packed((l15 & 1) ? pack8<P>(v[1]) : pack8<P>(v[0]));
+        const int y = (ty * 16 + ph * 8) / 2 + 2 * q + (l15 & 1), x = tx * 8 + (l15 >> 1);
+        *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * COUT) = r;
+      }
+    }
+  }
+}
+
+template <class P, bool POOL, bool FUSE1A>
+static void conv64r_launch_t(const ConvArgs& a, hipStream_t st) {
+  constexpr int LDS = 2 * C64R_TILE_STRIDE + (FUSE1A ? 2 * C64R_PATCH * 4 : 0);
+  static bool attr_done = false;
+  auto kfn = conv64r_kernel<P, POOL, FUSE1A>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  const int tiles_x = a.W / 16, tiles_y = a.H / 16;
+  const int ntiles = tiles_x * tiles_y * a.B;
+  const int grid = ntiles < 256 ? ntiles : 256;
+  for (int cb0 = 0; cb0 < a.COUT / 64; ++cb0)          // 64 output channels per pass
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), LDS, st, a, tiles_x, tiles_y, ntiles, cb0);
+}
+
+// requires CIN == 64, COUT % 64 == 0, relu, H % 16 == 0, W % 16 == 0.  a.img != nullptr selects the fused conv1a + conv1b
+// form (input = fp32 image [B][H+2][W+2] with zero border, a.w1a [64][9], a.b1a [64]; always followed by the 2x2 max-pool).
+void launch_conv64r(int prec, const ConvArgs& a, hipStream_t st) {
+  if (a.img) {
+    if (prec == 1) conv64r_launch_t<PF16, true, true>(a, st); else conv64r_launch_t<PBF16, true, true>(a, st);
+    return;
+  }
+  if (prec == 1) {
+    if (a.pool) conv64r_launch_t<PF16, true, false>(a, st); else conv64r_launch_t<PF16, false, false>(a, st);
+  } else {
+    if (a.pool) conv64r_launch_t<PBF16, true, false>(a, st); else conv64r_launch_t<PBF16, false, false>(a, st);
+  }
+}
+
+}  // namespace airfe

@@ -180,7 +180,7 @@ static void conv_launch_p(const ConvArgs& a, hipStream_t st) {
 
 void launch_conv3x3(int prec, const ConvArgs& a, hipStream_t st) {
   if (a.CIN == 64 && (a.COUT % 64) == 0 && a.relu && (a.H % 16) == 0 && (a.W % 16) == 0) {
-    launch_conv64ws(prec, a, st);      // weight-stationary persistent kernel (kernels_conv64.hip)
+    launch_conv64r(prec, a, st);       // persistent kernel, filters resident in registers (kernels_conv64r.hip)
     return;
   }
   if (a.CIN == 128 && (a.COUT % 128) == 0 && (a.H % 8) == 0 && (a.W % 16) == 0) {
