@@ -63,6 +63,19 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 __device__ __forceinline__ uint32_t relu_packed(uint32_t u) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), s16x2{0, 0}));
 }
+// max of packed 2-byte floats through v_pk_max_i16.  Exact whenever a ReLU follows: a non-negative float beats any negative
+// one, two non-negative ones order like integers, and two negative ones give "some negative value" that the ReLU zeroes.
+__device__ __forceinline__ uint32_t max_packed_pre_relu(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint4 max_packed_pre_relu(uint4 a, uint4 b) {
+  return uint4{max_packed_pre_relu(a.x, b.x), max_packed_pre_relu(a.y, b.y), max_packed_pre_relu(a.z, b.z), max_packed_pre_relu(a.w, b.w)};
+}
+// value held by the horizontally adjacent lane (lane ^ 1): one DPP move (quad_perm [1,0,3,2]), no LDS crossbar trip
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint4 dpp_xor1(uint4 v) { return uint4{dpp_xor1(v.x), dpp_xor1(v.y), dpp_xor1(v.z), dpp_xor1(v.w)}; }
 __device__ __forceinline__ uint4 relu_packed(uint4 u) {
   return uint4{relu_packed(u.x), relu_packed(u.y), relu_packed(u.z), relu_packed(u.w)};
 }

@@ -34,6 +34,10 @@ __device__ __forceinline__ void c64r_glds16(const void* gsrc, unsigned lds_off) 
 
 constexpr int C64R_TILE_STRIDE = 21 * 16 * 128;    // 43008: buffer pitch, padded to 21 whole groups of 16 pixels (fused conv1a)
 constexpr int C64R_PIECES = 18 * 18 * 8;           // 2592 sixteen-byte pieces
+#ifndef C64R_SCHED
+#define C64R_SCHED 1
+#endif
+constexpr bool SCHED = C64R_SCHED;
 constexpr int C64R_PATCH = 20 * 20;                // fused conv1a: fp32 image patch per tile (halo 2)
 
 template <class P, bool POOL, bool FUSE1A>
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
 #pragma unroll
     for (int m = 0; m < 8; ++m)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 2; ++t) acc[m][t] = f32x4{bias[t * 4], bias[t * 4 + 1], bias[t * 4 + 2], bias[t * 4 + 3]};
     // 6 combos (column shift dx, channel half ks); the 10 pixel-row fragments of combo c+1 are requested before the
     // 48 MFMAs (3 filter rows x 8 pixel rows x 2 cout tiles) of combo c
     typename P::vec8 bf[2][10];
@@ -238,6 +242,7 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
       for (int r = 0; r < 10; ++r) bf[set][r] = lds_frag<P>(smem, (boff[r][dx] ^ (ks << 6)) + xoff);
     };
     load_combo(0, 0);
+    if (SCHED) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       if (c + 1 < 6) load_combo(c + 1, (c + 1) & 1);
@@ -251,45 +256,53 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
 #pragma unroll
           for (int t = 0; t < 2; ++t) acc[m][t] = P::mfma(wreg[dy * 3 + dx][ks][t], bf[c & 1][m + dy], acc[m][t]);
       if constexpr (FUSE1A) prod_finish(c, taps, nty, ntx, (i + 1) & 1);
+      // issue-order pipeline for the scheduler: one fragment read of the NEXT combo per 4 MFMAs of this one (hipcc otherwise
+      // sinks the reads down to their first use and every 6 MFMAs wait out a full LDS latency)
+      if (SCHED) {
+#pragma unroll
+        for (int sidx = 0; sidx < 10; ++sidx) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if constexpr (FUSE1A) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, FUSE1A ? 12 : 8, 0);
+      }
     }
 
     // wait for the next tile's LDS-DMA BEFORE this tile's stores are issued (vmcnt counts stores too), then one barrier:
     // "next tile complete" and "the buffer just read is free"
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- epilogue: bias, ReLU, optional 2x2 max-pool; a lane owns 8 contiguous couts (16 bytes) of its pixel
+    // ---- epilogue (the bias is already in the accumulators): round to the 2-byte storage type FIRST, then ReLU and the
+    // 2x2 max-pool on packed pairs (v_pk_max_i16; rounding is monotonic, so pooling after it gives the same bits)
     const int b = tile / per_img, rem = tile - b * per_img;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     uint16_t* ybase = a.Y + (size_t)b * (Ho + 2 * opad) * orow + cb0 * 64 + ch * 32 + g * 8;
+    uint4 pk[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      pk[m].x = P::pack2(acc[m][0][0], acc[m][0][1]);
+      pk[m].y = P::pack2(acc[m][0][2], acc[m][0][3]);
+      pk[m].z = P::pack2(acc[m][1][0], acc[m][1][1]);
+      pk[m].w = P::pack2(acc[m][1][2], acc[m][1][3]);
+    }
     if constexpr (!POOL) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[m][0][e] + bias[e];
-          v[4 + e] = acc[m][1][e] + bias[4 + e];
-        }
         const int y = ty * 16 + ph * 8 + m, x = tx * 16 + l15;
-        *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * COUT) = relu_packed(pack8<P>(v));
+        *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * COUT) = relu_packed(pk[m]);
       }
     } else {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        float v[2][8];
+        uint4 v[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int m0 = (2 * q + h) * 2;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[h][e] = fmaxf(acc[m0][0][e], acc[m0 + 1][0][e]);
-            v[h][4 + e] = fmaxf(acc[m0][1][e], acc[m0 + 1][1][e]);
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[h][e] = fmaxf(v[h][e], __shfl_xor(v[h][e], 1)) + bias[e];
+          const uint4 vert = max_packed_pre_relu(pk[4 * q + 2 * h], pk[4 * q + 2 * h + 1]);
+          v[h] = max_packed_pre_relu(vert, dpp_xor1(vert));
         }
         // both lanes of a column pair hold both pooled rows: the even lane stores row 2q, the odd lane row 2q + 1
-        const uint4 r = relu_packed((l15 & 1) ? pack8<P>(v[1]) : pack8<P>(v[0]));
+        const uint4 r = relu_packed((l15 & 1) ? v[1] : v[0]);
         const int y = (ty * 16 + ph * 8) / 2 + 2 * q + (l15 & 1), x = tx * 8 + (l15 >> 1);
         *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * COUT) = r;
       }
