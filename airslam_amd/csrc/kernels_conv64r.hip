@@ -38,14 +38,23 @@ constexpr int C64R_PIECES = 18 * 18 * 8;           // 2592 sixteen-byte pieces
 #define C64R_SCHED 1
 #endif
 constexpr bool SCHED = C64R_SCHED;
+#ifndef C64R_RW
+#define C64R_RW 4
+#endif
 constexpr int C64R_PATCH = 20 * 20;                // fused conv1a: fp32 image patch per tile (halo 2)
+constexpr int C64R_CONST_OFF = 2 * C64R_TILE_STRIDE + 2 * C64R_PATCH * 4;   // conv1a A fragments (4 KiB) + bias (256 B)
 
-template <class P, bool POOL, bool FUSE1A>
-__global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x, int tiles_y, int ntiles, int cb0) {
+// RW = pixel rows per wave: 8 -> 4 waves (one per SIMD, 512 registers each), 4 -> 8 waves (two per SIMD)
+template <class P, bool POOL, bool FUSE1A, int RW>
+__global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int tiles_x, int tiles_y, int ntiles, int cb0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ph = wave >> 1, ch = wave & 1;             // pixel-row half, cout half of this wave
+  constexpr bool CONST_IN_LDS = RW == 4;               // two waves per SIMD: 256 registers each, small constants live in LDS
+  constexpr int NT = 2048 / RW;                        // threads per workgroup
+  constexpr int NG = (21 * RW + 31) / 32;              // fused conv1a: 16-pixel groups per wave (21 groups over 32/RW waves)
+  constexpr int NPC = (C64R_PIECES + NT - 1) / NT;     // LDS-DMA pieces per thread
+  const int ph = wave >> 1, ch = wave & 1;             // pixel-row block, cout half of this wave
   const int H = a.H, W = a.W, COUT = a.COUT;
   const size_t in_row = (size_t)(W + 2) * 128;
   const size_t in_img = (size_t)(H + 2) * in_row;
@@ -77,31 +86,31 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
   // ---- loop-invariant offsets: LDS-DMA piece q = j*256 + tid lands at LDS byte q*16; it is channel chunk
   // (q&7) ^ swz(pixel) of pixel q>>3 (the swizzle is applied on the SOURCE address)
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(las_ptr64r)smem);
-  int goff[11];
+  int goff[NPC];
 #pragma unroll
-  for (int j = 0; j < 11; ++j) {
-    const int q = min(j * 256 + tid, C64R_PIECES - 1);
+  for (int j = 0; j < NPC; ++j) {
+    const int q = min(j * NT + tid, C64R_PIECES - 1);
     const int p = q >> 3, c = (q & 7) ^ swz128(p);
     const int pr = p / 18, pc = p - pr * 18;
     goff[j] = pr * (int)in_row + pc * 128 + c * 16;
   }
-  const bool last_piece = 10 * 256 + tid < C64R_PIECES;
+  const bool last_piece = (NPC - 1) * NT + tid < C64R_PIECES;
   auto stage = [&](int tile, int buf) {
     const int b = tile / per_img, rem = tile - b * per_img;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const char* xin = reinterpret_cast<const char*>(a.X) + (size_t)b * in_img + (size_t)ty * 16 * in_row + (size_t)tx * 16 * 128;
     const unsigned dst = lds_base + buf * C64R_TILE_STRIDE + wave * 1024;
 #pragma unroll
-    for (int j = 0; j < 10; ++j) c64r_glds16(xin + goff[j], dst + j * 4096);
-    if (last_piece) c64r_glds16(xin + goff[10], dst + 10 * 4096);
+    for (int j = 0; j < NPC - 1; ++j) c64r_glds16(xin + goff[j], dst + j * (NT * 16));
+    if (last_piece) c64r_glds16(xin + goff[NPC - 1], dst + (NPC - 1) * (NT * 16));
   };
-  // pixel fragments: tile rows ph*8 + {0..9}, column shifts {0,1,2}; channel half ks = 1 is XOR 64
-  int boff[10][3];
+  // pixel fragments: tile rows ph*RW + {0..RW+1}, column shifts {0,1,2}; channel half ks = 1 is XOR 64
+  int boff[RW + 2][3];
 #pragma unroll
-  for (int r = 0; r < 10; ++r)
+  for (int r = 0; r < RW + 2; ++r)
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
-      const int p = (ph * 8 + r) * 18 + l15 + dx;
+      const int p = (ph * RW + r) * 18 + l15 + dx;
       boff[r][dx] = p * 128 + ((g ^ swz128(p)) << 4);
     }
 
@@ -127,7 +136,12 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
         w[0] = (_Float16)a.b1a[co];
       }
       w1[t] = w;
+      if constexpr (CONST_IN_LDS) { if (wave == 0) *reinterpret_cast<f16x8*>(smem + C64R_CONST_OFF + (t * 64 + lane) * 16) = w; }
     }
+  }
+  if constexpr (CONST_IN_LDS) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) reinterpret_cast<float*>(smem + C64R_CONST_OFF + 4096)[(ch * 4 + g) * 8 + e] = bias[e];
   }
   // 20x20 fp32 patch of tile t -> pbuf[buf] by 4-byte LDS-DMA.  The image buffer has a 1-pixel zero border; rows/cols
   // beyond even that are clamped: they only feed halo pixels outside the image, which are forced to 0 anyway.
@@ -136,23 +150,23 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const float* img = a.img + (size_t)b * (H + 2) * (W + 2);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int q = j * 256 + tid;
+    for (int j = 0; j < (C64R_PATCH + NT - 1) / NT; ++j) {
+      const int q = j * NT + tid;
       if (q < C64R_PATCH) {
         const int r = q / 20, cc = q - r * 20;
         const int gy = min(max(ty * 16 - 1 + r, 0), H + 1), gx = min(max(tx * 16 - 1 + cc, 0), W + 1);
-        c64r_glds4(img + (size_t)gy * (W + 2) + gx, pbase + buf * (C64R_PATCH * 4) + (j * 256 + wave * 64) * 4);
+        c64r_glds4(img + (size_t)gy * (W + 2) + gx, pbase + buf * (C64R_PATCH * 4) + (j * NT + wave * 64) * 4);
       }
     }
   };
   // conv1a + ReLU of one tile = 21 groups of 16 halo pixels; wave w owns groups w, w+4, ..  (the sixth slot of every wave
   // is group 20: four identical copies, cheaper than a wave-divergent tail).  Everything that does not depend on the tile
   // is hoisted; the per-group work is branch-free so that it can be scheduled INTO the main MFMA loop (one group per combo).
-  [[maybe_unused]] int prd[6], pwr[6], pyx[6];
+  [[maybe_unused]] int prd[NG], pwr[NG], pyx[NG];
   if constexpr (FUSE1A) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int k = min(wave + 4 * j, 20);
+    for (int j = 0; j < NG; ++j) {
+      const int k = min(wave + (32 / RW) * j, 20);
       const int p = k * 16 + l15, pc = min(p, 323);              // p >= 324 (group 20, lanes 4..15): lands in the pad rows
       const int py = pc / 18, px = pc - py * 18;
       prd[j] = ((py + min(g, 2)) * 20 + px) * 4;
@@ -177,7 +191,11 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
     for (int e = 3; e < 8; ++e) bfr[e] = (_Float16)0.f;
     f32x4 c1[4];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) c1[tt] = PF16::mfma(w1[tt], bfr, f32x4{0.f, 0.f, 0.f, 0.f});
+    for (int tt = 0; tt < 4; ++tt) {
+      f16x8 wf = w1[tt];
+      if constexpr (CONST_IN_LDS) wf = *reinterpret_cast<const f16x8*>(smem + C64R_CONST_OFF + (tt * 64 + lane) * 16);
+      c1[tt] = PF16::mfma(wf, bfr, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp) {
       float v[8];
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
       int ty0, tx0;
       tile_xy(tile, ty0, tx0);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) prod_finish(j, prod_load(j, 0), ty0, tx0, 0);
+      for (int j = 0; j < NG; ++j) prod_finish(j, prod_load(j, 0), ty0, tx0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -225,47 +243,55 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
       if (next < ntiles) stage(next, (i + 1) & 1);
     }
 
-    f32x4 acc[8][2];
+    f32x4 acc[RW][2];
 #pragma unroll
-    for (int m = 0; m < 8; ++m)
+    for (int m = 0; m < RW; ++m)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[m][t] = f32x4{bias[t * 4], bias[t * 4 + 1], bias[t * 4 + 2], bias[t * 4 + 3]};
+      for (int t = 0; t < 2; ++t) {
+        if constexpr (CONST_IN_LDS) acc[m][t] = *reinterpret_cast<const f32x4*>(smem + C64R_CONST_OFF + 4096 + (ch * 4 + g) * 32 + t * 16);
+        else acc[m][t] = f32x4{bias[t * 4], bias[t * 4 + 1], bias[t * 4 + 2], bias[t * 4 + 3]};
+      }
     // 6 combos (column shift dx, channel half ks); the 10 pixel-row fragments of combo c+1 are requested before the
     // 48 MFMAs (3 filter rows x 8 pixel rows x 2 cout tiles) of combo c
-    typename P::vec8 bf[2][10];
+    constexpr int NB = RW == 8 ? 2 : 1;   // fragment double-buffering only when a wave is alone on its SIMD
+    typename P::vec8 bf[NB][RW + 2];
     const int xoff = (i & 1) * C64R_TILE_STRIDE;
     [[maybe_unused]] int nty = 0, ntx = 0;
     if constexpr (FUSE1A) tile_xy(next < ntiles ? next : tile, nty, ntx);   // past the end: harmless rewrite of a dead buffer
     auto load_combo = [&](int c, int set) {
       const int dx = c >> 1, ks = c & 1;
 #pragma unroll
-      for (int r = 0; r < 10; ++r) bf[set][r] = lds_frag<P>(smem, (boff[r][dx] ^ (ks << 6)) + xoff);
+      for (int r = 0; r < RW + 2; ++r) bf[set][r] = lds_frag<P>(smem, (boff[r][dx] ^ (ks << 6)) + xoff);
     };
     load_combo(0, 0);
-    if (SCHED) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+    if (SCHED) __builtin_amdgcn_sched_group_barrier(0x100, RW + 2, 0);
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      if (c + 1 < 6) load_combo(c + 1, (c + 1) & 1);
+      if (NB == 2 && c + 1 < 6) load_combo(c + 1, (c + 1) & 1);
+      if (NB == 1 && c > 0) load_combo(c, 0);
       [[maybe_unused]] Taps taps{};
-      if constexpr (FUSE1A) taps = prod_load(c, (i + 1) & 1);   // conv1a of the NEXT tile, group c (its patch landed an iteration ago)
+      constexpr int PG = 6 / NG;                               // one conv1a group every PG combos
+      const bool prod_here = FUSE1A && c % PG == 0;
+      if constexpr (FUSE1A) { if (prod_here) taps = prod_load(c / PG, (i + 1) & 1); }   // conv1a of the NEXT tile, group c (its patch landed an iteration ago)
       const int dx = c >> 1, ks = c & 1;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
+        for (int m = 0; m < RW; ++m)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) acc[m][t] = P::mfma(wreg[dy * 3 + dx][ks][t], bf[c & 1][m + dy], acc[m][t]);
-      if constexpr (FUSE1A) prod_finish(c, taps, nty, ntx, (i + 1) & 1);
+          for (int t = 0; t < 2; ++t) acc[m][t] = P::mfma(wreg[dy * 3 + dx][ks][t], bf[c & (NB - 1)][m + dy], acc[m][t]);
+      if constexpr (FUSE1A) { if (prod_here) prod_finish(c / PG, taps, nty, ntx, (i + 1) & 1); }
       // issue-order pipeline for the scheduler: one fragment read of the NEXT combo per 4 MFMAs of this one (hipcc otherwise
       // sinks the reads down to their first use and every 6 MFMAs wait out a full LDS latency)
-      if (SCHED) {
+      if (SCHED && NB == 2) {
 #pragma unroll
-        for (int sidx = 0; sidx < 10; ++sidx) {
+        for (int sidx = 0; sidx < RW + 2; ++sidx) {
           __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if constexpr (FUSE1A) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          if (prod_here) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, FUSE1A ? 12 : 8, 0);
+        if (prod_here) __builtin_amdgcn_sched_group_barrier(0x008, 6 * RW - 4 * (RW + 2) + 4, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x008, 6 * RW - 4 * (RW + 2), 0);
       }
     }
 
@@ -278,9 +304,9 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
     const int b = tile / per_img, rem = tile - b * per_img;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     uint16_t* ybase = a.Y + (size_t)b * (Ho + 2 * opad) * orow + cb0 * 64 + ch * 32 + g * 8;
-    uint4 pk[8];
+    uint4 pk[RW];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < RW; ++m) {
       pk[m].x = P::pack2(acc[m][0][0], acc[m][0][1]);
       pk[m].y = P::pack2(acc[m][0][2], acc[m][0][3]);
       pk[m].z = P::pack2(acc[m][1][0], acc[m][1][1]);
@@ -288,13 +314,13 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
     }
     if constexpr (!POOL) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int y = ty * 16 + ph * 8 + m, x = tx * 16 + l15;
+      for (int m = 0; m < RW; ++m) {
+        const int y = ty * 16 + ph * RW + m, x = tx * 16 + l15;
         *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * COUT) = relu_packed(pk[m]);
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < RW / 4; ++q) {
         uint4 v[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -303,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
         }
         // both lanes of a column pair hold both pooled rows: the even lane stores row 2q, the odd lane row 2q + 1
         const uint4 r = relu_packed((l15 & 1) ? v[1] : v[0]);
-        const int y = (ty * 16 + ph * 8) / 2 + 2 * q + (l15 & 1), x = tx * 8 + (l15 >> 1);
+        const int y = (ty * 16 + ph * RW) / 2 + 2 * q + (l15 & 1), x = tx * 8 + (l15 >> 1);
         *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * COUT) = r;
       }
     }
@@ -312,9 +338,10 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(ConvArgs a, int tiles_x
 
 template <class P, bool POOL, bool FUSE1A>
 static void conv64r_launch_t(const ConvArgs& a, hipStream_t st) {
-  constexpr int LDS = 2 * C64R_TILE_STRIDE + (FUSE1A ? 2 * C64R_PATCH * 4 : 0);
+  constexpr int RW = C64R_RW;
+  constexpr int LDS = C64R_CONST_OFF + 4096 + 256;
   static bool attr_done = false;
-  auto kfn = conv64r_kernel<P, POOL, FUSE1A>;
+  auto kfn = conv64r_kernel<P, POOL, FUSE1A, RW>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
@@ -323,7 +350,7 @@ static void conv64r_launch_t(const ConvArgs& a, hipStream_t st) {
   const int ntiles = tiles_x * tiles_y * a.B;
   const int grid = ntiles < 256 ? ntiles : 256;
   for (int cb0 = 0; cb0 < a.COUT / 64; ++cb0)          // 64 output channels per pass
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), LDS, st, a, tiles_x, tiles_y, ntiles, cb0);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(2048 / RW), LDS, st, a, tiles_x, tiles_y, ntiles, cb0);
 }
 
 // requires CIN == 64, COUT % 64 == 0, relu, H % 16 == 0, W % 16 == 0.  a.img != nullptr selects the fused conv1a + conv1b
