@@ -238,8 +238,16 @@ class Context:
             torch.cuda.synchronize()
         return stream
 
-    def profile(self, on: bool):
-        self._chk(self._l.airfe_profile_enable(self._h, int(on)), "airfe_profile_enable")
+    def profile(self, on=True, stages=None):
+        """Per-stage hipEvent timers: on=False off, on=True every stage, stages=[names] only those (cheaper)."""
+        mask = 0
+        if stages is not None:
+            names = [self._l.airfe_profile_stage_name(i).decode() for i in range(self._l.airfe_profile_stages())]
+            for s in stages:
+                mask |= 1 << names.index(s)
+        elif on:
+            mask = -1
+        self._chk(self._l.airfe_profile_enable(self._h, mask), "airfe_profile_enable")
 
     def profile_read(self):
         n = self._l.airfe_profile_stages()

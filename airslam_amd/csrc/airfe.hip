@@ -214,7 +214,7 @@ struct airfe_ctx {
 
   // per-stage hipEvent timers (airfe_profile_*): events are recorded on the launch stream only
   struct Mark { int stage; hipEvent_t a, b; double flops, bytes; };
-  bool prof_on = false;
+  uint32_t prof_mask = 0;        // bit i = stage i is bracketed by events
   std::vector<Mark> marks;
   std::vector<hipEvent_t> ev_pool;
 };
@@ -229,7 +229,7 @@ static const char* kStageNames[ST_COUNT] = {
 
 struct ProfScope {
   airfe_ctx* c; hipStream_t st; bool on; airfe_ctx::Mark m;
-  ProfScope(airfe_ctx* c_, int stage, hipStream_t st_, double flops, double bytes) : c(c_), st(st_), on(c_->prof_on) {
+  ProfScope(airfe_ctx* c_, int stage, hipStream_t st_, double flops, double bytes) : c(c_), st(st_), on((c_->prof_mask >> stage) & 1u) {
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;
@@ -890,7 +890,7 @@ int airfe_profile_enable(airfe_ctx* c, int on) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (auto& m : c->marks) { c->ev_pool.push_back(m.a); c->ev_pool.push_back(m.b); }
   c->marks.clear();
-  c->prof_on = on != 0;
+  c->prof_mask = on < 0 ? 0xFFFFFFFFu : (uint32_t)on;
   return 0;
 }
 

@@ -111,7 +111,9 @@ int airfe_stereo_batch_dev(airfe_ctx* ctx, const uint8_t* d_left, const uint8_t*
 int airfe_sync(airfe_ctx* ctx);
 
 /* ---- per-stage hipEvent timers (measurement; SURVEY.md §5 "tracing") ----------------------------------- */
-/* enable/disable + reset; while enabled every kernel group is bracketed by events on its launch stream */
+/* select + reset: on = 0 off, on < 0 every stage, on > 0 bit mask (bit i = stage i).  A selected stage has each of its
+   kernel groups bracketed by two events on the launch stream; an event pair costs ~4 us of stream time (measured: all
+   stages on = +8 % per step), so timed runs select only the stage they need. */
 int airfe_profile_enable(airfe_ctx* ctx, int on);
 int airfe_profile_stages(void);
 const char* airfe_profile_stage_name(int i);
