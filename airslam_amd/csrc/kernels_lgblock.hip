@@ -1,0 +1,270 @@
+// airfe — LightGlue "post-attention block" in ONE kernel:
+//     msg = Wo . attn + bo ;  h = W1 . cat(x, msg) + b1 ;  h = GELU(LayerNorm(h)) ;  x += W2 . h + b2
+// (reference model: LightGlue SelfBlock / CrossBlock tail — out_proj / to_out, ffn.0, ffn.1 LayerNorm, ffn.2 GELU, ffn.3,
+//  residual; executed by the reference through TensorRT, src/light_glue.cpp:76-113 infer()).
+//
+// Why: as four launches (3 GEMMs + LayerNorm/GELU) these are 63 % of LightGlue's linear FLOPs but moved 8.7 KB of
+// activations per token through HBM and ran at ~350 TFLOP/s.  Here a wave owns 32 tokens for the whole chain:
+//   * swapped-operand MFMA (A = weight rows, B = tokens): the accumulator layout of one GEMM, rounded to 2 bytes, IS the
+//     B-fragment layout of the next (lane (token, g) holds 8 consecutive features per tile pair), so msg and h never leave
+//     registers — no LDS round trip, no cross-wave LayerNorm reduction (a token's 512 features live in 4 lanes of one wave);
+//   * HBM traffic per token: read attn 512 B + x 512 B + fp32 residual 1 KB, write x 512 B + residual 1 KB (2.5x less);
+//   * the 896 KB of weights per block stream through a 2 x 64 KiB LDS ring by LDS-DMA in the exact order the MFMAs consume
+//     them ("fragment-linear" packing done once on the host), one s_barrier per stage = 128 MFMAs per wave.
+// The kernel is LDS-read bound by construction (each 1 KB weight fragment feeds only 2 MFMAs per wave): ~50 % of the
+// MFMA peak is the ceiling of this decomposition; it is still 3x the separate GEMMs.
+#include "common.h"
+#include "kernels.h"
+
+namespace airfe {
+
+typedef __attribute__((address_space(3))) void* las_ptr_lb;
+
+// LDS-DMA, scalar-base form: 16 bytes per lane from sbase + voff to LDS address M0 + lane*16.  The base is a RUNNING scalar
+// pointer: with per-stage constant offsets hipcc hoisted all 224 64-bit piece addresses out of the tile loop and spilled them.
+__device__ __forceinline__ void lb_glds16(unsigned voff, const void* sbase, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_off)
+               : "memory");
+}
+
+constexpr int LB_STAGE = 65536;                    // one ring slot: 64 weight fragments of 1 KB = [8 k-steps][8 feature tiles]
+constexpr int LB_NSTAGE = LGB_STREAM_STAGES / 2;   // 2 (out-proj) + 8 (ffn.0) + 4 (ffn.3) stages of 64 KiB
+constexpr int LB_SLOTS = 2;
+constexpr int LB_PARAM_OFF = LB_SLOTS * LB_STAGE;
+constexpr int LB_LDS = LB_PARAM_OFF + LGB_PARAM_FLOATS * 4;
+// parameter block (floats): bo[256] | b1[512] | gamma[512] | beta[512] | b2[256]
+constexpr int LB_BO = 0, LB_B1 = 256, LB_GAMMA = 768, LB_BETA = 1280, LB_B2 = 1792;
+
+__device__ __forceinline__ float lb_gelu(float y) {          // exact-erf GELU, Abramowitz & Stegun 7.1.26 (as ln_gelu_kernel)
+  const float x = fabsf(y) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erfa = 1.0f - poly * t * __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
+  return 0.5f * y * (1.0f + copysignf(erfa, y));
+}
+
+// ds_read_b128 issued from inline asm: the read stays where it is written (hipcc sinks a plain LDS load down to its first
+// use, and with 2 MFMAs per fragment every pair then waits out a full LDS latency; sched_group_barrier pins the order too
+// but its solver does not terminate in reasonable time on a 1800-MFMA region).  The matching lgkmcnt wait is placed by hand.
+template <class V>
+__device__ __forceinline__ void lb_ds_read(V& dst, unsigned addr, int off) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(off) : "memory");
+}
+// 128 MFMAs of one stage: 8 k-steps x 8 feature tiles x 2 token tiles; B fragments b[OFF + ks][m] (OFF is a compile-time
+// constant: every register array here must be indexed by constants only, or hipcc demotes it to scratch).  The 8 weight
+// fragments of k-step ks+1 are requested before the 16 MFMAs of k-step ks issue and awaited after them.
+template <class P, int OFF, int N>
+__device__ __forceinline__ void lb_stage_mfma(unsigned sb, const typename P::vec8 (&b)[N][2], f32x4 (&acc)[8][2]) {
+  typename P::vec8 wf[2][8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) lb_ds_read(wf[0][t], sb, t * 1024);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    if (ks + 1 < 8) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) lb_ds_read(wf[(ks + 1) & 1][t], sb, ((ks + 1) * 8 + t) * 1024);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[t][m] = P::mfma(wf[ks & 1][t], b[OFF + ks][m], acc[t][m]);
+    if (ks + 1 < 8) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+// accumulators start at the bias of their 4 features
+__device__ __forceinline__ void lb_init_acc(const float* bias, int g, f32x4 (&acc)[8][2]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (t >> 1) * 32 + g * 8 + (t & 1) * 4);
+    acc[t][0] = bv;
+    acc[t][1] = bv;
+  }
+}
+// features tp*32 + g*8 .. +7 of both token tiles, rounded to 2 bytes = the next GEMM's B fragments dst[DST + tp][m]
+template <class P, int DST, int N>
+__device__ __forceinline__ void lb_pack_chunk(const f32x4 (&acc)[8][2], typename P::vec8 (&dst)[N][2]) {
+#pragma unroll
+  for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      uint4 u;
+      u.x = P::pack2(acc[2 * tp][m][0], acc[2 * tp][m][1]);
+      u.y = P::pack2(acc[2 * tp][m][2], acc[2 * tp][m][3]);
+      u.z = P::pack2(acc[2 * tp + 1][m][0], acc[2 * tp + 1][m][1]);
+      u.w = P::pack2(acc[2 * tp + 1][m][2], acc[2 * tp + 1][m][3]);
+      dst[DST + tp][m] = __builtin_bit_cast(typename P::vec8, u);
+    }
+}
+
+template <class P>
+__global__ __launch_bounds__(256, 1) void lg_block_kernel(LgBlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(las_ptr_lb)smem);
+  float* prm = reinterpret_cast<float*>(smem + LB_PARAM_OFF);
+  for (int i = tid; i < LGB_PARAM_FLOATS; i += 256) prm[i] = a.params[i];
+  __syncthreads();
+
+  const unsigned wvoff = tid * 16;
+  const char* wq = reinterpret_cast<const char*>(a.wstream);        // wave-uniform cursor into the cyclic weight stream
+  const unsigned sbase = lds_base + lane * 16;      // LDS byte address of this lane's 16 bytes inside a fragment
+  // stage sg of the cyclic weight stream -> ring slot sg & 1
+#define LB_DMA(SG)                                                                                         \
+  {                                                                                                        \
+    if ((SG) == LB_NSTAGE) wq = reinterpret_cast<const char*>(a.wstream);                                  \
+    const unsigned dst_ = lds_base + ((SG) & 1) * LB_STAGE + wave * 1024;                                  \
+    _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                    \
+      lb_glds16(wvoff, wq, dst_ + j_ * 4096);                                                              \
+      wq += 4096;                                                                                          \
+    }                                                                                                      \
+  }
+  // stage boundary: my pieces of stage S have landed (issued one stage = ~2000 MFMA cycles ago), everyone's have (barrier),
+  // the other slot — read during the previous stage — is refilled with stage S+1; then the 128 MFMAs of stage S
+#define LB_RUN(S, ARR, OFF, N)                                                                             \
+  {                                                                                                        \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    LB_DMA((S) + 1)                                                                                        \
+    lb_stage_mfma<P, OFF, N>(sbase + ((S) & 1) * LB_STAGE, ARR, acc);                                      \
+  }
+
+  const int ntiles = a.M >> 7;
+  int tile = blockIdx.x;
+  if (tile < ntiles) LB_DMA(0)
+
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int tok0 = tile * 128 + wave * 32;
+    // ---- token fragments straight from HBM: lane (token l15, g) holds k = ks*32 + g*8 .. +7
+    typename P::vec8 obf[8][2], xf[8][2], msgf[8][2], hf[16][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const size_t row = (size_t)(tok0 + m * 16 + l15) * 256 + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        obf[ks][m] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(a.attn + row + ks * 32));
+    }
+    f32x4 acc[8][2];
+
+    // ---- out-projection: msg[256] = Wo . attn + bo           (stages 0..1)
+#define LB_OUT_CHUNK(FC)                                     \
+    lb_init_acc(prm + LB_BO + (FC) * 128, g, acc);           \
+    LB_RUN((FC), obf, 0, 8)                                  \
+    lb_pack_chunk<P, (FC) * 4, 8>(acc, msgf);
+    LB_OUT_CHUNK(0)
+    LB_OUT_CHUNK(1)
+    // x fragments only now: the attention fragments are dead, so at most 64 + 64 + 128 fragment registers are ever live
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const size_t row = (size_t)(tok0 + m * 16 + l15) * 256 + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        xf[ks][m] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(a.xb + row + ks * 32));
+    }
+
+    // ---- ffn.0: h[512] = W1 . cat(x, msg) + b1 ; LayerNorm statistics from the fp32 accumulators   (stages 2..9)
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#define LB_FFN0_CHUNK(FC)                                    \
+    lb_init_acc(prm + LB_B1 + (FC) * 128, g, acc);           \
+    LB_RUN(2 + (FC) * 2 + 0, xf, 0, 8)                       \
+    LB_RUN(2 + (FC) * 2 + 1, msgf, 0, 8)                     \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t)            \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {        \
+        s1[0] += acc[t][0][r];                               \
+        s1[1] += acc[t][1][r];                               \
+        s2[0] = fmaf(acc[t][0][r], acc[t][0][r], s2[0]);     \
+        s2[1] = fmaf(acc[t][1][r], acc[t][1][r], s2[1]);     \
+      }                                                      \
+    lb_pack_chunk<P, (FC) * 4, 16>(acc, hf);
+    LB_FFN0_CHUNK(0)
+    LB_FFN0_CHUNK(1)
+    LB_FFN0_CHUNK(2)
+    LB_FFN0_CHUNK(3)
+
+    // ---- LayerNorm(512) + GELU, in registers: a token's features sit in the 4 lanes {l15, l15+16, l15+32, l15+48}
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float a1 = s1[m], a2 = s2[m];
+      a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
+      a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+      mean[m] = a1 * (1.0f / 512.0f);
+      const float var = fmaxf(a2 * (1.0f / 512.0f) - mean[m] * mean[m], 0.f);
+      rstd[m] = 1.0f / sqrtf(var + 1e-5f);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(prm + LB_GAMMA + kk * 32 + g * 8);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(prm + LB_GAMMA + kk * 32 + g * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(prm + LB_BETA + kk * 32 + g * 8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(prm + LB_BETA + kk * 32 + g * 8 + 4);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float v[8];
+        unpack8<P>(__builtin_bit_cast(uint4, hf[kk][m]), v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = lb_gelu(fmaf((v[e] - mean[m]) * rstd[m], g0[e], b0[e]));
+          v[4 + e] = lb_gelu(fmaf((v[4 + e] - mean[m]) * rstd[m], g1[e], b1[e]));
+        }
+        hf[kk][m] = __builtin_bit_cast(typename P::vec8, pack8<P>(v));
+      }
+    }
+
+    // ---- ffn.3 + residual: x += W2 . h + b2     (stages 10..13)
+#define LB_FFN3_CHUNK(FC)                                                                                  \
+    lb_init_acc(prm + LB_B2 + (FC) * 128, g, acc);                                                         \
+    LB_RUN(10 + (FC) * 2 + 0, hf, 0, 16)                                                                   \
+    LB_RUN(10 + (FC) * 2 + 1, hf, 8, 16)                                                                   \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                        \
+      const size_t row = (size_t)(tok0 + m * 16 + l15) * 256 + (FC) * 128 + g * 8;                         \
+      _Pragma("unroll") for (int tp = 0; tp < 4; ++tp) {                                                   \
+        float* xr = a.x32 + row + tp * 32;                                                                 \
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(xr), r1 = *reinterpret_cast<const f32x4*>(xr + 4);\
+        float v[8];                                                                                        \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
+          v[e] = acc[2 * tp][m][e] + r0[e];                                                                \
+          v[4 + e] = acc[2 * tp + 1][m][e] + r1[e];                                                        \
+        }                                                                                                  \
+        *reinterpret_cast<f32x4*>(xr) = f32x4{v[0], v[1], v[2], v[3]};                                     \
+        *reinterpret_cast<f32x4*>(xr + 4) = f32x4{v[4], v[5], v[6], v[7]};                                 \
+        *reinterpret_cast<uint4*>(a.xb + row + tp * 32) = pack8<P>(v);                                     \
+      }                                                                                                    \
+    }
+    LB_FFN3_CHUNK(0)
+    LB_FFN3_CHUNK(1)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prefetched first stage of a tile that does not exist
+#undef LB_DMA
+#undef LB_RUN
+#undef LB_OUT_CHUNK
+#undef LB_FFN0_CHUNK
+#undef LB_FFN3_CHUNK
+}
+
+// requires M % 128 == 0.  attn / xb: [M][256] 2-byte rows, x32: [M][256] fp32 residual stream (xb and x32 updated in place)
+void launch_lg_block(int prec, const LgBlockArgs& a, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lg_block_kernel<PBF16>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lg_block_kernel<PF16>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS);
+    attr_done = true;
+  }
+  const int ntiles = a.M / 128;
+  const int grid = ntiles < 256 ? ntiles : 256;
+  if (prec == 1) hipLaunchKernelGGL(lg_block_kernel<PF16>, dim3(grid), dim3(256), LB_LDS, st, a);
+  else hipLaunchKernelGGL(lg_block_kernel<PBF16>, dim3(grid), dim3(256), LB_LDS, st, a);
+}
+
+}  // namespace airfe
