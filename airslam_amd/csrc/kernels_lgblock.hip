@@ -33,6 +33,10 @@ __device__ __forceinline__ void lb_glds16(unsigned voff, const void* sbase, unsi
 constexpr int LB_STAGE = 65536;                    // one ring slot: 64 weight fragments of 1 KB = [8 k-steps][8 feature tiles]
 constexpr int LB_NSTAGE = LGB_STREAM_STAGES / 2;   // 2 (out-proj) + 8 (ffn.0) + 4 (ffn.3) stages of 64 KiB
 constexpr int LB_SLOTS = 2;
+#ifndef LB_NM_DEF
+#define LB_NM_DEF 2
+#endif
+constexpr int LB_NM = LB_NM_DEF;                   // 16-token tiles per wave: 1 -> 8 waves (two per SIMD), 2 -> 4 waves
 constexpr int LB_PARAM_OFF = LB_SLOTS * LB_STAGE;
 constexpr int LB_LDS = LB_PARAM_OFF + LGB_PARAM_FLOATS * 4;
 // parameter block (floats): bo[256] | b1[512] | gamma[512] | beta[512] | b2[256]
@@ -59,45 +63,62 @@ __device__ __forceinline__ void lb_ds_read(V& dst, unsigned addr, int off) {
 // 128 MFMAs of one stage: 8 k-steps x 8 feature tiles x 2 token tiles; B fragments b[OFF + ks][m] (OFF is a compile-time
 // constant: every register array here must be indexed by constants only, or hipcc demotes it to scratch).  The 8 weight
 // fragments of k-step ks+1 are requested before the 16 MFMAs of k-step ks issue and awaited after them.
-template <class P, int OFF, int N>
-__device__ __forceinline__ void lb_stage_mfma(unsigned sb, const typename P::vec8 (&b)[N][2], f32x4 (&acc)[8][2]) {
-  typename P::vec8 wf[2][8];
+template <class P, int OFF, int N, int NM>
+__device__ __forceinline__ void lb_stage_mfma(unsigned sb, const typename P::vec8 (&b)[N][NM], f32x4 (&acc)[8][NM]) {
+  if constexpr (NM == 1) {
+    // two waves per SIMD: the sibling wave's MFMAs cover this wave's LDS latency; one fragment buffer (32 registers)
 #pragma unroll
-  for (int t = 0; t < 8; ++t) lb_ds_read(wf[0][t], sb, t * 1024);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
+    for (int ks = 0; ks < 8; ++ks) {
+      typename P::vec8 wf[8];
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    if (ks + 1 < 8) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) lb_ds_read(wf[(ks + 1) & 1][t], sb, ((ks + 1) * 8 + t) * 1024);
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) acc[t][m] = P::mfma(wf[ks & 1][t], b[OFF + ks][m], acc[t][m]);
-    if (ks + 1 < 8) {
+      for (int t = 0; t < 8; ++t) lb_ds_read(wf[t], sb, (ks * 8 + t) * 1024);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t][0] = P::mfma(wf[t], b[OFF + ks][0], acc[t][0]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    typename P::vec8 wf[2][8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) lb_ds_read(wf[0][t], sb, t * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) lb_ds_read(wf[(ks + 1) & 1][t], sb, ((ks + 1) * 8 + t) * 1024);
+        __builtin_amdgcn_sched_barrier(0);   // or the MFMAs below are hoisted above the reads and the two buffers collapse into one
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) acc[t][m] = P::mfma(wf[ks & 1][t], b[OFF + ks][m], acc[t][m]);
+      if (ks + 1 < 8) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 }
 // accumulators start at the bias of their 4 features
-__device__ __forceinline__ void lb_init_acc(const float* bias, int g, f32x4 (&acc)[8][2]) {
+template <int NM>
+__device__ __forceinline__ void lb_init_acc(const float* bias, int g, f32x4 (&acc)[8][NM]) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (t >> 1) * 32 + g * 8 + (t & 1) * 4);
-    acc[t][0] = bv;
-    acc[t][1] = bv;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc[t][m] = bv;
   }
 }
 // features tp*32 + g*8 .. +7 of both token tiles, rounded to 2 bytes = the next GEMM's B fragments dst[DST + tp][m]
-template <class P, int DST, int N>
-__device__ __forceinline__ void lb_pack_chunk(const f32x4 (&acc)[8][2], typename P::vec8 (&dst)[N][2]) {
+template <class P, int DST, int N, int NM>
+__device__ __forceinline__ void lb_pack_chunk(const f32x4 (&acc)[8][NM], typename P::vec8 (&dst)[N][NM]) {
 #pragma unroll
   for (int tp = 0; tp < 4; ++tp)
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < NM; ++m) {
       uint4 u;
       u.x = P::pack2(acc[2 * tp][m][0], acc[2 * tp][m][1]);
       u.y = P::pack2(acc[2 * tp][m][2], acc[2 * tp][m][3]);
@@ -107,95 +128,116 @@ __device__ __forceinline__ void lb_pack_chunk(const f32x4 (&acc)[8][2], typename
     }
 }
 
-template <class P>
-__global__ __launch_bounds__(256, 1) void lg_block_kernel(LgBlockArgs a) {
+// Code size matters here: fully unrolled, the 14 stages are ~100 KB of instructions, more than the 64 KB instruction cache
+// two CUs share, and every tile re-fetched all of it from L2 (measured: removing the MFMAs AND the LDS reads from that
+// version barely changed its run time).  So each GEMM is a ROLLED loop over 128-feature chunks whose body always uses the
+// same registers; the packed results enter msgf / hf through a 4-entry shift (register moves, ~300 per tile) instead of
+// through chunk-dependent register indices.
+// NM = 16-token tiles per wave; a workgroup is always 128 tokens = 8 / NM waves
+template <class P, int NM>
+__global__ __launch_bounds__(512 / NM, 1) void lg_block_kernel(LgBlockArgs a) {
+  constexpr int NT = 512 / NM;                      // threads
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(las_ptr_lb)smem);
   float* prm = reinterpret_cast<float*>(smem + LB_PARAM_OFF);
-  for (int i = tid; i < LGB_PARAM_FLOATS; i += 256) prm[i] = a.params[i];
+  for (int i = tid; i < LGB_PARAM_FLOATS; i += NT) prm[i] = a.params[i];
   __syncthreads();
 
   const unsigned wvoff = tid * 16;
   const char* wq = reinterpret_cast<const char*>(a.wstream);        // wave-uniform cursor into the cyclic weight stream
   const unsigned sbase = lds_base + lane * 16;      // LDS byte address of this lane's 16 bytes inside a fragment
-  // stage sg of the cyclic weight stream -> ring slot sg & 1
-#define LB_DMA(SG)                                                                                         \
+  int sg = 0;                                       // stage (0..13) the NEXT LB_DMA fetches; ring slot = sg & 1
+#define LB_DMA()                                                                                           \
   {                                                                                                        \
-    if ((SG) == LB_NSTAGE) wq = reinterpret_cast<const char*>(a.wstream);                                  \
-    const unsigned dst_ = lds_base + ((SG) & 1) * LB_STAGE + wave * 1024;                                  \
-    _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                    \
-      lb_glds16(wvoff, wq, dst_ + j_ * 4096);                                                              \
-      wq += 4096;                                                                                          \
-    }                                                                                                      \
+    const unsigned dst_ = lds_base + (sg & 1) * LB_STAGE + wave * 1024;                                    \
+    _Pragma("unroll") for (int j_ = 0; j_ < LB_STAGE / (NT * 16); ++j_) lb_glds16(wvoff, wq + j_ * (NT * 16), dst_ + j_ * (NT * 16)); \
+    wq += LB_STAGE;                                                                                        \
+    if (++sg == LB_NSTAGE) { sg = 0; wq = reinterpret_cast<const char*>(a.wstream); }                      \
   }
-  // stage boundary: my pieces of stage S have landed (issued one stage = ~2000 MFMA cycles ago), everyone's have (barrier),
-  // the other slot — read during the previous stage — is refilled with stage S+1; then the 128 MFMAs of stage S
-#define LB_RUN(S, ARR, OFF, N)                                                                             \
+  // stage boundary: my pieces of the current stage have landed (issued one stage = ~2000 MFMA cycles ago), everyone's have
+  // (barrier), the other slot — read during the previous stage — is refilled with the next stage; then 128 MFMAs.
+  // (LB_NSTAGE is even: the stage being computed sits in the slot the next LB_DMA does NOT target.)
+#define LB_RUN(ARR, OFF, N)                                                                                \
   {                                                                                                        \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
     __builtin_amdgcn_s_barrier();                                                                          \
-    LB_DMA((S) + 1)                                                                                        \
-    lb_stage_mfma<P, OFF, N>(sbase + ((S) & 1) * LB_STAGE, ARR, acc);                                      \
+    const unsigned cur_ = sbase + ((sg & 1) ^ 1) * LB_STAGE;                                               \
+    LB_DMA()                                                                                               \
+    lb_stage_mfma<P, OFF, N, NM>(cur_, ARR, acc);                                                              \
   }
 
   const int ntiles = a.M >> 7;
   int tile = blockIdx.x;
-  if (tile < ntiles) LB_DMA(0)
+  if (tile < ntiles) LB_DMA()
+
+  // ---- token fragments straight from HBM: lane (token l15, g) holds k = ks*32 + g*8 .. +7.  With one wave per SIMD nothing
+  // hides a load but the wave's own MFMAs, so every HBM read is issued a stage or more before its first use: the attention
+  // rows of tile i+1 during the last two stages of tile i, x at the top of the tile (first used in stage 2), the fp32
+  // residual at the top of each ffn.3 chunk.  (The memory-clobbering asm of the stage boundaries keeps the loads in place.)
+  typename P::vec8 obf[8][NM];
+#define LB_LOAD_ATTN(TILE)                                                                                 \
+  _Pragma("unroll") for (int m = 0; m < NM; ++m) {                                                         \
+    const size_t row_ = (size_t)((TILE) * 128 + wave * (16 * NM) + m * 16 + l15) * 256 + g * 8;            \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks)                                                       \
+      obf[ks][m] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(a.attn + row_ + ks * 32)); \
+  }
+  constexpr bool PREF = NM == 2;                    // one wave per SIMD: nothing but explicit prefetch hides HBM latency
+  if (PREF && tile < ntiles) { LB_LOAD_ATTN(tile) }
 
   for (; tile < ntiles; tile += gridDim.x) {
-    const int tok0 = tile * 128 + wave * 32;
-    // ---- token fragments straight from HBM: lane (token l15, g) holds k = ks*32 + g*8 .. +7
-    typename P::vec8 obf[8][2], xf[8][2], msgf[8][2], hf[16][2];
+    const int tok0 = tile * 128 + wave * (16 * NM);
+    typename P::vec8 xf[8][NM], msgf[8][NM], hf[16][NM];
+    if (!PREF) { LB_LOAD_ATTN(tile) }
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const size_t row = (size_t)(tok0 + m * 16 + l15) * 256 + g * 8;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-        obf[ks][m] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(a.attn + row + ks * 32));
-    }
-    f32x4 acc[8][2];
-
-    // ---- out-projection: msg[256] = Wo . attn + bo           (stages 0..1)
-#define LB_OUT_CHUNK(FC)                                     \
-    lb_init_acc(prm + LB_BO + (FC) * 128, g, acc);           \
-    LB_RUN((FC), obf, 0, 8)                                  \
-    lb_pack_chunk<P, (FC) * 4, 8>(acc, msgf);
-    LB_OUT_CHUNK(0)
-    LB_OUT_CHUNK(1)
-    // x fragments only now: the attention fragments are dead, so at most 64 + 64 + 128 fragment registers are ever live
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < NM; ++m) {
       const size_t row = (size_t)(tok0 + m * 16 + l15) * 256 + g * 8;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks)
         xf[ks][m] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(a.xb + row + ks * 32));
     }
+    f32x4 acc[8][NM];
 
-    // ---- ffn.0: h[512] = W1 . cat(x, msg) + b1 ; LayerNorm statistics from the fp32 accumulators   (stages 2..9)
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-#define LB_FFN0_CHUNK(FC)                                    \
-    lb_init_acc(prm + LB_B1 + (FC) * 128, g, acc);           \
-    LB_RUN(2 + (FC) * 2 + 0, xf, 0, 8)                       \
-    LB_RUN(2 + (FC) * 2 + 1, msgf, 0, 8)                     \
-    _Pragma("unroll") for (int t = 0; t < 8; ++t)            \
-      _Pragma("unroll") for (int r = 0; r < 4; ++r) {        \
-        s1[0] += acc[t][0][r];                               \
-        s1[1] += acc[t][1][r];                               \
-        s2[0] = fmaf(acc[t][0][r], acc[t][0][r], s2[0]);     \
-        s2[1] = fmaf(acc[t][1][r], acc[t][1][r], s2[1]);     \
-      }                                                      \
-    lb_pack_chunk<P, (FC) * 4, 16>(acc, hf);
-    LB_FFN0_CHUNK(0)
-    LB_FFN0_CHUNK(1)
-    LB_FFN0_CHUNK(2)
-    LB_FFN0_CHUNK(3)
-
-    // ---- LayerNorm(512) + GELU, in registers: a token's features sit in the 4 lanes {l15, l15+16, l15+32, l15+48}
-    float mean[2], rstd[2];
+    // ---- out-projection: msg[256] = Wo . attn + bo           (stages 0..1)
+#pragma unroll 1
+    for (int fc = 0; fc < 2; ++fc) {
+      lb_init_acc<NM>(prm + LB_BO + fc * 128, g, acc);
+      LB_RUN(obf, 0, 8)
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) msgf[i][m] = msgf[i + 4][m];
+      lb_pack_chunk<P, 4, 8, NM>(acc, msgf);
+    }
+    // ---- ffn.0: h[512] = W1 . cat(x, msg) + b1 ; LayerNorm statistics from the fp32 accumulators   (stages 2..9)
+    float s1[NM], s2[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
+#pragma unroll 1
+    for (int fc = 0; fc < 4; ++fc) {
+      lb_init_acc<NM>(prm + LB_B1 + fc * 128, g, acc);
+      LB_RUN(xf, 0, 8)
+      LB_RUN(msgf, 0, 8)
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int m = 0; m < NM; ++m) {
+            s1[m] += acc[t][m][r];
+            s2[m] = fmaf(acc[t][m][r], acc[t][m][r], s2[m]);
+          }
+#pragma unroll
+      for (int i = 0; i < 12; ++i)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) hf[i][m] = hf[i + 4][m];
+      lb_pack_chunk<P, 12, 16, NM>(acc, hf);
+    }
+    // ---- LayerNorm(512) + GELU, in registers: a token's features sit in the 4 lanes {l15, l15+16, l15+32, l15+48}
+    float mean[NM], rstd[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
       float a1 = s1[m], a2 = s2[m];
       a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
       a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
@@ -203,68 +245,95 @@ __global__ __launch_bounds__(256, 1) void lg_block_kernel(LgBlockArgs a) {
       const float var = fmaxf(a2 * (1.0f / 512.0f) - mean[m] * mean[m], 0.f);
       rstd[m] = 1.0f / sqrtf(var + 1e-5f);
     }
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {                    // 4 k-steps per trip: take the front of the shift register, append behind
+      typename P::vec8 res[4][NM];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(prm + LB_GAMMA + kk * 32 + g * 8);
-      const f32x4 g1 = *reinterpret_cast<const f32x4*>(prm + LB_GAMMA + kk * 32 + g * 8 + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(prm + LB_BETA + kk * 32 + g * 8);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(prm + LB_BETA + kk * 32 + g * 8 + 4);
+      for (int i = 0; i < 4; ++i) {
+        const float* gp = prm + LB_GAMMA + (q * 4 + i) * 32 + g * 8;
+        const float* bp = prm + LB_BETA + (q * 4 + i) * 32 + g * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float v[8];
-        unpack8<P>(__builtin_bit_cast(uint4, hf[kk][m]), v);
+        for (int m = 0; m < NM; ++m) {
+          float v[8];
+          unpack8<P>(__builtin_bit_cast(uint4, hf[i][m]), v);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = lb_gelu(fmaf((v[e] - mean[m]) * rstd[m], g0[e], b0[e]));
-          v[4 + e] = lb_gelu(fmaf((v[4 + e] - mean[m]) * rstd[m], g1[e], b1[e]));
+          for (int e = 0; e < 4; ++e) {
+            v[e] = lb_gelu(fmaf((v[e] - mean[m]) * rstd[m], g0[e], b0[e]));
+            v[4 + e] = lb_gelu(fmaf((v[4 + e] - mean[m]) * rstd[m], g1[e], b1[e]));
+          }
+          res[i][m] = __builtin_bit_cast(typename P::vec8, pack8<P>(v));
         }
-        hf[kk][m] = __builtin_bit_cast(typename P::vec8, pack8<P>(v));
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) hf[i][m] = hf[i + 4][m];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) hf[12 + i][m] = res[i][m];
+    }
+    // ---- ffn.3 + residual: x += W2 . h + b2     (stages 10..13)
+#pragma unroll 1
+    for (int fc = 0; fc < 2; ++fc) {
+      lb_init_acc<NM>(prm + LB_B2 + fc * 128, g, acc);
+      [[maybe_unused]] f32x4 rsd[NM][4][2];
+      if constexpr (PREF) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          const float* xr = a.x32 + (size_t)(tok0 + m * 16 + l15) * 256 + fc * 128 + g * 8;
+#pragma unroll
+          for (int tp = 0; tp < 4; ++tp) {
+            rsd[m][tp][0] = *reinterpret_cast<const f32x4*>(xr + tp * 32);
+            rsd[m][tp][1] = *reinterpret_cast<const f32x4*>(xr + tp * 32 + 4);
+          }
+        }
+      }
+      LB_RUN(hf, 0, 16)
+      if (PREF && fc == 1 && tile + (int)gridDim.x < ntiles) { LB_LOAD_ATTN(tile + gridDim.x) }
+      LB_RUN(hf, 8, 16)
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const size_t row = (size_t)(tok0 + m * 16 + l15) * 256 + fc * 128 + g * 8;
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+          float* xr = a.x32 + row + tp * 32;
+          f32x4 r0, r1;
+          if constexpr (PREF) { r0 = rsd[m][tp][0]; r1 = rsd[m][tp][1]; }
+          else { r0 = *reinterpret_cast<const f32x4*>(xr); r1 = *reinterpret_cast<const f32x4*>(xr + 4); }
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[2 * tp][m][e] + r0[e];
+            v[4 + e] = acc[2 * tp + 1][m][e] + r1[e];
+          }
+          *reinterpret_cast<f32x4*>(xr) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(xr + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          *reinterpret_cast<uint4*>(a.xb + row + tp * 32) = pack8<P>(v);
+        }
       }
     }
-
-    // ---- ffn.3 + residual: x += W2 . h + b2     (stages 10..13)
-#define LB_FFN3_CHUNK(FC)                                                                                  \
-    lb_init_acc(prm + LB_B2 + (FC) * 128, g, acc);                                                         \
-    LB_RUN(10 + (FC) * 2 + 0, hf, 0, 16)                                                                   \
-    LB_RUN(10 + (FC) * 2 + 1, hf, 8, 16)                                                                   \
-    _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                        \
-      const size_t row = (size_t)(tok0 + m * 16 + l15) * 256 + (FC) * 128 + g * 8;                         \
-      _Pragma("unroll") for (int tp = 0; tp < 4; ++tp) {                                                   \
-        float* xr = a.x32 + row + tp * 32;                                                                 \
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(xr), r1 = *reinterpret_cast<const f32x4*>(xr + 4);\
-        float v[8];                                                                                        \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
-          v[e] = acc[2 * tp][m][e] + r0[e];                                                                \
-          v[4 + e] = acc[2 * tp + 1][m][e] + r1[e];                                                        \
-        }                                                                                                  \
-        *reinterpret_cast<f32x4*>(xr) = f32x4{v[0], v[1], v[2], v[3]};                                     \
-        *reinterpret_cast<f32x4*>(xr + 4) = f32x4{v[4], v[5], v[6], v[7]};                                 \
-        *reinterpret_cast<uint4*>(a.xb + row + tp * 32) = pack8<P>(v);                                     \
-      }                                                                                                    \
-    }
-    LB_FFN3_CHUNK(0)
-    LB_FFN3_CHUNK(1)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prefetched first stage of a tile that does not exist
 #undef LB_DMA
+#undef LB_LOAD_ATTN
 #undef LB_RUN
-#undef LB_OUT_CHUNK
-#undef LB_FFN0_CHUNK
-#undef LB_FFN3_CHUNK
 }
 
 // requires M % 128 == 0.  attn / xb: [M][256] 2-byte rows, x32: [M][256] fp32 residual stream (xb and x32 updated in place)
 void launch_lg_block(int prec, const LgBlockArgs& a, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lg_block_kernel<PBF16>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lg_block_kernel<PF16>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lg_block_kernel<PBF16, LB_NM>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lg_block_kernel<PF16, LB_NM>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS);
     attr_done = true;
   }
   const int ntiles = a.M / 128;
   const int grid = ntiles < 256 ? ntiles : 256;
-  if (prec == 1) hipLaunchKernelGGL(lg_block_kernel<PF16>, dim3(grid), dim3(256), LB_LDS, st, a);
-  else hipLaunchKernelGGL(lg_block_kernel<PBF16>, dim3(grid), dim3(256), LB_LDS, st, a);
+  if (prec == 1) hipLaunchKernelGGL((lg_block_kernel<PF16, LB_NM>), dim3(grid), dim3(512 / LB_NM), LB_LDS, st, a);
+  else hipLaunchKernelGGL((lg_block_kernel<PBF16, LB_NM>), dim3(grid), dim3(512 / LB_NM), LB_LDS, st, a);
 }
 
 }  // namespace airfe

@@ -1,0 +1,65 @@
+// LDS read-bandwidth probe for gfx950: every wave issues ITER x 16 independent ds_read_b128 (1 KiB per instruction per wave,
+// lane-linear addresses = conflict-free) and the workgroup reports bytes / clock for its CU.
+//   hipcc --offload-arch=gfx950 -O3 tools/microbench/lds_bw.hip -o /tmp/lds_bw && /tmp/lds_bw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+template <int WIDTH>
+__global__ void probe(unsigned long long* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 65536 / 4; i += blockDim.x) reinterpret_cast<float*>(smem)[i] = (float)i;
+  __syncthreads();
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem + (tid & 63) * WIDTH;
+  float acc = 0.f;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    if (WIDTH == 16) {
+      float4 v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[k]) : "v"(base), "n"(k * 1024));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += v[k].x;
+    } else {
+      float2 v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[k]) : "v"(base), "n"(k * 512));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += v[k].x;
+    }
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (tid == 0) out[blockIdx.x] = t1 - t0;
+  if (acc == 12345.678f) out[1000] = 1;
+}
+
+int main() {
+  unsigned long long* d;
+  hipMalloc(&d, 8192);
+  const int iters = 2000;
+  for (int width : {16, 8})
+    for (int waves : {1, 2, 4, 8, 16}) {
+      hipMemset(d, 0, 8192);
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0); hipEventCreate(&e1);
+      hipEventRecord(e0, 0);
+      if (width == 16) hipLaunchKernelGGL(probe<16>, dim3(256), dim3(waves * 64), 65536, 0, d, iters);
+      else hipLaunchKernelGGL(probe<8>, dim3(256), dim3(waves * 64), 65536, 0, d, iters);
+      hipEventRecord(e1, 0);
+      hipDeviceSynchronize();
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
+      std::vector<unsigned long long> h(256);
+      hipMemcpy(h.data(), d, 256 * 8, hipMemcpyDeviceToHost);
+      double cyc = 0;
+      for (auto c : h) cyc += (double)c;
+      cyc /= 256;
+      const double bytes = (double)iters * 16 * 64 * width * waves;
+      printf("ds_read_b%-3d waves/CU=%2d : %.1f bytes/tick/CU  (%.0f ticks, kernel %.3f ms -> %.0f ticks/us, %.1f GB/s/CU)\n", width * 8, waves,
+             bytes / cyc, cyc, ms, cyc / (ms * 1e3), bytes / (ms * 1e-3) / 1e9);
+    }
+  return 0;
+}
