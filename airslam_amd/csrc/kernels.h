@@ -70,8 +70,8 @@ struct ConvArgs {
 void launch_conv3x3(int prec, const ConvArgs& a, hipStream_t st);
 // persistent weight-stationary variant for CIN == COUT == 64 (launch_conv3x3 dispatches to it)
 void launch_conv64r(int prec, const ConvArgs& a, hipStream_t st);
+void launch_conv128r(int prec, const ConvArgs& a, hipStream_t st);
 // persistent tap-streamed variant for CIN == 128, COUT % 128 == 0 (launch_conv3x3 dispatches to it)
-void launch_conv128ws(int prec, const ConvArgs& a, hipStream_t st);
 
 // conv1a: fp32 image [B][H+2][W+2] (zero border) -> 2-byte [B][H+2][W+2][64], 3x3, Cin=1, ReLU
 void launch_conv1a(int prec, const float* img, const float* w /*[64][9]*/, const float* bias, uint16_t* out,

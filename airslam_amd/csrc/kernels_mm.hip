@@ -183,8 +183,8 @@ void launch_conv3x3(int prec, const ConvArgs& a, hipStream_t st) {
     launch_conv64r(prec, a, st);       // persistent kernel, filters resident in registers (kernels_conv64r.hip)
     return;
   }
-  if (a.CIN == 128 && (a.COUT % 128) == 0 && (a.H % 8) == 0 && (a.W % 16) == 0) {
-    launch_conv128ws(prec, a, st);     // persistent tap-streamed kernel (kernels_conv128.hip)
+  if (a.CIN == 128 && (a.COUT % 128) == 0 && a.relu && (a.H % 8) == 0 && (a.W % 16) == 0) {
+    launch_conv128r(prec, a, st);      // persistent kernel, filters resident in registers (kernels_conv128r.hip)
     return;
   }
   if (prec == 1) conv_launch_p<PF16>(a, st); else conv_launch_p<PBF16>(a, st);
