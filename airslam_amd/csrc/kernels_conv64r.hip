@@ -42,7 +42,7 @@ constexpr bool SCHED = C64R_SCHED;
 #define C64R_RW 4
 #endif
 constexpr int C64R_PATCH = 20 * 20;                // fused conv1a: fp32 image patch per tile (halo 2)
-constexpr int C64R_CONST_OFF = 2 * C64R_TILE_STRIDE + 2 * C64R_PATCH * 4;   // conv1a A fragments (4 KiB) + bias (256 B)
+constexpr int C64R_CONST_OFF = 2 * C64R_TILE_STRIDE + 3 * C64R_PATCH * 4;   // conv1a A fragments (4 KiB) + bias (256 B)
 
 // RW = pixel rows per wave: 8 -> 4 waves (one per SIMD, 512 registers each), 4 -> 8 waves (two per SIMD)
 template <class P, bool POOL, bool FUSE1A, int RW>
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
     // pipeline prologue: patch(1) in flight, conv1a of tile(0) produced, both visible before the loop
     if (tile < ntiles) {
       if (tile + (int)gridDim.x < ntiles) stage_patch(tile + gridDim.x, 1);
+      if (tile + 2 * (int)gridDim.x < ntiles) stage_patch(tile + 2 * gridDim.x, 2);
       int ty0, tx0;
       tile_xy(tile, ty0, tx0);
 #pragma unroll
@@ -234,11 +235,14 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
     __syncthreads();
   }
 
+  int pb3 = 0, pb1 = 1;                                // i % 3 and (i + 1) % 3
   for (int i = 0; tile < ntiles; ++i, tile += gridDim.x) {
     const int next = tile + gridDim.x;
     if constexpr (FUSE1A) {
-      // patch(i+2) -> pbuf[i&1] (consumed by produce one iteration ago); it has the whole MFMA phase to land
-      if (next + (int)gridDim.x < ntiles) stage_patch(next + gridDim.x, i & 1);
+      // patch(i+3) -> pbuf[i % 3] (consumed by the conv1a of one iteration ago).  Three patch buffers: the wait at the end
+      // of this iteration only covers patch(i+2), issued a whole iteration earlier — with two buffers it also covered
+      // the patch issued a few hundred cycles ago, i.e. an HBM round trip per tile (25 % of the kernel, measured).
+      if (tile + 3 * (int)gridDim.x < ntiles) stage_patch(tile + 3 * gridDim.x, pb3);
     } else {
       if (next < ntiles) stage(next, (i + 1) & 1);
     }
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
       [[maybe_unused]] Taps taps{};
       constexpr int PG = 6 / NG;                               // one conv1a group every PG combos
       const bool prod_here = FUSE1A && c % PG == 0;
-      if constexpr (FUSE1A) { if (prod_here) taps = prod_load(c / PG, (i + 1) & 1); }   // conv1a of the NEXT tile, group c (its patch landed an iteration ago)
+      if constexpr (FUSE1A) { if (prod_here) taps = prod_load(c / PG, pb1); }   // conv1a of the NEXT tile, group c (its patch landed an iteration ago)
       const int dx = c >> 1, ks = c & 1;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
@@ -297,8 +301,19 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
 
     // wait for the next tile's LDS-DMA BEFORE this tile's stores are issued (vmcnt counts stores too), then one barrier:
     // "next tile complete" and "the buffer just read is free"
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (FUSE1A) {
+      // only patch(i+2) has to be down: the youngest vector-memory operation of every wave, patch(i+3), may stay in flight
+      // (raw s_barrier: __syncthreads() would add its own vmcnt(0) for the output stores)
+      constexpr int NPP = (C64R_PATCH + NT - 1) / NT;
+      if (tile + 3 * (int)gridDim.x < ntiles) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // tail: nothing younger was issued
+      __builtin_amdgcn_s_barrier();
+      pb3 = pb3 == 2 ? 0 : pb3 + 1;
+      pb1 = pb1 == 2 ? 0 : pb1 + 1;
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     // ---- epilogue (the bias is already in the accumulators): round to the 2-byte storage type FIRST, then ReLU and the
     // 2x2 max-pool on packed pairs (v_pk_max_i16; rounding is monotonic, so pooling after it gives the same bits)
     const int b = tile / per_img, rem = tile - b * per_img;
