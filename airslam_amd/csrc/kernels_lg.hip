@@ -283,6 +283,10 @@ void launch_ln_gelu(int prec, uint16_t* h, const float* gamma, const float* beta
 }
 
 // =============================================================================== matchability
+__device__ __forceinline__ float logsigmoidf(float z) { return fminf(z, 0.f) - log1pf(expf(-fabsf(z))); }
+
+// z[row] = logsigmoid(w . x + b): the assignment only ever uses the matchability through its log-sigmoid, so it is taken
+// once per token here instead of once per (row, column) of the score matrix
 __global__ void rowdot256_kernel(const float* __restrict__ x32, const float* __restrict__ w, float b,
                                  float* __restrict__ z, int M) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -290,7 +294,7 @@ __global__ void rowdot256_kernel(const float* __restrict__ x32, const float* __r
   const float4 x = *(reinterpret_cast<const float4*>(x32 + (size_t)row * 256) + lane);
   const float4 ww = *(reinterpret_cast<const float4*>(w) + lane);
   const float d = wave_sum(x.x * ww.x + x.y * ww.y + x.z * ww.z + x.w * ww.w);
-  if (lane == 0) z[row] = d + b;
+  if (lane == 0) z[row] = logsigmoidf(d + b);
 }
 
 void launch_rowdot256(const float* x32, const float* w, float b, float* z, int M, hipStream_t st) {
@@ -333,7 +337,6 @@ void launch_sim(int prec, const uint16_t* md, float* sim, int B, int Np, hipStre
 }
 
 // =============================================================================== assignment + filter
-__device__ __forceinline__ float logsigmoidf(float z) { return fminf(z, 0.f) - log1pf(expf(-fabsf(z))); }
 
 // wave per row: log-sum-exp over j < n1
 __global__ void lg_rowlse_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np,
@@ -351,18 +354,28 @@ __global__ void lg_rowlse_kernel(const float* __restrict__ sim, const int* __res
   if (lane == 0) rowlse[(size_t)b * Np + i] = mx + logf(s);
 }
 
-// thread per column: log-sum-exp over i < n0 (coalesced across the block's columns)
-__global__ void lg_collse_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np,
-                                 float* __restrict__ collse) {
-  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+// 64 columns x 4 row slices per workgroup: log-sum-exp over i < n0 (coalesced across the block's columns; a single thread
+// per column walked its 400 rows as one dependent chain of L2 loads and took longer than the similarity GEMM)
+__global__ __launch_bounds__(256) void lg_collse_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np,
+                                                        float* __restrict__ collse) {
+  __shared__ float part[4][64];
+  const int b = blockIdx.y, jj = threadIdx.x & 63, q = threadIdx.x >> 6, j = blockIdx.x * 64 + jj;
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
-  if (j >= n1) return;
+  const bool live = j < n1;
   const float* c = sim + (size_t)b * Np * Np + j;
   float mx = -INFINITY;
-  for (int i = 0; i < n0; ++i) mx = fmaxf(mx, c[(size_t)i * Np]);
-  float s = 0.f;
-  for (int i = 0; i < n0; ++i) s += expf(c[(size_t)i * Np] - mx);
-  collse[(size_t)b * Np + j] = mx + logf(s);
+  if (live)
+    for (int i = q; i < n0; i += 4) mx = fmaxf(mx, c[(size_t)i * Np]);
+  part[q][jj] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(part[0][jj], part[1][jj]), fmaxf(part[2][jj], part[3][jj]));
+  __syncthreads();
+  float sm = 0.f;
+  if (live)
+    for (int i = q; i < n0; i += 4) sm += expf(c[(size_t)i * Np] - mx);
+  part[q][jj] = sm;
+  __syncthreads();
+  if (q == 0 && live) collse[(size_t)b * Np + j] = mx + logf((part[0][jj] + part[1][jj]) + (part[2][jj] + part[3][jj]));
 }
 
 __device__ __forceinline__ float lg_score(float sv, float rl, float cl, float c0, float c1) {
@@ -378,13 +391,13 @@ __global__ void lg_rowarg_kernel(const float* __restrict__ sim, const float* __r
   if (i >= n0) return;
   const float* r = sim + ((size_t)b * Np + i) * Np;
   const float rl = rowlse[(size_t)b * Np + i];
-  const float c0 = logsigmoidf(z[(size_t)(2 * b) * Np + i]);
+  const float c0 = z[(size_t)(2 * b) * Np + i];
   const float* z1 = z + (size_t)(2 * b + 1) * Np;
   const float* cl = collse + (size_t)b * Np;
   float best = -INFINITY;
   int bj = 0x7FFFFFFF;
   for (int j = lane; j < n1; j += 64) {
-    const float sc = lg_score(r[j], rl, cl[j], c0, logsigmoidf(z1[j]));
+    const float sc = lg_score(r[j], rl, cl[j], c0, z1[j]);
     if (scores_out) scores_out[((size_t)b * Np + i) * Np + j] = sc;
     if (sc > best) { best = sc; bj = j; }
   }
@@ -400,25 +413,41 @@ __global__ void lg_rowarg_kernel(const float* __restrict__ sim, const float* __r
   }
 }
 
-// thread per column: column arg-max over rows, strict '>' (first maximum wins)
-__global__ void lg_colarg_kernel(const float* __restrict__ sim, const float* __restrict__ z, const int* __restrict__ lens,
-                                 int Np, const float* __restrict__ rowlse, const float* __restrict__ collse,
-                                 int* __restrict__ colarg) {
-  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+// 64 columns x 4 row slices per workgroup: column arg-max over rows, first maximum wins (strict '>' inside a slice, lowest row
+// index between slices); z holds log-sigmoid matchabilities.
+__global__ __launch_bounds__(256) void lg_colarg_kernel(const float* __restrict__ sim, const float* __restrict__ z,
+                                                        const int* __restrict__ lens, int Np, const float* __restrict__ rowlse,
+                                                        const float* __restrict__ collse, int* __restrict__ colarg) {
+  __shared__ float pbest[256];
+  __shared__ int pidx[256];
+  const int b = blockIdx.y, jj = threadIdx.x & 63, q = threadIdx.x >> 6, j = blockIdx.x * 64 + jj;
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
-  if (j >= n1) return;
-  const float* c = sim + (size_t)b * Np * Np + j;
-  const float cl = collse[(size_t)b * Np + j];
-  const float c1 = logsigmoidf(z[(size_t)(2 * b + 1) * Np + j]);
   const float* z0 = z + (size_t)(2 * b) * Np;
-  const float* rl = rowlse + (size_t)b * Np;
+  const bool live = j < n1;
   float best = -INFINITY;
-  int bi = 0;
-  for (int i = 0; i < n0; ++i) {
-    const float sc = lg_score(c[(size_t)i * Np], rl[i], cl, logsigmoidf(z0[i]), c1);
-    if (sc > best) { best = sc; bi = i; }
+  int bi = 0x7FFFFFFF;
+  if (live) {
+    const float* c = sim + (size_t)b * Np * Np + j;
+    const float cl = collse[(size_t)b * Np + j];
+    const float c1 = z[(size_t)(2 * b + 1) * Np + j];
+    const float* rl = rowlse + (size_t)b * Np;
+    for (int i = q; i < n0; i += 4) {
+      const float sc = lg_score(c[(size_t)i * Np], rl[i], cl, z0[i], c1);
+      if (sc > best) { best = sc; bi = i; }
+    }
   }
-  colarg[(size_t)b * Np + j] = bi;
+  pbest[q * 64 + jj] = best;
+  pidx[q * 64 + jj] = bi;
+  __syncthreads();
+  if (q == 0 && live) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float ob = pbest[k * 64 + jj];
+      const int oi = pidx[k * 64 + jj];
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    colarg[(size_t)b * Np + j] = (bi == 0x7FFFFFFF) ? 0 : bi;
+  }
 }
 
 // one 1024-thread workgroup per pair: mutual check + exp(score) > thr, ordered compaction (ascending row)
@@ -459,10 +488,10 @@ void launch_lg_assign(const float* sim, const float* z, const int* lens, int B, 
                       float* collse, float* scores_out, int* rowarg, float* rowval, int* colarg, int32_t* idx,
                       float* score, int* nmatch, hipStream_t st) {
   hipLaunchKernelGGL(lg_rowlse_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, sim, lens, Np, rowlse);
-  hipLaunchKernelGGL(lg_collse_kernel, dim3((Np + 63) / 64, B), dim3(64), 0, st, sim, lens, Np, collse);
+  hipLaunchKernelGGL(lg_collse_kernel, dim3((Np + 63) / 64, B), dim3(256), 0, st, sim, lens, Np, collse);
   hipLaunchKernelGGL(lg_rowarg_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, sim, z, lens, Np, rowlse, collse,
                      scores_out, rowarg, rowval);
-  hipLaunchKernelGGL(lg_colarg_kernel, dim3((Np + 63) / 64, B), dim3(64), 0, st, sim, z, lens, Np, rowlse, collse, colarg);
+  hipLaunchKernelGGL(lg_colarg_kernel, dim3((Np + 63) / 64, B), dim3(256), 0, st, sim, z, lens, Np, rowlse, collse, colarg);
   hipLaunchKernelGGL(lg_filter_kernel, dim3(B), dim3(1024), 0, st, lens, Np, cap, thr, rowarg, rowval, colarg, idx, score,
                      nmatch);
 }
