@@ -159,6 +159,7 @@ struct airfe_ctx {
   int prec = 0;
   int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
   bool has_sp = false, has_lg = false;
+  bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
   bool fuse_lg_block = true;     // LightGlue out-proj + FFN + residual as one kernel; AIRFE_FUSE_LG_BLOCK=0 selects the 4-launch form
   bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
 
@@ -719,7 +720,9 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
     g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b;
     g.M = cells; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
     { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024)); launch_gemm(c->prec, 256, false, g, st); }
-    { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * 2048); launch_l2norm256(c->desc, cells, st); }
+    // F.normalize of the dense map is applied lazily: sample_desc_kernel normalises just the 4 taps each keypoint reads
+    // (same operations, same bits) — a dense pass moved 8 MB/image to serve 400 x 4 cell reads.
+    c->desc_normalised = false;
   }
   const int ccap = R * R;
   {
@@ -740,7 +743,7 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
   }
   {
     ProfScope ps(c, ST_SAMPLE, st, 0, (double)B * c->cfg.max_keypoints * (4096 + 1036));
-    launch_sample_desc(c->desc, B, R / 8, R / 8, d_feat, d_n, cap, (float)w / (float)R, (float)h / (float)R, st);
+    launch_sample_desc(c->desc, B, R / 8, R / 8, d_feat, d_n, cap, (float)w / (float)R, (float)h / (float)R, c->desc_normalised ? 0 : 1, st);
   }
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -1012,7 +1015,14 @@ int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_
   const size_t R = AIRFE_INTERNAL_SIZE;
   if (heat_raw) HIPCHK(c, hipMemcpy(heat_raw, c->heat, (size_t)B * R * R * 4, hipMemcpyDeviceToHost));
   if (heat_nms) HIPCHK(c, hipMemcpy(heat_nms, c->cfg.nms_radius > 0 ? c->heat_nms : c->heat, (size_t)B * R * R * 4, hipMemcpyDeviceToHost));
-  if (desc) HIPCHK(c, hipMemcpy(desc, c->desc, (size_t)B * 64 * 64 * 256 * 4, hipMemcpyDeviceToHost));
+  if (desc) {
+    if (!c->desc_normalised) {      // the inspection hook returns the map the reference would hold: normalised
+      launch_l2norm256(c->desc, c->Bmax * 64 * 64, c->stream);
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      c->desc_normalised = true;
+    }
+    HIPCHK(c, hipMemcpy(desc, c->desc, (size_t)B * 64 * 64 * 256 * 4, hipMemcpyDeviceToHost));
+  }
   return 0;
 }
 
@@ -1105,7 +1115,7 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
   if (want_junctions) {
     const float* hsel = c->cfg.nms_radius > 0 ? c->heat_nms : c->heat;
     launch_junction_scan(c->jmap, hsel, R, c->cfg.remove_borders, c->junc_feat, JUNC_CAP, c->d_njunc, st);
-    launch_sample_desc(c->desc, 1, R / 8, R / 8, c->junc_feat, c->d_njunc, JUNC_CAP, ws, hs, st);
+    launch_sample_desc(c->desc, 1, R / 8, R / 8, c->junc_feat, c->d_njunc, JUNC_CAP, ws, hs, c->desc_normalised ? 0 : 1, st);
     HIPCHK(c, hipMemcpyAsync(&nj, c->d_njunc, 4, hipMemcpyDeviceToHost, st));
   }
   HIPCHK(c, hipStreamSynchronize(st));

@@ -103,7 +103,7 @@ void launch_select_list(const unsigned long long* cand, const int* cand_cnt, int
 // bilinear descriptor sampling + L2 norm (plnet.cpp:369-417), then x,y *= (w_scale,h_scale)
 //   desc fp32 [B][HC][WC][256]
 void launch_sample_desc(const float* desc, int B, int HC, int WC, float* feat, const int* n, int cap,
-                        float w_scale, float h_scale, hipStream_t st);
+                        float w_scale, float h_scale, int normalise, hipStream_t st);
 
 // ---- LightGlue ------------------------------------------------------------------------------
 struct LgPrepArgs {

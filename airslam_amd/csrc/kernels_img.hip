@@ -120,15 +120,20 @@ void launch_softmax_d2s(const float* logits, int ldl, float* heat, int B, int HC
   hipLaunchKernelGGL(softmax_d2s_kernel, dim3((ncell + 127) / 128), dim3(128), 0, st, logits, ldl, heat, ncell, HC, WC);
 }
 
-// F.normalize(dim=channel): one wave per 256-channel row
+// F.normalize(dim=channel) of one 256-channel row spread over a wave, 4 channels per lane
+__device__ __forceinline__ void l2norm_lane4(float4& v) {
+  const float ss = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+}
+
+// dense form, one wave per row (inspection hook only; the product normalises lazily inside sample_desc_kernel)
 __global__ void l2norm256_kernel(float* __restrict__ d, int rows) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   float4* p = reinterpret_cast<float4*>(d + (size_t)row * 256) + lane;
   float4 v = *p;
-  const float ss = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
-  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-  v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+  l2norm_lane4(v);
   *p = v;
 }
 
@@ -203,7 +208,7 @@ __device__ __forceinline__ int clipi(int v, int mx) { return v < 0 ? 0 : min(v, 
 __global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restrict__ desc, int HC, int WC,
                                                           float* __restrict__ feat, const int* __restrict__ n, int cap,
                                                           float sx, float bx, float sy, float by, float w_scale,
-                                                          float h_scale) {
+                                                          float h_scale, int normalise) {
   const int b = blockIdx.y, k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (k >= n[b]) return;
   float* f = feat + ((size_t)b * cap + k) * 259;
@@ -221,10 +226,16 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restric
   const float sw = __fmul_rn(__fsub_rn((float)ix_ne, ix), __fsub_rn(iy, (float)iy_ne));
   const float se = __fmul_rn(__fsub_rn(ix, (float)ix_nw), __fsub_rn(iy, (float)iy_nw));
   const float* d = desc + (size_t)b * HC * WC * 256 + lane * 4;
-  const float4 a0 = *reinterpret_cast<const float4*>(d + ((size_t)iy_nw * WC + ix_nw) * 256);
-  const float4 a1 = *reinterpret_cast<const float4*>(d + ((size_t)iy_ne * WC + ix_ne) * 256);
-  const float4 a2 = *reinterpret_cast<const float4*>(d + ((size_t)iy_sw * WC + ix_sw) * 256);
-  const float4 a3 = *reinterpret_cast<const float4*>(d + ((size_t)iy_se * WC + ix_se) * 256);
+  float4 a0 = *reinterpret_cast<const float4*>(d + ((size_t)iy_nw * WC + ix_nw) * 256);
+  float4 a1 = *reinterpret_cast<const float4*>(d + ((size_t)iy_ne * WC + ix_ne) * 256);
+  float4 a2 = *reinterpret_cast<const float4*>(d + ((size_t)iy_sw * WC + ix_sw) * 256);
+  float4 a3 = *reinterpret_cast<const float4*>(d + ((size_t)iy_se * WC + ix_se) * 256);
+  if (normalise) {       // F.normalize(dim=channel) of the four cells, operation for operation as l2norm256_kernel does it
+    l2norm_lane4(a0);
+    l2norm_lane4(a1);
+    l2norm_lane4(a2);
+    l2norm_lane4(a3);
+  }
   float v[4];
   const float n0[4] = {a0.x, a0.y, a0.z, a0.w}, n1[4] = {a1.x, a1.y, a1.z, a1.w};
   const float n2[4] = {a2.x, a2.y, a2.z, a2.w}, n3[4] = {a3.x, a3.y, a3.z, a3.w};
@@ -249,12 +260,12 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restric
 }
 
 void launch_sample_desc(const float* desc, int B, int HC, int WC, float* feat, const int* n, int cap, float w_scale,
-                        float h_scale, hipStream_t st) {
+                        float h_scale, int normalise, hipStream_t st) {
   const int s = 8;
   const float sx = (float)(2.0 / (WC * s - s / 2 - 0.5)), bx = (float)((1 - s) / (WC * s - s / 2 - 0.5) - 1);
   const float sy = (float)(2.0 / (HC * s - s / 2 - 0.5)), by = (float)((1 - s) / (HC * s - s / 2 - 0.5) - 1);
   hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4, B), dim3(256), 0, st, desc, HC, WC, feat, n, cap, sx, bx,
-                     sy, by, w_scale, h_scale);
+                     sy, by, w_scale, h_scale, normalise);
 }
 
 }  // namespace airfe
