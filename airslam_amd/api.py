@@ -64,7 +64,7 @@ class Context:
         self._h = h
         self.cfg = c
         self.max_keypoints = c.max_keypoints
-        self.np_rows = (c.max_keypoints + 63) // 64 * 64
+        self.np_rows = (c.max_keypoints + 15) // 16 * 16
 
     def close(self):
         if getattr(self, "_h", None):

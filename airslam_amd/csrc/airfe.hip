@@ -508,7 +508,10 @@ int load_lightglue(airfe_ctx* c, const char* path) {
 int alloc_matcher_arena(airfe_ctx* c) {
   if (c->has_arena) return 0;
   const int S = 2 * c->Pmax, Np = c->Np;
-  const size_t M = (size_t)S * Np;
+  // Token rows: S sequences of Np, PLUS slack.  The GEMMs run over M rounded up to 128 rows; the up-to-127 surplus rows are
+  // garbage tokens of "sequences" S, S+1, .. whose head-major outputs land one or more whole sequences past the real data,
+  // and attention's last key tile reads up to 63 rows past a sequence.  All of it stays inside this zero-initialised slack.
+  const size_t M = (size_t)(S + 2 + 128 / Np) * Np + 256;
   c->x32 = dalloc<float>(c, M * 256);
   c->xb = dalloc<uint16_t>(c, M * 256);
   c->qb = dalloc<uint16_t>(c, M * 256);
@@ -783,6 +786,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   if (B < 1 || B > c->Pmax) return fail(c, "pair batch exceeds cfg.max_batch / 2");
   if (cap > c->Np) return fail(c, "feature capacity exceeds the matcher arena (max_keypoints)");
   const int S = 2 * B, Np = c->Np, M = S * Np;
+  const int Mg = (M + 127) / 128 * 128;          // rows the matrix kernels run over (surplus rows: arena slack, see alloc_matcher_arena)
   LgPrepArgs pa;
   pa.f0 = f0; pa.f1 = f1; pa.n0 = n0; pa.n1 = n1; pa.ld = ld; pa.kp_off = kp_off; pa.normalize = normalize;
   // PointMatcher::NormalizeKeypoints (src/point_matcher.cc:39-48): integer width/2, L_inv = 1.0/max(w,h)*scale
@@ -794,27 +798,27 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   { ProfScope ps(c, ST_LG_PREPARE, st, 0, (double)M * (1036 + 1536 + 256)); launch_lg_prepare(c->prec, pa, st); }
   for (const LgLayer& l : c->lg) {
     // ---- self block
-    run_linear(c, l.qk, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS, ACT_NONE, c->qb, 0, st, false, c->kb, nullptr, c->rot_cos, c->rot_sin);
-    run_linear(c, l.v, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
+    run_linear(c, l.qk, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS, ACT_NONE, c->qb, 0, st, false, c->kb, nullptr, c->rot_cos, c->rot_sin);
+    run_linear(c, l.v, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
     if (c->fuse_lg_block) {
-      lg_block(c, l.blk, M, st);
+      lg_block(c, l.blk, Mg, st);
     } else {
-      run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, M, EPI_STORE, ACT_NONE, c->msg, 256, st);
-      lg_ffn(c, l.ffn0, l.ln_g, l.ln_b, l.ffn3, M, st);
+      run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
+      lg_ffn(c, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
     }
     // ---- cross block (one shared projection for q and k; the two sides swap roles)
-    run_linear(c, l.cqk, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS, ACT_NONE, c->qb, 0, st);
-    run_linear(c, l.cv, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
+    run_linear(c, l.cqk, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS, ACT_NONE, c->qb, 0, st);
+    run_linear(c, l.cv, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
     if (c->fuse_lg_block) {
-      lg_block(c, l.cblk, M, st);
+      lg_block(c, l.cblk, Mg, st);
     } else {
-      run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, M, EPI_STORE, ACT_NONE, c->msg, 256, st);
-      lg_ffn(c, l.cffn0, l.cln_g, l.cln_b, l.cffn3, M, st);
+      run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
+      lg_ffn(c, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st);
     }
   }
-  run_linear(c, c->lg_final, c->xb, 256, 256, nullptr, 0, M, EPI_STORE, ACT_NONE, c->mdb, 256, st);
+  run_linear(c, c->lg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
   ProfScope ps(c, ST_LG_ASSIGN, st, 2.0 * B * Np * (double)Np * 256, (double)B * Np * Np * 4 * 6);
   launch_rowdot256(c->x32, c->lg_mw, c->lg_mb, c->zbuf, M, st);
   launch_sim(c->prec, c->mdb, c->simbuf, B, Np, st);
@@ -831,6 +835,7 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   if (B < 1 || B > c->Pmax) return fail(c, "pair batch exceeds cfg.max_batch");
   if (cap > c->Np) return fail(c, "feature capacity exceeds the matcher arena (max_keypoints)");
   const int S = 2 * B, Np = c->Np, M = S * Np;
+  const int Mg = (M + 127) / 128 * 128;
   const float cx = (float)(c->cfg.image_width / 2), cy = (float)(c->cfg.image_height / 2);
   const float linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.7f);   // point_matcher.cc:58
   launch_sg_prepare(c->prec, f0, f1, n0, n1, AIRFE_FEAT_DIM, normalize, cx, cy, linv, c->sg_kenc, B, cap, Np, c->x32, c->xb,
@@ -839,17 +844,17 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   for (const SgLayer& l : c->sg) {
     const int cross = li & 1;      // names = ['self','cross'] * 9
     ++li;
-    run_linear(c, l.qk, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS, ACT_NONE, c->qb, 0, st, false, c->kb);
-    run_linear(c, l.v, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
+    run_linear(c, l.qk, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS, ACT_NONE, c->qb, 0, st, false, c->kb);
+    run_linear(c, l.v, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
     {
       ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048);
       launch_attention(c->prec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, cross, 0.125f, st);
     }
-    run_linear(c, l.merge, c->ob, 256, 256, nullptr, 0, M, EPI_STORE, ACT_NONE, c->msg, 256, st);
-    run_linear(c, l.mlp0, c->xb, 256, 256, c->msg, 256, M, EPI_STORE, ACT_RELU, c->hb, 512, st);
-    run_linear(c, l.mlp3, c->hb, 512, 512, nullptr, 0, M, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
+    run_linear(c, l.merge, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
+    run_linear(c, l.mlp0, c->xb, 256, 256, c->msg, 256, Mg, EPI_STORE, ACT_RELU, c->hb, 512, st);
+    run_linear(c, l.mlp3, c->hb, 512, 512, nullptr, 0, Mg, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
   }
-  run_linear(c, c->sg_final, c->xb, 256, 256, nullptr, 0, M, EPI_STORE, ACT_NONE, c->mdb, 256, st);
+  run_linear(c, c->sg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
   launch_sim(c->prec, c->mdb, c->simbuf, B, Np, st);
   launch_sg_sinkhorn(c->simbuf, c->lens, B, Np, c->Lz, c->sg_alpha, c->cfg.sinkhorn_iters, c->sg_u, c->sg_v, c->sg_Z, st);
   launch_sg_decode(c->sg_Z, c->lens, B, Np, c->Lz, 0.2f, c->sg_idx0, c->sg_max0, c->sg_idx1, c->sg_out0, c->sg_out1, c->sg_ms0,
@@ -909,7 +914,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   c->Bmax = std::max(cfg->max_batch, 1);
   c->chunk = std::min(std::max(cfg->enc_chunk, 1), c->Bmax);
   c->Pmax = c->Bmax;
-  c->Np = (cfg->max_keypoints + 63) / 64 * 64;
+  c->Np = (cfg->max_keypoints + 15) / 16 * 16;      // matcher rows per sequence: whole 16-token MFMA tiles, no further padding
   c->fuse_lg_block = !(getenv("AIRFE_FUSE_LG_BLOCK") && atoi(getenv("AIRFE_FUSE_LG_BLOCK")) == 0);
   c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -319,19 +319,22 @@ __global__ __launch_bounds__(256) void sim_kernel(const uint16_t* __restrict__ m
     const typename P::vec8 af = __builtin_bit_cast(typename P::vec8, ua);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
+      if (j0 + jt * 16 >= Np) continue;                 // Np is a multiple of 16, not of 64: whole column tiles drop out
       const uint4 ub = *reinterpret_cast<const uint4*>(Bm + (size_t)jt * 16 * 256 + ks * 32 + g * 8);
       acc[jt] = P::mfma(af, __builtin_bit_cast(typename P::vec8, ub), acc[jt]);
     }
   }
   float* out = sim + ((size_t)b * Np + i0) * Np + j0;
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
+  for (int jt = 0; jt < 4; ++jt) {
+    if (j0 + jt * 16 >= Np) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[(size_t)(g * 4 + r) * Np + jt * 16 + l15] = acc[jt][r];
+  }
 }
 
 void launch_sim(int prec, const uint16_t* md, float* sim, int B, int Np, hipStream_t st) {
-  dim3 grid((Np / 16 + 3) / 4, Np / 64, B);
+  dim3 grid((Np / 16 + 3) / 4, (Np + 63) / 64, B);
   if (prec == 1) hipLaunchKernelGGL(sim_kernel<PF16>, grid, dim3(256), 0, st, md, sim, Np);
   else hipLaunchKernelGGL(sim_kernel<PBF16>, grid, dim3(256), 0, st, md, sim, Np);
 }
