@@ -30,13 +30,26 @@ __device__ __forceinline__ void lb_glds16(unsigned voff, const void* sbase, unsi
                : "memory");
 }
 
-constexpr int LB_STAGE = 65536;                    // one ring slot: 64 weight fragments of 1 KB = [8 k-steps][8 feature tiles]
-constexpr int LB_NSTAGE = LGB_STREAM_STAGES / 2;   // 2 (out-proj) + 8 (ffn.0) + 4 (ffn.3) stages of 64 KiB
+// one ring slot = KS k-steps x 8 feature tiles of 1 KiB fragments: KS = 8 -> 64 KiB stages (2 + 8 + 4 per block),
+// KS = 4 -> 32 KiB stages (4 + 16 + 8); always two slots
 constexpr int LB_SLOTS = 2;
 #ifndef LB_NM_DEF
 #define LB_NM_DEF 2
 #endif
 constexpr int LB_NM = LB_NM_DEF;                   // 16-token tiles per wave: 1 -> 8 waves (two per SIMD), 2 -> 4 waves
+// geometry: LB_NM 16-token tiles per wave, LB_NW waves, LB_KS k-steps per stage.
+//   (2, 4, 8): 128 tokens per workgroup, one workgroup per CU, 512 registers per wave
+//   (1, 4, 4):  64 tokens per workgroup, TWO workgroups per CU (72 KiB LDS, 256 registers): two waves per SIMD without a shared
+//               barrier, at the price of streaming the weights once per 64 tokens
+#ifndef LB_NW_DEF
+#define LB_NW_DEF 4
+#endif
+#ifndef LB_KS_DEF
+#define LB_KS_DEF (LB_NM_DEF == 2 ? 8 : 4)
+#endif
+constexpr int LB_NW = LB_NW_DEF, LB_KS = LB_KS_DEF;
+constexpr int LB_STAGE = LB_KS * 8192;
+constexpr int LB_NSTAGE = LGB_STREAM_STAGES * 4 / LB_KS;
 constexpr int LB_PARAM_OFF = LB_SLOTS * LB_STAGE;
 constexpr int LB_LDS = LB_PARAM_OFF + LGB_PARAM_FLOATS * 4;
 // parameter block (floats): bo[256] | b1[512] | gamma[512] | beta[512] | b2[256]
@@ -63,12 +76,12 @@ __device__ __forceinline__ void lb_ds_read(V& dst, unsigned addr, int off) {
 // 128 MFMAs of one stage: 8 k-steps x 8 feature tiles x 2 token tiles; B fragments b[OFF + ks][m] (OFF is a compile-time
 // constant: every register array here must be indexed by constants only, or hipcc demotes it to scratch).  The 8 weight
 // fragments of k-step ks+1 are requested before the 16 MFMAs of k-step ks issue and awaited after them.
-template <class P, int OFF, int N, int NM>
+template <class P, int OFF, int N, int NM, int KS>
 __device__ __forceinline__ void lb_stage_mfma(unsigned sb, const typename P::vec8 (&b)[N][NM], f32x4 (&acc)[8][NM]) {
   if constexpr (NM == 1) {
     // two waves per SIMD: the sibling wave's MFMAs cover this wave's LDS latency; one fragment buffer (32 registers)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       typename P::vec8 wf[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) lb_ds_read(wf[t], sb, (ks * 8 + t) * 1024);
@@ -85,8 +98,8 @@ __device__ __forceinline__ void lb_stage_mfma(unsigned sb, const typename P::vec
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      if (ks + 1 < 8) {
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) lb_ds_read(wf[(ks + 1) & 1][t], sb, ((ks + 1) * 8 + t) * 1024);
         __builtin_amdgcn_sched_barrier(0);   // or the MFMAs below are hoisted above the reads and the two buffers collapse into one
@@ -95,7 +108,7 @@ __device__ __forceinline__ void lb_stage_mfma(unsigned sb, const typename P::vec
       for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int m = 0; m < NM; ++m) acc[t][m] = P::mfma(wf[ks & 1][t], b[OFF + ks][m], acc[t][m]);
-      if (ks + 1 < 8) {
+      if (ks + 1 < KS) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -133,10 +146,11 @@ __device__ __forceinline__ void lb_pack_chunk(const f32x4 (&acc)[8][NM], typenam
 // version barely changed its run time).  So each GEMM is a ROLLED loop over 128-feature chunks whose body always uses the
 // same registers; the packed results enter msgf / hf through a 4-entry shift (register moves, ~300 per tile) instead of
 // through chunk-dependent register indices.
-// NM = 16-token tiles per wave; a workgroup is always 128 tokens = 8 / NM waves
-template <class P, int NM>
-__global__ __launch_bounds__(512 / NM, 1) void lg_block_kernel(LgBlockArgs a) {
-  constexpr int NT = 512 / NM;                      // threads
+// NM = 16-token tiles per wave, NW waves, KS k-steps per weight stage
+template <class P, int NM, int NW, int KS>
+__global__ __launch_bounds__(NW * 64, (NM == 1 && NW == 4) ? 2 : 1) void lg_block_kernel(LgBlockArgs a) {
+  constexpr int NT = NW * 64;                       // threads
+  constexpr int TW = NW * NM * 16;                  // tokens per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -165,10 +179,16 @@ __global__ __launch_bounds__(512 / NM, 1) void lg_block_kernel(LgBlockArgs a) {
     __builtin_amdgcn_s_barrier();                                                                          \
     const unsigned cur_ = sbase + ((sg & 1) ^ 1) * LB_STAGE;                                               \
     LB_DMA()                                                                                               \
-    lb_stage_mfma<P, OFF, N, NM>(cur_, ARR, acc);                                                              \
+    lb_stage_mfma<P, OFF, N, NM, KS>(cur_, ARR, acc);                                                      \
+  }
+  /* 8 k-steps of B fragments starting at OFF: one 64 KiB stage or two 32 KiB stages */
+#define LB_RUN8(ARR, OFF, N)                                                                               \
+  {                                                                                                        \
+    LB_RUN(ARR, OFF, N)                                                                                    \
+    if constexpr (KS == 4) LB_RUN(ARR, (OFF) + 4, N)                                                        \
   }
 
-  const int ntiles = a.M >> 7;
+  const int ntiles = a.M / TW;
   int tile = blockIdx.x;
   if (tile < ntiles) LB_DMA()
 
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(512 / NM, 1) void lg_block_kernel(LgBlockArgs a) {
   typename P::vec8 obf[8][NM];
 #define LB_LOAD_ATTN(TILE)                                                                                 \
   _Pragma("unroll") for (int m = 0; m < NM; ++m) {                                                         \
-    const size_t row_ = (size_t)((TILE) * 128 + wave * (16 * NM) + m * 16 + l15) * 256 + g * 8;            \
+    const size_t row_ = (size_t)((TILE) * TW + wave * (16 * NM) + m * 16 + l15) * 256 + g * 8;             \
     _Pragma("unroll") for (int ks = 0; ks < 8; ++ks)                                                       \
       obf[ks][m] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(a.attn + row_ + ks * 32)); \
   }
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(512 / NM, 1) void lg_block_kernel(LgBlockArgs a) {
   if (PREF && tile < ntiles) { LB_LOAD_ATTN(tile) }
 
   for (; tile < ntiles; tile += gridDim.x) {
-    const int tok0 = tile * 128 + wave * (16 * NM);
+    const int tok0 = tile * TW + wave * (16 * NM);
     typename P::vec8 xf[8][NM], msgf[8][NM], hf[16][NM];
     if (!PREF) { LB_LOAD_ATTN(tile) }
 #pragma unroll
@@ -203,7 +223,7 @@ __global__ __launch_bounds__(512 / NM, 1) void lg_block_kernel(LgBlockArgs a) {
 #pragma unroll 1
     for (int fc = 0; fc < 2; ++fc) {
       lb_init_acc<NM>(prm + LB_BO + fc * 128, g, acc);
-      LB_RUN(obf, 0, 8)
+      LB_RUN8(obf, 0, 8)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -217,8 +237,8 @@ __global__ __launch_bounds__(512 / NM, 1) void lg_block_kernel(LgBlockArgs a) {
 #pragma unroll 1
     for (int fc = 0; fc < 4; ++fc) {
       lb_init_acc<NM>(prm + LB_B1 + fc * 128, g, acc);
-      LB_RUN(xf, 0, 8)
-      LB_RUN(msgf, 0, 8)
+      LB_RUN8(xf, 0, 8)
+      LB_RUN8(msgf, 0, 8)
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -291,9 +311,9 @@ __global__ __launch_bounds__(512 / NM, 1) void lg_block_kernel(LgBlockArgs a) {
           }
         }
       }
-      LB_RUN(hf, 0, 16)
+      LB_RUN8(hf, 0, 16)
       if (PREF && fc == 1 && tile + (int)gridDim.x < ntiles) { LB_LOAD_ATTN(tile + gridDim.x) }
-      LB_RUN(hf, 8, 16)
+      LB_RUN8(hf, 8, 16)
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         const size_t row = (size_t)(tok0 + m * 16 + l15) * 256 + fc * 128 + g * 8;
@@ -320,20 +340,22 @@ __global__ __launch_bounds__(512 / NM, 1) void lg_block_kernel(LgBlockArgs a) {
 #undef LB_DMA
 #undef LB_LOAD_ATTN
 #undef LB_RUN
+#undef LB_RUN8
 }
 
-// requires M % 128 == 0.  attn / xb: [M][256] 2-byte rows, x32: [M][256] fp32 residual stream (xb and x32 updated in place)
+// requires M % (LB_NW * LB_NM * 16) == 0 (128 in the default geometry).  attn / xb: [M][256] 2-byte rows, x32: [M][256] fp32 residual stream (xb and x32 updated in place)
 void launch_lg_block(int prec, const LgBlockArgs& a, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lg_block_kernel<PBF16, LB_NM>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lg_block_kernel<PF16, LB_NM>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lg_block_kernel<PBF16, LB_NM, LB_NW, LB_KS>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lg_block_kernel<PF16, LB_NM, LB_NW, LB_KS>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS);
     attr_done = true;
   }
-  const int ntiles = a.M / 128;
-  const int grid = ntiles < 256 ? ntiles : 256;
-  if (prec == 1) hipLaunchKernelGGL((lg_block_kernel<PF16, LB_NM>), dim3(grid), dim3(512 / LB_NM), LB_LDS, st, a);
-  else hipLaunchKernelGGL((lg_block_kernel<PBF16, LB_NM>), dim3(grid), dim3(512 / LB_NM), LB_LDS, st, a);
+  constexpr int TW = LB_NW * LB_NM * 16, WGS = (LB_NM == 1 && LB_NW == 4) ? 512 : 256;
+  const int ntiles = a.M / TW;
+  const int grid = ntiles < WGS ? ntiles : WGS;
+  if (prec == 1) hipLaunchKernelGGL((lg_block_kernel<PF16, LB_NM, LB_NW, LB_KS>), dim3(grid), dim3(LB_NW * 64), LB_LDS, st, a);
+  else hipLaunchKernelGGL((lg_block_kernel<PBF16, LB_NM, LB_NW, LB_KS>), dim3(grid), dim3(LB_NW * 64), LB_LDS, st, a);
 }
 
 }  // namespace airfe
