@@ -172,6 +172,7 @@ struct airfe_ctx {
   uint16_t *a1a = nullptr, *a1b = nullptr, *a2a = nullptr, *a2b = nullptr, *a3a = nullptr, *a3b = nullptr, *a4a = nullptr,
            *a4b = nullptr, *aPa = nullptr, *aDa = nullptr;
   float *logits = nullptr, *heat = nullptr, *heat_nms = nullptr, *nms_tmp = nullptr, *desc = nullptr;
+  unsigned char* nms_mask = nullptr;   // max_mask + supp_mask planes of the per-pool NMS launches
   int *xtab = nullptr, *ytab = nullptr;
   float* lut = nullptr;
   unsigned long long* cand = nullptr;   // [Bmax][512*512] detect_point candidate keys
@@ -391,6 +392,7 @@ int load_superpoint(airfe_ctx* c, const char* path) {
   c->desc = dalloc<float>(c, cells * 256);
   c->heat = dalloc<float>(c, (size_t)B * R * R);
   c->heat_nms = dalloc<float>(c, (size_t)B * R * R);
+  c->nms_mask = dalloc<unsigned char>(c, (size_t)2 * B * R * R);
   const bool multipass_nms = c->cfg.nms_radius > 0 && c->cfg.nms_radius != 4;
   c->nms_tmp = dalloc<float>(c, multipass_nms ? (size_t)4 * B * R * R : 1);
   c->cand = dalloc<unsigned long long>(c, (size_t)B * R * R, false);
@@ -731,7 +733,7 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
   {
     ProfScope ps(c, ST_NMS, st, 0, (double)B * R * R * 8);
     if (c->cfg.nms_radius == 4) {
-      launch_nms4_candidates(c->heat, c->heat_nms, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand,
+      launch_nms4_candidates(c->heat, c->heat_nms, c->nms_mask, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand,
                              c->cand_cnt, ccap, st);
     } else if (c->cfg.nms_radius > 0) {
       launch_simple_nms(c->heat, c->heat_nms, c->nms_tmp, B, R, R, c->cfg.nms_radius, st);

@@ -89,9 +89,10 @@ void launch_softmax_d2s(const float* logits, int ldl, float* heat, int B, int HC
 void launch_l2norm256(float* d, int rows, hipStream_t st);
 // SuperPoint simple_nms(radius) on fp32 [B][H][W]; tmp: 3 maps of the same size
 void launch_simple_nms(const float* heat, float* out, float* tmp, int B, int H, int W, int radius, hipStream_t st);
-// fused simple_nms(4) in LDS: out = NMS'd map, and the detect_point candidates (score >= thr inside the border box)
+// simple_nms(4): out = NMS'd map, and the detect_point candidates (score >= thr inside the border box)
 // are appended to cand [B][cand_cap] (49-bit keys) / cand_cnt [B]
-void launch_nms4_candidates(const float* heat, float* out, int B, int H, int W, float thr, int border,
+// one launch per max-pool over 64x32 tiles with a 4-pixel halo; mask = 2 bytes per pixel of scratch
+void launch_nms4_candidates(const float* heat, float* out, unsigned char* mask, int B, int H, int W, float thr, int border,
                             unsigned long long* cand, int* cand_cnt, int cand_cap, hipStream_t st);
 // candidates from a finished map (NMS off, or radius != 4 through the multi-pass launch_simple_nms)
 void launch_candidates(const float* heat, int B, int H, int W, float thr, int border, unsigned long long* cand,

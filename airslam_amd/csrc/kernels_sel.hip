@@ -17,13 +17,7 @@ __device__ __forceinline__ bool in_border_box(int x, int y, int W, int H, int bo
   return !(x < border || x > W - border || y < border || y > H - border);      // upper bound INCLUSIVE (plnet.cpp:332)
 }
 
-// =============================================================================== fused simple_nms, radius 4
-constexpr int NT = 48;             // output tile
-constexpr int NH = 20;             // halo = 5 dependent 9x9 max-pools x radius 4
-constexpr int NR = NT + 2 * NH;    // 88: region held in LDS
-constexpr int NP = NR + 1;         // row pitch (odd => column walks are bank-conflict free)
-constexpr int NSTRIP = NR / 8;     // 11 strips of 8
-
+// =============================================================================== simple_nms, radius 4
 __device__ __forceinline__ void max9_of16(const float* x, float* o) {
   float a[15], b[13], c[9];
 #pragma unroll
@@ -36,111 +30,122 @@ __device__ __forceinline__ void max9_of16(const float* x, float* o) {
   for (int i = 0; i < 8; ++i) o[i] = fmaxf(c[i], x[i + 8]);       // max over x[i .. i+8]
 }
 
-// Both passes produce only the band [4, NR-4) along the pooled axis (10 strips of 8): every window then lies inside the
-// region, so there are no bounds tests (PMCs: the first version spent ~25k VALU instructions per workgroup, mostly on
-// them).  A 9-wide pool of a region-88 map is only meaningful there anyway; stale values outside the band can only reach
-// the don't-care margin of later pools (the 20-pixel halo is exactly 5 pools x radius 4).
-template <class F>
-__device__ __forceinline__ void nms_hpass(F in, float* T) {
-  for (int s = threadIdx.x; s < NR * (NSTRIP - 1); s += 256) {
-    const int k = s / NR, r = s - k * NR, c0 = 4 + k * 8;
-    float x[16], o[8];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = in(r, c0 - 4 + i);
-    max9_of16(x, o);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) T[r * NP + c0 + i] = o[i];
-  }
-}
+// Public SuperPoint simple_nms(scores, 4) = 5 dependent 9x9 max-pools, one LAUNCH per pool over 64x32 tiles with a 4-pixel
+// halo (1.27x the work, 23 KB of LDS, 6 workgroups per CU); between launches only two byte planes (max_mask M, supp_mask D)
+// travel through L2/HBM.  (Round 1a fused all five pools in one kernel: 20-pixel halo = a 48x48 tile computes 88x88, 78 KB
+// of LDS, two workgroups per CU parked on barriers 60 % of the time — 0.69 ms per 64 images against 0.33 ms now.)
+// Each pool is separable: 9-wide row maxima into T (8 outputs per thread from 16 inputs), then column maxima.
+//   MODE 0: M  = S == pool(S)                                   (scores -> max_mask)
+//   MODE 1: D  = pool(M) > 0                                    (max_mask -> supp_mask)
+//   MODE 2: M |= !D && ss == pool(ss),  ss = D ? 0 : S          (supp_scores -> new max_mask)
+//   MODE 3: MODE 2, then out = M ? S : 0 and the detect_point candidate list
+constexpr int PT_W = 64, PT_H = 32, PR_W = PT_W + 8, PR_H = PT_H + 8, PP = PR_W + 1;
 
-template <class G>
-__device__ __forceinline__ void nms_vpass(const float* T, G out) {
-  for (int s = threadIdx.x; s < (NR - 8) * (NSTRIP - 1); s += 256) {
-    const int k = s / (NR - 8), c = 4 + s - k * (NR - 8), r0 = 4 + k * 8;
-    float x[16], o[8];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = T[(r0 - 4 + i) * NP + c];
-    max9_of16(x, o);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) out(r0 + i, c, o[i]);
-  }
-}
-
-// public SuperPoint simple_nms(scores, 4) on fp32 [B][H][W], + candidate emission for detect_point
-__global__ __launch_bounds__(256) void nms4_fused_kernel(const float* __restrict__ heat, float* __restrict__ out, int H, int W,
-                                                         int tiles_x, float thr, int border, u64* __restrict__ cand,
-                                                         int* __restrict__ cand_cnt, int cand_cap) {
-  extern __shared__ __attribute__((aligned(16))) char nms_smem[];
-  float* S = reinterpret_cast<float*>(nms_smem);
-  float* T = S + NR * NP;
-  unsigned char* M = reinterpret_cast<unsigned char*>(T + NR * NP);
-  unsigned char* P = M + NR * NP;
+template <int MODE>
+__global__ __launch_bounds__(256) void nms_pool_kernel(const float* __restrict__ heat, unsigned char* __restrict__ Mg,
+                                                       unsigned char* __restrict__ Dg, float* __restrict__ out, int H, int W,
+                                                       int tiles_x, float thr, int border, u64* __restrict__ cand,
+                                                       int* __restrict__ cand_cnt, int cand_cap) {
+  __shared__ __attribute__((aligned(16))) float AT[2 * PR_H * PP];     // input region | row maxima; later the candidate keys
+  __shared__ int lcnt[2];
+  float* A = AT;
+  float* T = AT + PR_H * PP;
   const int b = blockIdx.y, tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int gy0 = ty * NT - NH, gx0 = tx * NT - NH;
-  const float* hm = heat + (size_t)b * H * W;
-  for (int i = threadIdx.x; i < NR * NR; i += 256) {
-    const int r = i / NR, c = i - r * NR, gy = gy0 + r, gx = gx0 + c;
-    S[r * NP + c] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? hm[(size_t)gy * W + gx] : -INFINITY;
+  const int gy0 = ty * PT_H - 4, gx0 = tx * PT_W - 4;
+  const size_t img = (size_t)b * H * W;
+  const float* S = heat + img;
+  unsigned char* M = Mg + img;
+  unsigned char* D = Dg + img;
+  for (int i = threadIdx.x; i < PR_H * PR_W; i += 256) {
+    const int r = i / PR_W, c = i - r * PR_W, gy = gy0 + r, gx = gx0 + c;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const size_t gi = (size_t)gy * W + gx;
+    float v;
+    if (MODE == 0) v = in ? S[gi] : -INFINITY;
+    else if (MODE == 1) v = (in && M[gi]) ? 1.f : 0.f;
+    else v = in ? (D[gi] ? 0.f : S[gi]) : -INFINITY;
+    A[r * PP + c] = v;
+  }
+  if (MODE == 3 && threadIdx.x == 0) lcnt[0] = 0;
+  __syncthreads();
+  for (int s = threadIdx.x; s < PR_H * (PT_W / 8); s += 256) {          // rows x 8 column strips
+    const int k = s / PR_H, r = s - k * PR_H, c0 = 4 + k * 8;
+    float x[16], o[8];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = A[r * PP + c0 - 4 + i];
+    max9_of16(x, o);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) T[r * PP + c0 + i] = o[i];
   }
   __syncthreads();
-  auto inimg = [&](int r, int c) { const int gy = gy0 + r, gx = gx0 + c; return gy >= 0 && gy < H && gx >= 0 && gx < W; };
-  // max_mask = scores == max_pool(scores)
-  nms_hpass([&](int r, int c) { return S[r * NP + c]; }, T);
-  __syncthreads();
-  nms_vpass(T, [&](int r, int c, float m) { M[r * NP + c] = inimg(r, c) && (S[r * NP + c] == m); });
-  __syncthreads();
-  for (int it = 0; it < 2; ++it) {
-    // supp_mask = max_pool(max_mask) > 0
-    nms_hpass([&](int r, int c) { return M[r * NP + c] ? 1.f : 0.f; }, T);
-    __syncthreads();
-    nms_vpass(T, [&](int r, int c, float m) { P[r * NP + c] = m > 0.f; });
-    __syncthreads();
-    // supp_scores = where(supp_mask, 0, scores); new_max_mask = supp_scores == max_pool(supp_scores)
-    nms_hpass([&](int r, int c) { return P[r * NP + c] ? 0.f : S[r * NP + c]; }, T);
-    __syncthreads();
-    nms_vpass(T, [&](int r, int c, float m) {
-      const bool p = P[r * NP + c];
-      const float ss = p ? 0.f : S[r * NP + c];
-      if (inimg(r, c) && !p && ss == m) M[r * NP + c] = 1;     // max_mask | (new_max_mask & ~supp_mask)
-    });
-    __syncthreads();
-  }
-  // candidates are collected in LDS (T is free now) and appended with ONE global atomic per workgroup: a per-thread
-  // atomic on the image's counter serialises the whole grid on one L2 word (measured 5x slower than the NMS itself)
-  u64* lkeys = reinterpret_cast<u64*>(T);
-  int* lcnt = reinterpret_cast<int*>(P);
-  if (threadIdx.x == 0) { lcnt[0] = 0; }
-  __syncthreads();
-  for (int i = threadIdx.x; i < NT * NT; i += 256) {
-    const int r = i / NT + NH, c = i % NT + NH, gy = gy0 + r, gx = gx0 + c;
-    if (gy < H && gx < W) {
-      const float v = M[r * NP + c] ? S[r * NP + c] : 0.f;
-      const int idx = gy * W + gx;
-      out[(size_t)b * H * W + idx] = v;
-      if (!(v < thr) && in_border_box(gx, gy, W, H, border)) lkeys[atomicAdd(&lcnt[0], 1)] = make_key(v, idx);
+  float keep_v[8];                                                       // MODE 3: surviving scores of this thread's 8 pixels
+  {
+    const int s = threadIdx.x;                                           // 64 columns x 4 row strips = 256 tasks
+    const int k = s >> 6, c = 4 + (s & 63), r0 = 4 + k * 8;
+    float x[16], o[8];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = T[(r0 - 4 + i) * PP + c];
+    max9_of16(x, o);
+    const int gx = gx0 + c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int gy = gy0 + r0 + i;
+      keep_v[i] = 0.f;
+      if (gy < H && gx < W) {
+        const size_t gi = (size_t)gy * W + gx;
+        const float a = A[(r0 + i) * PP + c];
+        if (MODE == 0) M[gi] = a == o[i];
+        else if (MODE == 1) D[gi] = o[i] > 0.f;
+        else {
+          const bool d = D[gi];
+          const bool m = M[gi] || (!d && a == o[i]);
+          if (MODE == 2) { if (m) M[gi] = 1; }
+          else {
+            const float v = m ? S[gi] : 0.f;
+            out[img + gi] = v;
+            keep_v[i] = v;
+          }
+        }
+      }
     }
   }
-  __syncthreads();
-  const int n = lcnt[0];
-  if (threadIdx.x == 0 && n > 0) lcnt[1] = atomicAdd(&cand_cnt[b], n);
-  __syncthreads();
-  const int base = lcnt[1];
-  for (int i = threadIdx.x; i < n; i += 256)
-    if (base + i < cand_cap) cand[(size_t)b * cand_cap + base + i] = lkeys[i];
+  if (MODE == 3) {
+    // candidates are collected in LDS (both planes are free after the barrier: 2920 keys >= the 2048 pixels of a tile) and
+    // appended with ONE global atomic per workgroup
+    __syncthreads();
+    u64* lkeys = reinterpret_cast<u64*>(AT);
+    const int k = threadIdx.x >> 6, c = 4 + (threadIdx.x & 63), r0 = 4 + k * 8, gx = gx0 + c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int gy = gy0 + r0 + i;
+      if (gy < H && gx < W && !(keep_v[i] < thr) && in_border_box(gx, gy, W, H, border))
+        lkeys[atomicAdd(&lcnt[0], 1)] = make_key(keep_v[i], gy * W + gx);
+    }
+    __syncthreads();
+    const int n = lcnt[0];
+    if (threadIdx.x == 0 && n > 0) lcnt[1] = atomicAdd(&cand_cnt[b], n);
+    __syncthreads();
+    const int base = lcnt[1];
+    for (int i = threadIdx.x; i < n; i += 256)
+      if (base + i < cand_cap) cand[(size_t)b * cand_cap + base + i] = lkeys[i];
+  }
 }
 
-void launch_nms4_candidates(const float* heat, float* out, int B, int H, int W, float thr, int border, u64* cand,
-                            int* cand_cnt, int cand_cap, hipStream_t st) {
-  const int tiles_x = (W + NT - 1) / NT, tiles_y = (H + NT - 1) / NT;
-  constexpr int LDS = NR * NP * (2 * (int)sizeof(float) + 2);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms4_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
-  }
+// mask: 2 bytes per pixel of scratch ([B][H][W] max_mask, then [B][H][W] supp_mask)
+void launch_nms4_candidates(const float* heat, float* out, unsigned char* mask, int B, int H, int W, float thr, int border,
+                            u64* cand, int* cand_cnt, int cand_cap, hipStream_t st) {
+  const int tiles_x = (W + PT_W - 1) / PT_W, tiles_y = (H + PT_H - 1) / PT_H;
+  const dim3 grid(tiles_x * tiles_y, B);
+  unsigned char* M = mask;
+  unsigned char* D = mask + (size_t)B * H * W;
   (void)hipMemsetAsync(cand_cnt, 0, (size_t)B * sizeof(int), st);
-  hipLaunchKernelGGL(nms4_fused_kernel, dim3(tiles_x * tiles_y, B), dim3(256), LDS, st, heat, out, H, W, tiles_x, thr, border,
-                     cand, cand_cnt, cand_cap);
+#define NMS_POOL(MODE) hipLaunchKernelGGL(nms_pool_kernel<MODE>, grid, dim3(256), 0, st, heat, M, D, out, H, W, tiles_x, thr, border, cand, cand_cnt, cand_cap)
+  NMS_POOL(0);
+  NMS_POOL(1);
+  NMS_POOL(2);
+  NMS_POOL(1);
+  NMS_POOL(3);
+#undef NMS_POOL
 }
 
 // plain threshold + border compaction of a heat map into the candidate list (NMS off, or after the multi-pass NMS)
