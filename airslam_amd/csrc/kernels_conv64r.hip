@@ -90,8 +90,9 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
 #pragma unroll
   for (int j = 0; j < NPC; ++j) {
     const int q = min(j * NT + tid, C64R_PIECES - 1);
-    const int p = q >> 3, c = (q & 7) ^ swz128(p);
+    const int p = q >> 3;
     const int pr = p / 18, pc = p - pr * 18;
+    const int c = (q & 7) ^ ((pc >> 1) & 7);           // chunk swizzle by pixel COLUMN (see cbase below)
     goff[j] = pr * (int)in_row + pc * 128 + c * 16;
   }
   const bool last_piece = (NPC - 1) * NT + tid < C64R_PIECES;
@@ -104,15 +105,13 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
     for (int j = 0; j < NPC - 1; ++j) c64r_glds16(xin + goff[j], dst + j * (NT * 16));
     if (last_piece) c64r_glds16(xin + goff[NPC - 1], dst + (NPC - 1) * (NT * 16));
   };
-  // pixel fragments: tile rows ph*RW + {0..RW+1}, column shifts {0,1,2}; channel half ks = 1 is XOR 64
-  int boff[RW + 2][3];
+  // pixel fragments: tile rows ph*RW + {0..RW+1}, column shifts {0,1,2}; channel half ks = 1 is XOR 64.  The 16-byte chunks
+  // are swizzled with the pixel COLUMN only (a fragment's 16 consecutive pixels of a row still hit 16 different bank groups;
+  // rows are 2304 bytes = whole bank rows apart), so the address is (per-lane column term) + (compile-time row offset):
+  // 3 address registers instead of 3 * (RW + 2).
+  int cbase[3];
 #pragma unroll
-  for (int r = 0; r < RW + 2; ++r)
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int p = (ph * RW + r) * 18 + l15 + dx;
-      boff[r][dx] = p * 128 + ((g ^ swz128(p)) << 4);
-    }
+  for (int dx = 0; dx < 3; ++dx) cbase[dx] = (ph * RW * 18 + l15 + dx) * 128 + ((g ^ (((l15 + dx) >> 1) & 7)) << 4);
 
   // ---- fused conv1a (Cin = 1, FUSE1A): the 18x18x64 input tile of conv1b is COMPUTED here from a 20x20 patch of the
   // fp32 image instead of being read back from HBM: conv1a's 32 MiB/image of output never exists (conv1b alone is at
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
       const int p = k * 16 + l15, pc = min(p, 323);              // p >= 324 (group 20, lanes 4..15): lands in the pad rows
       const int py = pc / 18, px = pc - py * 18;
       prd[j] = ((py + min(g, 2)) * 20 + px) * 4;
-      pwr[j] = p * 128 + ((g ^ swz128(p)) << 4);
+      pwr[j] = p * 128 + ((g ^ (((p % 18) >> 1) & 7)) << 4);
       pyx[j] = (py << 8) | px;
     }
   }
@@ -257,15 +256,16 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
       }
     // 6 combos (column shift dx, channel half ks); the 10 pixel-row fragments of combo c+1 are requested before the
     // 48 MFMAs (3 filter rows x 8 pixel rows x 2 cout tiles) of combo c
-    constexpr int NB = RW == 8 ? 2 : 1;   // fragment double-buffering only when a wave is alone on its SIMD
+    constexpr int NB = RW == 8 ? 2 : 1;   // fragment double-buffering only when a wave is alone on its SIMD (measured: with two waves per SIMD it is slower)
     typename P::vec8 bf[NB][RW + 2];
     const int xoff = (i & 1) * C64R_TILE_STRIDE;
     [[maybe_unused]] int nty = 0, ntx = 0;
     if constexpr (FUSE1A) tile_xy(next < ntiles ? next : tile, nty, ntx);   // past the end: harmless rewrite of a dead buffer
     auto load_combo = [&](int c, int set) {
       const int dx = c >> 1, ks = c & 1;
+      const char* fb = smem + ((cbase[dx] ^ (ks << 6)) + xoff);
 #pragma unroll
-      for (int r = 0; r < RW + 2; ++r) bf[set][r] = lds_frag<P>(smem, (boff[r][dx] ^ (ks << 6)) + xoff);
+      for (int r = 0; r < RW + 2; ++r) bf[set][r] = lds_frag<P>(fb, r * (18 * 128));
     };
     load_combo(0, 0);
     if (SCHED) __builtin_amdgcn_sched_group_barrier(0x100, RW + 2, 0);
