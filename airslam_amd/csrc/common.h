@@ -139,6 +139,26 @@ __device__ __forceinline__ void line_exchange(uint4& a, uint4& b, int l15) {
 }
 // after line_exchange: for lanes >= 8 `a` holds the partner pixel's B chunk and `b` its own B; see call sites
 
+// Reductions across the four 16-lane rows of a wave (lane ^ 16, lane ^ 32) on the VALU: gfx950's v_permlane16_swap /
+// v_permlane32_swap exchange rows (halves) between two registers, so swap(x, x) leaves the two partners of every lane side
+// by side — one swap + one op instead of a ds_bpermute round trip through the LDS crossbar (~100 cycles of latency each).
+__device__ __forceinline__ float rows_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float m = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+  const unsigned um = __builtin_bit_cast(unsigned, m);
+  const auto b = __builtin_amdgcn_permlane16_swap(um, um, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float m = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+  const unsigned um = __builtin_bit_cast(unsigned, m);
+  const auto b = __builtin_amdgcn_permlane16_swap(um, um, false, false);
+  return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -160,8 +160,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
       for (int kti = 0; kti < 4; ++kti)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kti][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = rows_max(mx);                               // the query's 64 keys of this tile sit in lanes l15, l15+16, +32, +48
       mx *= scale_log2e;                               // scale > 0: max commutes with the scaling
       const float m_new = fmaxf(m_i[qt], mx);
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
@@ -210,9 +209,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l = l_i[qt];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    const float l = rows_sum(l_i[qt]);
     const float inv = (l > 0.f) ? 1.0f / l : 0.f;
     const int q = q0 + qt * 16 + l15;
     if (q < Np) {

@@ -258,9 +258,7 @@ __global__ __launch_bounds__(NW * 64, (NM == 1 && NW == 4) ? 2 : 1) void lg_bloc
     float mean[NM], rstd[NM];
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
-      float a1 = s1[m], a2 = s2[m];
-      a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
-      a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+      const float a1 = rows_sum(s1[m]), a2 = rows_sum(s2[m]);
       mean[m] = a1 * (1.0f / 512.0f);
       const float var = fmaxf(a2 * (1.0f / 512.0f) - mean[m] * mean[m], 0.f);
       rstd[m] = 1.0f / sqrtf(var + 1e-5f);
