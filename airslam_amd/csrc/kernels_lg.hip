@@ -64,7 +64,7 @@ void launch_lg_prepare(int prec, const LgPrepArgs& a, hipStream_t st) {
 //   S^T = K . Q^T   (A = K rows from LDS, B = Q fragments in VGPRs)  -> lane (q = lane&15, g) holds 4 keys/tile
 //   O^T = V^T . P^T (A = V^T rows from LDS, B = P packed straight from the S^T accumulators, no shuffles)
 template <class P>
-__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K,
+__global__ __launch_bounds__(256, 3) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K,
                                                         const uint16_t* __restrict__ Vt, uint16_t* __restrict__ O,
                                                         const int* __restrict__ lens, int H, int Np, int cross,
                                                         float scale_log2e) {
