@@ -32,7 +32,10 @@ __device__ __forceinline__ void lb_glds16(unsigned voff, const void* sbase, unsi
 
 // one ring slot = KS k-steps x 8 feature tiles of 1 KiB fragments: KS = 8 -> 64 KiB stages (2 + 8 + 4 per block),
 // KS = 4 -> 32 KiB stages (4 + 16 + 8); always two slots
-constexpr int LB_SLOTS = 2;
+#ifndef LB_SLOTS_DEF
+#define LB_SLOTS_DEF 4
+#endif
+constexpr int LB_SLOTS = LB_SLOTS_DEF;             // ring depth: the stage fetched at a boundary is consumed LB_SLOTS - 1 boundaries later
 #ifndef LB_NM_DEF
 #define LB_NM_DEF 2
 #endif
@@ -45,7 +48,7 @@ constexpr int LB_NM = LB_NM_DEF;                   // 16-token tiles per wave: 1
 #define LB_NW_DEF 4
 #endif
 #ifndef LB_KS_DEF
-#define LB_KS_DEF (LB_NM_DEF == 2 ? 8 : 4)
+#define LB_KS_DEF 4
 #endif
 constexpr int LB_NW = LB_NW_DEF, LB_KS = LB_KS_DEF;
 constexpr int LB_STAGE = LB_KS * 8192;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(NW * 64, (NM == 1 && NW == 4) ? 2 : 1) void lg_bloc
   int sg = 0;                                       // stage (0..13) the NEXT LB_DMA fetches; ring slot = sg & 1
 #define LB_DMA()                                                                                           \
   {                                                                                                        \
-    const unsigned dst_ = lds_base + (sg & 1) * LB_STAGE + wave * 1024;                                    \
+    const unsigned dst_ = lds_base + (sg % LB_SLOTS) * LB_STAGE + wave * 1024;                             \
     _Pragma("unroll") for (int j_ = 0; j_ < LB_STAGE / (NT * 16); ++j_) lb_glds16(wvoff, wq + j_ * (NT * 16), dst_ + j_ * (NT * 16)); \
     wq += LB_STAGE;                                                                                        \
     if (++sg == LB_NSTAGE) { sg = 0; wq = reinterpret_cast<const char*>(a.wstream); }                      \
@@ -175,9 +178,9 @@ __global__ __launch_bounds__(NW * 64, (NM == 1 && NW == 4) ? 2 : 1) void lg_bloc
   // (LB_NSTAGE is even: the stage being computed sits in the slot the next LB_DMA does NOT target.)
 #define LB_RUN(ARR, OFF, N)                                                                                \
   {                                                                                                        \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LB_SLOTS - 2) * (LB_STAGE / (NT * 16))) : "memory");         \
     __builtin_amdgcn_s_barrier();                                                                          \
-    const unsigned cur_ = sbase + ((sg & 1) ^ 1) * LB_STAGE;                                               \
+    const unsigned cur_ = sbase + ((sg + 1) % LB_SLOTS) * LB_STAGE;                                        \
     LB_DMA()                                                                                               \
     lb_stage_mfma<P, OFF, N, NM, KS>(cur_, ARR, acc);                                                      \
   }
@@ -185,12 +188,17 @@ __global__ __launch_bounds__(NW * 64, (NM == 1 && NW == 4) ? 2 : 1) void lg_bloc
 #define LB_RUN8(ARR, OFF, N)                                                                               \
   {                                                                                                        \
     LB_RUN(ARR, OFF, N)                                                                                    \
-    if constexpr (KS == 4) LB_RUN(ARR, (OFF) + 4, N)                                                        \
+    if constexpr (KS <= 4) LB_RUN(ARR, (OFF) + KS, N)                                                       \
+    if constexpr (KS == 2) { LB_RUN(ARR, (OFF) + 4, N) LB_RUN(ARR, (OFF) + 6, N) }                          \
   }
 
   const int ntiles = a.M / TW;
   int tile = blockIdx.x;
-  if (tile < ntiles) LB_DMA()
+  static_assert(LB_NSTAGE % LB_SLOTS == 0, "ring slots must stay aligned across tiles");
+  if (tile < ntiles) {
+#pragma unroll
+    for (int d = 0; d < LB_SLOTS - 1; ++d) LB_DMA()
+  }
 
   // ---- token fragments straight from HBM: lane (token l15, g) holds k = ks*32 + g*8 .. +7.  With one wave per SIMD nothing
   // hides a load but the wave's own MFMAs, so every HBM read is issued a stage or more before its first use: the attention
