@@ -38,6 +38,9 @@ constexpr int C64R_PIECES = 18 * 18 * 8;           // 2592 sixteen-byte pieces
 #define C64R_SCHED 1
 #endif
 constexpr bool SCHED = C64R_SCHED;
+#ifndef C64R_PIN
+#define C64R_PIN 1
+#endif
 #ifndef C64R_RW
 #define C64R_RW 4
 #endif
@@ -256,7 +259,11 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
       }
     // 6 combos (column shift dx, channel half ks); the 10 pixel-row fragments of combo c+1 are requested before the
     // 48 MFMAs (3 filter rows x 8 pixel rows x 2 cout tiles) of combo c
-    constexpr int NB = RW == 8 ? 2 : 1;   // fragment double-buffering only when a wave is alone on its SIMD (measured: with two waves per SIMD it is slower)
+    // PIN (RW = 4): fragment reads are inline-asm ds_read_b128 pinned one combo ahead of their MFMAs with sched_barrier(0)
+    // and an explicit lgkmcnt wait — left to itself hipcc sinks every read down to its first use, and sched_group_barrier
+    // pipelines made this variant slower.
+    constexpr bool PIN = RW == 4 && C64R_PIN;
+    constexpr int NB = (RW == 8 || PIN) ? 2 : 1;
     typename P::vec8 bf[NB][RW + 2];
     const int xoff = (i & 1) * C64R_TILE_STRIDE;
     [[maybe_unused]] int nty = 0, ntx = 0;
@@ -267,12 +274,29 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
 #pragma unroll
       for (int r = 0; r < RW + 2; ++r) bf[set][r] = lds_frag<P>(fb, r * (18 * 128));
     };
-    load_combo(0, 0);
-    if (SCHED) __builtin_amdgcn_sched_group_barrier(0x100, RW + 2, 0);
+    auto pin_combo = [&](int c, int set) {
+      const int dx = c >> 1, ks = c & 1;
+      const unsigned fa = lds_base + ((cbase[dx] ^ (ks << 6)) + xoff);
+#pragma unroll
+      for (int r = 0; r < RW + 2; ++r)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(bf[set][r]) : "v"(fa), "n"(r * (18 * 128)) : "memory");
+    };
+    if constexpr (PIN) {
+      pin_combo(0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      load_combo(0, 0);
+      if (SCHED) __builtin_amdgcn_sched_group_barrier(0x100, RW + 2, 0);
+    }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      if (NB == 2 && c + 1 < 6) load_combo(c + 1, (c + 1) & 1);
-      if (NB == 1 && c > 0) load_combo(c, 0);
+      if constexpr (PIN) {
+        if (c + 1 < 6) { pin_combo(c + 1, (c + 1) & 1); __builtin_amdgcn_sched_barrier(0); }
+      } else {
+        if (NB == 2 && c + 1 < 6) load_combo(c + 1, (c + 1) & 1);
+        if (NB == 1 && c > 0) load_combo(c, 0);
+      }
       [[maybe_unused]] Taps taps{};
       constexpr int PG = 6 / NG;                               // one conv1a group every PG combos
       const bool prod_here = FUSE1A && c % PG == 0;
@@ -287,7 +311,10 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
       if constexpr (FUSE1A) { if (prod_here) prod_finish(c / PG, taps, nty, ntx, (i + 1) & 1); }
       // issue-order pipeline for the scheduler: one fragment read of the NEXT combo per 4 MFMAs of this one (hipcc otherwise
       // sinks the reads down to their first use and every 6 MFMAs wait out a full LDS latency)
-      if (SCHED && NB == 2) {
+      if constexpr (PIN) {
+        if (c + 1 < 6) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+      }
+      if (SCHED && NB == 2 && !PIN) {
 #pragma unroll
         for (int sidx = 0; sidx < RW + 2; ++sidx) {
           __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
