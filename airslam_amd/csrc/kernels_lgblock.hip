@@ -9,8 +9,8 @@
 //     B-fragment layout of the next (lane (token, g) holds 8 consecutive features per tile pair), so msg and h never leave
 //     registers — no LDS round trip, no cross-wave LayerNorm reduction (a token's 512 features live in 4 lanes of one wave);
 //   * HBM traffic per token: read attn 512 B + x 512 B + fp32 residual 1 KB, write x 512 B + residual 1 KB (2.5x less);
-//   * the 896 KB of weights per block stream through a 2 x 64 KiB LDS ring by LDS-DMA in the exact order the MFMAs consume
-//     them ("fragment-linear" packing done once on the host), one s_barrier per stage = 128 MFMAs per wave.
+//   * the 896 KB of weights per block stream through a 4 x 32 KiB LDS ring by LDS-DMA (prefetch distance 3 stages) in the
+//     exact order the MFMAs consume them ("fragment-linear" packing done once on the host), one s_barrier per stage.
 // The kernel is LDS-read bound by construction (each 1 KB weight fragment feeds only 2 MFMAs per wave): ~50 % of the
 // MFMA peak is the ceiling of this decomposition; it is still 3x the separate GEMMs.
 #include "common.h"

@@ -1,6 +1,6 @@
-// airfe — keypoint selection: fused simple_nms (radius 4) in LDS that also emits the compact candidate list, and the
-// exact top-K (detect_point, src/plnet.cpp:309-355) on that list.  HBM traffic: heat read once, NMS map written once,
-// a few thousand 8-byte candidates per image instead of ten 1 MB map passes + six full-map select passes.
+// airfe — keypoint selection: simple_nms (radius 4) as five LDS-tiled max-pool launches, the last of which also emits the
+// compact candidate list, and the exact top-K (detect_point, src/plnet.cpp:309-355) on that list: a few thousand 8-byte
+// candidates per image instead of six full-map select passes.
 #include "common.h"
 #include "kernels.h"
 
