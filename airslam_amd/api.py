@@ -169,6 +169,21 @@ class Context:
                   "airfe_match_superglue")
         return i0, i1, m0, m1
 
+    def assign_points_to_lines(self, lines: np.ndarray, feat: np.ndarray):
+        """AssignPointsToLines (src/line_processor.cc:68-120).  lines [L,4] float64, feat [N,259] float32 rows ->
+        list of L dicts {point index: distance} (ascending index, like the reference's std::map<int,double>)."""
+        lines = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 4)
+        feat = np.ascontiguousarray(feat, dtype=np.float32).reshape(-1, 259)
+        L, N = lines.shape[0], feat.shape[0]
+        cap = max(L * N, 1)
+        row_ptr = np.zeros((L + 1,), np.int32)
+        idx = np.empty((cap,), np.int32); dist = np.empty((cap,), np.float64)
+        total = C.c_int(0)
+        self._chk(self._l.airfe_assign_points_to_lines(self._h, lines.ctypes.data, L, feat.ctypes.data, N, row_ptr.ctypes.data,
+                                                       idx.ctypes.data, dist.ctypes.data, cap, C.byref(total)),
+                  "airfe_assign_points_to_lines")
+        return [dict(zip(idx[row_ptr[i]:row_ptr[i + 1]].tolist(), dist[row_ptr[i]:row_ptr[i + 1]].tolist())) for i in range(L)]
+
     def superglue_scores(self, f0: np.ndarray, f1: np.ndarray) -> np.ndarray:
         f0 = np.ascontiguousarray(f0, dtype=np.float32)
         f1 = np.ascontiguousarray(f1, dtype=np.float32)

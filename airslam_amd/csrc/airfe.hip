@@ -159,6 +159,8 @@ struct airfe_ctx {
   int prec = 0;
   int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
   bool has_sp = false, has_lg = false;
+  char* pl_stage = nullptr;      // staging of airfe_assign_points_to_lines
+  size_t pl_bytes = 0;
   bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
   bool fuse_lg_block = true;     // LightGlue out-proj + FFN + residual as one kernel; AIRFE_FUSE_LG_BLOCK=0 selects the 4-launch form
   bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
@@ -1086,6 +1088,45 @@ int airfe_stereo_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d
   if (detect_dev(c, d_left, B, h, w, stride, img_stride, d_featL, cap, d_nL, st)) return 1;
   if (detect_dev(c, d_right, B, h, w, stride, img_stride, d_featR, cap, d_nR, st)) return 1;
   return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
+}
+
+int airfe_assign_points_to_lines(airfe_ctx* c, const double* lines, int L, const float* feat, int N, int32_t* row_ptr,
+                                 int32_t* pt_idx, double* pt_dist, int cap, int* total) {
+  if (!c) return 1;
+  if (L < 0 || N < 0 || cap < 0 || !row_ptr || !total) return fail(c, "assign_points_to_lines: bad argument");
+  *total = 0;
+  if (L == 0) { row_ptr[0] = 0; return 0; }
+  if (!lines || (N > 0 && !feat)) return fail(c, "assign_points_to_lines: null input");
+  // staging grows on demand (lines and points per frame are a few hundred)
+  const size_t need = (size_t)L * 32 + (size_t)std::max(N, 1) * 259 * 4 + (size_t)(2 * L + 2) * 4 + (size_t)std::max(cap, 1) * 12 + 64;
+  if (need > c->pl_bytes) {
+    void* p = nullptr;
+    HIPCHK(c, hipMalloc(&p, need));
+    c->allocs.push_back(p);
+    c->pl_stage = reinterpret_cast<char*>(p);
+    c->pl_bytes = need;
+  }
+  char* q = c->pl_stage;
+  double* d_lines = reinterpret_cast<double*>(q); q += (size_t)L * 32;
+  double* d_dist = reinterpret_cast<double*>(q); q += (size_t)std::max(cap, 1) * 8;
+  float* d_feat = reinterpret_cast<float*>(q); q += (size_t)std::max(N, 1) * 259 * 4;
+  int* d_counts = reinterpret_cast<int*>(q); q += (size_t)L * 4;
+  int* d_rowptr = reinterpret_cast<int*>(q); q += (size_t)(L + 1) * 4;
+  int* d_idx = reinterpret_cast<int*>(q);
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(d_lines, lines, (size_t)L * 32, hipMemcpyHostToDevice, st));
+  if (N > 0) HIPCHK(c, hipMemcpyAsync(d_feat, feat, (size_t)N * 259 * 4, hipMemcpyHostToDevice, st));
+  launch_assign_points_to_lines(d_lines, L, d_feat, N, d_counts, d_rowptr, d_idx, d_dist, cap, st);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(row_ptr, d_rowptr, (size_t)(L + 1) * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  *total = row_ptr[L];
+  if (*total > cap) return fail(c, "assign_points_to_lines: output capacity too small");
+  if (*total > 0) {
+    HIPCHK(c, hipMemcpy(pt_idx, d_idx, (size_t)*total * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(pt_dist, d_dist, (size_t)*total * 8, hipMemcpyDeviceToHost));
+  }
+  return 0;
 }
 
 int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, const airfe_plnet_stage0* s0, float* feat,

@@ -160,4 +160,9 @@ void launch_sg_sinkhorn(const float* sim, const int* lens, int B, int Np, int Lz
 void launch_sg_decode(const float* Z, const int* lens, int B, int Np, int Lz, float thr, int* idx0, float* max0, int* idx1,
                       int32_t* out0, int32_t* out1, float* ms0, float* ms1, hipStream_t st);
 
+// ---- point <-> line association (AssignPointsToLines, src/line_processor.cc:68-120) as CSR: row_ptr [L+1], entries
+//      (point index ascending, distance) per line; counts [L] is scratch
+void launch_assign_points_to_lines(const double* lines, int L, const float* feat, int N, int* counts, int* row_ptr, int* pt_idx,
+                                   double* pt_dist, int cap, hipStream_t st);
+
 }  // namespace airfe

@@ -498,4 +498,95 @@ void launch_sg_decode(const float* Z, const int* lens, int B, int Np, int Lz, fl
   hipLaunchKernelGGL(sg_decode_kernel, dim3(B), dim3(1024), 0, st, lens, Lz, idx0, max0, idx1, thr, out0, out1, ms0, ms1);
 }
 
+// =============================================================================== point <-> line association
+// AssignPointsToLines (src/line_processor.cc:68-120): for every line the points lying on it
+// (bounding box +-3 px, point-line distance <= 3 px, endpoint / projection test), as a CSR list in ascending point
+// index (= the iteration order of the reference's std::map<int, double>).  All arithmetic in double, every product
+// rounded separately (no FMA contraction) like the oracle's numpy restatement; the distance is narrowed to float exactly
+// where the reference narrows it.
+// a product that must be rounded on its own: the empty asm makes it opaque to hipcc, which otherwise fuses a * b + c into
+// an FMA even through __dmul_rn / __dadd_rn and `#pragma clang fp contract(off)` (seen: 1-ulp differences on points that
+// lie exactly on a line, where the numerator cancels catastrophically)
+__device__ __forceinline__ double rounded_mul(double a, double b) {
+  double m = a * b;
+  asm volatile("" : "+v"(m));
+  return m;
+}
+__device__ __forceinline__ bool point_on_line(double lx1, double ly1, double lx2, double ly2, double px, double py, float& dist) {
+  const double A = ly2 - ly1, B = lx1 - lx2;
+  const double C = rounded_mul(lx2, ly1) - rounded_mul(lx1, ly2);
+  const double D = __dsqrt_rn(rounded_mul(A, A) + rounded_mul(B, B));
+  double min_lx = lx1, max_lx = lx2, min_ly = ly1, max_ly = ly2;
+  if (lx1 > lx2) { min_lx = lx2; max_lx = lx1; }
+  if (ly1 > ly2) { min_ly = ly2; max_ly = ly1; }
+  if (px < min_lx - 3 || px > max_lx + 3 || py < min_ly - 3 || py > max_ly + 3) return false;
+  const float pl = (float)__ddiv_rn(fabs((rounded_mul(A, px) + rounded_mul(B, py)) + C), D);
+  if (pl > 3) return false;
+  const double dx1 = lx1 - px, dy1 = ly1 - py, dx2 = lx2 - px, dy2 = ly2 - py;
+  const double side1 = rounded_mul(dx1, dx1) + rounded_mul(dy1, dy1);
+  const double side2 = rounded_mul(dx2, dx2) + rounded_mul(dy2, dy2);
+  const double line_side = rounded_mul(D, D);
+  dist = pl;
+  return side1 <= 9 || side2 <= 9 || ((side1 < line_side + side2) && (side2 < line_side + side1));
+}
+
+// one wave per line; pass 0 counts, pass 1 writes at row_ptr[line] (ballot + prefix keeps ascending point order)
+template <bool WRITE>
+__global__ __launch_bounds__(256) void pl_assign_kernel(const double* __restrict__ lines, int L, const float* __restrict__ feat,
+                                                        int N, int* __restrict__ counts, const int* __restrict__ row_ptr,
+                                                        int* __restrict__ pt_idx, double* __restrict__ pt_dist, int cap) {
+  const int line = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (line >= L) return;
+  const double lx1 = lines[line * 4 + 0], ly1 = lines[line * 4 + 1], lx2 = lines[line * 4 + 2], ly2 = lines[line * 4 + 3];
+  int cnt = 0;
+  const int base = WRITE ? row_ptr[line] : 0;
+  for (int j0 = 0; j0 < N; j0 += 64) {
+    const int j = j0 + lane;
+    float d = 0.f;
+    bool hit = false;
+    if (j < N) hit = point_on_line(lx1, ly1, lx2, ly2, (double)feat[(size_t)j * 259 + 1], (double)feat[(size_t)j * 259 + 2], d);
+    const unsigned long long m = __ballot(hit);
+    if (WRITE && hit) {
+      const int pos = base + cnt + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < cap) { pt_idx[pos] = j; pt_dist[pos] = (double)d; }
+    }
+    cnt += __popcll(m);
+  }
+  if (!WRITE && lane == 0) counts[line] = cnt;
+}
+
+// exclusive scan of counts[L] -> row_ptr[L+1] (L is a few hundred: one workgroup, serial per 256-chunk carry)
+__global__ __launch_bounds__(256) void pl_scan_kernel(const int* __restrict__ counts, int L, int* __restrict__ row_ptr) {
+  __shared__ int buf[256];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < L; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    const int v = i < L ? counts[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < L) row_ptr[i] = carry + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry += buf[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) row_ptr[L] = carry;
+}
+
+void launch_assign_points_to_lines(const double* lines, int L, const float* feat, int N, int* counts, int* row_ptr, int* pt_idx,
+                                   double* pt_dist, int cap, hipStream_t st) {
+  if (L <= 0) return;
+  const dim3 grid((L + 3) / 4);
+  hipLaunchKernelGGL(pl_assign_kernel<false>, grid, dim3(256), 0, st, lines, L, feat, N, counts, row_ptr, pt_idx, pt_dist, cap);
+  hipLaunchKernelGGL(pl_scan_kernel, dim3(1), dim3(256), 0, st, counts, L, row_ptr);
+  hipLaunchKernelGGL(pl_assign_kernel<true>, grid, dim3(256), 0, st, lines, L, feat, N, counts, row_ptr, pt_idx, pt_dist, cap);
+}
+
 }  // namespace airfe

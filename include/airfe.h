@@ -95,6 +95,15 @@ int airfe_match_lightglue(airfe_ctx* ctx, const float* f0, int n0, const float* 
 int airfe_match_superglue(airfe_ctx* ctx, const float* f0, int n0, const float* f1, int n1, int32_t* idx0, int32_t* idx1,
                           double* ms0, double* ms1);
 
+/* ---- next row after the path ---------------------------------------------------- */
+/* ≙ AssignPointsToLines (src/line_processor.cc:68-120), called on the path's own outputs (frame.cc:125,177,184).
+ *   lines [L][4] doubles (x1,y1,x2,y2) = the std::vector<Eigen::Vector4d> storage; feat [N][259] rows (x,y = floats 1,2).
+ *   Result in CSR form: row_ptr [L+1]; for line i the entries row_ptr[i] .. row_ptr[i+1]-1 of pt_idx / pt_dist are the
+ *   (point index, distance) pairs of relation[i] in ascending point index = the iteration order of its std::map<int,double>.
+ *   cap = capacity of pt_idx / pt_dist; *total = row_ptr[L]; fails (and writes nothing past cap) if total > cap. */
+int airfe_assign_points_to_lines(airfe_ctx* ctx, const double* lines, int L, const float* feat, int N, int32_t* row_ptr,
+                                 int32_t* pt_idx, double* pt_dist, int cap, int* total);
+
 /* ---- device-resident batch pipeline (NEW: no reference counterpart) ------------------------------------ */
 /* d_gray: [B] images, image b at d_gray + b*img_stride, rows `stride` bytes apart.  d_feat [B][cap][259], d_n [B]. */
 int airfe_detect_points_batch_dev(airfe_ctx* ctx, const uint8_t* d_gray, int B, int h, int w, int stride,

@@ -315,3 +315,42 @@ def log_optimal_transport(scores: np.ndarray, alpha: float = 2.3457, iters: int 
         u = (log_mu - np.log(np.sum(np.exp(c + v[None, :]), axis=1, dtype=F))).astype(F)
         v = (log_nu - np.log(np.sum(np.exp(c + u[:, None]), axis=0, dtype=F))).astype(F)
     return (c + u[:, None] + v[None, :] - norm).astype(F)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# point <-> line association
+def assign_points_to_lines(lines: np.ndarray, points: np.ndarray):
+    """AssignPointsToLines, src/line_processor.cc:68-120, statement by statement in float64 (the reference casts the
+    float32 keypoints to double, :70) with the point-line distance narrowed to float32 where the reference does (:106).
+    lines [L,4] (x1,y1,x2,y2) float64, points [259,N] or [N,259]-style rows given as [N,259] float32.
+    -> list of L dicts {point index j: distance} in ascending j (std::map<int,double> order)."""
+    lines = np.asarray(lines, dtype=np.float64).reshape(-1, 4)
+    pts = np.asarray(points, dtype=np.float32).reshape(-1, 259)
+    x = pts[:, 1].astype(np.float64)
+    y = pts[:, 2].astype(np.float64)
+    x1, y1, x2, y2 = lines[:, 0], lines[:, 1], lines[:, 2], lines[:, 3]
+    A = y2 - y1                                   # :81
+    B = x1 - x2                                   # :82
+    C = x2 * y1 - x1 * y2                         # :83
+    D = np.sqrt(A * A + B * B)                    # :84
+    relation = []
+    for i in range(lines.shape[0]):
+        on_line = {}
+        lx1, ly1, lx2, ly2 = x1[i], y1[i], x2[i], y2[i]
+        min_lx, max_lx = (lx2, lx1) if lx1 > lx2 else (lx1, lx2)          # :100-103
+        min_ly, max_ly = (ly2, ly1) if ly1 > ly2 else (ly1, ly2)
+        for j in range(pts.shape[0]):
+            px, py = x[j], y[j]
+            if px < min_lx - 3 or px > max_lx + 3 or py < min_ly - 3 or py > max_ly + 3:   # :104
+                continue
+            with np.errstate(divide="ignore", invalid="ignore"):
+                pl = np.float32(np.abs(A[i] * px + B[i] * py + C[i]) / D[i])                # :107 (float)
+            if pl > 3:                                                                      # :108 (NaN compares false)
+                continue
+            side1 = (lx1 - px) * (lx1 - px) + (ly1 - py) * (ly1 - py)                       # :110
+            side2 = (lx2 - px) * (lx2 - px) + (ly2 - py) * (ly2 - py)                       # :111
+            line_side = D[i] * D[i]                                                         # :112
+            if side1 <= 9 or side2 <= 9 or (side1 < line_side + side2 and side2 < line_side + side1):   # :113
+                on_line[j] = float(pl)                                                      # :114
+        relation.append(on_line)
+    return relation

@@ -171,3 +171,44 @@ def test_normalize_keypoints_integer_halves():
     linv = np.float32(1.0 / 752 * 0.5)
     np.testing.assert_array_equal(o[:, 1], (f[:, 1] - 376) * linv)
     np.testing.assert_array_equal(o[:, 2], (f[:, 2] - 240) * linv)
+
+
+# ---- AssignPointsToLines (src/line_processor.cc:68-120)
+def _feat_rows(xy):
+    f = np.zeros((len(xy), 259), np.float32)
+    f[:, 1:3] = np.asarray(xy, np.float32)
+    return f
+
+
+def test_assign_points_to_lines_hand_cases():
+    lines = np.array([[10.0, 10.0, 50.0, 10.0],      # horizontal segment
+                      [20.0, 5.0, 20.0, 5.0]])       # degenerate (zero length): D = 0, distance NaN -> only the <= 9 tests decide
+    pts = _feat_rows([(30.0, 12.0),    # 2 px above the segment, projection inside      -> on line 0, dist 2
+                      (30.0, 13.5),    # 3.5 px away                                   -> off
+                      (52.5, 10.0),    # beyond the end by 2.5 px: side2 = 6.25 <= 9   -> on line 0, dist 0
+                      (54.0, 10.0),    # outside the +-3 box                           -> off
+                      (21.0, 6.0),     # 1.41 px from the degenerate line's point      -> on line 1 (side1 = 2 <= 9), dist NaN
+                      (10.0, 7.0)])    # exactly 3 px: pl_distance > 3 is false        -> on line 0, dist 3
+    rel = rp.assign_points_to_lines(lines, pts)
+    assert list(rel[0].keys()) == [0, 2, 5]
+    assert rel[0][0] == 2.0 and rel[0][2] == 0.0 and rel[0][5] == 3.0
+    assert list(rel[1].keys()) == [4] and np.isnan(rel[1][4])
+
+
+def test_assign_points_to_lines_vectorised_cross_check():
+    """The statement-by-statement loops agree with an independent vectorised formulation on random data."""
+    rng = np.random.default_rng(11)
+    lines = rng.uniform(0, 200, size=(40, 4))
+    pts = _feat_rows(rng.uniform(0, 200, size=(300, 2)))
+    rel = rp.assign_points_to_lines(lines, pts)
+    x, y = pts[:, 1].astype(np.float64), pts[:, 2].astype(np.float64)
+    for i, (x1, y1, x2, y2) in enumerate(lines):
+        A, B, C = y2 - y1, x1 - x2, x2 * y1 - x1 * y2
+        D = np.sqrt(A * A + B * B)
+        pl = (np.abs(A * x + B * y + C) / D).astype(np.float32)
+        box = (x >= min(x1, x2) - 3) & (x <= max(x1, x2) + 3) & (y >= min(y1, y2) - 3) & (y <= max(y1, y2) + 3)
+        s1 = (x1 - x) ** 2 + (y1 - y) ** 2
+        s2 = (x2 - x) ** 2 + (y2 - y) ** 2
+        ok = box & ~(pl > 3) & ((s1 <= 9) | (s2 <= 9) | ((s1 < D * D + s2) & (s2 < D * D + s1)))
+        assert list(rel[i].keys()) == np.nonzero(ok)[0].tolist()
+        assert np.array_equal(np.array(list(rel[i].values()), np.float32), pl[ok])
