@@ -162,7 +162,9 @@ struct airfe_ctx {
   char* pl_stage = nullptr;      // staging of airfe_assign_points_to_lines
   size_t pl_bytes = 0;
   bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
-  bool fuse_lg_block = true;     // LightGlue out-proj + FFN + residual as one kernel; AIRFE_FUSE_LG_BLOCK=0 selects the 4-launch form
+  int gemm_small_max = 4096, gemm8_min = 16000;   // GemmArgs::small_max / g8_min (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M)
+  int block_min = 16000;         // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
+  int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
 
   // detector weights
@@ -719,6 +721,7 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
     GemmArgs g;
     g.X1 = c->aPa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cPb.w; g.bias = c->cPb.b;
     g.M = cells; g.N = 65; g.cb_total = c->cPb.cbt; g.epi = EPI_STORE_F32; g.out = c->logits; g.ldo = 72;
+    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min;
     { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 288)); launch_gemm(c->prec, 256, false, g, st); }
     { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * (260 + 256)); launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st); }
   }
@@ -726,6 +729,7 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
     GemmArgs g;
     g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b;
     g.M = cells; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
+    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min;
     { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024)); launch_gemm(c->prec, 256, false, g, st); }
     // F.normalize of the dense map is applied lazily: sample_desc_kernel normalises just the 4 taps each keypoint reads
     // (same operations, same bits) — a dense pass moved 8 MB/image to serve 400 x 4 cell reads.
@@ -764,6 +768,7 @@ void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1
   g.Wp = w.w; g.bias = w.b; g.M = M; g.N = w.N; g.cb_total = w.cbt;
   g.epi = epi; g.act = act; g.out = out; g.out2 = out2; g.ldo = ldo; g.x32 = x32;
   g.rot_cos = rc; g.rot_sin = rs; g.Np = c->Np; g.H = 4;
+  g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min;
   ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * w.K * w.N, (double)M * (w.K + w.N) * 2 + (double)w.K * w.N * 2);
   launch_gemm(c->prec, w.K, trans, g, st);
 }
@@ -800,12 +805,16 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   pa.wr = c->lg_wr; pa.B = B; pa.cap = cap; pa.Np = Np;
   pa.x32 = c->x32; pa.xb = c->xb; pa.rot_cos = c->rot_cos; pa.rot_sin = c->rot_sin; pa.lens = c->lens;
   { ProfScope ps(c, ST_LG_PREPARE, st, 0, (double)M * (1036 + 1536 + 256)); launch_lg_prepare(c->prec, pa, st); }
+  // lg_block's tile time is set by its 1.3 MB weight stream, not by the token count (58 us per round of 256 tiles), so below
+  // ~16000 tokens (20 pairs of 400) the four separate launches are quicker: 1.42 vs 2.12 ms per step at 1 pair, 2.61 vs 3.09 ms
+  // at 8 pairs, 3.60 vs 3.89 ms at 16 pairs; from 20 pairs on the fused kernel wins (4.71 vs 5.31 ms at 24 pairs).
+  const bool fused_block = c->fuse_lg_block == 1 || (c->fuse_lg_block < 0 && Mg >= c->block_min);
   for (const LgLayer& l : c->lg) {
     // ---- self block
     run_linear(c, l.qk, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS, ACT_NONE, c->qb, 0, st, false, c->kb, nullptr, c->rot_cos, c->rot_sin);
     run_linear(c, l.v, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
-    if (c->fuse_lg_block) {
+    if (fused_block) {
       lg_block(c, l.blk, Mg, st);
     } else {
       run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
@@ -815,7 +824,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     run_linear(c, l.cqk, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS, ACT_NONE, c->qb, 0, st);
     run_linear(c, l.cv, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
-    if (c->fuse_lg_block) {
+    if (fused_block) {
       lg_block(c, l.cblk, Mg, st);
     } else {
       run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
@@ -919,7 +928,10 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   c->chunk = std::min(std::max(cfg->enc_chunk, 1), c->Bmax);
   c->Pmax = c->Bmax;
   c->Np = (cfg->max_keypoints + 15) / 16 * 16;      // matcher rows per sequence: whole 16-token MFMA tiles, no further padding
-  c->fuse_lg_block = !(getenv("AIRFE_FUSE_LG_BLOCK") && atoi(getenv("AIRFE_FUSE_LG_BLOCK")) == 0);
+  c->fuse_lg_block = getenv("AIRFE_FUSE_LG_BLOCK") ? (atoi(getenv("AIRFE_FUSE_LG_BLOCK")) != 0) : -1;
+  if (getenv("AIRFE_SMALL_MAX_M")) c->gemm_small_max = atoi(getenv("AIRFE_SMALL_MAX_M"));
+  if (getenv("AIRFE_GEMM8_MIN_M")) c->gemm8_min = atoi(getenv("AIRFE_GEMM8_MIN_M"));
+  if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
   c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -1317,6 +1329,7 @@ int airfe_debug_gemm(airfe_ctx* c, const float* x, int M, int K, const float* w,
     GemmArgs g;
     g.X1 = dx; g.ld1 = K; g.K1 = K; g.Wp = lw.w; g.bias = lw.b; g.M = Mp; g.N = N; g.cb_total = lw.cbt;
     g.epi = EPI_STORE_F32; g.act = relu ? ACT_RELU : ACT_NONE; g.out = dy; g.ldo = Np8;
+    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min;
     launch_gemm(prec, K, false, g, c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, "debug_gemm: kernel failed");
   }

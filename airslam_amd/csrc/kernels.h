@@ -33,6 +33,9 @@ struct GemmArgs {
   const float* rot_cos = nullptr;  // [M][32] (rotary on when non-null)
   const float* rot_sin = nullptr;
   int Np = 0, H = 4;
+  // kernel choice by row count (measured on MI355X, LightGlue at 400 keypoints per image): M <= small_max -> gemm_small_kernel
+  // (no LDS, one round trip), M >= g8_min and M % 256 == 0 -> gemm8_kernel (256x256 tiles want >= 60 row tiles), else gemm_kernel
+  int small_max = 4096, g8_min = 16000;
 };
 
 // out[M][N] = X[M][K] * W^T ; K in {128,256,512}; trans => EPI_HEADS_T (operand roles swapped)

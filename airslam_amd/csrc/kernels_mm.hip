@@ -390,9 +390,85 @@ static void gemm_launch_t(int K, const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kfn, grid, dim3(256), LDS, st, a, K, npairs / gy);
 }
 
+// Small-M GEMM (the matcher on one or two pairs: 800-1600 tokens).  32 rows x 64 features per workgroup, no LDS and no K loop:
+// every lane fetches its MFMA fragments for the WHOLE K extent straight from global memory (the packed weight slabs are
+// stored in fragment order, an activation fragment is 16 contiguous bytes of a row), so a launch costs one L2 round trip plus
+// 2*K/32 MFMAs per wave instead of K/64 load -> LDS -> barrier rounds; at M = 896 the staged kernel above is latency-bound at
+// ~11 us per launch with 14-28 workgroups, this one runs 112-224 workgroups.  Accumulation order over K is the same (ascending
+// 32-wide steps), so results are bit-identical to gemm_kernel's.
+template <class P, bool TRANS, int NK>   // NK = K / 32
+__global__ __launch_bounds__(256, 1) void gemm_small_kernel(GemmArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int tp = wave >> 1;                       // feature tile pair (32 features) of the 64-feature block
+  const int cb = blockIdx.y, m0 = blockIdx.x * 32 + (wave & 1) * 16;
+  constexpr int NS = NK / 2;
+  const char* wbase = reinterpret_cast<const char*>(a.Wp) + (size_t)cb * NS * SLAB_BYTES;
+  typename P::vec8 wf[2][NK], xf[NK];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int rr = (2 * tp + u) * 16 + l15;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks)
+      wf[u][ks] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(
+          wbase + (ks >> 1) * SLAB_BYTES + rr * 128 + ((((ks & 1) * 4 + g) ^ swz128(rr)) << 4)));
+  }
+  const int row = m0 + l15;
+  const uint16_t* x1 = a.X1 + (size_t)row * a.ld1 + g * 8;
+  const uint16_t* x2 = a.X2 ? a.X2 + (size_t)row * a.ld2 + g * 8 - a.K1 : x1;
+  const int K1 = a.X2 ? a.K1 : NK * 32;
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks)
+    xf[ks] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>((ks * 32 < K1 ? x1 : x2) + ks * 32));
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if constexpr (TRANS) acc[u] = P::mfma(xf[ks], wf[u][ks], acc[u]);
+      else acc[u] = P::mfma(wf[u][ks], xf[ks], acc[u]);
+    }
+  if (cb >= a.cb_total) return;
+  if constexpr (!TRANS) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = acc[0][e];
+      v[4 + e] = acc[1][e];
+    }
+    gemm_store_run<P>(a, row, cb * 64 + tp * 32 + g * 8, v);
+  } else {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int co = cb * 64 + slab_row_to_feature((2 * tp + u) * 16 + l15);
+      const float bv = a.bias[co];
+      const int h = co >> 6, d = co & 63;
+      const int row0 = m0 + g * 4;
+      const int sq = row0 / a.Np, n = row0 - sq * a.Np;
+      uint16_t* o = reinterpret_cast<uint16_t*>(a.out) + (((size_t)sq * a.H + h) * 64 + d) * a.Np + n;
+      *reinterpret_cast<uint2*>(o) = pack4<P>(acc[u][0] + bv, acc[u][1] + bv, acc[u][2] + bv, acc[u][3] + bv);
+    }
+  }
+}
+
+template <class P, bool TRANS>
+static void gemm_small_launch_t(int K, const GemmArgs& a, hipStream_t st) {
+  dim3 grid((unsigned)(a.M / 32), (unsigned)a.cb_total);
+  if (K == 128) hipLaunchKernelGGL((gemm_small_kernel<P, TRANS, 4>), grid, dim3(256), 0, st, a);
+  else if (K == 256) hipLaunchKernelGGL((gemm_small_kernel<P, TRANS, 8>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_small_kernel<P, TRANS, 16>), grid, dim3(256), 0, st, a);
+}
+
 void launch_gemm(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st) {
-  if (a.M % 256 == 0 && a.M >= 4096) {       // large-M path: 8-wave, 3-stage LDS-DMA ring (kernels_gemm8.hip)
+  if (a.M % 256 == 0 && a.M >= a.g8_min && a.M > a.small_max) {       // large-M path: 8-wave, 3-stage LDS-DMA ring (kernels_gemm8.hip)
     launch_gemm8(prec, K, trans, a, st);
+    return;
+  }
+  if (a.M <= a.small_max && a.M % 32 == 0 && (K == 128 || K == 256 || K == 512)) {
+    if (prec == 1) {
+      if (trans) gemm_small_launch_t<PF16, true>(K, a, st); else gemm_small_launch_t<PF16, false>(K, a, st);
+    } else {
+      if (trans) gemm_small_launch_t<PBF16, true>(K, a, st); else gemm_small_launch_t<PBF16, false>(K, a, st);
+    }
     return;
   }
   if (prec == 1) {

@@ -35,13 +35,19 @@ def test_conv3x3(cin, cout, pool, B, H, W):
     assert not bad.any()
 
 
+# launch_gemm picks the kernel by row count: M <= 4096 gemm_small_kernel (no LDS), M >= 16000 and M % 256 == 0 gemm8_kernel
+# (kernels_gemm8.hip), otherwise gemm_kernel.  "staged" moves the thresholds so that the same shapes run through the other two.
+GEMM_POLICIES = {"default": {}, "staged": {"AIRFE_SMALL_MAX_M": "0", "AIRFE_GEMM8_MIN_M": "4096"}}
+
+
+@pytest.mark.parametrize("policy", list(GEMM_POLICIES))
 @pytest.mark.parametrize("K,N,M,relu", [(256, 256, 128, False), (256, 65, 200, False), (512, 512, 64, True),
                                         (512, 256, 300, False), (128, 128, 128, False), (256, 768, 1000, False),
-                                        # M >= 4096 and M % 256 == 0 -> the 8-wave LDS-DMA kernel (kernels_gemm8.hip)
                                         (256, 512, 4096, False), (512, 256, 4352, True), (256, 65, 4096, False),
-                                        (128, 320, 8192, False)])
-def test_gemm(K, N, M, relu):
-    ctx, _, _ = context("sp")
+                                        (128, 320, 8192, False), (256, 512, 4224, False), (256, 512, 16384, False),
+                                        (512, 256, 16640, True)])
+def test_gemm(K, N, M, relu, policy):
+    ctx, _, _ = context("sp", env=GEMM_POLICIES[policy])
     rng = np.random.default_rng(K + N + M)
     x = to_2byte(rng.normal(size=(M, K)).astype(np.float32))
     w = to_2byte((rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32))
@@ -53,6 +59,6 @@ def test_gemm(K, N, M, relu):
     err = np.abs(y - ref)
     bad = err > 2e-4 * (1 + np.abs(ref))
     worst = np.unravel_index(np.argmax(err), err.shape)
-    diag(f"gemm_{K}_{N}_{M}", max_err=err.max(), n_bad=int(bad.sum()), worst=list(map(int, worst)), y_at=y[worst],
+    diag(f"gemm_{K}_{N}_{M}_{policy}", max_err=err.max(), n_bad=int(bad.sum()), worst=list(map(int, worst)), y_at=y[worst],
          ref_at=ref[worst], bad_cols=np.nonzero(bad.sum(0))[0][:32], bad_rows=np.nonzero(bad.sum(1))[0][:32])
     assert not bad.any()

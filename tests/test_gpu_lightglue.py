@@ -35,9 +35,15 @@ def _pair(n0, n1, seed):
     return f0, f1, np.ascontiguousarray(n0f[:, 1:]), np.ascontiguousarray(n1f[:, 1:])
 
 
+# A context picks the LightGlue block form by token count (fused lg_block_kernel from 4096 tokens, four launches below);
+# AIRFE_FUSE_LG_BLOCK forces either, so that both forms meet the oracle at every size.
+FORMS = [{"AIRFE_FUSE_LG_BLOCK": "1"}, {"AIRFE_FUSE_LG_BLOCK": "0"}]
+
+
+@pytest.mark.parametrize("env", FORMS, ids=["fused_block", "four_launches"])
 @pytest.mark.parametrize("n0,n1", [(400, 400), (317, 400), (64, 65), (1, 5), (2, 1)])
-def test_lightglue_scores_vs_oracle(n0, n1):
-    ctx, _, lg = context("lg", max_batch=4)
+def test_lightglue_scores_vs_oracle(n0, n1, env):
+    ctx, _, lg = context("lg", env=env, max_batch=4)
     _, _, a, b = _pair(n0, n1, n0 * 3 + n1)
     s = ctx.lightglue_scores(a, b)
     ref = ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
@@ -47,7 +53,7 @@ def test_lightglue_scores_vs_oracle(n0, n1):
     # filter_matches on the DEVICE scores must be reproduced exactly (index work)
     didx, dsc = ref_post.filter_matches(s, 0.1)
     agree = len(set(map(tuple, idx)) & set(map(tuple, ridx))) / max(len(ridx), 1)
-    diag(f"lg_scores_{n0}_{n1}", max_err=err.max(), mean_err=err.mean(), ref_absmax=np.abs(ref).max(), n_dev=len(idx),
+    diag(f"lg_scores_{n0}_{n1}_{'fused' if env['AIRFE_FUSE_LG_BLOCK'] == '1' else 'split'}", max_err=err.max(), mean_err=err.mean(), ref_absmax=np.abs(ref).max(), n_dev=len(idx),
          n_ref=len(ridx), match_agreement=agree, nan=int(np.isnan(s).sum()))
     assert not np.isnan(s).any()
     np.testing.assert_array_equal(idx, didx)
@@ -106,12 +112,14 @@ def test_matching_points_early_out():
     assert pm.MatchingPoints(np.zeros((259, 0), np.float32), np.zeros((259, 7), np.float32)) == (0, [])
 
 
-def test_large_batch_uses_gemm8_and_agrees_with_single_pair_path():
-    """8 pairs -> M = 16 x 448 = 7168 rows: the linears go through the 8-wave LDS-DMA GEMM (kernels_gemm8.hip);
-    a single pair (M = 896) goes through the 4-wave kernel.  Same K-order accumulation => same matches."""
+@pytest.mark.parametrize("env", FORMS, ids=["fused_block", "four_launches"])
+def test_large_batch_uses_gemm8_and_agrees_with_single_pair_path(env):
+    """8 pairs -> M = 16 x 400 = 6400 rows: with the gemm8 threshold lowered to 4096 the linears go through the 8-wave
+    LDS-DMA GEMM (kernels_gemm8.hip); a single pair (M = 896) goes through gemm_small_kernel.  Same K-order accumulation
+    => same matches, with the block form held fixed (it is what changes the rounding points)."""
     import torch
     from airslam_amd import api
-    ctx, _, lg = context("lg", max_batch=8)
+    ctx, _, lg = context("lg", env=dict(env, AIRFE_GEMM8_MIN_M="4096"), max_batch=8)
     B = 8
     pairs = [_pair(400 - 7 * i, 390 - 11 * i, 40 + i) for i in range(B)]
     f0 = torch.zeros((B, 400, 259)); f1 = torch.zeros((B, 400, 259))
@@ -132,3 +140,34 @@ def test_large_batch_uses_gemm8_and_agrees_with_single_pair_path():
         assert k == cnt
         assert [tuple(g) for g in idx[i, :k].cpu().numpy()] == [(m[0], m[1]) for m in matches]
         np.testing.assert_allclose(1.0 - sc[i, :k].cpu().numpy(), [m[2] for m in matches], atol=1e-5)
+
+
+def test_block_form_switch_by_token_count_keeps_the_matches():
+    """Switch point lowered to 4096 tokens: 1 pair (800 tokens) runs the four-launch block through gemm_small_kernel,
+    8 pairs (6400 tokens) the fused kernel + gemm_kernel.  The two block forms round at different points, so scores agree
+    to bf16 noise and the match sets almost entirely."""
+    import torch
+    from airslam_amd import api
+    ctx, _, lg = context("lg", env={"AIRFE_BLOCK_MIN_M": "4096"}, max_batch=8)
+    B = 8
+    pairs = [_pair(400 - 7 * i, 390 - 11 * i, 140 + i) for i in range(B)]
+    f0 = torch.zeros((B, 400, 259)); f1 = torch.zeros((B, 400, 259))
+    n0 = torch.tensor([p[0].shape[0] for p in pairs], dtype=torch.int32)
+    n1 = torch.tensor([p[1].shape[0] for p in pairs], dtype=torch.int32)
+    for i, (a, b, _, _) in enumerate(pairs):
+        f0[i, :a.shape[0]] = torch.from_numpy(a); f1[i, :b.shape[0]] = torch.from_numpy(b)
+    f0, f1, n0, n1 = f0.cuda(), f1.cuda(), n0.cuda(), n1.cuda()
+    idx = torch.zeros((B, 400, 2), dtype=torch.int32, device="cuda")
+    sc = torch.zeros((B, 400), dtype=torch.float32, device="cuda")
+    nm = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    ctx.match_lightglue_batch_dev(f0, n0, f1, n1, idx, sc, nm)
+    ctx.sync()
+    pm = api.PointMatcher(ctx, 752, 480, 0)
+    agree = []
+    for i, (a, b, _, _) in enumerate(pairs):
+        cnt, matches = pm.MatchingPoints(np.asfortranarray(a.T), np.asfortranarray(b.T))
+        batch = {tuple(g) for g in idx[i, :int(nm[i])].cpu().numpy()}
+        single = {(m[0], m[1]) for m in matches}
+        agree.append(len(batch & single) / max(len(batch | single), 1))
+    diag("lg_block_form_switch", min_agreement=min(agree), mean_agreement=float(np.mean(agree)))
+    assert min(agree) >= 0.95
