@@ -171,3 +171,24 @@ def test_block_form_switch_by_token_count_keeps_the_matches():
         agree.append(len(batch & single) / max(len(batch | single), 1))
     diag("lg_block_form_switch", min_agreement=min(agree), mean_agreement=float(np.mean(agree)))
     assert min(agree) >= 0.95
+
+
+@pytest.mark.parametrize("n0,n1", [(1024, 1024), (1024, 777)])
+def test_lightglue_at_the_profile_maximum(n0, n1):
+    """N = 1024 is the engine's optimisation-profile maximum (light_glue.cpp:52); the arena is sized by max_keypoints."""
+    from airslam_amd import api, weights
+    lg = weights.synthetic_lightglue(1234)
+    ctx = api.Context(lightglue=lg, max_batch=2, max_keypoints=1024)
+    _, _, a, b = _pair(n0, n1, 1024 + n1)
+    s = ctx.lightglue_scores(a, b)
+    ref = ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
+    err = np.abs(s - ref)
+    idx, sc = ctx.match_lightglue(a, b)
+    didx, dsc = ref_post.filter_matches(s, 0.1)
+    diag(f"lg_max_{n0}_{n1}", max_err=err.max(), mean_err=err.mean(), ref_absmax=np.abs(ref).max(), n_dev=len(idx),
+         nan=int(np.isnan(s).sum()))
+    assert s.shape == (n0, n1) and not np.isnan(s).any()
+    np.testing.assert_array_equal(idx, didx)
+    np.testing.assert_allclose(sc, dsc, rtol=2e-6)
+    assert err.max() <= 0.05 * max(1.0, np.abs(ref).mean())
+    ctx.close()

@@ -122,3 +122,31 @@ def test_matching_points_superglue_branch():
     assert cnt == len(ref)
     assert [(m[0], m[1]) for m in matches] == [(r[0], r[1]) for r in ref]
     ctx.close()
+
+
+def test_superglue_cfg5_max_size_fp16():
+    """1280x720, SuperGlue-outdoor shape, N at the engine profile maximum 1024 (super_glue.cpp:55), fp16,
+    100 Sinkhorn iterations."""
+    w = weights.synthetic_superglue(1234)
+    ctx = api.Context(superglue=w, matcher=1, max_batch=2, sinkhorn_iters=100, max_keypoints=1024, precision=1,
+                      image_width=1280, image_height=720)
+    rng = np.random.default_rng(55)
+    f0, f1 = _features(1024, 501), _features(1000, 502)
+    for f in (f0, f1):
+        f[:, 1] = rng.uniform(4, 1276, f.shape[0]); f[:, 2] = rng.uniform(4, 716, f.shape[0])
+    f0 = ref_post.normalize_keypoints(f0, 1280, 720, 0.7)
+    f1 = ref_post.normalize_keypoints(f1, 1280, 720, 0.7)
+    z = ctx.superglue_scores(f0, f1)
+    ref = ref_nets.superglue_forward(w, f0[:, 1:3], f0[:, 0], f0[:, 3:], f1[:, 1:3], f1[:, 0], f1[:, 3:], iters=100)
+    err = np.abs(z - ref)
+    i0, i1, m0, m1 = ctx.match_superglue(f0, f1)
+    d0, d1, dm0, dm1 = ref_post.superglue_decode(z, 0.2)
+    diag("sg_cfg5_1024_1000_fp16", max_err=err.max(), mean_err=err.mean(), ref_absmax=np.abs(ref).max(),
+         n_valid=int((i0 >= 0).sum()), nan=int(np.isnan(z).sum()))
+    assert z.shape == (1025, 1001) and not np.isnan(z).any()
+    assert i0.shape == (1024,) and i1.shape == (1000,)            # lengths h-1, w-1: super_glue.cpp:357-358
+    np.testing.assert_array_equal(i0, d0)
+    np.testing.assert_array_equal(i1, d1)
+    np.testing.assert_allclose(m0, dm0, rtol=2e-6)
+    assert err.max() <= 0.05 * max(1.0, np.abs(ref).mean())
+    ctx.close()
