@@ -164,6 +164,7 @@ struct airfe_ctx {
   bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
   int gemm_small_max = 4096, gemm8_min = 16000;   // GemmArgs::small_max / g8_min (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M)
   int block_min = 16000;         // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
+  int block_form = 0;            // fused block kernel: 0 token-stationary weight stream (kernels_lgblock), 1 feature-split (kernels_lgblockf); AIRFE_LG_BLOCK_FORM
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
 
@@ -781,6 +782,14 @@ void lg_block(airfe_ctx* c, const LgBlockW& w, int M, hipStream_t st) {
   launch_lg_block(c->prec, a, st);
 }
 
+void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st) {
+  LgBlockFArgs a;
+  a.attn = c->ob; a.xb = c->xb; a.x32 = c->x32; a.wo = out.w; a.w1 = f0.w; a.w2 = f3.w;
+  a.bo = out.b; a.b1 = f0.b; a.gamma = g; a.beta = b; a.b2 = f3.b; a.M = M;
+  ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * (256.0 * 256 + 512.0 * 512 + 512.0 * 256), (double)M * (512 + 512 + 1024 + 512 + 1024) + 917504.0);
+  launch_lg_blockf(c->prec, a, st);
+}
+
 void lg_ffn(airfe_ctx* c, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st) {
   run_linear(c, f0, c->xb, 256, 256, c->msg, 256, M, EPI_STORE, ACT_NONE, c->hb, 512, st);
   { ProfScope ps(c, ST_LG_LNGELU, st, 0, (double)M * 2048); launch_ln_gelu(c->prec, c->hb, g, b, M, st); }
@@ -814,7 +823,9 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     run_linear(c, l.qk, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS, ACT_NONE, c->qb, 0, st, false, c->kb, nullptr, c->rot_cos, c->rot_sin);
     run_linear(c, l.v, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
-    if (fused_block) {
+    if (fused_block && c->block_form == 1) {
+      lg_blockf(c, l.out, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
+    } else if (fused_block) {
       lg_block(c, l.blk, Mg, st);
     } else {
       run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
@@ -824,7 +835,9 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     run_linear(c, l.cqk, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS, ACT_NONE, c->qb, 0, st);
     run_linear(c, l.cv, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
-    if (fused_block) {
+    if (fused_block && c->block_form == 1) {
+      lg_blockf(c, l.cout, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st);
+    } else if (fused_block) {
       lg_block(c, l.cblk, Mg, st);
     } else {
       run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
@@ -931,6 +944,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   c->fuse_lg_block = getenv("AIRFE_FUSE_LG_BLOCK") ? (atoi(getenv("AIRFE_FUSE_LG_BLOCK")) != 0) : -1;
   if (getenv("AIRFE_SMALL_MAX_M")) c->gemm_small_max = atoi(getenv("AIRFE_SMALL_MAX_M"));
   if (getenv("AIRFE_GEMM8_MIN_M")) c->gemm8_min = atoi(getenv("AIRFE_GEMM8_MIN_M"));
+  if (getenv("AIRFE_LG_BLOCK_FORM")) c->block_form = atoi(getenv("AIRFE_LG_BLOCK_FORM"));
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
   c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {

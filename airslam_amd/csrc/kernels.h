@@ -55,6 +55,16 @@ struct LgBlockArgs {
   int M;                     // tokens, multiple of 128
 };
 void launch_lg_block(int prec, const LgBlockArgs& a, hipStream_t st);
+// the same block, feature-split form (kernels_lgblockf.hip): weights straight from the packed slabs of the separate linears
+struct LgBlockFArgs {
+  const uint16_t* attn;      // [M][256]
+  uint16_t* xb;              // [M][256], updated in place
+  float* x32;                // [M][256], updated in place
+  const uint16_t *wo, *w1, *w2;                    // LinW::w of out-proj (256->256), ffn.0 (512->512), ffn.3 (512->256)
+  const float *bo, *b1, *gamma, *beta, *b2;
+  int M;                     // tokens, multiple of 128
+};
+void launch_lg_blockf(int prec, const LgBlockFArgs& a, hipStream_t st);
 
 struct ConvArgs {
   const uint16_t* X = nullptr;  // [B][H+2][W+2][CIN], zero border
