@@ -163,8 +163,8 @@ struct airfe_ctx {
   size_t pl_bytes = 0;
   bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
   int gemm_small_max = 4096, gemm8_min = 16000;   // GemmArgs::small_max / g8_min (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M)
-  int block_min = 16000;         // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
-  int block_form = 0;            // fused block kernel: 0 token-stationary weight stream (kernels_lgblock), 1 feature-split (kernels_lgblockf); AIRFE_LG_BLOCK_FORM
+  int block_min = 3200;          // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
+  int block_form = 1;            // fused block kernel: 1 feature-split (kernels_lgblockf), 0 token-stationary weight stream (kernels_lgblock); AIRFE_LG_BLOCK_FORM
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
 
@@ -814,9 +814,9 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   pa.wr = c->lg_wr; pa.B = B; pa.cap = cap; pa.Np = Np;
   pa.x32 = c->x32; pa.xb = c->xb; pa.rot_cos = c->rot_cos; pa.rot_sin = c->rot_sin; pa.lens = c->lens;
   { ProfScope ps(c, ST_LG_PREPARE, st, 0, (double)M * (1036 + 1536 + 256)); launch_lg_prepare(c->prec, pa, st); }
-  // lg_block's tile time is set by its 1.3 MB weight stream, not by the token count (58 us per round of 256 tiles), so below
-  // ~16000 tokens (20 pairs of 400) the four separate launches are quicker: 1.42 vs 2.12 ms per step at 1 pair, 2.61 vs 3.09 ms
-  // at 8 pairs, 3.60 vs 3.89 ms at 16 pairs; from 20 pairs on the fused kernel wins (4.71 vs 5.31 ms at 24 pairs).
+  // The fused block (kernels_lgblockf.hip) streams 0.9 MB of weights per 128-token workgroup whatever the batch, so below 3200
+  // tokens (4 pairs of 400) the four separate launches are quicker: 1.82 vs 1.85 ms per step at 3 pairs, 2.01 vs 1.98 at 4,
+  // 2.65 vs 2.45 at 8 (profiles/r01d_small_batch_sweeps.txt).
   const bool fused_block = c->fuse_lg_block == 1 || (c->fuse_lg_block < 0 && Mg >= c->block_min);
   for (const LgLayer& l : c->lg) {
     // ---- self block

@@ -4,24 +4,28 @@
 // kernels_lgblock.hip keeps a token's whole chain inside one wave (msg and h never leave registers), which forces every wave
 // to read every weight through LDS, one wave per SIMD, one workgroup-wide barrier per 32 KiB of weights.  This form is the
 // other cut: the 8 waves (two per SIMD) split the OUTPUT FEATURES of each GEMM, every wave fetches only its own rows of the
-// packed weight slabs straight from global memory into MFMA A-fragments (each weight byte is read once per workgroup, no LDS,
-// no barrier), and the activations are the B operand shared through LDS: attn / x / msg tiles of [128][256] 2-byte (64 KiB)
-// and the h tile of [128][512] (128 KiB, over the dead attn/x and msg tiles).  Five workgroup barriers per tile instead of 28.
+// packed weight slabs straight from global memory into MFMA A-fragments (each weight byte is read once per workgroup,
+// no LDS, no barrier), and the activations are the B operand shared through LDS: attn / x / msg tiles of [128][256] 2-byte
+// (64 KiB) and the h tile of [128][512] (128 KiB, over the dead attn/x and msg tiles).  Five workgroup barriers.
 //   LDS:  R0 [0, 64K) attn -> x -> h(lo)   R1 [64K, 128K) msg -> h(hi)   ST [128K, 136K) LayerNorm partial sums
 //   rows are swizzled by XOR of the 16-byte piece index with (token & 15): conflict-free ds_read_b128 / ds_write_b128.
 // Weights are the SAME packed slabs the separate launches use (LinW::w, [N/64][K/64][8 KiB]); the feature order inside a slab
 // (slab_row_to_feature) is what makes a lane's accumulators 8 contiguous features of one token.
+//
+// One workgroup = one pass over 128 tokens.  (Dealing the token tiles out evenly over 256 persistent workgroups in passes of
+// 6-7 tiles — 51200 tokens are 400 fixed tiles on 256 CUs, a second round for 144 of them — measured the same: with every CU
+// in the same phase at the same time the passes do not get shorter in proportion to their tokens.)
+//
+// What the per-phase timers said (round 1, 128-token pass, us): attn 3.0 | out-proj 3.9 | ffn.0 5.1 + 1.6 + 4.0 | LN sums 2.9
+// | GELU 10.3 | ffn.3 4.7 | epilogue 2.6.  Removing the LDS reads changes nothing, removing the weight loads 10 %: the GEMMs
+// sit at the ~80 % two-waves-per-SIMD MFMA ceiling; the GELU phase is VALU-bound (see lf_gelu2).
 #include "common.h"
 #include "kernels.h"
 
 namespace airfe {
 
-constexpr int LF_TM = 128;
 constexpr int LF_R0 = 0, LF_R1 = 65536, LF_ST = 131072;
-constexpr int LF_LDS = LF_ST + 8 * LF_TM * 8;
-#ifndef LF_XDMA_SLAB
-#define LF_XDMA_SLAB 3
-#endif
+constexpr int LF_LDS = LF_ST + 8 * 128 * 8;
 
 __device__ __forceinline__ void lf_glds16(const void* gsrc, unsigned lds_off) {
   unsigned keep;
@@ -35,8 +39,7 @@ __device__ __forceinline__ void lf_glds16(const void* gsrc, unsigned lds_off) {
 // R = log2(erfcx) a degree-8 polynomial in u = x/3 - 1 on x in [0, 6] (Chebyshev fit, |dR| < 1e-5; beyond 6 erfc < 3e-17).
 // One transcendental instead of the two (rcp, exp) of Abramowitz & Stegun 7.1.26 in ln_gelu_kernel, no cancellation on the
 // negative side (max abs error 1.1e-6, relative 2e-4 in the far negative tail where 7.1.26 returns 0), and written on float
-// PAIRS so that the 19 multiply-adds become v_pk_fma_f32 / v_pk_mul_f32: this epilogue is 128 elements per lane per tile and
-// was as long as the tile's MFMA time.
+// PAIRS so that the multiply-adds become v_pk_fma_f32 / v_pk_mul_f32: this epilogue is 128 elements per lane per workgroup.
 __device__ __forceinline__ f32x2 lf_gelu2(f32x2 y) {
   const f32x2 a = __builtin_elementwise_abs(y);
   f32x2 x = a * 0.70710678118654752f;
@@ -55,14 +58,13 @@ __device__ __forceinline__ f32x2 lf_gelu2(f32x2 y) {
   return __builtin_elementwise_max(y, f32x2{0.f, 0.f}) - (x * 0.70710678118654752f) * q;
 }
 
-// [128 tokens][256] 2-byte rows of `src` -> LDS region (64 KiB) by LDS-DMA: 64 wave-instructions of 1 KiB (two rows each), eight
-// per wave; lane i of an instruction lands at +16 i, so the swizzle is applied on the global side.
-__device__ __forceinline__ void lf_stage_rows(const uint16_t* src, int m0, int region, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int inst = wave * 8 + i;
+// [16 nmt tokens][256] 2-byte rows of `src` -> LDS region by LDS-DMA: 8 nmt wave-instructions of 1 KiB (two rows each), nmt per
+// wave; lane i of an instruction lands at +16 i, so the swizzle is applied on the global side.
+__device__ __forceinline__ void lf_stage_rows(const uint16_t* src, int row0, int nmt, int region, int wave, int lane) {
+  for (int i = 0; i < nmt; ++i) {
+    const int inst = wave * nmt + i;
     const int r = inst * 2 + (lane >> 5), pp = lane & 31;
-    lf_glds16(src + (size_t)(m0 + r) * 256 + ((pp ^ (r & 15)) << 3), (unsigned)(region + inst * 1024));
+    lf_glds16(src + (size_t)(row0 + r) * 256 + ((pp ^ (r & 15)) << 3), (unsigned)(region + inst * 1024));
   }
 }
 
@@ -82,14 +84,15 @@ __device__ __forceinline__ void lf_first(typename P::vec8 (&cur)[NT][2], const c
   }
 }
 
-// acc[t][m] += W(tiles t of this wave, slabs 0..nslab-1) x B(token tiles m = 0..7): w0 / w1 = this lane's fragment address in
-// slab 0, tile 0 for the two 32-wide halves of the slab's 64-wide K chunk; tile t at +2048 t, slab s at +8192 s.  `cur` holds
-// slab 0 on entry; the next slab's fragments are fetched while the current one feeds 16 NT MFMAs, and during the last slab the
-// fetch goes to n0 / n1 (the first slab of whatever this wave multiplies next), which `cur` holds on exit.
 struct LfNoHook { __device__ __forceinline__ void operator()(int) const {} };
 
-template <class P, int NT, class Hook = LfNoHook>
-__device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][8], typename P::vec8 (&cur)[NT][2], const char* w0, const char* w1, int nslab,
+// acc[t][m] += W(tiles t of this wave, slabs 0..nslab-1) x B(token tiles m < NMT): w0 / w1 = this lane's fragment address in
+// slab 0, tile 0 for the two 32-wide halves of the slab's 64-wide K chunk; tile t at +2048 t, slab s at +8192 s.  `cur` holds
+// slab 0 on entry; the next slab's fragments are fetched while the current one feeds 2 NT NMT MFMAs, and during the last slab
+// the fetch goes to n0 / n1 (the first slab of whatever this wave multiplies next), which `cur` holds on exit.  (Fetching two
+// or three slabs ahead for the 32-feature GEMMs measured no faster on the whole block.)
+template <class P, int NT, int NMT, class Hook = LfNoHook>
+__device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (&cur)[NT][2], const char* w0, const char* w1, int nslab,
                                        const char* n0, const char* n1, const char* breg, int pitch, int l15, int g, Hook hook = Hook()) {
   typename P::vec8 nxt[NT][2];
   const char* brow = breg + l15 * pitch;
@@ -109,14 +112,16 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][8], typename P::vec8 (&c
     for (int h = 0; h < 2; ++h) {
       const int boff = (((s * 8 + h * 4 + g) ^ l15) << 4);
 #pragma unroll
-      for (int mh = 0; mh < 2; ++mh) {
+      for (int mb = 0; mb < NMT; mb += 4) {
         typename P::vec8 bf[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = lds_frag<P>(brow, boff + (mh * 4 + j) * 16 * pitch);
+        for (int j = 0; j < 4; ++j)
+          if (mb + j < NMT) bf[j] = lds_frag<P>(brow, boff + (mb + j) * 16 * pitch);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[t][mh * 4 + j] = P::mfma(cur[t][h], bf[j], acc[t][mh * 4 + j]);
+          for (int j = 0; j < 4; ++j)
+            if (mb + j < NMT) acc[t][mb + j] = P::mfma(cur[t][h], bf[j], acc[t][mb + j]);
       }
     }
 #pragma unroll
@@ -127,79 +132,17 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][8], typename P::vec8 (&c
   }
 }
 
-// The 32-feature GEMMs (out-proj, ffn.3): one slab is only 32 MFMAs per wave, less than an L2 round trip, so the A fragments
-// run THREE slabs ahead through a four-buffer ring (fully unrolled: the ring index is a compile-time constant).  `first`
-// holds slab 0 on entry.
-template <class P, int NSLAB>
-__device__ __forceinline__ void lf_mma2(f32x4 (&acc)[2][8], typename P::vec8 (&first)[2][2], const char* w0, const char* w1,
-                                        const char* breg, int pitch, int l15, int g) {
-  typename P::vec8 ring[4][2][2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    ring[0][t][0] = first[t][0];
-    ring[0][t][1] = first[t][1];
-  }
-#pragma unroll
-  for (int s = 1; s < 3 && s < NSLAB; ++s)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      ring[s][t][0] = lf_ldg<P>(w0 + s * SLAB_BYTES + t * 2048);
-      ring[s][t][1] = lf_ldg<P>(w1 + s * SLAB_BYTES + t * 2048);
-    }
-  const char* brow = breg + l15 * pitch;
-#pragma unroll
-  for (int s = 0; s < NSLAB; ++s) {
-    if (s + 3 < NSLAB) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        ring[(s + 3) & 3][t][0] = lf_ldg<P>(w0 + (s + 3) * SLAB_BYTES + t * 2048);
-        ring[(s + 3) & 3][t][1] = lf_ldg<P>(w1 + (s + 3) * SLAB_BYTES + t * 2048);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int boff = (((s * 8 + h * 4 + g) ^ l15) << 4);
-#pragma unroll
-      for (int mh = 0; mh < 2; ++mh) {
-        typename P::vec8 bf[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = lds_frag<P>(brow, boff + (mh * 4 + j) * 16 * pitch);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[t][mh * 4 + j] = P::mfma(ring[s & 3][t][h], bf[j], acc[t][mh * 4 + j]);
-      }
-    }
-  }
-}
+struct LfLane {                       // per-lane constants of the whole kernel
+  int lane, wave, l15, g, wf, cb, tp, fo0, fo1;
+  const char *wob, *w1b, *w2b;
+};
 
-#ifdef LF_TIMING
-__device__ long long lf_dbg[512 * 8 * 12];
-#define LF_STAMP(i) if (lane == 0 && blockIdx.x < 512) lf_dbg[(blockIdx.x * 8 + wave) * 12 + (i)] = wall_clock64();
-#else
-#define LF_STAMP(i)
-#endif
-
-template <class P>
-__global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * LF_TM;
-  const int sw = (l15 >> 1) & 7;                                  // swz128 of this lane's slab row (same for every tile)
-  const int fo0 = l15 * 128 + ((g ^ sw) << 4), fo1 = l15 * 128 + (((4 + g) ^ sw) << 4);
-  // Which feature block a wave owns rotates with the workgroup (among the workgroups of one XCD: blockIdx / 8), so that the
-  // 32 CUs of an XCD do not all ask its L2 for the same weight lines at the same moment.  Numerics do not depend on it.
-  const int wf = (wave + (blockIdx.x >> 3)) & 7;
-  const int cb = wf >> 1, tp = wf & 1;                            // 256-feature GEMMs: wave = 32 features (one tile pair)
-
-  LF_STAMP(0)
-  lf_stage_rows(a.attn, m0, LF_R0, wave, lane);
-  const char* wob = reinterpret_cast<const char*>(a.wo) + (size_t)cb * 4 * SLAB_BYTES + 2 * tp * 2048;
-  const char* w1b = reinterpret_cast<const char*>(a.w1) + (size_t)wf * 8 * SLAB_BYTES;
-  const char* w2b = reinterpret_cast<const char*>(a.w2) + (size_t)cb * 8 * SLAB_BYTES + 2 * tp * 2048;
+// One pass over NMT token tiles (16 tokens each) starting at token `row0`; its attn tile is already in flight into R0.
+template <class P, int NMT>
+__device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const LfLane& L, int row0) {
+  const int lane = L.lane, wave = L.wave, l15 = L.l15, g = L.g, wf = L.wf, cb = L.cb, tp = L.tp, fo0 = L.fo0, fo1 = L.fo1;
   typename P::vec8 c2[2][2], c4[4][2];                            // A fragments in flight: 32-feature GEMMs / the 64-feature one
-  lf_first<P, 2>(c2, wob + fo0, wob + fo1);
+  lf_first<P, 2>(c2, L.wob + fo0, L.wob + fo1);
   f32x4 bo2[2], b14[4];                                           // biases of the first two GEMMs: fetched with the attn tile
 #pragma unroll
   for (int u = 0; u < 2; ++u) bo2[u] = *reinterpret_cast<const f32x4*>(a.bo + cb * 64 + tp * 32 + g * 8 + u * 4);
@@ -207,20 +150,19 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
   for (int t = 0; t < 4; ++t) b14[t] = *reinterpret_cast<const f32x4*>(a.b1 + wf * 64 + (t >> 1) * 32 + g * 8 + (t & 1) * 4);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  LF_STAMP(1)
 
   // ---- msg = Wo attn + bo -> R1
   {
-    f32x4 acc[2][8];
+    f32x4 acc[2][NMT];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int m = 0; m < 8; ++m) acc[u][m] = bo2[u];
-    lf_mma2<P, 4>(acc, c2, wob + fo0, wob + fo1, smem + LF_R0, 512, l15, g);
-    lf_first<P, 4>(c4, w1b + 4 * SLAB_BYTES + fo0, w1b + 4 * SLAB_BYTES + fo1);      // lands while msg is packed and the barrier drains
+      for (int m = 0; m < NMT; ++m) acc[u][m] = bo2[u];
+    lf_mma<P, 2, NMT>(acc, c2, L.wob + fo0, L.wob + fo1, 4, L.wob + fo0, L.wob + fo1, smem + LF_R0, 512, l15, g);
+    lf_first<P, 4>(c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1);  // lands while msg is packed and the barrier drains
     const int piece = cb * 8 + tp * 4 + g;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < NMT; ++m) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -231,23 +173,19 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
     }
   }
   __syncthreads();                                                // msg complete, attn dead
-  LF_STAMP(2)
 
   // ---- h = W1 cat(x, msg) + b1: the msg half first; the x tile's DMA into R0 is issued behind the msg half's LAST weight
   // prefetch — vmcnt retires in order, so issued any earlier every wait for weights would also wait for the HBM-latency DMA
-  f32x4 h[4][8];
+  f32x4 h[4][NMT];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int m = 0; m < 8; ++m) h[t][m] = b14[t];
-  lf_mma<P, 4>(h, c4, w1b + 4 * SLAB_BYTES + fo0, w1b + 4 * SLAB_BYTES + fo1, 4, w1b + fo0, w1b + fo1, smem + LF_R1, 512, l15, g,
-               [&](int s) { if (s == LF_XDMA_SLAB) lf_stage_rows(a.xb, m0, LF_R0, wave, lane); });
-  LF_STAMP(3)
+    for (int m = 0; m < NMT; ++m) h[t][m] = b14[t];
+  lf_mma<P, 4, NMT>(h, c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R1, 512, l15, g,
+                    [&](int s) { if (s == 3) lf_stage_rows(a.xb, row0, NMT, LF_R0, wave, lane); });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  LF_STAMP(4)
-  lf_mma<P, 4>(h, c4, w1b + fo0, w1b + fo1, 4, w1b + fo0, w1b + fo1, smem + LF_R0, 512, l15, g);
-  LF_STAMP(5)
+  lf_mma<P, 4, NMT>(h, c4, L.w1b + fo0, L.w1b + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R0, 512, l15, g);
 
   // LayerNorm scale / shift of this wave's 64 features: fetched now, used after the next barrier
   f32x4 gam[2][2], bet[2][2];
@@ -258,11 +196,12 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
       gam[q][u] = *reinterpret_cast<const f32x4*>(a.gamma + wf * 64 + q * 32 + g * 8 + u * 4);
       bet[q][u] = *reinterpret_cast<const f32x4*>(a.beta + wf * 64 + q * 32 + g * 8 + u * 4);
     }
-  // ---- LayerNorm(512): per-wave partial sums over its 64 features, exchanged through ST
+  // ---- LayerNorm(512): per-wave partial sums over its 64 features, exchanged through ST (indexed by feature block, so the
+  // summation order does not depend on which wave owned it)
   {
     float2* st = reinterpret_cast<float2*>(smem + LF_ST);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < NMT; ++m) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -273,29 +212,28 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
         }
       s1 = rows_sum(s1);
       s2 = rows_sum(s2);
-      if (g == 0) st[wf * LF_TM + m * 16 + l15] = make_float2(s1, s2);
+      if (g == 0) st[wf * 128 + m * 16 + l15] = make_float2(s1, s2);
     }
   }
   __syncthreads();                                                // sums visible; x and msg tiles dead
-  LF_STAMP(6)
   // ffn.3's first weight fragments are fetched now, the fp32 residual rows half way: their latency hides under the GELU arithmetic
   const int co = cb * 64 + tp * 32 + g * 8;
-  float* xr0 = a.x32 + (size_t)(m0 + l15) * 256 + co;
-  float4 r0[8], r1[8];
-  lf_first<P, 2>(c2, w2b + fo0, w2b + fo1);
+  float* xr0 = a.x32 + (size_t)(row0 + l15) * 256 + co;
+  float4 r0[NMT], r1[NMT];
+  lf_first<P, 2>(c2, L.w2b + fo0, L.w2b + fo1);
   f32x4 b22[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) b22[u] = *reinterpret_cast<const f32x4*>(a.b2 + co + u * 4);
   __builtin_amdgcn_sched_barrier(0);
   {
     const float2* st = reinterpret_cast<const float2*>(smem + LF_ST);
-    float nmr[8], rstd[8];                                        // (h - mean) rstd = h rstd + nmr
+    float nmr[NMT], rstd[NMT];                                    // (h - mean) rstd = h rstd + nmr
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < NMT; ++m) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
-        const float2 p = st[w * LF_TM + m * 16 + l15];
+        const float2 p = st[w * 128 + m * 16 + l15];
         s1 += p.x;
         s2 += p.y;
       }
@@ -304,24 +242,20 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
       rstd[m] = 1.0f / sqrtf(var + 1e-5f);
       nmr[m] = -mean * rstd[m];
     }
-    // ---- GELU(LN(h)) -> h tile [128][512] 2-byte over R0 + R1
+    // ---- GELU(LN(h)) -> h tile [16 NMT][512] 2-byte over R0 + R1
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const f32x4 g0 = gam[q][0], g1 = gam[q][1], be0 = bet[q][0], be1 = bet[q][1];
       const int piece = wf * 8 + q * 4 + g;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
+      for (int m = 0; m < NMT; ++m) {
         const f32x2 rs = {rstd[m], rstd[m]}, nm = {nmr[m], nmr[m]};
         float v[8];
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
           const f32x2 y0 = (f32x2{h[2 * q][m][e], h[2 * q][m][e + 1]} * rs + nm) * f32x2{g0[e], g0[e + 1]} + f32x2{be0[e], be0[e + 1]};
           const f32x2 y1 = (f32x2{h[2 * q + 1][m][e], h[2 * q + 1][m][e + 1]} * rs + nm) * f32x2{g1[e], g1[e + 1]} + f32x2{be1[e], be1[e + 1]};
-#ifdef LF_NOGELU
-          const f32x2 o0 = y0, o1 = y1;
-#else
           const f32x2 o0 = lf_gelu2(y0), o1 = lf_gelu2(y1);
-#endif
           v[e] = o0.x; v[e + 1] = o0.y;
           v[4 + e] = o1.x; v[5 + e] = o1.y;
         }
@@ -329,7 +263,7 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
       }
       if (q == 0) {           // half of h's registers are free now: the residual rows take them
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < NMT; ++m) {
           r0[m] = *reinterpret_cast<const float4*>(xr0 + (size_t)m * 16 * 256);
           r1[m] = *reinterpret_cast<const float4*>(xr0 + (size_t)m * 16 * 256 + 4);
         }
@@ -338,20 +272,18 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
     }
   }
   __syncthreads();
-  LF_STAMP(7)
 
   // ---- x += W2 h + b2
   {
-    f32x4 acc[2][8];
+    f32x4 acc[2][NMT];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int m = 0; m < 8; ++m) acc[u][m] = b22[u];
-    lf_mma2<P, 8>(acc, c2, w2b + fo0, w2b + fo1, smem, 1024, l15, g);
-    LF_STAMP(8)
+      for (int m = 0; m < NMT; ++m) acc[u][m] = b22[u];
+    lf_mma<P, 2, NMT>(acc, c2, L.w2b + fo0, L.w2b + fo1, 8, L.w2b + fo0, L.w2b + fo1, smem, 1024, l15, g);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const size_t row = (size_t)(m0 + m * 16 + l15);
+    for (int m = 0; m < NMT; ++m) {
+      const size_t row = (size_t)(row0 + m * 16 + l15);
       float* xr = xr0 + (size_t)m * 16 * 256;
       float v[8] = {acc[0][m][0] + r0[m].x, acc[0][m][1] + r0[m].y, acc[0][m][2] + r0[m].z, acc[0][m][3] + r0[m].w,
                     acc[1][m][0] + r1[m].x, acc[1][m][1] + r1[m].y, acc[1][m][2] + r1[m].z, acc[1][m][3] + r1[m].w};
@@ -360,12 +292,33 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
       *reinterpret_cast<uint4*>(a.xb + row * 256 + co) = pack8<P>(v);
     }
   }
-  LF_STAMP(9)
 }
 
-#ifdef LF_TIMING
-extern "C" int airfe_dbg_lf(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lf_dbg), sizeof(long long) * 512 * 8 * 12); }
-#endif
+template <class P>
+__global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  LfLane L;
+  L.lane = tid & 63;
+  L.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  L.l15 = L.lane & 15;
+  L.g = L.lane >> 4;
+  const int sw = (L.l15 >> 1) & 7;                                // swz128 of this lane's slab row (same for every tile)
+  L.fo0 = L.l15 * 128 + ((L.g ^ sw) << 4);
+  L.fo1 = L.l15 * 128 + (((4 + L.g) ^ sw) << 4);
+  // Which feature block a wave owns rotates with the workgroup (among the workgroups of one XCD: blockIdx / 8), so that the
+  // 32 CUs of an XCD do not all ask its L2 for the same weight lines at the same moment.  Numerics do not depend on it.
+  L.wf = (L.wave + (blockIdx.x >> 3)) & 7;
+  L.cb = L.wf >> 1;                                               // 256-feature GEMMs: wave = 32 features (one tile pair)
+  L.tp = L.wf & 1;
+  L.wob = reinterpret_cast<const char*>(a.wo) + (size_t)L.cb * 4 * SLAB_BYTES + 2 * L.tp * 2048;
+  L.w1b = reinterpret_cast<const char*>(a.w1) + (size_t)L.wf * 8 * SLAB_BYTES;
+  L.w2b = reinterpret_cast<const char*>(a.w2) + (size_t)L.cb * 8 * SLAB_BYTES + 2 * L.tp * 2048;
+
+  const int row0 = blockIdx.x * 128;
+  lf_stage_rows(a.attn, row0, 8, LF_R0, L.wave, L.lane);
+  lf_pass<P, 8>(a, smem, L, row0);
+}
 
 template <class P>
 static void launch_f(const LgBlockFArgs& a, hipStream_t st) {
@@ -375,7 +328,7 @@ static void launch_f(const LgBlockFArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kfn, dim3((unsigned)(a.M / LF_TM)), dim3(512), LF_LDS, st, a);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(a.M / 128)), dim3(512), LF_LDS, st, a);
 }
 
 void launch_lg_blockf(int prec, const LgBlockFArgs& a, hipStream_t st) {
