@@ -138,11 +138,9 @@ std::vector<uint16_t> pack_slabs(int cbt, int nslab, int prec, const std::functi
 
 struct ConvW { uint16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; };
 struct LinW { uint16_t* w = nullptr; float* b = nullptr; int K = 0, N = 0, cbt = 0; };
-struct LgBlockW { uint16_t* stream = nullptr; float* params = nullptr; };   // fused post-attention block (kernels_lgblock.hip)
 struct LgLayer {
   LinW qk, v, out, ffn0, ffn3, cqk, cv, cout, cffn0, cffn3;
   float *ln_g = nullptr, *ln_b = nullptr, *cln_g = nullptr, *cln_b = nullptr;
-  LgBlockW blk, cblk;
 };
 struct SgLayer { LinW qk, v, merge, mlp0, mlp3; };
 constexpr int LINE_CAP = 16384;     // unique candidate lines per image (the reference's TensorRT profile allows 50000)
@@ -164,7 +162,6 @@ struct airfe_ctx {
   bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
   int gemm_small_max = 4096, gemm8_min = 16000;   // GemmArgs::small_max / g8_min (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M)
   int block_min = 3200;          // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
-  int block_form = 1;            // fused block kernel: 1 feature-split (kernels_lgblockf), 0 token-stationary weight stream (kernels_lgblock); AIRFE_LG_BLOCK_FORM
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
 
@@ -417,51 +414,6 @@ int load_superpoint(airfe_ctx* c, const char* path) {
 
 int alloc_matcher_arena(airfe_ctx* c);
 
-// "Fragment-linear" weight stream of one post-attention block: the three matrices in the exact order lg_block_kernel's
-// MFMAs consume them.  GEMM (F features, K inputs) -> for each 128-feature chunk, for each 128-wide K quarter: one 32 KiB
-// stage = [4 k-steps][8 feature tiles] fragments of 1 KiB; fragment lane (i = lane & 15, g = lane >> 4) holds
-// W[feature(tile, i)][k-step * 32 + g * 8 .. + 7] with feature(tile, i) = chunk*128 + (tile>>1)*32 + (i>>2)*8 + (tile&1)*4 + (i&3)
-// (the accumulator rows of a tile pair are then 8 consecutive features per lane = the next GEMM's B fragment).
-bool make_lg_block(airfe_ctx* c, const Pack& p, const std::string& pre, const std::string& out_name, LgBlockW& out, std::string& err) {
-  const Tensor *wo = need(p, pre + "." + out_name + ".weight", err), *bo = need(p, pre + "." + out_name + ".bias", err);
-  const Tensor *w1 = need(p, pre + ".ffn.0.weight", err), *b1 = need(p, pre + ".ffn.0.bias", err);
-  const Tensor *gm = need(p, pre + ".ffn.1.weight", err), *bt = need(p, pre + ".ffn.1.bias", err);
-  const Tensor *w2 = need(p, pre + ".ffn.3.weight", err), *b2 = need(p, pre + ".ffn.3.bias", err);
-  if (!wo || !bo || !w1 || !b1 || !gm || !bt || !w2 || !b2) return false;
-  if (wo->data.size() != 256 * 256 || w1->data.size() != 512 * 512 || w2->data.size() != 256 * 512 || bo->data.size() != 256 ||
-      b1->data.size() != 512 || gm->data.size() != 512 || bt->data.size() != 512 || b2->data.size() != 256) {
-    err = pre + ": unexpected block shapes";
-    return false;
-  }
-  std::vector<uint16_t> st;
-  st.reserve((size_t)LGB_STREAM_STAGES * 16384);
-  auto emit = [&](const float* W, int F, int K) {
-    for (int fc = 0; fc < F / 128; ++fc)
-      for (int kq = 0; kq < K / 128; ++kq)
-        for (int ks = 0; ks < 4; ++ks)
-          for (int t = 0; t < 8; ++t)
-            for (int lane = 0; lane < 64; ++lane) {
-              const int i = lane & 15, g = lane >> 4;
-              const int feat = fc * 128 + (t >> 1) * 32 + (i >> 2) * 8 + (t & 1) * 4 + (i & 3);
-              const int k0 = kq * 128 + ks * 32 + g * 8;
-              for (int e = 0; e < 8; ++e) st.push_back(cvt2(W[(size_t)feat * K + k0 + e], c->prec));
-            }
-  };
-  emit(wo->data.data(), 256, 256);
-  emit(w1->data.data(), 512, 512);
-  emit(w2->data.data(), 256, 512);
-  std::vector<float> prm;
-  prm.insert(prm.end(), bo->data.begin(), bo->data.end());
-  prm.insert(prm.end(), b1->data.begin(), b1->data.end());
-  prm.insert(prm.end(), gm->data.begin(), gm->data.end());
-  prm.insert(prm.end(), bt->data.begin(), bt->data.end());
-  prm.insert(prm.end(), b2->data.begin(), b2->data.end());
-  if (st.size() != (size_t)LGB_STREAM_STAGES * 16384 || prm.size() != (size_t)LGB_PARAM_FLOATS) { err = pre + ": block packing size mismatch"; return false; }
-  out.stream = dupload(c, st);
-  out.params = dupload(c, prm);
-  return out.stream && out.params;
-}
-
 int load_lightglue(airfe_ctx* c, const char* path) {
   Pack p;
   std::string err;
@@ -494,7 +446,6 @@ int load_lightglue(airfe_ctx* c, const char* path) {
     ok = ok && make_linear_named(c, p, x + ".to_out", 256, 256, l.cout, err);
     ok = ok && make_linear_named(c, p, x + ".ffn.0", 512, 512, l.cffn0, err);
     ok = ok && make_linear_named(c, p, x + ".ffn.3", 512, 256, l.cffn3, err);
-    ok = ok && make_lg_block(c, p, s, "out_proj", l.blk, err) && make_lg_block(c, p, x, "to_out", l.cblk, err);
     const Tensor *g1 = need(p, s + ".ffn.1.weight", err), *b1 = need(p, s + ".ffn.1.bias", err);
     const Tensor *g2 = need(p, x + ".ffn.1.weight", err), *b2 = need(p, x + ".ffn.1.bias", err);
     if (!g1 || !b1 || !g2 || !b2) { ok = false; break; }
@@ -774,14 +725,7 @@ void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1
   launch_gemm(c->prec, w.K, trans, g, st);
 }
 
-// out-proj + FFN + residual of one block as ONE kernel (kernels_lgblock.hip); flops/bytes are the algorithmic ones
-void lg_block(airfe_ctx* c, const LgBlockW& w, int M, hipStream_t st) {
-  LgBlockArgs a;
-  a.attn = c->ob; a.xb = c->xb; a.x32 = c->x32; a.wstream = w.stream; a.params = w.params; a.M = M;
-  ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * (256.0 * 256 + 512.0 * 512 + 512.0 * 256), (double)M * (512 + 512 + 1024 + 512 + 1024) + 917504.0);
-  launch_lg_block(c->prec, a, st);
-}
-
+// out-proj + FFN + residual of one block as ONE kernel (kernels_lgblockf.hip); flops/bytes are the algorithmic ones
 void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st) {
   LgBlockFArgs a;
   a.attn = c->ob; a.xb = c->xb; a.x32 = c->x32; a.wo = out.w; a.w1 = f0.w; a.w2 = f3.w;
@@ -823,10 +767,8 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     run_linear(c, l.qk, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS, ACT_NONE, c->qb, 0, st, false, c->kb, nullptr, c->rot_cos, c->rot_sin);
     run_linear(c, l.v, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
-    if (fused_block && c->block_form == 1) {
+    if (fused_block) {
       lg_blockf(c, l.out, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
-    } else if (fused_block) {
-      lg_block(c, l.blk, Mg, st);
     } else {
       run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
       lg_ffn(c, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
@@ -835,10 +777,8 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     run_linear(c, l.cqk, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS, ACT_NONE, c->qb, 0, st);
     run_linear(c, l.cv, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
-    if (fused_block && c->block_form == 1) {
+    if (fused_block) {
       lg_blockf(c, l.cout, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st);
-    } else if (fused_block) {
-      lg_block(c, l.cblk, Mg, st);
     } else {
       run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
       lg_ffn(c, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st);
@@ -944,7 +884,6 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   c->fuse_lg_block = getenv("AIRFE_FUSE_LG_BLOCK") ? (atoi(getenv("AIRFE_FUSE_LG_BLOCK")) != 0) : -1;
   if (getenv("AIRFE_SMALL_MAX_M")) c->gemm_small_max = atoi(getenv("AIRFE_SMALL_MAX_M"));
   if (getenv("AIRFE_GEMM8_MIN_M")) c->gemm8_min = atoi(getenv("AIRFE_GEMM8_MIN_M"));
-  if (getenv("AIRFE_LG_BLOCK_FORM")) c->block_form = atoi(getenv("AIRFE_LG_BLOCK_FORM"));
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
   c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -43,19 +43,8 @@ void launch_gemm(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st)
 // M % 256 == 0: 256x128 tile, 8 waves, three-stage LDS-DMA ring (launch_gemm dispatches to it for large M)
 void launch_gemm8(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st);
 
-// ---- fused LightGlue post-attention block (kernels_lgblock.hip): out-proj -> ffn.0 -> LayerNorm -> GELU -> ffn.3 -> residual
-constexpr int LGB_STREAM_STAGES = 28;      // 32 KiB stages of the fragment-linear weight stream: 4 + 16 + 8
-constexpr int LGB_PARAM_FLOATS = 2048;     // bo[256] | b1[512] | gamma[512] | beta[512] | b2[256]
-struct LgBlockArgs {
-  const uint16_t* attn;      // [M][256] attention output (2-byte)
-  uint16_t* xb;              // [M][256] token state (2-byte copy), updated in place
-  float* x32;                // [M][256] fp32 residual stream, updated in place
-  const uint16_t* wstream;   // LGB_STREAM_STAGES x 32 KiB
-  const float* params;       // LGB_PARAM_FLOATS
-  int M;                     // tokens, multiple of 128
-};
-void launch_lg_block(int prec, const LgBlockArgs& a, hipStream_t st);
-// the same block, feature-split form (kernels_lgblockf.hip): weights straight from the packed slabs of the separate linears
+// ---- fused LightGlue post-attention block (kernels_lgblockf.hip): out-proj -> ffn.0 -> LayerNorm -> GELU -> ffn.3 -> residual;
+// weights straight from the packed slabs of the separate linears
 struct LgBlockFArgs {
   const uint16_t* attn;      // [M][256]
   uint16_t* xb;              // [M][256], updated in place

@@ -35,7 +35,7 @@ def _pair(n0, n1, seed):
     return f0, f1, np.ascontiguousarray(n0f[:, 1:]), np.ascontiguousarray(n1f[:, 1:])
 
 
-# A context picks the LightGlue block form by token count (fused lg_block_kernel from 4096 tokens, four launches below);
+# A context picks the LightGlue block form by token count (fused lg_blockf_kernel from 3200 tokens, four launches below);
 # AIRFE_FUSE_LG_BLOCK forces either, so that both forms meet the oracle at every size.
 FORMS = [{"AIRFE_FUSE_LG_BLOCK": "1"}, {"AIRFE_FUSE_LG_BLOCK": "0"}]
 
