@@ -160,7 +160,7 @@ struct airfe_ctx {
   char* pl_stage = nullptr;      // staging of airfe_assign_points_to_lines
   size_t pl_bytes = 0;
   bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
-  int gemm_small_max = 4096, gemm8_min = 16000;   // GemmArgs::small_max / g8_min (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M)
+  int gemm_small_max = 4096, gemm8_min = 16000, gemmr_min = 8192;   // GemmArgs::small_max / g8_min / gr_min (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M, AIRFE_GEMMR_MIN_M)
   int block_min = 3200;          // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
@@ -673,7 +673,7 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
     GemmArgs g;
     g.X1 = c->aPa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cPb.w; g.bias = c->cPb.b;
     g.M = cells; g.N = 65; g.cb_total = c->cPb.cbt; g.epi = EPI_STORE_F32; g.out = c->logits; g.ldo = 72;
-    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min;
+    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min;
     { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 288)); launch_gemm(c->prec, 256, false, g, st); }
     { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * (260 + 256)); launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st); }
   }
@@ -681,7 +681,7 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
     GemmArgs g;
     g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b;
     g.M = cells; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
-    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min;
+    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min;
     { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024)); launch_gemm(c->prec, 256, false, g, st); }
     // F.normalize of the dense map is applied lazily: sample_desc_kernel normalises just the 4 taps each keypoint reads
     // (same operations, same bits) — a dense pass moved 8 MB/image to serve 400 x 4 cell reads.
@@ -720,7 +720,7 @@ void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1
   g.Wp = w.w; g.bias = w.b; g.M = M; g.N = w.N; g.cb_total = w.cbt;
   g.epi = epi; g.act = act; g.out = out; g.out2 = out2; g.ldo = ldo; g.x32 = x32;
   g.rot_cos = rc; g.rot_sin = rs; g.Np = c->Np; g.H = 4;
-  g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min;
+  g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min;
   ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * w.K * w.N, (double)M * (w.K + w.N) * 2 + (double)w.K * w.N * 2);
   launch_gemm(c->prec, w.K, trans, g, st);
 }
@@ -884,6 +884,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   c->fuse_lg_block = getenv("AIRFE_FUSE_LG_BLOCK") ? (atoi(getenv("AIRFE_FUSE_LG_BLOCK")) != 0) : -1;
   if (getenv("AIRFE_SMALL_MAX_M")) c->gemm_small_max = atoi(getenv("AIRFE_SMALL_MAX_M"));
   if (getenv("AIRFE_GEMM8_MIN_M")) c->gemm8_min = atoi(getenv("AIRFE_GEMM8_MIN_M"));
+  if (getenv("AIRFE_GEMMR_MIN_M")) c->gemmr_min = atoi(getenv("AIRFE_GEMMR_MIN_M"));
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
   c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -1282,7 +1283,7 @@ int airfe_debug_gemm(airfe_ctx* c, const float* x, int M, int K, const float* w,
     GemmArgs g;
     g.X1 = dx; g.ld1 = K; g.K1 = K; g.Wp = lw.w; g.bias = lw.b; g.M = Mp; g.N = N; g.cb_total = lw.cbt;
     g.epi = EPI_STORE_F32; g.act = relu ? ACT_RELU : ACT_NONE; g.out = dy; g.ldo = Np8;
-    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min;
+    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min;
     launch_gemm(prec, K, false, g, c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, "debug_gemm: kernel failed");
   }

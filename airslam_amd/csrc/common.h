@@ -159,6 +159,17 @@ __device__ __forceinline__ float rows_sum(float v) {
   return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
 }
 
+// LightGlue rotary embedding on the four (even, odd) pairs of v[0..7]: one definition for every GEMM epilogue, so that the
+// kernels launch_gemm may pick for the same linear stay bit-identical.
+__device__ __forceinline__ void rotate_pairs(float* v, const f32x4& c, const f32x4& s) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = v[2 * i], x1 = v[2 * i + 1];
+    v[2 * i] = x0 * c[i] - x1 * s[i];
+    v[2 * i + 1] = x1 * c[i] + x0 * s[i];
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

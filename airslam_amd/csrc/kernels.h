@@ -36,12 +36,16 @@ struct GemmArgs {
   // kernel choice by row count (measured on MI355X, LightGlue at 400 keypoints per image): M <= small_max -> gemm_small_kernel
   // (no LDS, one round trip), M >= g8_min and M % 256 == 0 -> gemm8_kernel (256x256 tiles want >= 60 row tiles), else gemm_kernel
   int small_max = 4096, g8_min = 16000;
+  int gr_min = 8192;             // rows from which the K = 256 linears go to the streaming kernel (where it applies)
 };
 
 // out[M][N] = X[M][K] * W^T ; K in {128,256,512}; trans => EPI_HEADS_T (operand roles swapped)
 void launch_gemm(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st);
 // M % 256 == 0: 256x128 tile, 8 waves, three-stage LDS-DMA ring (launch_gemm dispatches to it for large M)
 void launch_gemm8(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st);
+// K = 256, N in {256, 512}, no rotary: persistent streaming kernel with register-resident weights (kernels_gemmr.hip)
+bool gemmr_applicable(int K, bool trans, const GemmArgs& a);
+void launch_gemmr(int prec, bool trans, const GemmArgs& a, hipStream_t st);
 
 // ---- fused LightGlue post-attention block (kernels_lgblockf.hip): out-proj -> ffn.0 -> LayerNorm -> GELU -> ffn.3 -> residual;
 // weights straight from the packed slabs of the separate linears

@@ -61,15 +61,9 @@ __device__ __forceinline__ void g8_store_run(const GemmArgs& a, int row, int co0
       const int s = row / a.Np, n = row - s * a.Np;
       const int sel = co0 >> 8, cw = co0 & 255, h = cw >> 6, d = cw & 63;
       if (a.rot_cos) {
-        const float4 c = *reinterpret_cast<const float4*>(a.rot_cos + (size_t)row * 32 + (d >> 1));
-        const float4 sn = *reinterpret_cast<const float4*>(a.rot_sin + (size_t)row * 32 + (d >> 1));
-        const float cs[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float x0 = v[2 * i], x1 = v[2 * i + 1];
-          v[2 * i] = x0 * cs[i] - x1 * ss[i];
-          v[2 * i + 1] = x1 * cs[i] + x0 * ss[i];
-        }
+        const f32x4 c = *reinterpret_cast<const f32x4*>(a.rot_cos + (size_t)row * 32 + (d >> 1));
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(a.rot_sin + (size_t)row * 32 + (d >> 1));
+        rotate_pairs(v, c, sn);
       }
       uint16_t* o = reinterpret_cast<uint16_t*>(sel ? a.out2 : a.out) + (((size_t)s * a.H + h) * a.Np + n) * 64 + d;
       *reinterpret_cast<uint4*>(o) = pack8<P>(v);

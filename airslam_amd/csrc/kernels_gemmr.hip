@@ -1,0 +1,204 @@
+// airfe — K = 256 linears of the matcher at large token counts (q/k/v projections, final projection): a STREAMING GEMM with the
+// weights resident in registers.
+//
+// These GEMMs are HBM-bound (K = 256: 512 B in, 512-1024 B out per token for 131-262 kFLOP), yet the tiled kernels ran them at
+// 1.8 TB/s: a 256 x 256 output tile has only four K chunks, so every workgroup is mostly pipeline fill and drain, one workgroup
+// per CU.  Here a persistent workgroup owns 256 output features for the whole launch: wave w holds its 32 features x 256 K as
+// 16 MFMA A-fragments (64 registers, loaded once), token tiles of 32 rows stream through an 8-slot LDS ring by LDS-DMA (seven
+// tiles = 112 KiB in flight per CU), and each tile costs one barrier, 16 ds_read_b128, 32 MFMAs and 2-4 stores per wave.
+// N = 512 (self q|k) runs as two feature groups; the two workgroups that read the same token tile sit on the same XCD
+// (blockIdx and blockIdx + 8) so the second read is an L2 hit.
+//
+// Nothing the compiler can see loads from global memory inside the tile loop (biases are preloaded into registers): a compiler-placed s_waitcnt would count only its own loads and drain the whole DMA ring.  The hand-placed
+// waits rely on loads retiring in order: "at most 2*(tiles still in flight behind the wanted one)" outstanding.
+// Rotary (self q|k): the cos / sin rows of a tile's tokens (2 x 4 KiB of fp32) ride the ring with it — one more DMA instruction per
+// wave and tile, six slots of 24 KiB instead of eight of 16 — and the epilogue rotates the accumulator pairs from LDS.
+#include "common.h"
+#include "kernels.h"
+
+namespace airfe {
+
+constexpr int GR_MT = 2;                          // 16-token MFMA tiles per streamed tile
+constexpr int GR_TT = 16 * GR_MT;                 // 32 tokens
+constexpr int GR_XBYTES = GR_TT * 512;            // [32][256] 2-byte = 16 KiB
+constexpr int GR_RBYTES = 2 * GR_TT * 128;        // cos | sin rows of the tile's tokens, [32][32] fp32 each = 8 KiB
+constexpr int GR_WGS = 256;
+
+template <int N>
+__device__ __forceinline__ void gr_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void gr_glds16(const void* gsrc, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_off)
+               : "memory");
+}
+
+template <class P, bool TRANS, bool ROT>
+__global__ __launch_bounds__(512, 1) void gemmr_kernel(GemmArgs a, int ntiles, int ngroups) {
+  constexpr int GR_SLOT = GR_XBYTES + (ROT ? GR_RBYTES : 0);
+  constexpr int GR_SLOTS = ROT ? 6 : 8;
+  constexpr int PER = ROT ? 3 : 2;                                    // DMA instructions per wave and tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = blockIdx.x;
+  const int group = (w >> 3) % ngroups;                               // 256-feature slice of the output
+  const int first = (w & 7) + 8 * (w / (8 * ngroups));                // first tile; the workgroups of a group stride by per_group
+  const int per_group = GR_WGS / ngroups;
+  const int n = first < ntiles ? (ntiles - first + per_group - 1) / per_group : 0;
+  if (n == 0) return;
+
+  // ---- this wave's weights: feature block cb, tile pair tp -> 16 fragments
+  const int cb = group * 4 + (wave >> 1), tp = wave & 1;
+  typename P::vec8 wreg[2][8];
+  {
+    const int sw = (l15 >> 1) & 7;
+    const char* wb = reinterpret_cast<const char*>(a.Wp) + (size_t)cb * 4 * SLAB_BYTES + 2 * tp * 2048 + l15 * 128;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        wreg[u][ks] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(
+            wb + u * 2048 + (ks >> 1) * SLAB_BYTES + ((((ks & 1) * 4 + g) ^ sw) << 4)));
+  }
+  f32x4 binit[2];                                                     // !TRANS: bias of the lane's 8 features
+  float bt[2];                                                        // TRANS: bias of the lane's feature column per tile
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    binit[u] = *reinterpret_cast<const f32x4*>(a.bias + cb * 64 + tp * 32 + g * 8 + u * 4);
+    bt[u] = a.bias[cb * 64 + slab_row_to_feature((2 * tp + u) * 16 + l15)];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- DMA of tile `t` (32 rows x 512 B) into ring slot `slot`: 16 wave-instructions of 1 KiB, two per wave, two rows each
+  const int ld = a.ld1;
+  auto dma = [&](int t, int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int inst = wave * 2 + i;
+      const int r = inst * 2 + (lane >> 5), pp = lane & 31;
+      gr_glds16(a.X1 + (size_t)(t * GR_TT + r) * ld + ((pp ^ (r & 15)) << 3), (unsigned)(slot * GR_SLOT + inst * 1024));
+    }
+    if constexpr (ROT) {                                              // waves 0-3: cos rows, 4-7: sin rows; 8 rows of 128 B per instruction
+      const float* src = (wave < 4 ? a.rot_cos : a.rot_sin) + ((size_t)t * GR_TT + (wave & 3) * 8) * 32 + lane * 4;
+      gr_glds16(src, (unsigned)(slot * GR_SLOT + GR_XBYTES + wave * 1024));
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < GR_SLOTS; ++j)
+    if (j < n) dma(first + j * per_group, j);
+  // tile 0 landed: at most PER * min(n - 1, GR_SLOTS - 1) younger DMA instructions may still be in flight
+  if (n >= GR_SLOTS) gr_wait_vm<PER * (GR_SLOTS - 1)>();
+  else gr_wait_vm<0>();
+  __syncthreads();
+
+  const int boff0 = l15 * 512;
+  for (int i = 0; i < n; ++i) {
+    const int t = first + i * per_group, slot = i & (GR_SLOTS - 1);
+    const char* xs = smem + slot * GR_SLOT + boff0;
+    f32x4 acc[2][GR_MT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int m = 0; m < GR_MT; ++m) acc[u][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      typename P::vec8 bf[GR_MT];
+#pragma unroll
+      for (int m = 0; m < GR_MT; ++m) bf[m] = lds_frag<P>(xs, m * 16 * 512 + (((ks * 4 + g) ^ l15) << 4));
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < GR_MT; ++m) {
+          if constexpr (TRANS) acc[u][m] = P::mfma(bf[m], wreg[u][ks], acc[u][m]);
+          else acc[u][m] = P::mfma(wreg[u][ks], bf[m], acc[u][m]);
+        }
+    }
+    // tile i+1 landed (this wave's part): behind it at most the tiles i+2 .. i+GR_SLOTS-1 are in flight, PER instructions each
+    const int behind = n - 2 - i;
+    if (behind >= GR_SLOTS - 2) gr_wait_vm<PER * (GR_SLOTS - 2)>();
+    else if (behind == 5) gr_wait_vm<PER * 5>();
+    else if (behind == 4) gr_wait_vm<PER * 4>();
+    else if (behind == 3) gr_wait_vm<PER * 3>();
+    else if (behind == 2) gr_wait_vm<PER * 2>();
+    else if (behind == 1) gr_wait_vm<PER>();
+    else gr_wait_vm<0>();
+
+    // ---- epilogue of tile i (stores only)
+    if constexpr (!TRANS) {
+      const int co = cb * 64 + tp * 32 + g * 8;
+#pragma unroll
+      for (int m = 0; m < GR_MT; ++m) {
+        const int row = t * GR_TT + m * 16 + l15;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[0][m][e] + binit[0][e];          // bias after the K sum, like the tiled kernels: bit-identical results
+          v[4 + e] = acc[1][m][e] + binit[1][e];
+        }
+        if constexpr (ROT) {                                          // rotary on the pairs (2i, 2i+1) of the head dimension: light_glue rotary, as gemm_store_run
+          const char* rt = smem + slot * GR_SLOT + GR_XBYTES + (m * 16 + l15) * 128 + (tp * 16 + g * 4) * 4;
+          const f32x4 cs = *reinterpret_cast<const f32x4*>(rt), sn = *reinterpret_cast<const f32x4*>(rt + GR_RBYTES / 2);
+          rotate_pairs(v, cs, sn);
+        }
+        if (a.epi == EPI_HEADS) {
+          const int s = row / a.Np, nn = row - s * a.Np;
+          const int sel = co >> 8, cw = co & 255, h = cw >> 6, d = cw & 63;
+          uint16_t* o = reinterpret_cast<uint16_t*>(sel ? a.out2 : a.out) + (((size_t)s * a.H + h) * a.Np + nn) * 64 + d;
+          *reinterpret_cast<uint4*>(o) = pack8<P>(v);
+        } else {                                                      // EPI_STORE
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.out) + (size_t)row * a.ldo + co) = pack8<P>(v);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int co = cb * 64 + slab_row_to_feature((2 * tp + u) * 16 + l15);
+        const int h = co >> 6, d = co & 63;
+#pragma unroll
+        for (int m = 0; m < GR_MT; ++m) {
+          const int row0 = t * GR_TT + m * 16 + g * 4;
+          const int sq = row0 / a.Np, nn = row0 - sq * a.Np;
+          uint16_t* o = reinterpret_cast<uint16_t*>(a.out) + (((size_t)sq * a.H + h) * 64 + d) * a.Np + nn;
+          *reinterpret_cast<uint2*>(o) = pack4<P>(acc[u][m][0] + bt[u], acc[u][m][1] + bt[u], acc[u][m][2] + bt[u], acc[u][m][3] + bt[u]);
+        }
+      }
+    }
+    __syncthreads();                                                  // every wave is done with slot i and has its part of tile i+1
+    if (i + GR_SLOTS < n) dma(first + (i + GR_SLOTS) * per_group, slot);
+  }
+}
+
+template <class P, bool TRANS, bool ROT>
+static void gemmr_launch_t(const GemmArgs& a, hipStream_t st) {
+  constexpr int LDS = ROT ? 6 * (GR_XBYTES + GR_RBYTES) : 8 * GR_XBYTES;
+  static bool attr_done = false;
+  auto kfn = gemmr_kernel<P, TRANS, ROT>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3(GR_WGS), dim3(512), LDS, st, a, a.M / GR_TT, a.cb_total / 4);
+}
+
+bool gemmr_applicable(int K, bool trans, const GemmArgs& a) {
+  const int ng = a.cb_total / 4;
+  return K == 256 && !a.X2 && (!a.rot_cos || (!trans && a.epi == EPI_HEADS)) && a.act == ACT_NONE && a.cb_total % 4 == 0 && (ng == 1 || ng == 2) && a.N == a.cb_total * 64 &&
+         a.M % GR_TT == 0 && (trans ? a.epi == EPI_HEADS_T : (a.epi == EPI_HEADS || (a.epi == EPI_STORE && a.ldo >= a.N)));
+}
+
+void launch_gemmr(int prec, bool trans, const GemmArgs& a, hipStream_t st) {
+  if (prec == 1) {
+    if (trans) gemmr_launch_t<PF16, true, false>(a, st);
+    else if (a.rot_cos) gemmr_launch_t<PF16, false, true>(a, st);
+    else gemmr_launch_t<PF16, false, false>(a, st);
+  } else {
+    if (trans) gemmr_launch_t<PBF16, true, false>(a, st);
+    else if (a.rot_cos) gemmr_launch_t<PBF16, false, true>(a, st);
+    else gemmr_launch_t<PBF16, false, false>(a, st);
+  }
+}
+
+}  // namespace airfe

@@ -228,15 +228,9 @@ __device__ __forceinline__ void gemm_store_run(const GemmArgs& a, int row, int c
       const int s = row / a.Np, n = row - s * a.Np;
       const int sel = co0 >> 8, cw = co0 & 255, h = cw >> 6, d = cw & 63;
       if (a.rot_cos) {
-        const float4 c = *reinterpret_cast<const float4*>(a.rot_cos + (size_t)row * 32 + (d >> 1));
-        const float4 sn = *reinterpret_cast<const float4*>(a.rot_sin + (size_t)row * 32 + (d >> 1));
-        const float cs[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float x0 = v[2 * i], x1 = v[2 * i + 1];
-          v[2 * i] = x0 * cs[i] - x1 * ss[i];
-          v[2 * i + 1] = x1 * cs[i] + x0 * ss[i];
-        }
+        const f32x4 c = *reinterpret_cast<const f32x4*>(a.rot_cos + (size_t)row * 32 + (d >> 1));
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(a.rot_sin + (size_t)row * 32 + (d >> 1));
+        rotate_pairs(v, c, sn);
       }
       uint16_t* o = reinterpret_cast<uint16_t*>(sel ? a.out2 : a.out) + (((size_t)s * a.H + h) * a.Np + n) * 64 + d;
       *reinterpret_cast<uint4*>(o) = pack8<P>(v);
@@ -459,6 +453,10 @@ static void gemm_small_launch_t(int K, const GemmArgs& a, hipStream_t st) {
 }
 
 void launch_gemm(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st) {
+  if (a.M >= a.gr_min && gemmr_applicable(K, trans, a)) {   // HBM-bound K = 256 linears: weights in registers, tokens streamed
+    launch_gemmr(prec, trans, a, st);
+    return;
+  }
   if (a.M % 256 == 0 && a.M >= a.g8_min && a.M > a.small_max) {       // large-M path: 8-wave, 3-stage LDS-DMA ring (kernels_gemm8.hip)
     launch_gemm8(prec, K, trans, a, st);
     return;

@@ -112,14 +112,22 @@ def test_matching_points_early_out():
     assert pm.MatchingPoints(np.zeros((259, 0), np.float32), np.zeros((259, 7), np.float32)) == (0, [])
 
 
+# which kernel the K = 256 projections of an 8-pair batch (6400 tokens) go through: the thresholds are lowered so that the
+# large-batch kernels are exercised at a size the oracle-free comparison below finishes quickly
+BIG_GEMMS = {"gemm8": {"AIRFE_GEMM8_MIN_M": "4096", "AIRFE_GEMMR_MIN_M": "1000000000"},
+             "gemmr": {"AIRFE_GEMM8_MIN_M": "4096", "AIRFE_GEMMR_MIN_M": "1024"}}
+
+
+@pytest.mark.parametrize("big", list(BIG_GEMMS))
 @pytest.mark.parametrize("env", FORMS, ids=["fused_block", "four_launches"])
-def test_large_batch_uses_gemm8_and_agrees_with_single_pair_path(env):
-    """8 pairs -> M = 16 x 400 = 6400 rows: with the gemm8 threshold lowered to 4096 the linears go through the 8-wave
-    LDS-DMA GEMM (kernels_gemm8.hip); a single pair (M = 896) goes through gemm_small_kernel.  Same K-order accumulation
-    => same matches, with the block form held fixed (it is what changes the rounding points)."""
+def test_large_batch_uses_gemm8_and_agrees_with_single_pair_path(env, big):
+    """8 pairs -> M = 16 x 400 = 6400 rows: the linears go through the 8-wave LDS-DMA GEMM (kernels_gemm8.hip) or, where it
+    applies (K = 256, no rotary), the register-resident streaming GEMM (kernels_gemmr.hip); a single pair (M = 896) goes
+    through gemm_small_kernel.  Same K-order accumulation => same matches, with the block form held fixed (it is what
+    changes the rounding points)."""
     import torch
     from airslam_amd import api
-    ctx, _, lg = context("lg", env=dict(env, AIRFE_GEMM8_MIN_M="4096"), max_batch=8)
+    ctx, _, lg = context("lg", env=dict(env, **BIG_GEMMS[big]), max_batch=8)
     B = 8
     pairs = [_pair(400 - 7 * i, 390 - 11 * i, 40 + i) for i in range(B)]
     f0 = torch.zeros((B, 400, 259)); f1 = torch.zeros((B, 400, 259))
