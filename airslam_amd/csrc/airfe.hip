@@ -160,8 +160,9 @@ struct airfe_ctx {
   char* pl_stage = nullptr;      // staging of airfe_assign_points_to_lines
   size_t pl_bytes = 0;
   bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
-  int gemm_small_max = 4096, gemm8_min = 16000, gemmr_min = 8192;   // GemmArgs::small_max / g8_min / gr_min (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M, AIRFE_GEMMR_MIN_M)
+  int gemm_small_max = 4096, gemm8_min = 16000, gemmr_min = 8192, gemmr_wgs = 256;   // GemmArgs::small_max / g8_min / gr_min / gr_wgs (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M, AIRFE_GEMMR_MIN_M, AIRFE_GEMMR_WGS)
   int block_min = 3200;          // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
+  bool qkv_pair = true;          // q|k and v of a layer in one streaming launch (AIRFE_QKV_PAIR=0: two launches)
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
 
@@ -673,7 +674,7 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
     GemmArgs g;
     g.X1 = c->aPa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cPb.w; g.bias = c->cPb.b;
     g.M = cells; g.N = 65; g.cb_total = c->cPb.cbt; g.epi = EPI_STORE_F32; g.out = c->logits; g.ldo = 72;
-    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min;
+    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
     { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 288)); launch_gemm(c->prec, 256, false, g, st); }
     { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * (260 + 256)); launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st); }
   }
@@ -681,7 +682,7 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
     GemmArgs g;
     g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b;
     g.M = cells; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
-    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min;
+    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
     { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024)); launch_gemm(c->prec, 256, false, g, st); }
     // F.normalize of the dense map is applied lazily: sample_desc_kernel normalises just the 4 taps each keypoint reads
     // (same operations, same bits) — a dense pass moved 8 MB/image to serve 400 x 4 cell reads.
@@ -720,9 +721,28 @@ void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1
   g.Wp = w.w; g.bias = w.b; g.M = M; g.N = w.N; g.cb_total = w.cbt;
   g.epi = epi; g.act = act; g.out = out; g.out2 = out2; g.ldo = ldo; g.x32 = x32;
   g.rot_cos = rc; g.rot_sin = rs; g.Np = c->Np; g.H = 4;
-  g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min;
+  g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
   ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * w.K * w.N, (double)M * (w.K + w.N) * 2 + (double)w.K * w.N * 2);
   launch_gemm(c->prec, w.K, trans, g, st);
+}
+
+// The attention inputs of one layer: head-major q|k (`qk`, rotary when rc != nullptr; q -> qout, k -> kout, or both roles in qout
+// for the cross block's shared projection) and transposed V (`v`).  One streaming launch where kernels_gemmr.hip applies (large
+// token counts), else the two linears separately — same arithmetic either way.
+void run_qkv(airfe_ctx* c, const LinW& qk, const LinW& v, int M, void* qout, void* kout, const float* rc, const float* rs, hipStream_t st) {
+  GemmArgs a, b;
+  a.X1 = c->xb; a.ld1 = 256; a.K1 = 256; a.Wp = qk.w; a.bias = qk.b; a.M = M; a.N = qk.N; a.cb_total = qk.cbt;
+  a.epi = EPI_HEADS; a.out = qout; a.out2 = kout; a.rot_cos = rc; a.rot_sin = rs; a.Np = c->Np; a.H = 4;
+  b.X1 = c->xb; b.ld1 = 256; b.K1 = 256; b.Wp = v.w; b.bias = v.b; b.M = M; b.N = v.N; b.cb_total = v.cbt;
+  b.epi = EPI_HEADS_T; b.out = c->vtb; b.Np = c->Np; b.H = 4;
+  a.gr_wgs = b.gr_wgs = c->gemmr_wgs;
+  if (c->qkv_pair && M >= c->gemmr_min && qk.K == 256 && v.K == 256 && gemmr_pair_applicable(a, b)) {
+    ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * 256.0 * (qk.N + v.N), (double)M * (256 + qk.N + v.N) * 2 + 256.0 * (qk.N + v.N) * 2);
+    launch_gemmr_pair(c->prec, a, b, st);
+    return;
+  }
+  run_linear(c, qk, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS, ACT_NONE, qout, 0, st, false, kout, nullptr, rc, rs);
+  run_linear(c, v, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
 }
 
 // out-proj + FFN + residual of one block as ONE kernel (kernels_lgblockf.hip); flops/bytes are the algorithmic ones
@@ -764,8 +784,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   const bool fused_block = c->fuse_lg_block == 1 || (c->fuse_lg_block < 0 && Mg >= c->block_min);
   for (const LgLayer& l : c->lg) {
     // ---- self block
-    run_linear(c, l.qk, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS, ACT_NONE, c->qb, 0, st, false, c->kb, nullptr, c->rot_cos, c->rot_sin);
-    run_linear(c, l.v, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
+    run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, c->rot_cos, c->rot_sin, st);
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
     if (fused_block) {
       lg_blockf(c, l.out, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
@@ -774,8 +793,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
       lg_ffn(c, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
     }
     // ---- cross block (one shared projection for q and k; the two sides swap roles)
-    run_linear(c, l.cqk, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS, ACT_NONE, c->qb, 0, st);
-    run_linear(c, l.cv, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
+    run_qkv(c, l.cqk, l.cv, Mg, c->qb, nullptr, nullptr, nullptr, st);
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
     if (fused_block) {
       lg_blockf(c, l.cout, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st);
@@ -810,8 +828,7 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   for (const SgLayer& l : c->sg) {
     const int cross = li & 1;      // names = ['self','cross'] * 9
     ++li;
-    run_linear(c, l.qk, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS, ACT_NONE, c->qb, 0, st, false, c->kb);
-    run_linear(c, l.v, c->xb, 256, 256, nullptr, 0, Mg, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
+    run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, nullptr, nullptr, st);
     {
       ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048);
       launch_attention(c->prec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, cross, 0.125f, st);
@@ -885,6 +902,8 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (getenv("AIRFE_SMALL_MAX_M")) c->gemm_small_max = atoi(getenv("AIRFE_SMALL_MAX_M"));
   if (getenv("AIRFE_GEMM8_MIN_M")) c->gemm8_min = atoi(getenv("AIRFE_GEMM8_MIN_M"));
   if (getenv("AIRFE_GEMMR_MIN_M")) c->gemmr_min = atoi(getenv("AIRFE_GEMMR_MIN_M"));
+  if (getenv("AIRFE_QKV_PAIR")) c->qkv_pair = atoi(getenv("AIRFE_QKV_PAIR")) != 0;
+  if (getenv("AIRFE_GEMMR_WGS")) c->gemmr_wgs = atoi(getenv("AIRFE_GEMMR_WGS"));
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
   c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -1283,7 +1302,7 @@ int airfe_debug_gemm(airfe_ctx* c, const float* x, int M, int K, const float* w,
     GemmArgs g;
     g.X1 = dx; g.ld1 = K; g.K1 = K; g.Wp = lw.w; g.bias = lw.b; g.M = Mp; g.N = N; g.cb_total = lw.cbt;
     g.epi = EPI_STORE_F32; g.act = relu ? ACT_RELU : ACT_NONE; g.out = dy; g.ldo = Np8;
-    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min;
+    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
     launch_gemm(prec, K, false, g, c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, "debug_gemm: kernel failed");
   }

@@ -37,6 +37,7 @@ struct GemmArgs {
   // (no LDS, one round trip), M >= g8_min and M % 256 == 0 -> gemm8_kernel (256x256 tiles want >= 60 row tiles), else gemm_kernel
   int small_max = 4096, g8_min = 16000;
   int gr_min = 8192;             // rows from which the K = 256 linears go to the streaming kernel (where it applies)
+  int gr_wgs = 256;              // its persistent workgroups (tests lower it so that a small batch wraps the DMA ring)
 };
 
 // out[M][N] = X[M][K] * W^T ; K in {128,256,512}; trans => EPI_HEADS_T (operand roles swapped)
@@ -46,6 +47,9 @@ void launch_gemm8(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st
 // K = 256, N in {256, 512}, no rotary: persistent streaming kernel with register-resident weights (kernels_gemmr.hip)
 bool gemmr_applicable(int K, bool trans, const GemmArgs& a);
 void launch_gemmr(int prec, bool trans, const GemmArgs& a, hipStream_t st);
+// head-major q|k linear `a` + transposed-V linear `b` over the same rows in one launch
+bool gemmr_pair_applicable(const GemmArgs& a, const GemmArgs& b);
+void launch_gemmr_pair(int prec, const GemmArgs& a, const GemmArgs& b, hipStream_t st);
 
 // ---- fused LightGlue post-attention block (kernels_lgblockf.hip): out-proj -> ffn.0 -> LayerNorm -> GELU -> ffn.3 -> residual;
 // weights straight from the packed slabs of the separate linears

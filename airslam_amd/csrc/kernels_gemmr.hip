@@ -6,8 +6,8 @@
 // per CU.  Here a persistent workgroup owns 256 output features for the whole launch: wave w holds its 32 features x 256 K as
 // 16 MFMA A-fragments (64 registers, loaded once), token tiles of 32 rows stream through an 8-slot LDS ring by LDS-DMA (seven
 // tiles = 112 KiB in flight per CU), and each tile costs one barrier, 16 ds_read_b128, 32 MFMAs and 2-4 stores per wave.
-// N = 512 (self q|k) runs as two feature groups; the two workgroups that read the same token tile sit on the same XCD
-// (blockIdx and blockIdx + 8) so the second read is an L2 hit.
+// N = 512 (self q|k) runs as two feature groups, and q|k + v of a layer as ONE launch of three (gemmr_pair_kernel); the
+// workgroups that read the same token tile sit on the same XCD (blockIdx, blockIdx + 8, ...) so the later reads are L2 hits.
 //
 // Nothing the compiler can see loads from global memory inside the tile loop (biases are preloaded into registers): a compiler-placed s_waitcnt would count only its own loads and drain the whole DMA ring.  The hand-placed
 // waits rely on loads retiring in order: "at most 2*(tiles still in flight behind the wanted one)" outstanding.
@@ -22,7 +22,6 @@ constexpr int GR_MT = 2;                          // 16-token MFMA tiles per str
 constexpr int GR_TT = 16 * GR_MT;                 // 32 tokens
 constexpr int GR_XBYTES = GR_TT * 512;            // [32][256] 2-byte = 16 KiB
 constexpr int GR_RBYTES = 2 * GR_TT * 128;        // cos | sin rows of the tile's tokens, [32][32] fp32 each = 8 KiB
-constexpr int GR_WGS = 256;
 
 template <int N>
 __device__ __forceinline__ void gr_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -35,18 +34,14 @@ __device__ __forceinline__ void gr_glds16(const void* gsrc, unsigned lds_off) {
                : "memory");
 }
 
+// One workgroup's whole launch: 256-feature slice `group` of linear `a`, token tiles first, first + per_group, ...
 template <class P, bool TRANS, bool ROT>
-__global__ __launch_bounds__(512, 1) void gemmr_kernel(GemmArgs a, int ntiles, int ngroups) {
+__device__ __forceinline__ void gemmr_body(const GemmArgs& a, char* smem, int group, int first, int per_group, int ntiles) {
   constexpr int GR_SLOT = GR_XBYTES + (ROT ? GR_RBYTES : 0);
   constexpr int GR_SLOTS = ROT ? 6 : 8;
   constexpr int PER = ROT ? 3 : 2;                                    // DMA instructions per wave and tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int w = blockIdx.x;
-  const int group = (w >> 3) % ngroups;                               // 256-feature slice of the output
-  const int first = (w & 7) + 8 * (w / (8 * ngroups));                // first tile; the workgroups of a group stride by per_group
-  const int per_group = GR_WGS / ngroups;
   const int n = first < ntiles ? (ntiles - first + per_group - 1) / per_group : 0;
   if (n == 0) return;
 
@@ -96,7 +91,7 @@ __global__ __launch_bounds__(512, 1) void gemmr_kernel(GemmArgs a, int ntiles, i
 
   const int boff0 = l15 * 512;
   for (int i = 0; i < n; ++i) {
-    const int t = first + i * per_group, slot = i & (GR_SLOTS - 1);
+    const int t = first + i * per_group, slot = i % GR_SLOTS;          // (six slots with rotary: not a power of two)
     const char* xs = smem + slot * GR_SLOT + boff0;
     f32x4 acc[2][GR_MT];
 #pragma unroll
@@ -171,6 +166,41 @@ __global__ __launch_bounds__(512, 1) void gemmr_kernel(GemmArgs a, int ntiles, i
   }
 }
 
+// Workgroup w -> (feature group, first tile): the groups that read the same token tile are w, w + 8, ... = the same XCD, so the
+// tile comes from HBM once and from that XCD's L2 afterwards.
+template <class P, bool TRANS, bool ROT>
+__global__ __launch_bounds__(512, 1) void gemmr_kernel(GemmArgs a, int ntiles, int ngroups) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int w = blockIdx.x;
+  gemmr_body<P, TRANS, ROT>(a, smem, (w >> 3) % ngroups, (w & 7) + 8 * (w / (8 * ngroups)), gridDim.x / ngroups, ntiles);
+}
+
+// q|k (or the cross block's shared qk) and v of one attention layer in ONE launch: the first ng_a feature groups belong to linear
+// `a` (head-major rows, rotary when ROT), the last one to linear `b` (V, stored transposed) — the token tiles are read from HBM once
+// for all of them and a launch is saved per layer.
+template <class P, bool ROT>
+__global__ __launch_bounds__(512, 1) void gemmr_pair_kernel(GemmArgs a, GemmArgs b, int ntiles, int ng_a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ngroups = ng_a + 1, w = blockIdx.x;
+  const int group = (w >> 3) % ngroups, first = (w & 7) + 8 * (w / (8 * ngroups)), per_group = gridDim.x / ngroups;
+  if (group < ng_a) gemmr_body<P, false, ROT>(a, smem, group, first, per_group, ntiles);
+  else gemmr_body<P, true, false>(b, smem, 0, first, per_group, ntiles);
+}
+
+template <class P, bool ROT>
+static void gemmr_pair_launch_t(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+  constexpr int LDS = ROT ? 6 * (GR_XBYTES + GR_RBYTES) : 8 * GR_XBYTES;
+  static bool attr_done = false;
+  auto kfn = gemmr_pair_kernel<P, ROT>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  const int ng_a = a.cb_total / 4, ngroups = ng_a + 1;
+  const int nwg = std::max(a.gr_wgs / (8 * ngroups), 1) * (8 * ngroups);   // 256 for two groups, 240 for three
+  hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(512), LDS, st, a, b, a.M / GR_TT, ng_a);
+}
+
 template <class P, bool TRANS, bool ROT>
 static void gemmr_launch_t(const GemmArgs& a, hipStream_t st) {
   constexpr int LDS = ROT ? 6 * (GR_XBYTES + GR_RBYTES) : 8 * GR_XBYTES;
@@ -180,13 +210,28 @@ static void gemmr_launch_t(const GemmArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kfn, dim3(GR_WGS), dim3(512), LDS, st, a, a.M / GR_TT, a.cb_total / 4);
+  const int ngroups = a.cb_total / 4;
+  const int nwg = std::max(a.gr_wgs / (8 * ngroups), 1) * (8 * ngroups);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(512), LDS, st, a, a.M / GR_TT, ngroups);
 }
 
 bool gemmr_applicable(int K, bool trans, const GemmArgs& a) {
   const int ng = a.cb_total / 4;
   return K == 256 && !a.X2 && (!a.rot_cos || (!trans && a.epi == EPI_HEADS)) && a.act == ACT_NONE && a.cb_total % 4 == 0 && (ng == 1 || ng == 2) && a.N == a.cb_total * 64 &&
          a.M % GR_TT == 0 && (trans ? a.epi == EPI_HEADS_T : (a.epi == EPI_HEADS || (a.epi == EPI_STORE && a.ldo >= a.N)));
+}
+
+bool gemmr_pair_applicable(const GemmArgs& a, const GemmArgs& b) {
+  return gemmr_applicable(256, false, a) && gemmr_applicable(256, true, b) && a.epi == EPI_HEADS && b.cb_total == 4 && a.X1 == b.X1 &&
+         a.ld1 == b.ld1 && a.M == b.M;
+}
+
+void launch_gemmr_pair(int prec, const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+  if (prec == 1) {
+    if (a.rot_cos) gemmr_pair_launch_t<PF16, true>(a, b, st); else gemmr_pair_launch_t<PF16, false>(a, b, st);
+  } else {
+    if (a.rot_cos) gemmr_pair_launch_t<PBF16, true>(a, b, st); else gemmr_pair_launch_t<PBF16, false>(a, b, st);
+  }
 }
 
 void launch_gemmr(int prec, bool trans, const GemmArgs& a, hipStream_t st) {

@@ -114,8 +114,12 @@ def test_matching_points_early_out():
 
 # which kernel the K = 256 projections of an 8-pair batch (6400 tokens) go through: the thresholds are lowered so that the
 # large-batch kernels are exercised at a size the oracle-free comparison below finishes quickly
+# (gemmr with 24 persistent workgroups instead of 256: 200 token tiles / 8 per feature group = 25 tiles per workgroup, so the
+# 6- and 8-slot DMA rings wrap several times, as they do at 64 pairs on 256 workgroups)
 BIG_GEMMS = {"gemm8": {"AIRFE_GEMM8_MIN_M": "4096", "AIRFE_GEMMR_MIN_M": "1000000000"},
-             "gemmr": {"AIRFE_GEMM8_MIN_M": "4096", "AIRFE_GEMMR_MIN_M": "1024"}}
+             "gemmr": {"AIRFE_GEMM8_MIN_M": "4096", "AIRFE_GEMMR_MIN_M": "1024"},
+             "gemmr_ring_wrap": {"AIRFE_GEMM8_MIN_M": "4096", "AIRFE_GEMMR_MIN_M": "1024", "AIRFE_GEMMR_WGS": "24"},
+             "gemmr_two_launches": {"AIRFE_GEMM8_MIN_M": "4096", "AIRFE_GEMMR_MIN_M": "1024", "AIRFE_GEMMR_WGS": "24", "AIRFE_QKV_PAIR": "0"}}
 
 
 @pytest.mark.parametrize("big", list(BIG_GEMMS))
