@@ -52,3 +52,40 @@ def test_stereo_is_deterministic():
         outs.append((fl.cpu().numpy(), idx.cpu().numpy(), nm.cpu().numpy()))
     for a, b in zip(outs[0], outs[1]):
         np.testing.assert_array_equal(a, b)
+
+
+def test_full_bench_batch_repeats_its_distinct_pairs():
+    """BASELINE workload size (64 stereo pairs per call, the bench's context shape) through a size-independent property: the
+    batch is 4 distinct pairs repeated 16 times, so every copy must reproduce its original bit for bit, and both must equal a
+    4-pair call on a small context — which goes through the small-batch kernels (gemm_small instead of the streaming gemmr
+    rings that wrap 13 times here, 2-image encoder chunks instead of 32)."""
+    import torch
+    big, _, _ = context("splg", max_batch=128, enc_chunk=32)
+    small, _, _ = context("splg", max_batch=8, enc_chunk=2)
+    ls4, rs4 = synth.stereo_batch(4, 480, 752, 77)
+
+    def run(ctx, ls, rs):
+        B = ls.shape[0]
+        L, R = torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda()
+        fl = torch.zeros((B, 400, 259), device="cuda"); fr = torch.zeros((B, 400, 259), device="cuda")
+        nl = torch.zeros((B,), dtype=torch.int32, device="cuda"); nr = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        idx = torch.zeros((B, 400, 2), dtype=torch.int32, device="cuda")
+        sc = torch.zeros((B, 400), device="cuda"); nm = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        ctx.stereo_batch_dev(L, R, fl, fr, nl, nr, idx, sc, nm)
+        ctx.sync()
+        return [t.cpu().numpy() for t in (fl, fr, nl, nr, idx, sc, nm)]
+
+    ref = run(small, ls4, rs4)
+    out = run(big, np.tile(ls4, (16, 1, 1)), np.tile(rs4, (16, 1, 1)))
+    diag("stereo_full_batch", keypoints=str(ref[2].tolist()), matches=str(ref[6].tolist()))
+    assert ref[2].min() > 100                       # the synthetic pairs do produce keypoints
+    for i in range(64):
+        j = i % 4
+        for k in (0, 1):                            # feature matrices (score, x, y, 256-d descriptor) of both images
+            n = int(ref[2 + k][j])
+            assert int(out[2 + k][i]) == n
+            np.testing.assert_array_equal(out[k][i, :n], ref[k][j, :n])
+        m = int(ref[6][j])
+        assert int(out[6][i]) == m
+        np.testing.assert_array_equal(out[4][i, :m], ref[4][j, :m])
+        np.testing.assert_array_equal(out[5][i, :m], ref[5][j, :m])
