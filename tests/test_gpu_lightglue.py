@@ -204,3 +204,38 @@ def test_lightglue_at_the_profile_maximum(n0, n1):
     np.testing.assert_allclose(sc, dsc, rtol=2e-6)
     assert err.max() <= 0.05 * max(1.0, np.abs(ref).mean())
     ctx.close()
+
+
+def test_bench_size_matcher_batch_repeats_its_distinct_pairs():
+    """64 pairs per call (the bench workload: 51200 tokens, the gemmr rings wrap 13 times, 400 block tiles on 256 CUs) = 4 distinct
+    planted pairs x 16: every copy must equal its original, and both must equal the 4-pair call of a small context, bit for bit."""
+    import torch
+    big, _, _ = context("lg", max_batch=128)
+    small, _, _ = context("lg", max_batch=8)
+    pairs = [_pair(400 - 9 * i, 397 - 13 * i, 300 + 7 * i) for i in range(4)]
+
+    def run(ctx, reps):
+        B = 4 * reps
+        f0 = torch.zeros((B, 400, 259)); f1 = torch.zeros((B, 400, 259))
+        n0 = torch.zeros((B,), dtype=torch.int32); n1 = torch.zeros((B,), dtype=torch.int32)
+        for i in range(B):
+            a, b, _, _ = pairs[i % 4]
+            f0[i, :a.shape[0]] = torch.from_numpy(a); f1[i, :b.shape[0]] = torch.from_numpy(b)
+            n0[i] = a.shape[0]; n1[i] = b.shape[0]
+        f0, f1, n0, n1 = f0.cuda(), f1.cuda(), n0.cuda(), n1.cuda()
+        idx = torch.zeros((B, 400, 2), dtype=torch.int32, device="cuda")
+        sc = torch.zeros((B, 400), dtype=torch.float32, device="cuda")
+        nm = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        ctx.match_lightglue_batch_dev(f0, n0, f1, n1, idx, sc, nm)
+        ctx.sync()
+        return idx.cpu().numpy(), sc.cpu().numpy(), nm.cpu().numpy()
+
+    ridx, rsc, rnm = run(small, 1)
+    oidx, osc, onm = run(big, 16)
+    diag("lg_bench_size_repeats", matches=str(rnm.tolist()))
+    assert rnm.sum() >= 4                           # the planted correspondences do produce matches
+    for i in range(64):
+        j, m = i % 4, int(rnm[i % 4])
+        assert int(onm[i]) == m
+        np.testing.assert_array_equal(oidx[i, :m], ridx[j, :m])
+        np.testing.assert_array_equal(osc[i, :m], rsc[j, :m])
