@@ -102,11 +102,17 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint16_t* __res
   const int r0 = c0 >> 3, r1 = c1 >> 3, cc0 = c0 & 7, cc1 = c1 & 7;
   const int d0 = r0 * 128 + ((cc0 ^ swz128(r0)) << 4), d1 = r1 * 128 + ((cc1 ^ swz128(r1)) << 4);
   uint4 pk0, pk1, pv0, pv1;
-  auto load_tile = [&](int kt) {
-    pk0 = *reinterpret_cast<const uint4*>(Kh + ((size_t)kt * 64 + r0) * 64 + cc0 * 8);
-    pk1 = *reinterpret_cast<const uint4*>(Kh + ((size_t)kt * 64 + r1) * 64 + cc1 * 8);
-    pv0 = *reinterpret_cast<const uint4*>(Vh + (size_t)r0 * Np + kt * 64 + cc0 * 8);
-    pv1 = *reinterpret_cast<const uint4*>(Vh + (size_t)r1 * Np + kt * 64 + cc1 * 8);
+  // running source pointers (one 64-bit add per load and tile instead of re-deriving every address: the kernel is issue-bound)
+  const uint16_t* kp0 = Kh + (size_t)r0 * 64 + cc0 * 8;
+  const uint16_t* kp1 = Kh + (size_t)r1 * 64 + cc1 * 8;
+  const uint16_t* vp0 = Vh + (size_t)r0 * Np + cc0 * 8;
+  const uint16_t* vp1 = Vh + (size_t)r1 * Np + cc1 * 8;
+  auto load_tile = [&](int) {
+    pk0 = *reinterpret_cast<const uint4*>(kp0);
+    pk1 = *reinterpret_cast<const uint4*>(kp1);
+    pv0 = *reinterpret_cast<const uint4*>(vp0);
+    pv1 = *reinterpret_cast<const uint4*>(vp1);
+    kp0 += 64 * 64; kp1 += 64 * 64; vp0 += 64; vp1 += 64;
   };
   auto write_tile = [&](int buf) {
     char* kb = smem + buf * 16384;
@@ -149,11 +155,13 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint16_t* __res
       // PMCs: 21 VALU instructions per MFMA with the straightforward softmax.  Trimmed: key masking only on the tail
       // tile, raw v_exp_f32 (arguments are <= 0, no denormal fix-up needed), log2e * scale folded into one FMA.
       if (tail) {
+        int left = len_kv - kt * 64;                 // opaque to the optimiser: otherwise the 16 compares are hoisted out of this
+        asm volatile("" : "+s"(left));              // branch and issued for every tile
 #pragma unroll
         for (int kti = 0; kti < 4; ++kti)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (kt * 64 + kti * 16 + g * 4 + r >= len_kv) st[qt][kti][r] = -INFINITY;
+            if (kti * 16 + g * 4 + r >= left) st[qt][kti][r] = -INFINITY;
       }
       float mx = -INFINITY;
 #pragma unroll
@@ -165,16 +173,15 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint16_t* __res
       const float m_new = fmaxf(m_i[qt], mx);
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = __builtin_amdgcn_exp2f(m_i[qt] - m_safe);
-      float ps = 0.f;
+      f32x4 psv = {0.f, 0.f, 0.f, 0.f};              // four partial sums: the fma and the add work on float pairs (v_pk_*)
 #pragma unroll
-      for (int kti = 0; kti < 4; ++kti)
+      for (int kti = 0; kti < 4; ++kti) {
+        const f32x4 e = st[qt][kti] * scale_log2e - m_safe;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(st[qt][kti][r], scale_log2e, -m_safe));
-          st[qt][kti][r] = p;
-          ps += p;
-        }
-      l_i[qt] = l_i[qt] * alpha + ps;
+        for (int r = 0; r < 4; ++r) st[qt][kti][r] = __builtin_amdgcn_exp2f(e[r]);
+        psv += st[qt][kti];
+      }
+      l_i[qt] = l_i[qt] * alpha + ((psv[0] + psv[1]) + (psv[2] + psv[3]));
       m_i[qt] = m_new;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o[qt][dt] *= alpha;
