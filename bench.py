@@ -150,11 +150,11 @@ def main():
         if dom:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
             traffic, tsrc = None, None
-            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01c_hbm_traffic.json")
+            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_hbm_traffic.json")
             if os.path.exists(tf):      # measured in separate --pmc passes (never together with other tracing), see profiles/README.md
                 with open(tf) as fh:
                     traffic = json.load(fh).get("conv3x3_cin64_stage", {}).get("hbm_bytes_per_launch")
-                tsrc = "profiles/r01c_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+                tsrc = "profiles/r01e_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
             out["roofline"] = {"bound": "mfma", "kernel": "conv64r_kernel (conv1a fused into conv1b + pool, conv2a, conv2b + pool, conv3a)",
                                "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
                                "traffic": traffic, "traffic_source": tsrc,
