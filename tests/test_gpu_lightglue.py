@@ -239,3 +239,24 @@ def test_bench_size_matcher_batch_repeats_its_distinct_pairs():
         assert int(onm[i]) == m
         np.testing.assert_array_equal(oidx[i, :m], ridx[j, :m])
         np.testing.assert_array_equal(osc[i, :m], rsc[j, :m])
+
+
+@pytest.mark.parametrize("env", [{"AIRFE_FUSE_LG_BLOCK": "1", "AIRFE_GEMMR_MIN_M": "512"}, {"AIRFE_FUSE_LG_BLOCK": "0"}],
+                         ids=["fused_block_gemmr", "four_launches"])
+def test_lightglue_fp16_storage(env):
+    """precision = 1 (fp16 operands, fp32 accumulate) through the same kernels: the PF16 instantiations of lg_blockf_kernel,
+    gemmr_kernel / gemmr_pair_kernel and gemm_small_kernel.  fp16 keeps 3 more mantissa bits than bf16, so the scores must sit
+    closer to the fp32 oracle than the bf16 bound of the tests above."""
+    ctx, _, lg = context("lg", env=env, max_batch=4, precision=1)
+    _, _, a, b = _pair(400, 371, 4242)
+    s = ctx.lightglue_scores(a, b)
+    ref = ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
+    err = np.abs(s - ref)
+    idx, sc = ctx.match_lightglue(a, b)
+    didx, dsc = ref_post.filter_matches(s, 0.1)
+    diag(f"lg_fp16_{'fused' if env['AIRFE_FUSE_LG_BLOCK'] == '1' else 'split'}", max_err=err.max(), mean_err=err.mean(),
+         ref_absmax=np.abs(ref).max(), n_dev=len(idx))
+    assert not np.isnan(s).any()
+    np.testing.assert_array_equal(idx, didx)
+    np.testing.assert_allclose(sc, dsc, rtol=2e-6)
+    assert err.max() <= 0.02 * max(1.0, np.abs(ref).mean()), "fp16 scores drifted from the fp32 oracle"
