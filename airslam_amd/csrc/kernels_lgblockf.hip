@@ -18,7 +18,7 @@
 //
 // What the per-phase timers said (round 1, 128-token pass, us): attn 3.0 | out-proj 3.9 | ffn.0 5.1 + 1.6 + 4.0 | LN sums 2.9
 // | GELU 10.3 | ffn.3 4.7 | epilogue 2.6.  Removing the LDS reads changes nothing, removing the weight loads 10 %: the GEMMs
-// sit at the ~80 % two-waves-per-SIMD MFMA ceiling; the GELU phase is VALU-bound (see lf_gelu2).
+// run at 75-80 % of the MFMA rate (a pure MFMA stream: 85 % with two waves per SIMD); the GELU phase is VALU-bound (see lf_gelu2).
 #include "common.h"
 #include "kernels.h"
 

@@ -1,3 +1,5 @@
+// SUPERSEDED by mfma_shape.hip: this probe times the FIRST launch of each configuration (module load included), which made one
+// wave per SIMD look like 1.22 PFLOP/s; warmed up it is 1.94.
 // MFMA issue-rate probe for gfx950: NACC independent v_mfma_f32_16x16x32_bf16 accumulators per wave, back to back.
 //   hipcc --offload-arch=gfx950 -O3 tools/microbench/mfma_rate.hip -o /tmp/mfma_rate && /tmp/mfma_rate
 #include <hip/hip_runtime.h>
