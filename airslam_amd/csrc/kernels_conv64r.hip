@@ -10,6 +10,12 @@
 //     10 ds_read_b128 per 48 MFMAs -> 240 KiB of LDS reads per tile (2.4x less), the kernel becomes MFMA-bound;
 //   * LDS now only holds the double-buffered halo tile (2 x 40.5 KiB), filled one tile ahead by LDS-DMA.
 #include "common.h"
+#ifdef C64R_TIMING
+__device__ long long c64_dbg[256 * 8 * 6];
+#define C64R_T(x) { const long long now_ = wall_clock64(); x += now_ - tp_; tp_ = now_; }
+#else
+#define C64R_T(x)
+#endif
 #include "kernels.h"
 
 namespace airfe {
@@ -238,6 +244,9 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
   }
 
   int pb3 = 0, pb1 = 1;                                // i % 3 and (i + 1) % 3
+#ifdef C64R_TIMING
+  long long t_top = 0, t_mma = 0, t_wait = 0, t_bar = 0, t_epi = 0, tp_ = wall_clock64();
+#endif
   for (int i = 0; tile < ntiles; ++i, tile += gridDim.x) {
     const int next = tile + gridDim.x;
     if constexpr (FUSE1A) {
@@ -289,6 +298,7 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
       load_combo(0, 0);
       if (SCHED) __builtin_amdgcn_sched_group_barrier(0x100, RW + 2, 0);
     }
+    C64R_T(t_top)
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       if constexpr (PIN) {
@@ -328,13 +338,16 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
 
     // wait for the next tile's LDS-DMA BEFORE this tile's stores are issued (vmcnt counts stores too), then one barrier:
     // "next tile complete" and "the buffer just read is free"
+    C64R_T(t_mma)
     if constexpr (FUSE1A) {
       // only patch(i+2) has to be down: the youngest vector-memory operation of every wave, patch(i+3), may stay in flight
       // (raw s_barrier: __syncthreads() would add its own vmcnt(0) for the output stores)
       constexpr int NPP = (C64R_PATCH + NT - 1) / NT;
       if (tile + 3 * (int)gridDim.x < ntiles) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPP) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // tail: nothing younger was issued
+      C64R_T(t_wait)
       __builtin_amdgcn_s_barrier();
+      C64R_T(t_bar)
       pb3 = pb3 == 2 ? 0 : pb3 + 1;
       pb1 = pb1 == 2 ? 0 : pb1 + 1;
     } else {
@@ -375,8 +388,21 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
         *reinterpret_cast<uint4*>(ybase + (size_t)(y + opad) * orow + (size_t)(x + opad) * COUT) = r;
       }
     }
+    C64R_T(t_epi)
   }
+#ifdef C64R_TIMING
+  if (lane == 0 && FUSE1A) {
+    long long* o = c64_dbg + (blockIdx.x * 8 + wave) * 6;
+    o[0] = t_top; o[1] = t_mma; o[2] = t_wait; o[3] = t_bar; o[4] = t_epi;
+  }
+#endif
 }
+
+#ifdef C64R_TIMING
+}  // namespace airfe
+extern "C" int airfe_dbg_c64(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c64_dbg), sizeof(long long) * 256 * 8 * 6); }
+namespace airfe {
+#endif
 
 template <class P, bool POOL, bool FUSE1A>
 static void conv64r_launch_t(const ConvArgs& a, hipStream_t st) {
