@@ -43,6 +43,8 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p]),
     "airfe_assign_points_to_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_int, C.c_void_p]),
+    "airfe_match_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_int, C.c_void_p]),
     "airfe_detect_points_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "airfe_match_lightglue_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

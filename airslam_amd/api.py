@@ -184,6 +184,27 @@ class Context:
                   "airfe_assign_points_to_lines")
         return [dict(zip(idx[row_ptr[i]:row_ptr[i + 1]].tolist(), dist[row_ptr[i]:row_ptr[i + 1]].tolist())) for i in range(L)]
 
+    @staticmethod
+    def _relation_csr(relation):
+        row_ptr = np.zeros((len(relation) + 1,), np.int32)
+        for i, rel in enumerate(relation):
+            row_ptr[i + 1] = row_ptr[i] + len(rel)
+        idx = np.array([k for rel in relation for k in sorted(rel)], np.int32).reshape(-1)
+        return row_ptr, np.ascontiguousarray(idx)
+
+    def match_lines(self, points_on_line0, points_on_line1, point_matches, point_num0: int, point_num1: int):
+        """MatchLines (src/line_processor.cc:122-172).  points_on_line{0,1}: the relations returned by assign_points_to_lines;
+        point_matches: [(queryIdx, trainIdx), ...] -> list of len(points_on_line0) matched line indices of frame 1 (-1: none)."""
+        rp0, pi0 = self._relation_csr(points_on_line0)
+        rp1, pi1 = self._relation_csr(points_on_line1)
+        m = np.ascontiguousarray(np.array([(int(a), int(b)) for a, b in point_matches], np.int32).reshape(-1, 2))
+        out = np.full((max(len(points_on_line0), 1),), -1, np.int32)
+        self._chk(self._l.airfe_match_lines(self._h, rp0.ctypes.data, pi0.ctypes.data if pi0.size else None, len(points_on_line0),
+                                            int(point_num0), rp1.ctypes.data, pi1.ctypes.data if pi1.size else None,
+                                            len(points_on_line1), int(point_num1), m.ctypes.data if m.size else None, m.shape[0],
+                                            out.ctypes.data), "airfe_match_lines")
+        return out[:len(points_on_line0)].tolist()
+
     def superglue_scores(self, f0: np.ndarray, f1: np.ndarray) -> np.ndarray:
         f0 = np.ascontiguousarray(f0, dtype=np.float32)
         f1 = np.ascontiguousarray(f1, dtype=np.float32)

@@ -1114,6 +1114,53 @@ int airfe_assign_points_to_lines(airfe_ctx* c, const double* lines, int L, const
   return 0;
 }
 
+int airfe_match_lines(airfe_ctx* c, const int32_t* row_ptr0, const int32_t* pt_idx0, int L0, int point_num0, const int32_t* row_ptr1,
+                      const int32_t* pt_idx1, int L1, int point_num1, const int32_t* matches, int M, int32_t* line_matches) {
+  if (!c) return 1;
+  if (L0 < 0 || L1 < 0 || M < 0 || point_num0 < 0 || point_num1 < 0 || (L0 > 0 && !line_matches)) return fail(c, "match_lines: bad argument");
+  for (int i = 0; i < L0; ++i) line_matches[i] = -1;                                  // line_processor.cc:127-131
+  if (point_num0 == 0 || point_num1 == 0 || L0 == 0 || L1 == 0) return 0;            // :132
+  if (!row_ptr0 || !row_ptr1 || (M > 0 && !matches)) return fail(c, "match_lines: null input");
+  const int t0 = row_ptr0[L0], t1 = row_ptr1[L1];
+  if (t0 < 0 || t1 < 0 || (t0 > 0 && !pt_idx0) || (t1 > 0 && !pt_idx1)) return fail(c, "match_lines: bad relation");
+  for (int m = 0; m < M; ++m)                                                         // the reference indexes vectors with these
+    if (matches[2 * m] < 0 || matches[2 * m] >= point_num0 || matches[2 * m + 1] < 0 || matches[2 * m + 1] >= point_num1)
+      return fail(c, "match_lines: point match index out of range");
+  const int W = std::max((M + 31) / 32, 1);
+  const size_t words = (size_t)(L0 + 1) + (L1 + 1) + std::max(t0, 1) + std::max(t1, 1) + (size_t)std::max(M, 1) * 2 + (size_t)(L0 + L1) * W +
+                       (size_t)L0 * L1 + 2 * (size_t)L0;
+  const size_t need = words * 4 + 64;
+  if (need > c->pl_bytes) {
+    void* p = nullptr;
+    HIPCHK(c, hipMalloc(&p, need));
+    c->allocs.push_back(p);
+    c->pl_stage = reinterpret_cast<char*>(p);
+    c->pl_bytes = need;
+  }
+  int* q = reinterpret_cast<int*>(c->pl_stage);
+  int* d_rp0 = q; q += L0 + 1;
+  int* d_rp1 = q; q += L1 + 1;
+  int* d_pi0 = q; q += std::max(t0, 1);
+  int* d_pi1 = q; q += std::max(t1, 1);
+  int* d_m = q; q += (size_t)std::max(M, 1) * 2;
+  unsigned* d_b0 = reinterpret_cast<unsigned*>(q); q += (size_t)L0 * W;
+  unsigned* d_b1 = reinterpret_cast<unsigned*>(q); q += (size_t)L1 * W;
+  int* d_vote = q; q += (size_t)L0 * L1;
+  int* d_rloc = q; q += L0;
+  int* d_lm = q;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(d_rp0, row_ptr0, (size_t)(L0 + 1) * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_rp1, row_ptr1, (size_t)(L1 + 1) * 4, hipMemcpyHostToDevice, st));
+  if (t0 > 0) HIPCHK(c, hipMemcpyAsync(d_pi0, pt_idx0, (size_t)t0 * 4, hipMemcpyHostToDevice, st));
+  if (t1 > 0) HIPCHK(c, hipMemcpyAsync(d_pi1, pt_idx1, (size_t)t1 * 4, hipMemcpyHostToDevice, st));
+  if (M > 0) HIPCHK(c, hipMemcpyAsync(d_m, matches, (size_t)M * 8, hipMemcpyHostToDevice, st));
+  launch_match_lines(d_rp0, d_pi0, L0, d_rp1, d_pi1, L1, d_m, M, d_b0, d_b1, d_vote, d_rloc, d_lm, st);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(line_matches, d_lm, (size_t)L0 * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return 0;
+}
+
 int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, const airfe_plnet_stage0* s0, float* feat,
                        int cap, int* n, double* lines, int capL, int* nlines, float* junc, int capJ, int* njunc,
                        int want_junctions) {

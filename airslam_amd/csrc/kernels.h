@@ -174,5 +174,9 @@ void launch_sg_decode(const float* Z, const int* lens, int B, int Np, int Lz, fl
 //      (point index ascending, distance) per line; counts [L] is scratch
 void launch_assign_points_to_lines(const double* lines, int L, const float* feat, int N, int* counts, int* row_ptr, int* pt_idx,
                                    double* pt_dist, int cap, hipStream_t st);
+// MatchLines (src/line_processor.cc:122-172) on two CSR point-line relations and the point matches; scratch: bits [L][ceil(M/32)],
+// vote [L0][L1], row_loc [L0]
+void launch_match_lines(const int* row_ptr0, const int* pt_idx0, int L0, const int* row_ptr1, const int* pt_idx1, int L1, const int* matches,
+                        int nmatch, unsigned* bits0, unsigned* bits1, int* vote, int* row_loc, int* line_matches, hipStream_t st);
 
 }  // namespace airfe

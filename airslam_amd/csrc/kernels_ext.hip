@@ -589,4 +589,86 @@ void launch_assign_points_to_lines(const double* lines, int L, const float* feat
   hipLaunchKernelGGL(pl_assign_kernel<true>, grid, dim3(256), 0, st, lines, L, feat, N, counts, row_ptr, pt_idx, pt_dist, cap);
 }
 
+// =============================================================================== MatchLines (src/line_processor.cc:122-172)
+// The voting matrix M[l0][l1] = number of point matches (q, t) with q on line l0 of frame 0 and t on line l1 of frame 1 is an
+// integer "GEMM" over the matches: one bit per (line, match) says whether the match's point lies on the line, and M is the
+// popcount of the AND of two bit rows.  All index work: exact.
+__global__ __launch_bounds__(256) void ml_bits_kernel(const int* __restrict__ row_ptr, const int* __restrict__ pt_idx, const int* __restrict__ matches,
+                                                      int side, int nmatch, int W, unsigned* __restrict__ bits) {
+  const int l = blockIdx.x, b = row_ptr[l], e = row_ptr[l + 1];
+  for (int w = threadIdx.x; w < W; w += blockDim.x) {
+    unsigned word = 0;
+    for (int k = 0; k < 32; ++k) {
+      const int m = w * 32 + k;
+      if (m >= nmatch) break;
+      const int p = matches[2 * m + side];
+      for (int r = b; r < e; ++r)
+        if (pt_idx[r] == p) { word |= 1u << k; break; }        // a std::map key occurs once per line
+    }
+    bits[(size_t)l * W + w] = word;
+  }
+}
+
+// first maximum (value, index) over a block: larger value wins, ties go to the smaller index (Eigen maxCoeff visits in order and
+// replaces on strict >)
+__device__ __forceinline__ void ml_first_max(int& v, int& i, int* sv, int* si) {
+  const int t = threadIdx.x;
+  sv[t] = v; si[t] = i;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if (t < o) {
+      const int v2 = sv[t + o], i2 = si[t + o];
+      if (v2 > sv[t] || (v2 == sv[t] && i2 < si[t])) { sv[t] = v2; si[t] = i2; }
+    }
+    __syncthreads();
+  }
+  v = sv[0]; i = si[0];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void ml_vote_rowmax_kernel(const unsigned* __restrict__ bits0, const unsigned* __restrict__ bits1, int L1, int W,
+                                                             int* __restrict__ vote, int* __restrict__ row_loc, int* __restrict__ line_matches) {
+  __shared__ int sv[256], si[256];
+  const int l0 = blockIdx.x;
+  const unsigned* r0 = bits0 + (size_t)l0 * W;
+  int bv = -1, bi = 0x7fffffff;
+  for (int l1 = threadIdx.x; l1 < L1; l1 += blockDim.x) {
+    const unsigned* r1 = bits1 + (size_t)l1 * W;
+    int v = 0;
+    for (int w = 0; w < W; ++w) v += __popc(r0[w] & r1[w]);
+    vote[(size_t)l0 * L1 + l1] = v;
+    if (v > bv) { bv = v; bi = l1; }                             // l1 ascends within a thread: strict > keeps the first
+  }
+  ml_first_max(bv, bi, sv, si);
+  if (threadIdx.x == 0) { row_loc[l0] = bi; line_matches[l0] = -1; }
+}
+
+__global__ __launch_bounds__(256) void ml_colmax_kernel(const int* __restrict__ vote, const int* __restrict__ row_loc, const int* __restrict__ row_ptr0,
+                                                        const int* __restrict__ row_ptr1, int L0, int L1, int* __restrict__ line_matches) {
+  __shared__ int sv[256], si[256];
+  const int j = blockIdx.x;
+  int bv = -1, bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < L0; i += blockDim.x) {
+    const int v = vote[(size_t)i * L1 + j];
+    if (v > bv) { bv = v; bi = i; }
+  }
+  ml_first_max(bv, bi, sv, si);
+  if (threadIdx.x == 0) {
+    if (bv < 2 || row_loc[bi] != j) return;                      // :171
+    const int n0 = row_ptr0[bi + 1] - row_ptr0[bi], n1 = row_ptr1[j + 1] - row_ptr1[j];
+    const float score = __fdiv_rn((float)(bv * bv), (float)min(n0, n1));        // :174 float / size_t -> float division
+    if ((double)score < 0.8) return;                             // :175
+    line_matches[bi] = j;                                        // distinct j cannot name the same row: row_loc[bi] == j
+  }
+}
+
+void launch_match_lines(const int* row_ptr0, const int* pt_idx0, int L0, const int* row_ptr1, const int* pt_idx1, int L1, const int* matches,
+                        int nmatch, unsigned* bits0, unsigned* bits1, int* vote, int* row_loc, int* line_matches, hipStream_t st) {
+  const int W = (nmatch + 31) / 32 > 0 ? (nmatch + 31) / 32 : 1;
+  hipLaunchKernelGGL(ml_bits_kernel, dim3(L0), dim3(256), 0, st, row_ptr0, pt_idx0, matches, 0, nmatch, W, bits0);
+  hipLaunchKernelGGL(ml_bits_kernel, dim3(L1), dim3(256), 0, st, row_ptr1, pt_idx1, matches, 1, nmatch, W, bits1);
+  hipLaunchKernelGGL(ml_vote_rowmax_kernel, dim3(L0), dim3(256), 0, st, bits0, bits1, L1, W, vote, row_loc, line_matches);
+  hipLaunchKernelGGL(ml_colmax_kernel, dim3(L1), dim3(256), 0, st, vote, row_loc, row_ptr0, row_ptr1, L0, L1, line_matches);
+}
+
 }  // namespace airfe

@@ -104,6 +104,13 @@ int airfe_match_superglue(airfe_ctx* ctx, const float* f0, int n0, const float* 
 int airfe_assign_points_to_lines(airfe_ctx* ctx, const double* lines, int L, const float* feat, int N, int32_t* row_ptr,
                                  int32_t* pt_idx, double* pt_dist, int cap, int* total);
 
+/* ≙ MatchLines (src/line_processor.cc:122-172), called right after the point matcher on two frames' relations (frame.cc:177-190).
+ *   (row_ptr0, pt_idx0) / (row_ptr1, pt_idx1): the CSR relations of airfe_assign_points_to_lines for frame 0 / frame 1 (L0 / L1 lines,
+ *   point_num0 / point_num1 keypoints); matches [M][2] = (queryIdx, trainIdx) of the cv::DMatch list.
+ *   line_matches [L0]: index of the matched line of frame 1 or -1 (all -1 when any of the four counts is 0, :132). */
+int airfe_match_lines(airfe_ctx* ctx, const int32_t* row_ptr0, const int32_t* pt_idx0, int L0, int point_num0, const int32_t* row_ptr1,
+                      const int32_t* pt_idx1, int L1, int point_num1, const int32_t* matches, int M, int32_t* line_matches);
+
 /* ---- device-resident batch pipeline (NEW: no reference counterpart) ------------------------------------ */
 /* d_gray: [B] images, image b at d_gray + b*img_stride, rows `stride` bytes apart.  d_feat [B][cap][259], d_n [B]. */
 int airfe_detect_points_batch_dev(airfe_ctx* ctx, const uint8_t* d_gray, int B, int h, int w, int stride,

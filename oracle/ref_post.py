@@ -354,3 +354,38 @@ def assign_points_to_lines(lines: np.ndarray, points: np.ndarray):
                 on_line[j] = float(pl)                                                      # :114
         relation.append(on_line)
     return relation
+
+
+def match_lines(points_on_line0, points_on_line1, point_matches, point_num0: int, point_num1: int):
+    """MatchLines, src/line_processor.cc:122-172, statement by statement.  points_on_line{0,1}: lists of dicts {point index:
+    distance} (the std::map<int,double> relation of AssignPointsToLines); point_matches: iterable of (queryIdx, trainIdx).
+    -> list of length len(points_on_line0): matched line index of frame 1, or -1."""
+    n0, n1 = len(points_on_line0), len(points_on_line1)
+    line_matches = [-1] * n0                                                     # :127-131
+    if point_num0 == 0 or point_num1 == 0 or n0 == 0 or n1 == 0:                # :132
+        return line_matches
+    assigned0 = [[] for _ in range(point_num0)]                                  # :134-147
+    assigned1 = [[] for _ in range(point_num1)]
+    for i, rel in enumerate(points_on_line0):
+        for k in rel:
+            assigned0[k].append(i)
+    for i, rel in enumerate(points_on_line1):
+        for k in rel:
+            assigned1[k].append(i)
+    mat = np.zeros((n0, n1), np.int32)                                           # :150
+    for q, t in point_matches:                                                   # :151-160
+        for l0 in assigned0[q]:
+            for l1 in assigned1[t]:
+                mat[l0, l1] += 1
+    row_loc = [int(np.argmax(mat[i])) for i in range(n0)]                        # :166-168 (maxCoeff: first maximum)
+    for j in range(n1):                                                          # :169-179
+        col = mat[:, j]
+        i = int(np.argmax(col))                                                  # first maximum
+        v = int(col[i])
+        if v < 2 or row_loc[i] != j:
+            continue
+        score = np.float32(v * v) / np.float32(min(len(points_on_line0[i]), len(points_on_line1[j])))   # :174 float / size_t
+        if float(score) < 0.8:
+            continue
+        line_matches[i] = j
+    return line_matches

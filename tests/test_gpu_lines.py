@@ -63,3 +63,36 @@ def test_assign_on_detector_output():
     ref = ref_post.assign_points_to_lines(lines, feat)
     _same(dev, ref)
     assert sum(len(r) for r in ref) >= 240       # at least the two endpoints of every line
+
+
+@pytest.mark.parametrize("seed,L0,L1,N0,N1,M", [(0, 150, 140, 400, 400, 300), (1, 1, 1, 5, 5, 5), (2, 37, 300, 1024, 900, 700),
+                                                (3, 600, 65, 400, 380, 33), (4, 5, 7, 30, 30, 0), (5, 40, 0, 50, 50, 20)])
+def test_match_lines_vs_oracle(seed, L0, L1, N0, N1, M):
+    """airfe_match_lines == MatchLines (line_processor.cc:122-172): integer votes, first-maximum ties, float score gate: exact."""
+    from test_oracle_post import _random_line_frames
+    ctx, _, _ = context("sp")
+    rel0, rel1, matches = _random_line_frames(100 + seed, L0, L1, N0, N1, M)
+    dev = ctx.match_lines(rel0, rel1, matches, N0, N1)
+    ref = ref_post.match_lines(rel0, rel1, matches, N0, N1)
+    diag(f"lines_match_{seed}", lines0=L0, lines1=L1, matches=len(matches), matched=int(sum(1 for r in ref if r >= 0)))
+    assert dev == ref
+
+
+def test_match_lines_on_assign_output():
+    """The reference's call order (frame.cc:125,177-190): AssignPointsToLines on both frames, then MatchLines with the point matches."""
+    ctx, _, _ = context("sp")
+    rng = np.random.default_rng(17)
+    pts0 = rng.uniform(20, 700, size=(300, 2)); pts0[:, 1] *= 480.0 / 752.0
+    shift = np.array([-14.0, 0.5])
+    pts1 = pts0 + shift + rng.normal(0, 0.2, size=pts0.shape)
+    ends = pts0[rng.integers(0, 300, size=(80, 2))]
+    lines0 = ends.reshape(80, 4).astype(np.float64)
+    lines1 = (ends + shift).reshape(80, 4).astype(np.float64)
+    f0, f1 = _feat(pts0), _feat(pts1)
+    rel0 = ctx.assign_points_to_lines(lines0, f0)
+    rel1 = ctx.assign_points_to_lines(lines1, f1)
+    matches = [(i, i) for i in range(0, 300, 1) if rng.uniform() < 0.9]
+    dev = ctx.match_lines(rel0, rel1, matches, 300, 300)
+    ref = ref_post.match_lines(ref_post.assign_points_to_lines(lines0, f0), ref_post.assign_points_to_lines(lines1, f1), matches, 300, 300)
+    assert dev == ref
+    assert sum(1 for i, j in enumerate(ref) if j == i) >= 40          # most lines find their shifted copy

@@ -212,3 +212,69 @@ def test_assign_points_to_lines_vectorised_cross_check():
         ok = box & ~(pl > 3) & ((s1 <= 9) | (s2 <= 9) | ((s1 < D * D + s2) & (s2 < D * D + s1)))
         assert list(rel[i].keys()) == np.nonzero(ok)[0].tolist()
         assert np.array_equal(np.array(list(rel[i].values()), np.float32), pl[ok])
+
+
+def _random_line_frames(seed, L0, L1, N0, N1, M):
+    """Two frames' point-line relations that share structure (so that votes >= 2 exist) + point matches."""
+    rng = np.random.default_rng(seed)
+    rel0 = [dict() for _ in range(L0)]
+    rel1 = [dict() for _ in range(L1)]
+    perm = rng.permutation(N1)                    # true correspondence point i (frame 0) <-> perm[i] (frame 1), where it exists
+    for i in range(L0):
+        for k in rng.choice(N0, size=int(rng.integers(0, min(9, N0) + 1)), replace=False) if N0 else []:
+            rel0[i][int(k)] = float(rng.uniform(0, 3))
+    for j in range(L1):
+        src = rel0[j % L0] if L0 and rng.uniform() < 0.7 else {}
+        for k in src:
+            if k < N1 and rng.uniform() < 0.8:
+                rel1[j][int(perm[k % N1])] = float(rng.uniform(0, 3))
+        for k in rng.choice(N1, size=int(rng.integers(0, min(4, N1) + 1)), replace=False) if N1 else []:
+            rel1[j][int(k)] = float(rng.uniform(0, 3))
+    matches = []
+    if N0 and N1:
+        for q in rng.choice(N0, size=min(M, N0), replace=False):
+            t = int(perm[q % N1]) if rng.uniform() < 0.85 else int(rng.integers(0, N1))
+            matches.append((int(q), t))
+    return rel0, rel1, matches
+
+
+def test_match_lines_hand_cases():
+    """MatchLines (line_processor.cc:122-172): votes, mutual first-maximum, the >= 2 and score >= 0.8 gates."""
+    rel0 = [{0: 1.0, 1: 1.0, 2: 1.0}, {3: 0.5}, {4: 0.1, 5: 0.2}]
+    rel1 = [{7: 1.0}, {10: 1.0, 11: 1.0, 12: 1.0}, {14: 0.3, 15: 0.3, 16: 0.1, 17: 0.2, 18: 0.0, 19: 0.0}]
+    matches = [(0, 10), (1, 11), (2, 12), (3, 7), (4, 14), (5, 15)]
+    # line 0 <-> line 1: 3 votes, score 9/3 = 3; line 1 <-> 0: one vote only (< 2); line 2 <-> 2: 2 votes, score 4/2 = 2 -> accepted
+    assert rp.match_lines(rel0, rel1, matches, 6, 20) == [1, -1, 2]
+    # score gate: 2 votes over lines of 6 points each: 4/6 < 0.8
+    rel0b = [{0: 0., 1: 0., 2: 0., 3: 0., 4: 0., 5: 0.}]
+    rel1b = [{0: 0., 1: 0., 2: 0., 3: 0., 4: 0., 5: 0.}]
+    assert rp.match_lines(rel0b, rel1b, [(0, 0), (1, 1)], 6, 6) == [-1]
+    assert rp.match_lines(rel0b, rel1b, [(0, 0), (1, 1), (2, 2), (3, 3), (4, 4)], 6, 6) == [0]      # 25/6
+    # early-outs (:132) and a tie: two frame-1 lines with equal votes -> the first one wins the row, the second is not mutual
+    assert rp.match_lines(rel0, rel1, matches, 0, 20) == [-1, -1, -1]
+    assert rp.match_lines([], rel1, matches, 6, 20) == []
+    tie1 = [{10: 0., 11: 0.}, {10: 0., 11: 0.}]
+    assert rp.match_lines([{0: 0., 1: 0.}], tie1, [(0, 10), (1, 11)], 2, 12) == [0]
+
+
+def test_match_lines_matrix_cross_check():
+    """The voting matrix of the statement-by-statement port equals the indicator-matrix product A0^T . P . A1 on random frames."""
+    for seed in range(6):
+        L0, L1, N0, N1 = 23 + seed, 19 + 2 * seed, 60, 70
+        rel0, rel1, matches = _random_line_frames(seed, L0, L1, N0, N1, 45)
+        a0 = np.zeros((L0, N0), np.int64); a1 = np.zeros((L1, N1), np.int64); pm = np.zeros((N0, N1), np.int64)
+        for i, r in enumerate(rel0):
+            a0[i, list(r)] = 1
+        for j, r in enumerate(rel1):
+            a1[j, list(r)] = 1
+        for q, t in matches:
+            pm[q, t] += 1
+        mat = a0 @ pm @ a1.T
+        want = [-1] * L0
+        row_loc = mat.argmax(1)
+        for j in range(L1):
+            i = int(mat[:, j].argmax()); v = int(mat[i, j])
+            if v >= 2 and row_loc[i] == j and np.float32(v * v) / np.float32(min(len(rel0[i]), len(rel1[j]))) >= 0.8:
+                want[i] = j
+        assert rp.match_lines(rel0, rel1, matches, N0, N1) == want
+        assert any(w >= 0 for w in want)
