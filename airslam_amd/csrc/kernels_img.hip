@@ -25,9 +25,51 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ src, int stride, s
   out[((size_t)b * (RH + 2) + y + 1) * (RW + 2) + x + 1] = lut[v];
 }
 
+// Same arithmetic, one workgroup per output row: the two source rows it blends are staged into LDS with 4-byte loads (the
+// per-pixel form issues four 1-byte global loads per output pixel: 64 bytes per wave instruction), then every thread picks its
+// taps from LDS.  Rows that are not 4-byte aligned, or wider than the staging buffer, take the per-pixel kernel.
+constexpr int PRE_MAX_W = 4096;
+__global__ __launch_bounds__(256) void preprocess_rows_kernel(const uint8_t* __restrict__ src, int stride, size_t img_stride, int w,
+                                                              const int4* __restrict__ xtab, const int4* __restrict__ ytab,
+                                                              const float* __restrict__ lut, float* __restrict__ out, int RH, int RW) {
+  __shared__ uint32_t sm[2][PRE_MAX_W / 4];
+  const int y = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int4 yt = ytab[y];
+  const uint8_t* s = src + (size_t)b * img_stride;
+  const uint8_t* r0 = s + (size_t)yt.x * stride;
+  const uint8_t* r1 = s + (size_t)yt.y * stride;
+  const int nfull = w >> 2;
+  for (int i = t; i < nfull; i += 256) {
+    sm[0][i] = reinterpret_cast<const uint32_t*>(r0)[i];
+    sm[1][i] = reinterpret_cast<const uint32_t*>(r1)[i];
+  }
+  if (t < (w & 3)) {                                    // tail bytes one by one: never read past the row
+    reinterpret_cast<uint8_t*>(sm[0])[nfull * 4 + t] = r0[nfull * 4 + t];
+    reinterpret_cast<uint8_t*>(sm[1])[nfull * 4 + t] = r1[nfull * 4 + t];
+  }
+  __syncthreads();
+  const uint8_t* a0 = reinterpret_cast<const uint8_t*>(sm[0]);
+  const uint8_t* a1 = reinterpret_cast<const uint8_t*>(sm[1]);
+  float* orow = out + ((size_t)b * (RH + 2) + y + 1) * (RW + 2) + 1;
+  for (int x = t; x < RW; x += 256) {
+    const int4 xt = xtab[x];
+    const int h0 = (int)a0[xt.x] * xt.z + (int)a0[xt.y] * xt.w;
+    const int h1 = (int)a1[xt.x] * xt.z + (int)a1[xt.y] * xt.w;
+    int v = (((yt.z * (h0 >> 4)) >> 16) + ((yt.w * (h1 >> 4)) >> 16) + 2) >> 2;
+    v = min(max(v, 0), 255);
+    orow[x] = lut[v];
+  }
+}
+
 void launch_preprocess(const uint8_t* src, int B, int h, int w, int stride, size_t img_stride, const int* xtab,
                        const int* ytab, const float* lut, float* out, int RH, int RW, hipStream_t st) {
-  (void)h; (void)w;
+  (void)h;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | (uintptr_t)img_stride) & 3) == 0;
+  if (aligned && w <= PRE_MAX_W) {
+    hipLaunchKernelGGL(preprocess_rows_kernel, dim3(RH, B), dim3(256), 0, st, src, stride, img_stride, w,
+                       reinterpret_cast<const int4*>(xtab), reinterpret_cast<const int4*>(ytab), lut, out, RH, RW);
+    return;
+  }
   dim3 grid((RW + 255) / 256, RH, B);
   hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, st, src, stride, img_stride,
                      reinterpret_cast<const int4*>(xtab), reinterpret_cast<const int4*>(ytab), lut, out, RH, RW);
