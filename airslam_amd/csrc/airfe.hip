@@ -691,7 +691,7 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
   const int ccap = R * R;
   {
     ProfScope ps(c, ST_NMS, st, 0, (double)B * R * R * 8);
-    if (c->cfg.nms_radius == 4) {
+    if (c->cfg.nms_radius == 4 && R % 64 == 0) {          // (the tiled kernel moves 4-pixel vectors: R = 512 always qualifies)
       launch_nms4_candidates(c->heat, c->heat_nms, c->nms_mask, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand,
                              c->cand_cnt, ccap, st);
     } else if (c->cfg.nms_radius > 0) {

@@ -41,12 +41,17 @@ __device__ __forceinline__ void max9_of16(const float* x, float* o) {
 //   MODE 3: MODE 2, then out = M ? S : 0 and the detect_point candidate list
 constexpr int PT_W = 64, PT_H = 32, PR_W = PT_W + 8, PR_H = PT_H + 8, PP = PR_W + 1;
 
+// Global traffic is 16-byte / 4-byte vectors only: a region row starts 4 pixels left of a 64-pixel tile, i.e. on a float4 (and
+// uchar4) boundary, and W % 4 == 0 makes every vector wholly inside or wholly outside the image.  The byte planes are read and
+// written through LDS byte tiles (one byte per lane and instruction was most of the load/store time of the first version).
 template <int MODE>
 __global__ __launch_bounds__(256) void nms_pool_kernel(const float* __restrict__ heat, unsigned char* __restrict__ Mg,
                                                        unsigned char* __restrict__ Dg, float* __restrict__ out, int H, int W,
                                                        int tiles_x, float thr, int border, u64* __restrict__ cand,
                                                        int* __restrict__ cand_cnt, int cand_cap) {
   __shared__ __attribute__((aligned(16))) float AT[2 * PR_H * PP];     // input region | row maxima; later the candidate keys
+  __shared__ __attribute__((aligned(4))) unsigned char Dt[PR_H * PR_W];   // MODE 2/3: supp_mask of the region (0 outside the image)
+  __shared__ __attribute__((aligned(4))) unsigned char Bt[PT_H * PT_W];   // byte plane of the tile: M in (MODE 2/3), result out
   __shared__ int lcnt[2];
   float* A = AT;
   float* T = AT + PR_H * PP;
@@ -56,15 +61,34 @@ __global__ __launch_bounds__(256) void nms_pool_kernel(const float* __restrict__
   const float* S = heat + img;
   unsigned char* M = Mg + img;
   unsigned char* D = Dg + img;
-  for (int i = threadIdx.x; i < PR_H * PR_W; i += 256) {
-    const int r = i / PR_W, c = i - r * PR_W, gy = gy0 + r, gx = gx0 + c;
+  constexpr int RV = PR_W / 4;                                          // 18 four-pixel vectors per region row
+  for (int i = threadIdx.x; i < PR_H * RV; i += 256) {
+    const int r = i / RV, c4 = i - r * RV, gy = gy0 + r, gx = gx0 + 4 * c4;
     const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
     const size_t gi = (size_t)gy * W + gx;
-    float v;
-    if (MODE == 0) v = in ? S[gi] : -INFINITY;
-    else if (MODE == 1) v = (in && M[gi]) ? 1.f : 0.f;
-    else v = in ? (D[gi] ? 0.f : S[gi]) : -INFINITY;
-    A[r * PP + c] = v;
+    float v[4];
+    if (MODE == 0) {
+      const float4 s4 = in ? *reinterpret_cast<const float4*>(S + gi) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      v[0] = s4.x; v[1] = s4.y; v[2] = s4.z; v[3] = s4.w;
+    } else if (MODE == 1) {
+      const uchar4 m4 = in ? *reinterpret_cast<const uchar4*>(M + gi) : make_uchar4(0, 0, 0, 0);
+      v[0] = m4.x ? 1.f : 0.f; v[1] = m4.y ? 1.f : 0.f; v[2] = m4.z ? 1.f : 0.f; v[3] = m4.w ? 1.f : 0.f;
+    } else {
+      const float4 s4 = in ? *reinterpret_cast<const float4*>(S + gi) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      const uchar4 d4 = in ? *reinterpret_cast<const uchar4*>(D + gi) : make_uchar4(0, 0, 0, 0);
+      v[0] = d4.x ? 0.f : s4.x; v[1] = d4.y ? 0.f : s4.y; v[2] = d4.z ? 0.f : s4.z; v[3] = d4.w ? 0.f : s4.w;
+      *reinterpret_cast<uchar4*>(Dt + r * PR_W + 4 * c4) = d4;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A[r * PP + 4 * c4 + k] = v[k];
+  }
+  if (MODE >= 2) {                                                      // max_mask of the tile itself, as 4-byte words
+    for (int i = threadIdx.x; i < PT_H * PT_W / 4; i += 256) {
+      const int r = i / (PT_W / 4), c4 = i - r * (PT_W / 4), gy = gy0 + 4 + r, gx = gx0 + 4 + 4 * c4;
+      uchar4 m4 = make_uchar4(0, 0, 0, 0);
+      if (gy < H && gx < W) m4 = *reinterpret_cast<const uchar4*>(M + (size_t)gy * W + gx);
+      *reinterpret_cast<uchar4*>(Bt + r * PT_W + 4 * c4) = m4;
+    }
   }
   if (MODE == 3 && threadIdx.x == 0) lcnt[0] = 0;
   __syncthreads();
@@ -91,22 +115,29 @@ __global__ __launch_bounds__(256) void nms_pool_kernel(const float* __restrict__
     for (int i = 0; i < 8; ++i) {
       const int gy = gy0 + r0 + i;
       keep_v[i] = 0.f;
-      if (gy < H && gx < W) {
-        const size_t gi = (size_t)gy * W + gx;
-        const float a = A[(r0 + i) * PP + c];
-        if (MODE == 0) M[gi] = a == o[i];
-        else if (MODE == 1) D[gi] = o[i] > 0.f;
-        else {
-          const bool d = D[gi];
-          const bool m = M[gi] || (!d && a == o[i]);
-          if (MODE == 2) { if (m) M[gi] = 1; }
-          else {
-            const float v = m ? S[gi] : 0.f;
-            out[img + gi] = v;
-            keep_v[i] = v;
-          }
+      const float a = A[(r0 + i) * PP + c];
+      const int bi = (r0 - 4 + i) * PT_W + (c - 4);                      // this pixel in the byte tile
+      if (MODE == 0) Bt[bi] = a == o[i];
+      else if (MODE == 1) Bt[bi] = o[i] > 0.f;
+      else {
+        const bool d = Dt[(r0 + i) * PR_W + c];
+        const bool m = Bt[bi] || (!d && a == o[i]);
+        if (MODE == 2) Bt[bi] = m;
+        else if (gy < H && gx < W) {
+          const size_t gi = (size_t)gy * W + gx;
+          const float v = m ? S[gi] : 0.f;
+          out[img + gi] = v;
+          keep_v[i] = v;
         }
       }
+    }
+  }
+  if (MODE != 3) {                                                       // the byte plane of the tile leaves as 4-byte words
+    __syncthreads();
+    unsigned char* dst = MODE == 1 ? D : M;
+    for (int i = threadIdx.x; i < PT_H * PT_W / 4; i += 256) {
+      const int r = i / (PT_W / 4), c4 = i - r * (PT_W / 4), gy = gy0 + 4 + r, gx = gx0 + 4 + 4 * c4;
+      if (gy < H && gx < W) *reinterpret_cast<uchar4*>(dst + (size_t)gy * W + gx) = *reinterpret_cast<const uchar4*>(Bt + r * PT_W + 4 * c4);
     }
   }
   if (MODE == 3) {
