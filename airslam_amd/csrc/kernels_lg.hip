@@ -369,28 +369,36 @@ __global__ void lg_rowlse_kernel(const float* __restrict__ sim, const int* __res
   if (lane == 0) rowlse[(size_t)b * Np + i] = mx + logf(s);
 }
 
-// 64 columns x 4 row slices per workgroup: log-sum-exp over i < n0 (coalesced across the block's columns; a single thread
-// per column walked its 400 rows as one dependent chain of L2 loads and took longer than the similarity GEMM)
-__global__ __launch_bounds__(256) void lg_collse_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np,
-                                                        float* __restrict__ collse) {
-  __shared__ float part[4][64];
+// 64 columns x 16 row slices per workgroup: log-sum-exp over i < n0 (coalesced across the block's columns; a single thread per
+// column walked its 400 rows as one dependent chain of L2 loads and took longer than the similarity GEMM; four slices: 54 us)
+constexpr int LG_CS = 16;                     // row slices of the column kernels
+__global__ __launch_bounds__(64 * LG_CS) void lg_collse_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np,
+                                                               float* __restrict__ collse) {
+  __shared__ float part[LG_CS][64];
   const int b = blockIdx.y, jj = threadIdx.x & 63, q = threadIdx.x >> 6, j = blockIdx.x * 64 + jj;
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
   const bool live = j < n1;
   const float* c = sim + (size_t)b * Np * Np + j;
   float mx = -INFINITY;
   if (live)
-    for (int i = q; i < n0; i += 4) mx = fmaxf(mx, c[(size_t)i * Np]);
+    for (int i = q; i < n0; i += LG_CS) mx = fmaxf(mx, c[(size_t)i * Np]);
   part[q][jj] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(part[0][jj], part[1][jj]), fmaxf(part[2][jj], part[3][jj]));
+  mx = part[0][jj];
+#pragma unroll
+  for (int k = 1; k < LG_CS; ++k) mx = fmaxf(mx, part[k][jj]);
   __syncthreads();
   float sm = 0.f;
   if (live)
-    for (int i = q; i < n0; i += 4) sm += expf(c[(size_t)i * Np] - mx);
+    for (int i = q; i < n0; i += LG_CS) sm += expf(c[(size_t)i * Np] - mx);
   part[q][jj] = sm;
   __syncthreads();
-  if (q == 0 && live) collse[(size_t)b * Np + j] = mx + logf((part[0][jj] + part[1][jj]) + (part[2][jj] + part[3][jj]));
+  if (q == 0 && live) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < LG_CS; ++k) tot += part[k][jj];
+    collse[(size_t)b * Np + j] = mx + logf(tot);
+  }
 }
 
 __device__ __forceinline__ float lg_score(float sv, float rl, float cl, float c0, float c1) {
@@ -430,11 +438,11 @@ __global__ void lg_rowarg_kernel(const float* __restrict__ sim, const float* __r
 
 // 64 columns x 4 row slices per workgroup: column arg-max over rows, first maximum wins (strict '>' inside a slice, lowest row
 // index between slices); z holds log-sigmoid matchabilities.
-__global__ __launch_bounds__(256) void lg_colarg_kernel(const float* __restrict__ sim, const float* __restrict__ z,
-                                                        const int* __restrict__ lens, int Np, const float* __restrict__ rowlse,
-                                                        const float* __restrict__ collse, int* __restrict__ colarg) {
-  __shared__ float pbest[256];
-  __shared__ int pidx[256];
+__global__ __launch_bounds__(64 * LG_CS) void lg_colarg_kernel(const float* __restrict__ sim, const float* __restrict__ z,
+                                                               const int* __restrict__ lens, int Np, const float* __restrict__ rowlse,
+                                                               const float* __restrict__ collse, int* __restrict__ colarg) {
+  __shared__ float pbest[64 * LG_CS];
+  __shared__ int pidx[64 * LG_CS];
   const int b = blockIdx.y, jj = threadIdx.x & 63, q = threadIdx.x >> 6, j = blockIdx.x * 64 + jj;
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
   const float* z0 = z + (size_t)(2 * b) * Np;
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(256) void lg_colarg_kernel(const float* __restrict_
     const float cl = collse[(size_t)b * Np + j];
     const float c1 = z[(size_t)(2 * b + 1) * Np + j];
     const float* rl = rowlse + (size_t)b * Np;
-    for (int i = q; i < n0; i += 4) {
+    for (int i = q; i < n0; i += LG_CS) {
       const float sc = lg_score(c[(size_t)i * Np], rl[i], cl, z0[i], c1);
       if (sc > best) { best = sc; bi = i; }
     }
@@ -456,7 +464,7 @@ __global__ __launch_bounds__(256) void lg_colarg_kernel(const float* __restrict_
   __syncthreads();
   if (q == 0 && live) {
 #pragma unroll
-    for (int k = 1; k < 4; ++k) {
+    for (int k = 1; k < LG_CS; ++k) {
       const float ob = pbest[k * 64 + jj];
       const int oi = pidx[k * 64 + jj];
       if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
@@ -503,10 +511,10 @@ void launch_lg_assign(const float* sim, const float* z, const int* lens, int B, 
                       float* collse, float* scores_out, int* rowarg, float* rowval, int* colarg, int32_t* idx,
                       float* score, int* nmatch, hipStream_t st) {
   hipLaunchKernelGGL(lg_rowlse_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, sim, lens, Np, rowlse);
-  hipLaunchKernelGGL(lg_collse_kernel, dim3((Np + 63) / 64, B), dim3(256), 0, st, sim, lens, Np, collse);
+  hipLaunchKernelGGL(lg_collse_kernel, dim3((Np + 63) / 64, B), dim3(64 * LG_CS), 0, st, sim, lens, Np, collse);
   hipLaunchKernelGGL(lg_rowarg_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, sim, z, lens, Np, rowlse, collse,
                      scores_out, rowarg, rowval);
-  hipLaunchKernelGGL(lg_colarg_kernel, dim3((Np + 63) / 64, B), dim3(256), 0, st, sim, z, lens, Np, rowlse, collse, colarg);
+  hipLaunchKernelGGL(lg_colarg_kernel, dim3((Np + 63) / 64, B), dim3(64 * LG_CS), 0, st, sim, z, lens, Np, rowlse, collse, colarg);
   hipLaunchKernelGGL(lg_filter_kernel, dim3(B), dim3(1024), 0, st, lens, Np, cap, thr, rowarg, rowval, colarg, idx, score,
                      nmatch);
 }
