@@ -45,6 +45,11 @@ int main() {
       hipMemset(d, 0, 8192);
       hipEvent_t e0, e1;
       hipEventCreate(&e0); hipEventCreate(&e1);
+      // untimed warm-up of the same configuration: the first launch of a kernel pays its module load (that is what made
+      // mfma_rate.hip's one-wave number 1.6x too slow)
+      if (width == 16) hipLaunchKernelGGL(probe<16>, dim3(256), dim3(waves * 64), 65536, 0, d, 50);
+      else hipLaunchKernelGGL(probe<8>, dim3(256), dim3(waves * 64), 65536, 0, d, 50);
+      hipDeviceSynchronize();
       hipEventRecord(e0, 0);
       if (width == 16) hipLaunchKernelGGL(probe<16>, dim3(256), dim3(waves * 64), 65536, 0, d, iters);
       else hipLaunchKernelGGL(probe<8>, dim3(256), dim3(waves * 64), 65536, 0, d, iters);
