@@ -1,0 +1,255 @@
+// EXPERIMENT, NOT BUILT (round 1): kernels_gemmr.hip with two DMA-only producer waves (waves 8, 9 of a 640-thread
+// workgroup) and eight MFMA + store consumer waves that never wait on vmcnt.  Measured the same 3.0 TB/s as the shipped 8-wave
+// kernel.  The `asm volatile("" ::: "memory")` before the epilogue is what keeps hipcc from moving the consumers' rotary LDS
+// reads; one large-batch case still failed with it.  Kept as a starting point only.
+// airfe — K = 256 linears of the matcher at large token counts (q/k/v projections, final projection): a STREAMING GEMM with the
+// weights resident in registers.
+//
+// These GEMMs are HBM-bound (K = 256: 512 B in, 512-1024 B out per token for 131-262 kFLOP), yet the tiled kernels ran them at
+// 1.8 TB/s: a 256 x 256 output tile has only four K chunks, so every workgroup is mostly pipeline fill and drain, one workgroup
+// per CU.  Here a persistent workgroup owns 256 output features for the whole launch: wave w holds its 32 features x 256 K as
+// 16 MFMA A-fragments (64 registers, loaded once), token tiles of 32 rows stream through an 8-slot LDS ring by LDS-DMA (seven
+// tiles = 112 KiB in flight per CU), and each tile costs one barrier, 16 ds_read_b128, 32 MFMAs and 2-4 stores per wave.
+// N = 512 (self q|k) runs as two feature groups, and q|k + v of a layer as ONE launch of three (gemmr_pair_kernel); the
+// workgroups that read the same token tile sit on the same XCD (blockIdx, blockIdx + 8, ...) so the later reads are L2 hits.
+//
+// Nothing the compiler can see loads from global memory inside the tile loop (biases are preloaded into registers): a compiler-placed s_waitcnt would count only its own loads and drain the whole DMA ring.  The hand-placed
+// waits rely on loads retiring in order: "at most 2*(tiles still in flight behind the wanted one)" outstanding.
+// Rotary (self q|k): the cos / sin rows of a tile's tokens (2 x 4 KiB of fp32) ride the ring with it — one more DMA instruction per
+// wave and tile, six slots of 24 KiB instead of eight of 16 — and the epilogue rotates the accumulator pairs from LDS.
+#include "../../airslam_amd/csrc/common.h"
+#include "../../airslam_amd/csrc/kernels.h"
+
+namespace airfe {
+
+constexpr int GR_MT = 2;                          // 16-token MFMA tiles per streamed tile
+constexpr int GR_TT = 16 * GR_MT;                 // 32 tokens
+constexpr int GR_XBYTES = GR_TT * 512;            // [32][256] 2-byte = 16 KiB
+constexpr int GR_RBYTES = 2 * GR_TT * 128;        // cos | sin rows of the tile's tokens, [32][32] fp32 each = 8 KiB
+
+template <int N>
+__device__ __forceinline__ void gr_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void gr_glds16(const void* gsrc, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_off)
+               : "memory");
+}
+
+// One workgroup's whole launch: 256-feature slice `group` of linear `a`, token tiles first, first + per_group, ...
+template <class P, bool TRANS, bool ROT>
+__device__ __forceinline__ void gemmr_body(const GemmArgs& a, char* smem, int group, int first, int per_group, int ntiles) {
+  constexpr int GR_SLOT = GR_XBYTES + (ROT ? GR_RBYTES : 0);
+  constexpr int GR_SLOTS = ROT ? 6 : 8;
+  constexpr int PER = ROT ? 12 : 8;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave0 >= 8;
+  const int pw = wave0 - 8, wave = wave0 & 7;
+  const int n = first < ntiles ? (ntiles - first + per_group - 1) / per_group : 0;
+  if (n == 0) return;
+
+  // ---- this wave's weights: feature block cb, tile pair tp -> 16 fragments
+  const int cb = group * 4 + (wave >> 1), tp = wave & 1;
+  typename P::vec8 wreg[2][8];
+  {
+    const int sw = (l15 >> 1) & 7;
+    const char* wb = reinterpret_cast<const char*>(a.Wp) + (size_t)cb * 4 * SLAB_BYTES + 2 * tp * 2048 + l15 * 128;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        wreg[u][ks] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(
+            wb + u * 2048 + (ks >> 1) * SLAB_BYTES + ((((ks & 1) * 4 + g) ^ sw) << 4)));
+  }
+  f32x4 binit[2];                                                     // !TRANS: bias of the lane's 8 features
+  float bt[2];                                                        // TRANS: bias of the lane's feature column per tile
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    binit[u] = *reinterpret_cast<const f32x4*>(a.bias + cb * 64 + tp * 32 + g * 8 + u * 4);
+    bt[u] = a.bias[cb * 64 + slab_row_to_feature((2 * tp + u) * 16 + l15)];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- DMA of tile `t` (32 rows x 512 B) into ring slot `slot`: 16 wave-instructions of 1 KiB, two per wave, two rows each
+  const int ld = a.ld1;
+  auto dma = [&](int t, int slot) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int inst = pw * 8 + i;
+      const int r = inst * 2 + (lane >> 5), pp = lane & 31;
+      gr_glds16(a.X1 + (size_t)(t * GR_TT + r) * ld + ((pp ^ (r & 15)) << 3), (unsigned)(slot * GR_SLOT + inst * 1024));
+    }
+    if constexpr (ROT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = pw * 4 + i;
+        const float* src = (q < 4 ? a.rot_cos : a.rot_sin) + ((size_t)t * GR_TT + (q & 3) * 8) * 32 + lane * 4;
+        gr_glds16(src, (unsigned)(slot * GR_SLOT + GR_XBYTES + q * 1024));
+      }
+    }
+  };
+  if (producer) {
+#pragma unroll
+    for (int j = 0; j < GR_SLOTS; ++j)
+      if (j < n) dma(first + j * per_group, j);
+    gr_wait_vm<0>();
+  }
+  __syncthreads();
+
+  const int boff0 = l15 * 512;
+  for (int i = 0; i < n; ++i) {
+    const int t = first + i * per_group, slot = i % GR_SLOTS;          // (six slots with rotary: not a power of two)
+    if (producer) {
+      gr_wait_vm<0>();
+      __syncthreads();
+      if (i + GR_SLOTS < n) dma(first + (i + GR_SLOTS) * per_group, slot);
+      continue;
+    }
+    const char* xs = smem + slot * GR_SLOT + boff0;
+    f32x4 acc[2][GR_MT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int m = 0; m < GR_MT; ++m) acc[u][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      typename P::vec8 bf[GR_MT];
+#pragma unroll
+      for (int m = 0; m < GR_MT; ++m) bf[m] = lds_frag<P>(xs, m * 16 * 512 + (((ks * 4 + g) ^ l15) << 4));
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < GR_MT; ++m) {
+          if constexpr (TRANS) acc[u][m] = P::mfma(bf[m], wreg[u][ks], acc[u][m]);
+          else acc[u][m] = P::mfma(wreg[u][ks], bf[m], acc[u][m]);
+        }
+    }
+    asm volatile("" ::: "memory");
+    // ---- epilogue of tile i (stores only)
+    if constexpr (!TRANS) {
+      const int co = cb * 64 + tp * 32 + g * 8;
+#pragma unroll
+      for (int m = 0; m < GR_MT; ++m) {
+        const int row = t * GR_TT + m * 16 + l15;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[0][m][e] + binit[0][e];          // bias after the K sum, like the tiled kernels: bit-identical results
+          v[4 + e] = acc[1][m][e] + binit[1][e];
+        }
+        if constexpr (ROT) {                                          // rotary on the pairs (2i, 2i+1) of the head dimension: light_glue rotary, as gemm_store_run
+          const char* rt = smem + slot * GR_SLOT + GR_XBYTES + (m * 16 + l15) * 128 + (tp * 16 + g * 4) * 4;
+          const f32x4 cs = *reinterpret_cast<const f32x4*>(rt), sn = *reinterpret_cast<const f32x4*>(rt + GR_RBYTES / 2);
+          rotate_pairs(v, cs, sn);
+        }
+        if (a.epi == EPI_HEADS) {
+          const int s = row / a.Np, nn = row - s * a.Np;
+          const int sel = co >> 8, cw = co & 255, h = cw >> 6, d = cw & 63;
+          uint16_t* o = reinterpret_cast<uint16_t*>(sel ? a.out2 : a.out) + (((size_t)s * a.H + h) * a.Np + nn) * 64 + d;
+          *reinterpret_cast<uint4*>(o) = pack8<P>(v);
+        } else {                                                      // EPI_STORE
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.out) + (size_t)row * a.ldo + co) = pack8<P>(v);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int co = cb * 64 + slab_row_to_feature((2 * tp + u) * 16 + l15);
+        const int h = co >> 6, d = co & 63;
+#pragma unroll
+        for (int m = 0; m < GR_MT; ++m) {
+          const int row0 = t * GR_TT + m * 16 + g * 4;
+          const int sq = row0 / a.Np, nn = row0 - sq * a.Np;
+          uint16_t* o = reinterpret_cast<uint16_t*>(a.out) + (((size_t)sq * a.H + h) * 64 + d) * a.Np + nn;
+          *reinterpret_cast<uint2*>(o) = pack4<P>(acc[u][m][0] + bt[u], acc[u][m][1] + bt[u], acc[u][m][2] + bt[u], acc[u][m][3] + bt[u]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Workgroup w -> (feature group, first tile): the groups that read the same token tile are w, w + 8, ... = the same XCD, so the
+// tile comes from HBM once and from that XCD's L2 afterwards.
+template <class P, bool TRANS, bool ROT>
+__global__ __launch_bounds__(640, 1) void gemmr_kernel(GemmArgs a, int ntiles, int ngroups) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int w = blockIdx.x;
+  gemmr_body<P, TRANS, ROT>(a, smem, (w >> 3) % ngroups, (w & 7) + 8 * (w / (8 * ngroups)), gridDim.x / ngroups, ntiles);
+}
+
+// q|k (or the cross block's shared qk) and v of one attention layer in ONE launch: the first ng_a feature groups belong to linear
+// `a` (head-major rows, rotary when ROT), the last one to linear `b` (V, stored transposed) — the token tiles are read from HBM once
+// for all of them and a launch is saved per layer.
+template <class P, bool ROT>
+__global__ __launch_bounds__(640, 1) void gemmr_pair_kernel(GemmArgs a, GemmArgs b, int ntiles, int ng_a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ngroups = ng_a + 1, w = blockIdx.x;
+  const int group = (w >> 3) % ngroups, first = (w & 7) + 8 * (w / (8 * ngroups)), per_group = gridDim.x / ngroups;
+  if (group < ng_a) gemmr_body<P, false, ROT>(a, smem, group, first, per_group, ntiles);
+  else gemmr_body<P, true, false>(b, smem, 0, first, per_group, ntiles);
+}
+
+template <class P, bool ROT>
+static void gemmr_pair_launch_t(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+  constexpr int LDS = ROT ? 6 * (GR_XBYTES + GR_RBYTES) : 8 * GR_XBYTES;
+  static bool attr_done = false;
+  auto kfn = gemmr_pair_kernel<P, ROT>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  const int ng_a = a.cb_total / 4, ngroups = ng_a + 1;
+  const int nwg = std::max(a.gr_wgs / (8 * ngroups), 1) * (8 * ngroups);   // 256 for two groups, 240 for three
+  hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(640), LDS, st, a, b, a.M / GR_TT, ng_a);
+}
+
+template <class P, bool TRANS, bool ROT>
+static void gemmr_launch_t(const GemmArgs& a, hipStream_t st) {
+  constexpr int LDS = ROT ? 6 * (GR_XBYTES + GR_RBYTES) : 8 * GR_XBYTES;
+  static bool attr_done = false;
+  auto kfn = gemmr_kernel<P, TRANS, ROT>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  const int ngroups = a.cb_total / 4;
+  const int nwg = std::max(a.gr_wgs / (8 * ngroups), 1) * (8 * ngroups);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(640), LDS, st, a, a.M / GR_TT, ngroups);
+}
+
+bool gemmr_applicable(int K, bool trans, const GemmArgs& a) {
+  const int ng = a.cb_total / 4;
+  return K == 256 && !a.X2 && (!a.rot_cos || (!trans && a.epi == EPI_HEADS)) && a.act == ACT_NONE && a.cb_total % 4 == 0 && (ng == 1 || ng == 2) && a.N == a.cb_total * 64 &&
+         a.M % GR_TT == 0 && (trans ? a.epi == EPI_HEADS_T : (a.epi == EPI_HEADS || (a.epi == EPI_STORE && a.ldo >= a.N)));
+}
+
+bool gemmr_pair_applicable(const GemmArgs& a, const GemmArgs& b) {
+  return gemmr_applicable(256, false, a) && gemmr_applicable(256, true, b) && a.epi == EPI_HEADS && b.cb_total == 4 && a.X1 == b.X1 &&
+         a.ld1 == b.ld1 && a.M == b.M;
+}
+
+void launch_gemmr_pair(int prec, const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+  if (prec == 1) {
+    if (a.rot_cos) gemmr_pair_launch_t<PF16, true>(a, b, st); else gemmr_pair_launch_t<PF16, false>(a, b, st);
+  } else {
+    if (a.rot_cos) gemmr_pair_launch_t<PBF16, true>(a, b, st); else gemmr_pair_launch_t<PBF16, false>(a, b, st);
+  }
+}
+
+void launch_gemmr(int prec, bool trans, const GemmArgs& a, hipStream_t st) {
+  if (prec == 1) {
+    if (trans) gemmr_launch_t<PF16, true, false>(a, st);
+    else if (a.rot_cos) gemmr_launch_t<PF16, false, true>(a, st);
+    else gemmr_launch_t<PF16, false, false>(a, st);
+  } else {
+    if (trans) gemmr_launch_t<PBF16, true, false>(a, st);
+    else if (a.rot_cos) gemmr_launch_t<PBF16, false, true>(a, st);
+    else gemmr_launch_t<PBF16, false, false>(a, st);
+  }
+}
+
+}  // namespace airfe
