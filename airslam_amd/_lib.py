@@ -78,6 +78,13 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m airslam_amd.build` "
                 "(hipcc, gfx950).  airslam_amd has no CPU fallback.")
+        # PyTorch-ROCm ships its own libamdhip64; with two HIP runtimes in one process the one that initialises second sees no
+        # device.  Importing torch BEFORE the dlopen makes libairfe.so bind to the runtime torch uses (same soname), whatever order
+        # the caller imports things in (__graft_entry__.build() loads the library before smoke() imports torch).
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)      # AttributeError if the library does not export it
