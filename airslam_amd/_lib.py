@@ -16,7 +16,7 @@ class Cfg(C.Structure):
         ("nms_radius", C.c_int), ("line_threshold", C.c_float), ("line_length_threshold", C.c_float),
         ("matcher", C.c_int), ("image_width", C.c_int), ("image_height", C.c_int), ("sinkhorn_iters", C.c_int),
         ("superpoint_pack", C.c_char_p), ("plnet_s1_pack", C.c_char_p), ("lightglue_pack", C.c_char_p),
-        ("superglue_pack", C.c_char_p),
+        ("superglue_pack", C.c_char_p), ("matcher_precision", C.c_int),
     ]
 
 
@@ -60,6 +60,8 @@ SIGNATURES = {
     "airfe_debug_detector_maps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "airfe_debug_lightglue_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "airfe_debug_superglue_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "airfe_debug_lg_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "airfe_debug_sg_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "airfe_debug_plnet_s1": (C.c_int, [C.c_void_p, C.POINTER(Stage0), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "airfe_debug_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "airfe_debug_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -213,6 +213,26 @@ class Context:
                                                        out.ctypes.data), "airfe_debug_superglue_scores")
         return out
 
+    def debug_lg_filter(self, scores: np.ndarray):
+        """filter_matches alone on a host score matrix [n0, n1] -> (idx [k,2], score [k])."""
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        cap = self.np_rows
+        idx = np.empty((cap, 2), np.int32); sc = np.empty((cap,), np.float32)
+        n = C.c_int(0)
+        self._chk(self._l.airfe_debug_lg_filter(self._h, scores.ctypes.data, scores.shape[0], scores.shape[1], idx.ctypes.data,
+                                                sc.ctypes.data, cap, C.byref(n)), "airfe_debug_lg_filter")
+        return idx[:n.value].copy(), sc[:n.value].copy()
+
+    def debug_sg_decode(self, z: np.ndarray):
+        """SuperGlue decode alone on a host score matrix [n0+1, n1+1] -> (indices0, indices1, mscores0, mscores1)."""
+        z = np.ascontiguousarray(z, dtype=np.float32)
+        n0, n1 = z.shape[0] - 1, z.shape[1] - 1
+        i0 = np.empty((n0,), np.int32); i1 = np.empty((n1,), np.int32)
+        m0 = np.empty((n0,), np.float64); m1 = np.empty((n1,), np.float64)
+        self._chk(self._l.airfe_debug_sg_decode(self._h, z.ctypes.data, n0, n1, i0.ctypes.data, i1.ctypes.data, m0.ctypes.data,
+                                                m1.ctypes.data), "airfe_debug_sg_decode")
+        return i0, i1, m0, m1
+
     def detector_maps(self, b: int = 1):
         heat = np.empty((b, 512, 512), np.float32)
         nms = np.empty((b, 512, 512), np.float32)

@@ -154,7 +154,9 @@ struct airfe_ctx {
   std::string err;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
-  int prec = 0;
+  int prec = 0;                  // detector storage type
+  int mprec = 1;                 // matcher storage type (cfg.matcher_precision)
+  int pack_prec = 0;             // storage type make_linear packs for (set by each load_* before it packs)
   int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
   bool has_sp = false, has_lg = false;
   char* pl_stage = nullptr;      // staging of airfe_assign_points_to_lines
@@ -317,7 +319,7 @@ bool make_linear(airfe_ctx* c, const float* W, const float* bias, int K, int N, 
                  const std::function<int(int)>* src_row = nullptr, const std::function<int(int)>* src_col = nullptr) {
   const int Kp = (K + 63) / 64 * 64, cbt = (N + 63) / 64;
   const int cbp = (cbt + 3) & ~3;        // the GEMMs consume feature blocks in pairs / quads (128- / 256-feature tiles): zero pad
-  auto slabs = pack_slabs(cbp, Kp / 64, c->prec, [&](int feat, int s, int k) {
+  auto slabs = pack_slabs(cbp, Kp / 64, c->pack_prec, [&](int feat, int s, int k) {
     const int kk = s * 64 + k;
     if (feat >= N || kk >= K) return 0.f;
     const int r = src_row ? (*src_row)(feat) : feat;
@@ -362,6 +364,7 @@ std::vector<int> resize_table(int dsize, int ssize) {
 }
 
 int load_superpoint(airfe_ctx* c, const char* path) {
+  c->pack_prec = c->prec;
   Pack p;
   std::string err;
   if (!load_pack(path, p, err)) return fail(c, err);
@@ -416,6 +419,7 @@ int load_superpoint(airfe_ctx* c, const char* path) {
 int alloc_matcher_arena(airfe_ctx* c);
 
 int load_lightglue(airfe_ctx* c, const char* path) {
+  c->pack_prec = c->mprec;
   Pack p;
   std::string err;
   if (!load_pack(path, p, err)) return fail(c, err);
@@ -508,6 +512,7 @@ float* upload_transposed(airfe_ctx* c, const Tensor& w, int N, int K) {
 }
 
 int load_superglue(airfe_ctx* c, const char* path) {
+  c->pack_prec = c->mprec;
   Pack p;
   std::string err;
   if (!load_pack(path, p, err)) return fail(c, err);
@@ -723,7 +728,7 @@ void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1
   g.rot_cos = rc; g.rot_sin = rs; g.Np = c->Np; g.H = 4;
   g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
   ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * w.K * w.N, (double)M * (w.K + w.N) * 2 + (double)w.K * w.N * 2);
-  launch_gemm(c->prec, w.K, trans, g, st);
+  launch_gemm(c->mprec, w.K, trans, g, st);
 }
 
 // The attention inputs of one layer: head-major q|k (`qk`, rotary when rc != nullptr; q -> qout, k -> kout, or both roles in qout
@@ -738,7 +743,7 @@ void run_qkv(airfe_ctx* c, const LinW& qk, const LinW& v, int M, void* qout, voi
   a.gr_wgs = b.gr_wgs = c->gemmr_wgs;
   if (c->qkv_pair && M >= c->gemmr_min && qk.K == 256 && v.K == 256 && gemmr_pair_applicable(a, b)) {
     ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * 256.0 * (qk.N + v.N), (double)M * (256 + qk.N + v.N) * 2 + 256.0 * (qk.N + v.N) * 2);
-    launch_gemmr_pair(c->prec, a, b, st);
+    launch_gemmr_pair(c->mprec, a, b, st);
     return;
   }
   run_linear(c, qk, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS, ACT_NONE, qout, 0, st, false, kout, nullptr, rc, rs);
@@ -751,12 +756,12 @@ void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, co
   a.attn = c->ob; a.xb = c->xb; a.x32 = c->x32; a.wo = out.w; a.w1 = f0.w; a.w2 = f3.w;
   a.bo = out.b; a.b1 = f0.b; a.gamma = g; a.beta = b; a.b2 = f3.b; a.M = M;
   ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * (256.0 * 256 + 512.0 * 512 + 512.0 * 256), (double)M * (512 + 512 + 1024 + 512 + 1024) + 917504.0);
-  launch_lg_blockf(c->prec, a, st);
+  launch_lg_blockf(c->mprec, a, st);
 }
 
 void lg_ffn(airfe_ctx* c, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st) {
   run_linear(c, f0, c->xb, 256, 256, c->msg, 256, M, EPI_STORE, ACT_NONE, c->hb, 512, st);
-  { ProfScope ps(c, ST_LG_LNGELU, st, 0, (double)M * 2048); launch_ln_gelu(c->prec, c->hb, g, b, M, st); }
+  { ProfScope ps(c, ST_LG_LNGELU, st, 0, (double)M * 2048); launch_ln_gelu(c->mprec, c->hb, g, b, M, st); }
   run_linear(c, f3, c->hb, 512, 512, nullptr, 0, M, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
 }
 
@@ -777,7 +782,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   pa.linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.5f);
   pa.wr = c->lg_wr; pa.B = B; pa.cap = cap; pa.Np = Np;
   pa.x32 = c->x32; pa.xb = c->xb; pa.rot_cos = c->rot_cos; pa.rot_sin = c->rot_sin; pa.lens = c->lens;
-  { ProfScope ps(c, ST_LG_PREPARE, st, 0, (double)M * (1036 + 1536 + 256)); launch_lg_prepare(c->prec, pa, st); }
+  { ProfScope ps(c, ST_LG_PREPARE, st, 0, (double)M * (1036 + 1536 + 256)); launch_lg_prepare(c->mprec, pa, st); }
   // The fused block (kernels_lgblockf.hip) streams 0.9 MB of weights per 128-token workgroup whatever the batch, so below 3200
   // tokens (4 pairs of 400) the four separate launches are quicker: 1.82 vs 1.85 ms per step at 3 pairs, 2.01 vs 1.98 at 4,
   // 2.65 vs 2.45 at 8 (profiles/r01d_small_batch_sweeps.txt).
@@ -785,7 +790,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   for (const LgLayer& l : c->lg) {
     // ---- self block
     run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, c->rot_cos, c->rot_sin, st);
-    { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
+    { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
     if (fused_block) {
       lg_blockf(c, l.out, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
     } else {
@@ -794,7 +799,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     }
     // ---- cross block (one shared projection for q and k; the two sides swap roles)
     run_qkv(c, l.cqk, l.cv, Mg, c->qb, nullptr, nullptr, nullptr, st);
-    { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->prec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
+    { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->mprec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
     if (fused_block) {
       lg_blockf(c, l.cout, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st);
     } else {
@@ -805,7 +810,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   run_linear(c, c->lg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
   ProfScope ps(c, ST_LG_ASSIGN, st, 2.0 * B * Np * (double)Np * 256, (double)B * Np * Np * 4 * 6);
   launch_rowdot256(c->x32, c->lg_mw, c->lg_mb, c->zbuf, M, st);
-  launch_sim(c->prec, c->mdb, c->simbuf, B, Np, st);
+  launch_sim(c->mprec, c->mdb, c->simbuf, B, Np, st);
   launch_lg_assign(c->simbuf, c->zbuf, c->lens, B, Np, mcap, 0.1f, c->rowlse, c->collse, scores_out, c->rowarg, c->rowval,
                    c->colarg, d_idx, d_score, d_nmatch, st);
   HIPCHK(c, hipGetLastError());
@@ -822,7 +827,7 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   const int Mg = (M + 127) / 128 * 128;
   const float cx = (float)(c->cfg.image_width / 2), cy = (float)(c->cfg.image_height / 2);
   const float linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.7f);   // point_matcher.cc:58
-  launch_sg_prepare(c->prec, f0, f1, n0, n1, AIRFE_FEAT_DIM, normalize, cx, cy, linv, c->sg_kenc, B, cap, Np, c->x32, c->xb,
+  launch_sg_prepare(c->mprec, f0, f1, n0, n1, AIRFE_FEAT_DIM, normalize, cx, cy, linv, c->sg_kenc, B, cap, Np, c->x32, c->xb,
                     c->lens, st);
   int li = 0;
   for (const SgLayer& l : c->sg) {
@@ -831,14 +836,14 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, nullptr, nullptr, st);
     {
       ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048);
-      launch_attention(c->prec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, cross, 0.125f, st);
+      launch_attention(c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, cross, 0.125f, st);
     }
     run_linear(c, l.merge, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
     run_linear(c, l.mlp0, c->xb, 256, 256, c->msg, 256, Mg, EPI_STORE, ACT_RELU, c->hb, 512, st);
     run_linear(c, l.mlp3, c->hb, 512, 512, nullptr, 0, Mg, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
   }
   run_linear(c, c->sg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
-  launch_sim(c->prec, c->mdb, c->simbuf, B, Np, st);
+  launch_sim(c->mprec, c->mdb, c->simbuf, B, Np, st);
   launch_sg_sinkhorn(c->simbuf, c->lens, B, Np, c->Lz, c->sg_alpha, c->cfg.sinkhorn_iters, c->sg_u, c->sg_v, c->sg_Z, st);
   launch_sg_decode(c->sg_Z, c->lens, B, Np, c->Lz, 0.2f, c->sg_idx0, c->sg_max0, c->sg_idx1, c->sg_out0, c->sg_out1, c->sg_ms0,
                    c->sg_ms1, st);
@@ -877,6 +882,7 @@ void airfe_default_cfg(airfe_cfg* cfg) {
   cfg->image_width = 752;
   cfg->image_height = 480;
   cfg->sinkhorn_iters = 100;
+  cfg->matcher_precision = 1;      // fp16, what the reference builds its matcher engines with (light_glue.cpp:115, super_glue.cpp:132)
 }
 
 const char* airfe_last_error(const airfe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
@@ -890,10 +896,14 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, "airfe_create: bad device ordinal");
   if (cfg->max_keypoints < 1 || cfg->max_keypoints > 1024) return fail(nullptr, "airfe_create: max_keypoints must be 1..1024");
   if (cfg->precision != 0 && cfg->precision != 1) return fail(nullptr, "airfe_create: precision must be 0 (bf16) or 1 (fp16)");
+  if (cfg->matcher_precision < -1 || cfg->matcher_precision > 1)
+    return fail(nullptr, "airfe_create: matcher_precision must be -1 (= precision), 0 (bf16) or 1 (fp16)");
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, "airfe_create: hipSetDevice failed");
   airfe_ctx* c = new airfe_ctx();
   c->cfg = *cfg;
   c->prec = cfg->precision;
+  c->mprec = cfg->matcher_precision < 0 ? cfg->precision : cfg->matcher_precision;
+  c->pack_prec = c->prec;
   c->Bmax = std::max(cfg->max_batch, 1);
   c->chunk = std::min(std::max(cfg->enc_chunk, 1), c->Bmax);
   c->Pmax = c->Bmax;
@@ -1056,6 +1066,28 @@ int airfe_match_lightglue(airfe_ctx* c, const float* f0, int n0, const float* f1
 
 int airfe_debug_lightglue_scores(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, float* scores) {
   return lg_host(c, f0, n0, f1, n1, nullptr, nullptr, 0, nullptr, scores);
+}
+
+/* filter_matches (src/light_glue.cpp:214-266) alone on one HOST score matrix [n0][n1] */
+int airfe_debug_lg_filter(airfe_ctx* c, const float* scores, int n0, int n1, int32_t* idx, float* score, int cap, int* nmatch) {
+  if (!c || !c->has_arena) return fail(c, "debug_lg_filter: no matcher loaded");
+  if (n0 < 1 || n1 < 1 || n0 > c->cfg.max_keypoints || n1 > c->cfg.max_keypoints || !scores || !idx || !score || !nmatch)
+    return fail(c, "debug_lg_filter: bad argument");
+  const int lens[2] = {n0, n1};
+  HIPCHK(c, hipMemcpyAsync(c->lens, lens, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(c->simbuf, (size_t)c->Np * 4, scores, (size_t)n1 * 4, (size_t)n1 * 4, n0, hipMemcpyHostToDevice, c->stream));
+  launch_lg_filter_scores(c->simbuf, c->lens, 1, c->Np, c->Np, 0.1f, c->rowarg, c->rowval, c->colarg, c->st_idx, c->st_score,
+                          c->st_nm, c->stream);
+  int nm = 0;
+  HIPCHK(c, hipMemcpyAsync(&nm, c->st_nm, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  nm = std::min(nm, cap);
+  if (nm > 0) {
+    HIPCHK(c, hipMemcpy(idx, c->st_idx, (size_t)nm * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(score, c->st_score, (size_t)nm * 4, hipMemcpyDeviceToHost));
+  }
+  *nmatch = nm;
+  return 0;
 }
 
 int airfe_match_lightglue_batch_dev(airfe_ctx* c, const float* d_f0, const int* d_n0, const float* d_f1, const int* d_n1,
@@ -1267,6 +1299,27 @@ static int sg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n
 int airfe_match_superglue(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx0, int32_t* idx1,
                           double* ms0, double* ms1) {
   return sg_host(c, f0, n0, f1, n1, idx0, idx1, ms0, ms1, nullptr);
+}
+
+/* decode (src/super_glue.cpp:339-367) alone on one HOST score matrix Z [n0+1][n1+1] */
+int airfe_debug_sg_decode(airfe_ctx* c, const float* Z, int n0, int n1, int32_t* idx0, int32_t* idx1, double* ms0, double* ms1) {
+  if (!c || !c->has_sg) return fail(c, "debug_sg_decode: SuperGlue not loaded");
+  if (n0 < 1 || n1 < 1 || n0 > c->cfg.max_keypoints || n1 > c->cfg.max_keypoints || !Z || !idx0 || !idx1 || !ms0 || !ms1)
+    return fail(c, "debug_sg_decode: bad argument");
+  const int lens[2] = {n0, n1};
+  HIPCHK(c, hipMemcpyAsync(c->lens, lens, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(c->sg_Z, (size_t)c->Lz * 4, Z, (size_t)(n1 + 1) * 4, (size_t)(n1 + 1) * 4, n0 + 1, hipMemcpyHostToDevice, c->stream));
+  launch_sg_decode(c->sg_Z, c->lens, 1, c->Np, c->Lz, 0.2f, c->sg_idx0, c->sg_max0, c->sg_idx1, c->sg_out0, c->sg_out1, c->sg_ms0,
+                   c->sg_ms1, c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<float> m0(n0), m1(n1);
+  HIPCHK(c, hipMemcpy(idx0, c->sg_out0, (size_t)n0 * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(idx1, c->sg_out1, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(m0.data(), c->sg_ms0, (size_t)n0 * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(m1.data(), c->sg_ms1, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n0; ++i) ms0[i] = (double)m0[i];
+  for (int j = 0; j < n1; ++j) ms1[j] = (double)m1[j];
+  return 0;
 }
 
 /* full SuperGlue output `scores` [n0+1][n1+1] (binding A.5) for one HOST pair */

@@ -145,6 +145,10 @@ void launch_lg_assign(const float* sim, const float* z, const int* lens, int B, 
                       float* rowlse, float* collse, float* scores_out, int* rowarg, float* rowval, int* colarg,
                       int32_t* idx, float* score, int* nmatch, hipStream_t st);
 
+// filter_matches alone on finished log-assignment matrices [B][Np][Np] (test hook)
+void launch_lg_filter_scores(const float* scores, const int* lens, int B, int Np, int cap, float thr, int* rowarg, float* rowval,
+                             int* colarg, int32_t* idx, float* score, int* nmatch, hipStream_t st);
+
 // ---- PLNet line path (src/plnet.cpp:272-307, 468-558) -------------------------------------------------------
 // table: [jn*jn] ints pre-filled with INT_MAX (left clean by the kernel); counts[0] = M1 kept, counts[1] = M2 unique
 void launch_wireframe(const float* iskeep, const float* imin, const float* imax, int n, int jn, int* table, int* keep,

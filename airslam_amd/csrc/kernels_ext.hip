@@ -1,5 +1,7 @@
 // airfe — PLNet line path (wireframe_matcher, stage-1 LOI head, line/junction filter) and the SuperGlue-specific
 // pieces (keypoint encoder, log-domain Sinkhorn, decode).  Small, irregular, fp32: VALU + LDS, no MFMA.
+#include <float.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -440,7 +442,7 @@ __global__ void sg_rowmax_kernel(const float* __restrict__ Z, const int* __restr
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
   if (i >= n0) return;
   const float* r = Z + ((size_t)b * Lz + i) * Lz;
-  float best = -INFINITY;
+  float best = -FLT_MAX;                       // super_glue.cpp:261: strict '<' from -FLT_MAX, index 0 when nothing exceeds it
   int bj = 0x7FFFFFFF;
   for (int j = lane; j < n1; j += 64) { const float v = r[j]; if (v > best) { best = v; bj = j; } }
 #pragma unroll
@@ -457,7 +459,7 @@ __global__ void sg_colmax_kernel(const float* __restrict__ Z, const int* __restr
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
   if (j >= n1) return;
   const float* c = Z + (size_t)b * Lz * Lz + j;
-  float best = -INFINITY;
+  float best = -FLT_MAX;
   int bi = 0;
   for (int i = 0; i < n0; ++i) { const float v = c[(size_t)i * Lz]; if (v > best) { best = v; bi = i; } }
   idx1[(size_t)b * Lz + j] = bi;

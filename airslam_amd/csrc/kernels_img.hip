@@ -293,8 +293,9 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restric
   }
   ss = wave_sum(ss);
   const float nrm = sqrtf(ss);
+  // Eigen (>= 3.3) colwise().normalize(): `if (squaredNorm() > 0) v /= sqrt(squaredNorm())` — a zero column stays zero, no NaN
 #pragma unroll
-  for (int j = 0; j < 4; ++j) f[3 + lane * 4 + j] = v[j] / nrm;
+  for (int j = 0; j < 4; ++j) f[3 + lane * 4 + j] = (ss > 0.f) ? v[j] / nrm : v[j];
   if (lane == 0) {
     f[1] = __fmul_rn(x, w_scale);
     f[2] = __fmul_rn(y, h_scale);

@@ -1,6 +1,8 @@
 // airfe — matcher kernels shared by LightGlue / SuperGlue: token preparation (+ Fourier positional
 // encoding), flash attention on MFMA (d_head = 64), LayerNorm+GELU, similarity GEMM, and the
 // LightGlue log-assignment + on-device filter_matches (src/light_glue.cpp:214-266).
+#include <float.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -413,14 +415,14 @@ __global__ void lg_rowarg_kernel(const float* __restrict__ sim, const float* __r
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
   if (i >= n0) return;
   const float* r = sim + ((size_t)b * Np + i) * Np;
-  const float rl = rowlse[(size_t)b * Np + i];
-  const float c0 = z[(size_t)(2 * b) * Np + i];
+  const float rl = rowlse ? rowlse[(size_t)b * Np + i] : 0.f;
+  const float c0 = rowlse ? z[(size_t)(2 * b) * Np + i] : 0.f;
   const float* z1 = z + (size_t)(2 * b + 1) * Np;
   const float* cl = collse + (size_t)b * Np;
-  float best = -INFINITY;
+  float best = -FLT_MAX;                       // light_glue.cpp:219: strict '>' from -FLT_MAX
   int bj = 0x7FFFFFFF;
   for (int j = lane; j < n1; j += 64) {
-    const float sc = lg_score(r[j], rl, cl[j], c0, z1[j]);
+    const float sc = rowlse ? lg_score(r[j], rl, cl[j], c0, z1[j]) : r[j];      // rowlse == nullptr: `sim` already holds scores
     if (scores_out) scores_out[((size_t)b * Np + i) * Np + j] = sc;
     if (sc > best) { best = sc; bj = j; }
   }
@@ -431,8 +433,9 @@ __global__ void lg_rowarg_kernel(const float* __restrict__ sim, const float* __r
     if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
   }
   if (lane == 0) {
+    // nothing above -FLT_MAX: row_max[row] keeps its value-initialised pair (0, 0.0f) (std::vector::resize, light_glue.cpp:217)
     rowarg[(size_t)b * Np + i] = (bj == 0x7FFFFFFF) ? 0 : bj;
-    rowval[(size_t)b * Np + i] = best;
+    rowval[(size_t)b * Np + i] = (bj == 0x7FFFFFFF) ? 0.f : best;
   }
 }
 
@@ -447,15 +450,15 @@ __global__ __launch_bounds__(64 * LG_CS) void lg_colarg_kernel(const float* __re
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
   const float* z0 = z + (size_t)(2 * b) * Np;
   const bool live = j < n1;
-  float best = -INFINITY;
+  float best = -FLT_MAX;
   int bi = 0x7FFFFFFF;
   if (live) {
     const float* c = sim + (size_t)b * Np * Np + j;
-    const float cl = collse[(size_t)b * Np + j];
-    const float c1 = z[(size_t)(2 * b + 1) * Np + j];
+    const float cl = rowlse ? collse[(size_t)b * Np + j] : 0.f;
+    const float c1 = rowlse ? z[(size_t)(2 * b + 1) * Np + j] : 0.f;
     const float* rl = rowlse + (size_t)b * Np;
     for (int i = q; i < n0; i += LG_CS) {
-      const float sc = lg_score(c[(size_t)i * Np], rl[i], cl, z0[i], c1);
+      const float sc = rowlse ? lg_score(c[(size_t)i * Np], rl[i], cl, z0[i], c1) : c[(size_t)i * Np];
       if (sc > best) { best = sc; bi = i; }
     }
   }
@@ -517,6 +520,16 @@ void launch_lg_assign(const float* sim, const float* z, const int* lens, int B, 
   hipLaunchKernelGGL(lg_colarg_kernel, dim3((Np + 63) / 64, B), dim3(64 * LG_CS), 0, st, sim, z, lens, Np, rowlse, collse, colarg);
   hipLaunchKernelGGL(lg_filter_kernel, dim3(B), dim3(1024), 0, st, lens, Np, cap, thr, rowarg, rowval, colarg, idx, score,
                      nmatch);
+}
+
+// filter_matches alone on finished score matrices [B][Np][Np] (test hook: hand-built ties, -inf, threshold-exact values)
+void launch_lg_filter_scores(const float* scores, const int* lens, int B, int Np, int cap, float thr, int* rowarg, float* rowval,
+                             int* colarg, int32_t* idx, float* score, int* nmatch, hipStream_t st) {
+  hipLaunchKernelGGL(lg_rowarg_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, scores, (const float*)nullptr, lens, Np,
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, rowarg, rowval);
+  hipLaunchKernelGGL(lg_colarg_kernel, dim3((Np + 63) / 64, B), dim3(64 * LG_CS), 0, st, scores, (const float*)nullptr, lens, Np,
+                     (const float*)nullptr, (const float*)nullptr, colarg);
+  hipLaunchKernelGGL(lg_filter_kernel, dim3(B), dim3(1024), 0, st, lens, Np, cap, thr, rowarg, rowval, colarg, idx, score, nmatch);
 }
 
 }  // namespace airfe

@@ -79,6 +79,7 @@ def lightglue_spec(n_layers: int = LG_LAYERS) -> Spec:
 
 
 SG_LAYERS = 18
+SG_RES_GAIN, SG_KENC_GAIN, SG_FINAL_DIAG = 0.06, 0.1, 16.0     # structured synthetic weights (synthetic_superglue)
 
 
 def superglue_spec(n_layers: int = SG_LAYERS) -> Spec:
@@ -142,28 +143,100 @@ def synthetic(spec: Spec, seed: int = 1234, gain: float = 1.0) -> Dict[str, np.n
     return out
 
 
-def synthetic_superpoint(seed: int = 1234) -> Dict[str, np.ndarray]:
-    w = synthetic(superpoint_spec(), seed)
-    # Make the heat map look like a trained detector's: strong dustbin, peaky logits.
-    rng = np.random.default_rng(seed + 1)
-    w["convPb.weight"] = (w["convPb.weight"] * 6.0).astype(np.float32)
-    b = rng.uniform(-0.5, 0.5, size=(65,)).astype(np.float32)
-    b[64] = 4.0
-    w["convPb.bias"] = b
-    return w
+def _whiten_descriptor_head(w: Dict[str, np.ndarray], seed: int, lam: float = 1.0, size: int = 512) -> None:
+    """Data-dependent initialisation of the descriptor head (LSUV-style: Mishkin & Matas, "All you need is a good init").
+
+    A randomly initialised VGG trunk produces dense descriptors that are almost collinear (cosine 0.9 +- 0.1 between ANY
+    two cells: one common-mode direction carries the norm), so no matcher can tell keypoints apart and every end-to-end run
+    ends with zero matches.  One forward pass of the seeded trunk over a seeded calibration image gives the mean and the
+    covariance C of the raw `convDb` outputs; `convDb` is then composed with the regularised whitening
+    A = (C + lam * mean(eig C) * I)^-1/2 and the mean is folded into its bias.  After this the descriptors of a synthetic
+    stereo pair have cosine ~0 +- 0.2 between unrelated cells and ~0.9 between corresponding ones — what a trained
+    SuperPoint delivers — and the SHAPES, FLOPs and kernels are unchanged.  torch is used as plumbing for the conv stack."""
+    import torch
+    import torch.nn.functional as Fn
+
+    from . import synth
+    # the calibration image goes the way every frame goes: a 752x480 synthetic frame resized to the internal 512x512
+    img = synth.gabor_image(480, 752, seed + 4321).astype(np.float32) / np.float32(255.0)
+    with torch.no_grad():
+        x = Fn.interpolate(torch.from_numpy(img)[None, None], size=(size, size), mode="bilinear", align_corners=False)
+        for name in ("conv1a", "conv1b", None, "conv2a", "conv2b", None, "conv3a", "conv3b", None, "conv4a", "conv4b", "convDa"):
+            if name is None:
+                x = Fn.max_pool2d(x, 2, 2)
+            else:
+                x = Fn.relu(Fn.conv2d(x, torch.from_numpy(w[name + ".weight"]), torch.from_numpy(w[name + ".bias"]), padding=1))
+        d = Fn.conv2d(x, torch.from_numpy(w["convDb.weight"]), torch.from_numpy(w["convDb.bias"]))
+    D = d[0].reshape(256, -1).numpy().astype(np.float64)
+    mean = D.mean(1)
+    ev, U = np.linalg.eigh(np.cov(D))
+    ev = np.maximum(ev, 0.0)
+    A = (U * (1.0 / np.sqrt(ev + lam * ev.mean()))[None, :]) @ U.T
+    W = w["convDb.weight"].reshape(256, 256).astype(np.float64)
+    w["convDb.weight"] = (A @ W).reshape(256, 256, 1, 1).astype(np.float32)
+    w["convDb.bias"] = (A @ (w["convDb.bias"].astype(np.float64) - mean)).astype(np.float32)
 
 
-def synthetic_lightglue(seed: int = 1234, n_layers: int = LG_LAYERS) -> Dict[str, np.ndarray]:
+_SP_CACHE: Dict[Tuple[int, bool], Dict[str, np.ndarray]] = {}
+
+
+def synthetic_superpoint(seed: int = 1234, structured: bool = True) -> Dict[str, np.ndarray]:
+    """Seeded SuperPoint weights.  `structured` (default): detector logits shaped like a trained detector's and a
+    whitened descriptor head (`_whiten_descriptor_head`), so that stereo pairs produce matchable descriptors;
+    structured=False is the plain He-uniform draw of round 1 (descriptors nearly collinear)."""
+    key = (seed, structured)
+    if key not in _SP_CACHE:
+        w = synthetic(superpoint_spec(), seed)
+        # Make the heat map look like a trained detector's: strong dustbin, peaky logits.
+        rng = np.random.default_rng(seed + 1)
+        w["convPb.weight"] = (w["convPb.weight"] * 6.0).astype(np.float32)
+        b = rng.uniform(-0.5, 0.5, size=(65,)).astype(np.float32)
+        b[64] = 4.0
+        w["convPb.bias"] = b
+        if structured:
+            _whiten_descriptor_head(w, seed)
+        _SP_CACHE[key] = w
+    return {k: v.copy() for k, v in _SP_CACHE[key].items()}
+
+
+def synthetic_lightglue(seed: int = 1234, n_layers: int = LG_LAYERS, structured: bool = True) -> Dict[str, np.ndarray]:
+    """Seeded LightGlue weights.  Every tensor is a He-uniform draw (gain 0.6); `structured` (default) then shapes three
+    things so that the network MATCHES instead of rejecting everything (a Kaiming `final_proj` gives log-assignments of
+    -6 .. -20 on every pair: 0-11 matches out of 200 planted correspondences, which left filter_matches untested):
+      * ffn.3 of every block is scaled by 0.06 — residual updates of ~0.3 per block, |x| grows 1 -> ~3 over 18 blocks, the
+        transformer output carries two thirds of the final state (cos(x, descriptor) ~0.33), and activations stay in the
+        range trained LightGlue layers keep them in (the plain draw lets |x| reach 37 with one common direction);
+      * final_proj = 12 I + draw: similarity ~ 9 <x0, x1>, a confident but finite softmax (planted pairs sit 8-12 above
+        the log-sum-exp of their row / column);
+      * matchability: weight / 10, bias +4  (sigmoid ~0.98, like keypoints a trained head believes in).
+    Oracle (fp32) on the planted-correspondence generator of tests/test_gpu_lightglue.py: 203 matches at N = 400,
+    514 at N = 1024."""
     w = synthetic(lightglue_spec(n_layers), seed + 10, gain=0.6)
     rng = np.random.default_rng(seed + 11)
     # upstream init: normal(0, gamma^-2), gamma = 1
     w["posenc.Wr.weight"] = rng.normal(0.0, 1.0, size=(32, 2)).astype(np.float32)
+    if structured:
+        for k in w:
+            if k.endswith("ffn.3.weight"):
+                w[k] = (w[k] * np.float32(0.06)).astype(np.float32)
+        a = f"log_assignment.{n_layers - 1}"
+        w[a + ".final_proj.weight"] = (w[a + ".final_proj.weight"] + np.float32(12.0) * np.eye(LG_DIM, dtype=np.float32)).astype(np.float32)
+        w[a + ".matchability.weight"] = (w[a + ".matchability.weight"] * np.float32(0.1)).astype(np.float32)
+        w[a + ".matchability.bias"] = np.array([4.0], dtype=np.float32)
     return w
 
 
-def synthetic_superglue(seed: int = 1234, n_layers: int = SG_LAYERS) -> Dict[str, np.ndarray]:
+def synthetic_superglue(seed: int = 1234, n_layers: int = SG_LAYERS, structured: bool = True) -> Dict[str, np.ndarray]:
+    """Seeded SuperGlue weights; `structured` as for LightGlue: mlp.3 of every layer and the keypoint encoder's last layer
+    scaled down (the descriptor stays the dominant part of the state), final_proj = c I + draw, low dustbin score."""
     w = synthetic(superglue_spec(n_layers), seed + 20, gain=0.6)
     w["bin_score"] = np.array([1.0], dtype=np.float32)
+    if structured:
+        for k in w:
+            if k.endswith("mlp.3.weight"):
+                w[k] = (w[k] * np.float32(SG_RES_GAIN)).astype(np.float32)
+        w["kenc.encoder.4.weight"] = (w["kenc.encoder.4.weight"] * np.float32(SG_KENC_GAIN)).astype(np.float32)
+        w["final_proj.weight"] = (w["final_proj.weight"] + np.float32(SG_FINAL_DIAG) * np.eye(256, dtype=np.float32)).astype(np.float32)
     return w
 
 

@@ -25,45 +25,52 @@ PEAK_MFMA_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROAR
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(sp, lg, h, w, n_pairs, max_kp):
+def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3):
     """The CPU oracle (PyTorch-CPU fp32 networks + numpy restatement of the reference's C++ post-processing) timed on
-    the host cores, on a bounded sample of the same workload."""
+    the host cores, on a bounded sample of the same workload: `warm` untimed pairs, then the MEDIAN per-pair time of
+    `n_pairs` pairs (median of >= 20 after 3 warm-ups)."""
     from airslam_amd import synth
     from oracle import ref_nets, ref_post
     torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads than this only adds sync overhead at batch 1
     base = synth.stereo_pair(h, w, 100)
-    pairs = [(np.roll(base[0], 7 * i, axis=1), np.roll(base[1], 7 * i, axis=1)) for i in range(n_pairs + 1)]   # inputs ready before the clock
-    t0 = 0.0
+    pairs = [(np.roll(base[0], 7 * i, axis=1), np.roll(base[1], 7 * i, axis=1)) for i in range(n_pairs + warm)]   # inputs ready before the clock
+    times, nmatch = [], []
     for i, (left, right) in enumerate(pairs):
-        if i == 1:
-            t0 = time.perf_counter()                   # pair 0 is the warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
         feats = []
         for img in (left, right):
             x, ws, hs = ref_post.process_image(img)
             heat, desc = ref_nets.superpoint_forward(sp, x[None])
             feats.append(ref_post.keypoints_decoder(ref_post.simple_nms(heat[0], 4), desc[0], 0.004, 4, max_kp, ws, hs))
+        k = 0
         if feats[0].shape[0] and feats[1].shape[0]:
             a = ref_post.normalize_keypoints(feats[0], w, h, 0.5)
             b = ref_post.normalize_keypoints(feats[1], w, h, 0.5)
             s = ref_nets.lightglue_forward(lg, a[:, 1:3], a[:, 3:], b[:, 1:3], b[:, 3:])
-            ref_post.filter_matches(s, 0.1)
-    dt = time.perf_counter() - t0
-    return dict(value=n_pairs / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n_pairs} synthetic {w}x{h} stereo pairs after 1 warm-up, fp32 PyTorch-CPU oracle + numpy post-processing, {dt:.1f} s")
+            k = len(ref_post.filter_matches(s, 0.1)[0])
+        if i >= warm:                                   # the first pairs warm the thread pool and the allocator
+            times.append(time.perf_counter() - t0)
+            nmatch.append(k)
+    med = float(np.median(times))
+    return dict(value=1.0 / med, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"median of {n_pairs} synthetic {w}x{h} stereo pairs after {warm} warm-ups ({sum(times):.1f} s), fp32 PyTorch-CPU "
+                       f"oracle + numpy post-processing, {float(np.mean(nmatch)):.0f} matches per pair")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=752)
     ap.add_argument("--max-keypoints", type=int, default=400)
     ap.add_argument("--chunk", type=int, default=32, help="images per pass through the full-resolution conv layers")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--cpu-pairs", type=int, default=16, help="CPU-baseline sample size (0 = skip)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="detector (encoder) storage type")
+    ap.add_argument("--matcher-dtype", default="fp16", choices=["bf16", "fp16"],
+                    help="matcher storage type (fp16 = the reference's kFP16 engines, light_glue.cpp:115)")
+    ap.add_argument("--cpu-pairs", type=int, default=20, help="CPU-baseline sample size (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--stage-steps", type=int, default=3, help="extra untimed steps for the per-stage table")
     args = ap.parse_args()
@@ -81,7 +88,8 @@ def main():
 
     sp = weights.synthetic_superpoint(1234)
     lg = weights.synthetic_lightglue(1234)
-    ctx = api.Context(superpoint=sp, lightglue=lg, device=local, precision=1 if args.dtype == "fp16" else 0, max_batch=B,
+    ctx = api.Context(superpoint=sp, lightglue=lg, device=local, precision=1 if args.dtype == "fp16" else 0,
+                      matcher_precision=1 if args.matcher_dtype == "fp16" else 0, max_batch=B,
                       enc_chunk=args.chunk, max_keypoints=K, image_width=W, image_height=H)
 
     ls, rs = synth.stereo_batch(B, H, W, 1000 + rank)
@@ -139,7 +147,8 @@ def main():
             "metric": "stereo detect+match pairs/sec (2x SuperPoint-VGG detect @512x512 internal + LightGlue match)",
             "value": total_pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype if args.dtype == args.matcher_dtype else f"{args.dtype} (encoder) + {args.matcher_dtype} (matcher), fp32 accumulate",
+            "data": "synthetic",
             "config": {"workload": f"{B} synthetic {W}x{H} uint8 stereo pairs per step per GPU, resident in HBM; "
                                    f"max_keypoints={K}, nms_radius=4, LightGlue 9 layers; seeded synthetic weights "
                                    f"(reference ONNX files are absent)",

@@ -48,6 +48,9 @@ typedef struct airfe_cfg {
   const char* plnet_s1_pack;
   const char* lightglue_pack;
   const char* superglue_pack;
+  int matcher_precision;       /* storage type of the LightGlue / SuperGlue tokens and weights: 1 = fp16 (default: the reference builds
+                                  both matcher engines with BuilderFlag::kFP16, light_glue.cpp:115, super_glue.cpp:132; measured 8x
+                                  closer to the fp32 oracle than bf16), 0 = bf16, -1 = same as `precision` */
 } airfe_cfg;
 
 void airfe_default_cfg(airfe_cfg* cfg);
@@ -142,6 +145,10 @@ int airfe_profile_read(airfe_ctx* ctx, double* ms, double* flops, double* bytes,
 int airfe_debug_detector_maps(airfe_ctx* ctx, int B, float* heat_raw, float* heat_nms, float* desc);
 /* run LightGlue on one HOST pair (258-float rows) and return the full log-assignment scores [n0][n1] */
 int airfe_debug_lightglue_scores(airfe_ctx* ctx, const float* f0, int n0, const float* f1, int n1, float* scores);
+/* the post-processing kernels alone on HOST score matrices (hand-built ties, -inf rows, threshold-exact values):
+ *   filter_matches (src/light_glue.cpp:214-266) on scores [n0][n1]; decode (src/super_glue.cpp:339-367) on Z [n0+1][n1+1] */
+int airfe_debug_lg_filter(airfe_ctx* ctx, const float* scores, int n0, int n1, int32_t* idx, float* score, int cap, int* nmatch);
+int airfe_debug_sg_decode(airfe_ctx* ctx, const float* Z, int n0, int n1, int32_t* idx0, int32_t* idx1, double* ms0, double* ms1);
 /* kernel-level checks on HOST fp32 tensors (test only): NCHW conv3x3(+ReLU, optional 2x2 max-pool) and
  *   y[M][N] = x[M][K] w[N][K]^T + b through the same MFMA kernels the pipelines use. */
 /* SuperGlue on one HOST pair ([n][259] rows, normalised x,y): the engine's `scores` output [n0+1][n1+1] */

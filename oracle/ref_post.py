@@ -154,8 +154,8 @@ def extract_descriptors(desc_chw: np.ndarray, xs: np.ndarray, ys: np.ndarray, s:
     v = (v + (d[:, iy_sw, ix_sw] * sw_[None]).astype(F)).astype(F)
     v = (v + (d[:, iy_se, ix_se] * se[None]).astype(F)).astype(F)      # [256, N]
     nrm = np.sqrt(np.sum((v * v).astype(F), axis=0, dtype=F)).astype(F)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        v = (v / nrm[None]).astype(F)                                  # Eigen normalize(): no epsilon
+    # Eigen >= 3.3 colwise().normalize(): `if (squaredNorm() > 0) derived() /= sqrt(...)` — a zero column stays zero
+    v = np.where(nrm[None] > 0, (v / np.where(nrm > 0, nrm, F(1))[None]).astype(F), v).astype(F)
     return np.ascontiguousarray(v.T)
 
 
@@ -255,15 +255,32 @@ def normalize_keypoints(feat: np.ndarray, width: int, height: int, scale: float)
     return out
 
 
+_FLT_MAX = np.finfo(np.float32).max
+
+
+def _first_max_above_floor(m: np.ndarray, axis: int):
+    """The reference's arg-max loops: `max = -FLT_MAX; if (v > max) {max = v; arg = j}` — first maximum wins, and an entry
+    that does not EXCEED -FLT_MAX (-inf, -FLT_MAX itself, NaN) never becomes the maximum.  Returns (arg, max, found)."""
+    above = m > -_FLT_MAX                                  # NaN compares false, like the C++
+    mm = np.where(above, m, -np.inf)
+    arg = np.argmax(mm, axis=axis)                         # np.argmax returns the first maximum
+    found = above.any(axis=axis)
+    val = np.take_along_axis(mm, np.expand_dims(arg, axis), axis).squeeze(axis)
+    return np.where(found, arg, 0), val, found
+
+
 def filter_matches(scores: np.ndarray, threshold: float = 0.1):
     """filter_matches src/light_glue.cpp:214-266: strict '>' from -FLT_MAX (first max wins), mutual check,
-    exp(max) > threshold, ascending row order.  Returns (idx [K,2] int32, score [K] float32)."""
+    exp(max) > threshold, ascending row order.  A row/column with nothing above -FLT_MAX keeps the value-initialised
+    pair (0, 0.0f) that `row_max.resize()` gave it (:217,232) — i.e. it points at column/row 0 with score 0 -> exp = 1.
+    Returns (idx [K,2] int32, score [K] float32)."""
     n0, n1 = scores.shape
     if n0 == 0 or n1 == 0:
         return np.zeros((0, 2), np.int32), np.zeros((0,), F)
-    rcol = np.argmax(scores, axis=1)           # np.argmax returns the first maximum
-    rval = scores[np.arange(n0), rcol]
-    crow = np.argmax(scores, axis=0)
+    s = scores.astype(F)
+    rcol, rval, rfound = _first_max_above_floor(s, 1)
+    rval = np.where(rfound, rval, F(0)).astype(F)
+    crow, _, _ = _first_max_above_floor(s, 0)
     rows = np.arange(n0)
     mutual = crow[rcol] == rows
     e = np.exp(rval.astype(F)).astype(F)
@@ -273,17 +290,20 @@ def filter_matches(scores: np.ndarray, threshold: float = 0.1):
 
 
 def superglue_decode(scores: np.ndarray, threshold: float = 0.2):
-    """decode src/super_glue.cpp:339-367 on scores [h,w] (h=N0+1, w=N1+1): uses rows 0..h-2, cols 0..w-2."""
+    """decode src/super_glue.cpp:339-367 on scores [h,w] (h=N0+1, w=N1+1): uses rows 0..h-2, cols 0..w-2;
+    max_matrix (:258-286): strict '<' from -FLT_MAX, index 0 / value -FLT_MAX when nothing exceeds it."""
     h, w = scores.shape
-    inner = scores[:h - 1, :w - 1]
+    inner = scores[:h - 1, :w - 1].astype(F)
     if inner.size == 0:
         return (np.zeros(h - 1, np.int32), np.zeros(w - 1, np.int32),
                 np.zeros(h - 1, np.float64), np.zeros(w - 1, np.float64))
-    idx0 = np.argmax(inner, axis=1); max0 = inner[np.arange(h - 1), idx0]
-    idx1 = np.argmax(inner, axis=0)
+    idx0, max0, f0 = _first_max_above_floor(inner, 1)
+    max0 = np.where(f0, max0, -_FLT_MAX).astype(F)
+    idx1, _, _ = _first_max_above_floor(inner, 0)
     mutual0 = idx1[idx0] == np.arange(h - 1)
     mutual1 = idx0[idx1] == np.arange(w - 1)
-    ms0 = np.where(mutual0, np.exp(max0.astype(F)).astype(F), F(0)).astype(F)
+    with np.errstate(under="ignore"):
+        ms0 = np.where(mutual0, np.exp(max0.astype(F)).astype(F), F(0)).astype(F)
     ms1 = np.where(mutual1, ms0[idx1], F(0)).astype(F)
     valid0 = mutual0 & (ms0 > F(threshold))
     valid1 = mutual1 & valid0[idx1]

@@ -15,16 +15,30 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _payload(rank, b=3, cap=400):
+    """What a rank holds after a step: the oracle's match lists of `b` planted pairs, in the device's [b][cap] buffer layout
+    (~200 matches each) — the real size and shape of the gather, not a toy."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from airslam_amd import weights
+    from oracle import ref_nets, ref_post
+    from planted import normalised, planted_pair
+    lg = weights.synthetic_lightglue(1234, n_layers=2)
+    idx = np.zeros((b, cap, 2), np.int32); sc = np.zeros((b, cap), np.float32); nm = np.zeros((b,), np.int32)
+    for i in range(b):
+        f0, f1 = planted_pair(400 - 17 * i, 400 - 9 * rank, 1000 * rank + i)
+        a, c = normalised(f0)[:, 1:], normalised(f1)[:, 1:]
+        m, s = ref_post.filter_matches(ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], c[:, :2], c[:, 2:], n_layers=2), 0.1)
+        nm[i] = len(m); idx[i, :len(m)] = m; sc[i, :len(m)] = s
+    return idx, sc, nm
+
+
+def _worker(rank, world, port, q, payload):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     from airslam_amd import dist as adist
     r, w, _ = adist.init_from_env("gloo")
-    rng = np.random.default_rng(rank)
-    b, cap = 3, 16
-    nm = torch.tensor(rng.integers(0, cap, b), dtype=torch.int32)
-    idx = torch.tensor(rng.integers(0, 400, (b, cap, 2)), dtype=torch.int32)
-    sc = torch.tensor(rng.random((b, cap)), dtype=torch.float32)
+    idx, sc, nm = (torch.from_numpy(x) for x in payload)
     out = adist.gather_matches(idx, sc, nm, dst=0)
     lo, hi = adist.shard_range(10, r, w)
     mx = adist.max_over_ranks(float(rank + 1), torch.device("cpu"))
@@ -41,7 +55,9 @@ def test_gather_matches_gloo_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    payloads = [_payload(r) for r in range(2)]
+    assert min(int(p[2].min()) for p in payloads) >= 100, "the gather must carry real match lists"
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, payloads[r])) for r in range(2)]
     for p in ps:
         p.start()
     res = [q.get(timeout=120) for _ in range(2)]
@@ -51,10 +67,9 @@ def test_gather_matches_gloo_world2():
     full = [r for r in res if len(r) == 5][0]
     other = [r for r in res if len(r) == 2][0]
     gi, gs, gn, rng0, mx = full
-    assert gi.shape == (6, 16, 2) and gs.shape == (6, 16) and gn.shape == (6,)
+    assert gi.shape == (6, 400, 2) and gs.shape == (6, 400) and gn.shape == (6,)
     for rank in range(2):
-        rng = np.random.default_rng(rank)
-        nm = rng.integers(0, 16, 3); idx = rng.integers(0, 400, (3, 16, 2)); sc = rng.random((3, 16)).astype(np.float32)
+        idx, sc, nm = payloads[rank]
         np.testing.assert_array_equal(gn[rank * 3:(rank + 1) * 3], nm)
         np.testing.assert_array_equal(gi[rank * 3:(rank + 1) * 3], idx)
         np.testing.assert_array_equal(gs[rank * 3:(rank + 1) * 3], sc)

@@ -1,38 +1,54 @@
-"""LightGlue parity on the GPU (C ABI) vs the CPU oracle; filter_matches is checked bit-exact on the device's
-own score matrix."""
+"""LightGlue parity on the GPU (C ABI) vs the CPU oracle.  The structured synthetic weights make the planted half of every
+pair match (203 matches at N = 400, 514 at N = 1024 in the oracle), so filter_matches, the match buffers and the batch paths
+are exercised on hundreds of entries; match INDEX SETS must be identical to the fp32 oracle's."""
+import math
+
 import numpy as np
 import pytest
 
 from gpu_common import context, diag
 from oracle import ref_nets, ref_post
+from planted import fragile_rows, normalised, planted_pair
 
 pytestmark = pytest.mark.gpu
 
-
-def _features(n, seed, w=752, h=480):
-    rng = np.random.default_rng(seed)
-    d = rng.normal(size=(n, 256)).astype(np.float32)
-    d /= np.linalg.norm(d, axis=1, keepdims=True)
-    xy = np.stack([rng.uniform(4, w - 4, n), rng.uniform(4, h - 4, n)], 1).astype(np.float32)
-    f = np.zeros((n, 259), np.float32)
-    f[:, 0] = rng.uniform(0.01, 1, n)
-    f[:, 1:3] = xy
-    f[:, 3:] = d
-    return f
+# Gates, absolute, in log-assignment units (the filter threshold is log 0.1 = -2.303):
+#   matcher_precision = 1 (fp16, the default = the reference's kFP16 engines): 0.05
+#   matcher_precision = 0 (bf16): 0.5 — eight mantissa bits; measured ~0.3, an emulation of the rounding points
+#   (tools/lg_precision_bisect.py) attributes it evenly to weights, the token shadow and the FFN hidden state
+TOL = {1: 0.05, 0: 0.5}
 
 
 def _pair(n0, n1, seed):
-    f0 = _features(n0, seed)
-    f1 = _features(n1, seed + 1)
-    k = min(n0, n1) // 2                      # plant true correspondences so that matches exist
-    rng = np.random.default_rng(seed + 2)
-    f1[:k, 3:] = f0[:k, 3:] + 0.05 * rng.normal(size=(k, 256)).astype(np.float32)
-    f1[:k, 3:] /= np.linalg.norm(f1[:k, 3:], axis=1, keepdims=True)
-    f1[:k, 1] = f0[:k, 1] - 12
-    f1[:k, 2] = f0[:k, 2]
-    n0f = ref_post.normalize_keypoints(f0, 752, 480, 0.5)
-    n1f = ref_post.normalize_keypoints(f1, 752, 480, 0.5)
+    f0, f1 = planted_pair(n0, n1, seed)
+    n0f, n1f = normalised(f0), normalised(f1)
     return f0, f1, np.ascontiguousarray(n0f[:, 1:]), np.ascontiguousarray(n1f[:, 1:])
+
+
+def _check_against_oracle(name, s, ref, idx, sc, tol, min_matches):
+    """scores within `tol` of the oracle everywhere; filter_matches reproduced exactly on the device's own scores; match index
+    set identical to the oracle's, except rows the oracle itself decides within the tolerance (must be a negligible share)."""
+    err = np.abs(s - ref)
+    ridx, rsc = ref_post.filter_matches(ref, 0.1)
+    didx, dsc = ref_post.filter_matches(s, 0.1)
+    frag = fragile_rows(ref, tol)
+    dev = {tuple(p) for p in idx if p[0] not in frag}
+    want = {tuple(p) for p in ridx if p[0] not in frag}
+    diag(name, max_err=err.max(), mean_err=err.mean(), ref_absmax=np.abs(ref).max(), n_dev=len(idx), n_ref=len(ridx),
+         fragile=len(frag), identical=(dev == want), nan=int(np.isnan(s).sum()))
+    assert not np.isnan(s).any()
+    np.testing.assert_array_equal(idx, didx)
+    np.testing.assert_allclose(sc, dsc, rtol=2e-6)
+    assert err.max() <= tol, "log-assignment scores drifted from the fp32 oracle"
+    assert len(ridx) >= min_matches, "the planted correspondences must come out as matches in the oracle"
+    assert len(frag) <= max(2, int(len(ridx) * (0.02 if tol <= 0.05 else 0.06)))
+    assert dev == want, f"match sets differ: device-only {sorted(dev - want)[:5]}, oracle-only {sorted(want - dev)[:5]}"
+    # scores of the common matches agree as probabilities too
+    common = sorted(dev & want)
+    ds = {tuple(p): v for p, v in zip(idx, sc)}
+    rs = {tuple(p): v for p, v in zip(ridx, rsc)}
+    if common:
+        assert max(abs(ds[c] - rs[c]) for c in common) <= 1.5 * tol
 
 
 # A context picks the LightGlue block form by token count (fused lg_blockf_kernel from 3200 tokens, four launches below);
@@ -40,27 +56,37 @@ def _pair(n0, n1, seed):
 FORMS = [{"AIRFE_FUSE_LG_BLOCK": "1"}, {"AIRFE_FUSE_LG_BLOCK": "0"}]
 
 
+@pytest.mark.parametrize("mprec", [1, 0], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("env", FORMS, ids=["fused_block", "four_launches"])
-@pytest.mark.parametrize("n0,n1", [(400, 400), (317, 400), (64, 65), (1, 5), (2, 1)])
-def test_lightglue_scores_vs_oracle(n0, n1, env):
-    ctx, _, lg = context("lg", env=env, max_batch=4)
+@pytest.mark.parametrize("n0,n1,min_matches", [(400, 400, 150), (317, 400, 110), (64, 65, 20), (1, 5, 0), (2, 1, 0)])
+def test_lightglue_scores_vs_oracle(n0, n1, min_matches, env, mprec):
+    ctx, _, lg = context("lg", env=env, max_batch=4, matcher_precision=mprec)
     _, _, a, b = _pair(n0, n1, n0 * 3 + n1)
     s = ctx.lightglue_scores(a, b)
     ref = ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
-    err = np.abs(s - ref)
     idx, sc = ctx.match_lightglue(a, b)
-    ridx, rsc = ref_post.filter_matches(ref, 0.1)
-    # filter_matches on the DEVICE scores must be reproduced exactly (index work)
-    didx, dsc = ref_post.filter_matches(s, 0.1)
-    agree = len(set(map(tuple, idx)) & set(map(tuple, ridx))) / max(len(ridx), 1)
-    diag(f"lg_scores_{n0}_{n1}_{'fused' if env['AIRFE_FUSE_LG_BLOCK'] == '1' else 'split'}", max_err=err.max(), mean_err=err.mean(), ref_absmax=np.abs(ref).max(), n_dev=len(idx),
-         n_ref=len(ridx), match_agreement=agree, nan=int(np.isnan(s).sum()))
-    assert not np.isnan(s).any()
-    np.testing.assert_array_equal(idx, didx)
-    np.testing.assert_allclose(sc, dsc, rtol=2e-6)
-    assert err.max() <= 0.05 * max(1.0, np.abs(ref).mean()), "log-assignment scores drifted from the fp32 oracle"
-    if len(ridx) >= 10:
-        assert agree >= 0.9
+    _check_against_oracle(f"lg_scores_{n0}_{n1}_{'fused' if env['AIRFE_FUSE_LG_BLOCK'] == '1' else 'split'}_{'fp16' if mprec else 'bf16'}",
+                          s, ref, idx, sc, TOL[mprec], min_matches)
+
+
+@pytest.mark.parametrize("name", ["ties_threshold_inf_row", "all_minus_inf", "all_equal_below", "all_equal_above",
+                                  "random_with_floor_nan", "single", "one_row"])
+def test_filter_kernels_on_hand_built_scores(name):
+    """lg_rowarg / lg_colarg / lg_filter straight on score matrices with ties, -inf rows, -FLT_MAX, NaN and values one ulp
+    either side of log(0.1): must equal the oracle (itself pinned to the C++ loops in tests/test_structured_weights_cpu.py)."""
+    from test_structured_weights_cpu import hand_built_score_matrices
+    ctx, _, _ = context("lg", max_batch=4)
+    s = hand_built_score_matrices()[name]
+    idx, sc = ctx.debug_lg_filter(s)
+    ridx, rsc = ref_post.filter_matches(s, 0.1)
+    # float32 exp on the device vs numpy may differ in the last bit exactly AT the threshold; everywhere else bit-for-bit
+    thr_rows = {i for i in range(s.shape[0]) if np.isfinite(s[i]).any() and abs(float(np.nanmax(s[i])) - math.log(0.1)) < 1e-6}
+    keep = lambda pairs: [tuple(p) for p in pairs if p[0] not in thr_rows]
+    assert keep(idx) == keep(ridx)
+    m = {tuple(p): v for p, v in zip(ridx, rsc)}
+    for p, v in zip(idx, sc):
+        if tuple(p) in m and p[0] not in thr_rows:
+            np.testing.assert_allclose(v, m[tuple(p)], rtol=2e-6)
 
 
 def test_lightglue_layer_states_drift():
@@ -185,8 +211,8 @@ def test_block_form_switch_by_token_count_keeps_the_matches():
     assert min(agree) >= 0.95
 
 
-@pytest.mark.parametrize("n0,n1", [(1024, 1024), (1024, 777)])
-def test_lightglue_at_the_profile_maximum(n0, n1):
+@pytest.mark.parametrize("n0,n1,min_matches", [(1024, 1024, 400), (1024, 777, 300)])
+def test_lightglue_at_the_profile_maximum(n0, n1, min_matches):
     """N = 1024 is the engine's optimisation-profile maximum (light_glue.cpp:52); the arena is sized by max_keypoints."""
     from airslam_amd import api, weights
     lg = weights.synthetic_lightglue(1234)
@@ -194,15 +220,9 @@ def test_lightglue_at_the_profile_maximum(n0, n1):
     _, _, a, b = _pair(n0, n1, 1024 + n1)
     s = ctx.lightglue_scores(a, b)
     ref = ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
-    err = np.abs(s - ref)
     idx, sc = ctx.match_lightglue(a, b)
-    didx, dsc = ref_post.filter_matches(s, 0.1)
-    diag(f"lg_max_{n0}_{n1}", max_err=err.max(), mean_err=err.mean(), ref_absmax=np.abs(ref).max(), n_dev=len(idx),
-         nan=int(np.isnan(s).sum()))
-    assert s.shape == (n0, n1) and not np.isnan(s).any()
-    np.testing.assert_array_equal(idx, didx)
-    np.testing.assert_allclose(sc, dsc, rtol=2e-6)
-    assert err.max() <= 0.05 * max(1.0, np.abs(ref).mean())
+    assert s.shape == (n0, n1)
+    _check_against_oracle(f"lg_max_{n0}_{n1}", s, ref, idx, sc, TOL[1], min_matches)
     ctx.close()
 
 
@@ -233,7 +253,7 @@ def test_bench_size_matcher_batch_repeats_its_distinct_pairs():
     ridx, rsc, rnm = run(small, 1)
     oidx, osc, onm = run(big, 16)
     diag("lg_bench_size_repeats", matches=str(rnm.tolist()))
-    assert rnm.sum() >= 4                           # the planted correspondences do produce matches
+    assert rnm.min() >= 150                         # the planted correspondences do produce matches: ~200 per pair
     for i in range(64):
         j, m = i % 4, int(rnm[i % 4])
         assert int(onm[i]) == m
@@ -243,20 +263,13 @@ def test_bench_size_matcher_batch_repeats_its_distinct_pairs():
 
 @pytest.mark.parametrize("env", [{"AIRFE_FUSE_LG_BLOCK": "1", "AIRFE_GEMMR_MIN_M": "512"}, {"AIRFE_FUSE_LG_BLOCK": "0"}],
                          ids=["fused_block_gemmr", "four_launches"])
-def test_lightglue_fp16_storage(env):
-    """precision = 1 (fp16 operands, fp32 accumulate) through the same kernels: the PF16 instantiations of lg_blockf_kernel,
-    gemmr_kernel / gemmr_pair_kernel and gemm_small_kernel.  fp16 keeps 3 more mantissa bits than bf16, so the scores must sit
-    closer to the fp32 oracle than the bf16 bound of the tests above."""
-    ctx, _, lg = context("lg", env=env, max_batch=4, precision=1)
+def test_lightglue_bf16_storage(env):
+    """matcher_precision = 0 (bf16 operands, fp32 accumulate) through the same kernels: the PBF16 instantiations of lg_blockf_kernel,
+    gemmr_kernel / gemmr_pair_kernel and gemm_small_kernel (the default matcher storage is fp16, tested above).  Three fewer mantissa
+    bits: ~8x the score error; the match set still has to be the oracle's outside the rows the oracle decides within that error."""
+    ctx, _, lg = context("lg", env=env, max_batch=4, matcher_precision=0)
     _, _, a, b = _pair(400, 371, 4242)
     s = ctx.lightglue_scores(a, b)
     ref = ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
-    err = np.abs(s - ref)
     idx, sc = ctx.match_lightglue(a, b)
-    didx, dsc = ref_post.filter_matches(s, 0.1)
-    diag(f"lg_fp16_{'fused' if env['AIRFE_FUSE_LG_BLOCK'] == '1' else 'split'}", max_err=err.max(), mean_err=err.mean(),
-         ref_absmax=np.abs(ref).max(), n_dev=len(idx))
-    assert not np.isnan(s).any()
-    np.testing.assert_array_equal(idx, didx)
-    np.testing.assert_allclose(sc, dsc, rtol=2e-6)
-    assert err.max() <= 0.02 * max(1.0, np.abs(ref).mean()), "fp16 scores drifted from the fp32 oracle"
+    _check_against_oracle(f"lg_bf16_{'fused' if env['AIRFE_FUSE_LG_BLOCK'] == '1' else 'split'}", s, ref, idx, sc, TOL[0], 150)

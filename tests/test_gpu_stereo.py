@@ -34,6 +34,57 @@ def test_stereo_batch_consistent_with_single_calls():
         assert k == cnt
         assert [tuple(g) for g in idx[b, :k].cpu().numpy()] == [(m[0], m[1]) for m in matches]
     diag("stereo_counts", counts=str(counts))
+    assert min(c[2] for c in counts) >= 60, "matches must exist for this comparison to mean anything"
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["bf16_encoder", "fp16_encoder"])
+def test_stereo_detect_then_match_vs_full_oracle(prec):
+    """End to end against the ORACLE (not against another HIP path): image -> resize -> SuperPoint -> NMS -> top-K -> descriptors ->
+    LightGlue -> filter_matches on both sides.  Two gates:
+      (1) matcher on real detections: the oracle matcher fed with the DEVICE's feature matrices must return the device's match set
+          (outside the rows it decides within the tolerance);
+      (2) whole chain: device matches vs the all-oracle chain, compared as geometry (both endpoints within 1 px), because the 2-byte
+          encoder moves a few keypoints across the top-K / threshold boundary."""
+    from airslam_amd import api
+    from oracle import ref_nets, ref_post
+    from planted import fragile_rows
+    ctx, sp, lg = context("splg", max_batch=4, enc_chunk=2, precision=prec)
+    left, right = synth.stereo_pair(480, 752, 3)
+    det, pm = api.FeatureDetector(ctx), api.PointMatcher(ctx, 752, 480, 0)
+    ok, f0, f1 = det.DetectStereo(left, right)
+    assert ok
+    cnt, matches = pm.MatchingPoints(f0, f1)
+    dev = {(m[0], m[1]) for m in matches}
+    # (1) oracle matcher on the device's features
+    a = np.ascontiguousarray(ref_post.normalize_keypoints(f0.T, 752, 480, 0.5)[:, 1:])
+    b = np.ascontiguousarray(ref_post.normalize_keypoints(f1.T, 752, 480, 0.5)[:, 1:])
+    ref = ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
+    ridx, _ = ref_post.filter_matches(ref, 0.1)
+    frag = fragile_rows(ref, 0.05)
+    want = {tuple(p) for p in ridx if p[0] not in frag}
+    got = {p for p in dev if p[0] not in frag}
+    # (2) the all-oracle chain
+    feats = []
+    for im in (left, right):
+        x, ws, hs = ref_post.process_image(im)
+        heat, desc = ref_nets.superpoint_forward(sp, x[None])
+        feats.append(ref_post.keypoints_decoder(ref_post.simple_nms(heat[0], 4), desc[0], 0.004, 4, 400, ws, hs))
+    o0, o1 = feats
+    oa = np.ascontiguousarray(ref_post.normalize_keypoints(o0, 752, 480, 0.5)[:, 1:])
+    ob = np.ascontiguousarray(ref_post.normalize_keypoints(o1, 752, 480, 0.5)[:, 1:])
+    oidx, _ = ref_post.filter_matches(ref_nets.lightglue_forward(lg, oa[:, :2], oa[:, 2:], ob[:, :2], ob[:, 2:]), 0.1)
+    omatch = np.array([[o0[i, 1], o0[i, 2], o1[j, 1], o1[j, 2]] for i, j in oidx], np.float32).reshape(-1, 4)
+    dmatch = np.array([[f0[1, i], f0[2, i], f1[1, j], f1[2, j]] for i, j in sorted(dev)], np.float32).reshape(-1, 4)
+    hit = 0
+    for m in dmatch:
+        d = np.abs(omatch - m[None]).max(1) if len(omatch) else np.array([9.0])
+        hit += int(d.min() <= 1.0 * max(752 / 512, 480 / 512))          # 1 px of the 512x512 grid, in image pixels
+    diag(f"stereo_vs_oracle_prec{prec}", n_dev=len(dev), n_oracle_on_dev_feats=len(ridx), fragile=len(frag), identical=(got == want),
+         n_all_oracle=len(oidx), geometric_hits=hit)
+    assert len(ridx) >= 80 and len(oidx) >= 80, "the synthetic pair must produce real matches"
+    assert got == want
+    assert abs(len(dev) - len(oidx)) <= 0.15 * len(oidx)
+    assert hit >= (0.9 if prec else 0.8) * len(dmatch)
 
 
 def test_stereo_is_deterministic():
@@ -79,6 +130,7 @@ def test_full_bench_batch_repeats_its_distinct_pairs():
     out = run(big, np.tile(ls4, (16, 1, 1)), np.tile(rs4, (16, 1, 1)))
     diag("stereo_full_batch", keypoints=str(ref[2].tolist()), matches=str(ref[6].tolist()))
     assert ref[2].min() > 100                       # the synthetic pairs do produce keypoints
+    assert ref[6].min() >= 60                       # ... and matches: the match buffers carry real payloads
     for i in range(64):
         j = i % 4
         for k in (0, 1):                            # feature matrices (score, x, y, 256-d descriptor) of both images

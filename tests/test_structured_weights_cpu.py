@@ -1,0 +1,181 @@
+"""The structured synthetic matcher weights do what they are for: in the fp32 ORACLE, planted correspondences come out as
+hundreds of matches (every matcher test and the bench ran on 0-11 matches).  Also pins the literal corner
+semantics of filter_matches / decode (-FLT_MAX floors, value-initialised pairs, ties, threshold equality) against
+statement-by-statement transcriptions of the C++."""
+import math
+
+import numpy as np
+import pytest
+
+from airslam_amd import weights
+from oracle import ref_nets, ref_post
+from planted import fragile_rows, normalised, planted_pair
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def _lg_oracle(n0, n1, seed, lg):
+    f0, f1 = planted_pair(n0, n1, seed)
+    a, b = normalised(f0)[:, 1:], normalised(f1)[:, 1:]
+    return ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
+
+
+@pytest.mark.parametrize("n0,n1,want", [(400, 400, 150), (1024, 1024, 400), (317, 400, 110)])
+def test_lightglue_oracle_matches_the_planted_half(n0, n1, want):
+    lg = weights.synthetic_lightglue(1234)
+    s = _lg_oracle(n0, n1, n0 * 3 + n1, lg)
+    idx, sc = ref_post.filter_matches(s, 0.1)
+    k = min(n0, n1) // 2
+    correct = sum(1 for i, j in idx if i == j and i < k)
+    assert len(idx) >= want and correct >= 0.95 * k
+    assert len(fragile_rows(s, 0.05)) <= 0.02 * len(idx)      # decisions are not balanced on the tolerance of the GPU tests
+
+
+def test_plain_kaiming_lightglue_rejects_everything():
+    """What round 1 tested on: the unstructured draw yields a handful of matches."""
+    lg = weights.synthetic_lightglue(1234, structured=False)
+    idx, _ = ref_post.filter_matches(_lg_oracle(400, 400, 1600, lg), 0.1)
+    assert len(idx) < 20
+
+
+@pytest.mark.parametrize("n0,n1,layers,iters,want", [(400, 400, 18, 100, 150), (300, 280, 4, 20, 100)])
+def test_superglue_oracle_matches_the_planted_half(n0, n1, layers, iters, want):
+    w = weights.synthetic_superglue(1234, n_layers=layers)
+    f0, f1 = planted_pair(n0, n1, n0 * 3 + n1)
+    a, b = normalised(f0, scale=0.7), normalised(f1, scale=0.7)
+    z = ref_nets.superglue_forward(w, a[:, 1:3], a[:, 0], a[:, 3:], b[:, 1:3], b[:, 0], b[:, 3:], n_layers=layers, iters=iters)
+    i0, i1, m0, m1 = ref_post.superglue_decode(z, 0.2)
+    k = min(n0, n1) // 2
+    assert int((i0 >= 0).sum()) >= want
+    assert int((i0[:k] == np.arange(k)).sum()) >= 0.95 * k
+
+
+# ------------------------------------------------------------------ literal transcriptions of the C++ loops
+def _filter_matches_loops(scores, threshold=0.1):
+    """src/light_glue.cpp:214-266 statement by statement (float32 compares, value-initialised row_max / col_max)."""
+    n0, n1 = scores.shape
+    row_max = [(0, np.float32(0.0))] * n0
+    for r in range(n0):
+        mv = np.float32(-FLT_MAX)
+        for c in range(n1):
+            if scores[r, c] > mv:
+                row_max[r] = (c, scores[r, c]); mv = scores[r, c]
+    col_max = [(0, np.float32(0.0))] * n1
+    for c in range(n1):
+        mv = np.float32(-FLT_MAX)
+        for r in range(n0):
+            if scores[r, c] > mv:
+                col_max[c] = (r, scores[r, c]); mv = scores[r, c]
+    idx, sc = [], []
+    for r in range(n0):
+        if r == col_max[row_max[r][0]][0]:
+            e = np.exp(np.float32(row_max[r][1]))
+            if e > np.float32(threshold):
+                idx.append((r, row_max[r][0])); sc.append(e)
+    return np.array(idx, np.int32).reshape(-1, 2), np.array(sc, np.float32)
+
+
+def _decode_loops(z, thr=0.2):
+    """src/super_glue.cpp:258-367 statement by statement."""
+    h, w = z.shape
+    i0 = [0] * (h - 1); v0 = [np.float32(-FLT_MAX)] * (h - 1); i1 = [0] * (w - 1)
+    for i in range(h - 1):
+        mv, mi = np.float32(-FLT_MAX), 0
+        for j in range(w - 1):
+            if mv < z[i, j]:
+                mv, mi = z[i, j], j
+        v0[i], i0[i] = mv, mi
+    for j in range(w - 1):
+        mv, mi = np.float32(-FLT_MAX), 0
+        for i in range(h - 1):
+            if mv < z[i, j]:
+                mv, mi = z[i, j], i
+        i1[j] = mi
+    mutual0 = [i1[i0[i]] == i for i in range(h - 1)]
+    mutual1 = [i0[i1[j]] == j for j in range(w - 1)]
+    with np.errstate(under="ignore"):
+        ms0 = [np.exp(np.float32(v0[i])) if mutual0[i] else np.float32(0) for i in range(h - 1)]
+    ms1 = [ms0[i1[j]] if mutual1[j] else np.float32(0) for j in range(w - 1)]
+    valid0 = [mutual0[i] and ms0[i] > np.float32(thr) for i in range(h - 1)]
+    valid1 = [mutual1[j] and valid0[i1[j]] for j in range(w - 1)]
+    return (np.array([i0[i] if valid0[i] else -1 for i in range(h - 1)], np.int32),
+            np.array([i1[j] if valid1[j] else -1 for j in range(w - 1)], np.int32),
+            np.array(ms0, np.float64), np.array(ms1, np.float64))
+
+
+def hand_built_score_matrices():
+    """Score matrices that exercise every branch of the two post-processing routines."""
+    rng = np.random.default_rng(3)
+    lt = np.float32(math.log(0.1))
+    cases = {}
+    s = np.full((6, 7), -20.0, np.float32)
+    s[0, 2] = s[0, 4] = -0.5                     # tie inside a row: the first maximum (col 2) wins
+    s[3, 2] = -0.5                               # tie inside column 2 between rows 0 and 3: row 0 wins -> row 3 not mutual
+    s[1, 1] = lt                                 # exp(log 0.1) vs 0.1: decided by float32 exp, whatever it yields
+    s[2, 5] = np.nextafter(lt, np.float32(0))    # one ulp above the threshold
+    s[4, 6] = np.nextafter(lt, np.float32(-100)) # one ulp below
+    s[5, :] = -np.inf                            # a row with nothing above -FLT_MAX: keeps (col 0, score 0.0f) -> exp = 1
+    cases["ties_threshold_inf_row"] = s
+    s2 = np.full((5, 4), -np.inf, np.float32)    # everything -inf: every row -> (0, 0.0), col_max[0] = (0, 0.0) -> only row 0 matches
+    cases["all_minus_inf"] = s2
+    s3 = np.full((4, 5), -3.0, np.float32)       # all equal, below threshold (exp(-3) = 0.0498): no match; rows all point at col 0
+    cases["all_equal_below"] = s3
+    s4 = np.full((4, 5), -1.0, np.float32)       # all equal, above threshold: only (0, 0) is mutual
+    cases["all_equal_above"] = s4
+    s5 = rng.normal(-4, 3, size=(40, 33)).astype(np.float32)
+    s5[5, :] = -FLT_MAX                          # equal to the floor: never exceeds it
+    s5[:, 7] = -np.inf
+    s5[9, 3] = np.nan                            # NaN never compares greater
+    for i in range(0, 30, 3):
+        s5[i, i] = -0.01 * (i + 1)
+    cases["random_with_floor_nan"] = s5
+    cases["single"] = np.array([[-0.2]], np.float32)
+    cases["one_row"] = np.array([[-5.0, -0.3, -0.3]], np.float32)
+    return cases
+
+
+@pytest.mark.parametrize("name", list(hand_built_score_matrices()))
+def test_filter_matches_oracle_equals_cxx_loops(name):
+    s = hand_built_score_matrices()[name]
+    idx, sc = ref_post.filter_matches(s, 0.1)
+    lidx, lsc = _filter_matches_loops(s, 0.1)
+    np.testing.assert_array_equal(idx, lidx)
+    np.testing.assert_array_equal(sc, lsc)
+
+
+@pytest.mark.parametrize("name", list(hand_built_score_matrices()))
+def test_superglue_decode_oracle_equals_cxx_loops(name):
+    s = hand_built_score_matrices()[name]
+    z = np.full((s.shape[0] + 1, s.shape[1] + 1), 5.0, np.float32)     # dustbin row / column must be ignored
+    z[:-1, :-1] = s
+    got = ref_post.superglue_decode(z, 0.2)
+    want = _decode_loops(z, 0.2)
+    for g, w_ in zip(got, want):
+        np.testing.assert_array_equal(g, w_)
+
+
+def test_hand_built_cases_hit_the_corners():
+    c = hand_built_score_matrices()
+    idx, sc = ref_post.filter_matches(c["ties_threshold_inf_row"], 0.1)
+    pairs = [tuple(p) for p in idx]
+    assert (0, 2) in pairs and (3, 2) not in pairs and (2, 5) in pairs and (4, 6) not in pairs
+    assert [tuple(p) for p in ref_post.filter_matches(c["all_minus_inf"], 0.1)[0]] == [(0, 0)]
+    assert len(ref_post.filter_matches(c["all_equal_below"], 0.1)[0]) == 0
+    assert [tuple(p) for p in ref_post.filter_matches(c["all_equal_above"], 0.1)[0]] == [(0, 0)]
+
+
+def test_synthetic_superpoint_descriptors_are_matchable():
+    """The whitened descriptor head: unrelated cells of a synthetic image are decorrelated (a plain draw gives cosine 0.9 +- 0.1
+    between ANY two cells)."""
+    from airslam_amd import synth
+    img = synth.gabor_image(480, 752, 3)
+    x, _, _ = ref_post.process_image(img)
+    rng = np.random.default_rng(0)
+    pick = rng.integers(0, 64 * 64, size=300)
+    for structured, lo, hi in ((True, -0.2, 0.2), (False, 0.6, 1.0)):
+        w = weights.synthetic_superpoint(1234, structured=structured)
+        _, d = ref_nets.superpoint_forward(w, x[None])
+        v = d[0].reshape(256, -1)[:, pick]
+        c = v.T @ v
+        off = c[~np.eye(300, dtype=bool)]
+        assert lo < off.mean() < hi, (structured, off.mean())
