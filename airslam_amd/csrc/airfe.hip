@@ -869,7 +869,7 @@ extern "C" {
 void airfe_default_cfg(airfe_cfg* cfg) {
   memset(cfg, 0, sizeof(*cfg));
   cfg->device = 0;
-  cfg->precision = 0;
+  cfg->precision = 1;              // fp16 storage: what the reference builds its engines with (super_point.cpp:97, plnet.cpp:216)
   cfg->max_batch = 2;
   cfg->enc_chunk = 32;   // measured: per-launch fixed costs dominate below ~16 images; no Infinity-Cache benefit from small chunks
   cfg->max_keypoints = 400;        // configs/visual_odometry/vo_euroc.yaml:3-5

@@ -67,7 +67,8 @@ def main():
     ap.add_argument("--width", type=int, default=752)
     ap.add_argument("--max-keypoints", type=int, default=400)
     ap.add_argument("--chunk", type=int, default=32, help="images per pass through the full-resolution conv layers")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="detector (encoder) storage type")
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"],
+                    help="detector (encoder) storage type; fp16 = the reference's kFP16 engines and the type that meets the parity gates")
     ap.add_argument("--matcher-dtype", default="fp16", choices=["bf16", "fp16"],
                     help="matcher storage type (fp16 = the reference's kFP16 engines, light_glue.cpp:115)")
     ap.add_argument("--cpu-pairs", type=int, default=20, help="CPU-baseline sample size (0 = skip)")

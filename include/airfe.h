@@ -31,7 +31,9 @@ typedef struct airfe_ctx airfe_ctx;
 /* Mirrors the knobs of PLNetConfig / SuperPointConfig / PointMatcherConfig (include/read_configs.h:9-103). */
 typedef struct airfe_cfg {
   int device;                  /* HIP device ordinal */
-  int precision;               /* 0 = bf16 storage (default), 1 = fp16 storage; accumulation is always fp32 */
+  int precision;               /* detector storage type: 1 = fp16 (default; the reference's engines are built with kFP16,
+                                  super_point.cpp:97, plnet.cpp:216 — and the only 2-byte type that meets the 1e-3 descriptor-cosine
+                                  tolerance once descriptors are decorrelated: bf16 measures 2e-2), 0 = bf16; accumulation is always fp32 */
   int max_batch;               /* images per detect batch / 2x pairs per match batch the arena is sized for */
   int enc_chunk;               /* images per pass through the full-resolution conv layers (cache blocking) */
   int max_keypoints;           /* plnet.max_keypoints        (<= 1024, light_glue.cpp:52) */

@@ -38,6 +38,7 @@ def _oracle_maps(sp, img):
 
 
 def test_detector_network_vs_oracle():
+    """Default storage (fp16, the reference's kFP16): the north-star tolerances on the dense maps."""
     ctx, sp, _ = context("sp", **CFG)
     img = synth.gabor_image(480, 752, 0)
     feat = ctx.detect_points(img)
@@ -48,22 +49,24 @@ def test_detector_network_vs_oracle():
     diag("detector_maps", heat_max_err=herr.max(), heat_mean_err=herr.mean(), heat_max=oh.max(), desc_cos_max=cd.max(),
          desc_cos_mean=cd.mean(), n_kpts=feat.shape[0], heat_sum_dev=float(heat[0].sum()), heat_sum_ref=float(oh.sum()))
     assert cd.max() <= 1e-3, "dense descriptors: cosine distance above the north-star tolerance"
-    # heat = softmax of logits of magnitude ~10: a 2-byte activation error d shows up as a RELATIVE heat error ~d.
-    # bf16 (8-bit mantissa) is allowed 5 % of the peak here; fp16 storage (test below) must be ~8x tighter.
-    assert herr.max() <= 0.05 * max(oh.max(), 1e-3) + 2e-3
+    # heat = softmax of logits of magnitude ~10: a 2-byte activation error d shows up as a RELATIVE heat error ~d
+    assert herr.max() <= 0.01 * max(oh.max(), 1e-3) + 1e-3
 
 
-def test_detector_network_fp16_storage_is_tighter():
-    ctx, sp, _ = context("sp", precision=1, **CFG)
+def test_detector_network_bf16_storage_is_looser():
+    """precision = 0 (bf16): same kernels, three fewer mantissa bits.  With DECORRELATED descriptors (the whitened synthetic head,
+    like a trained one) the dense descriptor map misses the 1e-3 cosine tolerance by 20x (round 1 passed only because a plain
+    random head makes all descriptors collinear, where the cosine cannot see the error) — which is why fp16 is the default."""
+    ctx, sp, _ = context("sp", precision=0, **CFG)
     img = synth.gabor_image(480, 752, 0)
     ctx.detect_points(img)
     heat, nms, desc = ctx.detector_maps(1)
     oh, od, ws, hs = _oracle_maps(sp, img)
     herr = np.abs(heat[0] - oh)
     cd = cosine_dist(desc[0].reshape(-1, 256), od.transpose(1, 2, 0).reshape(-1, 256))
-    diag("detector_maps_fp16", heat_max_err=herr.max(), heat_mean_err=herr.mean(), desc_cos_max=cd.max())
-    assert cd.max() <= 1e-4
-    assert herr.max() <= 0.01 * max(oh.max(), 1e-3) + 1e-3
+    diag("detector_maps_bf16", heat_max_err=herr.max(), heat_mean_err=herr.mean(), desc_cos_max=cd.max(), desc_cos_mean=cd.mean())
+    assert cd.max() <= 0.05 and cd.mean() <= 0.01
+    assert herr.max() <= 0.05 * max(oh.max(), 1e-3) + 2e-3
 
 
 def test_nms_and_decode_bit_exact_on_device_maps():
@@ -113,7 +116,9 @@ def test_keypoints_vs_oracle_end_to_end():
     cd = cosine_dist(feat[near, 3:], ref[j[near], 3:])
     diag("e2e_keypoints", n_dev=feat.shape[0], n_ref=ref.shape[0], frac_within_1px=near.mean(), desc_cos_max=cd.max(),
          desc_cos_mean=cd.mean(), score_err_max=np.abs(feat[near, 0] - ref[j[near], 0]).max())
-    assert near.mean() >= 0.95
+    # north star: keypoints <= 1 px, descriptors <= 1e-3 cosine.  The remainder (< 1 %) are detections whose score sits on the
+    # threshold / top-K boundary, where ANY rounding of the network flips membership (the reference's own FP16 engine does too)
+    assert near.mean() >= 0.99
     assert cd.max() <= 1e-3
 
 
