@@ -136,6 +136,11 @@ std::vector<uint16_t> pack_slabs(int cbt, int nslab, int prec, const std::functi
   return out;
 }
 
+// sqrt(scale * log2 e), scale = 1/sqrt(d_head) = 0.125: folded into BOTH the q and the k projection (weights and biases; rotary is
+// linear, so it commutes), so that q.k comes out of the attention MFMA as log2(e) * (q.k) / 8, ready for v_exp_f32 — the product of two
+// packed operands, each rounded once, exactly like the unscaled q and k were
+constexpr float ATT_QK_FOLD = 0.42466090014400953f;
+
 struct ConvW { uint16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; };
 struct LinW { uint16_t* w = nullptr; float* b = nullptr; int K = 0, N = 0, cbt = 0; };
 struct LgLayer {
@@ -166,6 +171,8 @@ struct airfe_ctx {
   int block_min = 3200;          // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
   bool qkv_pair = true;          // q|k and v of a layer in one streaming launch (AIRFE_QKV_PAIR=0: two launches)
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
+  int attn_occ = 3;              // AIRFE_ATTN_OCC: attention32_kernel variant compiled for 2 (no spills) or 3 waves per SIMD
+  bool attn_v1 = false;          // AIRFE_ATTN_V1=1: the round-1 16x16x32 attention kernel (A/B runs)
   bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
 
   // detector weights
@@ -441,12 +448,12 @@ int load_lightglue(airfe_ctx* c, const char* path) {
     // Wqkv output index = h*192 + d*3 + {q,k,v}  (qkv.unflatten(-1,(H,-1,3)))  ->  [q(h,d) | k(h,d)] and v(h,d)
     std::function<int(int)> qk_row = [](int f) { const int sel = f >> 8, hd = f & 255; return (hd >> 6) * 192 + (hd & 63) * 3 + sel; };
     std::function<int(int)> v_row = [](int f) { return (f >> 6) * 192 + (f & 63) * 3 + 2; };
-    ok = ok && make_linear(c, wqkv->data.data(), bqkv->data.data(), 256, 512, l.qk, 1.f, &qk_row);
+    ok = ok && make_linear(c, wqkv->data.data(), bqkv->data.data(), 256, 512, l.qk, ATT_QK_FOLD, &qk_row);
     ok = ok && make_linear(c, wqkv->data.data(), bqkv->data.data(), 256, 256, l.v, 1.f, &v_row);
     ok = ok && make_linear_named(c, p, s + ".out_proj", 256, 256, l.out, err);
     ok = ok && make_linear_named(c, p, s + ".ffn.0", 512, 512, l.ffn0, err);
     ok = ok && make_linear_named(c, p, s + ".ffn.3", 512, 256, l.ffn3, err);
-    ok = ok && make_linear_named(c, p, x + ".to_qk", 256, 256, l.cqk, err);
+    ok = ok && make_linear_named(c, p, x + ".to_qk", 256, 256, l.cqk, err, ATT_QK_FOLD);
     ok = ok && make_linear_named(c, p, x + ".to_v", 256, 256, l.cv, err);
     ok = ok && make_linear_named(c, p, x + ".to_out", 256, 256, l.cout, err);
     ok = ok && make_linear_named(c, p, x + ".ffn.0", 512, 512, l.cffn0, err);
@@ -546,7 +553,7 @@ int load_superglue(airfe_ctx* c, const char* path) {
       bqk[f] = bq->data[hm(f)];
       bqk[256 + f] = bk->data[hm(f)];
     }
-    ok = ok && make_linear(c, wqk.data(), bqk.data(), 256, 512, l.qk);
+    ok = ok && make_linear(c, wqk.data(), bqk.data(), 256, 512, l.qk, ATT_QK_FOLD);
     ok = ok && make_linear(c, wv->data.data(), bv->data.data(), 256, 256, l.v, 1.f, &hm);
     ok = ok && make_linear(c, wm->data.data(), bm->data.data(), 256, 256, l.merge, 1.f, nullptr, &hm);
     ok = ok && make_linear_named(c, p, g + ".mlp.0", 512, 512, l.mlp0, err);
@@ -731,6 +738,15 @@ void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1
   launch_gemm(c->mprec, w.K, trans, g, st);
 }
 
+void run_attention(airfe_ctx* c, int prec, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, const int* lens, int S,
+                   int H, int Np, int cross, float scale, hipStream_t st) {
+  // `scale` (1/sqrt(d_head)) and log2 e are already inside q and k (ATT_QK_FOLD), so the kernels exponentiate the raw products:
+  // the round-1 kernel is told scale * log2 e = 1
+  (void)scale;
+  if (c->attn_v1) launch_attention(prec, Q, K, Vt, O, lens, S, H, Np, cross, 0.6931471805599453f, st);
+  else launch_attention32(prec, Q, K, Vt, O, lens, S, H, Np, cross, c->attn_occ, st);
+}
+
 // The attention inputs of one layer: head-major q|k (`qk`, rotary when rc != nullptr; q -> qout, k -> kout, or both roles in qout
 // for the cross block's shared projection) and transposed V (`v`).  One streaming launch where kernels_gemmr.hip applies (large
 // token counts), else the two linears separately — same arithmetic either way.
@@ -790,7 +806,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   for (const LgLayer& l : c->lg) {
     // ---- self block
     run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, c->rot_cos, c->rot_sin, st);
-    { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
+    { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); run_attention(c, c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
     if (fused_block) {
       lg_blockf(c, l.out, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
     } else {
@@ -799,7 +815,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     }
     // ---- cross block (one shared projection for q and k; the two sides swap roles)
     run_qkv(c, l.cqk, l.cv, Mg, c->qb, nullptr, nullptr, nullptr, st);
-    { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); launch_attention(c->mprec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
+    { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); run_attention(c, c->mprec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
     if (fused_block) {
       lg_blockf(c, l.cout, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st);
     } else {
@@ -836,7 +852,7 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, nullptr, nullptr, st);
     {
       ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048);
-      launch_attention(c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, cross, 0.125f, st);
+      run_attention(c, c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, cross, 0.125f, st);
     }
     run_linear(c, l.merge, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
     run_linear(c, l.mlp0, c->xb, 256, 256, c->msg, 256, Mg, EPI_STORE, ACT_RELU, c->hb, 512, st);
@@ -915,6 +931,8 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (getenv("AIRFE_QKV_PAIR")) c->qkv_pair = atoi(getenv("AIRFE_QKV_PAIR")) != 0;
   if (getenv("AIRFE_GEMMR_WGS")) c->gemmr_wgs = atoi(getenv("AIRFE_GEMMR_WGS"));
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
+  if (getenv("AIRFE_ATTN_OCC")) c->attn_occ = atoi(getenv("AIRFE_ATTN_OCC")) == 3 ? 3 : 2;
+  c->attn_v1 = getenv("AIRFE_ATTN_V1") && atoi(getenv("AIRFE_ATTN_V1")) != 0;
   c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -1392,6 +1410,7 @@ int airfe_debug_gemm(airfe_ctx* c, const float* x, int M, int K, const float* w,
   for (size_t i = 0; i < (size_t)M * K; ++i) xin[i] = cvt2(x[i], prec);
   airfe_ctx tmp;   // only as an allocation list holder
   tmp.prec = prec;
+  tmp.pack_prec = prec;
   LinW lw;
   if (!make_linear(&tmp, w, b, K, N, lw)) return fail(c, "debug_gemm: allocation failed");
   uint16_t* dx = dupload(&tmp, xin);

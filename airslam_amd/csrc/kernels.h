@@ -133,6 +133,10 @@ void launch_lg_prepare(int prec, const LgPrepArgs& a, hipStream_t st);
 // flash attention over head-major Q,K [S][H][Np][64] and Vt [S][H][64][Np]; cross => kv sequence s^1
 void launch_attention(int prec, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O /*[S][Np][256]*/,
                       const int* lens, int S, int H, int Np, int cross, float scale, hipStream_t st);
+// the same on the 32x32x16 MFMA, one query per lane (kernels_attn.hip) — the default; the 16x16x32 kernel above stays for A/B runs
+// q and k arrive PRE-SCALED by sqrt(scale * log2 e) each (folded into their projection weights: ATT_QK_FOLD in airfe.hip)
+void launch_attention32(int prec, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, const int* lens,
+                        int S, int H, int Np, int cross, int occ /* waves per SIMD the kernel is compiled for: 2 or 3 */, hipStream_t st);
 // in-place LayerNorm(512, eps) + exact GELU on 2-byte [M][512]
 void launch_ln_gelu(int prec, uint16_t* h, const float* gamma, const float* beta, int M, hipStream_t st);
 // z[M] = logsigmoid-ready matchability: dot(x32[m], w) + b
