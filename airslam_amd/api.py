@@ -129,7 +129,7 @@ class Context:
             setattr(st, name, a.ctypes.data)
         return st, keep
 
-    def detect_plnet(self, gray: np.ndarray, stage0=None, want_junctions: bool = False, cap_lines: int = 16384,
+    def detect_plnet(self, gray: np.ndarray, stage0=None, want_junctions: bool = False, cap_lines: int = 45056,
                      cap_junc: int = 2048):
         """≙ PLNet::infer -> (feat [n,259], lines [L,4] float64, junctions [K,259])."""
         gray = np.asarray(gray)
@@ -149,7 +149,20 @@ class Context:
                                              C.byref(nj), int(want_junctions)), "airfe_detect_plnet")
         return feat[:n.value].copy(), lines[:nl.value].copy(), junc[:nj.value].copy()
 
-    def debug_plnet_s1(self, stage0, cap: int = 16384):
+    def debug_plnet_stage0(self):
+        """The on-device stage-0 line branch of the last detected image: dict in synth.plnet_stage0_lines' layout + jloc / joff."""
+        n = 3 * 128 * 128
+        out = dict(juncs_pred=np.empty((300, 2), np.float32), lines_pred=np.empty((n, 4), np.float32),
+                   iskeep=np.empty((1, 3, 128, 128), np.float32), idx_junc_to_end_min=np.empty((1, 3, 128, 128), np.float32),
+                   idx_junc_to_end_max=np.empty((1, 3, 128, 128), np.float32), loi_features=np.empty((1, 128, 128, 128), np.float32),
+                   loi_features_thin=np.empty((1, 4, 128, 128), np.float32), loi_features_aux=np.empty((1, 4, 128, 128), np.float32),
+                   jloc=np.empty((128, 128), np.float32), joff=np.empty((2, 128, 128), np.float32))
+        self._chk(self._l.airfe_debug_plnet_stage0(self._h, *[out[k].ctypes.data for k in (
+            "juncs_pred", "lines_pred", "iskeep", "idx_junc_to_end_min", "idx_junc_to_end_max", "loi_features",
+            "loi_features_thin", "loi_features_aux", "jloc", "joff")]), "airfe_debug_plnet_stage0")
+        return out
+
+    def debug_plnet_s1(self, stage0, cap: int = 45056):
         st, keep = self._stage0(stage0)
         la = np.empty((cap, 4), np.float32)
         sc = np.empty((cap,), np.float32)

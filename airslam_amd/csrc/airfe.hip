@@ -148,7 +148,7 @@ struct LgLayer {
   float *ln_g = nullptr, *ln_b = nullptr, *cln_g = nullptr, *cln_b = nullptr;
 };
 struct SgLayer { LinW qk, v, merge, mlp0, mlp3; };
-constexpr int LINE_CAP = 16384;     // unique candidate lines per image (the reference's TensorRT profile allows 50000)
+constexpr int LINE_CAP = 45056;     // unique candidate lines per image: 300 junctions give at most 300 * 299 / 2 = 44850 (min, max) pairs
 constexpr int KEEP_CAP = 3 * 128 * 128;
 constexpr int JUNC_CAP = 2048;
 
@@ -220,6 +220,13 @@ struct airfe_ctx {
   int *sg_idx0 = nullptr, *sg_idx1 = nullptr;
   int32_t *sg_out0 = nullptr, *sg_out1 = nullptr;
 
+  // PLNet stage-0 line branch (HAWP-style head on the shared trunk; weights ride in the detector pack as line.*)
+  bool has_s0 = false;
+  ConvW cL1;                     // line.conv1: 3x3 128 -> 128 on the conv3a features
+  LinW cLh;                      // line.head : 1x1 128 -> 145 = loi (128) | md0-2 dis res | jloc0-1 | joffx joffy | thin0-3 | aux0-3
+  uint16_t* l_feat = nullptr;    // [128*128][128] 2-byte
+  float *l_head = nullptr, *l_jloc = nullptr, *l_jnms = nullptr, *l_joff = nullptr, *l_sel = nullptr;
+  int* l_nsel = nullptr;
   // PLNet stage 1 + line path
   bool has_s1 = false;
   const float* s1_w[11] = {nullptr};
@@ -420,6 +427,23 @@ int load_superpoint(airfe_ctx* c, const char* path) {
       !c->cand || !c->cand_cnt)
     return fail(c, "device allocation failed (detector arena)");
   c->has_sp = true;
+  if (p.count("line.conv1.weight")) {       // a PLNet stage-0 pack: the line branch rides along
+    const Tensor *hw = need(p, "line.head.weight", err), *hb = need(p, "line.head.bias", err);
+    if (!hw || !hb || hw->data.size() != 145 * 128 || hb->data.size() != 145) return fail(c, err.empty() ? "line.head: unexpected shape" : err);
+    if (!make_conv(c, p, "line.conv1", 128, 128, c->cL1, err) || !make_linear(c, hw->data.data(), hb->data.data(), 128, 145, c->cLh))
+      return fail(c, err.empty() ? "device allocation failed while packing the line branch" : err);
+    const size_t npx = 128 * 128;
+    c->l_feat = dalloc<uint16_t>(c, npx * 128);
+    c->l_head = dalloc<float>(c, npx * 160);
+    c->l_jloc = dalloc<float>(c, npx);
+    c->l_jnms = dalloc<float>(c, npx);
+    c->l_joff = dalloc<float>(c, 2 * npx);
+    c->l_sel = dalloc<float>(c, (size_t)320 * AIRFE_FEAT_DIM);
+    c->l_nsel = dalloc<int>(c, 1);
+    if (!c->l_feat || !c->l_head || !c->l_jloc || !c->l_jnms || !c->l_joff || !c->l_sel || !c->l_nsel)
+      return fail(c, "device allocation failed (line branch arena)");
+    c->has_s0 = true;
+  }
   return 0;
 }
 
@@ -867,6 +891,33 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   return 0;
 }
 
+// PLNet stage-0 LINE branch for the image the detector just ran on (batch slot 0): fills c->s0_stage with the Appendix A.1 tensors
+// in the contract's own layouts, so that everything downstream (wireframe dedup, stage 1, filters) is the code the golden tests pin.
+int line_branch_dev(airfe_ctx* c, hipStream_t st) {
+  if (!c->has_s0) return fail(c, "the detector pack carries no line branch (line.* tensors)");
+  const int NP = KEEP_CAP, F = 128;
+  float* d = c->s0_stage;
+  float *d_juncs = d, *d_lp = d + 600, *d_keep = d_lp + (size_t)NP * 4, *d_min = d_keep + NP, *d_max = d_min + NP;
+  float *d_loi = d_max + NP, *d_thin = d_loi + 128 * 128 * 128, *d_aux = d_thin + 4 * 128 * 128;
+  run_conv(c, c->cL1, c->a3a, c->l_feat, 1, F, F, 0, 0, st);                 // conv3a features (zero-bordered NHWC) -> [128*128][128]
+  {
+    GemmArgs g;
+    g.X1 = c->l_feat; g.ld1 = 128; g.K1 = 128; g.Wp = c->cLh.w; g.bias = c->cLh.b;
+    g.M = F * F; g.N = 145; g.cb_total = c->cLh.cbt; g.epi = EPI_STORE_F32; g.out = c->l_head; g.ldo = 160;
+    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
+    ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * F * F * 128 * 145, (double)F * F * (256 + 580));
+    launch_gemm(c->prec, 128, false, g, st);
+  }
+  launch_s0_decode(c->l_head, d_lp, c->l_jloc, c->l_jnms, c->l_joff, d_thin, d_aux, d_loi, st);
+  // get_junctions: top-300 of the suppressed junction map (score descending, raster ascending on ties)
+  launch_candidates(c->l_jnms, 1, F, F, 1e-30f, 0, c->cand, c->cand_cnt, AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE, st);
+  launch_select_list(c->cand, c->cand_cnt, AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE, 1, F, 300, 320, c->l_sel, c->l_nsel, st);
+  launch_s0_juncs(c->l_sel, c->l_nsel, c->l_joff, d_juncs, 300, st);
+  launch_s0_j2l(d_lp, d_juncs, 300, NP, 10.0f, d_keep, d_min, d_max, st);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int ensure_stage_img(airfe_ctx* c, size_t bytes) {
   if (bytes <= c->st_img_bytes) return 0;
   void* p = nullptr;
@@ -1211,6 +1262,8 @@ int airfe_match_lines(airfe_ctx* c, const int32_t* row_ptr0, const int32_t* pt_i
   return 0;
 }
 
+int airfe_has_line_branch(const airfe_ctx* c) { return c && c->has_s0 && c->has_s1; }
+
 int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, const airfe_plnet_stage0* s0, float* feat,
                        int cap, int* n, double* lines, int capL, int* nlines, float* junc, int capJ, int* njunc,
                        int want_junctions) {
@@ -1218,24 +1271,28 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
   if (nlines) *nlines = 0;
   if (njunc) *njunc = 0;
   if (airfe_detect_points(c, gray, h, w, stride, feat, cap, n)) return 1;      // point branch: plnet.cpp:560
-  if (!s0) return 0;
+  if (!s0 && !c->has_s0) return 0;            // no line branch available: points only (the shim says so, loudly, at build())
   if (!c->has_s1) return fail(c, "PLNet stage-1 weights were not loaded (cfg.plnet_s1_pack)");
   hipStream_t st = c->stream;
   const int R = AIRFE_INTERNAL_SIZE, NP = KEEP_CAP;
   float* d = c->s0_stage;
   float *d_juncs = d, *d_lp = d + 600, *d_keep = d_lp + (size_t)NP * 4, *d_min = d_keep + NP, *d_max = d_min + NP;
   float *d_loi = d_max + NP, *d_thin = d_loi + 128 * 128 * 128, *d_aux = d_thin + 4 * 128 * 128;
-  HIPCHK(c, hipMemcpyAsync(d_juncs, s0->juncs_pred, 600 * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_lp, s0->lines_pred, (size_t)NP * 16, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_keep, s0->iskeep, (size_t)NP * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_min, s0->idx_junc_to_end_min, (size_t)NP * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_max, s0->idx_junc_to_end_max, (size_t)NP * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_loi, s0->loi_features, (size_t)128 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_thin, s0->loi_features_thin, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_aux, s0->loi_features_aux, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+  if (s0) {                                   // caller-supplied stage-0 tensors (golden / known-answer tests of everything downstream)
+    HIPCHK(c, hipMemcpyAsync(d_juncs, s0->juncs_pred, 600 * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_lp, s0->lines_pred, (size_t)NP * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_keep, s0->iskeep, (size_t)NP * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_min, s0->idx_junc_to_end_min, (size_t)NP * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_max, s0->idx_junc_to_end_max, (size_t)NP * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_loi, s0->loi_features, (size_t)128 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_thin, s0->loi_features_thin, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_aux, s0->loi_features_aux, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+  } else if (line_branch_dev(c, st)) {        // the stage-0 line branch on the device: nothing crosses PCIe (the reference moves
+    return 1;                                 // 15.5 MB D2H + 9.7 MB H2D here, plnet.cpp:237,494-509)
+  }
   HIPCHK(c, hipMemsetAsync(c->jmap, 0, (size_t)R * R, st));
   const float ws = (float)w / (float)R, hs = (float)h / (float)R;
-  launch_wireframe(d_keep, d_min, d_max, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, LINE_CAP, c->wf_counts, st);
+  launch_wireframe(d_keep, d_min, d_max, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, c->wf_counts, st);
   launch_plnet_s1(d_juncs, d_lp, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, d_loi, d_thin, d_aux, c->s1_w, c->s1_la,
                   c->s1_sc, LINE_CAP, st);
   launch_line_filter(c->s1_la, c->s1_sc, c->wf_counts, c->cfg.remove_borders, c->cfg.line_threshold,
@@ -1258,6 +1315,26 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
   return 0;
 }
 
+/* the on-device stage-0 line branch of the LAST detected image, copied out in the Appendix A.1 layouts (NULL = skip) */
+int airfe_debug_plnet_stage0(airfe_ctx* c, float* juncs_pred, float* lines_pred, float* iskeep, float* idx_min, float* idx_max,
+                             float* loi, float* thin, float* aux, float* jloc, float* joff) {
+  if (!c || !c->has_s0 || !c->has_s1) return fail(c, "debug_plnet_stage0: line branch / stage 1 not loaded");
+  hipStream_t st = c->stream;
+  if (line_branch_dev(c, st)) return 1;
+  HIPCHK(c, hipStreamSynchronize(st));
+  const int NP = KEEP_CAP;
+  float* d = c->s0_stage;
+  float *d_juncs = d, *d_lp = d + 600, *d_keep = d_lp + (size_t)NP * 4, *d_min = d_keep + NP, *d_max = d_min + NP;
+  float *d_loi = d_max + NP, *d_thin = d_loi + 128 * 128 * 128, *d_aux = d_thin + 4 * 128 * 128;
+  struct { float* h; const float* dv; size_t n; } cp[10] = {
+      {juncs_pred, d_juncs, 600}, {lines_pred, d_lp, (size_t)NP * 4}, {iskeep, d_keep, (size_t)NP}, {idx_min, d_min, (size_t)NP},
+      {idx_max, d_max, (size_t)NP}, {loi, d_loi, (size_t)128 * 128 * 128}, {thin, d_thin, (size_t)4 * 128 * 128},
+      {aux, d_aux, (size_t)4 * 128 * 128}, {jloc, c->l_jloc, (size_t)128 * 128}, {joff, c->l_joff, (size_t)2 * 128 * 128}};
+  for (auto& e : cp)
+    if (e.h) HIPCHK(c, hipMemcpy(e.h, e.dv, e.n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 /* stage-1 alone on HOST stage-0 tensors: lines_adjusted [M2][4] + scores_line [M2] (parity vs the real plnet_s1.onnx) */
 int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* lines_adjusted, float* scores_line, int cap, int* m2) {
   if (!c || !c->has_s1 || !s0) return fail(c, "debug_plnet_s1: stage-1 not loaded");
@@ -1274,7 +1351,7 @@ int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* line
   HIPCHK(c, hipMemcpyAsync(d_loi, s0->loi_features, (size_t)128 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d_thin, s0->loi_features_thin, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d_aux, s0->loi_features_aux, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
-  launch_wireframe(d_keep, d_min, d_max, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, LINE_CAP, c->wf_counts, st);
+  launch_wireframe(d_keep, d_min, d_max, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, c->wf_counts, st);
   launch_plnet_s1(d_juncs, d_lp, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, d_loi, d_thin, d_aux, c->s1_w, c->s1_la,
                   c->s1_sc, LINE_CAP, st);
   int cnt[2] = {0, 0};

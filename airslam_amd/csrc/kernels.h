@@ -167,6 +167,17 @@ void launch_line_filter(const float* la, const float* sc, const int* counts, int
 void launch_junction_scan(const unsigned char* jmap, const float* heat, int R, int border, float* feat, int cap, int* n_out,
                           hipStream_t st);
 
+// ---- PLNet stage-0 line branch (kernels_s0.hip): decode of the fused head GEMM output [128*128][160] fp32
+//      (128 LOI channels | md0..2 dis res | jloc0 jloc1 | joffx joffy | thin0..3 | aux0..3) into the Appendix A.1 tensors
+void launch_s0_decode(const float* head, float* lines_pred /*[3*128*128][4]*/, float* jloc /*[128*128]*/, float* jnms /*[128*128]*/,
+                      float* joff /*[2][128*128]*/, float* thin /*[4][128*128]*/, float* aux /*[4][128*128]*/, float* loi /*CHW [128][128*128]*/,
+                      hipStream_t st);
+// rows (score, x, y) of the junction top-K -> juncs_pred [jn][2]
+void launch_s0_juncs(const float* sel, const int* n_sel, const float* joff, float* juncs, int jn, hipStream_t st);
+// HAWP wireframe_matcher: nearest junctions of both endpoints of n proposals -> iskeep, idx_junc_to_end_min / _max (floats)
+void launch_s0_j2l(const float* lines_pred, const float* juncs, int jn, int n, float thr, float* iskeep, float* imin, float* imax,
+                   hipStream_t st);
+
 // ---- SuperGlue ----------------------------------------------------------------------------------------------
 // w: 10 device pointers {W0t[3][32], b0, W1t[32][64], b1, W2t[64][128], b2, W3t[128][256], b3, W4t[256][256], b4}
 void launch_sg_prepare(int prec, const float* f0, const float* f1, const int* n0, const int* n1, int ld, int normalize,

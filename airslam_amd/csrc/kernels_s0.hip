@@ -1,0 +1,145 @@
+// airfe — PLNet stage-0 LINE BRANCH on the device (the tensors of SURVEY.md Appendix A.1 that src/plnet.cpp:453-462 fetches from
+// the stage-0 engine and :468-509 feeds to stage 1).  plnet_s0.onnx is absent from the reference checkout, so the head below is
+// the PUBLISHED architecture those tensors come from — HAWPv3 (Xue et al., "Holistically-Attracted Wireframe Parsing", hawp/fsl/
+// model/detector.py: hafm_decoding, non_maximum_suppression + get_junctions, wireframe_matcher) — on the shared VGG trunk:
+//     conv3a features [128][128][128]  -> 3x3 conv 128 -> 128 + ReLU  (MFMA, kernels_conv128r.hip)
+//                                      -> 1x1 conv 128 -> 145         (MFMA GEMM): loi_features (128) | md (3) dis res | jloc (2) | joff (2) | thin (4) | aux (4)
+// and the decode kernels of this file.  Contract and layouts are the reference's (names, shapes, the [3][128][128] proposal
+// order, float-typed junction indices); the WEIGHTS are seeded synthetic ones, parity = against the oracle restatement
+// (oracle/ref_nets.py::plnet_s0_lines), UNPINNED against the missing model.
+#include "common.h"
+#include "kernels.h"
+
+namespace airfe {
+
+constexpr int S0_F = 128;                 // feature-map side (512 / 4)
+constexpr int S0_NPX = S0_F * S0_F;
+constexpr int S0_LD = 160;                // row pitch of the fused head GEMM output (145 valid)
+constexpr int S0_HEAD = 128;              // first non-LOI channel
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// per feature-map pixel: HAFM decoding (3 proposals: residual sign -1, 0, +1), junction probability / offset maps, thin / aux CHW
+__global__ __launch_bounds__(256) void s0_decode_kernel(const float* __restrict__ head /*[NPX][S0_LD]*/, float* __restrict__ lines_pred /*[3*NPX][4]*/,
+                                                        float* __restrict__ jloc /*[NPX]*/, float* __restrict__ joff /*[2][NPX]*/,
+                                                        float* __restrict__ thin /*[4][NPX]*/, float* __restrict__ aux /*[4][NPX]*/) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= S0_NPX) return;
+  const float* o = head + (size_t)p * S0_LD + S0_HEAD;
+  const float4 a = *reinterpret_cast<const float4*>(o), b = *reinterpret_cast<const float4*>(o + 4), c4 = *reinterpret_cast<const float4*>(o + 8),
+               d4 = *reinterpret_cast<const float4*>(o + 12);
+  const float o16 = o[16];
+  const float md0 = sigmoidf_(a.x), md1 = sigmoidf_(a.y), md2 = sigmoidf_(a.z), dis = sigmoidf_(a.w), res = sigmoidf_(b.x);
+  // jloc = softmax(o5, o6)[1]; joff = sigmoid - 0.5
+  const float mx = fmaxf(b.y, b.z), e0 = expf(b.y - mx), e1 = expf(b.z - mx);
+  jloc[p] = e1 / (e0 + e1);
+  joff[p] = sigmoidf_(b.w) - 0.5f;
+  joff[S0_NPX + p] = sigmoidf_(c4.x) - 0.5f;
+  thin[p] = c4.y; thin[S0_NPX + p] = c4.z; thin[2 * S0_NPX + p] = c4.w; thin[3 * S0_NPX + p] = d4.x;
+  aux[p] = d4.y; aux[S0_NPX + p] = d4.z; aux[2 * S0_NPX + p] = d4.w; aux[3 * S0_NPX + p] = o16;
+  // hafm_decoding: md_un = (md0 - 0.5) 2 pi; st_un = md1 pi/2; ed_un = -md2 pi/2; scale = 5
+  const float PI = 3.14159265358979323846f;
+  const float md_un = (md0 - 0.5f) * PI * 2.0f, st_un = md1 * PI / 2.0f, ed_un = -md2 * PI / 2.0f;
+  const float cs = cosf(md_un), ss = sinf(md_un), yst = tanf(st_un), yed = tanf(ed_un);
+  const float x0 = (float)(p & (S0_F - 1)), y0 = (float)(p >> 7);
+  const float lim = (float)(S0_F - 1);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const float d = fminf(fmaxf(dis + res * (float)(s - 1), 0.f), 1.f);
+    const float xs = (cs - ss * yst) * d * 5.0f, ys = (ss + cs * yst) * d * 5.0f;
+    const float xe = (cs - ss * yed) * d * 5.0f, ye = (ss + cs * yed) * d * 5.0f;
+    float4 l;
+    l.x = fminf(fmaxf(xs + x0, 0.f), lim); l.y = fminf(fmaxf(ys + y0, 0.f), lim);
+    l.z = fminf(fmaxf(xe + x0, 0.f), lim); l.w = fminf(fmaxf(ye + y0, 0.f), lim);
+    *reinterpret_cast<float4*>(lines_pred + ((size_t)s * S0_NPX + p) * 4) = l;
+  }
+}
+
+// non_maximum_suppression: a * (a == max_pool2d(a, 3, stride 1, padding 1))
+__global__ __launch_bounds__(256) void s0_jnms_kernel(const float* __restrict__ jloc, float* __restrict__ out) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= S0_NPX) return;
+  const int x = p & (S0_F - 1), y = p >> 7;
+  const float a = jloc[p];
+  float m = a;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xx = x + dx, yy = y + dy;
+      if (xx >= 0 && xx < S0_F && yy >= 0 && yy < S0_F) m = fmaxf(m, jloc[yy * S0_F + xx]);
+    }
+  out[p] = (a == m) ? a : 0.f;
+}
+
+// loi_features: NHWC rows of the head GEMM -> the contract's CHW [128][128][128]; 32 pixels x 128 channels per workgroup via LDS
+__global__ __launch_bounds__(256) void s0_loi_chw_kernel(const float* __restrict__ head, float* __restrict__ loi) {
+  __shared__ float t[32][129];
+  const int p0 = blockIdx.x * 32, tid = threadIdx.x;
+  for (int i = tid; i < 32 * 128; i += 256) {
+    const int px = i >> 7, ch = i & 127;
+    t[px][ch] = head[(size_t)(p0 + px) * S0_LD + ch];
+  }
+  __syncthreads();
+  for (int i = tid; i < 32 * 128; i += 256) {
+    const int ch = i >> 5, px = i & 31;
+    loi[(size_t)ch * S0_NPX + p0 + px] = t[px][ch];
+  }
+}
+
+// get_junctions: rows (score, x, y) of the top-K selection -> juncs_pred [jn][2] = (x + joff_x + 0.5, y + joff_y + 0.5)
+__global__ void s0_juncs_kernel(const float* __restrict__ sel /*[jn][259]*/, const int* __restrict__ n_sel, const float* __restrict__ joff,
+                                float* __restrict__ juncs, int jn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= jn) return;
+  float x = 0.f, y = 0.f;
+  if (i < *n_sel) {
+    const float fx = sel[(size_t)i * 259 + 1], fy = sel[(size_t)i * 259 + 2];
+    const int idx = (int)fy * S0_F + (int)fx;
+    x = __fadd_rn(__fadd_rn(fx, joff[idx]), 0.5f);
+    y = __fadd_rn(__fadd_rn(fy, joff[S0_NPX + idx]), 0.5f);
+  }
+  juncs[i * 2] = x;
+  juncs[i * 2 + 1] = y;
+}
+
+// wireframe_matcher of HAWP (NOT the C++ routine of that name): nearest junction of both endpoints of every proposal (squared
+// distance, first minimum), idx_junc_to_end_min / _max, iskeep = (min < max) and both squared distances < j2l threshold (10)
+__global__ __launch_bounds__(256) void s0_j2l_kernel(const float* __restrict__ lines_pred, const float* __restrict__ juncs, int jn, int n,
+                                                     float thr, float* __restrict__ iskeep, float* __restrict__ imin, float* __restrict__ imax) {
+  __shared__ float jx[320], jy[320];
+  for (int i = threadIdx.x; i < jn; i += 256) { jx[i] = juncs[i * 2]; jy[i] = juncs[i * 2 + 1]; }
+  __syncthreads();
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const float4 l = *reinterpret_cast<const float4*>(lines_pred + (size_t)p * 4);
+  float c1 = INFINITY, c2 = INFINITY;
+  int i1 = 0, i2 = 0;
+  for (int j = 0; j < jn; ++j) {
+    const float ax = __fsub_rn(l.x, jx[j]), ay = __fsub_rn(l.y, jy[j]);
+    const float bx = __fsub_rn(l.z, jx[j]), by = __fsub_rn(l.w, jy[j]);
+    const float d1 = __fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)), d2 = __fadd_rn(__fmul_rn(bx, bx), __fmul_rn(by, by));
+    if (d1 < c1) { c1 = d1; i1 = j; }
+    if (d2 < c2) { c2 = d2; i2 = j; }
+  }
+  const int lo = min(i1, i2), hi = max(i1, i2);
+  iskeep[p] = (lo < hi && c1 < thr && c2 < thr) ? 1.0f : 0.0f;
+  imin[p] = (float)lo;
+  imax[p] = (float)hi;
+}
+
+void launch_s0_decode(const float* head, float* lines_pred, float* jloc, float* jnms, float* joff, float* thin, float* aux, float* loi,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(s0_decode_kernel, dim3(S0_NPX / 256), dim3(256), 0, st, head, lines_pred, jloc, joff, thin, aux);
+  hipLaunchKernelGGL(s0_jnms_kernel, dim3(S0_NPX / 256), dim3(256), 0, st, jloc, jnms);
+  hipLaunchKernelGGL(s0_loi_chw_kernel, dim3(S0_NPX / 32), dim3(256), 0, st, head, loi);
+}
+void launch_s0_juncs(const float* sel, const int* n_sel, const float* joff, float* juncs, int jn, hipStream_t st) {
+  hipLaunchKernelGGL(s0_juncs_kernel, dim3((jn + 63) / 64), dim3(64), 0, st, sel, n_sel, joff, juncs, jn);
+}
+void launch_s0_j2l(const float* lines_pred, const float* juncs, int jn, int n, float thr, float* iskeep, float* imin, float* imax,
+                   hipStream_t st) {
+  hipLaunchKernelGGL(s0_j2l_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lines_pred, juncs, jn, n, thr, iskeep, imin, imax);
+}
+
+}  // namespace airfe

@@ -48,6 +48,14 @@ def superpoint_spec() -> Spec:
     return spec
 
 
+def plnet_line_spec() -> Spec:
+    """PLNet stage-0 LINE branch on the shared trunk (SURVEY.md Appendix A.1 contract; HAWPv3-style head, UNVERIFIED-UPSTREAM —
+    plnet_s0.onnx is absent from the reference checkout): a 3x3 conv on the conv3a features and one fused 1x1 head whose 145
+    output channels are loi_features (128) | md0 md1 md2 dis res | jloc0 jloc1 | joff_x joff_y | thin0..3 | aux0..3."""
+    return [("line.conv1.weight", (128, 128, 3, 3)), ("line.conv1.bias", (128,)),
+            ("line.head.weight", (145, 128)), ("line.head.bias", (145,))]
+
+
 LG_LAYERS = 9
 LG_DIM = 256
 LG_HEADS = 4
@@ -197,6 +205,15 @@ def synthetic_superpoint(seed: int = 1234, structured: bool = True) -> Dict[str,
             _whiten_descriptor_head(w, seed)
         _SP_CACHE[key] = w
     return {k: v.copy() for k, v in _SP_CACHE[key].items()}
+
+
+def synthetic_plnet_s0(seed: int = 1234) -> Dict[str, np.ndarray]:
+    """A PLNet stage-0 pack: the SuperPoint-VGG point branch (`synthetic_superpoint`) + the seeded line branch."""
+    w = synthetic_superpoint(seed)
+    w.update(synthetic(plnet_line_spec(), seed + 40))
+    # junction logits: a clear "no junction" prior so that the probability map is peaky, like a trained head's
+    w["line.head.bias"][128 + 5] = 2.0
+    return w
 
 
 def synthetic_lightglue(seed: int = 1234, n_layers: int = LG_LAYERS, structured: bool = True) -> Dict[str, np.ndarray]:

@@ -69,12 +69,14 @@ const char* airfe_last_error(const airfe_ctx* ctx); /* ctx may be NULL (creation
  *   x,y are in ORIGINAL image pixels.  Fails (non-zero) on an empty image, like the reference returns false. */
 int airfe_detect_points(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int stride, float* feat, int cap, int* n);
 
-/* ≙ PLNet::infer (src/plnet.cpp:221-244).  Point branch as above.  Line branch: the stage-0 line tensors
- *   (Appendix A.1 contract) are supplied by the caller because plnet_s0.onnx is absent from the reference
- *   checkout; everything downstream of them (wireframe_matcher :272-307, stage-1 LOI head :468-514,
- *   line/junction filter :519-558, junction_detector :425-448, rescale :569-582) runs on the device.
- *   lines: [capL][4] doubles (x1,y1,x2,y2) original pixels (std::vector<Eigen::Vector4d> layout);
- *   junc: [capJ][259].  stage0 may be NULL -> no lines/junctions (counts 0). */
+/* ≙ PLNet::infer (src/plnet.cpp:221-244).  Point branch as above.  Line branch: stage0 == NULL (what the shim passes) runs
+ *   the stage-0 line head ON THE DEVICE when the detector pack carries it (tensors line.conv1.*, line.head.*: a HAWPv3-style
+ *   head producing the Appendix A.1 tensors juncs_pred, lines_pred, iskeep, idx_junc_to_end_min/max, loi_features[_thin|_aux] —
+ *   plnet_s0.onnx itself is absent from the reference checkout, so its weights here are synthetic); a non-NULL stage0 supplies
+ *   those tensors from the HOST instead (known-answer tests of everything downstream).  Downstream of them wireframe_matcher
+ *   :272-307, the stage-1 LOI head :468-514, the line/junction filter :519-558, junction_detector :425-448 and the rescale
+ *   :569-582 run on the device.  lines: [capL][4] doubles (x1,y1,x2,y2) original pixels (std::vector<Eigen::Vector4d> layout);
+ *   junc: [capJ][259].  No line branch in the pack and stage0 == NULL -> points only (counts 0). */
 typedef struct airfe_plnet_stage0 {
   const float* juncs_pred;          /* [300][2]        */
   const float* lines_pred;          /* [3*128*128][4]  */
@@ -85,6 +87,7 @@ typedef struct airfe_plnet_stage0 {
   const float* loi_features_thin;   /* [4][128][128]   */
   const float* loi_features_aux;    /* [4][128][128]   */
 } airfe_plnet_stage0;
+int airfe_has_line_branch(const airfe_ctx* ctx); /* 1 when the detector pack carried line.* tensors AND stage 1 is loaded: infer() yields lines */
 int airfe_detect_plnet(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int stride, const airfe_plnet_stage0* stage0,
                        float* feat, int cap, int* n, double* lines, int capL, int* nlines, float* junc, int capJ,
                        int* njunc, int want_junctions);
@@ -155,6 +158,11 @@ int airfe_debug_sg_decode(airfe_ctx* ctx, const float* Z, int n0, int n1, int32_
  *   y[M][N] = x[M][K] w[N][K]^T + b through the same MFMA kernels the pipelines use. */
 /* SuperGlue on one HOST pair ([n][259] rows, normalised x,y): the engine's `scores` output [n0+1][n1+1] */
 int airfe_debug_superglue_scores(airfe_ctx* ctx, const float* f0, int n0, const float* f1, int n1, float* scores);
+/* the on-device stage-0 line branch of the last detected image in the Appendix A.1 layouts + the junction probability / offset
+ *   maps behind juncs_pred (any pointer may be NULL): juncs_pred [300][2], lines_pred [49152][4], iskeep / idx_min / idx_max [49152],
+ *   loi [128][128][128], thin / aux [4][128][128], jloc [128][128], joff [2][128][128] */
+int airfe_debug_plnet_stage0(airfe_ctx* ctx, float* juncs_pred, float* lines_pred, float* iskeep, float* idx_min, float* idx_max,
+                             float* loi, float* thin, float* aux, float* jloc, float* joff);
 /* wireframe_matcher + stage-1 LOI head alone: lines_adjusted [cap][4], scores_line [cap], *m2 = unique lines */
 int airfe_debug_plnet_s1(airfe_ctx* ctx, const airfe_plnet_stage0* stage0, float* lines_adjusted, float* scores_line,
                          int cap, int* m2);

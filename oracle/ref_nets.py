@@ -66,6 +66,88 @@ def superpoint_forward(w: W, x: np.ndarray):
     return p.numpy(), d.numpy()
 
 
+# ------------------------------------------------------------------ PLNet stage-0 line branch
+def plnet_s0_lines(w: W, x: np.ndarray, topk: int = 300, scale: float = 5.0, j2l: float = 10.0):
+    """The stage-0 LINE branch: x [H,W] float32 in [0,1] (512x512) -> dict with the Appendix A.1 tensors
+    (`juncs_pred` [300,2], `lines_pred` [3*128*128,4], `iskeep` / `idx_junc_to_end_min` / `idx_junc_to_end_max` [1,3,128,128],
+    `loi_features` [1,128,128,128], `loi_features_thin` / `_aux` [1,4,128,128]) plus `jloc` / `joff` maps.
+    PARITY UNPINNED: plnet_s0.onnx is absent; this restates the PUBLISHED HAWPv3 decoding (hawp/fsl/model/detector.py:
+    hafm_decoding, non_maximum_suppression, get_junctions, wireframe_matcher) on the shared trunk with the channel layout of
+    airslam_amd.weights.plnet_line_spec.  The reference consumes these tensors at src/plnet.cpp:453-509."""
+    with torch.no_grad():
+        def c(name, t):
+            return Fn.relu(Fn.conv2d(t, _t(w[name + ".weight"]), _t(w[name + ".bias"]), padding=1))
+        f = _t(x)[None, None]
+        f = c("conv1a", f); f = c("conv1b", f); f = Fn.max_pool2d(f, 2, 2)
+        f = c("conv2a", f); f = c("conv2b", f); f = Fn.max_pool2d(f, 2, 2)
+        f = c("conv3a", f)                                                   # [1,128,128,128]
+        f = c("line.conv1", f)
+        o = Fn.conv2d(f, _t(w["line.head.weight"])[:, :, None, None], _t(w["line.head.bias"]))[0]    # [145,128,128]
+        loi, h = o[:128], o[128:]
+        md, dis, res = torch.sigmoid(h[0:3]), torch.sigmoid(h[3:4]), torch.sigmoid(h[4:5])
+        jloc = torch.softmax(h[5:7], 0)[1]
+        joff = torch.sigmoid(h[7:9]) - 0.5
+        thin, aux = h[9:13], h[13:17]
+        hh, ww = jloc.shape
+        # hafm_decoding (residual sign pad -1, 0, +1)
+        y0, x0 = torch.meshgrid(torch.arange(hh, dtype=torch.float32), torch.arange(ww, dtype=torch.float32), indexing="ij")
+        sign = torch.tensor([-1.0, 0.0, 1.0]).reshape(3, 1, 1)
+        d = (dis + res * sign).clamp(0.0, 1.0)                               # [3,128,128]
+        pi = torch.tensor(np.float32(np.pi))
+        md_un = (md[0] - 0.5) * pi * 2.0
+        st_un = md[1] * pi / 2.0
+        ed_un = -md[2] * pi / 2.0
+        cs, ss, yst, yed = md_un.cos(), md_un.sin(), st_un.tan(), ed_un.tan()
+        xs = ((cs - ss * yst) * d * scale + x0).clamp(0, ww - 1)
+        ys = ((ss + cs * yst) * d * scale + y0).clamp(0, hh - 1)
+        xe = ((cs - ss * yed) * d * scale + x0).clamp(0, ww - 1)
+        ye = ((ss + cs * yed) * d * scale + y0).clamp(0, hh - 1)
+        lines = torch.stack([xs, ys, xe, ye], -1).reshape(-1, 4)             # [3*128*128, 4]
+        juncs = junctions_topk(jloc.numpy(), joff.numpy(), topk)
+        keep, imin, imax = j2l_match(lines.numpy(), juncs, j2l)
+    return dict(juncs_pred=juncs, lines_pred=lines.numpy(), iskeep=keep.reshape(1, 3, hh, ww),
+                idx_junc_to_end_min=imin.reshape(1, 3, hh, ww), idx_junc_to_end_max=imax.reshape(1, 3, hh, ww),
+                loi_features=loi.numpy()[None], loi_features_thin=thin.numpy()[None], loi_features_aux=aux.numpy()[None],
+                jloc=jloc.numpy(), joff=joff.numpy())
+
+
+def junctions_topk(jloc: np.ndarray, joff: np.ndarray, topk: int = 300) -> np.ndarray:
+    """non_maximum_suppression (a * (a == max_pool2d(a, 3, 1, 1))) + get_junctions (top-k scores; x = col + joff_x + 0.5,
+    y = row + joff_y + 0.5).  Ties: torch.topk leaves their order unspecified — fixed here as ascending raster index."""
+    h, w = jloc.shape
+    pad = np.full((h + 2, w + 2), -np.inf, np.float32)
+    pad[1:-1, 1:-1] = jloc
+    mp = np.max(np.stack([pad[dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)]), 0)
+    a = np.where(jloc == mp, jloc, np.float32(0)).astype(np.float32).reshape(-1)
+    order = np.argsort(-a.astype(np.float64), kind="stable")[:topk]
+    out = np.zeros((topk, 2), np.float32)
+    valid = a[order] > 0                    # the device emits only suppressed maxima with a positive score (always >= topk of them in practice)
+    idx = order[valid]
+    out[:idx.size, 0] = ((idx % w).astype(np.float32) + joff[0].reshape(-1)[idx]).astype(np.float32) + np.float32(0.5)
+    out[:idx.size, 1] = ((idx // w).astype(np.float32) + joff[1].reshape(-1)[idx]).astype(np.float32) + np.float32(0.5)
+    return out
+
+
+def j2l_match(lines: np.ndarray, juncs: np.ndarray, thr: float = 10.0):
+    """HAWP wireframe_matcher: squared distances of both endpoints to every junction (float32, products rounded separately),
+    first minimum; idx_min / idx_max; iskeep = (min < max) & (d1 < thr) & (d2 < thr).  Returns three float32 arrays [n]."""
+    l = lines.astype(np.float32); j = juncs.astype(np.float32)
+    n = l.shape[0]
+    i1 = np.zeros(n, np.int64); i2 = np.zeros(n, np.int64)
+    c1 = np.full(n, np.inf, np.float32); c2 = np.full(n, np.inf, np.float32)
+    for k in range(j.shape[0]):
+        ax = (l[:, 0] - j[k, 0]).astype(np.float32); ay = (l[:, 1] - j[k, 1]).astype(np.float32)
+        bx = (l[:, 2] - j[k, 0]).astype(np.float32); by = (l[:, 3] - j[k, 1]).astype(np.float32)
+        d1 = ((ax * ax).astype(np.float32) + (ay * ay).astype(np.float32)).astype(np.float32)
+        d2 = ((bx * bx).astype(np.float32) + (by * by).astype(np.float32)).astype(np.float32)
+        u1 = d1 < c1; u2 = d2 < c2
+        c1[u1] = d1[u1]; i1[u1] = k
+        c2[u2] = d2[u2]; i2[u2] = k
+    lo, hi = np.minimum(i1, i2), np.maximum(i1, i2)
+    keep = ((lo < hi) & (c1 < np.float32(thr)) & (c2 < np.float32(thr))).astype(np.float32)
+    return keep, lo.astype(np.float32), hi.astype(np.float32)
+
+
 # ------------------------------------------------------------------ LightGlue
 def _rotate_half(x):
     x = x.unflatten(-1, (-1, 2))

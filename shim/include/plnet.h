@@ -26,13 +26,14 @@ class PLNet {
   void save_engine() {}                         // weight packing is redone at build(); nothing to cache
   bool deserialize_engine() { return false; }
 
-  // Optional provider of the stage-0 line-branch tensors.  plnet_s0.onnx is not in the
-  // reference checkout, so its line branch cannot be rebuilt; until it is, infer() returns points only.
+  // Optional HOST provider of the stage-0 line-branch tensors, overriding the on-device line branch
+  // that a stage-0 pack with line.* tensors gives (known-answer tests of the downstream stages use it).
   void set_stage0_provider(const airfe_plnet_stage0* (*fn)(const cv::Mat&, void*), void* user) { s0_fn_ = fn; s0_user_ = user; }
 
  private:
   PLNetConfig plnet_config_;
   airfe_ctx* ctx_ = nullptr;
+  bool has_lines_ = false;
   const airfe_plnet_stage0* (*s0_fn_)(const cv::Mat&, void*) = nullptr;
   void* s0_user_ = nullptr;
   std::vector<float> feat_, junc_;

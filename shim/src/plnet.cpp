@@ -22,7 +22,7 @@ bool PLNet::build() {
   cfg.remove_borders = plnet_config_.remove_borders;
   cfg.line_threshold = plnet_config_.line_threshold;
   cfg.line_length_threshold = plnet_config_.line_length_threshold;
-  const std::string s0 = airfe_shim::pack_path(plnet_config_.plnet_s0_onnx);   // point branch (VGG trunk + heads)
+  const std::string s0 = airfe_shim::pack_path(plnet_config_.plnet_s0_onnx);   // stage 0: VGG trunk + point heads + line branch (line.*)
   const std::string s1 = airfe_shim::pack_path(plnet_config_.plnet_s1_onnx);   // LOI line-verification head
   cfg.superpoint_pack = s0.c_str();
   cfg.plnet_s1_pack = s1.c_str();
@@ -31,10 +31,17 @@ bool PLNet::build() {
     ctx_ = nullptr;
     return false;
   }
+  // The stage-0 pack normally carries the line branch (tensors line.conv1.*, line.head.*) and infer() then needs nothing from the
+  // host.  A point-only pack leaves PLNet::infer without lines and junctions: the reference's callers (feature_detector.cc:52-69,
+  // map_builder.cc) would silently turn into a point-only SLAM, so say it LOUDLY, once, here.
+  has_lines_ = airfe_has_line_branch(ctx_) != 0;
+  if (!has_lines_)
+    std::cout << "PLNet: " << s0 << " has no line branch (line.* tensors): infer() will return POINTS ONLY — no lines, no junctions — "
+              << "unless set_stage0_provider() supplies the stage-0 line tensors." << std::endl;
   const int cap = (cfg.max_keypoints + 63) / 64 * 64;
   feat_.resize((size_t)cap * AIRFE_FEAT_DIM);
   junc_.resize((size_t)2048 * AIRFE_FEAT_DIM);
-  lines_.resize((size_t)16384 * 4);
+  lines_.resize((size_t)45056 * 4);                                 // 300 junctions: at most 44850 unique lines
   return true;
 }
 
