@@ -89,7 +89,7 @@ class Context:
             raise TypeError("expected a 2-D uint8 image")
         if gray.size == 0:
             raise AirfeError("empty image")
-        if gray.strides[1] != 1:
+        if gray.strides[1] != 1 or gray.strides[0] < gray.shape[1]:      # negative / overlapping row strides: hand over a copy
             gray = np.ascontiguousarray(gray)
         cap = self.np_rows
         feat = np.empty((cap, FEAT), dtype=np.float32)
@@ -97,6 +97,44 @@ class Context:
         self._chk(self._l.airfe_detect_points(self._h, gray.ctypes.data, gray.shape[0], gray.shape[1], gray.strides[0],
                                               feat.ctypes.data, cap, C.byref(n)), "airfe_detect_points")
         return feat[:n.value].copy()
+
+    def bow_load(self, voc: dict):
+        """voc: dict(desc [n,256] f32, first_child [n] i32, n_children [n] i32, word_id [n] i32, weight [n] f64) — weights.synthetic_vocabulary."""
+        d = np.ascontiguousarray(voc["desc"], np.float32); fc = np.ascontiguousarray(voc["first_child"], np.int32)
+        nc = np.ascontiguousarray(voc["n_children"], np.int32); wi = np.ascontiguousarray(voc["word_id"], np.int32)
+        w = np.ascontiguousarray(voc["weight"], np.float64)
+        self._chk(self._l.airfe_bow_load(self._h, d.ctypes.data, fc.ctypes.data, nc.ctypes.data, wi.ctypes.data, w.ctypes.data, d.shape[0]),
+                  "airfe_bow_load")
+
+    def bow_transform(self, feat_rows: np.ndarray):
+        """≙ the per-feature loop of Database::FrameToBow -> (word_of_features [N] uint32 (UINT_MAX = stopped), weights [N] float64)."""
+        f = np.ascontiguousarray(feat_rows, np.float32).reshape(-1, FEAT)
+        wid = np.empty((f.shape[0],), np.uint32); w = np.empty((f.shape[0],), np.float64)
+        self._chk(self._l.airfe_bow_transform(self._h, f.ctypes.data, f.shape[0], wid.ctypes.data, w.ctypes.data), "airfe_bow_transform")
+        return wid, w
+
+    def set_rectify_maps(self, side: int, mapx: np.ndarray, mapy: np.ndarray):
+        """≙ Camera's cv::initUndistortRectifyMap outputs (_mapl1/_mapl2 = side 0, _mapr1/_mapr2 = side 1): float32 [h, w] maps."""
+        mx = np.ascontiguousarray(mapx, np.float32); my = np.ascontiguousarray(mapy, np.float32)
+        if mx.shape != my.shape or mx.ndim != 2:
+            raise TypeError("maps must be two 2-D arrays of one shape")
+        self._chk(self._l.airfe_set_rectify_maps(self._h, side, mx.ctypes.data, my.ctypes.data, mx.shape[0], mx.shape[1]), "airfe_set_rectify_maps")
+
+    def rectify_detect(self, side: int, raw: np.ndarray, detect: bool = True):
+        """≙ Camera::UndistortImage + Detect: raw uint8 image -> (rectified uint8 [h, w], features [n, 259] or None)."""
+        raw = np.asarray(raw)
+        if raw.ndim != 2 or raw.dtype != np.uint8 or raw.size == 0:
+            raise AirfeError("empty image")
+        if raw.strides[1] != 1 or raw.strides[0] < raw.shape[1]:
+            raw = np.ascontiguousarray(raw)
+        rect = np.empty(raw.shape, np.uint8)
+        cap = self.np_rows
+        feat = np.empty((cap, FEAT), np.float32) if detect else None
+        n = C.c_int(0)
+        self._chk(self._l.airfe_rectify_detect_points(self._h, side, raw.ctypes.data, raw.shape[0], raw.shape[1], raw.strides[0],
+                                                      rect.ctypes.data, feat.ctypes.data if detect else None, cap, C.byref(n)),
+                  "airfe_rectify_detect_points")
+        return rect, (feat[:n.value].copy() if detect else None)
 
     def match_lightglue(self, f0: np.ndarray, f1: np.ndarray):
         """f0/f1: [n, 258] rows (normalised x, y, desc) -> (idx [k,2] int32, score [k] float32)."""
@@ -135,7 +173,7 @@ class Context:
         gray = np.asarray(gray)
         if gray.ndim != 2 or gray.dtype != np.uint8 or gray.size == 0:
             raise AirfeError("empty image")
-        if gray.strides[1] != 1:
+        if gray.strides[1] != 1 or gray.strides[0] < gray.shape[1]:
             gray = np.ascontiguousarray(gray)
         cap = self.np_rows
         feat = np.empty((cap, FEAT), np.float32)

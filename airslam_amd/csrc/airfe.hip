@@ -190,6 +190,15 @@ struct airfe_ctx {
   unsigned long long* cand = nullptr;   // [Bmax][512*512] detect_point candidate keys
   int* cand_cnt = nullptr;
   int tab_w = -1, tab_h = -1;
+  // BoW vocabulary tree
+  float *bow_desc = nullptr, *bow_weight = nullptr, *bow_outw = nullptr;
+  int *bow_first = nullptr, *bow_nch = nullptr, *bow_word = nullptr;
+  unsigned* bow_out = nullptr;
+  int bow_nodes = 0;
+  // rectification maps of Camera (camera.cc:60-75), one pair per side, and the rectified-image staging
+  float* rmap[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  int rmap_h[2] = {0, 0}, rmap_w[2] = {0, 0};
+  uint8_t* st_rect = nullptr; size_t st_rect_bytes = 0;
   // host-API staging
   uint8_t* st_img = nullptr; size_t st_img_bytes = 0;
   float *st_feat0 = nullptr, *st_feat1 = nullptr, *st_score = nullptr;
@@ -918,13 +927,32 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st) {
   return 0;
 }
 
-int ensure_stage_img(airfe_ctx* c, size_t bytes) {
-  if (bytes <= c->st_img_bytes) return 0;
+// grow-on-demand staging block: the previous block is freed (it used to stay in `allocs` until destroy)
+int ensure_block(airfe_ctx* c, uint8_t*& blk, size_t& have, size_t bytes) {
+  if (bytes <= have) return 0;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   void* p = nullptr;
   HIPCHK(c, hipMalloc(&p, bytes));
+  if (blk) {
+    auto it = std::find(c->allocs.begin(), c->allocs.end(), (void*)blk);
+    if (it != c->allocs.end()) c->allocs.erase(it);
+    (void)hipFree(blk);
+  }
   c->allocs.push_back(p);
-  c->st_img = reinterpret_cast<uint8_t*>(p);
-  c->st_img_bytes = bytes;
+  blk = reinterpret_cast<uint8_t*>(p);
+  have = bytes;
+  return 0;
+}
+int ensure_stage_img(airfe_ctx* c, size_t bytes) { return ensure_block(c, c->st_img, c->st_img_bytes, bytes); }
+
+// host image -> c->st_img with the SAME row pitch: exactly (h - 1) * stride + w bytes are read (a cv::Mat ROI / numpy view has no
+// bytes behind its last row's w-th pixel that are ours to read)
+int upload_image(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride) {
+  if (!gray || h < 1 || w < 1) return fail(c, "empty image");     // plnet.cpp:247
+  if (stride < w) return fail(c, "image stride smaller than its width");
+  const size_t bytes = (size_t)(h - 1) * stride + w;
+  if (ensure_stage_img(c, (size_t)h * stride)) return 1;
+  HIPCHK(c, hipMemcpyAsync(c->st_img, gray, bytes, hipMemcpyHostToDevice, c->stream));
   return 0;
 }
 
@@ -1068,17 +1096,115 @@ int airfe_detect_points_batch_dev(airfe_ctx* c, const uint8_t* d_gray, int B, in
 
 int airfe_detect_points(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, float* feat, int cap, int* n) {
   if (!c) return 1;
-  if (!gray || h < 1 || w < 1) return fail(c, "empty image");     // plnet.cpp:247
   if (cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
-  const size_t bytes = (size_t)h * stride;
-  if (ensure_stage_img(c, bytes)) return 1;
-  HIPCHK(c, hipMemcpyAsync(c->st_img, gray, bytes, hipMemcpyHostToDevice, c->stream));
-  if (detect_dev(c, c->st_img, 1, h, w, stride, bytes, c->st_feat0, c->Np, c->st_n0, c->stream)) return 1;
+  if (upload_image(c, gray, h, w, stride)) return 1;
+  if (detect_dev(c, c->st_img, 1, h, w, stride, (size_t)h * stride, c->st_feat0, c->Np, c->st_n0, c->stream)) return 1;
   int nn = 0;
   HIPCHK(c, hipMemcpyAsync(&nn, c->st_n0, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (nn > 0) HIPCHK(c, hipMemcpy(feat, c->st_feat0, (size_t)nn * AIRFE_FEAT_DIM * 4, hipMemcpyDeviceToHost));
   *n = nn;
+  return 0;
+}
+
+/* ---- BoW quantisation behind the path: Database::FrameToBow's per-feature tree descent --------------- */
+int airfe_bow_load(airfe_ctx* c, const float* node_desc, const int32_t* first_child, const int32_t* n_children, const int32_t* word_id,
+                   const double* weight, int n_nodes) {
+  if (!c) return 1;
+  if (!node_desc || !first_child || !n_children || !word_id || !weight || n_nodes < 1) return fail(c, "bow_load: bad argument");
+  for (int i = 0; i < n_nodes; ++i) {                    // the device follows these indices: validate them here, once
+    if (n_children[i] < 0 || (n_children[i] > 0 && (first_child[i] <= i || first_child[i] + n_children[i] > n_nodes)))
+      return fail(c, "bow_load: children must lie after their parent and inside the node table");
+  }
+  if (c->bow_nodes) return fail(c, "bow_load: a vocabulary is already loaded in this context");
+  std::vector<float> d(node_desc, node_desc + (size_t)n_nodes * 256), w(n_nodes);
+  for (int i = 0; i < n_nodes; ++i) w[i] = (float)weight[i];
+  std::vector<int> fc(first_child, first_child + n_nodes), nc(n_children, n_children + n_nodes), wi(word_id, word_id + n_nodes);
+  c->bow_desc = dupload(c, d); c->bow_weight = dupload(c, w);
+  c->bow_first = dupload(c, fc); c->bow_nch = dupload(c, nc); c->bow_word = dupload(c, wi);
+  c->bow_out = dalloc<unsigned>(c, 1024); c->bow_outw = dalloc<float>(c, 1024);
+  if (!c->bow_desc || !c->bow_weight || !c->bow_first || !c->bow_nch || !c->bow_word || !c->bow_out || !c->bow_outw)
+    return fail(c, "device allocation failed (vocabulary)");
+  c->bow_nodes = n_nodes;
+  return 0;
+}
+
+int airfe_bow_transform_dev(airfe_ctx* c, const float* d_feat, int N, uint32_t* d_word, float* d_weight, void* stream) {
+  if (!c) return 1;
+  if (!c->bow_nodes) return fail(c, "bow_transform: no vocabulary loaded (airfe_bow_load)");
+  if (N < 0 || (N > 0 && (!d_feat || !d_word || !d_weight))) return fail(c, "bow_transform: bad argument");
+  launch_bow_transform(d_feat, AIRFE_FEAT_DIM, 3, N, c->bow_desc, c->bow_first, c->bow_nch, c->bow_word, c->bow_weight, d_word, d_weight,
+                       stream ? (hipStream_t)stream : c->stream);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int airfe_bow_transform(airfe_ctx* c, const float* feat, int N, uint32_t* word_of_features, double* weight_of_features) {
+  if (!c) return 1;
+  if (N == 0) return 0;                                  // database.cc:60
+  if (N < 0 || N > c->Np || N > 1024 || !feat || !word_of_features) return fail(c, "bow_transform: bad argument / more features than max_keypoints");
+  HIPCHK(c, hipMemcpyAsync(c->st_feat0, feat, (size_t)N * AIRFE_FEAT_DIM * 4, hipMemcpyHostToDevice, c->stream));
+  if (airfe_bow_transform_dev(c, c->st_feat0, N, c->bow_out, c->bow_outw, c->stream)) return 1;
+  std::vector<float> w(N);
+  HIPCHK(c, hipMemcpyAsync(word_of_features, c->bow_out, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(w.data(), c->bow_outw, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (weight_of_features)
+    for (int i = 0; i < N; ++i) weight_of_features[i] = (double)w[i];
+  return 0;
+}
+
+/* ---- rectification in front of the path: Camera::UndistortImage, src/camera.cc:161-182 ------------- */
+int airfe_set_rectify_maps(airfe_ctx* c, int side, const float* mapx, const float* mapy, int h, int w) {
+  if (!c) return 1;
+  if (side < 0 || side > 1 || !mapx || !mapy || h < 1 || w < 1) return fail(c, "set_rectify_maps: bad argument");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t n = (size_t)h * w;
+  for (int k = 0; k < 2; ++k) {
+    if (c->rmap[side][k]) {
+      auto it = std::find(c->allocs.begin(), c->allocs.end(), (void*)c->rmap[side][k]);
+      if (it != c->allocs.end()) c->allocs.erase(it);
+      (void)hipFree(c->rmap[side][k]);
+    }
+    c->rmap[side][k] = dalloc<float>(c, n, false);
+    if (!c->rmap[side][k]) return fail(c, "device allocation failed (rectification maps)");
+    HIPCHK(c, hipMemcpy(c->rmap[side][k], k ? mapy : mapx, n * 4, hipMemcpyHostToDevice));
+  }
+  c->rmap_h[side] = h;
+  c->rmap_w[side] = w;
+  return 0;
+}
+
+int airfe_rectify_batch_dev(airfe_ctx* c, int side, const uint8_t* d_raw, int B, int h, int w, int stride, size_t img_stride,
+                            uint8_t* d_rect, int rstride, size_t rimg_stride, void* stream) {
+  if (!c) return 1;
+  if (side < 0 || side > 1 || !c->rmap[side][0]) return fail(c, "rectify: no maps set for this side (airfe_set_rectify_maps)");
+  if (h != c->rmap_h[side] || w != c->rmap_w[side]) return fail(c, "rectify: image size differs from the maps'");
+  if (stride < w || rstride < w) return fail(c, "rectify: stride smaller than the width");
+  launch_remap_linear(d_raw, B, h, w, stride, img_stride, c->rmap[side][0], c->rmap[side][1], d_rect, rstride, rimg_stride,
+                      stream ? (hipStream_t)stream : c->stream);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+/* raw HOST image -> rectified image (HOST, tight rows, may be NULL) + point features of the RECTIFIED image: the rectified
+   image never leaves the device on its way into the detector */
+int airfe_rectify_detect_points(airfe_ctx* c, int side, const uint8_t* raw, int h, int w, int stride, uint8_t* rect_out, float* feat,
+                                int cap, int* n) {
+  if (!c) return 1;
+  if (feat && cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
+  if (upload_image(c, raw, h, w, stride)) return 1;
+  if (ensure_block(c, c->st_rect, c->st_rect_bytes, (size_t)h * w)) return 1;
+  if (airfe_rectify_batch_dev(c, side, c->st_img, 1, h, w, stride, (size_t)h * stride, c->st_rect, w, (size_t)h * w, c->stream)) return 1;
+  int nn = 0;
+  if (feat) {
+    if (detect_dev(c, c->st_rect, 1, h, w, w, (size_t)h * w, c->st_feat0, c->Np, c->st_n0, c->stream)) return 1;
+    HIPCHK(c, hipMemcpyAsync(&nn, c->st_n0, 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  if (rect_out) HIPCHK(c, hipMemcpyAsync(rect_out, c->st_rect, (size_t)h * w, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (feat && nn > 0) HIPCHK(c, hipMemcpy(feat, c->st_feat0, (size_t)nn * AIRFE_FEAT_DIM * 4, hipMemcpyDeviceToHost));
+  if (n) *n = nn;
   return 0;
 }
 
@@ -1426,9 +1552,8 @@ int airfe_debug_superglue_scores(airfe_ctx* c, const float* f0, int n0, const fl
 int airfe_debug_preprocess(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, float* out) {
   if (!c || !c->has_sp) return fail(c, "debug_preprocess: detector not loaded");
   const size_t bytes = (size_t)h * stride;
-  if (ensure_stage_img(c, bytes) || ensure_tables(c, h, w)) return 1;
+  if (upload_image(c, gray, h, w, stride) || ensure_tables(c, h, w)) return 1;
   const int R = AIRFE_INTERNAL_SIZE;
-  HIPCHK(c, hipMemcpyAsync(c->st_img, gray, bytes, hipMemcpyHostToDevice, c->stream));
   launch_preprocess(c->st_img, 1, h, w, stride, bytes, c->xtab, c->ytab, c->lut, c->img32, R, R, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy2D(out, (size_t)R * 4, c->img32 + (R + 2) + 1, (size_t)(R + 2) * 4, (size_t)R * 4, R, hipMemcpyDeviceToHost));

@@ -92,6 +92,10 @@ void launch_preprocess(const uint8_t* src, int B, int h, int w, int stride, size
                        const int* xtab /*[RW][4]: x0,x1,a0,a1*/, const int* ytab /*[RH][4]*/, const float* lut /*[256]*/,
                        float* out, int RH, int RW, hipStream_t st);
 
+// cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) of B 8-bit images through one pair of CV_32FC1 maps [h][w] (Camera::UndistortImage, camera.cc:161-182)
+void launch_remap_linear(const uint8_t* src, int B, int h, int w, int stride, size_t img_stride, const float* mapx, const float* mapy,
+                         uint8_t* dst, int dstride, size_t dimg_stride, hipStream_t st);
+
 // ---- detector heads -----------------------------------------------------------------------
 // logits fp32 [B*HC*WC][ldl] (65 valid) -> heat fp32 [B][HC*8][WC*8]
 void launch_softmax_d2s(const float* logits, int ldl, float* heat, int B, int HC, int WC, hipStream_t st);
@@ -188,6 +192,12 @@ void launch_sg_sinkhorn(const float* sim, const int* lens, int B, int Np, int Lz
                         float* Z, hipStream_t st);
 void launch_sg_decode(const float* Z, const int* lens, int B, int Np, int Lz, float thr, int* idx0, float* max0, int* idx1,
                       int32_t* out0, int32_t* out1, float* ms0, float* ms1, hipStream_t st);
+
+// ---- BoW quantisation: TemplatedVocabulary::transform per feature (tree descent by nearest child descriptor); feature i's descriptor
+//      starts at feat + i * ld + off; out_word = word id or UINT_MAX when the leaf's weight is <= 0
+void launch_bow_transform(const float* feat, int ld, int off, int N, const float* node_desc, const int* first_child,
+                          const int* n_children, const int* word_id, const float* weight, unsigned* out_word, float* out_weight,
+                          hipStream_t st);
 
 // ---- point <-> line association (AssignPointsToLines, src/line_processor.cc:68-120) as CSR: row_ptr [L+1], entries
 //      (point index ascending, distance) per line; counts [L] is scratch

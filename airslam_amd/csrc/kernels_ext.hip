@@ -500,6 +500,48 @@ void launch_sg_decode(const float* Z, const int* lens, int B, int Np, int Lz, fl
   hipLaunchKernelGGL(sg_decode_kernel, dim3(B), dim3(1024), 0, st, lens, Lz, idx0, max0, idx1, thr, out0, out1, ms0, ms1);
 }
 
+// =============================================================================== BoW quantisation
+// TemplatedVocabulary::transform(feature, word_id, weight) (3rdparty/DBoW2/include/DBoW2/TemplatedVocabulary.h:1313-1352) for every
+// feature of a frame, as Database::FrameToBow calls it (src/bow/database.cc:57-89): descend the vocabulary tree, at every node
+// taking the child whose 256-d descriptor is nearest in squared L2 distance (FSuperpoint::distance, src/bow/FSuperpoint.cc:45-49),
+// FIRST minimum on ties (strict '<'), until a leaf; emit the leaf's word id and weight.  One wave per feature: the feature sits in
+// registers (4 floats per lane), every candidate child is one coalesced 1 KiB row read.
+__global__ __launch_bounds__(256) void bow_transform_kernel(const float* __restrict__ feat, int ld, int off, int N,
+                                                            const float* __restrict__ node_desc, const int* __restrict__ first_child,
+                                                            const int* __restrict__ n_children, const int* __restrict__ word_id,
+                                                            const float* __restrict__ weight, unsigned* __restrict__ out_word,
+                                                            float* __restrict__ out_weight) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= N) return;
+  const float4 f = *reinterpret_cast<const float4*>(feat + (size_t)i * ld + off + lane * 4);
+  int node = 0;
+  for (int nc = n_children[0]; nc > 0; nc = n_children[node]) {
+    const int c0 = first_child[node];
+    float best = INFINITY;
+    int bi = c0;
+    for (int c = 0; c < nc; ++c) {
+      const float4 d = *reinterpret_cast<const float4*>(node_desc + (size_t)(c0 + c) * 256 + lane * 4);
+      const float dx = f.x - d.x, dy = f.y - d.y, dz = f.z - d.z, dw = f.w - d.w;
+      const float dist = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw);
+      if (dist < best) { best = dist; bi = c0 + c; }
+    }
+    node = bi;
+  }
+  if (lane == 0) {
+    const float w = weight[node];
+    out_word[i] = w > 0.f ? (unsigned)word_id[node] : 0xFFFFFFFFu;      // database.cc:77-83: stopped words -> UINT_MAX
+    out_weight[i] = w;
+  }
+}
+
+void launch_bow_transform(const float* feat, int ld, int off, int N, const float* node_desc, const int* first_child,
+                          const int* n_children, const int* word_id, const float* weight, unsigned* out_word, float* out_weight,
+                          hipStream_t st) {
+  if (N < 1) return;
+  hipLaunchKernelGGL(bow_transform_kernel, dim3((N + 3) / 4), dim3(256), 0, st, feat, ld, off, N, node_desc, first_child, n_children,
+                     word_id, weight, out_word, out_weight);
+}
+
 // =============================================================================== point <-> line association
 // AssignPointsToLines (src/line_processor.cc:68-120): for every line the points lying on it
 // (bounding box +-3 px, point-line distance <= 3 px, endpoint / projection test), as a CSR list in ascending point

@@ -61,6 +61,38 @@ __global__ __launch_bounds__(256) void preprocess_rows_kernel(const uint8_t* __r
   }
 }
 
+// =============================================================================== rectification
+// cv::remap(src, dst, map1, map2, INTER_LINEAR) with CV_32FC1 maps and the default BORDER_CONSTANT(0) as Camera::UndistortImage
+// calls it (src/camera.cc:161-182), 8-bit single channel, restated from OpenCV 4.x imgproc/src/imgwarp.cpp (RemapInvoker +
+// remapBilinear<FixedPtCast<int, uchar, 15>>):  sx = cvRound(mapx * 32), sy = cvRound(mapy * 32) (round half to even);
+// integer part = s >> 5, fraction index = s & 31; weights from the 32 x 32 bilinear table of 15-bit integers
+// w = (32 - fx)(32 - fy) * 32 ... — exact products, except the (0, 0) entry where saturate_cast<short>(32768) = 32767 and the
+// table's sum correction puts the missing 1 on the diagonal tap; result = (sum w_i p_i + 2^14) >> 15, taps outside the image = 0.
+__global__ __launch_bounds__(256) void remap_linear_kernel(const uint8_t* __restrict__ src, int B, int h, int w, int stride, size_t img_stride,
+                                                          const float* __restrict__ mapx, const float* __restrict__ mapy,
+                                                          uint8_t* __restrict__ dst, int dstride, size_t dimg_stride) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+  if (x >= w || y >= h) return;
+  const uint8_t* S = src + (size_t)b * img_stride;
+  const int sx = __float2int_rn(__fmul_rn(mapx[(size_t)y * w + x], 32.f)), sy = __float2int_rn(__fmul_rn(mapy[(size_t)y * w + x], 32.f));
+  // XY = saturate_cast<short>(s >> 5): far-away coordinates clamp to +-32767 / -32768 and land outside any image either way
+  const int ix = max(-32768, min(32767, sx >> 5)), iy = max(-32768, min(32767, sy >> 5));
+  const int fx = sx & 31, fy = sy & 31;
+  int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+  if ((fx | fy) == 0) { w00 = 32767; w11 = 1; }
+  auto tap = [&](int xx, int yy) -> int { return ((unsigned)xx < (unsigned)w && (unsigned)yy < (unsigned)h) ? (int)S[(size_t)yy * stride + xx] : 0; };
+  int v = 0;
+  if (!(ix >= w || ix + 1 < 0 || iy >= h || iy + 1 < 0))
+    v = (tap(ix, iy) * w00 + tap(ix + 1, iy) * w01 + tap(ix, iy + 1) * w10 + tap(ix + 1, iy + 1) * w11 + (1 << 14)) >> 15;
+  dst[(size_t)b * dimg_stride + (size_t)y * dstride + x] = (uint8_t)min(max(v, 0), 255);
+}
+
+void launch_remap_linear(const uint8_t* src, int B, int h, int w, int stride, size_t img_stride, const float* mapx, const float* mapy,
+                         uint8_t* dst, int dstride, size_t dimg_stride, hipStream_t st) {
+  hipLaunchKernelGGL(remap_linear_kernel, dim3((w + 63) / 64, (h + 3) / 4, B), dim3(256), 0, st, src, B, h, w, stride, img_stride, mapx, mapy,
+                     dst, dstride, dimg_stride);
+}
+
 void launch_preprocess(const uint8_t* src, int B, int h, int w, int stride, size_t img_stride, const int* xtab,
                        const int* ytab, const float* lut, float* out, int RH, int RW, hipStream_t st) {
   (void)h;

@@ -74,3 +74,19 @@ def plnet_stage0_lines(seed: int, n_lines: int = 400, fh: int = 128, fw: int = 1
                 iskeep=iskeep.reshape(1, 3, fh, fw), idx_junc_to_end_min=idx_min.reshape(1, 3, fh, fw),
                 idx_junc_to_end_max=idx_max.reshape(1, 3, fh, fw),
                 loi_features=loi[None], loi_features_thin=thin[None], loi_features_aux=aux[None])
+
+
+def rectify_maps(h: int, w: int, seed: int, k1: float = -0.28, k2: float = 0.07, rot_deg: float = 1.5):
+    """Stand-in for cv::initUndistortRectifyMap's CV_32FC1 output (Camera's constructor, src/camera.cc:60-75): for every pixel of
+    the rectified image the float source coordinates in the raw (radially distorted, slightly rotated) image.  EuRoC-like
+    coefficients; corners map outside the raw image, so the BORDER_CONSTANT path is exercised."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 0.61 * w
+    cx, cy = w / 2 + rng.uniform(-8, 8), h / 2 + rng.uniform(-6, 6)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    x = (xx - w / 2) / fx; y = (yy - h / 2) / fy
+    a = np.deg2rad(rot_deg) * rng.uniform(0.5, 1.0)
+    xr = x * np.cos(a) - y * np.sin(a); yr = x * np.sin(a) + y * np.cos(a)
+    r2 = xr * xr + yr * yr
+    d = 1 + k1 * r2 + k2 * r2 * r2
+    return (xr * d * fx + cx).astype(np.float32), (yr * d * fy + cy).astype(np.float32)

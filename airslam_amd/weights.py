@@ -263,6 +263,30 @@ def synthetic_plnet_s1(seed: int = 1234) -> Dict[str, np.ndarray]:
     return w
 
 
+def synthetic_vocabulary(seed: int = 1234, k: int = 10, L: int = 4, stop_fraction: float = 0.05) -> Dict[str, np.ndarray]:
+    """Stand-in for voc/point_voc_L4.bin (absent from the reference checkout): a k-ary, L-level DBoW2 tree over 256-d unit descriptors
+    in breadth-first order (children of a node are consecutive), as hierarchical k-means would leave it — every child is its parent
+    plus a perturbation that shrinks with depth.  Leaves carry word ids 0.. and idf-like weights; a few are 'stopped' (weight 0)."""
+    rng = np.random.default_rng(seed + 50)
+    n = (k ** (L + 1) - 1) // (k - 1)
+    desc = np.zeros((n, 256), np.float32)
+    first = np.zeros(n, np.int32); nch = np.zeros(n, np.int32); word = np.zeros(n, np.int32); weight = np.zeros(n, np.float64)
+    level_start, nxt, words = 0, 1, 0
+    for lvl in range(L + 1):
+        cnt = k ** lvl
+        for i in range(level_start, level_start + cnt):
+            if lvl < L:
+                first[i], nch[i] = nxt, k
+                ch = desc[i][None] + rng.normal(size=(k, 256)).astype(np.float32) * np.float32(0.9 / (lvl + 1))
+                desc[nxt:nxt + k] = ch / np.linalg.norm(ch, axis=1, keepdims=True)
+                nxt += k
+            else:
+                word[i] = words; words += 1
+                weight[i] = 0.0 if rng.uniform() < stop_fraction else float(rng.uniform(0.5, 8.0))
+        level_start += cnt
+    return dict(desc=desc, first_child=first, n_children=nch, word_id=word, weight=weight, k=k, L=L)
+
+
 # ---------------------------------------------------------------------------- packs
 def save_pack(path: str, tensors: Dict[str, np.ndarray]) -> None:
     with open(path, "wb") as f:

@@ -119,6 +119,33 @@ int airfe_assign_points_to_lines(airfe_ctx* ctx, const double* lines, int L, con
 int airfe_match_lines(airfe_ctx* ctx, const int32_t* row_ptr0, const int32_t* pt_idx0, int L0, int point_num0, const int32_t* row_ptr1,
                       const int32_t* pt_idx1, int L1, int point_num1, const int32_t* matches, int M, int32_t* line_matches);
 
+/* ---- the step AFTER the path: BoW quantisation of the descriptors ------------------------------------------ */
+/* ≙ the vocabulary Database's constructor loads (src/bow/database.cc; voc/point_voc_L4.bin is absent from the reference checkout):
+ *   the tree of TemplatedVocabulary (3rdparty/DBoW2/include/DBoW2/TemplatedVocabulary.h:298-323) flattened so that the children of
+ *   node i are the n_children[i] consecutive nodes from first_child[i] on (0 children = leaf = word); node 0 is the root;
+ *   node_desc [n_nodes][256] floats, word_id / weight per node (meaningful at leaves). */
+int airfe_bow_load(airfe_ctx* ctx, const float* node_desc, const int32_t* first_child, const int32_t* n_children, const int32_t* word_id,
+                   const double* weight, int n_nodes);
+/* ≙ the loop of Database::FrameToBow (src/bow/database.cc:66-84): TemplatedVocabulary::transform(feature, id, w) (…Vocabulary.h:1313-1352)
+ *   for each of the N feature rows [N][259]: word_of_features[i] = leaf word id, or UINT_MAX where the leaf weight is <= 0;
+ *   weight_of_features[i] = w (may be NULL).  bow_vector.addWeight / normalize and word_features (std::map work) stay reference code. */
+int airfe_bow_transform(airfe_ctx* ctx, const float* feat, int N, uint32_t* word_of_features, double* weight_of_features);
+int airfe_bow_transform_dev(airfe_ctx* ctx, const float* d_feat, int N, uint32_t* d_word, float* d_weight, void* stream);
+
+/* ---- the step BEFORE the path: rectification ------------------------------------------------------- */
+/* ≙ the maps Camera's constructor builds with cv::initUndistortRectifyMap (src/camera.cc:60-75; _mapl1/_mapl2 = side 0, _mapr1/_mapr2 =
+ *   side 1): CV_32FC1 x / y maps [h][w], uploaded once.  The map CONSTRUCTION (stereoRectify etc.) stays reference code. */
+int airfe_set_rectify_maps(airfe_ctx* ctx, int side, const float* mapx, const float* mapy, int h, int w);
+/* ≙ Camera::UndistortImage (src/camera.cc:161-182: cv::remap(..., INTER_LINEAR), BORDER_CONSTANT 0) + FeatureDetector::Detect on its
+ *   result, in one call: raw HOST image in; rect_out (HOST, h x w tight rows, may be NULL) receives the rectified image the tracker and
+ *   the visualisation still need (map_builder.cc:43,71-72,177); feat / n as airfe_detect_points (feat may be NULL: rectify only).
+ *   The rectified image goes from the remap kernel straight into the detector's pre-process without leaving the device. */
+int airfe_rectify_detect_points(airfe_ctx* ctx, int side, const uint8_t* raw, int h, int w, int stride, uint8_t* rect_out, float* feat,
+                                int cap, int* n);
+/* device-resident batch form: d_raw / d_rect [B] images (image b at + b * img_stride, rows stride bytes apart) */
+int airfe_rectify_batch_dev(airfe_ctx* ctx, int side, const uint8_t* d_raw, int B, int h, int w, int stride, size_t img_stride,
+                            uint8_t* d_rect, int rstride, size_t rimg_stride, void* stream);
+
 /* ---- device-resident batch pipeline (NEW: no reference counterpart) ------------------------------------ */
 /* d_gray: [B] images, image b at d_gray + b*img_stride, rows `stride` bytes apart.  d_feat [B][cap][259], d_n [B]. */
 int airfe_detect_points_batch_dev(airfe_ctx* ctx, const uint8_t* d_gray, int B, int h, int w, int stride,

@@ -66,6 +66,76 @@ def process_image(image: np.ndarray, rw: int = 512, rh: int = 512):
     return x, w_scale, h_scale
 
 
+# ------------------------------------------------------------------ BoW quantisation
+def bow_transform(voc: dict, desc: np.ndarray, return_margin: bool = False):
+    """TemplatedVocabulary::transform(feature, word_id, weight) (3rdparty/DBoW2/include/DBoW2/TemplatedVocabulary.h:1313-1352) per row of
+    desc [N,256]: descend from the root, at every node to the child with the smallest squared L2 distance (FSuperpoint::distance,
+    src/bow/FSuperpoint.cc:45-49; FIRST minimum, strict '<'), to a leaf.  Returns (word_of_features uint32 with UINT_MAX where the
+    leaf weight is <= 0 — src/bow/database.cc:77-83 —, weights float64[, the smallest relative gap between the two nearest children
+    seen on the way: rows with a tiny gap are decided by float summation order])."""
+    d = desc.astype(np.float32)
+    n = d.shape[0]
+    words = np.zeros(n, np.uint32); weights = np.zeros(n, np.float64); margin = np.full(n, np.inf)
+    for i in range(n):
+        node = 0
+        while voc["n_children"][node] > 0:
+            c0, nc = int(voc["first_child"][node]), int(voc["n_children"][node])
+            diff = voc["desc"][c0:c0 + nc].astype(np.float64) - d[i].astype(np.float64)[None]
+            dist = (diff * diff).sum(1)
+            j = int(np.argmin(dist))                                   # first minimum
+            if nc > 1:
+                s2 = np.partition(dist, 1)[:2]
+                margin[i] = min(margin[i], (s2[1] - s2[0]) / max(s2[1], 1e-30))
+            node = c0 + j
+        w = float(voc["weight"][node])
+        weights[i] = w
+        words[i] = np.uint32(voc["word_id"][node]) if w > 0 else np.uint32(0xFFFFFFFF)
+    return (words, weights, margin) if return_margin else (words, weights)
+
+
+def frame_to_bow(words: np.ndarray, weights: np.ndarray):
+    """The rest of Database::FrameToBow (src/bow/database.cc:66-97) on the per-feature (word, weight) pairs: BowVector::addWeight (sum per
+    word, std::map order), word_features[id] = feature indices, then L1 normalisation (DBoW2's default scoring, L1_NORM)."""
+    bow, wf = {}, {}
+    for i, (wid, w) in enumerate(zip(words.tolist(), weights.tolist())):
+        if w > 0:
+            bow[wid] = bow.get(wid, 0.0) + w
+            wf.setdefault(wid, []).append(i)
+    tot = sum(abs(v) for v in bow.values())
+    if tot > 0:
+        bow = {k: v / tot for k, v in bow.items()}
+    return dict(sorted(bow.items())), dict(sorted(wf.items()))
+
+
+# ------------------------------------------------------------------ rectification (SURVEY.md 8(f) rank 1)
+def remap_linear_u8(src: np.ndarray, mapx: np.ndarray, mapy: np.ndarray) -> np.ndarray:
+    """cv::remap(src, dst, map1, map2, cv::INTER_LINEAR) for CV_8UC1 with CV_32FC1 maps and the default BORDER_CONSTANT(0), as
+    Camera::UndistortImage calls it (src/camera.cc:161-182).  Restated from OpenCV 4.x imgproc/src/imgwarp.cpp (RemapInvoker,
+    initInterTab2D, remapBilinear<FixedPtCast<int, uchar, INTER_REMAP_COEF_BITS = 15>>) — PARITY UNPINNED: OpenCV is absent here.
+      sx = cvRound(mapx * 32) (float multiply, round half to even); integer part sx >> 5 saturated to short, fraction sx & 31
+      weights = bilinear products * 2^15 — exact integers, except entry (0, 0): saturate_cast<short>(32768) = 32767 and the table's
+      sum correction adds the missing 1 to the DIAGONAL tap (initInterTab2D's index arithmetic for ksize = 2)
+      dst = (sum_i w_i * tap_i + 2^14) >> 15 ; a tap outside the image contributes 0 ; wholly outside -> 0"""
+    h, w = src.shape
+    assert mapx.shape == mapy.shape
+    sx = np.rint((mapx.astype(F) * F(32)).astype(F)).astype(np.int64)
+    sy = np.rint((mapy.astype(F) * F(32)).astype(F)).astype(np.int64)
+    ix = np.clip(sx >> 5, -32768, 32767)
+    iy = np.clip(sy >> 5, -32768, 32767)
+    fx, fy = sx & 31, sy & 31
+    w00 = (32 - fx) * (32 - fy) * 32; w01 = fx * (32 - fy) * 32; w10 = (32 - fx) * fy * 32; w11 = fx * fy * 32
+    z = (fx | fy) == 0
+    w00 = np.where(z, 32767, w00); w11 = np.where(z, 1, w11)
+    s = src.astype(np.int64)
+
+    def tap(xx, yy):
+        ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+        return np.where(ok, s[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)], 0)
+    v = (tap(ix, iy) * w00 + tap(ix + 1, iy) * w01 + tap(ix, iy + 1) * w10 + tap(ix + 1, iy + 1) * w11 + (1 << 14)) >> 15
+    outside = (ix >= w) | (ix + 1 < 0) | (iy >= h) | (iy + 1 < 0)
+    return np.where(outside, 0, np.clip(v, 0, 255)).astype(np.uint8)
+
+
 # ------------------------------------------------------------------ model-side NMS
 def simple_nms(scores: np.ndarray, radius: int) -> np.ndarray:
     """SuperPoint `simple_nms` (public SuperGluePretrainedNetwork models/superpoint.py); believed
