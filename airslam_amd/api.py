@@ -331,6 +331,12 @@ class Context:
                                                           score_t.data_ptr(), idx_t.shape[1], nm_t.data_ptr(), self._stream(stream)),
                   "airfe_match_lightglue_batch_dev")
 
+    def match_superglue_batch_dev(self, f0_t, n0_t, f1_t, n1_t, idx0_t, idx1_t, ms0_t, ms1_t, stream=None):
+        self._chk(self._l.airfe_match_superglue_batch_dev(self._h, f0_t.data_ptr(), n0_t.data_ptr(), f1_t.data_ptr(), n1_t.data_ptr(),
+                                                          f0_t.shape[0], f0_t.shape[1], idx0_t.data_ptr(), idx1_t.data_ptr(),
+                                                          ms0_t.data_ptr(), ms1_t.data_ptr(), self._stream(stream)),
+                  "airfe_match_superglue_batch_dev")
+
     def stereo_batch_dev(self, left_t, right_t, featL, featR, nL, nR, idx_t, score_t, nm_t, stream=None):
         b, h, w = left_t.shape
         self._chk(self._l.airfe_stereo_batch_dev(self._h, left_t.data_ptr(), right_t.data_ptr(), b, h, w, left_t.stride(1),

@@ -166,6 +166,7 @@ struct airfe_ctx {
   bool has_sp = false, has_lg = false;
   char* pl_stage = nullptr;      // staging of airfe_assign_points_to_lines
   size_t pl_bytes = 0;
+  bool nms_map_valid = true;     // heat_nms holds the last batch's NMS'd maps (large batches skip writing them)
   bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
   int gemm_small_max = 4096, gemm8_min = 16000, gemmr_min = 8192, gemmr_wgs = 256;   // GemmArgs::small_max / g8_min / gr_min / gr_wgs (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M, AIRFE_GEMMR_MIN_M, AIRFE_GEMMR_WGS)
   int block_min = 3200;          // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
@@ -227,6 +228,7 @@ struct airfe_ctx {
   int Lz = 0;
   float *sg_u = nullptr, *sg_v = nullptr, *sg_Z = nullptr, *sg_max0 = nullptr, *sg_ms0 = nullptr, *sg_ms1 = nullptr;
   int *sg_idx0 = nullptr, *sg_idx1 = nullptr;
+  unsigned* sg_cnt = nullptr;    // per-pair rendezvous counters of the fused Sinkhorn kernel
   int32_t *sg_out0 = nullptr, *sg_out1 = nullptr;
 
   // PLNet stage-0 line branch (HAWP-style head on the shared trunk; weights ride in the detector pack as line.*)
@@ -603,9 +605,10 @@ int load_superglue(airfe_ctx* c, const char* path) {
   c->sg_u = dalloc<float>(c, pl); c->sg_v = dalloc<float>(c, pl); c->sg_Z = dalloc<float>(c, pl * c->Lz);
   c->sg_max0 = dalloc<float>(c, pl); c->sg_ms0 = dalloc<float>(c, pl); c->sg_ms1 = dalloc<float>(c, pl);
   c->sg_idx0 = dalloc<int>(c, pl); c->sg_idx1 = dalloc<int>(c, pl);
+  c->sg_cnt = dalloc<unsigned>(c, (size_t)P * 16);
   c->sg_out0 = dalloc<int32_t>(c, pl); c->sg_out1 = dalloc<int32_t>(c, pl);
   if (!c->sg_u || !c->sg_v || !c->sg_Z || !c->sg_max0 || !c->sg_ms0 || !c->sg_ms1 || !c->sg_idx0 || !c->sg_idx1 ||
-      !c->sg_out0 || !c->sg_out1)
+      !c->sg_out0 || !c->sg_out1 || !c->sg_cnt)
     return fail(c, "device allocation failed (SuperGlue arena)");
   c->has_sg = true;
   return 0;
@@ -737,9 +740,13 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
   {
     ProfScope ps(c, ST_NMS, st, 0, (double)B * R * R * 8);
     if (c->cfg.nms_radius == 4 && R % 64 == 0) {          // (the tiled kernel moves 4-pixel vectors: R = 512 always qualifies)
-      launch_nms4_candidates(c->heat, c->heat_nms, c->nms_mask, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand,
-                             c->cand_cnt, ccap, st);
+      // the dense NMS'd map is consumed only by the batch-1 line path (junction scores) and the inspection hook: large batches skip
+      // its 1 MB / image write (airfe_debug_detector_maps rebuilds it on demand)
+      c->nms_map_valid = B <= 2;
+      launch_nms4_candidates(c->heat, c->nms_map_valid ? c->heat_nms : nullptr, c->nms_mask, B, R, R, c->cfg.keypoint_threshold,
+                             c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
     } else if (c->cfg.nms_radius > 0) {
+      c->nms_map_valid = true;
       launch_simple_nms(c->heat, c->heat_nms, c->nms_tmp, B, R, R, c->cfg.nms_radius, st);
       launch_candidates(c->heat_nms, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
     } else {
@@ -893,7 +900,7 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   }
   run_linear(c, c->sg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
   launch_sim(c->mprec, c->mdb, c->simbuf, B, Np, st);
-  launch_sg_sinkhorn(c->simbuf, c->lens, B, Np, c->Lz, c->sg_alpha, c->cfg.sinkhorn_iters, c->sg_u, c->sg_v, c->sg_Z, st);
+  launch_sg_sinkhorn(c->simbuf, c->lens, B, Np, c->Lz, c->sg_alpha, c->cfg.sinkhorn_iters, c->sg_u, c->sg_v, c->sg_Z, c->sg_cnt, st);
   launch_sg_decode(c->sg_Z, c->lens, B, Np, c->Lz, 0.2f, c->sg_idx0, c->sg_max0, c->sg_idx1, c->sg_out0, c->sg_out1, c->sg_ms0,
                    c->sg_ms1, st);
   HIPCHK(c, hipGetLastError());
@@ -1213,6 +1220,12 @@ int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t R = AIRFE_INTERNAL_SIZE;
   if (heat_raw) HIPCHK(c, hipMemcpy(heat_raw, c->heat, (size_t)B * R * R * 4, hipMemcpyDeviceToHost));
+  if (heat_nms && c->cfg.nms_radius > 0 && !c->nms_map_valid) {      // the batch path skipped the dense map: rebuild it from the heat maps
+    launch_nms4_candidates(c->heat, c->heat_nms, c->nms_mask, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt,
+                           R * R, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->nms_map_valid = true;
+  }
   if (heat_nms) HIPCHK(c, hipMemcpy(heat_nms, c->cfg.nms_radius > 0 ? c->heat_nms : c->heat, (size_t)B * R * R * 4, hipMemcpyDeviceToHost));
   if (desc) {
     if (!c->desc_normalised) {      // the inspection hook returns the map the reference would hold: normalised
@@ -1540,6 +1553,21 @@ int airfe_debug_sg_decode(airfe_ctx* c, const float* Z, int n0, int n1, int32_t*
   HIPCHK(c, hipMemcpy(m1.data(), c->sg_ms1, (size_t)n1 * 4, hipMemcpyDeviceToHost));
   for (int i = 0; i < n0; ++i) ms0[i] = (double)m0[i];
   for (int j = 0; j < n1; ++j) ms1[j] = (double)m1[j];
+  return 0;
+}
+
+/* SuperGlue on B pairs of DEVICE feature matrices (259-float rows, original pixel coordinates; NormalizeKeypoints with scale 0.7 on
+   the device): d_idx0 / d_idx1 [B][cap] (-1 = unmatched), d_ms0 / d_ms1 [B][cap] floats.  No reference counterpart (batch-1 there). */
+int airfe_match_superglue_batch_dev(airfe_ctx* c, const float* d_f0, const int* d_n0, const float* d_f1, const int* d_n1, int B, int cap,
+                                    int32_t* d_idx0, int32_t* d_idx1, float* d_ms0, float* d_ms1, void* stream) {
+  if (!c) return 1;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  if (superglue_dev(c, d_f0, d_n0, d_f1, d_n1, B, cap, 1, st)) return 1;
+  const size_t sp = (size_t)c->Lz * 4, dp = (size_t)cap * 4, wb = (size_t)std::min(cap, c->Lz) * 4;
+  HIPCHK(c, hipMemcpy2DAsync(d_idx0, dp, c->sg_out0, sp, wb, B, hipMemcpyDeviceToDevice, st));
+  HIPCHK(c, hipMemcpy2DAsync(d_idx1, dp, c->sg_out1, sp, wb, B, hipMemcpyDeviceToDevice, st));
+  HIPCHK(c, hipMemcpy2DAsync(d_ms0, dp, c->sg_ms0, sp, wb, B, hipMemcpyDeviceToDevice, st));
+  HIPCHK(c, hipMemcpy2DAsync(d_ms1, dp, c->sg_ms1, sp, wb, B, hipMemcpyDeviceToDevice, st));
   return 0;
 }
 

@@ -175,14 +175,13 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
           int lo = two ? left - 32 : left;               // opaque to the optimiser: otherwise the compares are hoisted out of this
           asm volatile("" : "+s"(lo));                  // branch and issued for every tile
           const int la = lo - 8 * hh;
-          if (two) {
+          // (value selects on BOTH accumulators: an if / else that writes st1 or st0 makes hipcc select between the two register
+          //  arrays by pointer and move them to scratch memory — 192 bytes per lane, 8x slower kernel)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (16 * (r >> 3) + (r & 7) >= la) st1[r] = -INFINITY;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (16 * (r >> 3) + (r & 7) >= la) st0[r] = -INFINITY;
+          for (int r = 0; r < 16; ++r) {
+            const bool hit = 16 * (r >> 3) + (r & 7) >= la;
+            st0[r] = (hit && !two) ? -INFINITY : st0[r];
+            st1[r] = (hit && two) ? -INFINITY : st1[r];
           }
         }
       };

@@ -18,16 +18,19 @@ __device__ __forceinline__ bool in_border_box(int x, int y, int W, int H, int bo
 }
 
 // =============================================================================== simple_nms, radius 4
+// eight sliding 9-maxima of 16 inputs with the three-input maximum: 14 + 8 = 22 v_max3_f32 (the two-input doubling scheme
+// max(x, x+1) -> +2 -> +4 -> +x[8] took 45 v_max_f32)
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ void max9_of16(const float* x, float* o) {
-  float a[15], b[13], c[9];
+  float t[14];
 #pragma unroll
-  for (int i = 0; i < 15; ++i) a[i] = fmaxf(x[i], x[i + 1]);
+  for (int i = 0; i < 14; ++i) t[i] = vmax3(x[i], x[i + 1], x[i + 2]);
 #pragma unroll
-  for (int i = 0; i < 13; ++i) b[i] = fmaxf(a[i], a[i + 2]);
-#pragma unroll
-  for (int i = 0; i < 9; ++i) c[i] = fmaxf(b[i], b[i + 4]);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = fmaxf(c[i], x[i + 8]);       // max over x[i .. i+8]
+  for (int i = 0; i < 8; ++i) o[i] = vmax3(t[i], t[i + 3], t[i + 6]);     // max over x[i .. i+8]
 }
 
 // Public SuperPoint simple_nms(scores, 4) = 5 dependent 9x9 max-pools, one LAUNCH per pool over 64x32 tiles with a 4-pixel
@@ -125,8 +128,11 @@ __global__ __launch_bounds__(256) void nms_pool_kernel(const float* __restrict__
         if (MODE == 2) Bt[bi] = m;
         else if (gy < H && gx < W) {
           const size_t gi = (size_t)gy * W + gx;
-          const float v = m ? S[gi] : 0.f;
-          out[img + gi] = v;
+          // a kept pixel's score: `a` is the SUPPRESSED score (0 inside its own suppression zone), so the original is fetched —
+          // only for the ~1 % of pixels that survive (a predicated load; the unconditional form re-read the whole map)
+          float v = 0.f;
+          if (m) v = S[gi];
+          if (out) out[img + gi] = v;                    // the dense NMS map is optional: the batch path only needs the candidates
           keep_v[i] = v;
         }
       }

@@ -155,6 +155,10 @@ int airfe_detect_points_batch_dev(airfe_ctx* ctx, const uint8_t* d_gray, int B, 
  *   d_idx [B][mcap][2], d_score [B][mcap], d_nmatch [B]. */
 int airfe_match_lightglue_batch_dev(airfe_ctx* ctx, const float* d_f0, const int* d_n0, const float* d_f1, const int* d_n1,
                                     int B, int cap, int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, void* stream);
+/* SuperGlue on B pairs (as above; NormalizeKeypoints scale 0.7, src/point_matcher.cc:58): d_idx0 / d_idx1 [B][cap] (-1 = unmatched,
+ *   decode semantics of src/super_glue.cpp:339-367), d_ms0 / d_ms1 [B][cap] floats. */
+int airfe_match_superglue_batch_dev(airfe_ctx* ctx, const float* d_f0, const int* d_n0, const float* d_f1, const int* d_n1, int B, int cap,
+                                    int32_t* d_idx0, int32_t* d_idx1, float* d_ms0, float* d_ms1, void* stream);
 /* One "stereo detect+match pair" x B (≙ map_builder.cc:85-86: Detect(L,R) + MatchingPoints(L,R)). */
 int airfe_stereo_batch_dev(airfe_ctx* ctx, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
                            size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR,

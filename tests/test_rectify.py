@@ -49,10 +49,15 @@ def test_remap_kernel_bit_exact(h, w, seed):
     ctx.set_rectify_maps(seed & 1, mx, my)
     rect, _ = ctx.rectify_detect(seed & 1, raw, detect=False)
     ref = ref_post.remap_linear_u8(raw, mx, my)
-    outside = (mx < -1) | (mx >= w) | (my < -1) | (my >= h)
-    if (h, w) == (480, 752):
-        assert outside.any() and (~outside).mean() > 0.8         # the BORDER_CONSTANT path and the interior are both exercised
     np.testing.assert_array_equal(rect, ref)
+    # the BORDER_CONSTANT path: the same map pushed 60 px off the image (taps partly / wholly outside along two edges)
+    ctx.set_rectify_maps(seed & 1, mx - 60, my + 45)
+    rect3, _ = ctx.rectify_detect(seed & 1, raw, detect=False)
+    ref3 = ref_post.remap_linear_u8(raw, mx - 60, my + 45)
+    if (h, w) == (480, 752):
+        assert 0.02 < (ref3 == 0).mean() < 0.6          # a real zero border AND a real interior
+    np.testing.assert_array_equal(rect3, ref3)
+    ctx.set_rectify_maps(seed & 1, mx, my)
     # a strided view (cv::Mat ROI) gives the same picture
     big = np.zeros((h, w + 24), np.uint8); big[:, 8:8 + w] = raw
     rect2, _ = ctx.rectify_detect(seed & 1, big[:, 8:8 + w], detect=False)
