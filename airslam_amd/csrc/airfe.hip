@@ -231,6 +231,17 @@ struct airfe_ctx {
   unsigned* sg_cnt = nullptr;    // per-pair rendezvous counters of the fused Sinkhorn kernel
   int32_t *sg_out0 = nullptr, *sg_out1 = nullptr;
 
+  // fp32 correctness path (cfg.precision = 2 / matcher_precision = 2): fp32 weights and activations, kernels_f32.hip
+  struct F32Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; };
+  struct F32Lin { float* w = nullptr; float* b = nullptr; int K = 0, N = 0; };
+  struct F32LgLayer { F32Lin qkv, out, ffn0, ffn3, cqk, cv, cout, cffn0, cffn3; float *ln_g, *ln_b, *cln_g, *cln_b; };
+  F32Conv f_c1b, f_c2a, f_c2b, f_c3a, f_c3b, f_c4a, f_c4b, f_cPa, f_cDa, f_cL1;
+  F32Lin f_cPb, f_cDb, f_cLh, f_lgfinal;
+  std::vector<F32LgLayer> f_lg;
+  int f_B = 0;                   // images per pass of the fp32 encoder (its activations are 4 bytes: 2 images at a time)
+  float *f1a = nullptr, *f1b = nullptr, *fp1 = nullptr, *f2a = nullptr, *f2b = nullptr, *fp2 = nullptr, *f3a = nullptr, *f3b = nullptr,
+        *fp3 = nullptr, *f4a = nullptr, *f4b = nullptr, *fPa = nullptr, *fDa = nullptr, *fL1 = nullptr;
+  float *m_qkv = nullptr, *m_ctx = nullptr, *m_msg = nullptr, *m_h = nullptr, *m_md = nullptr;
   // PLNet stage-0 line branch (HAWP-style head on the shared trunk; weights ride in the detector pack as line.*)
   bool has_s0 = false;
   ConvW cL1;                     // line.conv1: 3x3 128 -> 128 on the conv3a features
@@ -388,8 +399,94 @@ std::vector<int> resize_table(int dsize, int ssize) {
   return t;
 }
 
+// ---- fp32 correctness path: weights as fp32, convolutions as [9][Cin][Cout]
+bool f32_conv(airfe_ctx* c, const Pack& p, const std::string& name, int cin, int cout, airfe_ctx::F32Conv& out, std::string& err) {
+  const Tensor* w = need(p, name + ".weight", err);
+  const Tensor* b = need(p, name + ".bias", err);
+  if (!w || !b) return false;
+  if ((int)w->data.size() != cout * cin * 9 || (int)b->data.size() != cout) { err = name + ": unexpected shape"; return false; }
+  std::vector<float> t((size_t)9 * cin * cout);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int tap = 0; tap < 9; ++tap) t[((size_t)tap * cin + ci) * cout + co] = w->data[((size_t)co * cin + ci) * 9 + tap];
+  out.w = dupload(c, t); out.b = dupload(c, b->data); out.cin = cin; out.cout = cout;
+  return out.w && out.b;
+}
+bool f32_lin(airfe_ctx* c, const float* W, const float* bias, int K, int N, airfe_ctx::F32Lin& out, const std::function<int(int)>* src_row = nullptr) {
+  std::vector<float> w((size_t)N * K), b(N);
+  for (int n = 0; n < N; ++n) {
+    const int r = src_row ? (*src_row)(n) : n;
+    memcpy(&w[(size_t)n * K], W + (size_t)r * K, (size_t)K * 4);
+    b[n] = bias[r];
+  }
+  out.w = dupload(c, w); out.b = dupload(c, b); out.K = K; out.N = N;
+  return out.w && out.b;
+}
+bool f32_lin_named(airfe_ctx* c, const Pack& p, const std::string& name, int K, int N, airfe_ctx::F32Lin& out, std::string& err) {
+  const Tensor* w = need(p, name + ".weight", err);
+  const Tensor* b = need(p, name + ".bias", err);
+  if (!w || !b) return false;
+  if ((int)w->data.size() != N * K || (int)b->data.size() != N) { err = name + ": unexpected shape"; return false; }
+  return f32_lin(c, w->data.data(), b->data.data(), K, N, out);
+}
+
+int load_superpoint_f32(airfe_ctx* c, const Pack& p) {
+  std::string err;
+  bool ok = f32_conv(c, p, "conv1b", 64, 64, c->f_c1b, err) && f32_conv(c, p, "conv2a", 64, 64, c->f_c2a, err) &&
+            f32_conv(c, p, "conv2b", 64, 64, c->f_c2b, err) && f32_conv(c, p, "conv3a", 64, 128, c->f_c3a, err) &&
+            f32_conv(c, p, "conv3b", 128, 128, c->f_c3b, err) && f32_conv(c, p, "conv4a", 128, 128, c->f_c4a, err) &&
+            f32_conv(c, p, "conv4b", 128, 128, c->f_c4b, err) && f32_conv(c, p, "convPa", 128, 256, c->f_cPa, err) &&
+            f32_conv(c, p, "convDa", 128, 256, c->f_cDa, err) && f32_lin_named(c, p, "convPb", 256, 65, c->f_cPb, err) &&
+            f32_lin_named(c, p, "convDb", 256, 256, c->f_cDb, err);
+  if (ok && p.count("line.conv1.weight"))
+    ok = f32_conv(c, p, "line.conv1", 128, 128, c->f_cL1, err) && f32_lin_named(c, p, "line.head", 128, 145, c->f_cLh, err);
+  if (!ok) return fail(c, err.empty() ? "device allocation failed while loading fp32 detector weights" : err);
+  const int R = AIRFE_INTERNAL_SIZE;
+  const size_t FB = c->f_B = std::min(c->Bmax, 2);
+  auto sq = [](size_t n) { return n * n; };
+  c->f1a = dalloc<float>(c, FB * sq(R + 2) * 64); c->f1b = dalloc<float>(c, FB * sq(R + 2) * 64);
+  c->fp1 = dalloc<float>(c, FB * sq(R / 2 + 2) * 64); c->f2a = dalloc<float>(c, FB * sq(R / 2 + 2) * 64); c->f2b = dalloc<float>(c, FB * sq(R / 2 + 2) * 64);
+  c->fp2 = dalloc<float>(c, FB * sq(R / 4 + 2) * 64); c->f3a = dalloc<float>(c, FB * sq(R / 4 + 2) * 128); c->f3b = dalloc<float>(c, FB * sq(R / 4 + 2) * 128);
+  c->fp3 = dalloc<float>(c, FB * sq(R / 8 + 2) * 128); c->f4a = dalloc<float>(c, FB * sq(R / 8 + 2) * 128); c->f4b = dalloc<float>(c, FB * sq(R / 8 + 2) * 128);
+  c->fPa = dalloc<float>(c, FB * sq(R / 8) * 256); c->fDa = dalloc<float>(c, FB * sq(R / 8) * 256);
+  c->fL1 = dalloc<float>(c, sq(R / 4) * 128);
+  if (!c->f1a || !c->f1b || !c->fp1 || !c->f2a || !c->f2b || !c->fp2 || !c->f3a || !c->f3b || !c->fp3 || !c->f4a || !c->f4b || !c->fPa ||
+      !c->fDa || !c->fL1)
+    return fail(c, "device allocation failed (fp32 detector arena)");
+  return 0;
+}
+
+int load_lightglue_f32(airfe_ctx* c, const Pack& p, int L) {
+  std::string err;
+  c->f_lg.resize(L);
+  bool ok = true;
+  // Wqkv output index = h*192 + d*3 + {q,k,v}  ->  rows [q(h,d) | k(h,d) | v(h,d)]
+  std::function<int(int)> qkv_row = [](int f) { const int sel = f >> 8, hd = f & 255; return (hd >> 6) * 192 + (hd & 63) * 3 + sel; };
+  for (int i = 0; i < L && ok; ++i) {
+    auto& l = c->f_lg[i];
+    const std::string s = "transformers." + std::to_string(i) + ".self_attn", x = "transformers." + std::to_string(i) + ".cross_attn";
+    const Tensor *wq = need(p, s + ".Wqkv.weight", err), *bq = need(p, s + ".Wqkv.bias", err);
+    const Tensor *g1 = need(p, s + ".ffn.1.weight", err), *b1 = need(p, s + ".ffn.1.bias", err);
+    const Tensor *g2 = need(p, x + ".ffn.1.weight", err), *b2 = need(p, x + ".ffn.1.bias", err);
+    if (!wq || !bq || !g1 || !b1 || !g2 || !b2) { ok = false; break; }
+    ok = f32_lin(c, wq->data.data(), bq->data.data(), 256, 768, l.qkv, &qkv_row) && f32_lin_named(c, p, s + ".out_proj", 256, 256, l.out, err) &&
+         f32_lin_named(c, p, s + ".ffn.0", 512, 512, l.ffn0, err) && f32_lin_named(c, p, s + ".ffn.3", 512, 256, l.ffn3, err) &&
+         f32_lin_named(c, p, x + ".to_qk", 256, 256, l.cqk, err) && f32_lin_named(c, p, x + ".to_v", 256, 256, l.cv, err) &&
+         f32_lin_named(c, p, x + ".to_out", 256, 256, l.cout, err) && f32_lin_named(c, p, x + ".ffn.0", 512, 512, l.cffn0, err) &&
+         f32_lin_named(c, p, x + ".ffn.3", 512, 256, l.cffn3, err);
+    l.ln_g = dupload(c, g1->data); l.ln_b = dupload(c, b1->data); l.cln_g = dupload(c, g2->data); l.cln_b = dupload(c, b2->data);
+  }
+  ok = ok && f32_lin_named(c, p, "log_assignment." + std::to_string(L - 1) + ".final_proj", 256, 256, c->f_lgfinal, err);
+  if (!ok) return fail(c, err.empty() ? "device allocation failed while loading fp32 LightGlue weights" : err);
+  const size_t M = (size_t)(2 * c->Pmax + 2 + 128 / c->Np) * c->Np + 256;
+  c->m_qkv = dalloc<float>(c, M * 768); c->m_ctx = dalloc<float>(c, M * 256); c->m_msg = dalloc<float>(c, M * 256);
+  c->m_h = dalloc<float>(c, M * 512); c->m_md = dalloc<float>(c, M * 256);
+  if (!c->m_qkv || !c->m_ctx || !c->m_msg || !c->m_h || !c->m_md) return fail(c, "device allocation failed (fp32 matcher arena)");
+  return 0;
+}
+
 int load_superpoint(airfe_ctx* c, const char* path) {
-  c->pack_prec = c->prec;
+  c->pack_prec = c->prec == 2 ? 1 : c->prec;
   Pack p;
   std::string err;
   if (!load_pack(path, p, err)) return fail(c, err);
@@ -455,13 +552,14 @@ int load_superpoint(airfe_ctx* c, const char* path) {
       return fail(c, "device allocation failed (line branch arena)");
     c->has_s0 = true;
   }
+  if (c->prec == 2 && load_superpoint_f32(c, p)) return 1;
   return 0;
 }
 
 int alloc_matcher_arena(airfe_ctx* c);
 
 int load_lightglue(airfe_ctx* c, const char* path) {
-  c->pack_prec = c->mprec;
+  c->pack_prec = c->mprec == 2 ? 1 : c->mprec;
   Pack p;
   std::string err;
   if (!load_pack(path, p, err)) return fail(c, err);
@@ -506,6 +604,7 @@ int load_lightglue(airfe_ctx* c, const char* path) {
   c->lg_mw = dupload(c, mw->data);
   c->lg_mb = mb->data[0];
   if (alloc_matcher_arena(c)) return 1;
+  if (c->mprec == 2 && load_lightglue_f32(c, p, L)) return 1;
   c->has_lg = true;
   return 0;
 }
@@ -677,6 +776,95 @@ void run_conv(airfe_ctx* c, const ConvW& w, const uint16_t* x, uint16_t* y, int 
   launch_conv3x3(c->prec, a, st);
 }
 
+// ---- fp32 correctness path: the SuperPoint-VGG encoder + heads up to the dense logits / descriptor maps (what follows — soft-max,
+// NMS, top-K, descriptor sampling — is fp32 in every mode and shared)
+void f32_conv(const airfe_ctx::F32Conv& w, const float* x, float* y, int B, int H, int W, int opad, hipStream_t st) {
+  launch_conv3x3_f32(x, w.w, w.b, y, B, H, W, w.cin, w.cout, opad, st);
+}
+int encode_f32(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, hipStream_t st) {
+  const int R = AIRFE_INTERNAL_SIZE;
+  for (int c0 = 0; c0 < B; c0 += c->f_B) {
+    const int cb = std::min(c->f_B, B - c0);
+    launch_preprocess(d_gray + (size_t)c0 * img_stride, cb, h, w, stride, img_stride, c->xtab, c->ytab, c->lut, c->img32, R, R, st);
+    launch_conv1a_f32(c->img32, c->c1a_w, c->c1a_b, c->f1a, cb, R, R, st);
+    f32_conv(c->f_c1b, c->f1a, c->f1b, cb, R, R, 1, st);
+    launch_maxpool2_f32(c->f1b, c->fp1, cb, R, R, 64, st);
+    f32_conv(c->f_c2a, c->fp1, c->f2a, cb, R / 2, R / 2, 1, st);
+    f32_conv(c->f_c2b, c->f2a, c->f2b, cb, R / 2, R / 2, 1, st);
+    launch_maxpool2_f32(c->f2b, c->fp2, cb, R / 2, R / 2, 64, st);
+    f32_conv(c->f_c3a, c->fp2, c->f3a, cb, R / 4, R / 4, 1, st);
+    f32_conv(c->f_c3b, c->f3a, c->f3b, cb, R / 4, R / 4, 1, st);
+    launch_maxpool2_f32(c->f3b, c->fp3, cb, R / 4, R / 4, 128, st);
+    f32_conv(c->f_c4a, c->fp3, c->f4a, cb, R / 8, R / 8, 1, st);
+    f32_conv(c->f_c4b, c->f4a, c->f4b, cb, R / 8, R / 8, 1, st);
+    f32_conv(c->f_cPa, c->f4b, c->fPa, cb, R / 8, R / 8, 0, st);
+    f32_conv(c->f_cDa, c->f4b, c->fDa, cb, R / 8, R / 8, 0, st);
+    const int cells = cb * (R / 8) * (R / 8);
+    const size_t cell0 = (size_t)c0 * (R / 8) * (R / 8);
+    GemmF32Args g;
+    g.X1 = c->fPa; g.ld1 = 256; g.K1 = 256; g.K = 256; g.W = c->f_cPb.w; g.bias = c->f_cPb.b; g.M = cells; g.N = 65;
+    g.Y = c->logits + cell0 * 72; g.ldy = 72;
+    launch_gemm_f32(g, st);
+    g.X1 = c->fDa; g.W = c->f_cDb.w; g.bias = c->f_cDb.b; g.N = 256; g.Y = c->desc + cell0 * 256; g.ldy = 256;
+    launch_gemm_f32(g, st);
+  }
+  launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st);
+  c->desc_normalised = false;
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// LightGlue forward in fp32 (same call contract as lightglue_dev): q|k|v from ONE [768][256] projection with the rows regrouped
+// head-major, rotary, exact soft-max attention, out-projection, FFN (LayerNorm, erf GELU), residual; the assignment tail is the
+// shared fp32 code
+int lightglue_dev_f32(airfe_ctx* c, const float* f0, const int* n0, const float* f1, const int* n1, int B, int cap, int ld, int kp_off,
+                      int normalize, int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, float* scores_out, hipStream_t st) {
+  const int S = 2 * B, Np = c->Np, M = S * Np;
+  LgPrepArgs pa;
+  pa.f0 = f0; pa.f1 = f1; pa.n0 = n0; pa.n1 = n1; pa.ld = ld; pa.kp_off = kp_off; pa.normalize = normalize;
+  pa.cx = (float)(c->cfg.image_width / 2);
+  pa.cy = (float)(c->cfg.image_height / 2);
+  pa.linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.5f);
+  pa.wr = c->lg_wr; pa.B = B; pa.cap = cap; pa.Np = Np;
+  pa.x32 = c->x32; pa.xb = c->xb; pa.rot_cos = c->rot_cos; pa.rot_sin = c->rot_sin; pa.lens = c->lens;
+  launch_lg_prepare(1, pa, st);
+  auto lin = [&](const airfe_ctx::F32Lin& w, const float* x1, int ld1, int K1, const float* x2, int ld2, float* y, int ldy, int acc, float scale = 1.f) {
+    GemmF32Args g;
+    g.X1 = x1; g.ld1 = ld1; g.K1 = K1; g.X2 = x2; g.ld2 = ld2; g.W = w.w; g.bias = w.b; g.Y = y; g.ldy = ldy;
+    g.M = M; g.N = w.N; g.K = w.K; g.accumulate = acc; g.scale = scale;
+    launch_gemm_f32(g, st);
+  };
+  auto ffn = [&](const airfe_ctx::F32Lin& f0w, const float* g, const float* b, const airfe_ctx::F32Lin& f3w) {
+    lin(f0w, c->x32, 256, 256, c->m_msg, 256, c->m_h, 512, 0);
+    launch_ln_gelu_f32(c->m_h, g, b, M, st);
+    lin(f3w, c->m_h, 512, 512, nullptr, 0, c->x32, 256, 1);
+  };
+  for (const auto& l : c->f_lg) {
+    lin(l.qkv, c->x32, 256, 256, nullptr, 0, c->m_qkv, 768, 0);
+    launch_rotary_f32(c->m_qkv, 768, c->rot_cos, c->rot_sin, M, st);
+    launch_attention_f32(c->m_qkv, 768, c->m_qkv + 256, 768, c->m_qkv + 512, 768, c->m_ctx, c->lens, S, 4, Np, 0, 0.125f, st);
+    lin(l.out, c->m_ctx, 256, 256, nullptr, 0, c->m_msg, 256, 0);
+    ffn(l.ffn0, l.ln_g, l.ln_b, l.ffn3);
+    lin(l.cqk, c->x32, 256, 256, nullptr, 0, c->m_qkv, 768, 0);
+    lin(l.cv, c->x32, 256, 256, nullptr, 0, c->m_qkv + 512, 768, 0);
+    launch_attention_f32(c->m_qkv, 768, c->m_qkv, 768, c->m_qkv + 512, 768, c->m_ctx, c->lens, S, 4, Np, 1, 0.125f, st);
+    lin(l.cout, c->m_ctx, 256, 256, nullptr, 0, c->m_msg, 256, 0);
+    ffn(l.cffn0, l.cln_g, l.cln_b, l.cffn3);
+  }
+  lin(c->f_lgfinal, c->x32, 256, 256, nullptr, 0, c->m_md, 256, 0, 0.25f);      // d^-1/4 on both sides, d = 256
+  launch_rowdot256(c->x32, c->lg_mw, c->lg_mb, c->zbuf, M, st);
+  for (int b = 0; b < B; ++b) {                                                   // sim[b] = md[2b] . md[2b+1]^T
+    GemmF32Args g;
+    g.X1 = c->m_md + (size_t)(2 * b) * Np * 256; g.ld1 = 256; g.K1 = 256; g.K = 256; g.W = c->m_md + (size_t)(2 * b + 1) * Np * 256;
+    g.Y = c->simbuf + (size_t)b * Np * Np; g.ldy = Np; g.M = Np; g.N = Np;
+    launch_gemm_f32(g, st);
+  }
+  launch_lg_assign(c->simbuf, c->zbuf, c->lens, B, Np, mcap, 0.1f, c->rowlse, c->collse, scores_out, c->rowarg, c->rowval, c->colarg, d_idx,
+                   d_score, d_nmatch, st);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat,
                int cap, int* d_n, hipStream_t st) {
   if (!c->has_sp) return fail(c, "detector weights were not loaded (cfg.superpoint_pack)");
@@ -685,56 +873,60 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
   if (cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
   if (ensure_tables(c, h, w)) return 1;
   const int R = AIRFE_INTERNAL_SIZE;
-  for (int c0 = 0; c0 < B; c0 += c->chunk) {
-    const int cb = std::min(c->chunk, B - c0);
-    {
-      ProfScope ps(c, ST_PREPROCESS, st, 0, (double)cb * ((double)h * w + (double)R * R * 4));
-      launch_preprocess(d_gray + (size_t)c0 * img_stride, cb, h, w, stride, img_stride, c->xtab, c->ytab, c->lut, c->img32, R, R, st);
-    }
-    if (c->fuse_conv1a) {
-      // conv1a (Cin = 1) fused into the persistent conv1b kernel: its 64-channel full-resolution output never
-      // reaches HBM (kernels_conv64r.hip).  FLOPs/bytes below are the algorithmic ones of conv1a + conv1b.
-      ConvArgs a;
-      a.Wp = c->c1b.w; a.bias = c->c1b.b; a.Y = c->a1b; a.B = cb; a.H = R; a.W = R; a.CIN = 64; a.COUT = 64;
-      a.pool = 1; a.out_pad = 1; a.relu = 1;
-      a.img = c->img32; a.w1a = c->c1a_w; a.b1a = c->c1a_b;
-      const double px = (double)cb * R * R;
-      ProfScope ps(c, ST_CONV3X3_C64, st, 2.0 * px * 9 * 64 + 2.0 * px * 64 * 64 * 9, px * 4 + px / 4 * 128 + 9.0 * 64 * 64 * 2);
-      launch_conv64r(c->prec, a, st);
-    } else {
+  if (c->prec == 2) {
+    if (encode_f32(c, d_gray, B, h, w, stride, img_stride, st)) return 1;
+  } else {
+    for (int c0 = 0; c0 < B; c0 += c->chunk) {
+      const int cb = std::min(c->chunk, B - c0);
       {
-        ProfScope ps(c, ST_CONV1A, st, 2.0 * cb * R * R * 9 * 64, (double)cb * R * R * (4 + 128));
-        launch_conv1a(c->prec, c->img32, c->c1a_w, c->c1a_b, c->a1a, cb, R, R, st);
+        ProfScope ps(c, ST_PREPROCESS, st, 0, (double)cb * ((double)h * w + (double)R * R * 4));
+        launch_preprocess(d_gray + (size_t)c0 * img_stride, cb, h, w, stride, img_stride, c->xtab, c->ytab, c->lut, c->img32, R, R, st);
       }
-      run_conv(c, c->c1b, c->a1a, c->a1b, cb, R, R, 1, 1, st);
+      if (c->fuse_conv1a) {
+        // conv1a (Cin = 1) fused into the persistent conv1b kernel: its 64-channel full-resolution output never
+        // reaches HBM (kernels_conv64r.hip).  FLOPs/bytes below are the algorithmic ones of conv1a + conv1b.
+        ConvArgs a;
+        a.Wp = c->c1b.w; a.bias = c->c1b.b; a.Y = c->a1b; a.B = cb; a.H = R; a.W = R; a.CIN = 64; a.COUT = 64;
+        a.pool = 1; a.out_pad = 1; a.relu = 1;
+        a.img = c->img32; a.w1a = c->c1a_w; a.b1a = c->c1a_b;
+        const double px = (double)cb * R * R;
+        ProfScope ps(c, ST_CONV3X3_C64, st, 2.0 * px * 9 * 64 + 2.0 * px * 64 * 64 * 9, px * 4 + px / 4 * 128 + 9.0 * 64 * 64 * 2);
+        launch_conv64r(c->prec, a, st);
+      } else {
+        {
+          ProfScope ps(c, ST_CONV1A, st, 2.0 * cb * R * R * 9 * 64, (double)cb * R * R * (4 + 128));
+          launch_conv1a(c->prec, c->img32, c->c1a_w, c->c1a_b, c->a1a, cb, R, R, st);
+        }
+        run_conv(c, c->c1b, c->a1a, c->a1b, cb, R, R, 1, 1, st);
+      }
+      run_conv(c, c->c2a, c->a1b, c->a2a, cb, R / 2, R / 2, 0, 1, st);
+      run_conv(c, c->c2b, c->a2a, c->a2b + (size_t)c0 * (R / 4 + 2) * (R / 4 + 2) * 64, cb, R / 2, R / 2, 1, 1, st);
     }
-    run_conv(c, c->c2a, c->a1b, c->a2a, cb, R / 2, R / 2, 0, 1, st);
-    run_conv(c, c->c2b, c->a2a, c->a2b + (size_t)c0 * (R / 4 + 2) * (R / 4 + 2) * 64, cb, R / 2, R / 2, 1, 1, st);
-  }
-  run_conv(c, c->c3a, c->a2b, c->a3a, B, R / 4, R / 4, 0, 1, st);
-  run_conv(c, c->c3b, c->a3a, c->a3b, B, R / 4, R / 4, 1, 1, st);
-  run_conv(c, c->c4a, c->a3b, c->a4a, B, R / 8, R / 8, 0, 1, st);
-  run_conv(c, c->c4b, c->a4a, c->a4b, B, R / 8, R / 8, 0, 1, st);
-  run_conv(c, c->cPa, c->a4b, c->aPa, B, R / 8, R / 8, 0, 0, st);
-  run_conv(c, c->cDa, c->a4b, c->aDa, B, R / 8, R / 8, 0, 0, st);
-  const int cells = B * (R / 8) * (R / 8);
-  {
-    GemmArgs g;
-    g.X1 = c->aPa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cPb.w; g.bias = c->cPb.b;
-    g.M = cells; g.N = 65; g.cb_total = c->cPb.cbt; g.epi = EPI_STORE_F32; g.out = c->logits; g.ldo = 72;
-    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-    { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 288)); launch_gemm(c->prec, 256, false, g, st); }
-    { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * (260 + 256)); launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st); }
-  }
-  {
-    GemmArgs g;
-    g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b;
-    g.M = cells; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
-    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-    { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024)); launch_gemm(c->prec, 256, false, g, st); }
-    // F.normalize of the dense map is applied lazily: sample_desc_kernel normalises just the 4 taps each keypoint reads
-    // (same operations, same bits) — a dense pass moved 8 MB/image to serve 400 x 4 cell reads.
-    c->desc_normalised = false;
+    run_conv(c, c->c3a, c->a2b, c->a3a, B, R / 4, R / 4, 0, 1, st);
+    run_conv(c, c->c3b, c->a3a, c->a3b, B, R / 4, R / 4, 1, 1, st);
+    run_conv(c, c->c4a, c->a3b, c->a4a, B, R / 8, R / 8, 0, 1, st);
+    run_conv(c, c->c4b, c->a4a, c->a4b, B, R / 8, R / 8, 0, 1, st);
+    run_conv(c, c->cPa, c->a4b, c->aPa, B, R / 8, R / 8, 0, 0, st);
+    run_conv(c, c->cDa, c->a4b, c->aDa, B, R / 8, R / 8, 0, 0, st);
+    const int cells = B * (R / 8) * (R / 8);
+    {
+      GemmArgs g;
+      g.X1 = c->aPa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cPb.w; g.bias = c->cPb.b;
+      g.M = cells; g.N = 65; g.cb_total = c->cPb.cbt; g.epi = EPI_STORE_F32; g.out = c->logits; g.ldo = 72;
+      g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
+      { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 288)); launch_gemm(c->prec, 256, false, g, st); }
+      { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * (260 + 256)); launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st); }
+    }
+    {
+      GemmArgs g;
+      g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b;
+      g.M = cells; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
+      g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
+      { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024)); launch_gemm(c->prec, 256, false, g, st); }
+      // F.normalize of the dense map is applied lazily: sample_desc_kernel normalises just the 4 taps each keypoint reads
+      // (same operations, same bits) — a dense pass moved 8 MB/image to serve 400 x 4 cell reads.
+      c->desc_normalised = false;
+    }
   }
   const int ccap = R * R;
   {
@@ -828,6 +1020,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   if (!c->has_lg) return fail(c, "LightGlue weights were not loaded (cfg.lightglue_pack)");
   if (B < 1 || B > c->Pmax) return fail(c, "pair batch exceeds cfg.max_batch / 2");
   if (cap > c->Np) return fail(c, "feature capacity exceeds the matcher arena (max_keypoints)");
+  if (c->mprec == 2) return lightglue_dev_f32(c, f0, n0, f1, n1, B, cap, ld, kp_off, normalize, d_idx, d_score, mcap, d_nmatch, scores_out, st);
   const int S = 2 * B, Np = c->Np, M = S * Np;
   const int Mg = (M + 127) / 128 * 128;          // rows the matrix kernels run over (surplus rows: arena slack, see alloc_matcher_arena)
   LgPrepArgs pa;
@@ -915,6 +1108,12 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st) {
   float* d = c->s0_stage;
   float *d_juncs = d, *d_lp = d + 600, *d_keep = d_lp + (size_t)NP * 4, *d_min = d_keep + NP, *d_max = d_min + NP;
   float *d_loi = d_max + NP, *d_thin = d_loi + 128 * 128 * 128, *d_aux = d_thin + 4 * 128 * 128;
+  if (c->prec == 2) {
+    launch_conv3x3_f32(c->f3a, c->f_cL1.w, c->f_cL1.b, c->fL1, 1, F, F, 128, 128, 0, st);
+    GemmF32Args g;
+    g.X1 = c->fL1; g.ld1 = 128; g.K1 = 128; g.K = 128; g.W = c->f_cLh.w; g.bias = c->f_cLh.b; g.M = F * F; g.N = 145; g.Y = c->l_head; g.ldy = 160;
+    launch_gemm_f32(g, st);
+  } else {
   run_conv(c, c->cL1, c->a3a, c->l_feat, 1, F, F, 0, 0, st);                 // conv3a features (zero-bordered NHWC) -> [128*128][128]
   {
     GemmArgs g;
@@ -923,6 +1122,7 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st) {
     g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
     ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * F * F * 128 * 145, (double)F * F * (256 + 580));
     launch_gemm(c->prec, 128, false, g, st);
+  }
   }
   launch_s0_decode(c->l_head, d_lp, c->l_jloc, c->l_jnms, c->l_joff, d_thin, d_aux, d_loi, st);
   // get_junctions: top-300 of the suppressed junction map (score descending, raster ascending on ties)
@@ -997,9 +1197,11 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
     return fail(nullptr, "airfe_create: no HIP device visible (the product path has no CPU fallback)");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, "airfe_create: bad device ordinal");
   if (cfg->max_keypoints < 1 || cfg->max_keypoints > 1024) return fail(nullptr, "airfe_create: max_keypoints must be 1..1024");
-  if (cfg->precision != 0 && cfg->precision != 1) return fail(nullptr, "airfe_create: precision must be 0 (bf16) or 1 (fp16)");
-  if (cfg->matcher_precision < -1 || cfg->matcher_precision > 1)
-    return fail(nullptr, "airfe_create: matcher_precision must be -1 (= precision), 0 (bf16) or 1 (fp16)");
+  if (cfg->precision < 0 || cfg->precision > 2) return fail(nullptr, "airfe_create: precision must be 0 (bf16), 1 (fp16) or 2 (fp32)");
+  if (cfg->matcher_precision < -1 || cfg->matcher_precision > 2)
+    return fail(nullptr, "airfe_create: matcher_precision must be -1 (= precision), 0 (bf16), 1 (fp16) or 2 (fp32)");
+  if ((cfg->matcher_precision == 2 || (cfg->matcher_precision < 0 && cfg->precision == 2)) && cfg->superglue_pack)
+    return fail(nullptr, "airfe_create: the fp32 mode covers SuperPoint / PLNet + LightGlue (BASELINE configs[1]); SuperGlue runs in fp16 / bf16");
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, "airfe_create: hipSetDevice failed");
   airfe_ctx* c = new airfe_ctx();
   c->cfg = *cfg;

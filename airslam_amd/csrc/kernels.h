@@ -171,6 +171,28 @@ void launch_line_filter(const float* la, const float* sc, const int* counts, int
 void launch_junction_scan(const unsigned char* jmap, const float* heat, int R, int border, float* feat, int cap, int* n_out,
                           hipStream_t st);
 
+// ---- fp32 correctness path (kernels_f32.hip; cfg.precision = 2): fp32 storage, f32-input MFMA, plain kernels
+struct GemmF32Args {
+  const float* X1 = nullptr; int ld1 = 0, K1 = 0;     // first K1 input columns
+  const float* X2 = nullptr; int ld2 = 0;             // remaining K - K1 columns (cat(x, msg) inputs)
+  const float* W = nullptr;                           // [N][K] row-major (PyTorch Linear layout)
+  const float* bias = nullptr;                        // [N] or nullptr
+  float* Y = nullptr; int ldy = 0;
+  int M = 0, N = 0, K = 0;
+  float scale = 1.f;                                  // applied to (acc + bias)
+  int relu = 0, accumulate = 0;                       // accumulate: Y += result (residual)
+};
+void launch_conv1a_f32(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t st);
+// X [B][H+2][W+2][CIN] zero-bordered -> Y [B][H+2 opad][W+2 opad][COUT]; Wt [9][CIN][COUT]; ReLU; W % 16 == 0, COUT % 64 == 0, CIN % 4 == 0
+void launch_conv3x3_f32(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int CIN, int COUT, int opad,
+                        hipStream_t st);
+void launch_maxpool2_f32(const float* X, float* Y, int B, int H, int W, int C, hipStream_t st);
+void launch_gemm_f32(const GemmF32Args& a, hipStream_t st);
+void launch_rotary_f32(float* qk, int ld, const float* rc, const float* rs, int M, hipStream_t st);
+void launch_attention_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, const int* lens, int S, int H,
+                          int Np, int cross, float scale, hipStream_t st);
+void launch_ln_gelu_f32(float* h, const float* gamma, const float* beta, int M, hipStream_t st);
+
 // ---- PLNet stage-0 line branch (kernels_s0.hip): decode of the fused head GEMM output [128*128][160] fp32
 //      (128 LOI channels | md0..2 dis res | jloc0 jloc1 | joffx joffy | thin0..3 | aux0..3) into the Appendix A.1 tensors
 void launch_s0_decode(const float* head, float* lines_pred /*[3*128*128][4]*/, float* jloc /*[128*128]*/, float* jnms /*[128*128]*/,

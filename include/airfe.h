@@ -31,7 +31,8 @@ typedef struct airfe_ctx airfe_ctx;
 /* Mirrors the knobs of PLNetConfig / SuperPointConfig / PointMatcherConfig (include/read_configs.h:9-103). */
 typedef struct airfe_cfg {
   int device;                  /* HIP device ordinal */
-  int precision;               /* detector storage type: 1 = fp16 (default; the reference's engines are built with kFP16,
+  int precision;               /* detector storage type: 2 = fp32 storage AND arithmetic (correctness mode, f32-input MFMA; BASELINE configs[1]),
+                                  1 = fp16 (default; the reference's engines are built with kFP16,
                                   super_point.cpp:97, plnet.cpp:216 — and the only 2-byte type that meets the 1e-3 descriptor-cosine
                                   tolerance once descriptors are decorrelated: bf16 measures 2e-2), 0 = bf16; accumulation is always fp32 */
   int max_batch;               /* images per detect batch / 2x pairs per match batch the arena is sized for */
@@ -52,7 +53,7 @@ typedef struct airfe_cfg {
   const char* superglue_pack;
   int matcher_precision;       /* storage type of the LightGlue / SuperGlue tokens and weights: 1 = fp16 (default: the reference builds
                                   both matcher engines with BuilderFlag::kFP16, light_glue.cpp:115, super_glue.cpp:132; measured 8x
-                                  closer to the fp32 oracle than bf16), 0 = bf16, -1 = same as `precision` */
+                                  closer to the fp32 oracle than bf16), 0 = bf16, 2 = fp32 (LightGlue only), -1 = same as `precision` */
 } airfe_cfg;
 
 void airfe_default_cfg(airfe_cfg* cfg);
