@@ -188,3 +188,56 @@ def load(path: str) -> Model:
             gout.append(_value_info_name(v))
     gin = [g for g in gin if g not in inits]
     return Model(nodes, inits, gin, gout, opset)
+
+
+# --------------------------------------------------------------------------------------- writer (tests / rehearsals only)
+def _enc_varint(v: int) -> bytes:
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        c = v & 0x7F
+        v >>= 7
+        out.append(c | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _enc_field(fn: int, wt: int, payload) -> bytes:
+    key = _enc_varint((fn << 3) | wt)
+    if wt == 0:
+        return key + _enc_varint(payload)
+    return key + _enc_varint(len(payload)) + payload
+
+
+def _enc_tensor(name: str, a: np.ndarray) -> bytes:
+    code = {np.dtype(v): k for k, v in _DT.items()}[np.dtype(a.dtype)]
+    b = b"".join(_enc_field(1, 0, int(d)) for d in a.shape) + _enc_field(2, 0, code) + _enc_field(8, 2, name.encode())
+    return b + _enc_field(9, 2, np.ascontiguousarray(a).tobytes())
+
+
+def save(path: str, nodes: List[Node], initializers: Dict[str, np.ndarray], inputs: List[str], outputs: List[str], opset: int = 17) -> None:
+    """Write a ModelProto that `load` reads back (fields of SURVEY.md B.5; integer / float / ints attributes only) — enough to
+    build ONNX-SHAPED files for rehearsing tools/onnx_to_pack.py on the model files the reference checkout does not carry."""
+    g = b""
+    for n in nodes:
+        nb = b"".join(_enc_field(1, 2, i.encode()) for i in n.inputs) + b"".join(_enc_field(2, 2, o.encode()) for o in n.outputs)
+        nb += _enc_field(3, 2, n.name.encode()) + _enc_field(4, 2, n.op.encode())
+        for k, v in n.attrs.items():
+            ab = _enc_field(1, 2, k.encode())
+            if isinstance(v, float):
+                ab += _enc_varint((2 << 3) | 5) + struct.pack("<f", v)
+            elif isinstance(v, int):
+                ab += _enc_field(3, 0, v)
+            else:
+                ab += _enc_field(8, 2, b"".join(_enc_varint(int(x)) for x in v))
+            nb += _enc_field(5, 2, ab)
+        g += _enc_field(1, 2, nb)
+    for k, a in initializers.items():
+        g += _enc_field(5, 2, _enc_tensor(k, a))
+    for name in inputs:
+        g += _enc_field(11, 2, _enc_field(1, 2, name.encode()))
+    for name in outputs:
+        g += _enc_field(12, 2, _enc_field(1, 2, name.encode()))
+    model = _enc_field(1, 0, 8) + _enc_field(7, 2, g) + _enc_field(8, 2, _enc_field(2, 0, opset))
+    with open(path, "wb") as f:
+        f.write(model)
