@@ -172,6 +172,7 @@ struct airfe_ctx {
   int block_min = 3200;          // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
   bool qkv_pair = true;          // q|k and v of a layer in one streaming launch (AIRFE_QKV_PAIR=0: two launches)
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
+  int lgb_tokens = 0;            // AIRFE_LGB_TOKENS: tokens per lg_blockf workgroup (128 or 112; 0 = by token count)
   int attn_occ = 3;              // AIRFE_ATTN_OCC: attention32_kernel variant compiled for 2 (no spills) or 3 waves per SIMD
   bool attn_v1 = false;          // AIRFE_ATTN_V1=1: the round-1 16x16x32 attention kernel (A/B runs)
   bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
@@ -1003,6 +1004,8 @@ void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, co
   LgBlockFArgs a;
   a.attn = c->ob; a.xb = c->xb; a.x32 = c->x32; a.wo = out.w; a.w1 = f0.w; a.w2 = f3.w;
   a.bo = out.b; a.b1 = f0.b; a.gamma = g; a.beta = b; a.b2 = f3.b; a.M = M;
+  // one workgroup per CU and pass: ceil(M / T) workgroups run in rounds of 256, a round lasts ~T — take the T with the smaller product
+  a.tokens_per_wg = c->lgb_tokens ? c->lgb_tokens : (((M + 111) / 112 + 255) / 256 * 112 < ((M + 127) / 128 + 255) / 256 * 128 ? 112 : 128);
   ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * (256.0 * 256 + 512.0 * 512 + 512.0 * 256), (double)M * (512 + 512 + 1024 + 512 + 1024) + 917504.0);
   launch_lg_blockf(c->mprec, a, st);
 }
@@ -1219,6 +1222,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (getenv("AIRFE_QKV_PAIR")) c->qkv_pair = atoi(getenv("AIRFE_QKV_PAIR")) != 0;
   if (getenv("AIRFE_GEMMR_WGS")) c->gemmr_wgs = atoi(getenv("AIRFE_GEMMR_WGS"));
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
+  if (getenv("AIRFE_LGB_TOKENS")) c->lgb_tokens = atoi(getenv("AIRFE_LGB_TOKENS")) == 112 ? 112 : (atoi(getenv("AIRFE_LGB_TOKENS")) == 128 ? 128 : 0);
   if (getenv("AIRFE_ATTN_OCC")) c->attn_occ = atoi(getenv("AIRFE_ATTN_OCC")) == 3 ? 3 : 2;
   c->attn_v1 = getenv("AIRFE_ATTN_V1") && atoi(getenv("AIRFE_ATTN_V1")) != 0;
   c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);

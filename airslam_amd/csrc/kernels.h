@@ -60,6 +60,7 @@ struct LgBlockFArgs {
   const uint16_t *wo, *w1, *w2;                    // LinW::w of out-proj (256->256), ffn.0 (512->512), ffn.3 (512->256)
   const float *bo, *b1, *gamma, *beta, *b2;
   int M;                     // tokens, multiple of 128
+  int tokens_per_wg = 128;   // 128 or 112 (see launch_lg_blockf)
 };
 void launch_lg_blockf(int prec, const LgBlockFArgs& a, hipStream_t st);
 

@@ -68,6 +68,8 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
   const size_t in_row = (size_t)(W + 2) * 128;
   const size_t in_img = (size_t)(H + 2) * in_row;
   const int per_img = tiles_x * tiles_y;
+  const bool p2 = (tiles_x & (tiles_x - 1)) == 0 && (per_img & (per_img - 1)) == 0;
+  const int sh_x = p2 ? __builtin_ctz(tiles_x) : -1, sh_img = p2 ? __builtin_ctz(per_img) : -1;
 
   // ---- filters: slab rows (2*ch + tt)*16 + l15 of every tap, both channel halves, as MFMA A fragments
   typename P::vec8 wreg[9][2][2];
@@ -106,8 +108,8 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
   }
   const bool last_piece = (NPC - 1) * NT + tid < C64R_PIECES;
   auto stage = [&](int tile, int buf) {
-    const int b = tile / per_img, rem = tile - b * per_img;
-    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    int b, ty, tx;
+    tile_decode(tile, per_img, tiles_x, sh_img, sh_x, b, ty, tx);
     const char* xin = reinterpret_cast<const char*>(a.X) + (size_t)b * in_img + (size_t)ty * 16 * in_row + (size_t)tx * 16 * 128;
     const unsigned dst = lds_base + buf * C64R_TILE_STRIDE + wave * 1024;
 #pragma unroll
@@ -154,8 +156,8 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
   // 20x20 fp32 patch of tile t -> pbuf[buf] by 4-byte LDS-DMA.  The image buffer has a 1-pixel zero border; rows/cols
   // beyond even that are clamped: they only feed halo pixels outside the image, which are forced to 0 anyway.
   auto stage_patch = [&](int t, int buf) {
-    const int b = t / per_img, rem = t - b * per_img;
-    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    int b, ty, tx;
+    tile_decode(t, per_img, tiles_x, sh_img, sh_x, b, ty, tx);
     const float* img = a.img + (size_t)b * (H + 2) * (W + 2);
 #pragma unroll
     for (int j = 0; j < (C64R_PATCH + NT - 1) / NT; ++j) {
@@ -216,9 +218,8 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
     }
   };
   auto tile_xy = [&](int t, int& ty, int& tx) {
-    const int rem = t % per_img;
-    ty = rem / tiles_x;
-    tx = rem - ty * tiles_x;
+    int b_;
+    tile_decode(t, per_img, tiles_x, sh_img, sh_x, b_, ty, tx);
   };
 
   int tile = blockIdx.x;
@@ -356,8 +357,8 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
     }
     // ---- epilogue (the bias is already in the accumulators): round to the 2-byte storage type FIRST, then ReLU and the
     // 2x2 max-pool on packed pairs (v_pk_max_i16; rounding is monotonic, so pooling after it gives the same bits)
-    const int b = tile / per_img, rem = tile - b * per_img;
-    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    int b, ty, tx;
+    tile_decode(tile, per_img, tiles_x, sh_img, sh_x, b, ty, tx);
     uint16_t* ybase = a.Y + (size_t)b * (Ho + 2 * opad) * orow + cb0 * 64 + ch * 32 + g * 8;
     uint4 pk[RW];
 #pragma unroll

@@ -294,7 +294,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   }
 }
 
-template <class P>
+template <class P, int NMT>
 __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -315,24 +315,31 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
   L.w1b = reinterpret_cast<const char*>(a.w1) + (size_t)L.wf * 8 * SLAB_BYTES;
   L.w2b = reinterpret_cast<const char*>(a.w2) + (size_t)L.cb * 8 * SLAB_BYTES + 2 * L.tp * 2048;
 
-  const int row0 = blockIdx.x * 128;
-  lf_stage_rows(a.attn, row0, 8, LF_R0, L.wave, L.lane);
-  lf_pass<P, 8>(a, smem, L, row0);
+  const int row0 = blockIdx.x * (16 * NMT);
+  lf_stage_rows(a.attn, row0, NMT, LF_R0, L.wave, L.lane);
+  lf_pass<P, NMT>(a, smem, L, row0);
 }
 
-template <class P>
+template <class P, int NMT>
 static void launch_f(const LgBlockFArgs& a, hipStream_t st) {
   static bool attr_done = false;
-  auto kfn = lg_blockf_kernel<P>;
+  auto kfn = lg_blockf_kernel<P, NMT>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kfn, dim3((unsigned)(a.M / 128)), dim3(512), LF_LDS, st, a);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)((a.M + 16 * NMT - 1) / (16 * NMT))), dim3(512), LF_LDS, st, a);
 }
 
+// Tokens per workgroup: one workgroup fits a CU (136 KiB of LDS), so a launch is ceil(M / tokens) workgroups in rounds of 256.
+// 51200 tokens (64 pairs) in 128-token passes are 400 workgroups = a full round + a 56 % round; in 112-token passes 458 = two rounds
+// that are each 1/8 shorter.  a.tokens_per_wg = 112 needs M rows + 111 of slack behind the last pass (the matcher arena has it).
 void launch_lg_blockf(int prec, const LgBlockFArgs& a, hipStream_t st) {
-  if (prec == 1) launch_f<PF16>(a, st); else launch_f<PBF16>(a, st);
+  if (a.tokens_per_wg == 112) {
+    if (prec == 1) launch_f<PF16, 7>(a, st); else launch_f<PBF16, 7>(a, st);
+  } else {
+    if (prec == 1) launch_f<PF16, 8>(a, st); else launch_f<PBF16, 8>(a, st);
+  }
 }
 
 }  // namespace airfe
