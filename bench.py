@@ -191,7 +191,19 @@ def side_workloads(args, rank, world, local, dev):
             ms_tot = sum(v["ms"] for v in stages.values()) / ns
             if fl_tot > 0 and ms_tot > 0:
                 ach = fl_tot / (ms_tot * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": "all bracketed matrix stages of one step (algorithmic FLOPs / their event time)",
+                util, usrc = None, None
+            pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_summary.json")
+            if os.path.exists(pf):      # counter-derived MFMA utilisation of the encoder kernels (separate --pmc pass, tools/pmc_summary.py)
+                with open(pf) as fh:
+                    ks = json.load(fh)["kernels"]
+                enc = {k: v for k, v in ks.items() if ("conv64r_kernel" in k or "conv128r_kernel" in k) and "mfma_util" in v}
+                wsum = sum(v["counters_per_launch"]["GRBM_GUI_ACTIVE"] * v["launches_sampled"] for v in enc.values())
+                if wsum > 0:
+                    util = {"encoder_time_weighted": sum(v["mfma_util"] * v["counters_per_launch"]["GRBM_GUI_ACTIVE"] * v["launches_sampled"]
+                                                         for v in enc.values()) / wsum,
+                            "per_kernel": {k.split("(")[0].replace("void airfe::", ""): round(v["mfma_util"], 3) for k, v in enc.items()}}
+                    usrc = "profiles/r02_pmc_summary.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)"
+            out["roofline"] = {"bound": "mfma", "mfma_util_counters": util, "mfma_util_source": usrc, "kernel": "all bracketed matrix stages of one step (algorithmic FLOPs / their event time)",
                                    "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS, "traffic": None}
         print(json.dumps(out))
     ctx.close()
@@ -311,12 +323,24 @@ def main():
         if dom:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
             traffic, tsrc = None, None
-            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_hbm_traffic.json")
+            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_hbm_traffic.json")
             if os.path.exists(tf):      # measured in separate --pmc passes (never together with other tracing), see profiles/README.md
                 with open(tf) as fh:
                     traffic = json.load(fh).get("conv3x3_cin64_stage", {}).get("hbm_bytes_per_launch")
-                tsrc = "profiles/r01e_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
-            out["roofline"] = {"bound": "mfma", "kernel": "conv64r_kernel (conv1a fused into conv1b + pool, conv2a, conv2b + pool, conv3a)",
+                tsrc = "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+            util, usrc = None, None
+            pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_summary.json")
+            if os.path.exists(pf):      # counter-derived MFMA utilisation of the encoder kernels (separate --pmc pass, tools/pmc_summary.py)
+                with open(pf) as fh:
+                    ks = json.load(fh)["kernels"]
+                enc = {k: v for k, v in ks.items() if ("conv64r_kernel" in k or "conv128r_kernel" in k) and "mfma_util" in v}
+                wsum = sum(v["counters_per_launch"]["GRBM_GUI_ACTIVE"] * v["launches_sampled"] for v in enc.values())
+                if wsum > 0:
+                    util = {"encoder_time_weighted": sum(v["mfma_util"] * v["counters_per_launch"]["GRBM_GUI_ACTIVE"] * v["launches_sampled"]
+                                                         for v in enc.values()) / wsum,
+                            "per_kernel": {k.split("(")[0].replace("void airfe::", ""): round(v["mfma_util"], 3) for k, v in enc.items()}}
+                    usrc = "profiles/r02_pmc_summary.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)"
+            out["roofline"] = {"bound": "mfma", "mfma_util_counters": util, "mfma_util_source": usrc, "kernel": "conv64r_kernel (conv1a fused into conv1b + pool, conv2a, conv2b + pool, conv3a)",
                                "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
                                "traffic": traffic, "traffic_source": tsrc,
                                "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1), "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
