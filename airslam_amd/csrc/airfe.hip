@@ -174,6 +174,7 @@ struct airfe_ctx {
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   int lgb_tokens = 0;            // AIRFE_LGB_TOKENS: tokens per lg_blockf workgroup (128 or 112; 0 = by token count)
   int attn_occ = 3;              // AIRFE_ATTN_OCC: attention32_kernel variant compiled for 2 (no spills) or 3 waves per SIMD
+  bool nms_v1 = false;           // AIRFE_NMS_V1=1: the five-launch LDS-tiled simple_nms (A/B runs)
   bool attn_v1 = false;          // AIRFE_ATTN_V1=1: the round-1 16x16x32 attention kernel (A/B runs)
   bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
 
@@ -229,6 +230,7 @@ struct airfe_ctx {
   int Lz = 0;
   float *sg_u = nullptr, *sg_v = nullptr, *sg_Z = nullptr, *sg_max0 = nullptr, *sg_ms0 = nullptr, *sg_ms1 = nullptr;
   int *sg_idx0 = nullptr, *sg_idx1 = nullptr;
+  float* sg_xch = nullptr;       // [P][2][16][Lz] (max, sum) column partials of the register-resident Sinkhorn kernel
   unsigned* sg_cnt = nullptr;    // per-pair rendezvous counters of the fused Sinkhorn kernel
   int32_t *sg_out0 = nullptr, *sg_out1 = nullptr;
 
@@ -706,9 +708,10 @@ int load_superglue(airfe_ctx* c, const char* path) {
   c->sg_max0 = dalloc<float>(c, pl); c->sg_ms0 = dalloc<float>(c, pl); c->sg_ms1 = dalloc<float>(c, pl);
   c->sg_idx0 = dalloc<int>(c, pl); c->sg_idx1 = dalloc<int>(c, pl);
   c->sg_cnt = dalloc<unsigned>(c, (size_t)P * 16);
+  c->sg_xch = dalloc<float>(c, pl * 64);
   c->sg_out0 = dalloc<int32_t>(c, pl); c->sg_out1 = dalloc<int32_t>(c, pl);
   if (!c->sg_u || !c->sg_v || !c->sg_Z || !c->sg_max0 || !c->sg_ms0 || !c->sg_ms1 || !c->sg_idx0 || !c->sg_idx1 ||
-      !c->sg_out0 || !c->sg_out1 || !c->sg_cnt)
+      !c->sg_out0 || !c->sg_out1 || !c->sg_cnt || !c->sg_xch)
     return fail(c, "device allocation failed (SuperGlue arena)");
   c->has_sg = true;
   return 0;
@@ -936,8 +939,12 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
       // the dense NMS'd map is consumed only by the batch-1 line path (junction scores) and the inspection hook: large batches skip
       // its 1 MB / image write (airfe_debug_detector_maps rebuilds it on demand)
       c->nms_map_valid = B <= 2;
-      launch_nms4_candidates(c->heat, c->nms_map_valid ? c->heat_nms : nullptr, c->nms_mask, B, R, R, c->cfg.keypoint_threshold,
-                             c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
+      if (c->nms_v1 || R != 512)
+        launch_nms4_candidates(c->heat, c->nms_map_valid ? c->heat_nms : nullptr, c->nms_mask, B, R, R, c->cfg.keypoint_threshold,
+                               c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
+      else
+        launch_nms512_candidates(c->heat, c->nms_map_valid ? c->heat_nms : nullptr, c->nms_mask, B, c->cfg.keypoint_threshold,
+                                 c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
     } else if (c->cfg.nms_radius > 0) {
       c->nms_map_valid = true;
       launch_simple_nms(c->heat, c->heat_nms, c->nms_tmp, B, R, R, c->cfg.nms_radius, st);
@@ -1096,7 +1103,7 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   }
   run_linear(c, c->sg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
   launch_sim(c->mprec, c->mdb, c->simbuf, B, Np, st);
-  launch_sg_sinkhorn(c->simbuf, c->lens, B, Np, c->Lz, c->sg_alpha, c->cfg.sinkhorn_iters, c->sg_u, c->sg_v, c->sg_Z, c->sg_cnt, st);
+  launch_sg_sinkhorn(c->simbuf, c->lens, B, Np, c->Lz, c->sg_alpha, c->cfg.sinkhorn_iters, c->sg_u, c->sg_v, c->sg_Z, c->sg_cnt, c->sg_xch, st);
   launch_sg_decode(c->sg_Z, c->lens, B, Np, c->Lz, 0.2f, c->sg_idx0, c->sg_max0, c->sg_idx1, c->sg_out0, c->sg_out1, c->sg_ms0,
                    c->sg_ms1, st);
   HIPCHK(c, hipGetLastError());
@@ -1224,6 +1231,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
   if (getenv("AIRFE_LGB_TOKENS")) c->lgb_tokens = atoi(getenv("AIRFE_LGB_TOKENS")) == 112 ? 112 : (atoi(getenv("AIRFE_LGB_TOKENS")) == 128 ? 128 : 0);
   if (getenv("AIRFE_ATTN_OCC")) c->attn_occ = atoi(getenv("AIRFE_ATTN_OCC")) == 3 ? 3 : 2;
+  c->nms_v1 = getenv("AIRFE_NMS_V1") && atoi(getenv("AIRFE_NMS_V1")) != 0;
   c->attn_v1 = getenv("AIRFE_ATTN_V1") && atoi(getenv("AIRFE_ATTN_V1")) != 0;
   c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -1427,8 +1435,12 @@ int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_
   const size_t R = AIRFE_INTERNAL_SIZE;
   if (heat_raw) HIPCHK(c, hipMemcpy(heat_raw, c->heat, (size_t)B * R * R * 4, hipMemcpyDeviceToHost));
   if (heat_nms && c->cfg.nms_radius > 0 && !c->nms_map_valid) {      // the batch path skipped the dense map: rebuild it from the heat maps
-    launch_nms4_candidates(c->heat, c->heat_nms, c->nms_mask, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt,
-                           R * R, c->stream);
+    if (c->nms_v1 || R != 512 || c->cfg.nms_radius != 4)
+      launch_nms4_candidates(c->heat, c->heat_nms, c->nms_mask, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt,
+                             R * R, c->stream);
+    else
+      launch_nms512_candidates(c->heat, c->heat_nms, c->nms_mask, (int)B, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt,
+                               R * R, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->nms_map_valid = true;
   }

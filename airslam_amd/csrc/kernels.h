@@ -109,6 +109,9 @@ void launch_simple_nms(const float* heat, float* out, float* tmp, int B, int H, 
 // one launch per max-pool over 64x32 tiles with a 4-pixel halo; mask = 2 bytes per pixel of scratch; out may be nullptr (no dense map)
 void launch_nms4_candidates(const float* heat, float* out, unsigned char* mask, int B, int H, int W, float thr, int border,
                             unsigned long long* cand, int* cand_cnt, int cand_cap, hipStream_t st);
+// the same on the 512 x 512 map as three register-resident launches (kernels_nms512.hip); planes = 2 x [B][64][64] 64-bit words
+void launch_nms512_candidates(const float* heat, float* out, void* planes, int B, float thr, int border, unsigned long long* cand,
+                              int* cand_cnt, int cand_cap, hipStream_t st);
 // candidates from a finished map (NMS off, or radius != 4 through the multi-pass launch_simple_nms)
 void launch_candidates(const float* heat, int B, int H, int W, float thr, int border, unsigned long long* cand,
                        int* cand_cnt, int cand_cap, hipStream_t st);
@@ -212,8 +215,9 @@ void launch_sg_prepare(int prec, const float* f0, const float* f1, const int* n0
                        uint16_t* xb, int* lens, hipStream_t st);
 // u, v: [B][Lz]; Z: [B][Lz][Lz] log-assignment incl. dustbins (rows 0..n0, cols 0..n1)
 // counters: B * 16 unsigned of scratch (one 64-byte line per pair) for the fused kernel's per-pair rendezvous; nullptr = the launch-per-half-iteration form
+// xch: B * 64 * Lz floats of scratch (the register-resident kernel's per-iteration exchange of column partials); nullptr = streaming kernels only
 void launch_sg_sinkhorn(const float* sim, const int* lens, int B, int Np, int Lz, float alpha, int iters, float* u, float* v,
-                        float* Z, unsigned* counters, hipStream_t st);
+                        float* Z, unsigned* counters, float* xch, hipStream_t st);
 void launch_sg_decode(const float* Z, const int* lens, int B, int Np, int Lz, float thr, int* idx0, float* max0, int* idx1,
                       int32_t* out0, int32_t* out1, float* ms0, float* ms1, hipStream_t st);
 

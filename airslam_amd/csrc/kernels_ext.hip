@@ -560,9 +560,202 @@ __global__ __launch_bounds__(512) void sg_sinkhorn_fused_kernel(const float* __r
       Z[((size_t)b * Lz + i) * Lz + j] = ((i < n0 && j < n1) ? S[(size_t)i * Np + j] : alpha) + u[i] + v[j] - norm + poison;
 }
 
+// Register-resident form: the couplings of a pair never leave the register files of the G workgroups that share it.  Workgroup g owns
+// a slice of the ROWS (wave w the rows r_lo + w, + 8, ...; lane l the columns l, l + 64, ...: RW x MAXC values per lane, 91 at N = 400,
+// 153 at N = 1024), loaded once.  The u half-iteration is wave-local (a row is one wave: two wave reductions, u[i] stays in that wave);
+// the v half-iteration reduces each column over the wave's own rows in registers, over the 8 waves through LDS, and over the G
+// workgroups through ONE exchange of (max, sum) pairs per column and iteration — one rendezvous per iteration, ~6 KB per workgroup,
+// instead of re-reading 643 KB of couplings twice.  The launch is COOPERATIVE (the runtime guarantees that all workgroups are
+// resident, or refuses the launch and the streaming kernel above runs); spins are bounded all the same.
+template <int CTRL>
+__device__ __forceinline__ float sk_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sk_wave_max(float v) {
+  v = fmaxf(v, sk_dpp<0xB1>(v));      // quad_perm [1,0,3,2]
+  v = fmaxf(v, sk_dpp<0x4E>(v));      // quad_perm [2,3,0,1]
+  v = fmaxf(v, sk_dpp<0x141>(v));     // row_half_mirror
+  v = fmaxf(v, sk_dpp<0x140>(v));     // row_mirror
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float sk_wave_sum(float v) {
+  v += sk_dpp<0xB1>(v);
+  v += sk_dpp<0x4E>(v);
+  v += sk_dpp<0x141>(v);
+  v += sk_dpp<0x140>(v);
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+
+template <int RW, int MAXC>
+__global__ __launch_bounds__(512) void sg_sinkhorn_reg_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np, int Lz,
+                                                             float alpha, int iters, int G, float2* __restrict__ xch,
+                                                             float* __restrict__ Z, unsigned* __restrict__ counters) {
+  constexpr int NW = 8, NT = 512, NC = 64 * MAXC;
+  __shared__ float pm[NW][NC], ps[NW][NC];
+  __shared__ float vs[NC];
+  __shared__ int s_fail;
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
+  const float* S = sim + (size_t)b * Np * Np;
+  unsigned* cnt = counters + b * 16;
+  const float norm = -logf((float)(n0 + n1));
+  const float lmu_last = logf((float)n1) + norm, lnu_last = logf((float)n0) + norm;
+  const int rper = (n0 + 1 + G - 1) / G, r_lo = g * rper, r_hi = min(r_lo + rper, n0 + 1);      // rper <= NW * RW (host)
+  float c[RW][MAXC], v[MAXC], u[RW];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) {
+    const int i = r_lo + wv + NW * q;
+    u[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int j = lane + 64 * k;
+      c[q][k] = -INFINITY;
+      if (i < r_hi && j <= n1) c[q][k] = (i < n0 && j < n1) ? S[(size_t)i * Np + j] : alpha;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) v[k] = 0.f;
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  unsigned target = 0;
+  for (int it = 0; it < iters && !s_fail; ++it) {
+    // ---- u[i] = log_mu[i] - logsumexp_j(C[i][j] + v[j]): a row is this wave's alone
+    float mx[RW], sm[RW];
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+      mx[q] = c[q][0] + v[0];
+#pragma unroll
+      for (int k = 1; k < MAXC; ++k) mx[q] = fmaxf(mx[q], c[q][k] + v[k]);
+    }
+#pragma unroll
+    for (int q = 0; q < RW; ++q) mx[q] = sk_wave_max(mx[q]);
+    // (the sums recompute c + v: without this fence hipcc keeps all RW x MAXC sums of the maximum pass alive and spills)
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) asm volatile("" : "+v"(v[k]));
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+      const float off = (mx[q] == -INFINITY) ? 0.f : mx[q];           // a row slot beyond r_hi: all -inf, sum 0, u unused
+      sm[q] = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) sm[q] += __expf(c[q][k] + v[k] - off);
+    }
+#pragma unroll
+    for (int q = 0; q < RW; ++q) sm[q] = sk_wave_sum(sm[q]);
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+      const int i = r_lo + wv + NW * q;
+      u[q] = (i < r_hi) ? ((i < n0) ? norm : lmu_last) - (mx[q] + __logf(sm[q])) : 0.f;
+    }
+    // ---- column partials over this wave's rows, then over the 8 waves
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      float cm = c[0][k] + u[0];
+#pragma unroll
+      for (int q = 1; q < RW; ++q) cm = fmaxf(cm, c[q][k] + u[q]);
+      const float off = (cm == -INFINITY) ? 0.f : cm;
+      float cs = 0.f;
+#pragma unroll
+      for (int q = 0; q < RW; ++q) cs += __expf(c[q][k] + u[q] - off);
+      pm[wv][lane + 64 * k] = cm;
+      ps[wv][lane + 64 * k] = cs;
+    }
+    __syncthreads();
+    float2* mine = xch + (((size_t)b * 2 + (it & 1)) * G + g) * Lz;
+    for (int j = tid; j <= n1; j += NT) {
+      float M = pm[0][j];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) M = fmaxf(M, pm[w][j]);
+      const float off = (M == -INFINITY) ? 0.f : M;
+      float T = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) T += ps[w][j] * __expf(pm[w][j] - off);
+      if (G > 1) mine[j] = make_float2(M, T);
+      else vs[j] = ((j < n1) ? norm : lnu_last) - (M + __logf(T));
+    }
+    if (G > 1) {
+      // all G workgroups of the pair have published their partials (release / acquire at agent scope, see the kernel above)
+      target += (unsigned)G;
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 19)) { s_fail = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      const float2* all = xch + ((size_t)b * 2 + (it & 1)) * G * Lz;
+      for (int j = tid; j <= n1; j += NT) {
+        float M = -INFINITY, T = 0.f;
+        for (int h = 0; h < G; ++h) {
+          const float2 p = all[(size_t)h * Lz + j];
+          const float Mn = fmaxf(M, p.x);
+          const float off = (Mn == -INFINITY) ? 0.f : Mn;
+          T = T * __expf(M - off) + p.y * __expf(p.x - off);       // first partial: T = 0, exp(-inf) = 0
+          M = Mn;
+        }
+        vs[j] = ((j < n1) ? norm : lnu_last) - (M + __logf(T));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int j = lane + 64 * k;
+      v[k] = (j <= n1) ? vs[j] : 0.f;
+    }
+  }
+  const float poison = s_fail ? NAN : 0.f;
+#pragma unroll
+  for (int q = 0; q < RW; ++q) {
+    const int i = r_lo + wv + NW * q;
+    if (i < r_hi) {
+#pragma unroll
+      for (int k = 0; k < MAXC; ++k) {
+        const int j = lane + 64 * k;
+        if (j <= n1) Z[((size_t)b * Lz + i) * Lz + j] = c[q][k] + u[q] + v[k] - norm + poison;
+      }
+    }
+  }
+}
+
+template <int RW, int MAXC>
+static bool try_sinkhorn_reg(const float* sim, const int* lens, int B, int Np, int Lz, float alpha, int iters, float2* xch, float* Z,
+                             unsigned* counters, hipStream_t st) {
+  int G = (Np + 1 + 8 * RW - 1) / (8 * RW);
+  if (G > 16 || Np + 1 > 64 * MAXC || Lz < 64 * MAXC) return false;
+  static int max_wgs = -1;                                   // co-resident workgroups of this instantiation on this device
+  if (max_wgs < 0) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sg_sinkhorn_reg_kernel<RW, MAXC>, 512, 0) != hipSuccess)
+      max_wgs = 0;
+    else
+      max_wgs = per_cu * prop.multiProcessorCount;
+  }
+  if (B * G > max_wgs) return false;
+  (void)hipMemsetAsync(counters, 0, (size_t)B * 64, st);
+  void* args[] = {(void*)&sim, (void*)&lens, (void*)&Np, (void*)&Lz, (void*)&alpha, (void*)&iters, (void*)&G, (void*)&xch, (void*)&Z, (void*)&counters};
+  const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&sg_sinkhorn_reg_kernel<RW, MAXC>), dim3(B * G), dim3(512), args, 0, st);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return true;
+}
+
 void launch_sg_sinkhorn(const float* sim, const int* lens, int B, int Np, int Lz, float alpha, int iters, float* u, float* v,
-                        float* Z, unsigned* counters, hipStream_t st) {
+                        float* Z, unsigned* counters, float* xch, hipStream_t st) {
   static const bool unfused = getenv("AIRFE_SINKHORN_UNFUSED") && atoi(getenv("AIRFE_SINKHORN_UNFUSED")) != 0;   // A/B runs
+  static const bool noreg = getenv("AIRFE_SINKHORN_STREAM") && atoi(getenv("AIRFE_SINKHORN_STREAM")) != 0;
+  if (!unfused && !noreg && counters && xch) {
+    float2* x2 = reinterpret_cast<float2*>(xch);
+    if (Np + 1 <= 448 && try_sinkhorn_reg<13, 7>(sim, lens, B, Np, Lz, alpha, iters, x2, Z, counters, st)) return;
+    if (Np + 1 <= 1088 && try_sinkhorn_reg<9, 17>(sim, lens, B, Np, Lz, alpha, iters, x2, Z, counters, st)) return;
+  }
   if (!unfused && Np <= 1024 && counters && B <= 128) {
     int G = 1;
     while (G < 16 && B * G * 2 <= 128) G *= 2;         // workgroups per pair: at ~140 registers ONE 8-wave workgroup fits a CU, so the grid stays
