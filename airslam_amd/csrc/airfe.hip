@@ -33,6 +33,9 @@ typedef std::map<std::string, Tensor> Pack;
 bool load_pack(const char* path, Pack& out, std::string& err) {
   FILE* f = fopen(path, "rb");
   if (!f) { err = std::string("cannot open weight pack ") + path; return false; }
+  fseek(f, 0, SEEK_END);
+  const long fsize = ftell(f);                     // every tensor's element count is bounded by what is left of the file
+  fseek(f, 0, SEEK_SET);
   char magic[8];
   uint32_t count = 0;
   bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "AIRFEPK1", 8) == 0 && fread(&count, 4, 1, f) == 1;
@@ -49,9 +52,11 @@ bool load_pack(const char* path, Pack& out, std::string& err) {
       uint32_t v = 0;
       ok = ok && fread(&v, 4, 1, f) == 1;
       t.dims.push_back((int)v);
-      n *= v;
+      if (v > 0x7FFFFFFFu || (v != 0 && n > (size_t)0x7FFFFFFFFFFFull / v)) ok = false;      // dims are untrusted
+      else n *= v;
     }
-    if (!ok) break;
+    const long pos = ftell(f);
+    if (!ok || pos < 0 || fsize < pos || n > (size_t)(fsize - pos) / 4) { ok = false; break; }
     t.data.resize(n);
     ok = fread(t.data.data(), 4, n, f) == n;
     out[name] = std::move(t);
@@ -164,7 +169,7 @@ struct airfe_ctx {
   int pack_prec = 0;             // storage type make_linear packs for (set by each load_* before it packs)
   int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
   bool has_sp = false, has_lg = false;
-  char* pl_stage = nullptr;      // staging of airfe_assign_points_to_lines
+  uint8_t* pl_stage = nullptr;   // staging of airfe_assign_points_to_lines / airfe_match_lines
   size_t pl_bytes = 0;
   bool nms_map_valid = true;     // heat_nms holds the last batch's NMS'd maps (large batches skip writing them)
   bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
@@ -746,7 +751,7 @@ int load_plnet_s1(airfe_ctx* c, const char* path) {
   c->jmap = dalloc<unsigned char>(c, (size_t)AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE);
   c->d_lines = dalloc<double>(c, (size_t)LINE_CAP * 4);
   c->d_nlines = dalloc<int>(c, 1);
-  c->d_njunc = dalloc<int>(c, 1);
+  c->d_njunc = dalloc<int>(c, 2);                  // [0] junctions kept (<= JUNC_CAP), [1] junctions found
   c->junc_feat = dalloc<float>(c, (size_t)JUNC_CAP * AIRFE_FEAT_DIM);
   for (int i = 0; i < 11; ++i) if (!c->s1_w[i]) return fail(c, "device allocation failed (plnet_s1 weights)");
   if (!c->wf_table || !c->wf_keep || !c->wf_pairs || !c->wf_rep || !c->wf_counts || !c->s1_la || !c->s1_sc || !c->s0_stage ||
@@ -759,6 +764,9 @@ int load_plnet_s1(airfe_ctx* c, const char* path) {
 int ensure_tables(airfe_ctx* c, int h, int w) {
   if (c->tab_w == w && c->tab_h == h) return 0;
   const auto xt = resize_table(AIRFE_INTERNAL_SIZE, w), yt = resize_table(AIRFE_INTERNAL_SIZE, h);
+  // the image size changed: a pre-process of the previous size may still be reading the tables on a CALLER's stream (the *_dev entry
+  // points), so the whole device is drained before they are rewritten — once per size change, not per call
+  if (c->tab_w != 0) HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpyAsync(c->xtab, xt.data(), xt.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->ytab, yt.data(), yt.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // host vectors go out of scope
@@ -1007,8 +1015,9 @@ void run_qkv(airfe_ctx* c, const LinW& qk, const LinW& v, int M, void* qout, voi
 }
 
 // out-proj + FFN + residual of one block as ONE kernel (kernels_lgblockf.hip); flops/bytes are the algorithmic ones
-void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st) {
+void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st, int relu = 0) {
   LgBlockFArgs a;
+  a.relu = relu;
   a.attn = c->ob; a.xb = c->xb; a.x32 = c->x32; a.wo = out.w; a.w1 = f0.w; a.w2 = f3.w;
   a.bo = out.b; a.b1 = f0.b; a.gamma = g; a.beta = b; a.b2 = f3.b; a.M = M;
   // one workgroup per CU and pass: ceil(M / T) workgroups run in rounds of 256, a round lasts ~T — take the T with the smaller product
@@ -1088,6 +1097,7 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   const float linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.7f);   // point_matcher.cc:58
   launch_sg_prepare(c->mprec, f0, f1, n0, n1, AIRFE_FEAT_DIM, normalize, cx, cy, linv, c->sg_kenc, B, cap, Np, c->x32, c->xb,
                     c->lens, st);
+  const bool fused_block = c->fuse_lg_block == 1 || (c->fuse_lg_block < 0 && Mg >= c->block_min);
   int li = 0;
   for (const SgLayer& l : c->sg) {
     const int cross = li & 1;      // names = ['self','cross'] * 9
@@ -1096,6 +1106,10 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     {
       ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048);
       run_attention(c, c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, cross, 0.125f, st);
+    }
+    if (fused_block) {          // merge + mlp.0 + ReLU + mlp.3 + residual as ONE kernel (the LightGlue block kernel with ReLU for LN + GELU)
+      lg_blockf(c, l.merge, l.mlp0, nullptr, nullptr, l.mlp3, Mg, st, 1);
+      continue;
     }
     run_linear(c, l.merge, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
     run_linear(c, l.mlp0, c->xb, 256, 256, c->msg, 256, Mg, EPI_STORE, ACT_RELU, c->hb, 512, st);
@@ -1278,7 +1292,7 @@ void airfe_destroy(airfe_ctx* c) {
 
 int airfe_profile_enable(airfe_ctx* c, int on) {
   if (!c) return 1;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipDeviceSynchronize());             // the events may have been recorded on a caller's stream (the *_dev entry points)
   for (auto& m : c->marks) { c->ev_pool.push_back(m.a); c->ev_pool.push_back(m.b); }
   c->marks.clear();
   c->prof_mask = on < 0 ? 0xFFFFFFFFu : (uint32_t)on;
@@ -1542,14 +1556,8 @@ int airfe_assign_points_to_lines(airfe_ctx* c, const double* lines, int L, const
   if (!lines || (N > 0 && !feat)) return fail(c, "assign_points_to_lines: null input");
   // staging grows on demand (lines and points per frame are a few hundred)
   const size_t need = (size_t)L * 32 + (size_t)std::max(N, 1) * 259 * 4 + (size_t)(2 * L + 2) * 4 + (size_t)std::max(cap, 1) * 12 + 64;
-  if (need > c->pl_bytes) {
-    void* p = nullptr;
-    HIPCHK(c, hipMalloc(&p, need));
-    c->allocs.push_back(p);
-    c->pl_stage = reinterpret_cast<char*>(p);
-    c->pl_bytes = need;
-  }
-  char* q = c->pl_stage;
+  if (ensure_block(c, c->pl_stage, c->pl_bytes, need)) return 1;      // grows by replacing (and freeing) the previous block
+  char* q = reinterpret_cast<char*>(c->pl_stage);
   double* d_lines = reinterpret_cast<double*>(q); q += (size_t)L * 32;
   double* d_dist = reinterpret_cast<double*>(q); q += (size_t)std::max(cap, 1) * 8;
   float* d_feat = reinterpret_cast<float*>(q); q += (size_t)std::max(N, 1) * 259 * 4;
@@ -1581,6 +1589,17 @@ int airfe_match_lines(airfe_ctx* c, const int32_t* row_ptr0, const int32_t* pt_i
   if (!row_ptr0 || !row_ptr1 || (M > 0 && !matches)) return fail(c, "match_lines: null input");
   const int t0 = row_ptr0[L0], t1 = row_ptr1[L1];
   if (t0 < 0 || t1 < 0 || (t0 > 0 && !pt_idx0) || (t1 > 0 && !pt_idx1)) return fail(c, "match_lines: bad relation");
+  // the device indexes with these: CSR rows must start at 0 and not decrease, point indices must be inside the frame's points
+  auto csr_ok = [](const int32_t* rp, const int32_t* pi, int L, int npts) {
+    if (rp[0] != 0) return false;
+    for (int i = 0; i < L; ++i)
+      if (rp[i + 1] < rp[i]) return false;
+    for (int e = 0; e < rp[L]; ++e)
+      if (pi[e] < 0 || pi[e] >= npts) return false;
+    return true;
+  };
+  if (!csr_ok(row_ptr0, pt_idx0, L0, point_num0) || !csr_ok(row_ptr1, pt_idx1, L1, point_num1))
+    return fail(c, "match_lines: relation is not a valid CSR (row_ptr must start at 0 and be non-decreasing, pt_idx within [0, point_num))");
   for (int m = 0; m < M; ++m)                                                         // the reference indexes vectors with these
     if (matches[2 * m] < 0 || matches[2 * m] >= point_num0 || matches[2 * m + 1] < 0 || matches[2 * m + 1] >= point_num1)
       return fail(c, "match_lines: point match index out of range");
@@ -1588,13 +1607,7 @@ int airfe_match_lines(airfe_ctx* c, const int32_t* row_ptr0, const int32_t* pt_i
   const size_t words = (size_t)(L0 + 1) + (L1 + 1) + std::max(t0, 1) + std::max(t1, 1) + (size_t)std::max(M, 1) * 2 + (size_t)(L0 + L1) * W +
                        (size_t)L0 * L1 + 2 * (size_t)L0;
   const size_t need = words * 4 + 64;
-  if (need > c->pl_bytes) {
-    void* p = nullptr;
-    HIPCHK(c, hipMalloc(&p, need));
-    c->allocs.push_back(p);
-    c->pl_stage = reinterpret_cast<char*>(p);
-    c->pl_bytes = need;
-  }
+  if (ensure_block(c, c->pl_stage, c->pl_bytes, need)) return 1;      // grows by replacing (and freeing) the previous block
   int* q = reinterpret_cast<int*>(c->pl_stage);
   int* d_rp0 = q; q += L0 + 1;
   int* d_rp1 = q; q += L1 + 1;
@@ -1654,17 +1667,19 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
                   c->s1_sc, LINE_CAP, st);
   launch_line_filter(c->s1_la, c->s1_sc, c->wf_counts, c->cfg.remove_borders, c->cfg.line_threshold,
                      c->cfg.line_length_threshold, ws, hs, R, c->jmap, c->d_lines, LINE_CAP, c->d_nlines, st);
-  int nl = 0, nj = 0;
+  int nl = 0, nj = 0, njf[2] = {0, 0};
   HIPCHK(c, hipMemcpyAsync(&nl, c->d_nlines, 4, hipMemcpyDeviceToHost, st));
   if (want_junctions) {
     const float* hsel = c->cfg.nms_radius > 0 ? c->heat_nms : c->heat;
     launch_junction_scan(c->jmap, hsel, R, c->cfg.remove_borders, c->junc_feat, JUNC_CAP, c->d_njunc, st);
     launch_sample_desc(c->desc, 1, R / 8, R / 8, c->junc_feat, c->d_njunc, JUNC_CAP, ws, hs, c->desc_normalised ? 0 : 1, st);
-    HIPCHK(c, hipMemcpyAsync(&nj, c->d_njunc, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(njf, c->d_njunc, 8, hipMemcpyDeviceToHost, st));
   }
   HIPCHK(c, hipStreamSynchronize(st));
-  nl = std::min(nl, capL);
-  nj = std::min(nj, capJ);
+  nj = njf[0];
+  // the reference has no junction limit (junction_detector, plnet.cpp:425-448): more than the arena holds is an ERROR, not a shorter list
+  if (njf[1] > JUNC_CAP) return fail(c, "detect_plnet: more junctions than the device arena holds (JUNC_CAP)");
+  if (nl > capL || nj > capJ) return fail(c, "detect_plnet: lines / junctions do not fit the caller's buffers (capL, capJ)");
   if (nl > 0 && lines) HIPCHK(c, hipMemcpy(lines, c->d_lines, (size_t)nl * 32, hipMemcpyDeviceToHost));
   if (nj > 0 && junc) HIPCHK(c, hipMemcpy(junc, c->junc_feat, (size_t)nj * AIRFE_FEAT_DIM * 4, hipMemcpyDeviceToHost));
   if (nlines) *nlines = nl;

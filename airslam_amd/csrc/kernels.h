@@ -61,6 +61,7 @@ struct LgBlockFArgs {
   const float *bo, *b1, *gamma, *beta, *b2;
   int M;                     // tokens, multiple of 128
   int tokens_per_wg = 128;   // 128 or 112 (see launch_lg_blockf)
+  int relu = 0;              // 1: ReLU instead of LayerNorm + GELU (the SuperGlue block; gamma / beta unused)
 };
 void launch_lg_blockf(int prec, const LgBlockFArgs& a, hipStream_t st);
 

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(1024) void junction_scan_kernel(const unsigned char
       ++off;
     }
   }
-  if (tid == 0) *n_out = min((int)tot, cap);
+  if (tid == 0) { n_out[0] = min((int)tot, cap); n_out[1] = (int)tot; }        // [1]: what was found (the caller reports an overflow)
 }
 
 void launch_junction_scan(const unsigned char* jmap, const float* heat, int R, int border, float* feat, int cap, int* n_out,
@@ -596,7 +596,14 @@ __global__ __launch_bounds__(512) void sg_sinkhorn_reg_kernel(const float* __res
   __shared__ float pm[NW][NC], ps[NW][NC];
   __shared__ float vs[NC];
   __shared__ int s_fail;
-  const int b = blockIdx.x / G, g = blockIdx.x - b * G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // The G workgroups of a pair should share an XCD (their exchange then stays in one L2): consecutive workgroup ids go round the 8
+  // XCDs, so id -> (xcd = id % 8, slot = id / 8) and the pairs are dealt out per XCD.  Only a placement hint: any mapping is correct.
+  int wid = blockIdx.x;
+  {
+    const int per_xcd = gridDim.x >> 3;
+    if ((gridDim.x & 7) == 0 && per_xcd % G == 0) wid = (wid & 7) * per_xcd + (wid >> 3);
+  }
+  const int b = wid / G, g = wid - b * G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
   const float* S = sim + (size_t)b * Np * Np;
   unsigned* cnt = counters + b * 16;
@@ -684,8 +691,7 @@ __global__ __launch_bounds__(512) void sg_sinkhorn_reg_kernel(const float* __res
         __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1 << 19)) { s_fail = 1; break; }
+          if (++spins > (1 << 20)) { s_fail = 1; break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
@@ -794,15 +800,29 @@ __global__ void sg_rowmax_kernel(const float* __restrict__ Z, const int* __restr
   if (lane == 0) { idx0[(size_t)b * Lz + i] = (bj == 0x7FFFFFFF) ? 0 : bj; max0[(size_t)b * Lz + i] = best; }
 }
 
-__global__ void sg_colmax_kernel(const float* __restrict__ Z, const int* __restrict__ lens, int Lz, int* __restrict__ idx1) {
-  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+// 64 columns x 8 contiguous row slices per workgroup; the slices are combined in ascending row order with the same strict '>'
+// (the first maximum wins, as in the reference's single ascending loop)
+__global__ __launch_bounds__(512) void sg_colmax_kernel(const float* __restrict__ Z, const int* __restrict__ lens, int Lz, int* __restrict__ idx1) {
+  __shared__ float sb[8][64];
+  __shared__ int si[8][64];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6, j = blockIdx.x * 64 + lane;
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
-  if (j >= n1) return;
-  const float* c = Z + (size_t)b * Lz * Lz + j;
+  const int per = (n0 + 7) / 8, lo = q * per, hi = min(lo + per, n0);
   float best = -FLT_MAX;
   int bi = 0;
-  for (int i = 0; i < n0; ++i) { const float v = c[(size_t)i * Lz]; if (v > best) { best = v; bi = i; } }
-  idx1[(size_t)b * Lz + j] = bi;
+  if (j < n1) {
+    const float* c = Z + (size_t)b * Lz * Lz + j;
+    for (int i = lo; i < hi; ++i) { const float v = c[(size_t)i * Lz]; if (v > best) { best = v; bi = i; } }
+  }
+  sb[q][lane] = best;
+  si[q][lane] = bi;
+  __syncthreads();
+  if (q == 0 && j < n1) {
+#pragma unroll
+    for (int r = 1; r < 8; ++r)
+      if (sb[r][lane] > best) { best = sb[r][lane]; bi = si[r][lane]; }
+    idx1[(size_t)b * Lz + j] = bi;
+  }
 }
 
 __global__ __launch_bounds__(1024) void sg_decode_kernel(const int* __restrict__ lens, int Lz, const int* __restrict__ idx0,
@@ -836,7 +856,7 @@ __global__ __launch_bounds__(1024) void sg_decode_kernel(const int* __restrict__
 void launch_sg_decode(const float* Z, const int* lens, int B, int Np, int Lz, float thr, int* idx0, float* max0, int* idx1,
                       int32_t* out0, int32_t* out1, float* ms0, float* ms1, hipStream_t st) {
   hipLaunchKernelGGL(sg_rowmax_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, Z, lens, Lz, idx0, max0);
-  hipLaunchKernelGGL(sg_colmax_kernel, dim3((Np + 63) / 64, B), dim3(64), 0, st, Z, lens, Lz, idx1);
+  hipLaunchKernelGGL(sg_colmax_kernel, dim3((Np + 63) / 64, B), dim3(512), 0, st, Z, lens, Lz, idx1);
   hipLaunchKernelGGL(sg_decode_kernel, dim3(B), dim3(1024), 0, st, lens, Lz, idx0, max0, idx1, thr, out0, out1, ms0, ms1);
 }
 

@@ -138,7 +138,9 @@ struct LfLane {                       // per-lane constants of the whole kernel
 };
 
 // One pass over NMT token tiles (16 tokens each) starting at token `row0`; its attn tile is already in flight into R0.
-template <class P, int NMT>
+// RELU = the SuperGlue propagation block (merge, mlp.0 + folded BatchNorm + ReLU, mlp.3: super_glue GNN layer) — the same three GEMMs
+// with ReLU in place of LayerNorm + GELU.
+template <class P, int NMT, bool RELU>
 __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const LfLane& L, int row0) {
   const int lane = L.lane, wave = L.wave, l15 = L.l15, g = L.g, wf = L.wf, cb = L.cb, tp = L.tp, fo0 = L.fo0, fo1 = L.fo1;
   typename P::vec8 c2[2][2], c4[4][2];                            // A fragments in flight: 32-feature GEMMs / the 64-feature one
@@ -188,17 +190,19 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   lf_mma<P, 4, NMT>(h, c4, L.w1b + fo0, L.w1b + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R0, 512, l15, g);
 
   // LayerNorm scale / shift of this wave's 64 features: fetched now, used after the next barrier
-  f32x4 gam[2][2], bet[2][2];
+  [[maybe_unused]] f32x4 gam[2][2], bet[2][2];
+  if constexpr (!RELU) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      gam[q][u] = *reinterpret_cast<const f32x4*>(a.gamma + wf * 64 + q * 32 + g * 8 + u * 4);
-      bet[q][u] = *reinterpret_cast<const f32x4*>(a.beta + wf * 64 + q * 32 + g * 8 + u * 4);
-    }
+      for (int u = 0; u < 2; ++u) {
+        gam[q][u] = *reinterpret_cast<const f32x4*>(a.gamma + wf * 64 + q * 32 + g * 8 + u * 4);
+        bet[q][u] = *reinterpret_cast<const f32x4*>(a.beta + wf * 64 + q * 32 + g * 8 + u * 4);
+      }
+  }
   // ---- LayerNorm(512): per-wave partial sums over its 64 features, exchanged through ST (indexed by feature block, so the
   // summation order does not depend on which wave owned it)
-  {
+  if constexpr (!RELU) {
     float2* st = reinterpret_cast<float2*>(smem + LF_ST);
 #pragma unroll
     for (int m = 0; m < NMT; ++m) {
@@ -227,9 +231,9 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   __builtin_amdgcn_sched_barrier(0);
   {
     const float2* st = reinterpret_cast<const float2*>(smem + LF_ST);
-    float nmr[NMT], rstd[NMT];                                    // (h - mean) rstd = h rstd + nmr
+    [[maybe_unused]] float nmr[NMT], rstd[NMT];                   // (h - mean) rstd = h rstd + nmr
 #pragma unroll
-    for (int m = 0; m < NMT; ++m) {
+    for (int m = 0; m < (RELU ? 0 : NMT); ++m) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
@@ -245,8 +249,20 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
     // ---- GELU(LN(h)) -> h tile [16 NMT][512] 2-byte over R0 + R1
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const f32x4 g0 = gam[q][0], g1 = gam[q][1], be0 = bet[q][0], be1 = bet[q][1];
       const int piece = wf * 8 + q * 4 + g;
+      if constexpr (RELU) {
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = fmaxf(h[2 * q][m][e], 0.f);
+            v[4 + e] = fmaxf(h[2 * q + 1][m][e], 0.f);
+          }
+          *reinterpret_cast<uint4*>(smem + (m * 16 + l15) * 1024 + ((piece ^ l15) << 4)) = pack8<P>(v);
+        }
+      } else {
+      const f32x4 g0 = gam[q][0], g1 = gam[q][1], be0 = bet[q][0], be1 = bet[q][1];
 #pragma unroll
       for (int m = 0; m < NMT; ++m) {
         const f32x2 rs = {rstd[m], rstd[m]}, nm = {nmr[m], nmr[m]};
@@ -260,6 +276,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
           v[4 + e] = o1.x; v[5 + e] = o1.y;
         }
         *reinterpret_cast<uint4*>(smem + (m * 16 + l15) * 1024 + ((piece ^ l15) << 4)) = pack8<P>(v);
+      }
       }
       if (q == 0) {           // half of h's registers are free now: the residual rows take them
 #pragma unroll
@@ -294,7 +311,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   }
 }
 
-template <class P, int NMT>
+template <class P, int NMT, bool RELU>
 __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -317,13 +334,13 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
 
   const int row0 = blockIdx.x * (16 * NMT);
   lf_stage_rows(a.attn, row0, NMT, LF_R0, L.wave, L.lane);
-  lf_pass<P, NMT>(a, smem, L, row0);
+  lf_pass<P, NMT, RELU>(a, smem, L, row0);
 }
 
-template <class P, int NMT>
+template <class P, int NMT, bool RELU>
 static void launch_f(const LgBlockFArgs& a, hipStream_t st) {
   static bool attr_done = false;
-  auto kfn = lg_blockf_kernel<P, NMT>;
+  auto kfn = lg_blockf_kernel<P, NMT, RELU>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS);
     attr_done = true;
@@ -335,10 +352,18 @@ static void launch_f(const LgBlockFArgs& a, hipStream_t st) {
 // 51200 tokens (64 pairs) in 128-token passes are 400 workgroups = a full round + a 56 % round; in 112-token passes 458 = two rounds
 // that are each 1/8 shorter.  a.tokens_per_wg = 112 needs M rows + 111 of slack behind the last pass (the matcher arena has it).
 void launch_lg_blockf(int prec, const LgBlockFArgs& a, hipStream_t st) {
+  if (a.relu) {
+    if (a.tokens_per_wg == 112) {
+      if (prec == 1) launch_f<PF16, 7, true>(a, st); else launch_f<PBF16, 7, true>(a, st);
+    } else {
+      if (prec == 1) launch_f<PF16, 8, true>(a, st); else launch_f<PBF16, 8, true>(a, st);
+    }
+    return;
+  }
   if (a.tokens_per_wg == 112) {
-    if (prec == 1) launch_f<PF16, 7>(a, st); else launch_f<PBF16, 7>(a, st);
+    if (prec == 1) launch_f<PF16, 7, false>(a, st); else launch_f<PBF16, 7, false>(a, st);
   } else {
-    if (prec == 1) launch_f<PF16, 8>(a, st); else launch_f<PBF16, 8>(a, st);
+    if (prec == 1) launch_f<PF16, 8, false>(a, st); else launch_f<PBF16, 8, false>(a, st);
   }
 }
 

@@ -195,27 +195,44 @@ __global__ __launch_bounds__(64) void nms512_kernel(const float* __restrict__ he
       *reinterpret_cast<float4*>(d + 4) = zf;
     }
   }
+  // Rounds of up to four surviving pixels per lane (a lane's 8 x 8 block holds at most four maxima that are more than 4 pixels apart;
+  // only exact ties give more): the four score loads of a round are in flight together and a round costs ONE global atomic per wave.
   u64 kept = M;
   while (__builtin_amdgcn_ballot_w64(kept != 0) != 0) {
-    const bool has = kept != 0;
-    const int k = has ? __builtin_ctzll(kept) : 0;
-    kept &= kept - 1;
-    const int gy = y0 + (k >> 3), gx = lane * 8 + (k & 7), gi = gy * NR + gx;
-    // the ORIGINAL score: the registers hold the suppressed one (0 inside a maximum's own suppression zone)
-    float v = 0.f;
-    if (has) {
-      v = S[gi];
-      if (out) out[img + gi] = v;
+    float v[4];
+    int gi[4];
+    bool pass[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool has = kept != 0;
+      const int k = has ? __builtin_ctzll(kept) : 0;
+      kept &= kept - 1;
+      const int gy = y0 + (k >> 3), gx = lane * 8 + (k & 7);
+      gi[t] = gy * NR + gx;
+      // the ORIGINAL score: the registers hold the suppressed one (0 inside a maximum's own suppression zone)
+      v[t] = has ? S[gi[t]] : 0.f;
+      pass[t] = has && !(gx < border || gx > NR - border || gy < border || gy > NR - border);
+      if (out && has) out[img + gi[t]] = v[t];
     }
-    const bool pass = has && !(v < thr) && !(gx < border || gx > NR - border || gy < border || gy > NR - border);
-    const u64 pm = __builtin_amdgcn_ballot_w64(pass);
-    if (pm != 0) {
-      const int leader = __builtin_ctzll(pm);
+    u64 pm[4];
+    int cnt = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      pass[t] = pass[t] && !(v[t] < thr);
+      pm[t] = __builtin_amdgcn_ballot_w64(pass[t]);
+      cnt += __builtin_popcountll(pm[t]);
+    }
+    if (cnt != 0) {                                                    // wave-uniform
       int base = 0;
-      if (lane == leader) base = atomicAdd(&cand_cnt[b], __builtin_popcountll(pm));
-      base = __builtin_amdgcn_readlane(base, leader);
-      const int pos = base + __builtin_popcountll(pm & ((1ull << lane) - 1ull));
-      if (pass && pos < cand_cap) cand[(size_t)b * cand_cap + pos] = nms_key(v, gi);
+      if (lane == 0) base = atomicAdd(&cand_cnt[b], cnt);
+      base = __builtin_amdgcn_readfirstlane(base);
+      const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int pos = base + __builtin_popcountll(pm[t] & lt);
+        if (pass[t] && pos < cand_cap) cand[(size_t)b * cand_cap + pos] = nms_key(v[t], gi[t]);
+        base += __builtin_popcountll(pm[t]);
+      }
     }
   }
 }

@@ -77,7 +77,8 @@ int airfe_detect_points(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int s
  *   those tensors from the HOST instead (known-answer tests of everything downstream).  Downstream of them wireframe_matcher
  *   :272-307, the stage-1 LOI head :468-514, the line/junction filter :519-558, junction_detector :425-448 and the rescale
  *   :569-582 run on the device.  lines: [capL][4] doubles (x1,y1,x2,y2) original pixels (std::vector<Eigen::Vector4d> layout);
- *   junc: [capJ][259].  No line branch in the pack and stage0 == NULL -> points only (counts 0). */
+ *   junc: [capJ][259].  No line branch in the pack and stage0 == NULL -> points only (counts 0).  The reference has no limit on lines
+ *   or junctions: results that do not fit capL / capJ (45056 lines, 2048 junctions always do) are an ERROR, never a shorter list. */
 typedef struct airfe_plnet_stage0 {
   const float* juncs_pred;          /* [300][2]        */
   const float* lines_pred;          /* [3*128*128][4]  */

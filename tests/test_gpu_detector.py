@@ -142,3 +142,23 @@ def test_empty_image_is_an_error_like_the_reference():
     ctx, _, _ = context("sp", **CFG)
     ok, f = api.FeatureDetector(ctx).Detect(np.zeros((0, 0), np.uint8))
     assert ok is False and f.shape == (259, 0)
+
+
+def test_malformed_weight_pack_is_refused(tmp_path):
+    """load_pack multiplies untrusted dims: a tensor that claims more elements than the file holds (or whose dims overflow) must make
+    airfe_create fail with a message, not allocate 2^64 bytes."""
+    import struct
+    from airslam_amd import api
+
+    def pack(dims, payload=b""):
+        name = b"conv1a.weight"
+        return b"AIRFEPK1" + struct.pack("<I", 1) + struct.pack("<I", len(name)) + name + struct.pack("<I", len(dims)) + \
+            struct.pack(f"<{len(dims)}I", *dims) + payload
+
+    cases = {"huge.airfe": pack([0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF]), "short.airfe": pack([64, 9], b"\0" * 100),
+             "overflow.airfe": pack([0x80000000, 0x80000000, 4, 4])}
+    for fn, blob in cases.items():
+        p = tmp_path / fn
+        p.write_bytes(blob)
+        with pytest.raises(api.AirfeError, match="malformed weight pack"):
+            api.Context(superpoint=str(p))

@@ -96,3 +96,26 @@ def test_match_lines_on_assign_output():
     ref = ref_post.match_lines(ref_post.assign_points_to_lines(lines0, f0), ref_post.assign_points_to_lines(lines1, f1), matches, 300, 300)
     assert dev == ref
     assert sum(1 for i, j in enumerate(ref) if j == i) >= 40          # most lines find their shifted copy
+
+
+def test_match_lines_rejects_malformed_relations():
+    """The device indexes bit rows with pt_idx and walks row_ptr: a relation that is not a valid CSR must be refused on the host
+    (ADVICE r01), not read out of bounds.  The wrapper builds valid CSR itself, so the C entry point is called directly."""
+    import ctypes as C
+    ctx, _, _ = context("sp")
+    out = np.full((2,), -1, np.int32)
+    m = np.array([[0, 0]], np.int32)
+
+    def call(rp0, pi0, rp1, pi1, n0=4, n1=4):
+        rp0, pi0, rp1, pi1 = (np.asarray(a, np.int32) for a in (rp0, pi0, rp1, pi1))
+        return ctx._l.airfe_match_lines(ctx._h, rp0.ctypes.data, pi0.ctypes.data, 2, n0, rp1.ctypes.data, pi1.ctypes.data, 2, n1,
+                                        m.ctypes.data, 1, out.ctypes.data)
+
+    good = ([0, 2, 3], [0, 1, 2])
+    assert call(*good, *good) == 0
+    assert call([0, 2, 1], [0, 1, 2], *good) != 0               # row_ptr decreases
+    assert call([1, 2, 3], [0, 1, 2], *good) != 0               # does not start at 0
+    assert call(*good, [0, 2, 3], [0, 1, 7]) != 0               # point index beyond point_num1
+    assert call([0, 2, 3], [0, -1, 2], *good) != 0              # negative point index
+    assert b"CSR" in C.string_at(ctx._l.airfe_last_error(ctx._h))
+    assert call(*good, *good) == 0                              # the context is still usable

@@ -114,13 +114,16 @@ def _check_superglue(name, ctx, w, f0, f1, layers, iters, tol, min_valid):
     return z
 
 
-@pytest.mark.parametrize("n0,n1,layers,iters,min_valid", [(300, 280, 4, 20, 100), (64, 65, 18, 100, 20), (1, 3, 2, 5, 0),
-                                                           (400, 400, 18, 100, 150)])
-def test_superglue_vs_oracle(n0, n1, layers, iters, min_valid):
+@pytest.mark.parametrize("n0,n1,layers,iters,min_valid,fused", [(300, 280, 4, 20, 100, 0), (64, 65, 18, 100, 20, 0), (1, 3, 2, 5, 0, 0),
+                                                                 (400, 400, 18, 100, 150, 0), (400, 400, 18, 100, 150, 1),
+                                                                 (300, 280, 4, 20, 100, 1), (1, 3, 2, 5, 0, 1)])
+def test_superglue_vs_oracle(n0, n1, layers, iters, min_valid, fused, monkeypatch):
+    # fused = the propagation block (merge, mlp.0 + ReLU, mlp.3, residual) as the one-kernel form large batches use
+    monkeypatch.setenv("AIRFE_FUSE_LG_BLOCK", str(fused))
     w = weights.synthetic_superglue(1234, n_layers=layers)
     ctx = api.Context(superglue=w, matcher=1, max_batch=2, sinkhorn_iters=iters)
     _, _, f0, f1 = _sg_pair(n0, n1, n0 * 3 + n1)
-    z = _check_superglue(f"sg_{n0}_{n1}_{layers}", ctx, w, f0, f1, layers, iters, 0.05, min_valid)
+    z = _check_superglue(f"sg_{n0}_{n1}_{layers}_{'fused' if fused else 'split'}", ctx, w, f0, f1, layers, iters, 0.05, min_valid)
     # marginals: exp(Z) rows/cols sum to the prescribed masses after `iters` iterations (column step is last)
     p = np.exp(z.astype(np.float64))
     np.testing.assert_allclose(p[:, :n1].sum(0), 1.0, atol=2e-3)
