@@ -179,6 +179,7 @@ struct airfe_ctx {
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   int lgb_tokens = 0;            // AIRFE_LGB_TOKENS: tokens per lg_blockf workgroup (128 or 112; 0 = by token count)
   int attn_occ = 3;              // AIRFE_ATTN_OCC: attention32_kernel variant compiled for 2 (no spills) or 3 waves per SIMD
+  bool fold_qkv = true;          // AIRFE_FOLD_QKV=0: q | k | v projections as launches of their own (A/B runs)
   bool nms_v1 = false;           // AIRFE_NMS_V1=1: the five-launch LDS-tiled simple_nms (A/B runs)
   bool attn_v1 = false;          // AIRFE_ATTN_V1=1: the round-1 16x16x32 attention kernel (A/B runs)
   bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
@@ -620,8 +621,9 @@ int load_lightglue(airfe_ctx* c, const char* path) {
 int alloc_matcher_arena(airfe_ctx* c) {
   if (c->has_arena) return 0;
   const int S = 2 * c->Pmax, Np = c->Np;
-  // Token rows: S sequences of Np, PLUS slack.  The GEMMs run over M rounded up to 128 rows; the up-to-127 surplus rows are
-  // garbage tokens of "sequences" S, S+1, .. whose head-major outputs land one or more whole sequences past the real data,
+  // Token rows: S sequences of Np, PLUS slack.  The GEMMs run over M rounded up to 128 rows and the fused block in passes of 112 on
+  // top of that: the up-to-238 surplus rows are garbage tokens of "sequences" S, S+1, .. whose head-major outputs (incl. the
+  // projections folded into the block) land one or more whole sequences past the real data,
   // and attention's last key tile reads up to 63 rows past a sequence.  All of it stays inside this zero-initialised slack.
   const size_t M = (size_t)(S + 2 + 128 / Np) * Np + 256;
   c->x32 = dalloc<float>(c, M * 256);
@@ -1015,14 +1017,23 @@ void run_qkv(airfe_ctx* c, const LinW& qk, const LinW& v, int M, void* qout, voi
 }
 
 // out-proj + FFN + residual of one block as ONE kernel (kernels_lgblockf.hip); flops/bytes are the algorithmic ones
-void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st, int relu = 0) {
+void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st, int relu = 0,
+               const LinW* nqk = nullptr, const LinW* nv = nullptr, bool rotary = false) {
   LgBlockFArgs a;
   a.relu = relu;
   a.attn = c->ob; a.xb = c->xb; a.x32 = c->x32; a.wo = out.w; a.w1 = f0.w; a.w2 = f3.w;
   a.bo = out.b; a.b1 = f0.b; a.gamma = g; a.beta = b; a.b2 = f3.b; a.M = M;
   // one workgroup per CU and pass: ceil(M / T) workgroups run in rounds of 256, a round lasts ~T — take the T with the smaller product
   a.tokens_per_wg = c->lgb_tokens ? c->lgb_tokens : (((M + 111) / 112 + 255) / 256 * 112 < ((M + 127) / 128 + 255) / 256 * 128 ? 112 : 128);
-  ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * (256.0 * 256 + 512.0 * 512 + 512.0 * 256), (double)M * (512 + 512 + 1024 + 512 + 1024) + 917504.0);
+  double fl = 2.0 * M * (256.0 * 256 + 512.0 * 512 + 512.0 * 256), by = (double)M * (512 + 512 + 1024 + 512 + 1024) + 917504.0;
+  if (nqk && nv) {            // the next attention layer's projections ride along (kernels_lgblockf.hip, FOLD)
+    a.nqk_w = nqk->w; a.nqk_b = nqk->b; a.nqk_n = nqk->N; a.nv_w = nv->w; a.nv_b = nv->b;
+    a.rot_cos = rotary ? c->rot_cos : nullptr; a.rot_sin = rotary ? c->rot_sin : nullptr;
+    a.q_out = c->qb; a.k_out = c->kb; a.vt_out = c->vtb; a.Np = c->Np; a.H = 4;
+    fl += 2.0 * M * 256.0 * (nqk->N + nv->N);
+    by += (double)M * (nqk->N + nv->N) * 2 + 256.0 * (nqk->N + nv->N) * 2;
+  }
+  ProfScope ps(c, ST_LG_GEMM, st, fl, by);
   launch_lg_blockf(c->mprec, a, st);
 }
 
@@ -1055,21 +1066,28 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   // tokens (4 pairs of 400) the four separate launches are quicker: 1.82 vs 1.85 ms per step at 3 pairs, 2.01 vs 1.98 at 4,
   // 2.65 vs 2.45 at 8 (profiles/r01d_small_batch_sweeps.txt).
   const bool fused_block = c->fuse_lg_block == 1 || (c->fuse_lg_block < 0 && Mg >= c->block_min);
-  for (const LgLayer& l : c->lg) {
+  // With the fused block the projections of the NEXT attention layer are computed inside it (FOLD): only the very first q | k | v
+  // projection is a launch of its own.
+  const bool fold = fused_block && c->fold_qkv;
+  const bool fold_c = fold, fold_s = fold;
+  for (size_t li = 0; li < c->lg.size(); ++li) {
+    const LgLayer& l = c->lg[li];
+    const LgLayer* nl = li + 1 < c->lg.size() ? &c->lg[li + 1] : nullptr;
     // ---- self block
-    run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, c->rot_cos, c->rot_sin, st);
+    if (!fold_s || li == 0) run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, c->rot_cos, c->rot_sin, st);
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); run_attention(c, c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
     if (fused_block) {
-      lg_blockf(c, l.out, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
+      lg_blockf(c, l.out, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st, 0, fold_c ? &l.cqk : nullptr, fold_c ? &l.cv : nullptr, false);
     } else {
       run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
       lg_ffn(c, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
     }
     // ---- cross block (one shared projection for q and k; the two sides swap roles)
-    run_qkv(c, l.cqk, l.cv, Mg, c->qb, nullptr, nullptr, nullptr, st);
+    if (!fold_c) run_qkv(c, l.cqk, l.cv, Mg, c->qb, nullptr, nullptr, nullptr, st);
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); run_attention(c, c->mprec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
     if (fused_block) {
-      lg_blockf(c, l.cout, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st);
+      const bool fn = fold_s && nl;
+      lg_blockf(c, l.cout, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st, 0, fn ? &nl->qk : nullptr, fn ? &nl->v : nullptr, true);
     } else {
       run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
       lg_ffn(c, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st);
@@ -1245,6 +1263,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
   if (getenv("AIRFE_LGB_TOKENS")) c->lgb_tokens = atoi(getenv("AIRFE_LGB_TOKENS")) == 112 ? 112 : (atoi(getenv("AIRFE_LGB_TOKENS")) == 128 ? 128 : 0);
   if (getenv("AIRFE_ATTN_OCC")) c->attn_occ = atoi(getenv("AIRFE_ATTN_OCC")) == 3 ? 3 : 2;
+  if (getenv("AIRFE_FOLD_QKV")) c->fold_qkv = atoi(getenv("AIRFE_FOLD_QKV")) != 0;
   c->nms_v1 = getenv("AIRFE_NMS_V1") && atoi(getenv("AIRFE_NMS_V1")) != 0;
   c->attn_v1 = getenv("AIRFE_ATTN_V1") && atoi(getenv("AIRFE_ATTN_V1")) != 0;
   c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);

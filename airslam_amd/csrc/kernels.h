@@ -62,6 +62,13 @@ struct LgBlockFArgs {
   int M;                     // tokens, multiple of 128
   int tokens_per_wg = 128;   // 128 or 112 (see launch_lg_blockf)
   int relu = 0;              // 1: ReLU instead of LayerNorm + GELU (the SuperGlue block; gamma / beta unused)
+  // the NEXT attention layer's projections, computed from the block's result (nqk_w == nullptr: none).  nqk_n = 512: q | k with rotary
+  // (rows 0..255 -> q_out, 256..511 -> k_out), 256: the cross block's shared projection (-> q_out); nv: V, stored transposed.
+  // Layouts as EPI_HEADS / EPI_HEADS_T; a ragged last pass stores its surplus rows too (arena slack).
+  const uint16_t *nqk_w = nullptr, *nv_w = nullptr;
+  const float *nqk_b = nullptr, *nv_b = nullptr, *rot_cos = nullptr, *rot_sin = nullptr;
+  int nqk_n = 0, Np = 0, H = 4;
+  uint16_t *q_out = nullptr, *k_out = nullptr, *vt_out = nullptr;
 };
 void launch_lg_blockf(int prec, const LgBlockFArgs& a, hipStream_t st);
 

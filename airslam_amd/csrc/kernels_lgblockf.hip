@@ -91,7 +91,7 @@ struct LfNoHook { __device__ __forceinline__ void operator()(int) const {} };
 // slab 0 on entry; the next slab's fragments are fetched while the current one feeds 2 NT NMT MFMAs, and during the last slab
 // the fetch goes to n0 / n1 (the first slab of whatever this wave multiplies next), which `cur` holds on exit.  (Fetching two
 // or three slabs ahead for the 32-feature GEMMs measured no faster on the whole block.)
-template <class P, int NT, int NMT, class Hook = LfNoHook>
+template <class P, int NT, int NMT, class Hook = LfNoHook, bool SWAP = false>
 __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (&cur)[NT][2], const char* w0, const char* w1, int nslab,
                                        const char* n0, const char* n1, const char* breg, int pitch, int l15, int g, Hook hook = Hook()) {
   typename P::vec8 nxt[NT][2];
@@ -121,7 +121,10 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (mb + j < NMT) acc[t][mb + j] = P::mfma(cur[t][h], bf[j], acc[t][mb + j]);
+            if (mb + j < NMT) {
+              if constexpr (SWAP) acc[t][mb + j] = P::mfma(bf[j], cur[t][h], acc[t][mb + j]);     // tokens x features: the transposed-V form
+              else acc[t][mb + j] = P::mfma(cur[t][h], bf[j], acc[t][mb + j]);
+            }
       }
     }
 #pragma unroll
@@ -140,7 +143,11 @@ struct LfLane {                       // per-lane constants of the whole kernel
 // One pass over NMT token tiles (16 tokens each) starting at token `row0`; its attn tile is already in flight into R0.
 // RELU = the SuperGlue propagation block (merge, mlp.0 + folded BatchNorm + ReLU, mlp.3: super_glue GNN layer) — the same three GEMMs
 // with ReLU in place of LayerNorm + GELU.
-template <class P, int NMT, bool RELU>
+// FOLD = the NEXT attention layer's projections computed here from the block's result while it is still in the workgroup (no re-read of x,
+// one launch less per layer): 1 = the cross block's shared q/k projection (256 features, head-major) + V (transposed); 2 = the self block's
+// q | k (512 features, rotary) + V.  Same fragments, same K order, bias after the sum and the same rotary code as gemmr_body
+// (kernels_gemmr.hip) / the tiled kernels: the three forms give the same bits.
+template <class P, int NMT, bool RELU, int FOLD>
 __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const LfLane& L, int row0) {
   const int lane = L.lane, wave = L.wave, l15 = L.l15, g = L.g, wf = L.wf, cb = L.cb, tp = L.tp, fo0 = L.fo0, fo1 = L.fo1;
   typename P::vec8 c2[2][2], c4[4][2];                            // A fragments in flight: 32-feature GEMMs / the 64-feature one
@@ -291,13 +298,15 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   __syncthreads();
 
   // ---- x += W2 h + b2
+  uint4 xpk[NMT];
   {
     f32x4 acc[2][NMT];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int m = 0; m < NMT; ++m) acc[u][m] = b22[u];
-    lf_mma<P, 2, NMT>(acc, c2, L.w2b + fo0, L.w2b + fo1, 8, L.w2b + fo0, L.w2b + fo1, smem, 1024, l15, g);
+    const char* nq = FOLD ? reinterpret_cast<const char*>(a.nqk_w) + (size_t)cb * 4 * SLAB_BYTES + 2 * tp * 2048 : L.w2b;   // FOLD: first unit = q/k unit wf
+    lf_mma<P, 2, NMT>(acc, c2, L.w2b + fo0, L.w2b + fo1, 8, nq + fo0, nq + fo1, smem, 1024, l15, g);
 #pragma unroll
     for (int m = 0; m < NMT; ++m) {
       const size_t row = (size_t)(row0 + m * 16 + l15);
@@ -306,12 +315,101 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
                     acc[1][m][0] + r1[m].x, acc[1][m][1] + r1[m].y, acc[1][m][2] + r1[m].z, acc[1][m][3] + r1[m].w};
       *reinterpret_cast<float4*>(xr) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(xr + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      *reinterpret_cast<uint4*>(a.xb + row * 256 + co) = pack8<P>(v);
+      xpk[m] = pack8<P>(v);
+      *reinterpret_cast<uint4*>(a.xb + row * 256 + co) = xpk[m];
+    }
+  }
+  if constexpr (FOLD != 0) {
+    __syncthreads();                                              // every wave is done with the h tile
+    {
+      const int piece = cb * 8 + tp * 4 + g;
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) *reinterpret_cast<uint4*>(smem + LF_R0 + (m * 16 + l15) * 512 + ((piece ^ l15) << 4)) = xpk[m];
+    }
+    __syncthreads();                                              // the new x tile [16 NMT][256] is complete in R0
+    const int H = a.H, Np = a.Np;
+    // q / k units: 32 features each, (cb', tp') = (id >> 1, id & 1); this wave takes id = wf (and wf + 8 of the 512-feature q | k)
+    constexpr int NQ = FOLD == 2 ? 2 : 1;
+    const char* vbase = reinterpret_cast<const char*>(a.nv_w) + (size_t)cb * 4 * SLAB_BYTES + 2 * tp * 2048;
+#pragma unroll
+    for (int qu = 0; qu < NQ; ++qu) {
+      const int cbq = cb + 4 * qu;
+      const char* wq = reinterpret_cast<const char*>(a.nqk_w) + (size_t)cbq * 4 * SLAB_BYTES + 2 * tp * 2048;
+      const char* nx = (qu + 1 < NQ) ? reinterpret_cast<const char*>(a.nqk_w) + (size_t)(cbq + 4) * 4 * SLAB_BYTES + 2 * tp * 2048 : vbase;
+      const int cq = cbq * 64 + tp * 32 + g * 8;                  // this lane's 8 features of the projection
+      f32x4 bq[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) bq[u] = *reinterpret_cast<const f32x4*>(a.nqk_b + cq + u * 4);
+      f32x4 acc[2][NMT];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) acc[u][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      lf_mma<P, 2, NMT>(acc, c2, wq + fo0, wq + fo1, 4, nx + fo0, nx + fo1, smem + LF_R0, 512, l15, g);
+      const int sel = cq >> 8, hh = (cq & 255) >> 6, d = cq & 63;
+      uint16_t* ob = sel ? a.k_out : a.q_out;
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) {
+        const int row = row0 + m * 16 + l15;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[0][m][e] + bq[0][e];                          // bias after the K sum, as gemmr_body
+          v[4 + e] = acc[1][m][e] + bq[1][e];
+        }
+        if constexpr (FOLD == 2) {
+          const f32x4 cs = *reinterpret_cast<const f32x4*>(a.rot_cos + (size_t)row * 32 + tp * 16 + g * 4);
+          const f32x4 sn = *reinterpret_cast<const f32x4*>(a.rot_sin + (size_t)row * 32 + tp * 16 + g * 4);
+          // The rotation is spelled out in single (non-packed) instructions.  rotate_pairs() compiled here to v_pk_mul_f32 / v_pk_fma_f32
+          // with op_sel operand swaps fed straight from the two table loads, and in 3-60 % of the launches (depending on the surrounding
+          // schedule) ONE rotated feature of the LAST 16-token tile of a pass came out wrong — always the same lane group, never in the
+          // separate-launch path, no missing wait to be found in the ISA.  400 of 400 runs are bit-identical with the form below
+          // (tests/test_gpu_lightglue.py::test_folded_projections_are_deterministic keeps watching); same products, same fma: same bits.
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float t0, t1, r0, r1;
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(v[2 * i + 1]), "v"(sn[i]));
+            asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(r0) : "v"(v[2 * i]), "v"(cs[i]), "v"(t0));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(v[2 * i]), "v"(sn[i]));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r1) : "v"(v[2 * i + 1]), "v"(cs[i]), "v"(t1));
+            v[2 * i] = r0;
+            v[2 * i + 1] = r1;
+          }
+        }
+        // no row guard: the rows of a ragged last pass are garbage tokens of "sequences" S, S + 1 whose outputs land in the arena's slack
+        // (alloc_matcher_arena), exactly like the surplus rows of the separate launches
+        const int sq = row / Np, nn = row - sq * Np;
+        *reinterpret_cast<uint4*>(ob + (((size_t)sq * H + hh) * Np + nn) * 64 + d) = pack8<P>(v);
+      }
+    }
+    // V unit id = wf, transposed: lane (l15 = feature column, g) holds 4 consecutive tokens per accumulator
+    {
+      float bt[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) bt[u] = a.nv_b[cb * 64 + slab_row_to_feature((2 * tp + u) * 16 + l15)];
+      f32x4 acc[2][NMT];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) acc[u][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      lf_mma<P, 2, NMT, LfNoHook, true>(acc, c2, vbase + fo0, vbase + fo1, 4, vbase + fo0, vbase + fo1, smem + LF_R0, 512, l15, g);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int cv = cb * 64 + slab_row_to_feature((2 * tp + u) * 16 + l15);
+        const int hh = cv >> 6, d = cv & 63;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+          const int rw = row0 + m * 16 + g * 4;
+          const int sq = rw / Np, nn = rw - sq * Np;
+          *reinterpret_cast<uint2*>(a.vt_out + (((size_t)sq * H + hh) * 64 + d) * Np + nn) =
+                pack4<P>(acc[u][m][0] + bt[u], acc[u][m][1] + bt[u], acc[u][m][2] + bt[u], acc[u][m][3] + bt[u]);
+        }
+      }
     }
   }
 }
 
-template <class P, int NMT, bool RELU>
+template <class P, int NMT, bool RELU, int FOLD>
 __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -334,13 +432,13 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
 
   const int row0 = blockIdx.x * (16 * NMT);
   lf_stage_rows(a.attn, row0, NMT, LF_R0, L.wave, L.lane);
-  lf_pass<P, NMT, RELU>(a, smem, L, row0);
+  lf_pass<P, NMT, RELU, FOLD>(a, smem, L, row0);
 }
 
-template <class P, int NMT, bool RELU>
+template <class P, int NMT, bool RELU, int FOLD = 0>
 static void launch_f(const LgBlockFArgs& a, hipStream_t st) {
   static bool attr_done = false;
-  auto kfn = lg_blockf_kernel<P, NMT, RELU>;
+  auto kfn = lg_blockf_kernel<P, NMT, RELU, FOLD>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS);
     attr_done = true;
@@ -357,6 +455,17 @@ void launch_lg_blockf(int prec, const LgBlockFArgs& a, hipStream_t st) {
       if (prec == 1) launch_f<PF16, 7, true>(a, st); else launch_f<PBF16, 7, true>(a, st);
     } else {
       if (prec == 1) launch_f<PF16, 8, true>(a, st); else launch_f<PBF16, 8, true>(a, st);
+    }
+    return;
+  }
+  if (a.nqk_w) {                                       // with the next layer's projections folded in
+    const bool t7 = a.tokens_per_wg == 112;
+    if (a.nqk_n == 512) {
+      if (prec == 1) { if (t7) launch_f<PF16, 7, false, 2>(a, st); else launch_f<PF16, 8, false, 2>(a, st); }
+      else { if (t7) launch_f<PBF16, 7, false, 2>(a, st); else launch_f<PBF16, 8, false, 2>(a, st); }
+    } else {
+      if (prec == 1) { if (t7) launch_f<PF16, 7, false, 1>(a, st); else launch_f<PF16, 8, false, 1>(a, st); }
+      else { if (t7) launch_f<PBF16, 7, false, 1>(a, st); else launch_f<PBF16, 8, false, 1>(a, st); }
     }
     return;
   }

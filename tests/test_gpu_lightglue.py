@@ -273,3 +273,47 @@ def test_lightglue_bf16_storage(env):
     ref = ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
     idx, sc = ctx.match_lightglue(a, b)
     _check_against_oracle(f"lg_bf16_{'fused' if env['AIRFE_FUSE_LG_BLOCK'] == '1' else 'split'}", s, ref, idx, sc, TOL[0], 150)
+
+
+def test_folded_projections_give_the_same_bits():
+    """The fused block computes the NEXT attention layer's q | k | v projections from its own result (kernels_lgblockf.hip, FOLD);
+    AIRFE_FOLD_QKV=0 runs them as launches of their own (gemmr_pair / the tiled kernels).  Same fragments, same K order, bias after
+    the sum, same rotary: the matches AND the scores must be bit-identical, at a size with a ragged last pass (8 pairs x 400 rows =
+    6400 tokens = 57.1 passes of 112) and with short sequences (rows beyond a sequence's length are computed, stored and masked)."""
+    import torch
+    outs = []
+    for fold in ("1", "0"):
+        ctx, _, lg = context("lg", env={"AIRFE_FUSE_LG_BLOCK": "1", "AIRFE_FOLD_QKV": fold}, max_batch=8)
+        B = 8
+        pairs = [_pair(400 - 31 * i, 390 - 17 * i, 240 + i) for i in range(B)]
+        f0 = torch.zeros((B, 400, 259)); f1 = torch.zeros((B, 400, 259))
+        n0 = torch.tensor([p[0].shape[0] for p in pairs], dtype=torch.int32)
+        n1 = torch.tensor([p[1].shape[0] for p in pairs], dtype=torch.int32)
+        for i, (a, b, _, _) in enumerate(pairs):
+            f0[i, :a.shape[0]] = torch.from_numpy(a); f1[i, :b.shape[0]] = torch.from_numpy(b)
+        f0, f1, n0, n1 = f0.cuda(), f1.cuda(), n0.cuda(), n1.cuda()
+        idx = torch.zeros((B, 400, 2), dtype=torch.int32, device="cuda")
+        sc = torch.zeros((B, 400), dtype=torch.float32, device="cuda")
+        nm = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        ctx.match_lightglue_batch_dev(f0, n0, f1, n1, idx, sc, nm)
+        ctx.sync()
+        outs.append((nm.cpu().numpy().copy(), idx.cpu().numpy().copy(), sc.cpu().numpy().copy()))
+    (nm_a, idx_a, sc_a), (nm_b, idx_b, sc_b) = outs
+    assert nm_a.min() >= 50
+    np.testing.assert_array_equal(nm_a, nm_b)
+    for i in range(len(nm_a)):
+        np.testing.assert_array_equal(idx_a[i, :nm_a[i]], idx_b[i, :nm_b[i]])
+        np.testing.assert_array_equal(sc_a[i, :nm_a[i]], sc_b[i, :nm_b[i]])
+
+
+def test_folded_projections_are_deterministic():
+    """150 forward passes of one pair, fused block with the folded projections: one result, and it is the separate-launch path's.
+    (A packed-math rotary epilogue once made ~3 % of the launches differ in a single feature of one 16-token tile — a failure that
+    no single-shot parity test sees.)"""
+    import hashlib
+    _, _, a, b = _pair(400, 400, 1600)
+    ref_ctx, _, _ = context("lg", env={"AIRFE_FUSE_LG_BLOCK": "1", "AIRFE_FOLD_QKV": "0"}, max_batch=4)
+    ref = hashlib.md5(ref_ctx.lightglue_scores(a, b).tobytes()).hexdigest()
+    ctx, _, _ = context("lg", env={"AIRFE_FUSE_LG_BLOCK": "1", "AIRFE_FOLD_QKV": "1"}, max_batch=4)
+    seen = {hashlib.md5(ctx.lightglue_scores(a, b).tobytes()).hexdigest() for _ in range(150)}
+    assert seen == {ref}
