@@ -168,6 +168,7 @@ struct airfe_ctx {
   int mprec = 1;                 // matcher storage type (cfg.matcher_precision)
   int pack_prec = 0;             // storage type make_linear packs for (set by each load_* before it packs)
   int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
+  int Dmax = 1;                  // images the detector arena holds: 2 x Bmax when a stereo step detects left and right as one batch
   bool has_sp = false, has_lg = false;
   uint8_t* pl_stage = nullptr;   // staging of airfe_assign_points_to_lines / airfe_match_lines
   size_t pl_bytes = 0;
@@ -179,6 +180,7 @@ struct airfe_ctx {
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   int lgb_tokens = 0;            // AIRFE_LGB_TOKENS: tokens per lg_blockf workgroup (128 or 112; 0 = by token count)
   int attn_occ = 3;              // AIRFE_ATTN_OCC: attention32_kernel variant compiled for 2 (no spills) or 3 waves per SIMD
+  bool stereo_one_pass = true;   // AIRFE_STEREO_ONE_PASS=0: airfe_stereo_batch_dev detects left and right as two batches (A/B runs)
   bool fold_qkv = true;          // AIRFE_FOLD_QKV=0: q | k | v projections as launches of their own (A/B runs)
   bool nms_v1 = false;           // AIRFE_NMS_V1=1: the five-launch LDS-tiled simple_nms (A/B runs)
   bool attn_v1 = false;          // AIRFE_ATTN_V1=1: the round-1 16x16x32 attention kernel (A/B runs)
@@ -512,7 +514,7 @@ int load_superpoint(airfe_ctx* c, const char* path) {
             make_linear_named(c, p, "convPb", 256, 65, c->cPb, err) && make_linear_named(c, p, "convDb", 256, 256, c->cDb, err);
   if (!ok) return fail(c, err.empty() ? "device allocation failed while packing SuperPoint weights" : err);
 
-  const int B = c->Bmax, ch = c->chunk, R = AIRFE_INTERNAL_SIZE;
+  const int B = c->Dmax, ch = c->chunk, R = AIRFE_INTERNAL_SIZE;
   c->img32 = dalloc<float>(c, (size_t)ch * (R + 2) * (R + 2));
   c->a1a = dalloc<uint16_t>(c, (size_t)ch * (R + 2) * (R + 2) * 64);
   c->a1b = dalloc<uint16_t>(c, (size_t)ch * (R / 2 + 2) * (R / 2 + 2) * 64);
@@ -879,22 +881,28 @@ int lightglue_dev_f32(airfe_ctx* c, const float* f0, const int* n0, const float*
   return 0;
 }
 
-int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat,
-               int cap, int* d_n, hipStream_t st) {
+// Detector over ONE batch of B images, or — d_gray1 != nullptr — over the 2 B images of B stereo pairs in one pass (images 0 .. B-1 from
+// d_gray, B .. 2B-1 from d_gray1; features to d_feat / d_feat1): every whole-batch kernel then runs once over twice the tiles instead
+// of twice (half the launches, prologues and tails of the second half of the network; per-image results do not depend on the batch).
+int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int Bs, int h, int w, int stride, size_t img_stride,
+                float* d_feat, float* d_feat1, int cap, int* d_n, int* d_n1, hipStream_t st) {
   if (!c->has_sp) return fail(c, "detector weights were not loaded (cfg.superpoint_pack)");
-  if (B < 1 || B > c->Bmax) return fail(c, "batch exceeds cfg.max_batch");
+  const int B = d_gray1 ? 2 * Bs : Bs;
+  if (Bs < 1 || Bs > c->Bmax || B > c->Dmax) return fail(c, "batch exceeds cfg.max_batch");
   if (h < 1 || w < 1) return fail(c, "empty image");
   if (cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
   if (ensure_tables(c, h, w)) return 1;
   const int R = AIRFE_INTERNAL_SIZE;
   if (c->prec == 2) {
+    if (d_gray1) return fail(c, "detect_dev2: the fp32 path takes one source");
     if (encode_f32(c, d_gray, B, h, w, stride, img_stride, st)) return 1;
   } else {
-    for (int c0 = 0; c0 < B; c0 += c->chunk) {
-      const int cb = std::min(c->chunk, B - c0);
+    for (int c0 = 0, cb = 0; c0 < B; c0 += cb) {
+      cb = std::min(c->chunk, (c0 < Bs ? Bs : B) - c0);                 // a chunk never straddles the two sources
+      const uint8_t* src = c0 < Bs ? d_gray + (size_t)c0 * img_stride : d_gray1 + (size_t)(c0 - Bs) * img_stride;
       {
         ProfScope ps(c, ST_PREPROCESS, st, 0, (double)cb * ((double)h * w + (double)R * R * 4));
-        launch_preprocess(d_gray + (size_t)c0 * img_stride, cb, h, w, stride, img_stride, c->xtab, c->ytab, c->lut, c->img32, R, R, st);
+        launch_preprocess(src, cb, h, w, stride, img_stride, c->xtab, c->ytab, c->lut, c->img32, R, R, st);
       }
       if (c->fuse_conv1a) {
         // conv1a (Cin = 1) fused into the persistent conv1b kernel: its 64-channel full-resolution output never
@@ -963,16 +971,27 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
       launch_candidates(c->heat, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
     }
   }
-  {
-    ProfScope ps(c, ST_SELECT, st, 0, (double)B * 8192 * 8);
-    launch_select_list(c->cand, c->cand_cnt, ccap, B, R, c->cfg.max_keypoints, cap, d_feat, d_n, st);
-  }
-  {
-    ProfScope ps(c, ST_SAMPLE, st, 0, (double)B * c->cfg.max_keypoints * (4096 + 1036));
-    launch_sample_desc(c->desc, B, R / 8, R / 8, d_feat, d_n, cap, (float)w / (float)R, (float)h / (float)R, c->desc_normalised ? 0 : 1, st);
+  for (int half = 0; half < (d_gray1 ? 2 : 1); ++half) {               // the two feature destinations: one launch each
+    const int b0 = half * Bs;
+    float* df = half ? d_feat1 : d_feat;
+    int* dn = half ? d_n1 : d_n;
+    {
+      ProfScope ps(c, ST_SELECT, st, 0, (double)Bs * 8192 * 8);
+      launch_select_list(c->cand + (size_t)b0 * ccap, c->cand_cnt + b0, ccap, Bs, R, c->cfg.max_keypoints, cap, df, dn, st);
+    }
+    {
+      ProfScope ps(c, ST_SAMPLE, st, 0, (double)Bs * c->cfg.max_keypoints * (4096 + 1036));
+      launch_sample_desc(c->desc + (size_t)b0 * (R / 8) * (R / 8) * 256, Bs, R / 8, R / 8, df, dn, cap, (float)w / (float)R, (float)h / (float)R,
+                         c->desc_normalised ? 0 : 1, st);
+    }
   }
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+
+int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat,
+               int cap, int* d_n, hipStream_t st) {
+  return detect_dev2(c, d_gray, nullptr, B, h, w, stride, img_stride, d_feat, nullptr, cap, d_n, nullptr, st);
 }
 
 void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1, const uint16_t* x2, int ld2, int M,
@@ -1263,6 +1282,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
   if (getenv("AIRFE_LGB_TOKENS")) c->lgb_tokens = atoi(getenv("AIRFE_LGB_TOKENS")) == 112 ? 112 : (atoi(getenv("AIRFE_LGB_TOKENS")) == 128 ? 128 : 0);
   if (getenv("AIRFE_ATTN_OCC")) c->attn_occ = atoi(getenv("AIRFE_ATTN_OCC")) == 3 ? 3 : 2;
+  if (getenv("AIRFE_STEREO_ONE_PASS")) c->stereo_one_pass = atoi(getenv("AIRFE_STEREO_ONE_PASS")) != 0;
   if (getenv("AIRFE_FOLD_QKV")) c->fold_qkv = atoi(getenv("AIRFE_FOLD_QKV")) != 0;
   c->nms_v1 = getenv("AIRFE_NMS_V1") && atoi(getenv("AIRFE_NMS_V1")) != 0;
   c->attn_v1 = getenv("AIRFE_ATTN_V1") && atoi(getenv("AIRFE_ATTN_V1")) != 0;
@@ -1271,6 +1291,8 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
     delete c;
     return fail(nullptr, "airfe_create: stream creation failed");
   }
+  // a context with a detector AND the stereo matcher runs airfe_stereo_batch_dev over left + right images as one detector batch
+  c->Dmax = (c->stereo_one_pass && c->prec != 2 && cfg->superpoint_pack && cfg->lightglue_pack) ? 2 * c->Bmax : c->Bmax;
   int rc = 0;
   if (cfg->superpoint_pack) rc = load_superpoint(c, cfg->superpoint_pack);
   if (!rc && cfg->lightglue_pack) rc = load_lightglue(c, cfg->lightglue_pack);
@@ -1463,7 +1485,7 @@ int airfe_rectify_detect_points(airfe_ctx* c, int side, const uint8_t* raw, int 
 }
 
 int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_nms, float* desc) {
-  if (!c || !c->has_sp || B > c->Bmax) return 1;
+  if (!c || !c->has_sp || B > c->Dmax) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t R = AIRFE_INTERNAL_SIZE;
   if (heat_raw) HIPCHK(c, hipMemcpy(heat_raw, c->heat, (size_t)B * R * R * 4, hipMemcpyDeviceToHost));
@@ -1480,7 +1502,7 @@ int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_
   if (heat_nms) HIPCHK(c, hipMemcpy(heat_nms, c->cfg.nms_radius > 0 ? c->heat_nms : c->heat, (size_t)B * R * R * 4, hipMemcpyDeviceToHost));
   if (desc) {
     if (!c->desc_normalised) {      // the inspection hook returns the map the reference would hold: normalised
-      launch_l2norm256(c->desc, c->Bmax * 64 * 64, c->stream);
+      launch_l2norm256(c->desc, c->Dmax * 64 * 64, c->stream);
       HIPCHK(c, hipStreamSynchronize(c->stream));
       c->desc_normalised = true;
     }
@@ -1561,8 +1583,12 @@ int airfe_stereo_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d
                            float* d_score, int mcap, int* d_nmatch, void* stream) {
   if (!c) return 1;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  if (detect_dev(c, d_left, B, h, w, stride, img_stride, d_featL, cap, d_nL, st)) return 1;
-  if (detect_dev(c, d_right, B, h, w, stride, img_stride, d_featR, cap, d_nR, st)) return 1;
+  if (c->stereo_one_pass && c->prec != 2 && 2 * B <= c->Dmax) {        // left and right images as ONE detector batch
+    if (detect_dev2(c, d_left, d_right, B, h, w, stride, img_stride, d_featL, d_featR, cap, d_nL, d_nR, st)) return 1;
+  } else {
+    if (detect_dev(c, d_left, B, h, w, stride, img_stride, d_featL, cap, d_nL, st)) return 1;
+    if (detect_dev(c, d_right, B, h, w, stride, img_stride, d_featR, cap, d_nR, st)) return 1;
+  }
   return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
 }
 
