@@ -180,6 +180,10 @@ struct airfe_ctx {
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   int lgb_tokens = 0;            // AIRFE_LGB_TOKENS: tokens per lg_blockf workgroup (128 or 112; 0 = by token count)
   int attn_occ = 3;              // AIRFE_ATTN_OCC: attention32_kernel variant compiled for 2 (no spills) or 3 waves per SIMD
+  bool sparse_desc = true;       // AIRFE_SPARSE_DESC=0: the descriptor head over every cell at every batch size (A/B runs)
+  bool desc_dense_valid = true;  // c->desc holds the dense map of the last batch (else: the gather GEMM's rows)
+  int last_B = 0;
+  int* desc_idx = nullptr;       // row list of the descriptor head's gather GEMM
   bool stereo_one_pass = true;   // AIRFE_STEREO_ONE_PASS=0: airfe_stereo_batch_dev detects left and right as two batches (A/B runs)
   bool fold_qkv = true;          // AIRFE_FOLD_QKV=0: q | k | v projections as launches of their own (A/B runs)
   bool nms_v1 = false;           // AIRFE_NMS_V1=1: the five-launch LDS-tiled simple_nms (A/B runs)
@@ -529,6 +533,7 @@ int load_superpoint(airfe_ctx* c, const char* path) {
   c->aDa = dalloc<uint16_t>(c, cells * 256);
   c->logits = dalloc<float>(c, cells * 72);
   c->desc = dalloc<float>(c, cells * 256);
+  c->desc_idx = dalloc<int>(c, (size_t)B * 1024 * 4 + 256);
   c->heat = dalloc<float>(c, (size_t)B * R * R);
   c->heat_nms = dalloc<float>(c, (size_t)B * R * R);
   c->nms_mask = dalloc<unsigned char>(c, (size_t)2 * B * R * R);
@@ -881,6 +886,19 @@ int lightglue_dev_f32(airfe_ctx* c, const float* f0, const int* n0, const float*
   return 0;
 }
 
+// convDb over every cell of the batch -> c->desc [B][64][64][256] fp32, un-normalised
+void dense_desc_head(airfe_ctx* c, int B, hipStream_t st) {
+  const int R = AIRFE_INTERNAL_SIZE, cells = B * (R / 8) * (R / 8);
+  GemmArgs g;
+  g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b;
+  g.M = cells; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
+  g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
+  { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024)); launch_gemm(c->prec, 256, false, g, st); }
+  // F.normalize of the dense map is applied lazily: sample_desc_kernel normalises just the 4 taps each keypoint reads
+  // (same operations, same bits) — a dense pass moved 8 MB/image to serve 400 x 4 cell reads.
+  c->desc_normalised = false;
+}
+
 // Detector over ONE batch of B images, or — d_gray1 != nullptr — over the 2 B images of B stereo pairs in one pass (images 0 .. B-1 from
 // d_gray, B .. 2B-1 from d_gray1; features to d_feat / d_feat1): every whole-batch kernel then runs once over twice the tiles instead
 // of twice (half the launches, prologues and tails of the second half of the network; per-image results do not depend on the batch).
@@ -893,6 +911,7 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
   if (cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
   if (ensure_tables(c, h, w)) return 1;
   const int R = AIRFE_INTERNAL_SIZE;
+  bool sparse_desc = false;
   if (c->prec == 2) {
     if (d_gray1) return fail(c, "detect_dev2: the fp32 path takes one source");
     if (encode_f32(c, d_gray, B, h, w, stride, img_stride, st)) return 1;
@@ -939,16 +958,14 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
       { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 288)); launch_gemm(c->prec, 256, false, g, st); }
       { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * (260 + 256)); launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st); }
     }
-    {
-      GemmArgs g;
-      g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b;
-      g.M = cells; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
-      g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-      { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024)); launch_gemm(c->prec, 256, false, g, st); }
-      // F.normalize of the dense map is applied lazily: sample_desc_kernel normalises just the 4 taps each keypoint reads
-      // (same operations, same bits) — a dense pass moved 8 MB/image to serve 400 x 4 cell reads.
-      c->desc_normalised = false;
-    }
+    // The descriptor head convDb (1x1, 256 -> 256) is only ever READ at the <= 4 cells each keypoint samples: large batches run it as a
+    // gather GEMM over those rows after the top-K (below) — 1600 of 4096 cells per image at 400 keypoints, and 1.6 instead of 4 MB
+    // of fp32 written.  The dense map stays for small batches (the batch-1 line path samples junction descriptors from it) and
+    // for the inspection hook, which rebuilds it on demand.  Same kernel, same K order: the rows are bit-identical either way.
+    sparse_desc = c->sparse_desc && B > 2 && cap * 4 <= (R / 8) * (R / 8) && cap <= 1024;
+    if (!sparse_desc) dense_desc_head(c, B, st);
+    c->desc_dense_valid = !sparse_desc;
+    c->last_B = B;
   }
   const int ccap = R * R;
   {
@@ -971,19 +988,33 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
       launch_candidates(c->heat, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
     }
   }
-  for (int half = 0; half < (d_gray1 ? 2 : 1); ++half) {               // the two feature destinations: one launch each
+  const int nhalf = d_gray1 ? 2 : 1;
+  for (int half = 0; half < nhalf; ++half) {                             // the two feature destinations: one launch each
     const int b0 = half * Bs;
-    float* df = half ? d_feat1 : d_feat;
-    int* dn = half ? d_n1 : d_n;
-    {
-      ProfScope ps(c, ST_SELECT, st, 0, (double)Bs * 8192 * 8);
-      launch_select_list(c->cand + (size_t)b0 * ccap, c->cand_cnt + b0, ccap, Bs, R, c->cfg.max_keypoints, cap, df, dn, st);
-    }
-    {
-      ProfScope ps(c, ST_SAMPLE, st, 0, (double)Bs * c->cfg.max_keypoints * (4096 + 1036));
-      launch_sample_desc(c->desc + (size_t)b0 * (R / 8) * (R / 8) * 256, Bs, R / 8, R / 8, df, dn, cap, (float)w / (float)R, (float)h / (float)R,
-                         c->desc_normalised ? 0 : 1, st);
-    }
+    ProfScope ps(c, ST_SELECT, st, 0, (double)Bs * 8192 * 8);
+    launch_select_list(c->cand + (size_t)b0 * ccap, c->cand_cnt + b0, ccap, Bs, R, c->cfg.max_keypoints, cap, half ? d_feat1 : d_feat,
+                       half ? d_n1 : d_n, st);
+  }
+  if (sparse_desc) {
+    const int M = B * cap * 4, Mp = (M + 255) / 256 * 256;
+    for (int half = 0; half < nhalf; ++half)
+      launch_desc_cells(half ? d_feat1 : d_feat, half ? d_n1 : d_n, cap, Bs, half * Bs, R / 8, R / 8, c->desc_idx + (size_t)half * Bs * cap * 4, st);
+    if (Mp > M) HIPCHK(c, hipMemsetAsync(c->desc_idx + M, 0, (size_t)(Mp - M) * 4, st));
+    GemmArgs g;
+    g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b; g.rowidx = c->desc_idx;
+    g.M = Mp; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
+    ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * Mp * 256 * 256, (double)Mp * (512 + 1024));
+    launch_gemm8(c->prec, 256, false, g, st);
+  }
+  for (int half = 0; half < nhalf; ++half) {
+    const int b0 = half * Bs;
+    ProfScope ps(c, ST_SAMPLE, st, 0, (double)Bs * c->cfg.max_keypoints * (4096 + 1036));
+    if (sparse_desc)
+      launch_sample_desc(c->desc + (size_t)b0 * cap * 4 * 256, Bs, R / 8, R / 8, half ? d_feat1 : d_feat, half ? d_n1 : d_n, cap, (float)w / (float)R,
+                         (float)h / (float)R, 1, st, 1);
+    else
+      launch_sample_desc(c->desc + (size_t)b0 * (R / 8) * (R / 8) * 256, Bs, R / 8, R / 8, half ? d_feat1 : d_feat, half ? d_n1 : d_n, cap,
+                         (float)w / (float)R, (float)h / (float)R, c->desc_normalised ? 0 : 1, st);
   }
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -1282,6 +1313,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
   if (getenv("AIRFE_LGB_TOKENS")) c->lgb_tokens = atoi(getenv("AIRFE_LGB_TOKENS")) == 112 ? 112 : (atoi(getenv("AIRFE_LGB_TOKENS")) == 128 ? 128 : 0);
   if (getenv("AIRFE_ATTN_OCC")) c->attn_occ = atoi(getenv("AIRFE_ATTN_OCC")) == 3 ? 3 : 2;
+  if (getenv("AIRFE_SPARSE_DESC")) c->sparse_desc = atoi(getenv("AIRFE_SPARSE_DESC")) != 0;
   if (getenv("AIRFE_STEREO_ONE_PASS")) c->stereo_one_pass = atoi(getenv("AIRFE_STEREO_ONE_PASS")) != 0;
   if (getenv("AIRFE_FOLD_QKV")) c->fold_qkv = atoi(getenv("AIRFE_FOLD_QKV")) != 0;
   c->nms_v1 = getenv("AIRFE_NMS_V1") && atoi(getenv("AIRFE_NMS_V1")) != 0;
@@ -1501,6 +1533,10 @@ int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_
   }
   if (heat_nms) HIPCHK(c, hipMemcpy(heat_nms, c->cfg.nms_radius > 0 ? c->heat_nms : c->heat, (size_t)B * R * R * 4, hipMemcpyDeviceToHost));
   if (desc) {
+    if (!c->desc_dense_valid) {     // the batch path ran the head on the sampled cells only: build the dense map from the kept activations
+      dense_desc_head(c, c->last_B, c->stream);
+      c->desc_dense_valid = true;
+    }
     if (!c->desc_normalised) {      // the inspection hook returns the map the reference would hold: normalised
       launch_l2norm256(c->desc, c->Dmax * 64 * 64, c->stream);
       HIPCHK(c, hipStreamSynchronize(c->stream));

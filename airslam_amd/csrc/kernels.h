@@ -38,6 +38,7 @@ struct GemmArgs {
   int small_max = 4096, g8_min = 16000;
   int gr_min = 8192;             // rows from which the K = 256 linears go to the streaming kernel (where it applies)
   int gr_wgs = 256;              // its persistent workgroups (tests lower it so that a small batch wraps the DMA ring)
+  const int* rowidx = nullptr;   // gemm8 only: row r of the GEMM reads X1 row rowidx[r] (a gather; [M] entries)
 };
 
 // out[M][N] = X[M][K] * W^T ; K in {128,256,512}; trans => EPI_HEADS_T (operand roles swapped)
@@ -130,7 +131,10 @@ void launch_select_list(const unsigned long long* cand, const int* cand_cnt, int
 // bilinear descriptor sampling + L2 norm (plnet.cpp:369-417), then x,y *= (w_scale,h_scale)
 //   desc fp32 [B][HC][WC][256]
 void launch_sample_desc(const float* desc, int B, int HC, int WC, float* feat, const int* n, int cap,
-                        float w_scale, float h_scale, int normalise, hipStream_t st);
+                        float w_scale, float h_scale, int normalise, hipStream_t st, int compact = 0);
+// idx[(b * cap + k) * 4 + tap] = row (b0 + b) * HC * WC + cell of the dense head input that keypoint k of image b samples (k >= n[b]: 0):
+// the row list of the descriptor head's gather GEMM; compact = 1 in launch_sample_desc reads that GEMM's output
+void launch_desc_cells(const float* feat, const int* n, int cap, int B, int b0, int HC, int WC, int* idx, hipStream_t st);
 
 // ---- LightGlue ------------------------------------------------------------------------------
 struct LgPrepArgs {

@@ -92,6 +92,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs a, int K, int qu
   const uint16_t* xp1 = a.X1 + (size_t)(m0 + xr) * a.ld1 + xcs;
   const uint16_t* xp2 = a.X2 ? a.X2 + (size_t)(m0 + xr) * a.ld2 + xcs : xp1;
   const size_t rstep1 = (size_t)64 * a.ld1, rstep2 = (size_t)64 * a.ld2;
+  // gather form (a.rowidx): this thread's four rows come from X1 rows rowidx[m0 + xr + 64 i]
+  const uint16_t* xg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xg[i] = a.rowidx ? a.X1 + (size_t)a.rowidx[m0 + xr + 64 * i] * a.ld1 + xcs : xp1 + i * rstep1;
   const char* wbase = reinterpret_cast<const char*>(a.Wp) + (size_t)tid * 16;
 
   auto dma = [&](int it) {
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs a, int K, int qu
     const size_t rs = first ? rstep1 : rstep2;
     const unsigned dst = lds_base + (it & 1) * G8_STAGE + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) g8_glds16(src + i * rs, dst + i * 8192);
+    for (int i = 0; i < 4; ++i) g8_glds16(first ? xg[i] + k0 : src + i * rs, dst + i * 8192);
     const char* w0 = wbase + ((size_t)(4 * qd) * NS + s) * SLAB_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) g8_glds16(w0 + (size_t)i * NS * SLAB_BYTES, dst + 32768 + i * 8192);

@@ -279,14 +279,9 @@ void launch_simple_nms(const float* heat, float* out, float* tmp, int B, int H, 
 // (plnet.cpp:574-575).  _rn intrinsics keep hipcc from contracting the reference's mul/add pairs.
 __device__ __forceinline__ int clipi(int v, int mx) { return v < 0 ? 0 : min(v, mx - 1); }
 
-__global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restrict__ desc, int HC, int WC,
-                                                          float* __restrict__ feat, const int* __restrict__ n, int cap,
-                                                          float sx, float bx, float sy, float by, float w_scale,
-                                                          float h_scale, int normalise) {
-  const int b = blockIdx.y, k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (k >= n[b]) return;
-  float* f = feat + ((size_t)b * cap + k) * 259;
-  const float x = f[1], y = f[2];
+// the four taps of a keypoint (grid_sample bilinear, align_corners semantics of extract_descriptors) and their weights
+struct DescTaps { int c[4]; float w[4]; };       // cell = iy * WC + ix of nw, ne, sw, se
+__device__ __forceinline__ DescTaps desc_taps(float x, float y, float sx, float bx, float sy, float by, int HC, int WC) {
   float kx = __fadd_rn(__fmul_rn(x, sx), bx), ky = __fadd_rn(__fmul_rn(y, sy), by);
   kx = __fmul_rn(__fadd_rn(kx, 1.0f), 0.5f);
   ky = __fmul_rn(__fadd_rn(ky, 1.0f), 0.5f);
@@ -295,15 +290,58 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restric
   const int ix_ne = clipi(ix_nw + 1, WC), iy_ne = clipi(iy_nw, HC);
   const int ix_sw = clipi(ix_nw, WC), iy_sw = clipi(iy_nw + 1, HC);
   const int ix_se = clipi(ix_nw + 1, WC), iy_se = clipi(iy_nw + 1, HC);
-  const float nw = __fmul_rn(__fsub_rn((float)ix_se, ix), __fsub_rn((float)iy_se, iy));
-  const float ne = __fmul_rn(__fsub_rn(ix, (float)ix_sw), __fsub_rn((float)iy_sw, iy));
-  const float sw = __fmul_rn(__fsub_rn((float)ix_ne, ix), __fsub_rn(iy, (float)iy_ne));
-  const float se = __fmul_rn(__fsub_rn(ix, (float)ix_nw), __fsub_rn(iy, (float)iy_nw));
-  const float* d = desc + (size_t)b * HC * WC * 256 + lane * 4;
-  float4 a0 = *reinterpret_cast<const float4*>(d + ((size_t)iy_nw * WC + ix_nw) * 256);
-  float4 a1 = *reinterpret_cast<const float4*>(d + ((size_t)iy_ne * WC + ix_ne) * 256);
-  float4 a2 = *reinterpret_cast<const float4*>(d + ((size_t)iy_sw * WC + ix_sw) * 256);
-  float4 a3 = *reinterpret_cast<const float4*>(d + ((size_t)iy_se * WC + ix_se) * 256);
+  DescTaps t;
+  t.w[0] = __fmul_rn(__fsub_rn((float)ix_se, ix), __fsub_rn((float)iy_se, iy));
+  t.w[1] = __fmul_rn(__fsub_rn(ix, (float)ix_sw), __fsub_rn((float)iy_sw, iy));
+  t.w[2] = __fmul_rn(__fsub_rn((float)ix_ne, ix), __fsub_rn(iy, (float)iy_ne));
+  t.w[3] = __fmul_rn(__fsub_rn(ix, (float)ix_nw), __fsub_rn(iy, (float)iy_nw));
+  t.c[0] = iy_nw * WC + ix_nw; t.c[1] = iy_ne * WC + ix_ne; t.c[2] = iy_sw * WC + ix_sw; t.c[3] = iy_se * WC + ix_se;
+  return t;
+}
+
+// rows of the dense head input that the keypoints of a batch will sample: idx[(b * cap + k) * 4 + tap] = (b0 + b) * HC * WC + cell
+// (slots k >= n[b]: row 0, computed and never read).  The descriptor head then runs as a GATHER GEMM over these rows only.
+__global__ void desc_cells_kernel(const float* __restrict__ feat, const int* __restrict__ n, int cap, int B, int b0, int HC, int WC,
+                                  float sx, float bx, float sy, float by, int* __restrict__ idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * cap) return;
+  const int b = i / cap, k = i - b * cap;
+  int4 o = make_int4(0, 0, 0, 0);
+  if (k < n[b]) {
+    const float* f = feat + (size_t)i * 259;
+    const DescTaps t = desc_taps(f[1], f[2], sx, bx, sy, by, HC, WC);
+    const int base = (b0 + b) * HC * WC;
+    o = make_int4(base + t.c[0], base + t.c[1], base + t.c[2], base + t.c[3]);
+  }
+  reinterpret_cast<int4*>(idx)[i] = o;
+}
+
+// compact != 0: `desc` holds the four head rows of keypoint (b, k) at rows (b * cap + k) * 4 + tap (the gather GEMM's output)
+// instead of the dense [B][HC][WC][256] map — same values, same operations from there on
+__global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restrict__ desc, int HC, int WC,
+                                                          float* __restrict__ feat, const int* __restrict__ n, int cap,
+                                                          float sx, float bx, float sy, float by, float w_scale,
+                                                          float h_scale, int normalise, int compact) {
+  const int b = blockIdx.y, k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= n[b]) return;
+  float* f = feat + ((size_t)b * cap + k) * 259;
+  const float x = f[1], y = f[2];
+  const DescTaps tp = desc_taps(x, y, sx, bx, sy, by, HC, WC);
+  const float nw = tp.w[0], ne = tp.w[1], sw = tp.w[2], se = tp.w[3];
+  float4 a0, a1, a2, a3;
+  if (compact) {
+    const float* d = desc + ((size_t)b * cap + k) * 4 * 256 + lane * 4;
+    a0 = *reinterpret_cast<const float4*>(d);
+    a1 = *reinterpret_cast<const float4*>(d + 256);
+    a2 = *reinterpret_cast<const float4*>(d + 512);
+    a3 = *reinterpret_cast<const float4*>(d + 768);
+  } else {
+    const float* d = desc + (size_t)b * HC * WC * 256 + lane * 4;
+    a0 = *reinterpret_cast<const float4*>(d + (size_t)tp.c[0] * 256);
+    a1 = *reinterpret_cast<const float4*>(d + (size_t)tp.c[1] * 256);
+    a2 = *reinterpret_cast<const float4*>(d + (size_t)tp.c[2] * 256);
+    a3 = *reinterpret_cast<const float4*>(d + (size_t)tp.c[3] * 256);
+  }
   if (normalise) {       // F.normalize(dim=channel) of the four cells, operation for operation as l2norm256_kernel does it
     l2norm_lane4(a0);
     l2norm_lane4(a1);
@@ -334,13 +372,24 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restric
   }
 }
 
-void launch_sample_desc(const float* desc, int B, int HC, int WC, float* feat, const int* n, int cap, float w_scale,
-                        float h_scale, int normalise, hipStream_t st) {
+static void desc_grid_coeffs(int HC, int WC, float& sx, float& bx, float& sy, float& by) {
   const int s = 8;
-  const float sx = (float)(2.0 / (WC * s - s / 2 - 0.5)), bx = (float)((1 - s) / (WC * s - s / 2 - 0.5) - 1);
-  const float sy = (float)(2.0 / (HC * s - s / 2 - 0.5)), by = (float)((1 - s) / (HC * s - s / 2 - 0.5) - 1);
+  sx = (float)(2.0 / (WC * s - s / 2 - 0.5)); bx = (float)((1 - s) / (WC * s - s / 2 - 0.5) - 1);
+  sy = (float)(2.0 / (HC * s - s / 2 - 0.5)); by = (float)((1 - s) / (HC * s - s / 2 - 0.5) - 1);
+}
+
+void launch_sample_desc(const float* desc, int B, int HC, int WC, float* feat, const int* n, int cap, float w_scale,
+                        float h_scale, int normalise, hipStream_t st, int compact) {
+  float sx, bx, sy, by;
+  desc_grid_coeffs(HC, WC, sx, bx, sy, by);
   hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4, B), dim3(256), 0, st, desc, HC, WC, feat, n, cap, sx, bx,
-                     sy, by, w_scale, h_scale, normalise);
+                     sy, by, w_scale, h_scale, normalise, compact);
+}
+
+void launch_desc_cells(const float* feat, const int* n, int cap, int B, int b0, int HC, int WC, int* idx, hipStream_t st) {
+  float sx, bx, sy, by;
+  desc_grid_coeffs(HC, WC, sx, bx, sy, by);
+  hipLaunchKernelGGL(desc_cells_kernel, dim3((B * cap + 255) / 256), dim3(256), 0, st, feat, n, cap, B, b0, HC, WC, sx, bx, sy, by, idx);
 }
 
 }  // namespace airfe
