@@ -40,6 +40,26 @@ __device__ __forceinline__ void lf_glds16(const void* gsrc, unsigned lds_off) {
 // One transcendental instead of the two (rcp, exp) of Abramowitz & Stegun 7.1.26 in ln_gelu_kernel, no cancellation on the
 // negative side (max abs error 1.1e-6, relative 2e-4 in the far negative tail where 7.1.26 returns 0), and written on float
 // PAIRS so that the multiply-adds become v_pk_fma_f32 / v_pk_mul_f32: this epilogue is 128 elements per lane per workgroup.
+#ifndef LF_GELU_ERFC
+// Cheaper form (default): GELU(y) = y (0.5 + E(t)),  E(t) = 0.5 erf(t / sqrt 2) = t P(t^2),  t = clamp(y, +-4.5): an odd polynomial of degree
+// 17 (least-squares Chebyshev fit in x = 2 t^2 / 4.5^2 - 1, weighted by t^2 = the weight of E in the result), no transcendental: 13
+// packed multiply-adds + 2 v_med3 per PAIR against ~20 + 2 v_exp_f32 (quarter rate) for the erfc form below.  Max abs error of the
+// fp32 evaluation 4.2e-5 (at y = 0.6; beyond |y| = 4.5 the result is y resp. y * 2e-6): a tenth of the 2-byte rounding the h tile
+// gets next.  -DLF_GELU_ERFC selects the erfc form (max abs error 1.1e-6).
+__device__ __forceinline__ f32x2 lf_gelu2(f32x2 y) {
+  const f32x2 t = {__builtin_amdgcn_fmed3f(y.x, -4.5f, 4.5f), __builtin_amdgcn_fmed3f(y.y, -4.5f, 4.5f)};
+  const f32x2 x = (t * t) * (2.0f / 20.25f) - 1.0f;
+  f32x2 r = x * 0.0031705170404165983f - 0.009152771905064583f;
+  r = r * x + 0.012448843568563461f;
+  r = r * x - 0.016971856355667114f;
+  r = r * x + 0.027542514726519585f;
+  r = r * x - 0.040475402027368546f;
+  r = r * x + 0.05482625961303711f;
+  r = r * x - 0.07717858254909515f;
+  r = r * x + 0.15690208971500397f;
+  return y * (t * r + 0.5f);
+}
+#else
 __device__ __forceinline__ f32x2 lf_gelu2(f32x2 y) {
   const f32x2 a = __builtin_elementwise_abs(y);
   f32x2 x = a * 0.70710678118654752f;
@@ -57,6 +77,7 @@ __device__ __forceinline__ f32x2 lf_gelu2(f32x2 y) {
   const f32x2 q = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
   return __builtin_elementwise_max(y, f32x2{0.f, 0.f}) - (x * 0.70710678118654752f) * q;
 }
+#endif
 
 // [16 nmt tokens][256] 2-byte rows of `src` -> LDS region by LDS-DMA: 8 nmt wave-instructions of 1 KiB (two rows each), nmt per
 // wave; lane i of an instruction lands at +16 i, so the swizzle is applied on the global side.
@@ -231,7 +252,8 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   const int co = cb * 64 + tp * 32 + g * 8;
   float* xr0 = a.x32 + (size_t)(row0 + l15) * 256 + co;
   float4 r0[NMT], r1[NMT];
-  lf_first<P, 2>(c2, L.w2b + fo0, L.w2b + fo1);
+  constexpr bool EARLY_W2 = NMT < 8;                              // (128-token passes are a few registers short: they fetch them after the GELU)
+  if constexpr (EARLY_W2) lf_first<P, 2>(c2, L.w2b + fo0, L.w2b + fo1);
   f32x4 b22[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) b22[u] = *reinterpret_cast<const f32x4*>(a.b2 + co + u * 4);
@@ -295,10 +317,12 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
       }
     }
   }
+  if constexpr (!EARLY_W2) lf_first<P, 2>(c2, L.w2b + fo0, L.w2b + fo1);
   __syncthreads();
 
   // ---- x += W2 h + b2
-  uint4 xpk[NMT];
+  constexpr bool KEEP_X = FOLD != 0 && NMT < 8;                   // 128-token passes have no registers to spare: they re-read their x rows
+  [[maybe_unused]] uint4 xpk[KEEP_X ? NMT : 1];
   {
     f32x4 acc[2][NMT];
 #pragma unroll
@@ -315,8 +339,9 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
                     acc[1][m][0] + r1[m].x, acc[1][m][1] + r1[m].y, acc[1][m][2] + r1[m].z, acc[1][m][3] + r1[m].w};
       *reinterpret_cast<float4*>(xr) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(xr + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      xpk[m] = pack8<P>(v);
-      *reinterpret_cast<uint4*>(a.xb + row * 256 + co) = xpk[m];
+      const uint4 xp = pack8<P>(v);
+      if constexpr (KEEP_X) xpk[m] = xp;
+      *reinterpret_cast<uint4*>(a.xb + row * 256 + co) = xp;
     }
   }
   if constexpr (FOLD != 0) {
@@ -324,7 +349,12 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
     {
       const int piece = cb * 8 + tp * 4 + g;
 #pragma unroll
-      for (int m = 0; m < NMT; ++m) *reinterpret_cast<uint4*>(smem + LF_R0 + (m * 16 + l15) * 512 + ((piece ^ l15) << 4)) = xpk[m];
+      for (int m = 0; m < NMT; ++m) {
+        uint4 xp;
+        if constexpr (KEEP_X) xp = xpk[m];
+        else xp = *reinterpret_cast<const uint4*>(a.xb + (size_t)(row0 + m * 16 + l15) * 256 + co);      // this lane's own store of a moment ago
+        *reinterpret_cast<uint4*>(smem + LF_R0 + (m * 16 + l15) * 512 + ((piece ^ l15) << 4)) = xp;
+      }
     }
     __syncthreads();                                              // the new x tile [16 NMT][256] is complete in R0
     const int H = a.H, Np = a.Np;
