@@ -180,6 +180,7 @@ struct airfe_ctx {
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   int lgb_tokens = 0;            // AIRFE_LGB_TOKENS: tokens per lg_blockf workgroup (128 or 112; 0 = by token count)
   int attn_occ = 3;              // AIRFE_ATTN_OCC: attention32_kernel variant compiled for 2 (no spills) or 3 waves per SIMD
+  bool fuse_head = true;         // AIRFE_FUSE_HEAD=0: detector head as GEMM + separate soft-max / depth-to-space kernel (A/B runs)
   bool sparse_desc = true;       // AIRFE_SPARSE_DESC=0: the descriptor head over every cell at every batch size (A/B runs)
   bool desc_dense_valid = true;  // c->desc holds the dense map of the last batch (else: the gather GEMM's rows)
   int last_B = 0;
@@ -955,8 +956,14 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
       g.X1 = c->aPa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cPb.w; g.bias = c->cPb.b;
       g.M = cells; g.N = 65; g.cb_total = c->cPb.cbt; g.epi = EPI_STORE_F32; g.out = c->logits; g.ldo = 72;
       g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-      { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 288)); launch_gemm(c->prec, 256, false, g, st); }
-      { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * (260 + 256)); launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st); }
+      if (c->fuse_head) {       // soft-max + depth-to-space in the GEMM's epilogue, at EVERY batch size (one summation order): no logits in memory
+        g.epi = EPI_SOFTMAX_D2S; g.out = c->heat; g.d2s_hc = R / 8; g.d2s_wc = R / 8;
+        ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 256));
+        launch_gemm8(c->prec, 256, false, g, st);
+      } else {
+        { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 288)); launch_gemm(c->prec, 256, false, g, st); }
+        { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * (260 + 256)); launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st); }
+      }
     }
     // The descriptor head convDb (1x1, 256 -> 256) is only ever READ at the <= 4 cells each keypoint samples: large batches run it as a
     // gather GEMM over those rows after the top-K (below) — 1600 of 4096 cells per image at 400 keypoints, and 1.6 instead of 4 MB
@@ -1313,6 +1320,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
   if (getenv("AIRFE_LGB_TOKENS")) c->lgb_tokens = atoi(getenv("AIRFE_LGB_TOKENS")) == 112 ? 112 : (atoi(getenv("AIRFE_LGB_TOKENS")) == 128 ? 128 : 0);
   if (getenv("AIRFE_ATTN_OCC")) c->attn_occ = atoi(getenv("AIRFE_ATTN_OCC")) == 3 ? 3 : 2;
+  if (getenv("AIRFE_FUSE_HEAD")) c->fuse_head = atoi(getenv("AIRFE_FUSE_HEAD")) != 0;
   if (getenv("AIRFE_SPARSE_DESC")) c->sparse_desc = atoi(getenv("AIRFE_SPARSE_DESC")) != 0;
   if (getenv("AIRFE_STEREO_ONE_PASS")) c->stereo_one_pass = atoi(getenv("AIRFE_STEREO_ONE_PASS")) != 0;
   if (getenv("AIRFE_FOLD_QKV")) c->fold_qkv = atoi(getenv("AIRFE_FOLD_QKV")) != 0;

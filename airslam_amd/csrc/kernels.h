@@ -12,6 +12,8 @@ enum Epi {
   EPI_RESID = 2,      // x32[M][ldo] += bias + acc ; out = 2-byte copy of x32
   EPI_HEADS = 3,      // bias (+rotary) -> 2-byte head-major [S][H][Np][64]; feature/256 selects out/out2
   EPI_HEADS_T = 4,    // (TRANS kernels) bias -> 2-byte [S][H][64][Np]
+  EPI_SOFTMAX_D2S = 5 // gemm8 only, N = 65: bias, soft-max over the 65 logits of a row (= cell), drop the dustbin, 8x8 depth-to-space ->
+                      // fp32 score map [B][8 d2s_hc][8 d2s_wc] (the SuperPoint detector head in the GEMM's epilogue)
 };
 enum Act { ACT_NONE = 0, ACT_RELU = 1 };
 
@@ -39,6 +41,7 @@ struct GemmArgs {
   int gr_min = 8192;             // rows from which the K = 256 linears go to the streaming kernel (where it applies)
   int gr_wgs = 256;              // its persistent workgroups (tests lower it so that a small batch wraps the DMA ring)
   const int* rowidx = nullptr;   // gemm8 only: row r of the GEMM reads X1 row rowidx[r] (a gather; [M] entries)
+  int d2s_hc = 0, d2s_wc = 0;    // EPI_SOFTMAX_D2S: cells per image column / row
 };
 
 // out[M][N] = X[M][K] * W^T ; K in {128,256,512}; trans => EPI_HEADS_T (operand roles swapped)

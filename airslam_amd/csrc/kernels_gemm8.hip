@@ -93,9 +93,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs a, int K, int qu
   const uint16_t* xp2 = a.X2 ? a.X2 + (size_t)(m0 + xr) * a.ld2 + xcs : xp1;
   const size_t rstep1 = (size_t)64 * a.ld1, rstep2 = (size_t)64 * a.ld2;
   // gather form (a.rowidx): this thread's four rows come from X1 rows rowidx[m0 + xr + 64 i]
-  const uint16_t* xg[4];
+  constexpr bool GATHER = !TRANS;                        // (the transposed form has no registers to spare and no caller that gathers)
+  const uint16_t* xg[GATHER ? 4 : 1];
+  if constexpr (GATHER) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) xg[i] = a.rowidx ? a.X1 + (size_t)a.rowidx[m0 + xr + 64 * i] * a.ld1 + xcs : xp1 + i * rstep1;
+    for (int i = 0; i < 4; ++i) xg[i] = a.rowidx ? a.X1 + (size_t)a.rowidx[m0 + xr + 64 * i] * a.ld1 + xcs : xp1 + i * rstep1;
+  }
   const char* wbase = reinterpret_cast<const char*>(a.Wp) + (size_t)tid * 16;
 
   auto dma = [&](int it) {
@@ -105,7 +108,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs a, int K, int qu
     const size_t rs = first ? rstep1 : rstep2;
     const unsigned dst = lds_base + (it & 1) * G8_STAGE + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) g8_glds16(first ? xg[i] + k0 : src + i * rs, dst + i * 8192);
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (GATHER) g8_glds16(first ? xg[i] + k0 : src + i * rs, dst + i * 8192);
+      else g8_glds16(src + i * rs, dst + i * 8192);
+    }
     const char* w0 = wbase + ((size_t)(4 * qd) * NS + s) * SLAB_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) g8_glds16(w0 + (size_t)i * NS * SLAB_BYTES, dst + 32768 + i * 8192);
@@ -160,7 +166,53 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs a, int K, int qu
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk it+1 has landed (and last iteration's stores retired)
     __syncthreads();
-    if (s == NS - 1) {
+    if (!TRANS && s == NS - 1 && a.epi == EPI_SOFTMAX_D2S) {
+      // The detector head in the epilogue: a row is a cell, its 65 logits are features 0..63 (this wave's first four tiles: lane (l15, g)
+      // holds 8 tp + .. of them, tp = 0, 1) and the dustbin, feature 64 (fifth tile, lane g = 0, element 0).  Soft-max across the four g
+      // lanes of the row, then each lane writes its two 8-pixel runs of the cell's 8x8 block (dy = 4 tp + g).  The logits never exist
+      // in memory (0.6 KB per cell written and read back by the separate kernel).
+      if (wn == 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int row = m0 + wm * 64 + m * 16 + l15;
+          float v[2][8];
+#pragma unroll
+          for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[tp][e] = acc[m][2 * tp][e] + a.bias[tp * 32 + g * 8 + e];
+              v[tp][4 + e] = acc[m][2 * tp + 1][e] + a.bias[tp * 32 + g * 8 + 4 + e];
+            }
+          const float dust = (g == 0) ? acc[m][4][0] + a.bias[64] : -INFINITY;
+          float mx = dust;
+#pragma unroll
+          for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[tp][e]);
+          mx = fmaxf(mx, __shfl_xor(mx, 16));
+          mx = fmaxf(mx, __shfl_xor(mx, 32));
+          float sum = expf(dust - mx);                        // exp(-inf) = 0 on the lanes that do not hold the dustbin
+#pragma unroll
+          for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[tp][e] = expf(v[tp][e] - mx);
+              sum += v[tp][e];
+            }
+          sum += __shfl_xor(sum, 16);
+          sum += __shfl_xor(sum, 32);
+          const float inv = 1.0f / sum;
+          const int per = a.d2s_hc * a.d2s_wc, b = row / per, rem = row - b * per, cy = rem / a.d2s_wc, cx = rem - cy * a.d2s_wc;
+          float* o = reinterpret_cast<float*>(a.out) + ((size_t)b * a.d2s_hc * 8 + (size_t)cy * 8) * (a.d2s_wc * 8) + cx * 8;
+#pragma unroll
+          for (int tp = 0; tp < 2; ++tp) {
+            float* r = o + (size_t)(tp * 4 + g) * (a.d2s_wc * 8);
+            *reinterpret_cast<float4*>(r) = make_float4(v[tp][0] * inv, v[tp][1] * inv, v[tp][2] * inv, v[tp][3] * inv);
+            *reinterpret_cast<float4*>(r + 4) = make_float4(v[tp][4] * inv, v[tp][5] * inv, v[tp][6] * inv, v[tp][7] * inv);
+          }
+        }
+      }
+    } else if (s == NS - 1) {
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         const int cb = 4 * (quad0 + it / NS) + wn * 2 + hb;

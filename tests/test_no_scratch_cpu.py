@@ -1,4 +1,5 @@
-"""Build-time guard: the hot kernels must not touch scratch memory.  A register array that hipcc cannot keep in registers (a pointer
+"""Build-time guard: the hot kernels must not touch scratch memory.  (gemm8_kernel is deliberately absent: it spills ~20 loop-invariant
+epilogue pointers once per workgroup in its prologue and reloads each once — outside the K loop, not a cost.)  A register array that hipcc cannot keep in registers (a pointer
 select between two accumulator arrays, a spill at the occupancy bound) silently moves to scratch and the kernel runs 3-8x slower with
 every parity test still green — it happened twice in round 2 (attention32_kernel: 46 -> 123 us with 45 spilled registers; later a
 masked-tail if/else put both score accumulators into 192 B of scratch per lane: 41 -> 330 us)."""
