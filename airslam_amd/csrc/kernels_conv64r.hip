@@ -50,6 +50,9 @@ constexpr bool SCHED = C64R_SCHED;
 #ifndef C64R_RW
 #define C64R_RW 4
 #endif
+#ifndef C64R_SPLIT_PROD
+#define C64R_SPLIT_PROD 1
+#endif
 constexpr int C64R_PATCH = 20 * 20;                // fused conv1a: fp32 image patch per tile (halo 2)
 constexpr int C64R_CONST_OFF = 2 * C64R_TILE_STRIDE + 3 * C64R_PATCH * 4;   // conv1a A fragments (4 KiB) + bias (256 B)
 
@@ -300,6 +303,18 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
       if (SCHED) __builtin_amdgcn_sched_group_barrier(0x100, RW + 2, 0);
     }
     C64R_T(t_top)
+    // conv1a of the NEXT tile (its patch landed an iteration ago) is vector work + 4 small MFMAs per group.  The two waves of a SIMD are
+    // served oldest first by the matrix pipe: the YOUNGER half of the waves produces its groups HERE, while it would wait for the pipe
+    // anyway, the OLDER half after its MFMAs, while the younger half still runs its own (before: spread over the combos of every wave;
+    // per-wave timers then: combos 669 vs 927 us per launch, barrier wait 324 vs 24 us — the younger waves' production sat in the
+    // tail where they run alone).
+    constexpr bool SPLIT_PROD = FUSE1A && C64R_SPLIT_PROD;
+    if constexpr (SPLIT_PROD) {
+      if (wave >= 16 / RW) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) prod_finish(j, prod_load(j, pb1), nty, ntx, (i + 1) & 1);
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       if constexpr (PIN) {
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
       }
       [[maybe_unused]] Taps taps{};
       constexpr int PG = 6 / NG;                               // one conv1a group every PG combos
-      const bool prod_here = FUSE1A && c % PG == 0;
+      const bool prod_here = FUSE1A && !SPLIT_PROD && c % PG == 0;
       if constexpr (FUSE1A) { if (prod_here) taps = prod_load(c / PG, pb1); }   // conv1a of the NEXT tile, group c (its patch landed an iteration ago)
       const int dx = c >> 1, ks = c & 1;
 #pragma unroll
@@ -334,6 +349,12 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
         }
         if (prod_here) __builtin_amdgcn_sched_group_barrier(0x008, 6 * RW - 4 * (RW + 2) + 4, 0);
         else __builtin_amdgcn_sched_group_barrier(0x008, 6 * RW - 4 * (RW + 2), 0);
+      }
+    }
+    if constexpr (SPLIT_PROD) {
+      if (wave < 16 / RW) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) prod_finish(j, prod_load(j, pb1), nty, ntx, (i + 1) & 1);
       }
     }
 

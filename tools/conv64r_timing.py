@@ -9,7 +9,7 @@ sys.path.insert(0, os.getcwd())
 subprocess.check_call(["cp", "airslam_amd/libairfe_T.so.tmp", "airslam_amd/libairfe.so"])
 import torch
 from airslam_amd import api, synth, weights, _lib
-ctx = api.Context(superpoint=weights.synthetic_superpoint(1234), max_batch=64, enc_chunk=32)
+ctx = api.Context(superpoint=weights.synthetic_superpoint(1234), max_batch=64, enc_chunk=64)
 ls, rs = synth.stereo_batch(4, 480, 752, 3)
 imgs = torch.from_numpy(np.tile(ls, (16, 1, 1))).cuda()
 feat = torch.zeros((64, 400, 259), device="cuda"); n = torch.zeros((64,), dtype=torch.int32, device="cuda")
