@@ -188,12 +188,12 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
     }
   }
   struct Taps { float q0, q1, q2; };
-  auto prod_load = [&](int j, int buf) {
-    const float* q = reinterpret_cast<const float*>(smem + 2 * C64R_TILE_STRIDE + buf * (C64R_PATCH * 4) + prd[j]);
+  auto prod_load_at = [&](int prd_j, int buf) {
+    const float* q = reinterpret_cast<const float*>(smem + 2 * C64R_TILE_STRIDE + buf * (C64R_PATCH * 4) + prd_j);
     return Taps{q[0], q[1], q[2]};
   };
-  auto prod_finish = [&](int j, const Taps& tp3, int ty, int tx, int xbuf) {
-    const int gy = ty * 16 - 1 + (pyx[j] >> 8), gx = tx * 16 - 1 + (pyx[j] & 255);
+  auto prod_finish_at = [&](int pwr_j, int pyx_j, const Taps& tp3, int ty, int tx, int xbuf) {
+    const int gy = ty * 16 - 1 + (pyx_j >> 8), gx = tx * 16 - 1 + (pyx_j & 255);
     const float m = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? 1.f : 0.f;
     const bool taps = g < 3;
     f16x8 bfr;
@@ -217,9 +217,11 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
         v[e] = c1[2 * tp][e];
         v[4 + e] = c1[2 * tp + 1][e];
       }
-      *reinterpret_cast<uint4*>(smem + xbuf * C64R_TILE_STRIDE + (pwr[j] ^ (tp << 6))) = relu_packed(pack8<P>(v));
+      *reinterpret_cast<uint4*>(smem + xbuf * C64R_TILE_STRIDE + (pwr_j ^ (tp << 6))) = relu_packed(pack8<P>(v));
     }
   };
+  auto prod_load = [&](int j, int buf) { return prod_load_at(prd[j], buf); };
+  auto prod_finish = [&](int j, const Taps& tp3, int ty, int tx, int xbuf) { prod_finish_at(pwr[j], pyx[j], tp3, ty, tx, xbuf); };
   auto tile_xy = [&](int t, int& ty, int& tx) {
     int b_;
     tile_decode(t, per_img, tiles_x, sh_img, sh_x, b_, ty, tx);
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
     // served oldest first by the matrix pipe: the YOUNGER half of the waves produces its groups HERE, while it would wait for the pipe
     // anyway, the OLDER half after its MFMAs, while the younger half still runs its own (before: spread over the combos of every wave;
     // per-wave timers then: combos 669 vs 927 us per launch, barrier wait 324 vs 24 us — the younger waves' production sat in the
-    // tail where they run alone).
+    // tail where they run alone).  (The older half producing ALL groups after its MFMAs measured 11 % slower: it becomes the critical path.)
     constexpr bool SPLIT_PROD = FUSE1A && C64R_SPLIT_PROD;
     if constexpr (SPLIT_PROD) {
       if (wave >= 16 / RW) {
