@@ -213,6 +213,17 @@ def synthetic_plnet_s0(seed: int = 1234) -> Dict[str, np.ndarray]:
     w.update(synthetic(plnet_line_spec(), seed + 40))
     # junction logits: a clear "no junction" prior so that the probability map is peaky, like a trained head's
     w["line.head.bias"][128 + 5] = 2.0
+    # Structured like the matchers' weights, so that the path DOWNSTREAM of the line branch carries lines (a plain draw gives the REAL
+    # stage-1 head, tests/golden/plnet_s1.airfe, features of std 0.7 it has never seen: every one of the ~1100 candidate lines scores
+    # < 0.5 and 1 line survives; the head is confident around features of std <= 0.15 — tools/plnet_s0_calibrate.py):
+    #   * LOI / thin / aux feature channels scaled by 0.2: 92 % of the candidates score > 0.5, 36 % pass the reference's 0.75;
+    #   * md1 / md2 (the two half-angles of the HAFM decoding) biased by +1: proposals half as long again, median final line 50 px,
+    #     51 % pass the 50-px length threshold.  ~240 lines per synthetic frame survive both filters (EuRoC frames: 100-300).
+    for sl in (slice(0, 128), slice(137, 145)):
+        w["line.head.weight"][sl] *= np.float32(0.2)
+        w["line.head.bias"][sl] *= np.float32(0.2)
+    w["line.head.bias"][128 + 1] = 1.0
+    w["line.head.bias"][128 + 2] = 1.0
     return w
 
 

@@ -81,10 +81,10 @@ def side_workloads(args, rank, world, local, dev):
 
     if args.detector == "plnet":
         root = os.path.dirname(os.path.abspath(__file__))
+        pairs = [synth.stereo_pair(H, W, 1000 + rank * 64 + i) for i in range(min(B, 8))]
         ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(root, "tests", "golden", "plnet_s1.airfe"),
                           **dict(cfg, max_batch=2, enc_chunk=2), **mkw)
         det, pm = api.FeatureDetector(ctx), api.PointMatcher(ctx, W, H, 1 if sg else 0)
-        pairs = [synth.stereo_pair(H, W, 1000 + rank * 64 + i) for i in range(min(B, 8))]
         lines_n = [0]
 
         def step():
