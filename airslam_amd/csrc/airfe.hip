@@ -180,6 +180,7 @@ struct airfe_ctx {
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   int lgb_tokens = 0;            // AIRFE_LGB_TOKENS: tokens per lg_blockf workgroup (128 or 112; 0 = by token count)
   int attn_occ = 3;              // AIRFE_ATTN_OCC: attention32_kernel variant compiled for 2 (no spills) or 3 waves per SIMD
+  int sg_kenc_gemm = -1;         // AIRFE_SG_KENC_GEMM=0/1: SuperGlue keypoint encoder's large layers as scalar loops / GEMMs (default: by token count)
   bool fuse_head = true;         // AIRFE_FUSE_HEAD=0: detector head as GEMM + separate soft-max / depth-to-space kernel (A/B runs)
   bool sparse_desc = true;       // AIRFE_SPARSE_DESC=0: the descriptor head over every cell at every batch size (A/B runs)
   bool desc_dense_valid = true;  // c->desc holds the dense map of the last batch (else: the gather GEMM's rows)
@@ -240,6 +241,7 @@ struct airfe_ctx {
   LinW sg_final;
   float sg_alpha = 1.f;
   const float* sg_kenc[10] = {nullptr};
+  LinW sg_k3, sg_k4;             // keypoint-encoder layers 3 (128 -> 256) and 4 (256 -> 256) for the GEMM path
   int Lz = 0;
   float *sg_u = nullptr, *sg_v = nullptr, *sg_Z = nullptr, *sg_max0 = nullptr, *sg_ms0 = nullptr, *sg_ms1 = nullptr;
   int *sg_idx0 = nullptr, *sg_idx1 = nullptr;
@@ -686,6 +688,9 @@ int load_superglue(airfe_ctx* c, const char* path) {
     c->sg_kenc[2 * i] = upload_transposed(c, *w, enc[i + 1], enc[i]);
     c->sg_kenc[2 * i + 1] = dupload(c, b->data);
   }
+  // the two large layers also as packed MFMA operands (large batches: launch_sg_prepare with h128, then two GEMMs)
+  if (!make_linear_named(c, p, "kenc.encoder.3", 128, 256, c->sg_k3, err) || !make_linear_named(c, p, "kenc.encoder.4", 256, 256, c->sg_k4, err))
+    return fail(c, err.empty() ? "kenc: packing failed" : err);
   // MultiHeadedAttention views channels as (dim, heads): channel = d*4 + h  ->  our head-major h*64 + d
   std::function<int(int)> hm = [](int f) { return (f & 63) * 4 + (f >> 6); };
   c->sg.resize(L);
@@ -1170,8 +1175,18 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   const int Mg = (M + 127) / 128 * 128;
   const float cx = (float)(c->cfg.image_width / 2), cy = (float)(c->cfg.image_height / 2);
   const float linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.7f);   // point_matcher.cc:58
+  // keypoint encoder: from block_min tokens on, its two large layers (98 of 108 kFLOP per keypoint) run as MFMA GEMMs
+  const bool kenc_gemm = c->sg_kenc_gemm == 1 || (c->sg_kenc_gemm < 0 && Mg >= c->block_min);
   launch_sg_prepare(c->mprec, f0, f1, n0, n1, AIRFE_FEAT_DIM, normalize, cx, cy, linv, c->sg_kenc, B, cap, Np, c->x32, c->xb,
-                    c->lens, st);
+                    c->lens, kenc_gemm ? c->msg : nullptr, st);
+  if (kenc_gemm) {
+    if (Mg > M) {          // the surplus rows of the 128-row rounding: zero inputs, so that the residual add leaves x = b4-ish garbage, not a running sum
+      HIPCHK(c, hipMemsetAsync(c->msg + (size_t)M * 128, 0, (size_t)(Mg - M) * 128 * 2, st));
+      HIPCHK(c, hipMemsetAsync(c->x32 + (size_t)M * 256, 0, (size_t)(Mg - M) * 256 * 4, st));
+    }
+    run_linear(c, c->sg_k3, c->msg, 128, 128, nullptr, 0, Mg, EPI_STORE, ACT_RELU, c->hb, 256, st);
+    run_linear(c, c->sg_k4, c->hb, 256, 256, nullptr, 0, Mg, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
+  }
   const bool fused_block = c->fuse_lg_block == 1 || (c->fuse_lg_block < 0 && Mg >= c->block_min);
   int li = 0;
   for (const SgLayer& l : c->sg) {
@@ -1320,6 +1335,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
   if (getenv("AIRFE_LGB_TOKENS")) c->lgb_tokens = atoi(getenv("AIRFE_LGB_TOKENS")) == 112 ? 112 : (atoi(getenv("AIRFE_LGB_TOKENS")) == 128 ? 128 : 0);
   if (getenv("AIRFE_ATTN_OCC")) c->attn_occ = atoi(getenv("AIRFE_ATTN_OCC")) == 3 ? 3 : 2;
+  if (getenv("AIRFE_SG_KENC_GEMM")) c->sg_kenc_gemm = atoi(getenv("AIRFE_SG_KENC_GEMM")) != 0;
   if (getenv("AIRFE_FUSE_HEAD")) c->fuse_head = atoi(getenv("AIRFE_FUSE_HEAD")) != 0;
   if (getenv("AIRFE_SPARSE_DESC")) c->sparse_desc = atoi(getenv("AIRFE_SPARSE_DESC")) != 0;
   if (getenv("AIRFE_STEREO_ONE_PASS")) c->stereo_one_pass = atoi(getenv("AIRFE_STEREO_ONE_PASS")) != 0;

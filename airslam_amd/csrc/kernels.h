@@ -224,10 +224,11 @@ void launch_s0_j2l(const float* lines_pred, const float* juncs, int jn, int n, f
                    hipStream_t st);
 
 // ---- SuperGlue ----------------------------------------------------------------------------------------------
+// h128 != nullptr: only the first three layers run (-> h128 [S*Np][128] 2-byte, x = descriptor); the caller adds the last two as GEMMs
 // w: 10 device pointers {W0t[3][32], b0, W1t[32][64], b1, W2t[64][128], b2, W3t[128][256], b3, W4t[256][256], b4}
 void launch_sg_prepare(int prec, const float* f0, const float* f1, const int* n0, const int* n1, int ld, int normalize,
                        float cx, float cy, float linv, const float* const* w, int B, int cap, int Np, float* x32,
-                       uint16_t* xb, int* lens, hipStream_t st);
+                       uint16_t* xb, int* lens, uint16_t* h128, hipStream_t st);
 // u, v: [B][Lz]; Z: [B][Lz][Lz] log-assignment incl. dustbins (rows 0..n0, cols 0..n1)
 // counters: B * 16 unsigned of scratch (one 64-byte line per pair) for the fused kernel's per-pair rendezvous; nullptr = the launch-per-half-iteration form
 // xch: B * 64 * Lz floats of scratch (the register-resident kernel's per-iteration exchange of column partials); nullptr = streaming kernels only

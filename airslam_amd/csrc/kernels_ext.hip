@@ -311,9 +311,13 @@ struct SgPrepArgs {
   const float* w[10];   // w0t,b0,...,w4t,b4
   int B, cap, Np;
   float* x32; uint16_t* xb; int* lens;
+  uint16_t* h128;       // SPLIT: [S * Np][128] 2-byte output of the third layer
 };
 
-template <class P>
+// SPLIT: only the three small layers (3 -> 32 -> 64 -> 128: 10 of the 108 kFLOP per keypoint) run here; the kernel writes the 128
+// hidden features (2-byte) and x = the descriptor, and the two large layers (128 -> 256 + ReLU, 256 -> 256 added to x) follow as MFMA
+// GEMMs (airfe.hip).  As scalar FMA loops all five layers took 0.29 ms per 51200 keypoints, latency-bound on LDS broadcast reads.
+template <class P, bool SPLIT>
 __global__ __launch_bounds__(256) void sg_prepare_kernel(SgPrepArgs a) {
   __shared__ float bufa[KE_LT][256], bufb[KE_LT][256];
   const int s = blockIdx.y, n0r = blockIdx.x * KE_LT, tid = threadIdx.x;
@@ -341,6 +345,18 @@ __global__ __launch_bounds__(256) void sg_prepare_kernel(SgPrepArgs a) {
   __syncthreads();
   ke_layer<64, 128>(a.w[4], a.w[5], &bufa[0][0], 256, &bufb[0][0], 256, true);
   __syncthreads();
+  if constexpr (SPLIT) {
+    for (int l = 0; l < KE_LT; ++l) {
+      const int n = n0r + l;
+      if (n >= a.Np) break;
+      const size_t row = (size_t)s * a.Np + n;
+      const float v = (n < len) ? fbase[(size_t)n * a.ld + 3 + tid] : 0.f;
+      a.x32[row * 256 + tid] = v;
+      a.xb[row * 256 + tid] = P::from_f32(v);
+      if (tid < 128) a.h128[row * 128 + tid] = P::from_f32(n < len ? bufb[l][tid] : 0.f);
+    }
+    return;
+  }
   ke_layer<128, 256>(a.w[6], a.w[7], &bufb[0][0], 256, &bufa[0][0], 256, true);
   __syncthreads();
   ke_layer<256, 256>(a.w[8], a.w[9], &bufa[0][0], 256, &bufb[0][0], 256, false);
@@ -358,14 +374,19 @@ __global__ __launch_bounds__(256) void sg_prepare_kernel(SgPrepArgs a) {
 
 void launch_sg_prepare(int prec, const float* f0, const float* f1, const int* n0, const int* n1, int ld, int normalize,
                        float cx, float cy, float linv, const float* const* w, int B, int cap, int Np, float* x32,
-                       uint16_t* xb, int* lens, hipStream_t st) {
+                       uint16_t* xb, int* lens, uint16_t* h128, hipStream_t st) {
   SgPrepArgs a;
   a.f0 = f0; a.f1 = f1; a.n0 = n0; a.n1 = n1; a.ld = ld; a.normalize = normalize; a.cx = cx; a.cy = cy; a.linv = linv;
   for (int i = 0; i < 10; ++i) a.w[i] = w[i];
-  a.B = B; a.cap = cap; a.Np = Np; a.x32 = x32; a.xb = xb; a.lens = lens;
+  a.B = B; a.cap = cap; a.Np = Np; a.x32 = x32; a.xb = xb; a.lens = lens; a.h128 = h128;
   dim3 grid((Np + KE_LT - 1) / KE_LT, 2 * B);
-  if (prec == 1) hipLaunchKernelGGL(sg_prepare_kernel<PF16>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(sg_prepare_kernel<PBF16>, grid, dim3(256), 0, st, a);
+  if (h128) {
+    if (prec == 1) hipLaunchKernelGGL((sg_prepare_kernel<PF16, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((sg_prepare_kernel<PBF16, true>), grid, dim3(256), 0, st, a);
+  } else {
+    if (prec == 1) hipLaunchKernelGGL((sg_prepare_kernel<PF16, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((sg_prepare_kernel<PBF16, false>), grid, dim3(256), 0, st, a);
+  }
 }
 
 // =============================================================================== SuperGlue: Sinkhorn

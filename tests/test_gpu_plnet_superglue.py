@@ -120,6 +120,7 @@ def _check_superglue(name, ctx, w, f0, f1, layers, iters, tol, min_valid):
 def test_superglue_vs_oracle(n0, n1, layers, iters, min_valid, fused, monkeypatch):
     # fused = the propagation block (merge, mlp.0 + ReLU, mlp.3, residual) as the one-kernel form large batches use
     monkeypatch.setenv("AIRFE_FUSE_LG_BLOCK", str(fused))
+    monkeypatch.setenv("AIRFE_SG_KENC_GEMM", str(fused))       # ... and the keypoint encoder's large layers as GEMMs (the large-batch form)
     w = weights.synthetic_superglue(1234, n_layers=layers)
     ctx = api.Context(superglue=w, matcher=1, max_batch=2, sinkhorn_iters=iters)
     _, _, f0, f1 = _sg_pair(n0, n1, n0 * 3 + n1)
