@@ -316,39 +316,49 @@ void launch_rowdot256(const float* x32, const float* w, float b, float* z, int M
 }
 
 // =============================================================================== similarity
-// sim[b][i][j] = md[2b][i] . md[2b+1][j], K = 256; each wave a 16 x 64 tile, fragments straight from L2.
+// sim[b][i][j] = md[2b][i] . md[2b+1][j], K = 256; each wave a 64 x 64 tile, fragments straight from L2: 64 KB of operands per 128
+// MFMAs (the first version's 16 x 64 tiles read 40 KB per 32 MFMAs — 7 MB per pair for 400 KB of data, 60 us per 64 pairs).
+// Same K order per output as before: same bits.
 template <class P>
 __global__ __launch_bounds__(256) void sim_kernel(const uint16_t* __restrict__ md, float* __restrict__ sim, int Np) {
   const int b = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
-  const int i0 = (blockIdx.x * 4 + wave) * 16, j0 = blockIdx.y * 64;
+  const int i0 = (blockIdx.x * 4 + wave) * 64, j0 = blockIdx.y * 64;
   if (i0 >= Np) return;
   const uint16_t* A = md + ((size_t)(2 * b) * Np + i0 + l15) * 256;
   const uint16_t* Bm = md + ((size_t)(2 * b + 1) * Np + j0 + l15) * 256;
-  f32x4 acc[4];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt) acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) acc[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
-    const uint4 ua = *reinterpret_cast<const uint4*>(A + ks * 32 + g * 8);
-    const typename P::vec8 af = __builtin_bit_cast(typename P::vec8, ua);
+    typename P::vec8 af[4], bf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                        // Np is a multiple of 16, not of 64: whole 16-row / 16-column sub-tiles drop out
+      af[t] = (i0 + t * 16 < Np) ? __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(A + (size_t)t * 16 * 256 + ks * 32 + g * 8)) : typename P::vec8{};
+      bf[t] = (j0 + t * 16 < Np) ? __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(Bm + (size_t)t * 16 * 256 + ks * 32 + g * 8)) : typename P::vec8{};
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) acc[it][jt] = P::mfma(af[it], bf[jt], acc[it][jt]);
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    if (i0 + it * 16 >= Np) continue;
+    float* out = sim + ((size_t)b * Np + i0 + it * 16) * Np + j0;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
-      if (j0 + jt * 16 >= Np) continue;                 // Np is a multiple of 16, not of 64: whole column tiles drop out
-      const uint4 ub = *reinterpret_cast<const uint4*>(Bm + (size_t)jt * 16 * 256 + ks * 32 + g * 8);
-      acc[jt] = P::mfma(af, __builtin_bit_cast(typename P::vec8, ub), acc[jt]);
+      if (j0 + jt * 16 >= Np) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(size_t)(g * 4 + r) * Np + jt * 16 + l15] = acc[it][jt][r];
     }
-  }
-  float* out = sim + ((size_t)b * Np + i0) * Np + j0;
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    if (j0 + jt * 16 >= Np) continue;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[(size_t)(g * 4 + r) * Np + jt * 16 + l15] = acc[jt][r];
   }
 }
 
 void launch_sim(int prec, const uint16_t* md, float* sim, int B, int Np, hipStream_t st) {
-  dim3 grid((Np / 16 + 3) / 4, (Np + 63) / 64, B);
+  dim3 grid((Np + 255) / 256, (Np + 63) / 64, B);
   if (prec == 1) hipLaunchKernelGGL(sim_kernel<PF16>, grid, dim3(256), 0, st, md, sim, Np);
   else hipLaunchKernelGGL(sim_kernel<PBF16>, grid, dim3(256), 0, st, md, sim, Np);
 }
