@@ -1,0 +1,46 @@
+"""bench.py prints ONE JSON line with the driver's contract (metric / value / unit / n_gpus / steps / warmup / ms_per_step / dtype / config /
+roofline / cpu_baseline): a small run of every workload switch, so that a change to the engine cannot silently break the line the
+driver parses."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_workload_line():
+    d = _run("--pairs", "8", "--steps", "3", "--warmup", "1", "--cpu-pairs", "2")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "fp16"
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["matches_mean"] > 50
+    rf = d["roofline"]
+    assert rf["bound"] in ("mfma", "hbm") and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert 0.0 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["traffic"] is None or rf["traffic"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "pairs/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+
+
+@pytest.mark.parametrize("args", [("--matcher", "superglue", "--pairs", "4"), ("--detector", "plnet", "--pairs", "2"),
+                                  ("--workload", "loop", "--pairs", "8")], ids=["superglue", "plnet", "loop"])
+def test_side_workload_lines(args):
+    d = _run(*args, "--steps", "2", "--warmup", "1", "--cpu-pairs", "0")
+    assert d["unit"] == "pairs/s" and d["value"] > 0 and d["steps"] == 2 and "workload" in d["config"]
+    if "plnet" in args:
+        assert d["config"]["lines_last_frame"] >= 50          # the structured synthetic line head: lines survive the reference's thresholds
