@@ -759,14 +759,14 @@ int load_plnet_s1(airfe_ctx* c, const char* path) {
   c->wf_keep = dalloc<int>(c, KEEP_CAP);
   c->wf_pairs = dalloc<int>(c, (size_t)LINE_CAP * 2);
   c->wf_rep = dalloc<int>(c, LINE_CAP);
-  c->wf_counts = dalloc<int>(c, 2);
+  c->wf_counts = dalloc<int>(c, 2 + 48);      // M1, M2, then the per-workgroup counts of wf_count_kernel
   c->s1_la = dalloc<float>(c, (size_t)LINE_CAP * 4);
   c->s1_sc = dalloc<float>(c, LINE_CAP);
   c->s0_stage = dalloc<float>(c, 600 + (size_t)KEEP_CAP * 7 + 128 * 128 * 128 + 2 * 4 * 128 * 128);
   c->jmap = dalloc<unsigned char>(c, (size_t)AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE);
   c->d_lines = dalloc<double>(c, (size_t)LINE_CAP * 4);
   c->d_nlines = dalloc<int>(c, 1);
-  c->d_njunc = dalloc<int>(c, 2);                  // [0] junctions kept (<= JUNC_CAP), [1] junctions found
+  c->d_njunc = dalloc<int>(c, 2 + 64);             // [0] junctions kept (<= JUNC_CAP), [1] junctions found, [2..] per-workgroup counts of the scan
   c->junc_feat = dalloc<float>(c, (size_t)JUNC_CAP * AIRFE_FEAT_DIM);
   for (int i = 0; i < 11; ++i) if (!c->s1_w[i]) return fail(c, "device allocation failed (plnet_s1 weights)");
   if (!c->wf_table || !c->wf_keep || !c->wf_pairs || !c->wf_rep || !c->wf_counts || !c->s1_la || !c->s1_sc || !c->s0_stage ||
@@ -1776,7 +1776,7 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
   HIPCHK(c, hipMemcpyAsync(&nl, c->d_nlines, 4, hipMemcpyDeviceToHost, st));
   if (want_junctions) {
     const float* hsel = c->cfg.nms_radius > 0 ? c->heat_nms : c->heat;
-    launch_junction_scan(c->jmap, hsel, R, c->cfg.remove_borders, c->junc_feat, JUNC_CAP, c->d_njunc, st);
+    launch_junction_scan(c->jmap, hsel, R, c->cfg.remove_borders, c->junc_feat, JUNC_CAP, c->d_njunc, c->d_njunc + 2, st);
     launch_sample_desc(c->desc, 1, R / 8, R / 8, c->junc_feat, c->d_njunc, JUNC_CAP, ws, hs, c->desc_normalised ? 0 : 1, st);
     HIPCHK(c, hipMemcpyAsync(njf, c->d_njunc, 8, hipMemcpyDeviceToHost, st));
   }

@@ -188,7 +188,7 @@ void launch_line_filter(const float* la, const float* sc, const int* counts, int
                         float w_scale, float h_scale, int R, unsigned char* jmap, double* lines_out, int capL, int* nlines,
                         hipStream_t st);
 void launch_junction_scan(const unsigned char* jmap, const float* heat, int R, int border, float* feat, int cap, int* n_out,
-                          hipStream_t st);
+                          int* wg_counts /* 64 ints of scratch */, hipStream_t st);
 
 // ---- fp32 correctness path (kernels_f32.hip; cfg.precision = 2): fp32 storage, f32-input MFMA, plain kernels
 struct GemmF32Args {

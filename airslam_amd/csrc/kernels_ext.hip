@@ -34,47 +34,97 @@ __device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* w
 // src/plnet.cpp:272-307 on the device.  keep = raster-ordered indices with iskeep > 0; unique (min,max) junction pairs
 // get ids in FIRST-SEEN order; rep[u] = position (in keep) of the first proposal of unique line u — which is also the
 // `perm` the stage-1 graph rebuilds with its reversed ScatterElements (oracle/onnx_run.py).
-__global__ __launch_bounds__(1024) void wireframe_kernel(const float* __restrict__ iskeep, const float* __restrict__ imin,
-                                                         const float* __restrict__ imax, int n, int jn, int* table,
-                                                         int* __restrict__ keep, int* __restrict__ pairs,
-                                                         int* __restrict__ rep, int cap, int* __restrict__ counts) {
-  __shared__ unsigned wsum[16];
-  const int tid = threadIdx.x;
-  const int per = (n + 1023) / 1024;
-  const int lo = tid * per, hi = min(lo + per, n);
-  unsigned cnt = 0;
-  for (int i = lo; i < hi; ++i) cnt += iskeep[i] > 0.f;
-  unsigned m1;
-  unsigned off = block_excl_scan_1024(cnt, wsum, &m1);
-  for (int i = lo; i < hi; ++i)
-    if (iskeep[i] > 0.f) { if (off < (unsigned)cap) keep[off] = i; ++off; }
-  m1 = min(m1, (unsigned)cap);
+// Three launches: the raster-ordered list of kept proposals is built by WF_WGS workgroups (count, then emit at the prefix of the counts
+// — ONE workgroup walking the 49152-entry map was latency-bound at 47 us per frame), the unique pairs by one workgroup over that list.
+constexpr int WF_WGS = 48;
+
+__global__ __launch_bounds__(256) void wf_count_kernel(const float* __restrict__ iskeep, int n, int* __restrict__ wg_counts) {
+  __shared__ int wsum[4];
+  const int per_wg = (n + WF_WGS - 1) / WF_WGS, lo = blockIdx.x * per_wg, hi = min(lo + per_wg, n);
+  int cnt = 0;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) cnt += iskeep[i] > 0.f;
+  cnt = (int)wave_sum((float)cnt);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
   __syncthreads();
+  if (threadIdx.x == 0) wg_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void wf_emit_kernel(const float* __restrict__ iskeep, int n, const int* __restrict__ wg_counts,
+                                                      int* __restrict__ keep, int cap) {
+  __shared__ int wcnt[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int per_wg = (n + WF_WGS - 1) / WF_WGS, lo = blockIdx.x * per_wg, hi = min(lo + per_wg, n);
+  int base = 0;
+  for (int w = 0; w < (int)blockIdx.x; ++w) base += wg_counts[w];
+  // every wave owns a contiguous quarter of the workgroup's run and walks it 64 at a time: positions by ballot + popcount
+  const int seg = (hi - lo + 3) / 4, s_lo = lo + wv * seg, s_hi = min(s_lo + seg, hi);
+  int wc = 0;
+  for (int b0 = s_lo; b0 < s_hi; b0 += 64) {
+    const int i = b0 + lane;
+    wc += __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < s_hi && iskeep[i] > 0.f));
+  }
+  if (lane == 0) wcnt[wv] = wc;
+  __syncthreads();
+  int off = base;
+  for (int w = 0; w < wv; ++w) off += wcnt[w];
+  for (int b0 = s_lo; b0 < s_hi; b0 += 64) {
+    const int i = b0 + lane;
+    const bool k = i < s_hi && iskeep[i] > 0.f;
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(k);
+    if (k) {
+      const int pos = off + __builtin_popcountll(mk & ((1ull << lane) - 1ull));
+      if (pos < cap) keep[pos] = i;
+    }
+    off += __builtin_popcountll(mk);
+  }
+}
+
+__global__ __launch_bounds__(1024) void wireframe_kernel(const float* __restrict__ imin, const float* __restrict__ imax, int jn, int* table,
+                                                         const int* __restrict__ wg_counts, const int* __restrict__ keep,
+                                                         int* __restrict__ pairs, int* __restrict__ rep, int cap, int* __restrict__ counts) {
+  __shared__ unsigned wcnt[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  unsigned m1 = 0;
+  for (int w = 0; w < WF_WGS; ++w) m1 += (unsigned)wg_counts[w];
+  m1 = min(m1, (unsigned)cap);
   for (unsigned k = tid; k < m1; k += 1024) {
     const int i = keep[k];
     const int a = (int)imin[i], b = (int)imax[i];
     if (a >= 0 && a < jn && b >= 0 && b < jn) atomicMin(&table[a * jn + b], (int)k);
   }
   __syncthreads();
-  const int per2 = ((int)m1 + 1023) / 1024;
-  const int lo2 = tid * per2, hi2 = min(lo2 + per2, (int)m1);
-  unsigned c2 = 0;
-  for (int k = lo2; k < hi2; ++k) {
+  // the first proposal of every unique pair, in keep order: the wave-segment walk over keep[0 .. m1)
+  const int seg2 = ((int)m1 + 15) / 16, t_lo = wv * seg2, t_hi = min(t_lo + seg2, (int)m1);
+  auto first_of_pair = [&](int k, int& a, int& b) {
     const int i = keep[k];
-    const int a = (int)imin[i], b = (int)imax[i];
-    c2 += (a >= 0 && a < jn && b >= 0 && b < jn) && __hip_atomic_load(&table[a * jn + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k;
+    a = (int)imin[i]; b = (int)imax[i];
+    return (a >= 0 && a < jn && b >= 0 && b < jn) && __hip_atomic_load(&table[a * jn + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k;
+  };
+  unsigned wc2 = 0;
+  for (int base = t_lo; base < t_hi; base += 64) {
+    const int k = base + lane;
+    int a, b;
+    wc2 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(k < t_hi && first_of_pair(k, a, b)));
   }
-  unsigned m2;
-  unsigned off2 = block_excl_scan_1024(c2, wsum, &m2);
-  for (int k = lo2; k < hi2; ++k) {
-    const int i = keep[k];
-    const int a = (int)imin[i], b = (int)imax[i];
-    if ((a >= 0 && a < jn && b >= 0 && b < jn) && __hip_atomic_load(&table[a * jn + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k) {
-      rep[off2] = k;
-      pairs[off2 * 2] = b;          // (max, min): plnet.cpp:301
-      pairs[off2 * 2 + 1] = a;
-      ++off2;
+  if (lane == 0) wcnt[wv] = wc2;
+  __syncthreads();
+  unsigned off2 = 0, m2 = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wv) off2 += wcnt[w];
+    m2 += wcnt[w];
+  }
+  for (int base = t_lo; base < t_hi; base += 64) {
+    const int k = base + lane;
+    int a = 0, b = 0;
+    const bool f = k < t_hi && first_of_pair(k, a, b);
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(f);
+    if (f) {
+      const unsigned pos = off2 + __builtin_popcountll(mk & ((1ull << lane) - 1ull));
+      rep[pos] = k;
+      pairs[pos * 2] = b;           // (max, min): plnet.cpp:301
+      pairs[pos * 2 + 1] = a;
     }
+    off2 += __builtin_popcountll(mk);
   }
   __syncthreads();
   for (unsigned k = tid; k < m1; k += 1024) {      // leave the table clean for the next call
@@ -85,9 +135,12 @@ __global__ __launch_bounds__(1024) void wireframe_kernel(const float* __restrict
   if (tid == 0) { counts[0] = (int)m1; counts[1] = (int)m2; }
 }
 
+// counts: [0] M1, [1] M2, [2 .. 2 + WF_WGS) scratch (per-workgroup counts)
 void launch_wireframe(const float* iskeep, const float* imin, const float* imax, int n, int jn, int* table, int* keep,
                       int* pairs, int* rep, int cap, int* counts, hipStream_t st) {
-  hipLaunchKernelGGL(wireframe_kernel, dim3(1), dim3(1024), 0, st, iskeep, imin, imax, n, jn, table, keep, pairs, rep, cap, counts);
+  hipLaunchKernelGGL(wf_count_kernel, dim3(WF_WGS), dim3(256), 0, st, iskeep, n, counts + 2);
+  hipLaunchKernelGGL(wf_emit_kernel, dim3(WF_WGS), dim3(256), 0, st, iskeep, n, counts + 2, keep, cap);
+  hipLaunchKernelGGL(wireframe_kernel, dim3(1), dim3(1024), 0, st, imin, imax, jn, table, counts + 2, keep, pairs, rep, cap, counts);
 }
 
 // =============================================================================== stage-1 LOI head
@@ -248,24 +301,76 @@ void launch_line_filter(const float* la, const float* sc, const int* counts, int
 }
 
 // junction_detector (src/plnet.cpp:425-448): raster scan of the junction map inside [border, R-border) (EXCLUSIVE upper)
-__global__ __launch_bounds__(1024) void junction_scan_kernel(const unsigned char* __restrict__ jmap,
-                                                             const float* __restrict__ heat, int R, int border,
-                                                             float* __restrict__ feat, int cap, int* __restrict__ n_out) {
-  __shared__ unsigned wsum[16];
-  const int tid = threadIdx.x, N = R * R;
-  const int per = (N + 1023) / 1024, lo = tid * per, hi = min(lo + per, N);
-  border = max(border, 0);
-  unsigned cnt = 0;
-  for (int i = lo; i < hi; ++i) {
-    const int y = i / R, x = i - y * R;
-    cnt += jmap[i] && x >= border && x < R - border && y >= border && y < R - border;
+// Two launches of 64 workgroups (one 1024-thread workgroup walking the whole 512 x 512 map took 192 us per frame — longer than the
+// encoder at batch 1): every workgroup owns a contiguous run of pixels, 16 per thread; counts first, then the ordered emit with the
+// sum of the preceding workgroups' counts as its base.  Raster order (the reference's scan order) is kept.
+constexpr int JS_WGS = 64, JS_PT = 16;
+
+__device__ __forceinline__ unsigned js_mask16(const unsigned char* __restrict__ jmap, int i0, int N, int R, int border) {
+  unsigned m = 0;
+  if (i0 + JS_PT <= N && (R % JS_PT) == 0 && (i0 % JS_PT) == 0) {   // the 16 pixels are in one row, aligned: one 16-byte load
+    const uint4 q = *reinterpret_cast<const uint4*>(jmap + i0);
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+    const int y = i0 / R, x0 = i0 - y * R;
+    const bool yin = y >= border && y < R - border;
+#pragma unroll
+    for (int k = 0; k < JS_PT; ++k) {
+      const int x = x0 + k;
+      if (((w[k >> 2] >> (8 * (k & 3))) & 0xFFu) && yin && x >= border && x < R - border) m |= 1u << k;
+    }
+  } else {
+    for (int k = 0; k < JS_PT; ++k) {
+      const int i = i0 + k;
+      if (i >= N) break;
+      const int y = i / R, x = i - y * R;
+      if (jmap[i] && x >= border && x < R - border && y >= border && y < R - border) m |= 1u << k;
+    }
   }
-  unsigned tot;
-  unsigned off = block_excl_scan_1024(cnt, wsum, &tot);
-  for (int i = lo; i < hi; ++i) {
-    const int y = i / R, x = i - y * R;
-    if (jmap[i] && x >= border && x < R - border && y >= border && y < R - border) {
-      if (off < (unsigned)cap) {
+  return m;
+}
+
+__global__ __launch_bounds__(256) void junction_count_kernel(const unsigned char* __restrict__ jmap, int R, int border, int* __restrict__ wg_counts) {
+  __shared__ int wsum[4];
+  const int N = R * R, per_wg = (N + JS_WGS - 1) / JS_WGS, per = (per_wg + 255) / 256;
+  border = max(border, 0);
+  int cnt = 0;
+  const int lo = blockIdx.x * per_wg + threadIdx.x * per, hi = min(min(lo + per, (blockIdx.x + 1) * per_wg), N);
+  for (int i0 = lo; i0 < hi; i0 += JS_PT) cnt += __builtin_popcount(js_mask16(jmap, i0, min(hi, N), R, border));
+  cnt = (int)wave_sum((float)cnt);                                   // < 2^24: exact in fp32
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) wg_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void junction_emit_kernel(const unsigned char* __restrict__ jmap, const float* __restrict__ heat, int R, int border,
+                                                            float* __restrict__ feat, int cap, int* __restrict__ n_out,
+                                                            const int* __restrict__ wg_counts) {
+  __shared__ int wsum[4];
+  const int N = R * R, per_wg = (N + JS_WGS - 1) / JS_WGS, per = (per_wg + 255) / 256;
+  border = max(border, 0);
+  int base = 0;
+  for (int w = 0; w < (int)blockIdx.x; ++w) base += wg_counts[w];
+  const int lo = blockIdx.x * per_wg + threadIdx.x * per, hi = min(min(lo + per, (blockIdx.x + 1) * per_wg), N);
+  int cnt = 0;
+  for (int i0 = lo; i0 < hi; i0 += JS_PT) cnt += __builtin_popcount(js_mask16(jmap, i0, min(hi, N), R, border));
+  // exclusive prefix over the 256 threads: within the wave by shuffles, then over the 4 waves
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if ((int)(threadIdx.x & 63) >= o) incl += t;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int off = base + incl - cnt;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
+  for (int i0 = lo; i0 < hi; i0 += JS_PT) {
+    unsigned m = js_mask16(jmap, i0, min(hi, N), R, border);
+    while (m) {
+      const int k = __builtin_ctz(m);
+      m &= m - 1;
+      const int i = i0 + k, y = i / R, x = i - y * R;
+      if (off < cap) {
         float* f = feat + (size_t)off * 259;
         f[0] = heat[i];
         f[1] = (float)x;
@@ -274,12 +379,13 @@ __global__ __launch_bounds__(1024) void junction_scan_kernel(const unsigned char
       ++off;
     }
   }
-  if (tid == 0) { n_out[0] = min((int)tot, cap); n_out[1] = (int)tot; }        // [1]: what was found (the caller reports an overflow)
+  if (blockIdx.x == JS_WGS - 1 && threadIdx.x == 255) { n_out[0] = min(off, cap); n_out[1] = off; }   // [1]: what was found (the caller reports an overflow)
 }
 
 void launch_junction_scan(const unsigned char* jmap, const float* heat, int R, int border, float* feat, int cap, int* n_out,
-                          hipStream_t st) {
-  hipLaunchKernelGGL(junction_scan_kernel, dim3(1), dim3(1024), 0, st, jmap, heat, R, border, feat, cap, n_out);
+                          int* wg_counts, hipStream_t st) {
+  hipLaunchKernelGGL(junction_count_kernel, dim3(JS_WGS), dim3(256), 0, st, jmap, R, border, wg_counts);
+  hipLaunchKernelGGL(junction_emit_kernel, dim3(JS_WGS), dim3(256), 0, st, jmap, heat, R, border, feat, cap, n_out, wg_counts);
 }
 
 // =============================================================================== SuperGlue: keypoint encoder
