@@ -344,6 +344,28 @@ class Context:
                                                  nL.data_ptr(), nR.data_ptr(), idx_t.data_ptr(), score_t.data_ptr(),
                                                  idx_t.shape[1], nm_t.data_ptr(), self._stream(stream)), "airfe_stereo_batch_dev")
 
+    def detect_plnet_batch_dev(self, gray_t, feat_t, n_t, lines_t, nlines_t, junc_t=None, njunc_t=None, found_t=None, stream=None):
+        """PLNet over a device batch: gray [B][h][w] u8, feat [B][cap][259] f32, n [B] i32, lines [B][capL][4] f64, nlines [B] i32,
+        junc [J][capJ][259] f32 + njunc [J] i32 for the first J images (None: no junctions), found [B + J] i32 (None: not reported)."""
+        b, h, w = gray_t.shape
+        nj = 0 if junc_t is None else junc_t.shape[0]
+        self._chk(self._l.airfe_detect_plnet_batch_dev(
+            self._h, gray_t.data_ptr(), b, h, w, gray_t.stride(1), gray_t.stride(0), feat_t.data_ptr(), feat_t.shape[1], n_t.data_ptr(),
+            lines_t.data_ptr(), lines_t.shape[1], nlines_t.data_ptr(), junc_t.data_ptr() if nj else None, junc_t.shape[1] if nj else 0,
+            njunc_t.data_ptr() if nj else None, nj, found_t.data_ptr() if found_t is not None else None, self._stream(stream)),
+            "airfe_detect_plnet_batch_dev")
+
+    def stereo_plnet_batch_dev(self, left_t, right_t, featL, featR, nL, nR, lines_t, nlines_t, juncL, njuncL, idx_t, score_t, nm_t,
+                               found_t=None, stream=None):
+        """B stereo pairs with the PLNet detector: lines [2B][capL][4] / nlines [2B] (left images first), junctions of the left images
+        juncL [B][capJ][259] / njuncL [B], LightGlue matches as stereo_batch_dev; found [3B] i32 (None: not reported)."""
+        b, h, w = left_t.shape
+        self._chk(self._l.airfe_stereo_plnet_batch_dev(
+            self._h, left_t.data_ptr(), right_t.data_ptr(), b, h, w, left_t.stride(1), left_t.stride(0), featL.data_ptr(), featR.data_ptr(),
+            featL.shape[1], nL.data_ptr(), nR.data_ptr(), lines_t.data_ptr(), lines_t.shape[1], nlines_t.data_ptr(), juncL.data_ptr(),
+            juncL.shape[1], njuncL.data_ptr(), found_t.data_ptr() if found_t is not None else None, idx_t.data_ptr(), score_t.data_ptr(),
+            idx_t.shape[1], nm_t.data_ptr(), self._stream(stream)), "airfe_stereo_plnet_batch_dev")
+
     def _stream(self, stream):
         # the ctx runs on its own non-blocking stream: order it after whatever torch queued on ITS streams
         if stream is None:

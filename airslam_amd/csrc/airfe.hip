@@ -156,6 +156,10 @@ struct SgLayer { LinW qk, v, merge, mlp0, mlp3; };
 constexpr int LINE_CAP = 45056;     // unique candidate lines per image: 300 junctions give at most 300 * 299 / 2 = 44850 (min, max) pairs
 constexpr int KEEP_CAP = 3 * 128 * 128;
 constexpr int JUNC_CAP = 2048;
+// One image's stage-0 line tensors (SURVEY.md Appendix A.1 layouts) inside its stage block, in floats; the CHW loi_features of the
+// batch-1 / host-supplied path live in their own block (s0_loi): the batched path samples them from the head GEMM's rows instead.
+constexpr size_t SG_JUNCS = 0, SG_LP = 600, SG_KEEP = SG_LP + (size_t)KEEP_CAP * 4, SG_MIN = SG_KEEP + KEEP_CAP, SG_MAX = SG_MIN + KEEP_CAP,
+                 SG_THIN = SG_MAX + KEEP_CAP, SG_AUX = SG_THIN + 4 * 128 * 128, SG_STRIDE = (SG_AUX + 4 * 128 * 128 + 63) / 64 * 64;
 
 }  // namespace
 
@@ -173,6 +177,8 @@ struct airfe_ctx {
   uint8_t* pl_stage = nullptr;   // staging of airfe_assign_points_to_lines / airfe_match_lines
   size_t pl_bytes = 0;
   bool nms_map_valid = true;     // heat_nms holds the last batch's NMS'd maps (large batches skip writing them)
+  bool force_nms_map = false;    // the batched PLNet path reads junction scores from them: written at every batch size while set
+  int Lmax = 1;                  // images the line-path arena holds (= Dmax)
   bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
   int gemm_small_max = 4096, gemm8_min = 16000, gemmr_min = 8192, gemmr_wgs = 256;   // GemmArgs::small_max / g8_min / gr_min / gr_wgs (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M, AIRFE_GEMMR_MIN_M, AIRFE_GEMMR_WGS)
   int block_min = 3200;          // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
@@ -264,17 +270,18 @@ struct airfe_ctx {
   bool has_s0 = false;
   ConvW cL1;                     // line.conv1: 3x3 128 -> 128 on the conv3a features
   LinW cLh;                      // line.head : 1x1 128 -> 145 = loi (128) | md0-2 dis res | jloc0-1 | joffx joffy | thin0-3 | aux0-3
-  uint16_t* l_feat = nullptr;    // [128*128][128] 2-byte
+  uint16_t* l_feat = nullptr;    // [Lmax][128*128][128] 2-byte
   float *l_head = nullptr, *l_jloc = nullptr, *l_jnms = nullptr, *l_joff = nullptr, *l_sel = nullptr;
   int* l_nsel = nullptr;
   // PLNet stage 1 + line path
   bool has_s1 = false;
   const float* s1_w[11] = {nullptr};
   int *wf_table = nullptr, *wf_keep = nullptr, *wf_pairs = nullptr, *wf_rep = nullptr, *wf_counts = nullptr;
-  float *s1_la = nullptr, *s1_sc = nullptr, *s0_stage = nullptr, *junc_feat = nullptr;
+  float *s1_la = nullptr, *s1_sc = nullptr, *s0_stage = nullptr /*[Lmax][SG_STRIDE]*/, *s0_loi = nullptr /*CHW [128][128][128], one image*/,
+        *junc_feat = nullptr;
   unsigned char* jmap = nullptr;
   double* d_lines = nullptr;
-  int *d_nlines = nullptr, *d_njunc = nullptr;
+  int *d_nlines = nullptr /*[Lmax] kept | [Lmax] found*/, *d_njunc = nullptr /*[Lmax] kept | [Lmax] found | [Lmax][64] scan scratch*/;
 
   // per-stage hipEvent timers (airfe_profile_*): events are recorded on the launch stream only
   struct Mark { int stage; hipEvent_t a, b; double flops, bytes; };
@@ -285,11 +292,11 @@ struct airfe_ctx {
 
 enum Stage {
   ST_PREPROCESS = 0, ST_CONV1A, ST_CONV3X3_C64, ST_CONV3X3_C128, ST_HEAD_GEMM, ST_HEAD_ELTWISE, ST_NMS, ST_SELECT,
-  ST_SAMPLE, ST_LG_PREPARE, ST_LG_GEMM, ST_LG_ATTENTION, ST_LG_LNGELU, ST_LG_ASSIGN, ST_COUNT
+  ST_SAMPLE, ST_LG_PREPARE, ST_LG_GEMM, ST_LG_ATTENTION, ST_LG_LNGELU, ST_LG_ASSIGN, ST_PL_DECODE, ST_PL_STAGE1, ST_PL_FILTER, ST_COUNT
 };
 static const char* kStageNames[ST_COUNT] = {
   "preprocess", "conv1a", "conv3x3_cin64", "conv3x3_cin128", "head_gemm", "head_eltwise", "simple_nms", "select_topk",
-  "sample_desc", "lg_prepare", "lg_gemm", "lg_attention", "lg_ln_gelu", "lg_assign"};
+  "sample_desc", "lg_prepare", "lg_gemm", "lg_attention", "lg_ln_gelu", "lg_assign", "plnet_s0_decode", "plnet_stage1", "plnet_filter"};
 
 struct ProfScope {
   airfe_ctx* c; hipStream_t st; bool on; airfe_ctx::Mark m;
@@ -559,14 +566,14 @@ int load_superpoint(airfe_ctx* c, const char* path) {
     if (!hw || !hb || hw->data.size() != 145 * 128 || hb->data.size() != 145) return fail(c, err.empty() ? "line.head: unexpected shape" : err);
     if (!make_conv(c, p, "line.conv1", 128, 128, c->cL1, err) || !make_linear(c, hw->data.data(), hb->data.data(), 128, 145, c->cLh))
       return fail(c, err.empty() ? "device allocation failed while packing the line branch" : err);
-    const size_t npx = 128 * 128;
+    const size_t npx = (size_t)c->Lmax * 128 * 128;                 // one slot per image of the largest detector batch
     c->l_feat = dalloc<uint16_t>(c, npx * 128);
     c->l_head = dalloc<float>(c, npx * 160);
     c->l_jloc = dalloc<float>(c, npx);
     c->l_jnms = dalloc<float>(c, npx);
     c->l_joff = dalloc<float>(c, 2 * npx);
-    c->l_sel = dalloc<float>(c, (size_t)320 * AIRFE_FEAT_DIM);
-    c->l_nsel = dalloc<int>(c, 1);
+    c->l_sel = dalloc<float>(c, (size_t)c->Lmax * 320 * AIRFE_FEAT_DIM);
+    c->l_nsel = dalloc<int>(c, c->Lmax);
     if (!c->l_feat || !c->l_head || !c->l_jloc || !c->l_jnms || !c->l_joff || !c->l_sel || !c->l_nsel)
       return fail(c, "device allocation failed (line branch arena)");
     c->has_s0 = true;
@@ -754,22 +761,24 @@ int load_plnet_s1(airfe_ctx* c, const char* path) {
   c->s1_w[8] = dupload(c, wh->data);
   c->s1_w[9] = dupload(c, bh->data);
   c->s1_w[10] = dupload(c, tt->data);
-  std::vector<int> tab(300 * 300, 0x7FFFFFFF);
-  c->wf_table = dupload(c, tab);
-  c->wf_keep = dalloc<int>(c, KEEP_CAP);
-  c->wf_pairs = dalloc<int>(c, (size_t)LINE_CAP * 2);
-  c->wf_rep = dalloc<int>(c, LINE_CAP);
-  c->wf_counts = dalloc<int>(c, 2 + 48);      // M1, M2, then the per-workgroup counts of wf_count_kernel
-  c->s1_la = dalloc<float>(c, (size_t)LINE_CAP * 4);
-  c->s1_sc = dalloc<float>(c, LINE_CAP);
-  c->s0_stage = dalloc<float>(c, 600 + (size_t)KEEP_CAP * 7 + 128 * 128 * 128 + 2 * 4 * 128 * 128);
-  c->jmap = dalloc<unsigned char>(c, (size_t)AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE);
+  const size_t L = (size_t)c->Lmax;
+  c->wf_table = dalloc<int>(c, L * 300 * 300, false);
+  if (c->wf_table) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->wf_table), 0x7FFFFFFF, L * 300 * 300, c->stream));
+  c->wf_keep = dalloc<int>(c, L * KEEP_CAP);
+  c->wf_pairs = dalloc<int>(c, L * LINE_CAP * 2);
+  c->wf_rep = dalloc<int>(c, L * LINE_CAP);
+  c->wf_counts = dalloc<int>(c, L * LINE_CNT_LD);      // per image: M1, M2, then the per-workgroup counts of wf_count_kernel
+  c->s1_la = dalloc<float>(c, L * LINE_CAP * 4);
+  c->s1_sc = dalloc<float>(c, L * LINE_CAP);
+  c->s0_stage = dalloc<float>(c, L * SG_STRIDE);
+  c->s0_loi = dalloc<float>(c, (size_t)128 * 128 * 128);
+  c->jmap = dalloc<unsigned char>(c, L * AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE);
   c->d_lines = dalloc<double>(c, (size_t)LINE_CAP * 4);
-  c->d_nlines = dalloc<int>(c, 1);
-  c->d_njunc = dalloc<int>(c, 2 + 64);             // [0] junctions kept (<= JUNC_CAP), [1] junctions found, [2..] per-workgroup counts of the scan
+  c->d_nlines = dalloc<int>(c, 2 * L);
+  c->d_njunc = dalloc<int>(c, L * (2 + 64));
   c->junc_feat = dalloc<float>(c, (size_t)JUNC_CAP * AIRFE_FEAT_DIM);
   for (int i = 0; i < 11; ++i) if (!c->s1_w[i]) return fail(c, "device allocation failed (plnet_s1 weights)");
-  if (!c->wf_table || !c->wf_keep || !c->wf_pairs || !c->wf_rep || !c->wf_counts || !c->s1_la || !c->s1_sc || !c->s0_stage ||
+  if (!c->wf_table || !c->wf_keep || !c->wf_pairs || !c->wf_rep || !c->wf_counts || !c->s1_la || !c->s1_sc || !c->s0_stage || !c->s0_loi ||
       !c->jmap || !c->d_lines || !c->d_nlines || !c->d_njunc || !c->junc_feat)
     return fail(c, "device allocation failed (line path arena)");
   c->has_s1 = true;
@@ -985,7 +994,7 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
     if (c->cfg.nms_radius == 4 && R % 64 == 0) {          // (the tiled kernel moves 4-pixel vectors: R = 512 always qualifies)
       // the dense NMS'd map is consumed only by the batch-1 line path (junction scores) and the inspection hook: large batches skip
       // its 1 MB / image write (airfe_debug_detector_maps rebuilds it on demand)
-      c->nms_map_valid = B <= 2;
+      c->nms_map_valid = B <= 2 || c->force_nms_map;
       if (c->nms_v1 || R != 512)
         launch_nms4_candidates(c->heat, c->nms_map_valid ? c->heat_nms : nullptr, c->nms_mask, B, R, R, c->cfg.keypoint_threshold,
                                c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
@@ -1214,36 +1223,78 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   return 0;
 }
 
-// PLNet stage-0 LINE branch for the image the detector just ran on (batch slot 0): fills c->s0_stage with the Appendix A.1 tensors
-// in the contract's own layouts, so that everything downstream (wireframe dedup, stage 1, filters) is the code the golden tests pin.
-int line_branch_dev(airfe_ctx* c, hipStream_t st) {
+// PLNet stage-0 LINE branch of images [i0, i0 + nb) of the batch the detector just ran on: fills stage slots 0 .. nb-1 with the Appendix
+// A.1 tensors in the contract's own layouts, so that everything downstream (wireframe dedup, stage 1, filters) is the code the golden
+// tests pin.  chw: also the contract's CHW loi_features of slot 0 (the inspection hook; the line path samples the head rows directly).
+int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
   if (!c->has_s0) return fail(c, "the detector pack carries no line branch (line.* tensors)");
+  if (!c->s0_stage) return fail(c, "the line path arena is not allocated (cfg.plnet_s1_pack)");
+  if (nb < 1 || nb > c->Lmax || i0 < 0 || i0 + nb > c->Dmax) return fail(c, "line branch: image range outside the arena");
   const int NP = KEEP_CAP, F = 128;
   float* d = c->s0_stage;
-  float *d_juncs = d, *d_lp = d + 600, *d_keep = d_lp + (size_t)NP * 4, *d_min = d_keep + NP, *d_max = d_min + NP;
-  float *d_loi = d_max + NP, *d_thin = d_loi + 128 * 128 * 128, *d_aux = d_thin + 4 * 128 * 128;
   if (c->prec == 2) {
+    if (nb != 1 || i0 != 0) return fail(c, "the fp32 mode runs the line branch one image at a time");
     launch_conv3x3_f32(c->f3a, c->f_cL1.w, c->f_cL1.b, c->fL1, 1, F, F, 128, 128, 0, st);
     GemmF32Args g;
     g.X1 = c->fL1; g.ld1 = 128; g.K1 = 128; g.K = 128; g.W = c->f_cLh.w; g.bias = c->f_cLh.b; g.M = F * F; g.N = 145; g.Y = c->l_head; g.ldy = 160;
     launch_gemm_f32(g, st);
   } else {
-  run_conv(c, c->cL1, c->a3a, c->l_feat, 1, F, F, 0, 0, st);                 // conv3a features (zero-bordered NHWC) -> [128*128][128]
-  {
+    // conv3a features (zero-bordered NHWC, still in the arena for the whole batch) -> [nb * 128*128][128]
+    run_conv(c, c->cL1, c->a3a + (size_t)i0 * (F + 2) * (F + 2) * 128, c->l_feat, nb, F, F, 0, 0, st);
     GemmArgs g;
     g.X1 = c->l_feat; g.ld1 = 128; g.K1 = 128; g.Wp = c->cLh.w; g.bias = c->cLh.b;
-    g.M = F * F; g.N = 145; g.cb_total = c->cLh.cbt; g.epi = EPI_STORE_F32; g.out = c->l_head; g.ldo = 160;
+    g.M = nb * F * F; g.N = 145; g.cb_total = c->cLh.cbt; g.epi = EPI_STORE_F32; g.out = c->l_head; g.ldo = 160;
     g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-    ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * F * F * 128 * 145, (double)F * F * (256 + 580));
+    ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * nb * F * F * 128 * 145, (double)nb * F * F * (256 + 580));
     launch_gemm(c->prec, 128, false, g, st);
   }
-  }
-  launch_s0_decode(c->l_head, d_lp, c->l_jloc, c->l_jnms, c->l_joff, d_thin, d_aux, d_loi, st);
+  // head rows read once (11 KB / pixel incl. the LOI channels the decode skips: 68 floats), 49152 proposals + maps written; the j2l match reads them again
+  ProfScope ps(c, ST_PL_DECODE, st, 0, (double)nb * (128.0 * 128 * (17 * 4 + 3 * 16 + 11 * 4) + 3.0 * 49152 * (16 + 12)));
+  launch_s0_decode(c->l_head, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, chw ? c->s0_loi : nullptr, nb, SG_STRIDE, st);
   // get_junctions: top-300 of the suppressed junction map (score descending, raster ascending on ties)
-  launch_candidates(c->l_jnms, 1, F, F, 1e-30f, 0, c->cand, c->cand_cnt, AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE, st);
-  launch_select_list(c->cand, c->cand_cnt, AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE, 1, F, 300, 320, c->l_sel, c->l_nsel, st);
-  launch_s0_juncs(c->l_sel, c->l_nsel, c->l_joff, d_juncs, 300, st);
-  launch_s0_j2l(d_lp, d_juncs, 300, NP, 10.0f, d_keep, d_min, d_max, st);
+  const int ccap = AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE;
+  launch_candidates(c->l_jnms, nb, F, F, 1e-30f, 0, c->cand, c->cand_cnt, ccap, st);
+  launch_select_list(c->cand, c->cand_cnt, ccap, nb, F, 300, 320, c->l_sel, c->l_nsel, st);
+  launch_s0_juncs(c->l_sel, c->l_nsel, c->l_joff, d + SG_JUNCS, 300, 320, nb, SG_STRIDE, st);
+  launch_s0_j2l(d + SG_LP, d + SG_JUNCS, 300, NP, 10.0f, d + SG_KEEP, d + SG_MIN, d + SG_MAX, nb, SG_STRIDE, st);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// Everything behind the stage-0 tensors for stage slots 0 .. nb-1 (= images i0 .. i0+nb-1 of the detector batch): wireframe_matcher,
+// stage 1, the line / junction filter (plnet.cpp:272-307, 468-558) and, for the first nj of them, junction_detector + descriptors
+// (plnet.cpp:425-448).  LOI features: the head GEMM's rows (loi == nullptr) or a CHW block.  Results go to DEVICE buffers:
+// d_lines [nb][capL][4], d_nlines / d_lfound [nb], d_junc [nj][capJ][259], d_njunc / d_jfound [nj] (found > cap = the caller's overflow).
+int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int w, double* d_lines, int capL, int* d_nlines, int* d_lfound,
+                  float* d_junc, int capJ, int* d_njunc, int* d_jfound, int nj, hipStream_t st) {
+  if (!c->has_s1) return fail(c, "PLNet stage-1 weights were not loaded (cfg.plnet_s1_pack)");
+  if (nb < 1 || nb > c->Lmax || nj < 0 || nj > nb) return fail(c, "line path: image range outside the arena");
+  const int R = AIRFE_INTERNAL_SIZE, NP = KEEP_CAP;
+  float* d = c->s0_stage;
+  HIPCHK(c, hipMemsetAsync(c->jmap, 0, (size_t)nb * R * R, st));
+  const float ws = (float)w / (float)R, hs = (float)h / (float)R;
+  {
+  ProfScope ps(c, ST_PL_STAGE1, st, 0, (double)nb * 49152 * 12);
+  launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
+                   c->wf_counts, nb, SG_STRIDE, st);
+  if (loi_chw)
+    launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, loi_chw, 0, 128 * 128, 1, d + SG_THIN, d + SG_AUX,
+                    c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
+  else
+    launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, c->l_head, (size_t)128 * 128 * 160, 1, 160,
+                    d + SG_THIN, d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
+  }
+  ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nb * R * R + (double)nj * R * R * 2);
+  launch_line_filter(c->s1_la, c->s1_sc, c->wf_counts, c->cfg.remove_borders, c->cfg.line_threshold, c->cfg.line_length_threshold, ws, hs, R,
+                     c->jmap, d_lines, capL, d_nlines, d_lfound, LINE_CAP, nb, st);
+  if (nj > 0) {
+    if (c->cfg.nms_radius > 0 && !c->nms_map_valid) return fail(c, "line path: the NMS'd score maps of this batch were not kept");
+    const float* hsel = (c->cfg.nms_radius > 0 ? c->heat_nms : c->heat) + (size_t)i0 * R * R;
+    launch_junction_scan(c->jmap, hsel, R, c->cfg.remove_borders, d_junc, capJ, d_njunc, d_jfound, c->d_njunc + 2 * c->Lmax, nj, st);
+    if (!c->desc_dense_valid) return fail(c, "line path: the dense descriptor map of this batch was not made");
+    launch_sample_desc(c->desc + (size_t)i0 * (R / 8) * (R / 8) * 256, nj, R / 8, R / 8, d_junc, d_njunc, capJ, ws, hs,
+                       c->desc_normalised ? 0 : 1, st);
+  }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1349,6 +1400,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   }
   // a context with a detector AND the stereo matcher runs airfe_stereo_batch_dev over left + right images as one detector batch
   c->Dmax = (c->stereo_one_pass && c->prec != 2 && cfg->superpoint_pack && cfg->lightglue_pack) ? 2 * c->Bmax : c->Bmax;
+  c->Lmax = c->Dmax;
   int rc = 0;
   if (cfg->superpoint_pack) rc = load_superpoint(c, cfg->superpoint_pack);
   if (!rc && cfg->lightglue_pack) rc = load_lightglue(c, cfg->lightglue_pack);
@@ -1739,6 +1791,21 @@ int airfe_match_lines(airfe_ctx* c, const int32_t* row_ptr0, const int32_t* pt_i
 
 int airfe_has_line_branch(const airfe_ctx* c) { return c && c->has_s0 && c->has_s1; }
 
+// caller-supplied stage-0 tensors (golden / known-answer tests of everything downstream) -> stage slot 0 + the CHW LOI block
+static int upload_stage0(airfe_ctx* c, const airfe_plnet_stage0* s0, hipStream_t st) {
+  const size_t NP = KEEP_CAP;
+  float* d = c->s0_stage;
+  HIPCHK(c, hipMemcpyAsync(d + SG_JUNCS, s0->juncs_pred, 600 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d + SG_LP, s0->lines_pred, NP * 16, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d + SG_KEEP, s0->iskeep, NP * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d + SG_MIN, s0->idx_junc_to_end_min, NP * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d + SG_MAX, s0->idx_junc_to_end_max, NP * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->s0_loi, s0->loi_features, (size_t)128 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d + SG_THIN, s0->loi_features_thin, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d + SG_AUX, s0->loi_features_aux, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
+  return 0;
+}
+
 int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, const airfe_plnet_stage0* s0, float* feat,
                        int cap, int* n, double* lines, int capL, int* nlines, float* junc, int capJ, int* njunc,
                        int want_junctions) {
@@ -1749,41 +1816,25 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
   if (!s0 && !c->has_s0) return 0;            // no line branch available: points only (the shim says so, loudly, at build())
   if (!c->has_s1) return fail(c, "PLNet stage-1 weights were not loaded (cfg.plnet_s1_pack)");
   hipStream_t st = c->stream;
-  const int R = AIRFE_INTERNAL_SIZE, NP = KEEP_CAP;
-  float* d = c->s0_stage;
-  float *d_juncs = d, *d_lp = d + 600, *d_keep = d_lp + (size_t)NP * 4, *d_min = d_keep + NP, *d_max = d_min + NP;
-  float *d_loi = d_max + NP, *d_thin = d_loi + 128 * 128 * 128, *d_aux = d_thin + 4 * 128 * 128;
-  if (s0) {                                   // caller-supplied stage-0 tensors (golden / known-answer tests of everything downstream)
-    HIPCHK(c, hipMemcpyAsync(d_juncs, s0->juncs_pred, 600 * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_lp, s0->lines_pred, (size_t)NP * 16, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_keep, s0->iskeep, (size_t)NP * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_min, s0->idx_junc_to_end_min, (size_t)NP * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_max, s0->idx_junc_to_end_max, (size_t)NP * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_loi, s0->loi_features, (size_t)128 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_thin, s0->loi_features_thin, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_aux, s0->loi_features_aux, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
-  } else if (line_branch_dev(c, st)) {        // the stage-0 line branch on the device: nothing crosses PCIe (the reference moves
-    return 1;                                 // 15.5 MB D2H + 9.7 MB H2D here, plnet.cpp:237,494-509)
+  if (s0) {
+    if (upload_stage0(c, s0, st)) return 1;
+  } else if (line_branch_dev(c, st, 0, 1, false)) {   // the stage-0 line branch on the device: nothing crosses PCIe (the reference moves
+    return 1;                                         // 15.5 MB D2H + 9.7 MB H2D here, plnet.cpp:237,494-509)
   }
-  HIPCHK(c, hipMemsetAsync(c->jmap, 0, (size_t)R * R, st));
-  const float ws = (float)w / (float)R, hs = (float)h / (float)R;
-  launch_wireframe(d_keep, d_min, d_max, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, c->wf_counts, st);
-  launch_plnet_s1(d_juncs, d_lp, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, d_loi, d_thin, d_aux, c->s1_w, c->s1_la,
-                  c->s1_sc, LINE_CAP, st);
-  launch_line_filter(c->s1_la, c->s1_sc, c->wf_counts, c->cfg.remove_borders, c->cfg.line_threshold,
-                     c->cfg.line_length_threshold, ws, hs, R, c->jmap, c->d_lines, LINE_CAP, c->d_nlines, st);
-  int nl = 0, nj = 0, njf[2] = {0, 0};
-  HIPCHK(c, hipMemcpyAsync(&nl, c->d_nlines, 4, hipMemcpyDeviceToHost, st));
+  int* nl_d = c->d_nlines;                            // [0] kept (<= LINE_CAP: the staging holds every candidate), [Lmax] found
+  int *nj_d = c->d_njunc, *njf_d = c->d_njunc + c->Lmax;
+  if (line_tail_dev(c, 0, 1, s0 ? c->s0_loi : nullptr, h, w, c->d_lines, LINE_CAP, nl_d, nl_d + c->Lmax, c->junc_feat, JUNC_CAP, nj_d, njf_d,
+                    want_junctions ? 1 : 0, st))
+    return 1;
+  int nl = 0, nj = 0, njf = 0;
+  HIPCHK(c, hipMemcpyAsync(&nl, nl_d, 4, hipMemcpyDeviceToHost, st));
   if (want_junctions) {
-    const float* hsel = c->cfg.nms_radius > 0 ? c->heat_nms : c->heat;
-    launch_junction_scan(c->jmap, hsel, R, c->cfg.remove_borders, c->junc_feat, JUNC_CAP, c->d_njunc, c->d_njunc + 2, st);
-    launch_sample_desc(c->desc, 1, R / 8, R / 8, c->junc_feat, c->d_njunc, JUNC_CAP, ws, hs, c->desc_normalised ? 0 : 1, st);
-    HIPCHK(c, hipMemcpyAsync(njf, c->d_njunc, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&nj, nj_d, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&njf, njf_d, 4, hipMemcpyDeviceToHost, st));
   }
   HIPCHK(c, hipStreamSynchronize(st));
-  nj = njf[0];
   // the reference has no junction limit (junction_detector, plnet.cpp:425-448): more than the arena holds is an ERROR, not a shorter list
-  if (njf[1] > JUNC_CAP) return fail(c, "detect_plnet: more junctions than the device arena holds (JUNC_CAP)");
+  if (njf > JUNC_CAP) return fail(c, "detect_plnet: more junctions than the device arena holds (JUNC_CAP)");
   if (nl > capL || nj > capJ) return fail(c, "detect_plnet: lines / junctions do not fit the caller's buffers (capL, capJ)");
   if (nl > 0 && lines) HIPCHK(c, hipMemcpy(lines, c->d_lines, (size_t)nl * 32, hipMemcpyDeviceToHost));
   if (nj > 0 && junc) HIPCHK(c, hipMemcpy(junc, c->junc_feat, (size_t)nj * AIRFE_FEAT_DIM * 4, hipMemcpyDeviceToHost));
@@ -1792,21 +1843,71 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
   return 0;
 }
 
+// PLNet::infer over a device-resident batch, after the point branch ran on it (images 0 .. B-1 of the detector arena): lines of every
+// image, junctions of the first nj
+static int plnet_lines_batch(airfe_ctx* c, int B, int h, int w, double* d_lines, int capL, int* d_nlines, float* d_junc, int capJ,
+                             int* d_njunc, int nj, int* d_found, hipStream_t st) {
+  if (!c->has_s0 || !c->has_s1) return fail(c, "the batched PLNet path needs the line branch (line.* in the detector pack) and cfg.plnet_s1_pack");
+  if (c->prec == 2) return fail(c, "the batched PLNet path runs in fp16 / bf16 (the fp32 mode is one image per call)");
+  if (B > c->Lmax) return fail(c, "batch exceeds the line-path arena");
+  if (capL < 1 || !d_lines || !d_nlines) return fail(c, "detect_plnet_batch: no line output");
+  if (nj < 0 || nj > B || (nj > 0 && (!d_junc || !d_njunc || capJ < 1))) return fail(c, "detect_plnet_batch: bad junction arguments");
+  if (line_branch_dev(c, st, 0, B, false)) return 1;
+  bool partial = false;
+  if (nj > 0 && !c->desc_dense_valid) {           // the point branch ran the descriptor head on the sampled cells only: the junction images'
+    dense_desc_head(c, nj, st);                   // dense maps now (the points have theirs already; c->desc is free to be rewritten)
+    c->desc_dense_valid = true;
+    partial = nj != c->last_B;
+  }
+  int* lfound = d_found ? d_found : c->d_nlines + c->Lmax;
+  int* jfound = d_found ? d_found + B : c->d_njunc + c->Lmax;
+  const int rc = line_tail_dev(c, 0, B, nullptr, h, w, d_lines, capL, d_nlines, lfound, d_junc, capJ, d_njunc, jfound, nj, st);
+  if (partial) c->desc_dense_valid = false;       // (only the first nj images' dense maps exist)
+  return rc;
+}
+
+int airfe_detect_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat,
+                                 int cap, int* d_n, double* d_lines, int capL, int* d_nlines, float* d_junc, int capJ, int* d_njunc,
+                                 int junction_images, int* d_found, void* stream) {
+  if (!c) return 1;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  c->force_nms_map = junction_images > 0;         // junction scores are read from the NMS'd maps
+  const int rc = detect_dev(c, d_gray, B, h, w, stride, img_stride, d_feat, cap, d_n, st);
+  c->force_nms_map = false;
+  if (rc) return 1;
+  return plnet_lines_batch(c, B, h, w, d_lines, capL, d_nlines, d_junc, capJ, d_njunc, junction_images, d_found, st);
+}
+
+int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
+                                 size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, double* d_lines,
+                                 int capL, int* d_nlines, float* d_juncL, int capJ, int* d_njuncL, int* d_found, int32_t* d_idx,
+                                 float* d_score, int mcap, int* d_nmatch, void* stream) {
+  if (!c) return 1;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  if (!(c->stereo_one_pass && c->prec != 2 && 2 * B <= c->Dmax))
+    return fail(c, "stereo_plnet_batch: needs the one-pass stereo detector (detector + LightGlue packs loaded, 2 B <= 2 max_batch, fp16 / bf16)");
+  c->force_nms_map = true;
+  int rc = detect_dev2(c, d_left, d_right, B, h, w, stride, img_stride, d_featL, d_featR, cap, d_nL, d_nR, st);
+  c->force_nms_map = false;
+  if (rc) return 1;
+  // lines of the 2 B images (left 0 .. B-1, right B .. 2B-1), junctions of the left ones (feature_detector.cc:100-101)
+  if (plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, st)) return 1;
+  return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
+}
+
 /* the on-device stage-0 line branch of the LAST detected image, copied out in the Appendix A.1 layouts (NULL = skip) */
 int airfe_debug_plnet_stage0(airfe_ctx* c, float* juncs_pred, float* lines_pred, float* iskeep, float* idx_min, float* idx_max,
                              float* loi, float* thin, float* aux, float* jloc, float* joff) {
   if (!c || !c->has_s0 || !c->has_s1) return fail(c, "debug_plnet_stage0: line branch / stage 1 not loaded");
   hipStream_t st = c->stream;
-  if (line_branch_dev(c, st)) return 1;
+  if (line_branch_dev(c, st, 0, 1, true)) return 1;
   HIPCHK(c, hipStreamSynchronize(st));
-  const int NP = KEEP_CAP;
+  const size_t NP = KEEP_CAP;
   float* d = c->s0_stage;
-  float *d_juncs = d, *d_lp = d + 600, *d_keep = d_lp + (size_t)NP * 4, *d_min = d_keep + NP, *d_max = d_min + NP;
-  float *d_loi = d_max + NP, *d_thin = d_loi + 128 * 128 * 128, *d_aux = d_thin + 4 * 128 * 128;
   struct { float* h; const float* dv; size_t n; } cp[10] = {
-      {juncs_pred, d_juncs, 600}, {lines_pred, d_lp, (size_t)NP * 4}, {iskeep, d_keep, (size_t)NP}, {idx_min, d_min, (size_t)NP},
-      {idx_max, d_max, (size_t)NP}, {loi, d_loi, (size_t)128 * 128 * 128}, {thin, d_thin, (size_t)4 * 128 * 128},
-      {aux, d_aux, (size_t)4 * 128 * 128}, {jloc, c->l_jloc, (size_t)128 * 128}, {joff, c->l_joff, (size_t)2 * 128 * 128}};
+      {juncs_pred, d + SG_JUNCS, 600}, {lines_pred, d + SG_LP, NP * 4}, {iskeep, d + SG_KEEP, NP}, {idx_min, d + SG_MIN, NP},
+      {idx_max, d + SG_MAX, NP}, {loi, c->s0_loi, (size_t)128 * 128 * 128}, {thin, d + SG_THIN, (size_t)4 * 128 * 128},
+      {aux, d + SG_AUX, (size_t)4 * 128 * 128}, {jloc, c->l_jloc, (size_t)128 * 128}, {joff, c->l_joff, (size_t)2 * 128 * 128}};
   for (auto& e : cp)
     if (e.h) HIPCHK(c, hipMemcpy(e.h, e.dv, e.n * 4, hipMemcpyDeviceToHost));
   return 0;
@@ -1816,21 +1917,12 @@ int airfe_debug_plnet_stage0(airfe_ctx* c, float* juncs_pred, float* lines_pred,
 int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* lines_adjusted, float* scores_line, int cap, int* m2) {
   if (!c || !c->has_s1 || !s0) return fail(c, "debug_plnet_s1: stage-1 not loaded");
   hipStream_t st = c->stream;
-  const int NP = KEEP_CAP;
+  if (upload_stage0(c, s0, st)) return 1;
   float* d = c->s0_stage;
-  float *d_juncs = d, *d_lp = d + 600, *d_keep = d_lp + (size_t)NP * 4, *d_min = d_keep + NP, *d_max = d_min + NP;
-  float *d_loi = d_max + NP, *d_thin = d_loi + 128 * 128 * 128, *d_aux = d_thin + 4 * 128 * 128;
-  HIPCHK(c, hipMemcpyAsync(d_juncs, s0->juncs_pred, 600 * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_lp, s0->lines_pred, (size_t)NP * 16, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_keep, s0->iskeep, (size_t)NP * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_min, s0->idx_junc_to_end_min, (size_t)NP * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_max, s0->idx_junc_to_end_max, (size_t)NP * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_loi, s0->loi_features, (size_t)128 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_thin, s0->loi_features_thin, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_aux, s0->loi_features_aux, (size_t)4 * 128 * 128 * 4, hipMemcpyHostToDevice, st));
-  launch_wireframe(d_keep, d_min, d_max, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, c->wf_counts, st);
-  launch_plnet_s1(d_juncs, d_lp, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, d_loi, d_thin, d_aux, c->s1_w, c->s1_la,
-                  c->s1_sc, LINE_CAP, st);
+  launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, KEEP_CAP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
+                   c->wf_counts, 1, SG_STRIDE, st);
+  launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, c->s0_loi, 0, 128 * 128, 1, d + SG_THIN, d + SG_AUX,
+                  c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, 1, SG_STRIDE, st);
   int cnt[2] = {0, 0};
   HIPCHK(c, hipMemcpyAsync(cnt, c->wf_counts, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));

@@ -36,10 +36,14 @@ __device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* w
 // `perm` the stage-1 graph rebuilds with its reversed ScatterElements (oracle/onnx_run.py).
 // Three launches: the raster-ordered list of kept proposals is built by WF_WGS workgroups (count, then emit at the prefix of the counts
 // — ONE workgroup walking the 49152-entry map was latency-bound at 47 us per frame), the unique pairs by one workgroup over that list.
+// Every kernel of the line path takes one image per grid row (blockIdx.y): iskeep / imin / imax / juncs / lines_pred / thin / aux are
+// image 0's pointers into its stage block (image b: + b * stage_stride floats), the work lists are dense per image.
 constexpr int WF_WGS = 48;
 
-__global__ __launch_bounds__(256) void wf_count_kernel(const float* __restrict__ iskeep, int n, int* __restrict__ wg_counts) {
+__global__ __launch_bounds__(256) void wf_count_kernel(const float* __restrict__ iskeep, int n, int* __restrict__ counts, size_t stage_stride) {
   __shared__ int wsum[4];
+  iskeep += (size_t)blockIdx.y * stage_stride;
+  int* wg_counts = counts + (size_t)blockIdx.y * LINE_CNT_LD + 2;
   const int per_wg = (n + WF_WGS - 1) / WF_WGS, lo = blockIdx.x * per_wg, hi = min(lo + per_wg, n);
   int cnt = 0;
   for (int i = lo + threadIdx.x; i < hi; i += 256) cnt += iskeep[i] > 0.f;
@@ -49,9 +53,12 @@ __global__ __launch_bounds__(256) void wf_count_kernel(const float* __restrict__
   if (threadIdx.x == 0) wg_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-__global__ __launch_bounds__(256) void wf_emit_kernel(const float* __restrict__ iskeep, int n, const int* __restrict__ wg_counts,
-                                                      int* __restrict__ keep, int cap) {
+__global__ __launch_bounds__(256) void wf_emit_kernel(const float* __restrict__ iskeep, int n, const int* __restrict__ counts,
+                                                      int* __restrict__ keep, int cap, size_t stage_stride) {
   __shared__ int wcnt[4];
+  iskeep += (size_t)blockIdx.y * stage_stride;
+  keep += (size_t)blockIdx.y * cap;
+  const int* wg_counts = counts + (size_t)blockIdx.y * LINE_CNT_LD + 2;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int per_wg = (n + WF_WGS - 1) / WF_WGS, lo = blockIdx.x * per_wg, hi = min(lo + per_wg, n);
   int base = 0;
@@ -80,9 +87,15 @@ __global__ __launch_bounds__(256) void wf_emit_kernel(const float* __restrict__ 
 }
 
 __global__ __launch_bounds__(1024) void wireframe_kernel(const float* __restrict__ imin, const float* __restrict__ imax, int jn, int* table,
-                                                         const int* __restrict__ wg_counts, const int* __restrict__ keep,
-                                                         int* __restrict__ pairs, int* __restrict__ rep, int cap, int* __restrict__ counts) {
+                                                         const int* __restrict__ keep, int* __restrict__ pairs, int* __restrict__ rep,
+                                                         int cap, int line_cap, int* __restrict__ counts, size_t stage_stride) {
   __shared__ unsigned wcnt[16];
+  {
+    const size_t img = blockIdx.y;
+    imin += img * stage_stride; imax += img * stage_stride;
+    table += img * jn * jn; keep += img * cap; pairs += img * line_cap * 2; rep += img * line_cap; counts += img * LINE_CNT_LD;
+  }
+  const int* wg_counts = counts + 2;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   unsigned m1 = 0;
   for (int w = 0; w < WF_WGS; ++w) m1 += (unsigned)wg_counts[w];
@@ -120,9 +133,11 @@ __global__ __launch_bounds__(1024) void wireframe_kernel(const float* __restrict
     const unsigned long long mk = __builtin_amdgcn_ballot_w64(f);
     if (f) {
       const unsigned pos = off2 + __builtin_popcountll(mk & ((1ull << lane) - 1ull));
-      rep[pos] = k;
-      pairs[pos * 2] = b;           // (max, min): plnet.cpp:301
-      pairs[pos * 2 + 1] = a;
+      if (pos < (unsigned)line_cap) {
+        rep[pos] = k;
+        pairs[pos * 2] = b;           // (max, min): plnet.cpp:301
+        pairs[pos * 2 + 1] = a;
+      }
     }
     off2 += __builtin_popcountll(mk);
   }
@@ -132,26 +147,30 @@ __global__ __launch_bounds__(1024) void wireframe_kernel(const float* __restrict
     const int a = (int)imin[i], b = (int)imax[i];
     if (a >= 0 && a < jn && b >= 0 && b < jn) table[a * jn + b] = 0x7FFFFFFF;
   }
-  if (tid == 0) { counts[0] = (int)m1; counts[1] = (int)m2; }
+  if (tid == 0) { counts[0] = (int)m1; counts[1] = (int)min(m2, (unsigned)line_cap); }
 }
 
-// counts: [0] M1, [1] M2, [2 .. 2 + WF_WGS) scratch (per-workgroup counts)
+// counts: LINE_CNT_LD ints per image — [0] M1, [1] M2, [2 .. 2 + WF_WGS) scratch (per-workgroup counts);
+// table [B][jn * jn] (0x7FFFFFFF everywhere), keep [B][cap], pairs [B][line_cap][2], rep [B][line_cap]
 void launch_wireframe(const float* iskeep, const float* imin, const float* imax, int n, int jn, int* table, int* keep,
-                      int* pairs, int* rep, int cap, int* counts, hipStream_t st) {
-  hipLaunchKernelGGL(wf_count_kernel, dim3(WF_WGS), dim3(256), 0, st, iskeep, n, counts + 2);
-  hipLaunchKernelGGL(wf_emit_kernel, dim3(WF_WGS), dim3(256), 0, st, iskeep, n, counts + 2, keep, cap);
-  hipLaunchKernelGGL(wireframe_kernel, dim3(1), dim3(1024), 0, st, imin, imax, jn, table, counts + 2, keep, pairs, rep, cap, counts);
+                      int* pairs, int* rep, int cap, int line_cap, int* counts, int B, size_t stage_stride, hipStream_t st) {
+  hipLaunchKernelGGL(wf_count_kernel, dim3(WF_WGS, B), dim3(256), 0, st, iskeep, n, counts, stage_stride);
+  hipLaunchKernelGGL(wf_emit_kernel, dim3(WF_WGS, B), dim3(256), 0, st, iskeep, n, counts, keep, cap, stage_stride);
+  hipLaunchKernelGGL(wireframe_kernel, dim3(1, B), dim3(1024), 0, st, imin, imax, jn, table, keep, pairs, rep, cap, line_cap, counts,
+                     stage_stride);
 }
 
 // =============================================================================== stage-1 LOI head
 // plnet_s1.onnx restated (oracle/ref_nets.py::plnet_s1_forward), fp32 throughout.
-__device__ __forceinline__ float bil_chw(const float* __restrict__ f, int H, int W, float x, float y) {
+// A feature plane is addressed as f[(y W + x) ps]: ps = 1 for the contract's CHW planes, the row pitch of the head GEMM's output when the
+// LOI features are sampled where that GEMM left them (one pixel's 128 channels are then one 512-byte run: the 128 lanes' taps coalesce).
+__device__ __forceinline__ float bil_plane(const float* __restrict__ f, int H, int W, int ps, float x, float y) {
   const float px = x - 0.5f, py = y - 0.5f;
   const float x0 = fminf(fmaxf(floorf(px), 0.f), (float)(W - 1)), y0 = fminf(fmaxf(floorf(py), 0.f), (float)(H - 1));
   const float x1 = fminf(fmaxf(x0 + 1.f, 0.f), (float)(W - 1)), y1 = fminf(fmaxf(y0 + 1.f, 0.f), (float)(H - 1));
   const int x0i = (int)x0, y0i = (int)y0, x1i = (int)x1, y1i = (int)y1;
-  return f[y0i * W + x0i] * (y1 - py) * (x1 - px) + f[y1i * W + x0i] * (py - y0) * (x1 - px) +
-         f[y0i * W + x1i] * (y1 - py) * (px - x0) + f[y1i * W + x1i] * (py - y0) * (px - x0);
+  return f[(y0i * W + x0i) * ps] * (y1 - py) * (x1 - px) + f[(y1i * W + x0i) * ps] * (py - y0) * (x1 - px) +
+         f[(y0i * W + x1i) * ps] * (y1 - py) * (px - x0) + f[(y1i * W + x1i) * ps] * (py - y0) * (px - x0);
 }
 
 constexpr int S1_LT = 8;   // lines per workgroup
@@ -174,19 +193,33 @@ __device__ __forceinline__ void s1_dense(const float* __restrict__ wt /*[K][128]
 struct S1Weights {
   const float *w0t, *b0, *w2t, *b2, *w4t, *b4, *wrt, *br, *wh, *bh, *tt;   // *t = transposed [K][128]; wh [2][128]
 };
+struct S1Loi {                       // where image b's LOI feature (channel ch, pixel p) lives: base[b * img + ch * cs + p * ps]
+  const float* base;
+  size_t img;
+  int cs, ps;
+};
 
 __global__ __launch_bounds__(128) void plnet_s1_kernel(const float* __restrict__ juncs, const float* __restrict__ lines_pred,
                                                        const int* __restrict__ keep, const int* __restrict__ pairs,
-                                                       const int* __restrict__ rep, const int* __restrict__ counts,
-                                                       const float* __restrict__ loi, const float* __restrict__ thin,
-                                                       const float* __restrict__ aux, S1Weights w,
-                                                       float* __restrict__ lines_adjusted, float* __restrict__ scores_line) {
+                                                       const int* __restrict__ rep, const int* __restrict__ counts, S1Loi loi,
+                                                       const float* __restrict__ thin, const float* __restrict__ aux, S1Weights w,
+                                                       float* __restrict__ lines_adjusted, float* __restrict__ scores_line,
+                                                       int keep_cap, int line_cap, size_t stage_stride) {
   __shared__ float xs[S1_LT][496];
   __shared__ float h0[S1_LT][128], h1[S1_LT][128];
   __shared__ float la[S1_LT][4], li[S1_LT][4];
+  {
+    const size_t img = blockIdx.y;
+    juncs += img * stage_stride; lines_pred += img * stage_stride; thin += img * stage_stride; aux += img * stage_stride;
+    keep += img * keep_cap; pairs += img * line_cap * 2; rep += img * line_cap; counts += img * LINE_CNT_LD;
+    lines_adjusted += img * line_cap * 4; scores_line += img * line_cap;
+    loi.base += img * loi.img;
+  }
   const int m2 = counts[1];
-  const int l0 = blockIdx.x * S1_LT, tid = threadIdx.x;
-  if (l0 >= m2) return;
+  const int tid = threadIdx.x;
+  // a workgroup walks the image's line tiles with the grid's stride (the count is on the device: no launch sized by it)
+  for (int l0 = blockIdx.x * S1_LT; l0 < m2; l0 += gridDim.x * S1_LT) {
+  __syncthreads();
   if (tid < S1_LT * 4) {
     const int l = tid >> 2, c = tid & 3, u = min(l0 + l, m2 - 1);
     const int j = pairs[u * 2 + (c >> 1)];
@@ -196,14 +229,15 @@ __global__ __launch_bounds__(128) void plnet_s1_kernel(const float* __restrict__
     if (l0 + l < m2) lines_adjusted[(size_t)(l0 + l) * 4 + c] = v;
   }
   __syncthreads();
+  const float* lch = loi.base + (size_t)tid * loi.cs;
   for (int l = 0; l < S1_LT; ++l) {
-    xs[l][tid] = bil_chw(loi + (size_t)tid * 128 * 128, 128, 128, la[l][0], la[l][1]);
-    xs[l][128 + tid] = bil_chw(loi + (size_t)tid * 128 * 128, 128, 128, la[l][2], la[l][3]);
+    xs[l][tid] = bil_plane(lch, 128, 128, loi.ps, la[l][0], la[l][1]);
+    xs[l][128 + tid] = bil_plane(lch, 128, 128, loi.ps, la[l][2], la[l][3]);
     if (tid < 120) {
       const int c = tid / 30, j = tid - c * 30;
       const float t = w.tt[j], t1 = 1.0f - t;
-      xs[l][256 + tid] = bil_chw(thin + (size_t)c * 128 * 128, 128, 128, la[l][0] * t + la[l][2] * t1, la[l][1] * t + la[l][3] * t1);
-      xs[l][376 + tid] = bil_chw(aux + (size_t)c * 128 * 128, 128, 128, li[l][0] * t + li[l][2] * t1, li[l][1] * t + li[l][3] * t1);
+      xs[l][256 + tid] = bil_plane(thin + (size_t)c * 128 * 128, 128, 128, 1, la[l][0] * t + la[l][2] * t1, la[l][1] * t + la[l][3] * t1);
+      xs[l][376 + tid] = bil_plane(aux + (size_t)c * 128 * 128, 128, 128, 1, li[l][0] * t + li[l][2] * t1, li[l][1] * t + li[l][3] * t1);
     }
   }
   __syncthreads();
@@ -234,14 +268,20 @@ __global__ __launch_bounds__(128) void plnet_s1_kernel(const float* __restrict__
     const float e0 = expf(z0 - m), e1 = expf(z1 - m);
     scores_line[l0 + tid] = e1 / (e0 + e1);
   }
+  }
 }
 
+// loi: the contract's CHW block of the stage (loi_ps = 1, loi_cs = 128 * 128, loi_img = stage_stride) or the head GEMM's rows
+// (loi_ps = row pitch, loi_cs = 1, loi_img = 128 * 128 * pitch).  keep [B][keep_cap], pairs / rep / lines_adjusted / scores_line [B][line_cap].
 void launch_plnet_s1(const float* juncs, const float* lines_pred, const int* keep, const int* pairs, const int* rep,
-                     const int* counts, const float* loi, const float* thin, const float* aux, const float* const* w,
-                     float* lines_adjusted, float* scores_line, int cap_lines, hipStream_t st) {
+                     const int* counts, const float* loi, size_t loi_img, int loi_cs, int loi_ps, const float* thin, const float* aux,
+                     const float* const* w, float* lines_adjusted, float* scores_line, int keep_cap, int line_cap, int B,
+                     size_t stage_stride, hipStream_t st) {
   S1Weights sw{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10]};
-  hipLaunchKernelGGL(plnet_s1_kernel, dim3((cap_lines + S1_LT - 1) / S1_LT), dim3(128), 0, st, juncs, lines_pred, keep, pairs, rep,
-                     counts, loi, thin, aux, sw, lines_adjusted, scores_line);
+  S1Loi sl{loi, loi_img, loi_cs, loi_ps};
+  const int gx = B == 1 ? 512 : (B <= 8 ? 128 : 48);
+  hipLaunchKernelGGL(plnet_s1_kernel, dim3(gx, B), dim3(128), 0, st, juncs, lines_pred, keep, pairs, rep, counts, sl, thin, aux, sw,
+                     lines_adjusted, scores_line, keep_cap, line_cap, stage_stride);
 }
 
 // =============================================================================== line filter + junction map
@@ -251,8 +291,14 @@ __global__ __launch_bounds__(1024) void line_filter_kernel(const float* __restri
                                                            const int* __restrict__ counts, int border, float line_thr,
                                                            float len_thr, float w_scale, float h_scale, int R,
                                                            unsigned char* __restrict__ jmap, double* __restrict__ lines_out,
-                                                           int capL, int* __restrict__ nlines) {
+                                                           int capL, int* __restrict__ nlines, int* __restrict__ nfound, int line_cap) {
   __shared__ unsigned wsum[16];
+  {
+    const size_t img = blockIdx.x;
+    la += img * line_cap * 4; sc += img * line_cap; counts += img * LINE_CNT_LD; jmap += img * R * R;
+    lines_out += img * capL * 4; nlines += img;
+    if (nfound) nfound += img;
+  }
   const int tid = threadIdx.x, m2 = counts[1];
   const int per = (m2 + 1023) / 1024, lo = tid * per, hi = min(lo + per, m2);
   const float thr2 = __fmul_rn(len_thr, len_thr);
@@ -289,20 +335,25 @@ __global__ __launch_bounds__(1024) void line_filter_kernel(const float* __restri
         ++off;
       }
     }
-    if (pass == 1 && tid == 0) *nlines = min((int)tot, capL);
+    if (pass == 1 && tid == 0) {
+      *nlines = min((int)tot, capL);
+      if (nfound) *nfound = (int)tot;        // what passed the filter: more than capL is the caller's overflow to report
+    }
   }
 }
 
+// one workgroup per image: la [B][line_cap][4], sc [B][line_cap], jmap [B][R * R] (zeroed by the caller), lines_out [B][capL][4], nlines /
+// nfound [B] (nfound may be nullptr)
 void launch_line_filter(const float* la, const float* sc, const int* counts, int border, float line_thr, float len_thr,
-                        float w_scale, float h_scale, int R, unsigned char* jmap, double* lines_out, int capL, int* nlines,
-                        hipStream_t st) {
-  hipLaunchKernelGGL(line_filter_kernel, dim3(1), dim3(1024), 0, st, la, sc, counts, border, line_thr, len_thr, w_scale,
-                     h_scale, R, jmap, lines_out, capL, nlines);
+                        float w_scale, float h_scale, int R, unsigned char* jmap, double* lines_out, int capL, int* nlines, int* nfound,
+                        int line_cap, int B, hipStream_t st) {
+  hipLaunchKernelGGL(line_filter_kernel, dim3(B), dim3(1024), 0, st, la, sc, counts, border, line_thr, len_thr, w_scale,
+                     h_scale, R, jmap, lines_out, capL, nlines, nfound, line_cap);
 }
 
 // junction_detector (src/plnet.cpp:425-448): raster scan of the junction map inside [border, R-border) (EXCLUSIVE upper)
-// Two launches of 64 workgroups (one 1024-thread workgroup walking the whole 512 x 512 map took 192 us per frame — longer than the
-// encoder at batch 1): every workgroup owns a contiguous run of pixels, 16 per thread; counts first, then the ordered emit with the
+// Two launches of 64 workgroups per image (one 1024-thread workgroup walking the whole 512 x 512 map took 192 us per frame — longer than
+// the encoder at batch 1): every workgroup owns a contiguous run of pixels, 16 per thread; counts first, then the ordered emit with the
 // sum of the preceding workgroups' counts as its base.  Raster order (the reference's scan order) is kept.
 constexpr int JS_WGS = 64, JS_PT = 16;
 
@@ -332,6 +383,7 @@ __device__ __forceinline__ unsigned js_mask16(const unsigned char* __restrict__ 
 __global__ __launch_bounds__(256) void junction_count_kernel(const unsigned char* __restrict__ jmap, int R, int border, int* __restrict__ wg_counts) {
   __shared__ int wsum[4];
   const int N = R * R, per_wg = (N + JS_WGS - 1) / JS_WGS, per = (per_wg + 255) / 256;
+  jmap += (size_t)blockIdx.y * N; wg_counts += (size_t)blockIdx.y * JS_WGS;
   border = max(border, 0);
   int cnt = 0;
   const int lo = blockIdx.x * per_wg + threadIdx.x * per, hi = min(min(lo + per, (blockIdx.x + 1) * per_wg), N);
@@ -343,10 +395,15 @@ __global__ __launch_bounds__(256) void junction_count_kernel(const unsigned char
 }
 
 __global__ __launch_bounds__(256) void junction_emit_kernel(const unsigned char* __restrict__ jmap, const float* __restrict__ heat, int R, int border,
-                                                            float* __restrict__ feat, int cap, int* __restrict__ n_out,
+                                                            float* __restrict__ feat, int cap, int* __restrict__ n_kept, int* __restrict__ n_found,
                                                             const int* __restrict__ wg_counts) {
   __shared__ int wsum[4];
   const int N = R * R, per_wg = (N + JS_WGS - 1) / JS_WGS, per = (per_wg + 255) / 256;
+  {
+    const size_t img = blockIdx.y;
+    jmap += img * N; heat += img * N; feat += img * cap * 259; wg_counts += img * JS_WGS;
+    n_kept += img; n_found += img;
+  }
   border = max(border, 0);
   int base = 0;
   for (int w = 0; w < (int)blockIdx.x; ++w) base += wg_counts[w];
@@ -379,13 +436,14 @@ __global__ __launch_bounds__(256) void junction_emit_kernel(const unsigned char*
       ++off;
     }
   }
-  if (blockIdx.x == JS_WGS - 1 && threadIdx.x == 255) { n_out[0] = min(off, cap); n_out[1] = off; }   // [1]: what was found (the caller reports an overflow)
+  if (blockIdx.x == JS_WGS - 1 && threadIdx.x == 255) { *n_kept = min(off, cap); *n_found = off; }   // found > cap: the caller reports the overflow
 }
 
-void launch_junction_scan(const unsigned char* jmap, const float* heat, int R, int border, float* feat, int cap, int* n_out,
-                          int* wg_counts, hipStream_t st) {
-  hipLaunchKernelGGL(junction_count_kernel, dim3(JS_WGS), dim3(256), 0, st, jmap, R, border, wg_counts);
-  hipLaunchKernelGGL(junction_emit_kernel, dim3(JS_WGS), dim3(256), 0, st, jmap, heat, R, border, feat, cap, n_out, wg_counts);
+// jmap / heat [B][R * R], feat [B][cap][259], n_kept / n_found [B], wg_counts [B][64] scratch
+void launch_junction_scan(const unsigned char* jmap, const float* heat, int R, int border, float* feat, int cap, int* n_kept, int* n_found,
+                          int* wg_counts, int B, hipStream_t st) {
+  hipLaunchKernelGGL(junction_count_kernel, dim3(JS_WGS, B), dim3(256), 0, st, jmap, R, border, wg_counts);
+  hipLaunchKernelGGL(junction_emit_kernel, dim3(JS_WGS, B), dim3(256), 0, st, jmap, heat, R, border, feat, cap, n_kept, n_found, wg_counts);
 }
 
 // =============================================================================== SuperGlue: keypoint encoder

@@ -22,9 +22,13 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // per feature-map pixel: HAFM decoding (3 proposals: residual sign -1, 0, +1), junction probability / offset maps, thin / aux CHW
 __global__ __launch_bounds__(256) void s0_decode_kernel(const float* __restrict__ head /*[NPX][S0_LD]*/, float* __restrict__ lines_pred /*[3*NPX][4]*/,
                                                         float* __restrict__ jloc /*[NPX]*/, float* __restrict__ joff /*[2][NPX]*/,
-                                                        float* __restrict__ thin /*[4][NPX]*/, float* __restrict__ aux /*[4][NPX]*/) {
+                                                        float* __restrict__ thin /*[4][NPX]*/, float* __restrict__ aux /*[4][NPX]*/,
+                                                        size_t stage_stride) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= S0_NPX) return;
+  const size_t img = blockIdx.y;                 // one image per grid row: head / jloc / joff are dense per image, the rest sits in its stage block
+  head += img * S0_NPX * S0_LD; jloc += img * S0_NPX; joff += img * 2 * S0_NPX;
+  lines_pred += img * stage_stride; thin += img * stage_stride; aux += img * stage_stride;
   const float* o = head + (size_t)p * S0_LD + S0_HEAD;
   const float4 a = *reinterpret_cast<const float4*>(o), b = *reinterpret_cast<const float4*>(o + 4), c4 = *reinterpret_cast<const float4*>(o + 8),
                d4 = *reinterpret_cast<const float4*>(o + 12);
@@ -59,6 +63,7 @@ __global__ __launch_bounds__(256) void s0_decode_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void s0_jnms_kernel(const float* __restrict__ jloc, float* __restrict__ out) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= S0_NPX) return;
+  jloc += (size_t)blockIdx.y * S0_NPX; out += (size_t)blockIdx.y * S0_NPX;
   const int x = p & (S0_F - 1), y = p >> 7;
   const float a = jloc[p];
   float m = a;
@@ -88,12 +93,15 @@ __global__ __launch_bounds__(256) void s0_loi_chw_kernel(const float* __restrict
 }
 
 // get_junctions: rows (score, x, y) of the top-K selection -> juncs_pred [jn][2] = (x + joff_x + 0.5, y + joff_y + 0.5)
-__global__ void s0_juncs_kernel(const float* __restrict__ sel /*[jn][259]*/, const int* __restrict__ n_sel, const float* __restrict__ joff,
-                                float* __restrict__ juncs, int jn) {
+__global__ void s0_juncs_kernel(const float* __restrict__ sel /*[B][sel_cap][259]*/, const int* __restrict__ n_sel /*[B]*/,
+                                const float* __restrict__ joff /*[B][2][NPX]*/, float* __restrict__ juncs, int jn, int sel_cap,
+                                size_t stage_stride) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= jn) return;
+  const size_t img = blockIdx.y;
+  sel += img * sel_cap * 259; joff += img * 2 * S0_NPX; juncs += img * stage_stride;
   float x = 0.f, y = 0.f;
-  if (i < *n_sel) {
+  if (i < n_sel[img]) {
     const float fx = sel[(size_t)i * 259 + 1], fy = sel[(size_t)i * 259 + 2];
     const int idx = (int)fy * S0_F + (int)fx;
     x = __fadd_rn(__fadd_rn(fx, joff[idx]), 0.5f);
@@ -106,8 +114,13 @@ __global__ void s0_juncs_kernel(const float* __restrict__ sel /*[jn][259]*/, con
 // wireframe_matcher of HAWP (NOT the C++ routine of that name): nearest junction of both endpoints of every proposal (squared
 // distance, first minimum), idx_junc_to_end_min / _max, iskeep = (min < max) and both squared distances < j2l threshold (10)
 __global__ __launch_bounds__(256) void s0_j2l_kernel(const float* __restrict__ lines_pred, const float* __restrict__ juncs, int jn, int n,
-                                                     float thr, float* __restrict__ iskeep, float* __restrict__ imin, float* __restrict__ imax) {
+                                                     float thr, float* __restrict__ iskeep, float* __restrict__ imin, float* __restrict__ imax,
+                                                     size_t stage_stride) {
   __shared__ float jx[320], jy[320];
+  {
+    const size_t o = (size_t)blockIdx.y * stage_stride;
+    lines_pred += o; juncs += o; iskeep += o; imin += o; imax += o;
+  }
   for (int i = threadIdx.x; i < jn; i += 256) { jx[i] = juncs[i * 2]; jy[i] = juncs[i * 2 + 1]; }
   __syncthreads();
   const int p = blockIdx.x * 256 + threadIdx.x;
@@ -128,18 +141,23 @@ __global__ __launch_bounds__(256) void s0_j2l_kernel(const float* __restrict__ l
   imax[p] = (float)hi;
 }
 
+// B images per launch (grid.y): head [B][NPX][160], jloc / jnms [B][NPX], joff [B][2][NPX] dense; lines_pred, thin, aux, loi, juncs, iskeep,
+// imin, imax are image 0's pointers into its stage block, image b's are stage_stride floats further.  loi != nullptr: the contract's CHW
+// copy of IMAGE 0's LOI features (the line path itself samples them from the head rows, launch_plnet_s1).
 void launch_s0_decode(const float* head, float* lines_pred, float* jloc, float* jnms, float* joff, float* thin, float* aux, float* loi,
-                      hipStream_t st) {
-  hipLaunchKernelGGL(s0_decode_kernel, dim3(S0_NPX / 256), dim3(256), 0, st, head, lines_pred, jloc, joff, thin, aux);
-  hipLaunchKernelGGL(s0_jnms_kernel, dim3(S0_NPX / 256), dim3(256), 0, st, jloc, jnms);
-  hipLaunchKernelGGL(s0_loi_chw_kernel, dim3(S0_NPX / 32), dim3(256), 0, st, head, loi);
+                      int B, size_t stage_stride, hipStream_t st) {
+  hipLaunchKernelGGL(s0_decode_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, head, lines_pred, jloc, joff, thin, aux, stage_stride);
+  hipLaunchKernelGGL(s0_jnms_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, jloc, jnms);
+  if (loi) hipLaunchKernelGGL(s0_loi_chw_kernel, dim3(S0_NPX / 32), dim3(256), 0, st, head, loi);
 }
-void launch_s0_juncs(const float* sel, const int* n_sel, const float* joff, float* juncs, int jn, hipStream_t st) {
-  hipLaunchKernelGGL(s0_juncs_kernel, dim3((jn + 63) / 64), dim3(64), 0, st, sel, n_sel, joff, juncs, jn);
+void launch_s0_juncs(const float* sel, const int* n_sel, const float* joff, float* juncs, int jn, int sel_cap, int B, size_t stage_stride,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(s0_juncs_kernel, dim3((jn + 63) / 64, B), dim3(64), 0, st, sel, n_sel, joff, juncs, jn, sel_cap, stage_stride);
 }
 void launch_s0_j2l(const float* lines_pred, const float* juncs, int jn, int n, float thr, float* iskeep, float* imin, float* imax,
-                   hipStream_t st) {
-  hipLaunchKernelGGL(s0_j2l_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lines_pred, juncs, jn, n, thr, iskeep, imin, imax);
+                   int B, size_t stage_stride, hipStream_t st) {
+  hipLaunchKernelGGL(s0_j2l_kernel, dim3((n + 255) / 256, B), dim3(256), 0, st, lines_pred, juncs, jn, n, thr, iskeep, imin, imax,
+                     stage_stride);
 }
 
 }  // namespace airfe

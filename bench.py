@@ -59,7 +59,8 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3):
 
 def side_workloads(args, rank, world, local, dev):
     """The other configurations of BASELINE.json behind the same contract (one JSON line, K timed steps between barriers):
-    SuperGlue as the matcher (configs[4]), PLNet as the detector (batch-1 host API), the matcher-only loop-closure replay."""
+    SuperGlue as the matcher (configs[4]), PLNet as the detector (device-resident batch, or --plnet-host: the batch-1 host API), the matcher-only
+    loop-closure replay."""
     import tempfile
     from airslam_amd import api, mapfile, synth, weights
     from airslam_amd import dist as adist
@@ -79,8 +80,11 @@ def side_workloads(args, rank, world, local, dev):
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    if args.detector == "plnet":
-        root = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(os.path.abspath(__file__))
+    plnet_batched = args.detector == "plnet" and not args.plnet_host
+    if plnet_batched and (sg or args.workload != "stereo"):
+        raise SystemExit("--detector plnet (batched) runs the stereo workload with LightGlue; add --plnet-host for the batch-1 host API")
+    if args.detector == "plnet" and not plnet_batched:
         pairs = [synth.stereo_pair(H, W, 1000 + rank * 64 + i) for i in range(min(B, 8))]
         ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(root, "tests", "golden", "plnet_s1.airfe"),
                           **dict(cfg, max_batch=2, enc_chunk=2), **mkw)
@@ -98,7 +102,10 @@ def side_workloads(args, rank, world, local, dev):
         what = (f"{B} stereo pairs per step through the batch-1 HOST API (PCIe and one sync per call included): 2x PLNet::infer "
                 f"(points + on-device line branch + real stage-1 weights + junctions on the left) + 1x {'SuperGlue' if sg else 'LightGlue'}")
     else:
-        ctx = api.Context(superpoint=weights.synthetic_superpoint(1234), **cfg, **mkw)
+        if plnet_batched:
+            ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(root, "tests", "golden", "plnet_s1.airfe"), **cfg, **mkw)
+        else:
+            ctx = api.Context(superpoint=weights.synthetic_superpoint(1234), **cfg, **mkw)
         ls, rs = synth.stereo_batch(B, H, W, 1000 + rank)
         L, R = torch.from_numpy(ls).to(dev), torch.from_numpy(rs).to(dev)
         fl = torch.zeros((B, K, 259), device=dev); fr = torch.zeros((B, K, 259), device=dev)
@@ -136,6 +143,17 @@ def side_workloads(args, rank, world, local, dev):
             B = B2
             what = (f"matcher only: {B} (query, candidate) frame pairs per step replayed from AirSLAM feature records (loop closure, "
                     f"map_refiner.cc:213-230: each query against its 5 best candidates), {'SuperGlue' if sg else 'LightGlue'}, {K} keypoints max")
+        elif plnet_batched:
+            CL, CJ = 1024, 1024
+            lines = torch.zeros((2 * B, CL, 4), dtype=torch.float64, device=dev); nlines = torch.zeros((2 * B,), dtype=torch.int32, device=dev)
+            junc = torch.zeros((B, CJ, 259), device=dev); njunc = torch.zeros((B,), dtype=torch.int32, device=dev)
+            found = torch.zeros((3 * B,), dtype=torch.int32, device=dev)
+
+            def step():
+                ctx.stereo_plnet_batch_dev(L, R, fl, fr, nl, nr, lines, nlines, junc, njunc, idx, sc, nm, found, stream=sh)
+            what = (f"{B} synthetic {W}x{H} stereo pairs per step per GPU, resident in HBM: ONE PLNet pass over the {2 * B} images (points + "
+                    f"stage-0 line branch + wireframe_matcher + real stage-1 weights + line filter for every image, junction_detector + "
+                    f"descriptors for the left ones) + LightGlue, max_keypoints={K}")
         else:
             def step():
                 ctx.detect_batch_dev(L, fl, nl, stream=sh)
@@ -166,7 +184,7 @@ def side_workloads(args, rank, world, local, dev):
         ctx.profile(False)
     barrier()
     if rank == 0:
-        if args.detector != "plnet":
+        if args.detector != "plnet" or plnet_batched:
             if sg:
                 n_match[0] = float((i0 >= 0).sum(1).float().mean())
             else:
@@ -180,7 +198,13 @@ def side_workloads(args, rank, world, local, dev):
                "config": {"workload": what + "; seeded synthetic weights (reference ONNX files are absent)", "pairs_per_step_per_gpu": B,
                           "detector": args.detector, "matcher": args.matcher, "matches_mean": n_match[0]},
                "roofline": None, "cpu_baseline": None}
-        if args.detector == "plnet":
+        if plnet_batched:
+            fh_ = found.cpu().numpy()
+            if (fh_[:2 * B] > CL).any() or (fh_[2 * B:] > CJ).any():
+                raise SystemExit("bench: line / junction capacity overflow")
+            out["config"]["lines_mean"] = float(nlines.float().mean())
+            out["config"]["junctions_mean_left"] = float(njunc.float().mean())
+        elif args.detector == "plnet":
             out["config"]["lines_last_frame"] = lines_n[0]
         if stages:
             tot = sum(v["ms"] for v in stages.values())
@@ -229,7 +253,8 @@ def main():
     ap.add_argument("--matcher", default="lightglue", choices=["lightglue", "superglue"],
                     help="superglue: 18-layer GNN + 100 Sinkhorn iterations (BASELINE configs[4]: --width 1280 --height 720 --max-keypoints 1024)")
     ap.add_argument("--detector", default="superpoint", choices=["superpoint", "plnet"],
-                    help="plnet: PLNet::infer (points + on-device line branch + stage 1 + junctions) through the batch-1 HOST API, PCIe included")
+                    help="plnet: PLNet::infer (points + on-device line branch + stage 1 + line filter, junctions on the left) over the device-resident batch")
+    ap.add_argument("--plnet-host", action="store_true", help="with --detector plnet: the batch-1 HOST API instead (PCIe and one sync per call included)")
     ap.add_argument("--workload", default="stereo", choices=["stereo", "loop"],
                     help="loop: matcher only, replaying a map file's feature records (loop closure, map_refiner.cc:213-230)")
     ap.add_argument("--no-profile", action="store_true")

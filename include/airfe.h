@@ -165,6 +165,24 @@ int airfe_match_superglue_batch_dev(airfe_ctx* ctx, const float* d_f0, const int
 int airfe_stereo_batch_dev(airfe_ctx* ctx, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
                            size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR,
                            int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, void* stream);
+/* NEW (no reference counterpart: PLNet::infer, src/plnet.cpp:221-244, is one image per call): PLNet over B device-resident images in one
+ * pass — points exactly as airfe_detect_points_batch_dev; the line branch (stage-0 line head, wireframe_matcher, stage 1, line filter)
+ * for every image; junction_detector (+ descriptors) for the FIRST `junction_images` images.  Per image the results are the bits
+ * airfe_detect_plnet returns for it.
+ *   d_lines [B][capL][4] doubles (x1,y1,x2,y2 in original-image pixels), d_nlines [B] (<= capL)
+ *   d_junc [junction_images][capJ][259], d_njunc [junction_images] (<= capJ)
+ *   d_found (may be NULL) [B + junction_images]: lines that passed the filter per image, then junctions found per image — a value
+ *   above capL / capJ is an overflow the caller must treat as an error (the reference has no limits; the batch-1 entry reports it itself) */
+int airfe_detect_plnet_batch_dev(airfe_ctx* ctx, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat,
+                                 int cap, int* d_n, double* d_lines, int capL, int* d_nlines, float* d_junc, int capJ, int* d_njunc,
+                                 int junction_images, int* d_found, void* stream);
+/* One "stereo detect+match pair" x B with the PLNet detector (≙ map_builder.cc:85-86 with use_superpoint = 0: Detect(L, R, lines, junctions)
+ * + MatchingPoints): one detector pass over the 2 B images, lines of all of them (d_lines [2B][capL][4], d_nlines [2B]: left images first),
+ * junctions of the left ones only (feature_detector.cc:100-101), LightGlue on the points.  d_found (may be NULL) [3B]. */
+int airfe_stereo_plnet_batch_dev(airfe_ctx* ctx, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
+                                 size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, double* d_lines,
+                                 int capL, int* d_nlines, float* d_juncL, int capJ, int* d_njuncL, int* d_found, int32_t* d_idx,
+                                 float* d_score, int mcap, int* d_nmatch, void* stream);
 int airfe_sync(airfe_ctx* ctx);
 
 /* ---- per-stage hipEvent timers (measurement; SURVEY.md §5 "tracing") ----------------------------------- */
