@@ -200,6 +200,12 @@ class Context:
             "loi_features_thin", "loi_features_aux", "jloc", "joff")]), "airfe_debug_plnet_stage0")
         return out
 
+    def debug_plnet_j2l(self, fast: bool):
+        """(iskeep, idx_min, idx_max) [3*128*128] of the last detected image: as the line path computes them (fast) or in full."""
+        out = [np.zeros((3 * 128 * 128,), np.float32) for _ in range(3)]
+        self._chk(self._l.airfe_debug_plnet_j2l(self._h, 1 if fast else 0, *(o.ctypes.data for o in out)), "airfe_debug_plnet_j2l")
+        return tuple(out)
+
     def debug_plnet_s1(self, stage0, cap: int = 45056):
         st, keep = self._stage0(stage0)
         la = np.empty((cap, 4), np.float32)

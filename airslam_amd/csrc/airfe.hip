@@ -271,13 +271,13 @@ struct airfe_ctx {
   ConvW cL1;                     // line.conv1: 3x3 128 -> 128 on the conv3a features
   LinW cLh;                      // line.head : 1x1 128 -> 145 = loi (128) | md0-2 dis res | jloc0-1 | joffx joffy | thin0-3 | aux0-3
   uint16_t* l_feat = nullptr;    // [Lmax][128*128][128] 2-byte
-  float *l_head = nullptr, *l_jloc = nullptr, *l_jnms = nullptr, *l_joff = nullptr, *l_sel = nullptr;
+  float *l_ta8 = nullptr /*[Lmax][128*128][8] thin | aux pixel-major*/, *l_head = nullptr, *l_jloc = nullptr, *l_jnms = nullptr, *l_joff = nullptr, *l_sel = nullptr;
   int* l_nsel = nullptr;
   // PLNet stage 1 + line path
   bool has_s1 = false;
   const float* s1_w[11] = {nullptr};
   int *wf_table = nullptr, *wf_keep = nullptr, *wf_pairs = nullptr, *wf_rep = nullptr, *wf_counts = nullptr;
-  float *s1_la = nullptr, *s1_sc = nullptr, *s0_stage = nullptr /*[Lmax][SG_STRIDE]*/, *s0_loi = nullptr /*CHW [128][128][128], one image*/,
+  float *s1_la = nullptr, *s1_sc = nullptr, *s1_jfeat = nullptr /*[Lmax][300][256]*/, *s0_stage = nullptr /*[Lmax][SG_STRIDE]*/, *s0_loi = nullptr /*CHW [128][128][128], one image*/,
         *junc_feat = nullptr;
   unsigned char* jmap = nullptr;
   double* d_lines = nullptr;
@@ -572,9 +572,10 @@ int load_superpoint(airfe_ctx* c, const char* path) {
     c->l_jloc = dalloc<float>(c, npx);
     c->l_jnms = dalloc<float>(c, npx);
     c->l_joff = dalloc<float>(c, 2 * npx);
+    c->l_ta8 = dalloc<float>(c, 8 * npx);
     c->l_sel = dalloc<float>(c, (size_t)c->Lmax * 320 * AIRFE_FEAT_DIM);
     c->l_nsel = dalloc<int>(c, c->Lmax);
-    if (!c->l_feat || !c->l_head || !c->l_jloc || !c->l_jnms || !c->l_joff || !c->l_sel || !c->l_nsel)
+    if (!c->l_feat || !c->l_ta8 || !c->l_head || !c->l_jloc || !c->l_jnms || !c->l_joff || !c->l_sel || !c->l_nsel)
       return fail(c, "device allocation failed (line branch arena)");
     c->has_s0 = true;
   }
@@ -672,8 +673,8 @@ int alloc_matcher_arena(airfe_ctx* c) {
 }
 
 // y = W x + b stored transposed [K][N] fp32 for the thread-per-neuron VALU kernels
-float* upload_transposed(airfe_ctx* c, const Tensor& w, int N, int K) {
-  std::vector<float> t((size_t)N * K);
+float* upload_transposed(airfe_ctx* c, const Tensor& w, int N, int K, int pad_rows = 0) {
+  std::vector<float> t((size_t)N * (K + pad_rows), 0.f);
   for (int n = 0; n < N; ++n)
     for (int k = 0; k < K; ++k) t[(size_t)k * N + n] = w.data[(size_t)n * K + k];
   return dupload(c, t);
@@ -753,7 +754,7 @@ int load_plnet_s1(airfe_ctx* c, const char* path) {
     const Tensor* w = need(p, std::string(ls[i].name) + ".weight", err);
     const Tensor* b = need(p, std::string(ls[i].name) + ".bias", err);
     if (!w || !b || (int)w->data.size() != ls[i].n * ls[i].k) return fail(c, err.empty() ? "plnet_s1: unexpected shape" : err);
-    c->s1_w[2 * i] = upload_transposed(c, *w, ls[i].n, ls[i].k);
+    c->s1_w[2 * i] = upload_transposed(c, *w, ls[i].n, ls[i].k, S1_WPAD);
     c->s1_w[2 * i + 1] = dupload(c, b->data);
   }
   const Tensor *wh = need(p, "fc2_head.weight", err), *bh = need(p, "fc2_head.bias", err), *tt = need(p, "sample_t", err);
@@ -770,6 +771,7 @@ int load_plnet_s1(airfe_ctx* c, const char* path) {
   c->wf_counts = dalloc<int>(c, L * LINE_CNT_LD);      // per image: M1, M2, then the per-workgroup counts of wf_count_kernel
   c->s1_la = dalloc<float>(c, L * LINE_CAP * 4);
   c->s1_sc = dalloc<float>(c, L * LINE_CAP);
+  c->s1_jfeat = dalloc<float>(c, L * 300 * 256);
   c->s0_stage = dalloc<float>(c, L * SG_STRIDE);
   c->s0_loi = dalloc<float>(c, (size_t)128 * 128 * 128);
   c->jmap = dalloc<unsigned char>(c, L * AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE);
@@ -778,7 +780,7 @@ int load_plnet_s1(airfe_ctx* c, const char* path) {
   c->d_njunc = dalloc<int>(c, L * (2 + 64));
   c->junc_feat = dalloc<float>(c, (size_t)JUNC_CAP * AIRFE_FEAT_DIM);
   for (int i = 0; i < 11; ++i) if (!c->s1_w[i]) return fail(c, "device allocation failed (plnet_s1 weights)");
-  if (!c->wf_table || !c->wf_keep || !c->wf_pairs || !c->wf_rep || !c->wf_counts || !c->s1_la || !c->s1_sc || !c->s0_stage || !c->s0_loi ||
+  if (!c->wf_table || !c->wf_keep || !c->wf_pairs || !c->wf_rep || !c->wf_counts || !c->s1_la || !c->s1_sc || !c->s1_jfeat || !c->s0_stage || !c->s0_loi ||
       !c->jmap || !c->d_lines || !c->d_nlines || !c->d_njunc || !c->junc_feat)
     return fail(c, "device allocation failed (line path arena)");
   c->has_s1 = true;
@@ -1250,13 +1252,13 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
   }
   // head rows read once (11 KB / pixel incl. the LOI channels the decode skips: 68 floats), 49152 proposals + maps written; the j2l match reads them again
   ProfScope ps(c, ST_PL_DECODE, st, 0, (double)nb * (128.0 * 128 * (17 * 4 + 3 * 16 + 11 * 4) + 3.0 * 49152 * (16 + 12)));
-  launch_s0_decode(c->l_head, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, chw ? c->s0_loi : nullptr, nb, SG_STRIDE, st);
+  launch_s0_decode(c->l_head, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, chw ? c->s0_loi : nullptr, c->l_ta8, nb, SG_STRIDE, st);
   // get_junctions: top-300 of the suppressed junction map (score descending, raster ascending on ties)
   const int ccap = AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE;
   launch_candidates(c->l_jnms, nb, F, F, 1e-30f, 0, c->cand, c->cand_cnt, ccap, st);
   launch_select_list(c->cand, c->cand_cnt, ccap, nb, F, 300, 320, c->l_sel, c->l_nsel, st);
   launch_s0_juncs(c->l_sel, c->l_nsel, c->l_joff, d + SG_JUNCS, 300, 320, nb, SG_STRIDE, st);
-  launch_s0_j2l(d + SG_LP, d + SG_JUNCS, 300, NP, 10.0f, d + SG_KEEP, d + SG_MIN, d + SG_MAX, nb, SG_STRIDE, st);
+  launch_s0_j2l(d + SG_LP, d + SG_JUNCS, 300, NP, 10.0f, d + SG_KEEP, d + SG_MIN, d + SG_MAX, nb, SG_STRIDE, chw ? 1 : 0, st);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1271,22 +1273,22 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
   if (nb < 1 || nb > c->Lmax || nj < 0 || nj > nb) return fail(c, "line path: image range outside the arena");
   const int R = AIRFE_INTERNAL_SIZE, NP = KEEP_CAP;
   float* d = c->s0_stage;
-  HIPCHK(c, hipMemsetAsync(c->jmap, 0, (size_t)nb * R * R, st));
+  if (nj > 0) launch_zero16(c->jmap, (size_t)nj * R * R, st);
   const float ws = (float)w / (float)R, hs = (float)h / (float)R;
   {
   ProfScope ps(c, ST_PL_STAGE1, st, 0, (double)nb * 49152 * 12);
   launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
                    c->wf_counts, nb, SG_STRIDE, st);
   if (loi_chw)
-    launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, loi_chw, 0, 128 * 128, 1, d + SG_THIN, d + SG_AUX,
-                    c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
+    launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, loi_chw, 0, 128 * 128, 1, nullptr, nullptr, d + SG_THIN,
+                    d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
   else
     launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, c->l_head, (size_t)128 * 128 * 160, 1, 160,
-                    d + SG_THIN, d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
+                    c->s1_jfeat, c->l_ta8, d + SG_THIN, d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
   }
   ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nb * R * R + (double)nj * R * R * 2);
   launch_line_filter(c->s1_la, c->s1_sc, c->wf_counts, c->cfg.remove_borders, c->cfg.line_threshold, c->cfg.line_length_threshold, ws, hs, R,
-                     c->jmap, d_lines, capL, d_nlines, d_lfound, LINE_CAP, nb, st);
+                     c->jmap, nj, d_lines, capL, d_nlines, d_lfound, LINE_CAP, nb, st);
   if (nj > 0) {
     if (c->cfg.nms_radius > 0 && !c->nms_map_valid) return fail(c, "line path: the NMS'd score maps of this batch were not kept");
     const float* hsel = (c->cfg.nms_radius > 0 ? c->heat_nms : c->heat) + (size_t)i0 * R * R;
@@ -1913,6 +1915,21 @@ int airfe_debug_plnet_stage0(airfe_ctx* c, float* juncs_pred, float* lines_pred,
   return 0;
 }
 
+/* the junction-to-line match of the LAST detected image as the line path runs it (fast = 1: cell search, exact where it is consumed) or
+   as the inspection hook exports it (fast = 0: every proposal against every junction): iskeep, idx_junc_to_end_min / _max [3*128*128] */
+int airfe_debug_plnet_j2l(airfe_ctx* c, int fast, float* iskeep, float* idx_min, float* idx_max) {
+  if (!c || !c->has_s0 || !c->has_s1) return fail(c, "debug_plnet_j2l: line branch / stage 1 not loaded");
+  hipStream_t st = c->stream;
+  if (line_branch_dev(c, st, 0, 1, fast == 0)) return 1;
+  HIPCHK(c, hipStreamSynchronize(st));
+  const size_t NP = KEEP_CAP;
+  float* d = c->s0_stage;
+  if (iskeep) HIPCHK(c, hipMemcpy(iskeep, d + SG_KEEP, NP * 4, hipMemcpyDeviceToHost));
+  if (idx_min) HIPCHK(c, hipMemcpy(idx_min, d + SG_MIN, NP * 4, hipMemcpyDeviceToHost));
+  if (idx_max) HIPCHK(c, hipMemcpy(idx_max, d + SG_MAX, NP * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 /* stage-1 alone on HOST stage-0 tensors: lines_adjusted [M2][4] + scores_line [M2] (parity vs the real plnet_s1.onnx) */
 int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* lines_adjusted, float* scores_line, int cap, int* m2) {
   if (!c || !c->has_s1 || !s0) return fail(c, "debug_plnet_s1: stage-1 not loaded");
@@ -1921,8 +1938,8 @@ int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* line
   float* d = c->s0_stage;
   launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, KEEP_CAP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
                    c->wf_counts, 1, SG_STRIDE, st);
-  launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, c->s0_loi, 0, 128 * 128, 1, d + SG_THIN, d + SG_AUX,
-                  c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, 1, SG_STRIDE, st);
+  launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, c->s0_loi, 0, 128 * 128, 1, nullptr, nullptr, d + SG_THIN,
+                  d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, 1, SG_STRIDE, st);
   int cnt[2] = {0, 0};
   HIPCHK(c, hipMemcpyAsync(cnt, c->wf_counts, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));

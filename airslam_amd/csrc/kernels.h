@@ -183,17 +183,22 @@ constexpr int LINE_CNT_LD = 64;       // ints of `counts` per image: [0] M1 kept
 // table: [B][jn*jn] ints pre-filled with INT_MAX (left clean by the kernel); keep [B][cap], pairs [B][line_cap][2], rep [B][line_cap]
 void launch_wireframe(const float* iskeep, const float* imin, const float* imax, int n, int jn, int* table, int* keep,
                       int* pairs, int* rep, int cap, int line_cap, int* counts, int B, size_t stage_stride, hipStream_t st);
-// w: 11 device pointers {W0t[496][128], b0, W2t, b2, W4t, b4, Wrt[240][128], br, Wh[2][128], bh, t[30]}
-// LOI feature (image b, channel ch, pixel p) = loi[b * loi_img + ch * loi_cs + p * loi_ps]: the contract's CHW block (cs = 128 * 128, ps = 1)
-// or the head GEMM's rows (cs = 1, ps = row pitch)
+// w: 11 device pointers {W0t[496][128], b0, W2t, b2, W4t, b4, Wrt[240][128], br, Wh[2][128], bh, t[30]}; every transposed table is followed by
+// S1_WPAD readable rows (the kernel's weight prefetch runs past the last row)
+constexpr int S1_WPAD = 128;
+// LOI feature (image b, channel ch, pixel p) = loi[b * loi_img + ch * loi_cs + p * loi_ps]: the contract's CHW block (cs = 128 * 128, ps = 1;
+// thin / aux: the stage's CHW planes) or the head GEMM's rows (cs = 1, ps = row pitch; jfeat = [B][300][256] floats of scratch for the
+// junctions' first-layer projections; ta8 = [B][128*128][8] thin | aux pixel-major from launch_s0_decode: thin / aux are then not used)
 void launch_plnet_s1(const float* juncs, const float* lines_pred, const int* keep, const int* pairs, const int* rep,
-                     const int* counts, const float* loi, size_t loi_img, int loi_cs, int loi_ps, const float* thin, const float* aux,
-                     const float* const* w, float* lines_adjusted, float* scores_line, int keep_cap, int line_cap, int B,
+                     const int* counts, const float* loi, size_t loi_img, int loi_cs, int loi_ps, float* jfeat, const float* ta8, const float* thin,
+                     const float* aux, const float* const* w, float* lines_adjusted, float* scores_line, int keep_cap, int line_cap, int B,
                      size_t stage_stride, hipStream_t st);
-// la [B][line_cap][4], sc [B][line_cap], jmap [B][R*R] (zeroed by the caller), lines_out [B][capL][4], nlines [B] (<= capL), nfound [B] or nullptr
+// la [B][line_cap][4], sc [B][line_cap], lines_out [B][capL][4], nlines [B] (<= capL), nfound [B] or nullptr; jmap [nj][R*R] (zeroed by the
+// caller): the first nj images write their junction maps
 void launch_line_filter(const float* la, const float* sc, const int* counts, int border, float line_thr, float len_thr,
-                        float w_scale, float h_scale, int R, unsigned char* jmap, double* lines_out, int capL, int* nlines, int* nfound,
+                        float w_scale, float h_scale, int R, unsigned char* jmap, int nj, double* lines_out, int capL, int* nlines, int* nfound,
                         int line_cap, int B, hipStream_t st);
+void launch_zero16(void* p, size_t bytes, hipStream_t st);        // bytes % 16 == 0, 16-byte aligned
 // jmap / heat [B][R*R], feat [B][cap][259], n_kept / n_found [B], wg_counts [B][64] scratch
 void launch_junction_scan(const unsigned char* jmap, const float* heat, int R, int border, float* feat, int cap, int* n_kept, int* n_found,
                           int* wg_counts, int B, hipStream_t st);
@@ -224,14 +229,17 @@ void launch_ln_gelu_f32(float* h, const float* gamma, const float* beta, int M, 
 //      (128 LOI channels | md0..2 dis res | jloc0 jloc1 | joffx joffy | thin0..3 | aux0..3) into the Appendix A.1 tensors
 // B images per launch: head [B][128*128][160], jloc / jnms [B][128*128], joff [B][2][128*128] dense; lines_pred [3*128*128][4], thin / aux
 // CHW [4][128*128] in the image's stage block (+ b * stage_stride floats).  loi != nullptr: CHW [128][128*128] copy of IMAGE 0's LOI channels.
+// ta8 != nullptr: [B][128*128][8], thin0..3 | aux0..3 pixel-major (what stage 1 samples on the device path).
 void launch_s0_decode(const float* head, float* lines_pred, float* jloc, float* jnms, float* joff, float* thin, float* aux, float* loi,
-                      int B, size_t stage_stride, hipStream_t st);
+                      float* ta8, int B, size_t stage_stride, hipStream_t st);
 // rows (score, x, y) of the junction top-K, sel [B][sel_cap][259], n_sel [B] -> juncs_pred [jn][2] in the stage block
 void launch_s0_juncs(const float* sel, const int* n_sel, const float* joff, float* juncs, int jn, int sel_cap, int B, size_t stage_stride,
                      hipStream_t st);
-// HAWP wireframe_matcher: nearest junctions of both endpoints of n proposals -> iskeep, idx_junc_to_end_min / _max (floats)
+// HAWP wireframe_matcher: nearest junctions of both endpoints of n proposals -> iskeep, idx_junc_to_end_min / _max (floats).
+// exact_all = 0: iskeep exact everywhere, min / max exact where iskeep > 0 (all that plnet.cpp:272-307 reads), by a cell search;
+// exact_all = 1: the contract's tensors in full (every proposal against every junction)
 void launch_s0_j2l(const float* lines_pred, const float* juncs, int jn, int n, float thr, float* iskeep, float* imin, float* imax,
-                   int B, size_t stage_stride, hipStream_t st);
+                   int B, size_t stage_stride, int exact_all, hipStream_t st);
 
 // ---- SuperGlue ----------------------------------------------------------------------------------------------
 // h128 != nullptr: only the first three layers run (-> h128 [S*Np][128] 2-byte, x = descriptor); the caller adds the last two as GEMMs

@@ -22,7 +22,6 @@
 
 namespace airfe {
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <class P> struct Mfma32;
 template <> struct Mfma32<PBF16> {

@@ -23,7 +23,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 __global__ __launch_bounds__(256) void s0_decode_kernel(const float* __restrict__ head /*[NPX][S0_LD]*/, float* __restrict__ lines_pred /*[3*NPX][4]*/,
                                                         float* __restrict__ jloc /*[NPX]*/, float* __restrict__ joff /*[2][NPX]*/,
                                                         float* __restrict__ thin /*[4][NPX]*/, float* __restrict__ aux /*[4][NPX]*/,
-                                                        size_t stage_stride) {
+                                                        float* __restrict__ ta8 /*[B][NPX][8] or nullptr*/, size_t stage_stride) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= S0_NPX) return;
   const size_t img = blockIdx.y;                 // one image per grid row: head / jloc / joff are dense per image, the rest sits in its stage block
@@ -41,6 +41,11 @@ __global__ __launch_bounds__(256) void s0_decode_kernel(const float* __restrict_
   joff[S0_NPX + p] = sigmoidf_(c4.x) - 0.5f;
   thin[p] = c4.y; thin[S0_NPX + p] = c4.z; thin[2 * S0_NPX + p] = c4.w; thin[3 * S0_NPX + p] = d4.x;
   aux[p] = d4.y; aux[S0_NPX + p] = d4.z; aux[2 * S0_NPX + p] = d4.w; aux[3 * S0_NPX + p] = o16;
+  if (ta8) {                                     // the same eight values pixel-major: stage 1 samples a point's 4 + 4 channels as two 16-byte taps
+    float4* t8 = reinterpret_cast<float4*>(ta8 + (img * S0_NPX + p) * 8);
+    t8[0] = make_float4(c4.y, c4.z, c4.w, d4.x);
+    t8[1] = make_float4(d4.y, d4.z, d4.w, o16);
+  }
   // hafm_decoding: md_un = (md0 - 0.5) 2 pi; st_un = md1 pi/2; ed_un = -md2 pi/2; scale = 5
   const float PI = 3.14159265358979323846f;
   const float md_un = (md0 - 0.5f) * PI * 2.0f, st_un = md1 * PI / 2.0f, ed_un = -md2 * PI / 2.0f;
@@ -141,12 +146,99 @@ __global__ __launch_bounds__(256) void s0_j2l_kernel(const float* __restrict__ l
   imax[p] = (float)hi;
 }
 
+// The same match for what the line path CONSUMES, 6-10x cheaper (the brute-force kernel above — 49152 proposals x 300 junctions —
+// was 0.63 ms per 128 images): wireframe_matcher (plnet.cpp:272-307) reads idx_junc_to_end_min / _max only where iskeep > 0, and iskeep
+// needs both nearest squared distances below thr (10).  Junctions are binned into 8 x 8-pixel cells (counting sort in LDS, per
+// workgroup) and an endpoint looks at the 3 x 3 cells around its own: a junction outside that block is more than 8 pixels away in x or
+// y (d^2 > 63), so for thr <= 60 iskeep is exact for every proposal and min / max are exact for every KEPT one; entries of proposals that
+// are not kept hold the block's nearest (or 0) instead of the global nearest.  Ties go to the lower junction index explicitly (the cell
+// order is not the index order), which is the brute-force loop's "first minimum".  The inspection hook keeps the brute-force kernel.
+constexpr int J2L_PT = 4;                 // proposals per thread
+
+__global__ __launch_bounds__(256) void s0_j2l_grid_kernel(const float* __restrict__ lines_pred, const float* __restrict__ juncs, int jn, int n,
+                                                          float thr, float* __restrict__ iskeep, float* __restrict__ imin,
+                                                          float* __restrict__ imax, size_t stage_stride) {
+  __shared__ float2 sxy[320];
+  __shared__ int sj[320];
+  __shared__ int cs[260], fill[256];
+  __shared__ int wtot[4];
+  {
+    const size_t o = (size_t)blockIdx.y * stage_stride;
+    lines_pred += o; juncs += o; iskeep += o; imin += o; imax += o;
+  }
+  const int t = threadIdx.x;
+  auto cell_of = [](float x, float y) { return min(15, max(0, (int)(y * 0.125f))) * 16 + min(15, max(0, (int)(x * 0.125f))); };
+  fill[t] = 0;
+  __syncthreads();
+  float2 mine[2];
+  int mc[2] = {-1, -1};
+  for (int r = 0; r < 2; ++r) {
+    const int i = t + r * 256;
+    if (i < jn) {
+      mine[r] = make_float2(juncs[i * 2], juncs[i * 2 + 1]);
+      mc[r] = cell_of(mine[r].x, mine[r].y);
+      atomicAdd(&fill[mc[r]], 1);
+    }
+  }
+  __syncthreads();
+  {                                                          // exclusive prefix of the 256 cell counts
+    const int v = fill[t], lane = t & 63, wv = t >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wv; ++w) off += wtot[w];
+    cs[t] = off + incl - v;
+    if (t == 255) cs[256] = off + incl;
+    fill[t] = 0;
+  }
+  __syncthreads();
+  for (int r = 0; r < 2; ++r)
+    if (mc[r] >= 0) {
+      const int pos = cs[mc[r]] + atomicAdd(&fill[mc[r]], 1);
+      sxy[pos] = mine[r];
+      sj[pos] = t + r * 256;
+    }
+  __syncthreads();
+  auto nearest = [&](float px, float py, float& best, int& bi) {
+    best = INFINITY; bi = 0;
+    const int cx = min(15, max(0, (int)(px * 0.125f))), cy = min(15, max(0, (int)(py * 0.125f)));
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, 15);
+    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, 15); ++yy)
+      for (int i = cs[yy * 16 + x0], e = cs[yy * 16 + x1 + 1]; i < e; ++i) {
+        const float2 q = sxy[i];
+        const int j = sj[i];
+        const float ax = __fsub_rn(px, q.x), ay = __fsub_rn(py, q.y);
+        const float d = __fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay));
+        if (d < best || (d == best && j < bi)) { best = d; bi = j; }
+      }
+  };
+  for (int r = 0; r < J2L_PT; ++r) {
+    const int p = (blockIdx.x * J2L_PT + r) * 256 + t;
+    if (p >= n) break;
+    const float4 l = *reinterpret_cast<const float4*>(lines_pred + (size_t)p * 4);
+    float c1, c2;
+    int i1, i2;
+    nearest(l.x, l.y, c1, i1);
+    nearest(l.z, l.w, c2, i2);
+    const int lo = min(i1, i2), hi = max(i1, i2);
+    iskeep[p] = (lo < hi && c1 < thr && c2 < thr) ? 1.0f : 0.0f;
+    imin[p] = (float)lo;
+    imax[p] = (float)hi;
+  }
+}
+
 // B images per launch (grid.y): head [B][NPX][160], jloc / jnms [B][NPX], joff [B][2][NPX] dense; lines_pred, thin, aux, loi, juncs, iskeep,
 // imin, imax are image 0's pointers into its stage block, image b's are stage_stride floats further.  loi != nullptr: the contract's CHW
 // copy of IMAGE 0's LOI features (the line path itself samples them from the head rows, launch_plnet_s1).
 void launch_s0_decode(const float* head, float* lines_pred, float* jloc, float* jnms, float* joff, float* thin, float* aux, float* loi,
-                      int B, size_t stage_stride, hipStream_t st) {
-  hipLaunchKernelGGL(s0_decode_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, head, lines_pred, jloc, joff, thin, aux, stage_stride);
+                      float* ta8, int B, size_t stage_stride, hipStream_t st) {
+  hipLaunchKernelGGL(s0_decode_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, head, lines_pred, jloc, joff, thin, aux, ta8, stage_stride);
   hipLaunchKernelGGL(s0_jnms_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, jloc, jnms);
   if (loi) hipLaunchKernelGGL(s0_loi_chw_kernel, dim3(S0_NPX / 32), dim3(256), 0, st, head, loi);
 }
@@ -155,9 +247,13 @@ void launch_s0_juncs(const float* sel, const int* n_sel, const float* joff, floa
   hipLaunchKernelGGL(s0_juncs_kernel, dim3((jn + 63) / 64, B), dim3(64), 0, st, sel, n_sel, joff, juncs, jn, sel_cap, stage_stride);
 }
 void launch_s0_j2l(const float* lines_pred, const float* juncs, int jn, int n, float thr, float* iskeep, float* imin, float* imax,
-                   int B, size_t stage_stride, hipStream_t st) {
-  hipLaunchKernelGGL(s0_j2l_kernel, dim3((n + 255) / 256, B), dim3(256), 0, st, lines_pred, juncs, jn, n, thr, iskeep, imin, imax,
-                     stage_stride);
+                   int B, size_t stage_stride, int exact_all, hipStream_t st) {
+  if (exact_all || thr > 60.f || jn > 320)
+    hipLaunchKernelGGL(s0_j2l_kernel, dim3((n + 255) / 256, B), dim3(256), 0, st, lines_pred, juncs, jn, n, thr, iskeep, imin, imax,
+                       stage_stride);
+  else
+    hipLaunchKernelGGL(s0_j2l_grid_kernel, dim3((n + 256 * J2L_PT - 1) / (256 * J2L_PT), B), dim3(256), 0, st, lines_pred, juncs, jn, n, thr,
+                       iskeep, imin, imax, stage_stride);
 }
 
 }  // namespace airfe

@@ -214,6 +214,10 @@ int airfe_debug_superglue_scores(airfe_ctx* ctx, const float* f0, int n0, const 
  *   loi [128][128][128], thin / aux [4][128][128], jloc [128][128], joff [2][128][128] */
 int airfe_debug_plnet_stage0(airfe_ctx* ctx, float* juncs_pred, float* lines_pred, float* iskeep, float* idx_min, float* idx_max,
                              float* loi, float* thin, float* aux, float* jloc, float* joff);
+/* the junction-to-line match (HAWP wireframe_matcher) of the LAST detected image: fast = 1 as the line path runs it (cell search: iskeep
+ * exact everywhere, idx_junc_to_end_min / _max exact where iskeep > 0 — all that src/plnet.cpp:272-307 reads), fast = 0 the contract's
+ * tensors in full.  [3*128*128] floats each, NULL = skip. */
+int airfe_debug_plnet_j2l(airfe_ctx* ctx, int fast, float* iskeep, float* idx_min, float* idx_max);
 /* wireframe_matcher + stage-1 LOI head alone: lines_adjusted [cap][4], scores_line [cap], *m2 = unique lines */
 int airfe_debug_plnet_s1(airfe_ctx* ctx, const airfe_plnet_stage0* stage0, float* lines_adjusted, float* scores_line,
                          int cap, int* m2);

@@ -83,6 +83,22 @@ def test_plnet_infer_needs_no_host_tensors(lt, ll, min_lines):
     assert ok and len(acc) == lines.shape[0] and j.shape[1] == junc.shape[0]
 
 
+@pytest.mark.parametrize("seed", [5, 8, 12, 33])
+def test_cell_search_match_equals_brute_force_where_it_is_read(seed):
+    """The line path's junction-to-line match looks at the 3 x 3 cells of 8 x 8 pixels around an endpoint instead of at all 300 junctions:
+    iskeep must be the brute-force kernel's EVERYWHERE, min / max wherever iskeep > 0 (all wireframe_matcher, plnet.cpp:272-307, reads)."""
+    ctx, _ = _ctx()
+    ctx.detect_points(synth.gabor_image(480, 752, seed))
+    k0, a0, b0 = ctx.debug_plnet_j2l(fast=False)
+    k1, a1, b1 = ctx.debug_plnet_j2l(fast=True)
+    np.testing.assert_array_equal(k0, k1)
+    kept = k0 > 0
+    np.testing.assert_array_equal(a0[kept], a1[kept])
+    np.testing.assert_array_equal(b0[kept], b1[kept])
+    diag(f"plnet_j2l_{seed}", kept=int(kept.sum()), same_elsewhere=float((a0[~kept] == a1[~kept]).mean()))
+    assert kept.sum() > 1000
+
+
 def test_point_only_pack_gives_points_only():
     """A detector pack WITHOUT line.* tensors (plain SuperPoint) and no host tensors: points, zero lines, no error — the reference-shaped
     shim prints that at build() (shim/src/plnet.cpp)."""
