@@ -270,6 +270,11 @@ struct airfe_ctx {
   bool has_s0 = false;
   ConvW cL1;                     // line.conv1: 3x3 128 -> 128 on the conv3a features
   LinW cLh;                      // line.head : 1x1 128 -> 145 = loi (128) | md0-2 dis res | jloc0-1 | joffx joffy | thin0-3 | aux0-3
+  LinW cLh_loi, cLh_dec;         // the same rows as two heads: the 128 LOI channels (run on the junctions' tap rows only) and the 17 decoded ones
+  bool line_sparse = false;      // the last line_branch_dev ran the split heads (else: the fused head over one image, l_head)
+  float* l_dec = nullptr;        // [Lmax][128*128][32]: the 17-channel head
+  int* l_ridx = nullptr;         // [Lmax * 1200 (+ pad)]: tap rows of the junctions
+  float* l_lrows = nullptr;      // [Lmax * 1200 (+ pad)][128]: LOI features of those rows
   uint16_t* l_feat = nullptr;    // [Lmax][128*128][128] 2-byte
   float *l_ta8 = nullptr /*[Lmax][128*128][8] thin | aux pixel-major*/, *l_head = nullptr, *l_jloc = nullptr, *l_jnms = nullptr, *l_joff = nullptr, *l_sel = nullptr;
   int* l_nsel = nullptr;
@@ -564,18 +569,24 @@ int load_superpoint(airfe_ctx* c, const char* path) {
   if (p.count("line.conv1.weight")) {       // a PLNet stage-0 pack: the line branch rides along
     const Tensor *hw = need(p, "line.head.weight", err), *hb = need(p, "line.head.bias", err);
     if (!hw || !hb || hw->data.size() != 145 * 128 || hb->data.size() != 145) return fail(c, err.empty() ? "line.head: unexpected shape" : err);
-    if (!make_conv(c, p, "line.conv1", 128, 128, c->cL1, err) || !make_linear(c, hw->data.data(), hb->data.data(), 128, 145, c->cLh))
+    std::function<int(int)> dec_row = [](int f) { return 128 + f; };
+    if (!make_conv(c, p, "line.conv1", 128, 128, c->cL1, err) || !make_linear(c, hw->data.data(), hb->data.data(), 128, 145, c->cLh) ||
+        !make_linear(c, hw->data.data(), hb->data.data(), 128, 128, c->cLh_loi) ||
+        !make_linear(c, hw->data.data(), hb->data.data(), 128, 17, c->cLh_dec, 1.f, &dec_row))
       return fail(c, err.empty() ? "device allocation failed while packing the line branch" : err);
     const size_t npx = (size_t)c->Lmax * 128 * 128;                 // one slot per image of the largest detector batch
     c->l_feat = dalloc<uint16_t>(c, npx * 128);
-    c->l_head = dalloc<float>(c, npx * 160);
+    c->l_head = dalloc<float>(c, (size_t)128 * 128 * 160);          // the fused head: one image (fp32 mode, inspection hook)
+    c->l_dec = dalloc<float>(c, npx * 32);
+    c->l_ridx = dalloc<int>(c, (size_t)c->Lmax * 1200 + 256);
+    c->l_lrows = dalloc<float>(c, ((size_t)c->Lmax * 1200 + 256) * 128);
     c->l_jloc = dalloc<float>(c, npx);
     c->l_jnms = dalloc<float>(c, npx);
     c->l_joff = dalloc<float>(c, 2 * npx);
     c->l_ta8 = dalloc<float>(c, 8 * npx);
     c->l_sel = dalloc<float>(c, (size_t)c->Lmax * 320 * AIRFE_FEAT_DIM);
     c->l_nsel = dalloc<int>(c, c->Lmax);
-    if (!c->l_feat || !c->l_ta8 || !c->l_head || !c->l_jloc || !c->l_jnms || !c->l_joff || !c->l_sel || !c->l_nsel)
+    if (!c->l_feat || !c->l_ta8 || !c->l_head || !c->l_dec || !c->l_ridx || !c->l_lrows || !c->l_jloc || !c->l_jnms || !c->l_joff || !c->l_sel || !c->l_nsel)
       return fail(c, "device allocation failed (line branch arena)");
     c->has_s0 = true;
   }
@@ -1234,8 +1245,14 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
   if (nb < 1 || nb > c->Lmax || i0 < 0 || i0 + nb > c->Dmax) return fail(c, "line branch: image range outside the arena");
   const int NP = KEEP_CAP, F = 128;
   float* d = c->s0_stage;
+  // Two forms of the 1x1 head.  FUSED (fp32 mode, inspection hook; one image): all 145 channels at every pixel -> l_head [128*128][160].
+  // SPLIT (everything else): the 17 decoded channels at every pixel -> l_dec [nb][128*128][32]; the 128 LOI channels — read only at the four
+  // bilinear taps of the <= 300 junctions — by a gather GEMM over those <= 1200 rows per image once the junctions are known (line_tail_dev):
+  // the fused head wrote 1.07 GB of LOI features per 128 images to read 7 % of them.  Same kernel, same K order: the same bits.
+  const bool fused = c->prec == 2 || chw;
+  if (fused && (nb != 1 || i0 != 0)) return fail(c, "the fused line head (fp32 mode, inspection hook) runs one image at a time");
+  c->line_sparse = !fused;
   if (c->prec == 2) {
-    if (nb != 1 || i0 != 0) return fail(c, "the fp32 mode runs the line branch one image at a time");
     launch_conv3x3_f32(c->f3a, c->f_cL1.w, c->f_cL1.b, c->fL1, 1, F, F, 128, 128, 0, st);
     GemmF32Args g;
     g.X1 = c->fL1; g.ld1 = 128; g.K1 = 128; g.K = 128; g.W = c->f_cLh.w; g.bias = c->f_cLh.b; g.M = F * F; g.N = 145; g.Y = c->l_head; g.ldy = 160;
@@ -1243,16 +1260,23 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
   } else {
     // conv3a features (zero-bordered NHWC, still in the arena for the whole batch) -> [nb * 128*128][128]
     run_conv(c, c->cL1, c->a3a + (size_t)i0 * (F + 2) * (F + 2) * 128, c->l_feat, nb, F, F, 0, 0, st);
+    const LinW& hw = fused ? c->cLh : c->cLh_dec;
     GemmArgs g;
-    g.X1 = c->l_feat; g.ld1 = 128; g.K1 = 128; g.Wp = c->cLh.w; g.bias = c->cLh.b;
-    g.M = nb * F * F; g.N = 145; g.cb_total = c->cLh.cbt; g.epi = EPI_STORE_F32; g.out = c->l_head; g.ldo = 160;
+    g.X1 = c->l_feat; g.ld1 = 128; g.K1 = 128; g.Wp = hw.w; g.bias = hw.b;
+    g.M = nb * F * F; g.N = hw.N; g.cb_total = hw.cbt; g.epi = EPI_STORE_F32; g.out = fused ? c->l_head : c->l_dec; g.ldo = fused ? 160 : 32;
     g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-    ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * nb * F * F * 128 * 145, (double)nb * F * F * (256 + 580));
+    static const bool dec_small = !(getenv("AIRFE_DEC_SMALL") && atoi(getenv("AIRFE_DEC_SMALL")) == 0);
+    if (!fused && dec_small) g.small_max = 1 << 30;      // one 64-feature block: the no-LDS kernel computes 64 columns per row instead of the tiled kernels' 256
+    ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * nb * F * F * 128 * hw.N, (double)nb * F * F * (256 + 4.0 * g.ldo));
     launch_gemm(c->prec, 128, false, g, st);
   }
-  // head rows read once (11 KB / pixel incl. the LOI channels the decode skips: 68 floats), 49152 proposals + maps written; the j2l match reads them again
+  // head rows read once, 49152 proposals + maps written; the j2l match reads them again
   ProfScope ps(c, ST_PL_DECODE, st, 0, (double)nb * (128.0 * 128 * (17 * 4 + 3 * 16 + 11 * 4) + 3.0 * 49152 * (16 + 12)));
-  launch_s0_decode(c->l_head, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, chw ? c->s0_loi : nullptr, c->l_ta8, nb, SG_STRIDE, st);
+  if (fused)
+    launch_s0_decode(c->l_head, 160, 128, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, chw ? c->s0_loi : nullptr, c->l_ta8, nb,
+                     SG_STRIDE, st);
+  else
+    launch_s0_decode(c->l_dec, 32, 0, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, nullptr, c->l_ta8, nb, SG_STRIDE, st);
   // get_junctions: top-300 of the suppressed junction map (score descending, raster ascending on ties)
   const int ccap = AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE;
   launch_candidates(c->l_jnms, nb, F, F, 1e-30f, 0, c->cand, c->cand_cnt, ccap, st);
@@ -1279,12 +1303,25 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
   ProfScope ps(c, ST_PL_STAGE1, st, 0, (double)nb * 49152 * 12);
   launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
                    c->wf_counts, nb, SG_STRIDE, st);
-  if (loi_chw)
-    launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, loi_chw, 0, 128 * 128, 1, nullptr, nullptr, d + SG_THIN,
+  if (loi_chw) {                    // host-supplied contract tensors: all 496 features per line from the CHW blocks
+    launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, loi_chw, 0, nullptr, nullptr, d + SG_THIN, d + SG_AUX,
+                    c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
+  } else {
+    if (c->line_sparse) {           // the LOI head at the junctions' tap rows only
+      const int M = nb * 1200, Mp = (M + 255) / 256 * 256;
+      launch_s1_junc_rows(d + SG_JUNCS, 300, c->l_ridx, nb, SG_STRIDE, st);
+      if (Mp > M) HIPCHK(c, hipMemsetAsync(c->l_ridx + M, 0, (size_t)(Mp - M) * 4, st));
+      GemmArgs g;
+      g.X1 = c->l_feat; g.ld1 = 128; g.K1 = 128; g.Wp = c->cLh_loi.w; g.bias = c->cLh_loi.b; g.rowidx = c->l_ridx;
+      g.M = Mp; g.N = 128; g.cb_total = c->cLh_loi.cbt; g.epi = EPI_STORE_F32; g.out = c->l_lrows; g.ldo = 128;
+      launch_gemm8(c->prec, 128, false, g, st);
+      launch_s1_junc_proj(d + SG_JUNCS, nullptr, 0, 0, c->l_lrows, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, st);
+    } else {
+      launch_s1_junc_proj(d + SG_JUNCS, c->l_head, (size_t)128 * 128 * 160, 160, nullptr, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, st);
+    }
+    launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, nullptr, 0, c->s1_jfeat, c->l_ta8, d + SG_THIN,
                     d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
-  else
-    launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, c->l_head, (size_t)128 * 128 * 160, 1, 160,
-                    c->s1_jfeat, c->l_ta8, d + SG_THIN, d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
+  }
   }
   ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nb * R * R + (double)nj * R * R * 2);
   launch_line_filter(c->s1_la, c->s1_sc, c->wf_counts, c->cfg.remove_borders, c->cfg.line_threshold, c->cfg.line_length_threshold, ws, hs, R,
@@ -1938,8 +1975,8 @@ int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* line
   float* d = c->s0_stage;
   launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, KEEP_CAP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
                    c->wf_counts, 1, SG_STRIDE, st);
-  launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, c->s0_loi, 0, 128 * 128, 1, nullptr, nullptr, d + SG_THIN,
-                  d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, 1, SG_STRIDE, st);
+  launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, c->s0_loi, 0, nullptr, nullptr, d + SG_THIN, d + SG_AUX,
+                  c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, 1, SG_STRIDE, st);
   int cnt[2] = {0, 0};
   HIPCHK(c, hipMemcpyAsync(cnt, c->wf_counts, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));

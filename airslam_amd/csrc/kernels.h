@@ -186,11 +186,15 @@ void launch_wireframe(const float* iskeep, const float* imin, const float* imax,
 // w: 11 device pointers {W0t[496][128], b0, W2t, b2, W4t, b4, Wrt[240][128], br, Wh[2][128], bh, t[30]}; every transposed table is followed by
 // S1_WPAD readable rows (the kernel's weight prefetch runs past the last row)
 constexpr int S1_WPAD = 128;
-// LOI feature (image b, channel ch, pixel p) = loi[b * loi_img + ch * loi_cs + p * loi_ps]: the contract's CHW block (cs = 128 * 128, ps = 1;
-// thin / aux: the stage's CHW planes) or the head GEMM's rows (cs = 1, ps = row pitch; jfeat = [B][300][256] floats of scratch for the
-// junctions' first-layer projections; ta8 = [B][128*128][8] thin | aux pixel-major from launch_s0_decode: thin / aux are then not used)
+// the device path: proj [B][300][256] = the LOI half of fc2.0 applied per junction (launch_s1_junc_proj: LOI features either sampled from the
+// fused head's rows `head` [B][128*128][ps], or combined from the four tap rows lrows [B][300][4][128] of the LOI head's gather GEMM whose row
+// list launch_s1_junc_rows writes: ridx [B][300][4], rows of the [B][128*128] line-feature matrix) + ta8 [B][128*128][8] (launch_s0_decode).
+// proj == nullptr: the contract's CHW tensors, loi [128][128*128] (+ b * loi_img), thin / aux the stage's planes.
+void launch_s1_junc_rows(const float* juncs, int jn, int* ridx, int B, size_t stage_stride, hipStream_t st);
+void launch_s1_junc_proj(const float* juncs, const float* head, size_t head_img, int ps, const float* lrows, int jn, const float* w0t,
+                         float* proj, int B, size_t stage_stride, hipStream_t st);
 void launch_plnet_s1(const float* juncs, const float* lines_pred, const int* keep, const int* pairs, const int* rep,
-                     const int* counts, const float* loi, size_t loi_img, int loi_cs, int loi_ps, float* jfeat, const float* ta8, const float* thin,
+                     const int* counts, const float* loi, size_t loi_img, const float* proj, const float* ta8, const float* thin,
                      const float* aux, const float* const* w, float* lines_adjusted, float* scores_line, int keep_cap, int line_cap, int B,
                      size_t stage_stride, hipStream_t st);
 // la [B][line_cap][4], sc [B][line_cap], lines_out [B][capL][4], nlines [B] (<= capL), nfound [B] or nullptr; jmap [nj][R*R] (zeroed by the
@@ -229,9 +233,10 @@ void launch_ln_gelu_f32(float* h, const float* gamma, const float* beta, int M, 
 //      (128 LOI channels | md0..2 dis res | jloc0 jloc1 | joffx joffy | thin0..3 | aux0..3) into the Appendix A.1 tensors
 // B images per launch: head [B][128*128][160], jloc / jnms [B][128*128], joff [B][2][128*128] dense; lines_pred [3*128*128][4], thin / aux
 // CHW [4][128*128] in the image's stage block (+ b * stage_stride floats).  loi != nullptr: CHW [128][128*128] copy of IMAGE 0's LOI channels.
-// ta8 != nullptr: [B][128*128][8], thin0..3 | aux0..3 pixel-major (what stage 1 samples on the device path).
-void launch_s0_decode(const float* head, float* lines_pred, float* jloc, float* jnms, float* joff, float* thin, float* aux, float* loi,
-                      float* ta8, int B, size_t stage_stride, hipStream_t st);
+// ta8 != nullptr: [B][128*128][8], thin0..3 | aux0..3 pixel-major (what stage 1 samples on the device path).  head [B][128*128][ld], the 17
+// decoded channels from column off (fused 145-channel head: ld 160, off 128; the 17-channel head: ld 32, off 0).
+void launch_s0_decode(const float* head, int ld, int off, float* lines_pred, float* jloc, float* jnms, float* joff, float* thin, float* aux,
+                      float* loi, float* ta8, int B, size_t stage_stride, hipStream_t st);
 // rows (score, x, y) of the junction top-K, sel [B][sel_cap][259], n_sel [B] -> juncs_pred [jn][2] in the stage block
 void launch_s0_juncs(const float* sel, const int* n_sel, const float* joff, float* juncs, int jn, int sel_cap, int B, size_t stage_stride,
                      hipStream_t st);

@@ -293,8 +293,11 @@ struct S1Loi {                       // where image b's LOI feature (channel ch,
 // of the same 496 products + bias: ~1e-7 relative, the golden outputs of the real graph are pinned at 5e-5).  A third of the MFMAs of
 // the whole head and half of its activation tile are gone.  8 junctions per workgroup; thread = (feature n, half h), fmaf chain in k order.
 constexpr int S1_PJ = 8;
+// LOI features of a junction: sampled from the fused head's rows (head, pitch ps: one image per call in practice), or combined from the four
+// tap rows lrows [B][jn][4][128] that the gather GEMM made for exactly these taps (s1_junc_rows_kernel lists them; same bil_eval).
 __global__ __launch_bounds__(256) void s1_junc_proj_kernel(const float* __restrict__ juncs, const float* __restrict__ head, size_t head_img,
-                                                           int ps, int jn, const float* __restrict__ w0t /*[496][128]*/,
+                                                           int ps, const float* __restrict__ lrows, int jn,
+                                                           const float* __restrict__ w0t /*[496][128]*/,
                                                            float* __restrict__ proj /*[B][jn][256]*/, size_t stage_stride) {
   __shared__ float fs[S1_PJ][128];
   const int t = threadIdx.x, n = t & 127, h = t >> 7, j0 = blockIdx.x * S1_PJ;
@@ -302,7 +305,13 @@ __global__ __launch_bounds__(256) void s1_junc_proj_kernel(const float* __restri
   const float* jp = juncs + img * stage_stride;
   for (int q = h; q < S1_PJ; q += 2) {
     const int j = min(j0 + q, jn - 1);
-    fs[q][n] = bil_plane(head + img * head_img + n, 128, 128, ps, jp[j * 2], jp[j * 2 + 1]);
+    if (lrows) {
+      const BilTap bt = bil_setup(128, 128, jp[j * 2], jp[j * 2 + 1]);
+      const float* r = lrows + ((img * jn + j) * 4) * 128 + n;
+      fs[q][n] = bil_eval(r[0], r[128], r[256], r[384], bt);
+    } else {
+      fs[q][n] = bil_plane(head + img * head_img + n, 128, 128, ps, jp[j * 2], jp[j * 2 + 1]);
+    }
   }
   __syncthreads();
   float acc[S1_PJ];
@@ -318,6 +327,27 @@ __global__ __launch_bounds__(256) void s1_junc_proj_kernel(const float* __restri
 #pragma unroll
   for (int q = 0; q < S1_PJ; ++q)
     if (j0 + q < jn) proj[((img * jn + j0 + q) * 2 + h) * 128 + n] = acc[q];
+}
+
+// rows of the line-feature matrix [B][128*128][128] that the junctions' bilinear taps read, in bil_eval's order (i00, i10, i01, i11):
+// the row list of the LOI head's gather GEMM — the head is computed at the <= 1200 pixels per image that are read, not at all 16384
+__global__ void s1_junc_rows_kernel(const float* __restrict__ juncs, int jn, int* __restrict__ ridx, size_t stage_stride) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= jn) return;
+  const size_t img = blockIdx.y;
+  const float* jp = juncs + img * stage_stride + j * 2;
+  const BilTap bt = bil_setup(128, 128, jp[0], jp[1]);
+  int* o = ridx + (img * jn + j) * 4;
+  const int base = (int)img * 128 * 128;
+  o[0] = base + bt.i00; o[1] = base + bt.i10; o[2] = base + bt.i01; o[3] = base + bt.i11;
+}
+void launch_s1_junc_rows(const float* juncs, int jn, int* ridx, int B, size_t stage_stride, hipStream_t st) {
+  hipLaunchKernelGGL(s1_junc_rows_kernel, dim3((jn + 63) / 64, B), dim3(64), 0, st, juncs, jn, ridx, stage_stride);
+}
+void launch_s1_junc_proj(const float* juncs, const float* head, size_t head_img, int ps, const float* lrows, int jn, const float* w0t,
+                         float* proj, int B, size_t stage_stride, hipStream_t st) {
+  hipLaunchKernelGGL(s1_junc_proj_kernel, dim3((jn + S1_PJ - 1) / S1_PJ, B), dim3(256), 0, st, juncs, head, head_img, ps, lrows, jn, w0t, proj,
+                     stage_stride);
 }
 
 // PRE: the device path (junction projections + pixel-major thin / aux: 240-row activation tile, 4 workgroups per CU); !PRE: the contract's
@@ -508,29 +538,23 @@ extern "C" int airfe_dbg_s1(unsigned long long* out, int reset) {
 namespace airfe {
 #endif
 
-// loi: the contract's CHW block of the stage (loi_ps = 1, loi_cs = 128 * 128, loi_img = stage_stride; thin / aux: the stage's CHW planes)
-// or the head GEMM's rows (loi_ps = row pitch, loi_cs = 1, loi_img = 128 * 128 * pitch, jfeat = [B][300][128] floats of scratch: the
-// junctions' LOI features are sampled into it first, thin / aux are read from the rows' columns 137..144).
+// proj != nullptr (the device path): [B][300][256] junction projections (launch_s1_junc_proj) + ta8 [B][128*128][8] thin | aux pixel-major
+// (launch_s0_decode); loi / thin / aux are not used.  proj == nullptr: the contract's CHW tensors — loi [128][128*128] (one image: loi_img
+// = 0), thin / aux the stage's CHW planes — all 496 features per line.
 // keep [B][keep_cap], pairs / rep / lines_adjusted / scores_line [B][line_cap].
 void launch_plnet_s1(const float* juncs, const float* lines_pred, const int* keep, const int* pairs, const int* rep,
-                     const int* counts, const float* loi, size_t loi_img, int loi_cs, int loi_ps, float* jfeat, const float* ta8, const float* thin,
+                     const int* counts, const float* loi, size_t loi_img, const float* proj, const float* ta8, const float* thin,
                      const float* aux, const float* const* w, float* lines_adjusted, float* scores_line, int keep_cap, int line_cap, int B,
                      size_t stage_stride, hipStream_t st) {
   S1Weights sw{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10]};
-  S1Loi sl{loi, loi_img, loi_cs, loi_ps, nullptr, 300, nullptr};
-  static const bool use_jfeat = !(getenv("AIRFE_S1_JFEAT") && atoi(getenv("AIRFE_S1_JFEAT")) == 0);
+  S1Loi sl{loi, loi_img, 128 * 128, 1, proj, 300, ta8};
   const int gx = B == 1 ? 512 : (B <= 8 ? 128 : 64);
-  if (jfeat && ta8 && loi_cs == 1 && use_jfeat) {
-    hipLaunchKernelGGL(s1_junc_proj_kernel, dim3((300 + S1_PJ - 1) / S1_PJ, B), dim3(256), 0, st, juncs, loi, loi_img, loi_ps, 300, w[0], jfeat,
-                       stage_stride);
-    sl.jfeat = jfeat;
-    sl.ta8 = ta8;
+  if (proj && ta8)
     hipLaunchKernelGGL(plnet_s1_kernel<true>, dim3(gx, B), dim3(256), 0, st, juncs, lines_pred, keep, pairs, rep, counts, sl, thin, aux, sw,
                        lines_adjusted, scores_line, keep_cap, line_cap, stage_stride);
-    return;
-  }
-  hipLaunchKernelGGL(plnet_s1_kernel<false>, dim3(gx, B), dim3(256), 0, st, juncs, lines_pred, keep, pairs, rep, counts, sl, thin, aux, sw,
-                     lines_adjusted, scores_line, keep_cap, line_cap, stage_stride);
+  else
+    hipLaunchKernelGGL(plnet_s1_kernel<false>, dim3(gx, B), dim3(256), 0, st, juncs, lines_pred, keep, pairs, rep, counts, sl, thin, aux, sw,
+                       lines_adjusted, scores_line, keep_cap, line_cap, stage_stride);
 }
 
 // =============================================================================== line filter + junction map

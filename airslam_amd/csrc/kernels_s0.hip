@@ -15,7 +15,6 @@ namespace airfe {
 constexpr int S0_F = 128;                 // feature-map side (512 / 4)
 constexpr int S0_NPX = S0_F * S0_F;
 constexpr int S0_LD = 160;                // row pitch of the fused head GEMM output (145 valid)
-constexpr int S0_HEAD = 128;              // first non-LOI channel
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -23,13 +22,14 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 __global__ __launch_bounds__(256) void s0_decode_kernel(const float* __restrict__ head /*[NPX][S0_LD]*/, float* __restrict__ lines_pred /*[3*NPX][4]*/,
                                                         float* __restrict__ jloc /*[NPX]*/, float* __restrict__ joff /*[2][NPX]*/,
                                                         float* __restrict__ thin /*[4][NPX]*/, float* __restrict__ aux /*[4][NPX]*/,
-                                                        float* __restrict__ ta8 /*[B][NPX][8] or nullptr*/, size_t stage_stride) {
+                                                        float* __restrict__ ta8 /*[B][NPX][8] or nullptr*/, size_t stage_stride, int ld,
+                                                        int off) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= S0_NPX) return;
   const size_t img = blockIdx.y;                 // one image per grid row: head / jloc / joff are dense per image, the rest sits in its stage block
-  head += img * S0_NPX * S0_LD; jloc += img * S0_NPX; joff += img * 2 * S0_NPX;
+  head += img * S0_NPX * ld; jloc += img * S0_NPX; joff += img * 2 * S0_NPX;
   lines_pred += img * stage_stride; thin += img * stage_stride; aux += img * stage_stride;
-  const float* o = head + (size_t)p * S0_LD + S0_HEAD;
+  const float* o = head + (size_t)p * ld + off;             // md0..2 dis res | jloc0 jloc1 | joffx joffy | thin0..3 | aux0..3
   const float4 a = *reinterpret_cast<const float4*>(o), b = *reinterpret_cast<const float4*>(o + 4), c4 = *reinterpret_cast<const float4*>(o + 8),
                d4 = *reinterpret_cast<const float4*>(o + 12);
   const float o16 = o[16];
@@ -233,12 +233,13 @@ __global__ __launch_bounds__(256) void s0_j2l_grid_kernel(const float* __restric
   }
 }
 
-// B images per launch (grid.y): head [B][NPX][160], jloc / jnms [B][NPX], joff [B][2][NPX] dense; lines_pred, thin, aux, loi, juncs, iskeep,
+// B images per launch (grid.y): head [B][NPX][ld] with the 17 decoded channels from column off (the fused 145-channel head: ld 160, off 128;
+// the 17-channel head of the batched path: ld 32, off 0), jloc / jnms [B][NPX], joff [B][2][NPX] dense; lines_pred, thin, aux, loi, juncs, iskeep,
 // imin, imax are image 0's pointers into its stage block, image b's are stage_stride floats further.  loi != nullptr: the contract's CHW
-// copy of IMAGE 0's LOI features (the line path itself samples them from the head rows, launch_plnet_s1).
-void launch_s0_decode(const float* head, float* lines_pred, float* jloc, float* jnms, float* joff, float* thin, float* aux, float* loi,
-                      float* ta8, int B, size_t stage_stride, hipStream_t st) {
-  hipLaunchKernelGGL(s0_decode_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, head, lines_pred, jloc, joff, thin, aux, ta8, stage_stride);
+// copy of IMAGE 0's LOI features out of the fused head's rows (pitch 160).
+void launch_s0_decode(const float* head, int ld, int off, float* lines_pred, float* jloc, float* jnms, float* joff, float* thin, float* aux,
+                      float* loi, float* ta8, int B, size_t stage_stride, hipStream_t st) {
+  hipLaunchKernelGGL(s0_decode_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, head, lines_pred, jloc, joff, thin, aux, ta8, stage_stride, ld, off);
   hipLaunchKernelGGL(s0_jnms_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, jloc, jnms);
   if (loi) hipLaunchKernelGGL(s0_loi_chw_kernel, dim3(S0_NPX / 32), dim3(256), 0, st, head, loi);
 }
