@@ -37,10 +37,14 @@ def test_default_workload_line():
     assert cb["kind"] == "port" and cb["unit"] == "pairs/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
 
 
-@pytest.mark.parametrize("args", [("--matcher", "superglue", "--pairs", "4"), ("--detector", "plnet", "--pairs", "2"),
-                                  ("--workload", "loop", "--pairs", "8")], ids=["superglue", "plnet", "loop"])
+@pytest.mark.parametrize("args", [("--matcher", "superglue", "--pairs", "4"), ("--detector", "plnet", "--pairs", "4"),
+                                  ("--detector", "plnet", "--plnet-host", "--pairs", "2"), ("--workload", "loop", "--pairs", "8")],
+                         ids=["superglue", "plnet", "plnet_host", "loop"])
 def test_side_workload_lines(args):
     d = _run(*args, "--steps", "2", "--warmup", "1", "--cpu-pairs", "0")
     assert d["unit"] == "pairs/s" and d["value"] > 0 and d["steps"] == 2 and "workload" in d["config"]
-    if "plnet" in args:
+    if "--plnet-host" in args:
         assert d["config"]["lines_last_frame"] >= 50          # the structured synthetic line head: lines survive the reference's thresholds
+    elif "plnet" in args:
+        assert d["config"]["lines_mean"] >= 50 and d["config"]["junctions_mean_left"] >= 50 and d["config"]["matches_mean"] > 50
+        assert "plnet_stage1" in d["stages"] and "plnet_s0_decode" in d["stages"]
