@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: stereo detect+match pairs/s/GPU @752x480 (BASELINE.json `metric`).
 
-A step = one pass of the hot path (2x SuperPoint-VGG detect + 1x LightGlue match, 512x512 internal resolution as the
-reference does, src/plnet.cpp:17-21) over one batch of `--pairs` synthetic stereo pairs that are already resident in
-HBM.  One process per GPU; ranks shard pairs (weak scaling) and gather their matches to rank 0 every step.
+A step = one pass of the hot path as the reference's front end runs it on a stereo keyframe (map_builder.cc:85-86:
+`Detect(left, right, features, lines, junctions)` + `MatchingPoints(left, right)`): PLNet on both images — points, the line branch,
+wireframe_matcher, stage 1 and the line filter, junctions + descriptors on the left one (feature_detector.cc:94-104) — and one LightGlue
+match, at the reference's 512x512 internal resolution (src/plnet.cpp:17-21), over one batch of `--pairs` synthetic stereo pairs that
+are already resident in HBM.  `--detector superpoint` is the point-only step (2x SuperPoint-VGG detect + LightGlue: what
+`Detect(left, right, features)` runs with use_superpoint = 1); it is also timed in the default run and reported beside the headline.
+One process per GPU; ranks shard pairs (weak scaling) and gather their matches to rank 0 every step.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -25,10 +29,11 @@ PEAK_MFMA_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROAR
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3):
+def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=0.75, line_length_threshold=50.0):
     """The CPU oracle (PyTorch-CPU fp32 networks + numpy restatement of the reference's C++ post-processing) timed on
     the host cores, on a bounded sample of the same workload: `warm` untimed pairs, then the MEDIAN per-pair time of
-    `n_pairs` pairs (median of >= 20 after 3 warm-ups)."""
+    `n_pairs` pairs (median of >= 20 after 3 warm-ups).  s1 (the stage-1 weights) selects the PLNet step: one trunk
+    pass per image feeding the point heads AND the line branch, wireframe_matcher, stage 1, line filter, junctions on the left."""
     from airslam_amd import synth
     from oracle import ref_nets, ref_post
     torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads than this only adds sync overhead at batch 1
@@ -38,10 +43,26 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3):
     for i, (left, right) in enumerate(pairs):
         t0 = time.perf_counter()
         feats = []
-        for img in (left, right):
+        for side, img in enumerate((left, right)):
             x, ws, hs = ref_post.process_image(img)
-            heat, desc = ref_nets.superpoint_forward(sp, x[None])
-            feats.append(ref_post.keypoints_decoder(ref_post.simple_nms(heat[0], 4), desc[0], 0.004, 4, max_kp, ws, hs))
+            if s1 is None:
+                heat, desc = ref_nets.superpoint_forward(sp, x[None])
+                feats.append(ref_post.keypoints_decoder(ref_post.simple_nms(heat[0], 4), desc[0], 0.004, 4, max_kp, ws, hs))
+                continue
+            with torch.no_grad():
+                taps = {}
+                f = ref_nets.superpoint_trunk(sp, torch.from_numpy(x)[None, None], taps)
+                heat, desc = (t.numpy() for t in ref_nets.superpoint_heads(sp, f))
+            nms = ref_post.simple_nms(heat[0], 4)
+            feats.append(ref_post.keypoints_decoder(nms, desc[0], 0.004, 4, max_kp, ws, hs))
+            s0 = ref_nets.plnet_s0_lines(sp, x, f3a=taps["conv3a"])
+            keep, inv, pr = ref_post.wireframe_matcher(s0["iskeep"], s0["idx_junc_to_end_min"], s0["idx_junc_to_end_max"])
+            la, sc = ref_nets.plnet_s1_forward(s1, s0["juncs_pred"], s0["lines_pred"], pr, inv, keep, s0["loi_features"][0],
+                                               s0["loi_features_thin"][0], s0["loi_features_aux"][0])
+            lines, jmap = ref_post.line_filter(la, sc, 4, line_threshold, line_length_threshold)
+            lines = ref_post.rescale_lines(lines, ws, hs)
+            if side == 0:                                   # junctions on the left image only (feature_detector.cc:100-101)
+                ref_post.junction_detector(nms, desc[0], jmap, 4, ws, hs)
         k = 0
         if feats[0].shape[0] and feats[1].shape[0]:
             a = ref_post.normalize_keypoints(feats[0], w, h, 0.5)
@@ -54,13 +75,14 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3):
     med = float(np.median(times))
     return dict(value=1.0 / med, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"median of {n_pairs} synthetic {w}x{h} stereo pairs after {warm} warm-ups ({sum(times):.1f} s), fp32 PyTorch-CPU "
-                       f"oracle + numpy post-processing, {float(np.mean(nmatch)):.0f} matches per pair")
+                       f"oracle + numpy post-processing ({'PLNet points + lines + junctions' if s1 is not None else 'SuperPoint'} + LightGlue), "
+                       f"{float(np.mean(nmatch)):.0f} matches per pair")
 
 
 def side_workloads(args, rank, world, local, dev):
     """The other configurations of BASELINE.json behind the same contract (one JSON line, K timed steps between barriers):
-    SuperGlue as the matcher (configs[4]), PLNet as the detector (device-resident batch, or --plnet-host: the batch-1 host API), the matcher-only
-    loop-closure replay."""
+    SuperGlue as the matcher (configs[4]; SuperPoint detector), PLNet through the batch-1 host API (--plnet-host), the matcher-only loop-closure
+    replay."""
     import tempfile
     from airslam_amd import api, mapfile, synth, weights
     from airslam_amd import dist as adist
@@ -81,10 +103,7 @@ def side_workloads(args, rank, world, local, dev):
         torch.cuda.synchronize(dev)
 
     root = os.path.dirname(os.path.abspath(__file__))
-    plnet_batched = args.detector == "plnet" and not args.plnet_host
-    if plnet_batched and (sg or args.workload != "stereo"):
-        raise SystemExit("--detector plnet (batched) runs the stereo workload with LightGlue; add --plnet-host for the batch-1 host API")
-    if args.detector == "plnet" and not plnet_batched:
+    if args.plnet_host:
         pairs = [synth.stereo_pair(H, W, 1000 + rank * 64 + i) for i in range(min(B, 8))]
         ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(root, "tests", "golden", "plnet_s1.airfe"),
                           **dict(cfg, max_batch=2, enc_chunk=2), **mkw)
@@ -102,10 +121,7 @@ def side_workloads(args, rank, world, local, dev):
         what = (f"{B} stereo pairs per step through the batch-1 HOST API (PCIe and one sync per call included): 2x PLNet::infer "
                 f"(points + on-device line branch + real stage-1 weights + junctions on the left) + 1x {'SuperGlue' if sg else 'LightGlue'}")
     else:
-        if plnet_batched:
-            ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(root, "tests", "golden", "plnet_s1.airfe"), **cfg, **mkw)
-        else:
-            ctx = api.Context(superpoint=weights.synthetic_superpoint(1234), **cfg, **mkw)
+        ctx = api.Context(superpoint=weights.synthetic_superpoint(1234), **cfg, **mkw)
         ls, rs = synth.stereo_batch(B, H, W, 1000 + rank)
         L, R = torch.from_numpy(ls).to(dev), torch.from_numpy(rs).to(dev)
         fl = torch.zeros((B, K, 259), device=dev); fr = torch.zeros((B, K, 259), device=dev)
@@ -143,17 +159,6 @@ def side_workloads(args, rank, world, local, dev):
             B = B2
             what = (f"matcher only: {B} (query, candidate) frame pairs per step replayed from AirSLAM feature records (loop closure, "
                     f"map_refiner.cc:213-230: each query against its 5 best candidates), {'SuperGlue' if sg else 'LightGlue'}, {K} keypoints max")
-        elif plnet_batched:
-            CL, CJ = 1024, 1024
-            lines = torch.zeros((2 * B, CL, 4), dtype=torch.float64, device=dev); nlines = torch.zeros((2 * B,), dtype=torch.int32, device=dev)
-            junc = torch.zeros((B, CJ, 259), device=dev); njunc = torch.zeros((B,), dtype=torch.int32, device=dev)
-            found = torch.zeros((3 * B,), dtype=torch.int32, device=dev)
-
-            def step():
-                ctx.stereo_plnet_batch_dev(L, R, fl, fr, nl, nr, lines, nlines, junc, njunc, idx, sc, nm, found, stream=sh)
-            what = (f"{B} synthetic {W}x{H} stereo pairs per step per GPU, resident in HBM: ONE PLNet pass over the {2 * B} images (points + "
-                    f"stage-0 line branch + wireframe_matcher + real stage-1 weights + line filter for every image, junction_detector + "
-                    f"descriptors for the left ones) + LightGlue, max_keypoints={K}")
         else:
             def step():
                 ctx.detect_batch_dev(L, fl, nl, stream=sh)
@@ -184,7 +189,7 @@ def side_workloads(args, rank, world, local, dev):
         ctx.profile(False)
     barrier()
     if rank == 0:
-        if args.detector != "plnet" or plnet_batched:
+        if not args.plnet_host:
             if sg:
                 n_match[0] = float((i0 >= 0).sum(1).float().mean())
             else:
@@ -196,15 +201,9 @@ def side_workloads(args, rank, world, local, dev):
                "dtype": args.dtype if args.dtype == args.matcher_dtype else f"{args.dtype} (encoder) + {args.matcher_dtype} (matcher), fp32 accumulate",
                "data": "synthetic",
                "config": {"workload": what + "; seeded synthetic weights (reference ONNX files are absent)", "pairs_per_step_per_gpu": B,
-                          "detector": args.detector, "matcher": args.matcher, "matches_mean": n_match[0]},
+                          "detector": "plnet (batch-1 host API)" if args.plnet_host else "superpoint", "matcher": args.matcher, "matches_mean": n_match[0]},
                "roofline": None, "cpu_baseline": None}
-        if plnet_batched:
-            fh_ = found.cpu().numpy()
-            if (fh_[:2 * B] > CL).any() or (fh_[2 * B:] > CJ).any():
-                raise SystemExit("bench: line / junction capacity overflow")
-            out["config"]["lines_mean"] = float(nlines.float().mean())
-            out["config"]["junctions_mean_left"] = float(njunc.float().mean())
-        elif args.detector == "plnet":
+        if args.plnet_host:
             out["config"]["lines_last_frame"] = lines_n[0]
         if stages:
             tot = sum(v["ms"] for v in stages.values())
@@ -252,9 +251,10 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=20, help="CPU-baseline sample size (0 = skip)")
     ap.add_argument("--matcher", default="lightglue", choices=["lightglue", "superglue"],
                     help="superglue: 18-layer GNN + 100 Sinkhorn iterations (BASELINE configs[4]: --width 1280 --height 720 --max-keypoints 1024)")
-    ap.add_argument("--detector", default="superpoint", choices=["superpoint", "plnet"],
-                    help="plnet: PLNet::infer (points + on-device line branch + stage 1 + line filter, junctions on the left) over the device-resident batch")
-    ap.add_argument("--plnet-host", action="store_true", help="with --detector plnet: the batch-1 HOST API instead (PCIe and one sync per call included)")
+    ap.add_argument("--detector", default="plnet", choices=["superpoint", "plnet"],
+                    help="plnet (default): PLNet::infer on both images (points + line branch + stage 1 + line filter, junctions on the left), the "
+                         "reference's keyframe step; superpoint: the point-only step")
+    ap.add_argument("--plnet-host", action="store_true", help="PLNet + matcher through the batch-1 HOST API instead (PCIe and one sync per call included)")
     ap.add_argument("--workload", default="stereo", choices=["stereo", "loop"],
                     help="loop: matcher only, replaying a map file's feature records (loop closure, map_refiner.cc:213-230)")
     ap.add_argument("--no-profile", action="store_true")
@@ -272,12 +272,14 @@ def main():
     dev = torch.device("cuda", local)
     B, H, W, K = args.pairs, args.height, args.width, args.max_keypoints
 
-    if args.detector == "plnet" or args.matcher == "superglue" or args.workload == "loop":
+    if args.plnet_host or args.matcher == "superglue" or args.workload == "loop":
         return side_workloads(args, rank, world, local, dev)
 
-    sp = weights.synthetic_superpoint(1234)
+    plnet = args.detector == "plnet"
+    s1_path = os.path.join(ROOT, "tests", "golden", "plnet_s1.airfe")      # the REAL stage-1 weights (output/plnet_s1.onnx of the reference)
+    sp = weights.synthetic_plnet_s0(1234) if plnet else weights.synthetic_superpoint(1234)
     lg = weights.synthetic_lightglue(1234)
-    ctx = api.Context(superpoint=sp, lightglue=lg, device=local, precision=1 if args.dtype == "fp16" else 0,
+    ctx = api.Context(superpoint=sp, lightglue=lg, plnet_s1=s1_path if plnet else None, device=local, precision=1 if args.dtype == "fp16" else 0,
                       matcher_precision=1 if args.matcher_dtype == "fp16" else 0, max_batch=B,
                       enc_chunk=args.chunk, max_keypoints=K, image_width=W, image_height=H)
 
@@ -288,11 +290,23 @@ def main():
     idx = torch.zeros((B, K, 2), dtype=torch.int32, device=dev)
     sc = torch.zeros((B, K), device=dev); nm = torch.zeros((B,), dtype=torch.int32, device=dev)
 
+    CL, CJ = 1024, 1024                  # line / junction capacity per image (the true counts come back in `found`: checked below)
+    if plnet:
+        lines = torch.zeros((2 * B, CL, 4), dtype=torch.float64, device=dev); nlines = torch.zeros((2 * B,), dtype=torch.int32, device=dev)
+        junc = torch.zeros((B, CJ, 259), device=dev); njunc = torch.zeros((B,), dtype=torch.int32, device=dev)
+        found = torch.zeros((3 * B,), dtype=torch.int32, device=dev)
+
     stream = torch.cuda.Stream(device=dev)
     sh = stream.cuda_stream
 
-    def step():
+    def points_step():
         ctx.stereo_batch_dev(L, R, fl, fr, nl, nr, idx, sc, nm, stream=sh)
+
+    def step():
+        if plnet:
+            ctx.stereo_plnet_batch_dev(L, R, fl, fr, nl, nr, lines, nlines, junc, njunc, idx, sc, nm, found, stream=sh)
+        else:
+            points_step()
         if world > 1:
             with torch.cuda.stream(stream):
                 adist.gather_matches(idx, sc, nm, dst=0)
@@ -328,12 +342,25 @@ def main():
         stages = ctx.profile_read()
         ctx.profile(False)
     barrier()
+    points_only = None
+    if plnet:                          # the point-only step (Detect(left, right, features) with use_superpoint = 1) on the same context and inputs
+        for _ in range(args.warmup):
+            points_step()
+        barrier()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            points_step()
+        barrier()
+        points_only = B * args.steps * world / adist.max_over_ranks(time.perf_counter() - tp, dev)
+        step()                         # (the counts reported below are the PLNet step's)
+        barrier()
 
     if rank == 0:
         total_pairs = B * args.steps * world
         ms_step = dt / args.steps * 1e3
         out = {
-            "metric": "stereo detect+match pairs/sec (2x SuperPoint-VGG detect @512x512 internal + LightGlue match)",
+            "metric": "stereo detect+match pairs/sec (" + ("2x PLNet @512x512 internal: points + lines, junctions on the left" if plnet
+                                                          else "2x SuperPoint-VGG detect @512x512 internal") + " + LightGlue match)",
             "value": total_pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype if args.dtype == args.matcher_dtype else f"{args.dtype} (encoder) + {args.matcher_dtype} (matcher), fp32 accumulate",
@@ -343,8 +370,19 @@ def main():
                                    f"(reference ONNX files are absent)",
                        "pairs_per_step_per_gpu": B, "internal_resolution": 512, "parallelism": f"frame-sharded x{world}",
                        "keypoints_left_right_mean": [float(nl.float().mean()), float(nr.float().mean())],
-                       "matches_mean": float(nm.float().mean())},
+                       "matches_mean": float(nm.float().mean()), "detector": args.detector},
         }
+        if plnet:
+            fh_ = found.cpu().numpy()
+            if (fh_[:2 * B] > CL).any() or (fh_[2 * B:] > CJ).any():
+                raise SystemExit("bench: line / junction capacity overflow")
+            out["config"]["workload"] += ("; PLNet line branch: published HAWPv3 head with seeded synthetic weights, stage 1 with the REAL weights of "
+                                          "output/plnet_s1.onnx, line_threshold / line_length_threshold at the reference's 0.75 / 50")
+            out["config"]["lines_mean"] = float(nlines.float().mean())
+            out["config"]["junctions_mean_left"] = float(njunc.float().mean())
+            out["config"]["points_only_pairs_per_s"] = points_only
+            out["config"]["points_only_note"] = ("the point-only step (2x detect + LightGlue, airfe_stereo_batch_dev: `--detector superpoint`) timed on the "
+                                                 "same context and inputs over the same number of steps")
         if dom:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
             traffic, tsrc = None, None
@@ -378,7 +416,7 @@ def main():
                                  "algo_gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
                              for k, v in stages.items() if v["launches"]}
         if world == 1 and args.cpu_pairs > 0:
-            out["cpu_baseline"] = cpu_baseline(sp, lg, H, W, args.cpu_pairs, K)
+            out["cpu_baseline"] = cpu_baseline(sp, lg, H, W, args.cpu_pairs, K, s1=weights.load_pack(s1_path) if plnet else None)
         print(json.dumps(out))
     ctx.close()
     if world > 1:

@@ -32,13 +32,17 @@ def _t(a) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ SuperPoint
-def superpoint_trunk(w: W, x: torch.Tensor) -> torch.Tensor:
-    """x [B,1,H,W] in [0,1] -> conv4b activations [B,128,H/8,W/8]."""
+def superpoint_trunk(w: W, x: torch.Tensor, taps: dict = None) -> torch.Tensor:
+    """x [B,1,H,W] in [0,1] -> conv4b activations [B,128,H/8,W/8].  taps (optional dict): receives the conv3a activations
+    [B,128,H/4,W/4], the input of the PLNet line branch (plnet_s0_lines(f3a=...): one trunk pass per image, as the stage-0 engine has)."""
     def c(name, t):
         return Fn.relu(Fn.conv2d(t, _t(w[name + ".weight"]), _t(w[name + ".bias"]), padding=1))
     x = c("conv1a", x); x = c("conv1b", x); x = Fn.max_pool2d(x, 2, 2)
     x = c("conv2a", x); x = c("conv2b", x); x = Fn.max_pool2d(x, 2, 2)
-    x = c("conv3a", x); x = c("conv3b", x); x = Fn.max_pool2d(x, 2, 2)
+    x = c("conv3a", x)
+    if taps is not None:
+        taps["conv3a"] = x
+    x = c("conv3b", x); x = Fn.max_pool2d(x, 2, 2)
     x = c("conv4a", x); x = c("conv4b", x)
     return x
 
@@ -67,7 +71,7 @@ def superpoint_forward(w: W, x: np.ndarray):
 
 
 # ------------------------------------------------------------------ PLNet stage-0 line branch
-def plnet_s0_lines(w: W, x: np.ndarray, topk: int = 300, scale: float = 5.0, j2l: float = 10.0):
+def plnet_s0_lines(w: W, x: np.ndarray, topk: int = 300, scale: float = 5.0, j2l: float = 10.0, f3a: torch.Tensor = None):
     """The stage-0 LINE branch: x [H,W] float32 in [0,1] (512x512) -> dict with the Appendix A.1 tensors
     (`juncs_pred` [300,2], `lines_pred` [3*128*128,4], `iskeep` / `idx_junc_to_end_min` / `idx_junc_to_end_max` [1,3,128,128],
     `loi_features` [1,128,128,128], `loi_features_thin` / `_aux` [1,4,128,128]) plus `jloc` / `joff` maps.
@@ -77,10 +81,13 @@ def plnet_s0_lines(w: W, x: np.ndarray, topk: int = 300, scale: float = 5.0, j2l
     with torch.no_grad():
         def c(name, t):
             return Fn.relu(Fn.conv2d(t, _t(w[name + ".weight"]), _t(w[name + ".bias"]), padding=1))
-        f = _t(x)[None, None]
-        f = c("conv1a", f); f = c("conv1b", f); f = Fn.max_pool2d(f, 2, 2)
-        f = c("conv2a", f); f = c("conv2b", f); f = Fn.max_pool2d(f, 2, 2)
-        f = c("conv3a", f)                                                   # [1,128,128,128]
+        if f3a is None:
+            f = _t(x)[None, None]
+            f = c("conv1a", f); f = c("conv1b", f); f = Fn.max_pool2d(f, 2, 2)
+            f = c("conv2a", f); f = c("conv2b", f); f = Fn.max_pool2d(f, 2, 2)
+            f = c("conv3a", f)                                               # [1,128,128,128]
+        else:
+            f = f3a                                                          # the point branch's own conv3a activations (superpoint_trunk taps)
         f = c("line.conv1", f)
         o = Fn.conv2d(f, _t(w["line.head.weight"])[:, :, None, None], _t(w["line.head.bias"]))[0]    # [145,128,128]
         loi, h = o[:128], o[128:]

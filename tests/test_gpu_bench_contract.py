@@ -29,6 +29,10 @@ def test_default_workload_line():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "fp16"
     assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["matches_mean"] > 50
+    # the default workload is the reference's keyframe step: PLNet with lines and junctions (map_builder.cc:85-86)
+    assert d["config"]["detector"] == "plnet" and d["config"]["lines_mean"] >= 50 and d["config"]["junctions_mean_left"] >= 50
+    assert d["config"]["points_only_pairs_per_s"] > d["value"]
+    assert "plnet_stage1" in d["stages"] and "plnet_s0_decode" in d["stages"]
     rf = d["roofline"]
     assert rf["bound"] in ("mfma", "hbm") and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
     assert 0.0 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
@@ -37,14 +41,13 @@ def test_default_workload_line():
     assert cb["kind"] == "port" and cb["unit"] == "pairs/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
 
 
-@pytest.mark.parametrize("args", [("--matcher", "superglue", "--pairs", "4"), ("--detector", "plnet", "--pairs", "4"),
-                                  ("--detector", "plnet", "--plnet-host", "--pairs", "2"), ("--workload", "loop", "--pairs", "8")],
-                         ids=["superglue", "plnet", "plnet_host", "loop"])
+@pytest.mark.parametrize("args", [("--matcher", "superglue", "--pairs", "4"), ("--detector", "superpoint", "--pairs", "4"),
+                                  ("--plnet-host", "--pairs", "2"), ("--workload", "loop", "--pairs", "8")],
+                         ids=["superglue", "superpoint", "plnet_host", "loop"])
 def test_side_workload_lines(args):
     d = _run(*args, "--steps", "2", "--warmup", "1", "--cpu-pairs", "0")
     assert d["unit"] == "pairs/s" and d["value"] > 0 and d["steps"] == 2 and "workload" in d["config"]
     if "--plnet-host" in args:
         assert d["config"]["lines_last_frame"] >= 50          # the structured synthetic line head: lines survive the reference's thresholds
-    elif "plnet" in args:
-        assert d["config"]["lines_mean"] >= 50 and d["config"]["junctions_mean_left"] >= 50 and d["config"]["matches_mean"] > 50
-        assert "plnet_stage1" in d["stages"] and "plnet_s0_decode" in d["stages"]
+    elif "superpoint" in args:
+        assert d["config"]["detector"] == "superpoint" and "lines_mean" not in d["config"] and d["config"]["matches_mean"] > 50
