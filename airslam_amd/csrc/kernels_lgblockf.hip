@@ -14,7 +14,9 @@
 //
 // One workgroup = one pass over 128 tokens.  (Dealing the token tiles out evenly over 256 persistent workgroups in passes of
 // 6-7 tiles — 51200 tokens are 400 fixed tiles on 256 CUs, a second round for 144 of them — measured the same: with every CU
-// in the same phase at the same time the passes do not get shorter in proportion to their tokens.)
+// in the same phase at the same time the passes do not get shorter in proportion to their tokens.  Round 2 tried the cheap form of the
+// same idea — workgroups 0..255 with 112 tokens, the second round's 235 with 96 — and measured 1.91 -> 1.90 / 1.94 -> 1.88 ms of linears
+// per step on one box: noise; not kept.)
 //
 // What the per-phase timers said (round 1, 128-token pass, us): attn 3.0 | out-proj 3.9 | ffn.0 5.1 + 1.6 + 4.0 | LN sums 2.9
 // | GELU 10.3 | ffn.3 4.7 | epilogue 2.6.  Removing the LDS reads changes nothing, removing the weight loads 10 %: the GEMMs
