@@ -1246,12 +1246,14 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
   const int NP = KEEP_CAP, F = 128;
   float* d = c->s0_stage;
   // Two forms of the 1x1 head.  FUSED (fp32 mode, inspection hook; one image): all 145 channels at every pixel -> l_head [128*128][160].
-  // SPLIT (everything else): the 17 decoded channels at every pixel -> l_dec [nb][128*128][32]; the 128 LOI channels — read only at the four
+  // SPLIT (everything else): the 17 decoded channels at every pixel, decoded in the same pass (or, AIRFE_FUSE_DEC=0, -> l_dec [nb][128*128][32]
+  // and a decode pass of its own); the 128 LOI channels — read only at the four
   // bilinear taps of the <= 300 junctions — by a gather GEMM over those <= 1200 rows per image once the junctions are known (line_tail_dev):
   // the fused head wrote 1.07 GB of LOI features per 128 images to read 7 % of them.  Same kernel, same K order: the same bits.
   const bool fused = c->prec == 2 || chw;
   if (fused && (nb != 1 || i0 != 0)) return fail(c, "the fused line head (fp32 mode, inspection hook) runs one image at a time");
   c->line_sparse = !fused;
+  bool head_done = false;
   if (c->prec == 2) {
     launch_conv3x3_f32(c->f3a, c->f_cL1.w, c->f_cL1.b, c->fL1, 1, F, F, 128, 128, 0, st);
     GemmF32Args g;
@@ -1260,19 +1262,27 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
   } else {
     // conv3a features (zero-bordered NHWC, still in the arena for the whole batch) -> [nb * 128*128][128]
     run_conv(c, c->cL1, c->a3a + (size_t)i0 * (F + 2) * (F + 2) * 128, c->l_feat, nb, F, F, 0, 0, st);
-    const LinW& hw = fused ? c->cLh : c->cLh_dec;
-    GemmArgs g;
-    g.X1 = c->l_feat; g.ld1 = 128; g.K1 = 128; g.Wp = hw.w; g.bias = hw.b;
-    g.M = nb * F * F; g.N = hw.N; g.cb_total = hw.cbt; g.epi = EPI_STORE_F32; g.out = fused ? c->l_head : c->l_dec; g.ldo = fused ? 160 : 32;
-    g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-    static const bool dec_small = !(getenv("AIRFE_DEC_SMALL") && atoi(getenv("AIRFE_DEC_SMALL")) == 0);
-    if (!fused && dec_small) g.small_max = 1 << 30;      // one 64-feature block: the no-LDS kernel computes 64 columns per row instead of the tiled kernels' 256
-    ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * nb * F * F * 128 * hw.N, (double)nb * F * F * (256 + 4.0 * g.ldo));
-    launch_gemm(c->prec, 128, false, g, st);
+    static const bool fuse_dec = !(getenv("AIRFE_FUSE_DEC") && atoi(getenv("AIRFE_FUSE_DEC")) == 0);
+    if (!fused && fuse_dec) {        // the 17-channel head and its decode in one pass over the line features (kernels_s0.hip)
+      ProfScope ps(c, ST_PL_DECODE, st, 2.0 * nb * F * F * 128 * 17, (double)nb * F * F * (256 + 92));
+      launch_s0_head_decode(c->prec, c->l_feat, c->cLh_dec.w, c->cLh_dec.b, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, c->l_ta8, nb, SG_STRIDE, st);
+      head_done = true;
+    } else {
+      const LinW& hw = fused ? c->cLh : c->cLh_dec;
+      GemmArgs g;
+      g.X1 = c->l_feat; g.ld1 = 128; g.K1 = 128; g.Wp = hw.w; g.bias = hw.b;
+      g.M = nb * F * F; g.N = hw.N; g.cb_total = hw.cbt; g.epi = EPI_STORE_F32; g.out = fused ? c->l_head : c->l_dec; g.ldo = fused ? 160 : 32;
+      g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
+      if (!fused) g.small_max = 1 << 30;      // one 64-feature block: the no-LDS kernel computes 64 columns per row instead of the tiled kernels' 256
+      ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * nb * F * F * 128 * hw.N, (double)nb * F * F * (256 + 4.0 * g.ldo));
+      launch_gemm(c->prec, 128, false, g, st);
+    }
   }
   // head rows read once, 49152 proposals + maps written; the j2l match reads them again
   ProfScope ps(c, ST_PL_DECODE, st, 0, (double)nb * (128.0 * 128 * (17 * 4 + 3 * 16 + 11 * 4) + 3.0 * 49152 * (16 + 12)));
-  if (fused)
+  if (head_done) {
+    // (lines_pred, jloc, jnms, joff and the pixel-major thin | aux are already there)
+  } else if (fused)
     launch_s0_decode(c->l_head, 160, 128, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, chw ? c->s0_loi : nullptr, c->l_ta8, nb,
                      SG_STRIDE, st);
   else

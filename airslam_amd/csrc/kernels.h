@@ -237,6 +237,10 @@ void launch_ln_gelu_f32(float* h, const float* gamma, const float* beta, int M, 
 // decoded channels from column off (fused 145-channel head: ld 160, off 128; the 17-channel head: ld 32, off 0).
 void launch_s0_decode(const float* head, int ld, int off, float* lines_pred, float* jloc, float* jnms, float* joff, float* thin, float* aux,
                       float* loi, float* ta8, int B, size_t stage_stride, hipStream_t st);
+// the 17-channel head and its decode in one pass (the batched path): X [B*128*128][128] 2-byte line features, Wp / bias the packed head;
+// writes lines_pred (stage), jloc / jnms / joff, ta8 — not the contract's CHW thin / aux planes
+void launch_s0_head_decode(int prec, const uint16_t* X, const uint16_t* Wp, const float* bias, float* lines_pred, float* jloc, float* jnms,
+                           float* joff, float* ta8, int B, size_t stage_stride, hipStream_t st);
 // rows (score, x, y) of the junction top-K, sel [B][sel_cap][259], n_sel [B] -> juncs_pred [jn][2] in the stage block
 void launch_s0_juncs(const float* sel, const int* n_sel, const float* joff, float* juncs, int jn, int sel_cap, int B, size_t stage_stride,
                      hipStream_t st);

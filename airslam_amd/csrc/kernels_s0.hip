@@ -7,6 +7,8 @@
 // and the decode kernels of this file.  Contract and layouts are the reference's (names, shapes, the [3][128][128] proposal
 // order, float-typed junction indices); the WEIGHTS are seeded synthetic ones, parity = against the oracle restatement
 // (oracle/ref_nets.py::plnet_s0_lines), UNPINNED against the missing model.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -18,8 +20,32 @@ constexpr int S0_LD = 160;                // row pitch of the fused head GEMM ou
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// per feature-map pixel: HAFM decoding (3 proposals: residual sign -1, 0, +1), junction probability / offset maps, thin / aux CHW
-__global__ __launch_bounds__(256) void s0_decode_kernel(const float* __restrict__ head /*[NPX][S0_LD]*/, float* __restrict__ lines_pred /*[3*NPX][4]*/,
+// The per-pixel decode, shared by the two kernels that run it (one expression each: the same bits from either).
+// hafm_decoding: md_un = (md0 - 0.5) 2 pi; st_un = md1 pi/2; ed_un = -md2 pi/2; scale = 5; 3 proposals = residual sign -1, 0, +1
+__device__ __forceinline__ void s0_hafm(float o_md0, float o_md1, float o_md2, float o_dis, float o_res, int p, float4 (&l)[3]) {
+  const float md0 = sigmoidf_(o_md0), md1 = sigmoidf_(o_md1), md2 = sigmoidf_(o_md2), dis = sigmoidf_(o_dis), res = sigmoidf_(o_res);
+  const float PI = 3.14159265358979323846f;
+  const float md_un = (md0 - 0.5f) * PI * 2.0f, st_un = md1 * PI / 2.0f, ed_un = -md2 * PI / 2.0f;
+  const float cs = cosf(md_un), ss = sinf(md_un), yst = tanf(st_un), yed = tanf(ed_un);
+  const float x0 = (float)(p & (S0_F - 1)), y0 = (float)(p >> 7);
+  const float lim = (float)(S0_F - 1);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const float d = fminf(fmaxf(dis + res * (float)(s - 1), 0.f), 1.f);
+    const float xs = (cs - ss * yst) * d * 5.0f, ys = (ss + cs * yst) * d * 5.0f;
+    const float xe = (cs - ss * yed) * d * 5.0f, ye = (ss + cs * yed) * d * 5.0f;
+    l[s].x = fminf(fmaxf(xs + x0, 0.f), lim); l[s].y = fminf(fmaxf(ys + y0, 0.f), lim);
+    l[s].z = fminf(fmaxf(xe + x0, 0.f), lim); l[s].w = fminf(fmaxf(ye + y0, 0.f), lim);
+  }
+}
+// jloc = softmax(o5, o6)[1]
+__device__ __forceinline__ float s0_jloc(float o5, float o6) {
+  const float mx = fmaxf(o5, o6), e0 = expf(o5 - mx), e1 = expf(o6 - mx);
+  return e1 / (e0 + e1);
+}
+
+// per feature-map pixel: HAFM decoding, junction probability / offset maps, thin / aux CHW (+ pixel-major)
+__global__ __launch_bounds__(256) void s0_decode_kernel(const float* __restrict__ head /*[NPX][ld]*/, float* __restrict__ lines_pred /*[3*NPX][4]*/,
                                                         float* __restrict__ jloc /*[NPX]*/, float* __restrict__ joff /*[2][NPX]*/,
                                                         float* __restrict__ thin /*[4][NPX]*/, float* __restrict__ aux /*[4][NPX]*/,
                                                         float* __restrict__ ta8 /*[B][NPX][8] or nullptr*/, size_t stage_stride, int ld,
@@ -33,10 +59,7 @@ __global__ __launch_bounds__(256) void s0_decode_kernel(const float* __restrict_
   const float4 a = *reinterpret_cast<const float4*>(o), b = *reinterpret_cast<const float4*>(o + 4), c4 = *reinterpret_cast<const float4*>(o + 8),
                d4 = *reinterpret_cast<const float4*>(o + 12);
   const float o16 = o[16];
-  const float md0 = sigmoidf_(a.x), md1 = sigmoidf_(a.y), md2 = sigmoidf_(a.z), dis = sigmoidf_(a.w), res = sigmoidf_(b.x);
-  // jloc = softmax(o5, o6)[1]; joff = sigmoid - 0.5
-  const float mx = fmaxf(b.y, b.z), e0 = expf(b.y - mx), e1 = expf(b.z - mx);
-  jloc[p] = e1 / (e0 + e1);
+  jloc[p] = s0_jloc(b.y, b.z);
   joff[p] = sigmoidf_(b.w) - 0.5f;
   joff[S0_NPX + p] = sigmoidf_(c4.x) - 0.5f;
   thin[p] = c4.y; thin[S0_NPX + p] = c4.z; thin[2 * S0_NPX + p] = c4.w; thin[3 * S0_NPX + p] = d4.x;
@@ -46,21 +69,83 @@ __global__ __launch_bounds__(256) void s0_decode_kernel(const float* __restrict_
     t8[0] = make_float4(c4.y, c4.z, c4.w, d4.x);
     t8[1] = make_float4(d4.y, d4.z, d4.w, o16);
   }
-  // hafm_decoding: md_un = (md0 - 0.5) 2 pi; st_un = md1 pi/2; ed_un = -md2 pi/2; scale = 5
-  const float PI = 3.14159265358979323846f;
-  const float md_un = (md0 - 0.5f) * PI * 2.0f, st_un = md1 * PI / 2.0f, ed_un = -md2 * PI / 2.0f;
-  const float cs = cosf(md_un), ss = sinf(md_un), yst = tanf(st_un), yed = tanf(ed_un);
-  const float x0 = (float)(p & (S0_F - 1)), y0 = (float)(p >> 7);
-  const float lim = (float)(S0_F - 1);
+  float4 l[3];
+  s0_hafm(a.x, a.y, a.z, a.w, b.x, p, l);
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const float d = fminf(fmaxf(dis + res * (float)(s - 1), 0.f), 1.f);
-    const float xs = (cs - ss * yst) * d * 5.0f, ys = (ss + cs * yst) * d * 5.0f;
-    const float xe = (cs - ss * yed) * d * 5.0f, ye = (ss + cs * yed) * d * 5.0f;
-    float4 l;
-    l.x = fminf(fmaxf(xs + x0, 0.f), lim); l.y = fminf(fmaxf(ys + y0, 0.f), lim);
-    l.z = fminf(fmaxf(xe + x0, 0.f), lim); l.w = fminf(fmaxf(ye + y0, 0.f), lim);
-    *reinterpret_cast<float4*>(lines_pred + ((size_t)s * S0_NPX + p) * 4) = l;
+  for (int s = 0; s < 3; ++s) *reinterpret_cast<float4*>(lines_pred + ((size_t)s * S0_NPX + p) * 4) = l[s];
+}
+
+// The 17-channel 1x1 head AND its decode in one pass over the line features (the batched path): a wave takes 16 pixels at a time, multiplies
+// their 128 features by the head's first 64-feature block exactly as gemm_small_kernel does (same packed slabs, same fragments, K in
+// ascending 32-wide steps from zero, bias added after the sum: the same bits as every GEMM kernel of this library), and decodes straight
+// from the accumulators: lane group g = lane / 16 of pixel l15 holds channels 8g .. 8g+7, so group 0 has md0..2 dis res jloc0 jloc1 (+ joffx)
+// and does the HAFM decode + jloc, group 1 has joffy thin0..3 aux0..2 (+ joffx from group 0, aux3 from group 2 by lane shuffles) and writes
+// joff + the pixel-major thin | aux.  The separate form moved 537 MB in, 268 MB out (no-LDS GEMM, 2.4 TB/s) and 284 MB in, 260 MB out
+// (decode) per 128 images; this one 537 MB in, 193 MB out — the CHW thin / aux planes of the contract are not written (only the
+// host-tensor path and the inspection hook read them, and those run the fused head + s0_decode_kernel).
+template <class P>
+__global__ __launch_bounds__(256) void s0_head_decode_kernel(const uint16_t* __restrict__ X /*[ntiles*16][128]*/, const uint16_t* __restrict__ Wp,
+                                                             const float* __restrict__ bias, int ntiles, float* __restrict__ lines_pred,
+                                                             float* __restrict__ jloc, float* __restrict__ joff, float* __restrict__ ta8,
+                                                             size_t stage_stride) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const char* wbase = reinterpret_cast<const char*>(Wp);
+  typename P::vec8 wf[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int rr = u * 16 + l15;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      wf[u][ks] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(
+          wbase + (ks >> 1) * SLAB_BYTES + rr * 128 + ((((ks & 1) * 4 + g) ^ swz128(rr)) << 4)));
+  }
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = bias[g * 8 + e];
+  const int nw = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  typename P::vec8 xn[4];
+  auto fetch = [&](int t) {
+    const uint16_t* xr = X + ((size_t)t * 16 + l15) * 128 + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xn[ks] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(xr + ks * 32));
+  };
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += nw) {
+    typename P::vec8 xf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xf[ks] = xn[ks];
+    if (tile + nw < ntiles) fetch(tile + nw);
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u] = P::mfma(wf[u][ks], xf[ks], acc[u]);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[e] = acc[0][e];
+      f[4 + e] = acc[1][e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += bv[e];
+    const float joffx = __shfl(f[7], l15), aux3 = __shfl(f[0], l15 + 32);
+    const int row = tile * 16 + l15, img = row >> 14, p = row & (S0_NPX - 1);
+    if (g == 0) {
+      float4 l[3];
+      s0_hafm(f[0], f[1], f[2], f[3], f[4], p, l);
+      float* lp = lines_pred + (size_t)img * stage_stride;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) *reinterpret_cast<float4*>(lp + ((size_t)s * S0_NPX + p) * 4) = l[s];
+      jloc[(size_t)img * S0_NPX + p] = s0_jloc(f[5], f[6]);
+    } else if (g == 1) {
+      float* jo = joff + (size_t)img * 2 * S0_NPX;
+      jo[p] = sigmoidf_(joffx) - 0.5f;
+      jo[S0_NPX + p] = sigmoidf_(f[0]) - 0.5f;
+      float4* t8 = reinterpret_cast<float4*>(ta8 + ((size_t)img * S0_NPX + p) * 8);
+      t8[0] = make_float4(f[1], f[2], f[3], f[4]);
+      t8[1] = make_float4(f[5], f[6], f[7], aux3);
+    }
   }
 }
 
@@ -242,6 +327,17 @@ void launch_s0_decode(const float* head, int ld, int off, float* lines_pred, flo
   hipLaunchKernelGGL(s0_decode_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, head, lines_pred, jloc, joff, thin, aux, ta8, stage_stride, ld, off);
   hipLaunchKernelGGL(s0_jnms_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, jloc, jnms);
   if (loi) hipLaunchKernelGGL(s0_loi_chw_kernel, dim3(S0_NPX / 32), dim3(256), 0, st, head, loi);
+}
+// X [B * 128*128][128] line features (2-byte), Wp / bias: the packed 17-channel head (its first 64-feature block); jnms = 3x3 NMS of jloc
+void launch_s0_head_decode(int prec, const uint16_t* X, const uint16_t* Wp, const float* bias, float* lines_pred, float* jloc, float* jnms,
+                           float* joff, float* ta8, int B, size_t stage_stride, hipStream_t st) {
+  const int ntiles = B * S0_NPX / 16;
+  const int wgs = std::min(ntiles / 4, 256 * 16);
+  if (prec == 1)
+    hipLaunchKernelGGL(s0_head_decode_kernel<PF16>, dim3(wgs), dim3(256), 0, st, X, Wp, bias, ntiles, lines_pred, jloc, joff, ta8, stage_stride);
+  else
+    hipLaunchKernelGGL(s0_head_decode_kernel<PBF16>, dim3(wgs), dim3(256), 0, st, X, Wp, bias, ntiles, lines_pred, jloc, joff, ta8, stage_stride);
+  hipLaunchKernelGGL(s0_jnms_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, jloc, jnms);
 }
 void launch_s0_juncs(const float* sel, const int* n_sel, const float* joff, float* juncs, int jn, int sel_cap, int B, size_t stage_stride,
                      hipStream_t st) {
