@@ -167,6 +167,9 @@ struct airfe_ctx {
   airfe_cfg cfg;
   std::string err;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;         // airfe_stereo_plnet_batch_dev: the line branch runs here while the matcher runs on the caller's stream
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap_lines = true;             // AIRFE_OVERLAP_LINES=0: one stream
   std::vector<void*> allocs;
   int prec = 0;                  // detector storage type
   int mprec = 1;                 // matcher storage type (cfg.matcher_precision)
@@ -1443,10 +1446,17 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   c->nms_v1 = getenv("AIRFE_NMS_V1") && atoi(getenv("AIRFE_NMS_V1")) != 0;
   c->attn_v1 = getenv("AIRFE_ATTN_V1") && atoi(getenv("AIRFE_ATTN_V1")) != 0;
   c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     delete c;
     return fail(nullptr, "airfe_create: stream creation failed");
   }
+  if (getenv("AIRFE_OVERLAP_LINES")) c->overlap_lines = atoi(getenv("AIRFE_OVERLAP_LINES")) != 0;
   // a context with a detector AND the stereo matcher runs airfe_stereo_batch_dev over left + right images as one detector batch
   c->Dmax = (c->stereo_one_pass && c->prec != 2 && cfg->superpoint_pack && cfg->lightglue_pack) ? 2 * c->Bmax : c->Bmax;
   c->Lmax = c->Dmax;
@@ -1485,6 +1495,9 @@ void airfe_destroy(airfe_ctx* c) {
   for (auto& m : c->marks) { (void)hipEventDestroy(m.a); (void)hipEventDestroy(m.b); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   delete c;
 }
 
@@ -1939,9 +1952,23 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint
   int rc = detect_dev2(c, d_left, d_right, B, h, w, stride, img_stride, d_featL, d_featR, cap, d_nL, d_nR, st);
   c->force_nms_map = false;
   if (rc) return 1;
-  // lines of the 2 B images (left 0 .. B-1, right B .. 2B-1), junctions of the left ones (feature_detector.cc:100-101)
-  if (plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, st)) return 1;
-  return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
+  // lines of the 2 B images (left 0 .. B-1, right B .. 2B-1), junctions of the left ones (feature_detector.cc:100-101).  The line path and
+  // the matcher both start from the detector's results and share nothing else (line arena / candidate list / score and descriptor maps
+  // against the matcher arena): the line path goes to the context's second stream and the two run side by side — a step is ~200 launches,
+  // each with a ramp and a tail that the other chain's workgroups fill.
+  // (With stage timers on anything behind the encoder the chains run one after the other: a stage's event pair must not span the other chain.)
+  const uint32_t enc_only = (1u << ST_PREPROCESS) | (1u << ST_CONV1A) | (1u << ST_CONV3X3_C64);
+  if (!c->overlap_lines || (c->prof_mask & ~enc_only) != 0) {
+    if (plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, st)) return 1;
+    return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
+  }
+  HIPCHK(c, hipEventRecord(c->ev_fork, st));
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+  rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2);
+  if (!rc) rc = lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
+  HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));      // (also after an error: the caller's stream never runs ahead of the side stream)
+  HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+  return rc;
 }
 
 /* the on-device stage-0 line branch of the LAST detected image, copied out in the Appendix A.1 layouts (NULL = skip) */
