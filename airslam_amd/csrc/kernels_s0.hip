@@ -231,29 +231,34 @@ __global__ __launch_bounds__(256) void s0_j2l_kernel(const float* __restrict__ l
   imax[p] = (float)hi;
 }
 
-// The same match for what the line path CONSUMES, 6-10x cheaper (the brute-force kernel above — 49152 proposals x 300 junctions —
+// The same match for what the line path CONSUMES, 8x cheaper (the brute-force kernel above — 49152 proposals x 300 junctions —
 // was 0.63 ms per 128 images): wireframe_matcher (plnet.cpp:272-307) reads idx_junc_to_end_min / _max only where iskeep > 0, and iskeep
-// needs both nearest squared distances below thr (10).  Junctions are binned into 8 x 8-pixel cells (counting sort in LDS, per
-// workgroup) and an endpoint looks at the 3 x 3 cells around its own: a junction outside that block is more than 8 pixels away in x or
-// y (d^2 > 63), so for thr <= 60 iskeep is exact for every proposal and min / max are exact for every KEPT one; entries of proposals that
-// are not kept hold the block's nearest (or 0) instead of the global nearest.  Ties go to the lower junction index explicitly (the cell
-// order is not the index order), which is the brute-force loop's "first minimum".  The inspection hook keeps the brute-force kernel.
-constexpr int J2L_PT = 4;                 // proposals per thread
+// needs both nearest squared distances below thr (10).  Junctions are binned into J2L_CELL x J2L_CELL-pixel cells (counting sort in LDS,
+// per workgroup) and an endpoint looks at the 3 x 3 cells around its own: a junction outside that block is more than J2L_CELL pixels away
+// in x or y, so for thr < J2L_CELL^2 iskeep is exact for every proposal and min / max are exact for every KEPT one; entries of proposals
+// that are not kept hold the block's nearest (or 0) instead of the global nearest.  Ties go to the lower junction index explicitly (the
+// cell order is not the index order), which is the brute-force loop's "first minimum".  The inspection hook keeps the brute-force kernel.
+// (8-pixel cells: ~10 candidates per endpoint, 157 us per 128 images; 4-pixel cells: ~2.6.)
+constexpr int J2L_PT = 4;                 // proposals per thread (1 .. 16 measured the same: the searches dominate, not the binning)
+constexpr int J2L_CELL = 4, J2L_NC = S0_F / J2L_CELL, J2L_CELLS = J2L_NC * J2L_NC, J2L_CPT = J2L_CELLS / 256;
+static_assert(J2L_CELLS % 256 == 0, "cells are dealt out evenly over the 256 threads");
 
 __global__ __launch_bounds__(256) void s0_j2l_grid_kernel(const float* __restrict__ lines_pred, const float* __restrict__ juncs, int jn, int n,
                                                           float thr, float* __restrict__ iskeep, float* __restrict__ imin,
                                                           float* __restrict__ imax, size_t stage_stride) {
   __shared__ float2 sxy[320];
   __shared__ int sj[320];
-  __shared__ int cs[260], fill[256];
+  __shared__ int cs[J2L_CELLS + 4], fill[J2L_CELLS];
   __shared__ int wtot[4];
   {
     const size_t o = (size_t)blockIdx.y * stage_stride;
     lines_pred += o; juncs += o; iskeep += o; imin += o; imax += o;
   }
   const int t = threadIdx.x;
-  auto cell_of = [](float x, float y) { return min(15, max(0, (int)(y * 0.125f))) * 16 + min(15, max(0, (int)(x * 0.125f))); };
-  fill[t] = 0;
+  constexpr float INV = 1.0f / J2L_CELL;
+  auto cell1 = [](float v) { return min(J2L_NC - 1, max(0, (int)(v * INV))); };
+#pragma unroll
+  for (int q = 0; q < J2L_CPT; ++q) fill[t * J2L_CPT + q] = 0;
   __syncthreads();
   float2 mine[2];
   int mc[2] = {-1, -1};
@@ -261,14 +266,17 @@ __global__ __launch_bounds__(256) void s0_j2l_grid_kernel(const float* __restric
     const int i = t + r * 256;
     if (i < jn) {
       mine[r] = make_float2(juncs[i * 2], juncs[i * 2 + 1]);
-      mc[r] = cell_of(mine[r].x, mine[r].y);
+      mc[r] = cell1(mine[r].y) * J2L_NC + cell1(mine[r].x);
       atomicAdd(&fill[mc[r]], 1);
     }
   }
   __syncthreads();
-  {                                                          // exclusive prefix of the 256 cell counts
-    const int v = fill[t], lane = t & 63, wv = t >> 6;
-    int incl = v;
+  {                                                          // exclusive prefix of the cell counts: J2L_CPT consecutive cells per thread
+    int v[J2L_CPT], tot = 0;
+#pragma unroll
+    for (int q = 0; q < J2L_CPT; ++q) { v[q] = fill[t * J2L_CPT + q]; tot += v[q]; }
+    const int lane = t & 63, wv = t >> 6;
+    int incl = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int u = __shfl_up(incl, o);
@@ -276,11 +284,11 @@ __global__ __launch_bounds__(256) void s0_j2l_grid_kernel(const float* __restric
     }
     if (lane == 63) wtot[wv] = incl;
     __syncthreads();
-    int off = 0;
+    int off = incl - tot;
     for (int w = 0; w < wv; ++w) off += wtot[w];
-    cs[t] = off + incl - v;
-    if (t == 255) cs[256] = off + incl;
-    fill[t] = 0;
+#pragma unroll
+    for (int q = 0; q < J2L_CPT; ++q) { cs[t * J2L_CPT + q] = off; off += v[q]; fill[t * J2L_CPT + q] = 0; }
+    if (t == 255) cs[J2L_CELLS] = off;
   }
   __syncthreads();
   for (int r = 0; r < 2; ++r)
@@ -292,10 +300,10 @@ __global__ __launch_bounds__(256) void s0_j2l_grid_kernel(const float* __restric
   __syncthreads();
   auto nearest = [&](float px, float py, float& best, int& bi) {
     best = INFINITY; bi = 0;
-    const int cx = min(15, max(0, (int)(px * 0.125f))), cy = min(15, max(0, (int)(py * 0.125f)));
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, 15);
-    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, 15); ++yy)
-      for (int i = cs[yy * 16 + x0], e = cs[yy * 16 + x1 + 1]; i < e; ++i) {
+    const int cx = cell1(px), cy = cell1(py);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, J2L_NC - 1);
+    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, J2L_NC - 1); ++yy)
+      for (int i = cs[yy * J2L_NC + x0], e = cs[yy * J2L_NC + x1 + 1]; i < e; ++i) {
         const float2 q = sxy[i];
         const int j = sj[i];
         const float ax = __fsub_rn(px, q.x), ay = __fsub_rn(py, q.y);
@@ -345,7 +353,7 @@ void launch_s0_juncs(const float* sel, const int* n_sel, const float* joff, floa
 }
 void launch_s0_j2l(const float* lines_pred, const float* juncs, int jn, int n, float thr, float* iskeep, float* imin, float* imax,
                    int B, size_t stage_stride, int exact_all, hipStream_t st) {
-  if (exact_all || thr > 60.f || jn > 320)
+  if (exact_all || thr >= (float)(J2L_CELL * J2L_CELL - 1) || jn > 320)
     hipLaunchKernelGGL(s0_j2l_kernel, dim3((n + 255) / 256, B), dim3(256), 0, st, lines_pred, juncs, jn, n, thr, iskeep, imin, imax,
                        stage_stride);
   else
