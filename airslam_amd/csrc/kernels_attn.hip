@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
   // staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 8 rows of a tile per instruction, no staging registers, no
   // ds_write): a K / V^T tile is 8 + 8 instructions, two + two per wave.  The LDS image is chunk-swizzled (swz128), so lane
   // (row 8 i + lane / 8, physical chunk pc = lane & 7) fetches logical chunk pc ^ swz128(row).  Tile t + 1 is issued at the top of
-  // iteration t into the buffer whose readers passed the barrier that ended iteration t - 1.
+  // iteration t into the buffer whose readers passed the barrier that ended iteration t - 1.  (A three-buffer ring with tile t + 2 in flight
+  // and `vmcnt(4)` waits measured 0.77 vs 0.75 ms of attention per step: the tile DMA is not what the waves wait for; not kept.)
   unsigned koff[2], voff[2];                            // element offsets of this lane's four 16-byte pieces inside tile 0
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
