@@ -168,8 +168,9 @@ struct airfe_ctx {
   std::string err;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;         // airfe_stereo_plnet_batch_dev: the line branch runs here while the matcher runs on the caller's stream
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool overlap_lines = true;             // AIRFE_OVERLAP_LINES=0: one stream
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_c3a = nullptr;
+  bool mark_c3a = false;                 // detect_dev2 records ev_c3a behind conv3a (the line branch's only input from the encoder)
+  bool overlap_lines = false;            // AIRFE_OVERLAP_LINES=1: line path beside the matcher (see airfe_stereo_plnet_batch_dev: not the default)
   std::vector<void*> allocs;
   int prec = 0;                  // detector storage type
   int mprec = 1;                 // matcher storage type (cfg.matcher_precision)
@@ -281,6 +282,8 @@ struct airfe_ctx {
   uint16_t* l_feat = nullptr;    // [Lmax][128*128][128] 2-byte
   float *l_ta8 = nullptr /*[Lmax][128*128][8] thin | aux pixel-major*/, *l_head = nullptr, *l_jloc = nullptr, *l_jnms = nullptr, *l_joff = nullptr, *l_sel = nullptr;
   int* l_nsel = nullptr;
+  unsigned long long* l_cand = nullptr;   // [Lmax][128*128] junction candidates (its own list: the line branch may run beside the point branch's tail)
+  int* l_cand_cnt = nullptr;
   // PLNet stage 1 + line path
   bool has_s1 = false;
   const float* s1_w[11] = {nullptr};
@@ -589,7 +592,9 @@ int load_superpoint(airfe_ctx* c, const char* path) {
     c->l_ta8 = dalloc<float>(c, 8 * npx);
     c->l_sel = dalloc<float>(c, (size_t)c->Lmax * 320 * AIRFE_FEAT_DIM);
     c->l_nsel = dalloc<int>(c, c->Lmax);
-    if (!c->l_feat || !c->l_ta8 || !c->l_head || !c->l_dec || !c->l_ridx || !c->l_lrows || !c->l_jloc || !c->l_jnms || !c->l_joff || !c->l_sel || !c->l_nsel)
+    c->l_cand = dalloc<unsigned long long>(c, (size_t)c->Lmax * 128 * 128, false);
+    c->l_cand_cnt = dalloc<int>(c, c->Lmax);
+    if (!c->l_feat || !c->l_ta8 || !c->l_head || !c->l_dec || !c->l_ridx || !c->l_lrows || !c->l_jloc || !c->l_jnms || !c->l_joff || !c->l_sel || !c->l_nsel || !c->l_cand || !c->l_cand_cnt)
       return fail(c, "device allocation failed (line branch arena)");
     c->has_s0 = true;
   }
@@ -975,6 +980,7 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
       run_conv(c, c->c2b, c->a2a, c->a2b + (size_t)c0 * (R / 4 + 2) * (R / 4 + 2) * 64, cb, R / 2, R / 2, 1, 1, st);
     }
     run_conv(c, c->c3a, c->a2b, c->a3a, B, R / 4, R / 4, 0, 1, st);
+    if (c->mark_c3a) HIPCHK(c, hipEventRecord(c->ev_c3a, st));
     run_conv(c, c->c3b, c->a3a, c->a3b, B, R / 4, R / 4, 1, 1, st);
     run_conv(c, c->c4a, c->a3b, c->a4a, B, R / 8, R / 8, 0, 1, st);
     run_conv(c, c->c4b, c->a4a, c->a4b, B, R / 8, R / 8, 0, 1, st);
@@ -1291,9 +1297,9 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
   else
     launch_s0_decode(c->l_dec, 32, 0, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, nullptr, c->l_ta8, nb, SG_STRIDE, st);
   // get_junctions: top-300 of the suppressed junction map (score descending, raster ascending on ties)
-  const int ccap = AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE;
-  launch_candidates(c->l_jnms, nb, F, F, 1e-30f, 0, c->cand, c->cand_cnt, ccap, st);
-  launch_select_list(c->cand, c->cand_cnt, ccap, nb, F, 300, 320, c->l_sel, c->l_nsel, st);
+  const int ccap = F * F;
+  launch_candidates(c->l_jnms, nb, F, F, 1e-30f, 0, c->l_cand, c->l_cand_cnt, ccap, st);
+  launch_select_list(c->l_cand, c->l_cand_cnt, ccap, nb, F, 300, 320, c->l_sel, c->l_nsel, st);
   launch_s0_juncs(c->l_sel, c->l_nsel, c->l_joff, d + SG_JUNCS, 300, 320, nb, SG_STRIDE, st);
   launch_s0_j2l(d + SG_LP, d + SG_JUNCS, 300, NP, 10.0f, d + SG_KEEP, d + SG_MIN, d + SG_MAX, nb, SG_STRIDE, chw ? 1 : 0, st);
   HIPCHK(c, hipGetLastError());
@@ -1304,14 +1310,16 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
 // stage 1, the line / junction filter (plnet.cpp:272-307, 468-558) and, for the first nj of them, junction_detector + descriptors
 // (plnet.cpp:425-448).  LOI features: the head GEMM's rows (loi == nullptr) or a CHW block.  Results go to DEVICE buffers:
 // d_lines [nb][capL][4], d_nlines / d_lfound [nb], d_junc [nj][capJ][259], d_njunc / d_jfound [nj] (found > cap = the caller's overflow).
+// phase: 1 = the lines (needs nothing of the point branch), 2 = the junctions (score maps, descriptor maps of the point branch), 3 = both.
 int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int w, double* d_lines, int capL, int* d_nlines, int* d_lfound,
-                  float* d_junc, int capJ, int* d_njunc, int* d_jfound, int nj, hipStream_t st) {
+                  float* d_junc, int capJ, int* d_njunc, int* d_jfound, int nj, hipStream_t st, int phase = 3) {
   if (!c->has_s1) return fail(c, "PLNet stage-1 weights were not loaded (cfg.plnet_s1_pack)");
   if (nb < 1 || nb > c->Lmax || nj < 0 || nj > nb) return fail(c, "line path: image range outside the arena");
   const int R = AIRFE_INTERNAL_SIZE, NP = KEEP_CAP;
   float* d = c->s0_stage;
-  if (nj > 0) launch_zero16(c->jmap, (size_t)nj * R * R, st);
   const float ws = (float)w / (float)R, hs = (float)h / (float)R;
+  if (phase & 1) {
+  if (nj > 0) launch_zero16(c->jmap, (size_t)nj * R * R, st);
   {
   ProfScope ps(c, ST_PL_STAGE1, st, 0, (double)nb * 49152 * 12);
   launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
@@ -1336,10 +1344,12 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
                     d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
   }
   }
-  ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nb * R * R + (double)nj * R * R * 2);
+  ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nb * R * R);
   launch_line_filter(c->s1_la, c->s1_sc, c->wf_counts, c->cfg.remove_borders, c->cfg.line_threshold, c->cfg.line_length_threshold, ws, hs, R,
                      c->jmap, nj, d_lines, capL, d_nlines, d_lfound, LINE_CAP, nb, st);
-  if (nj > 0) {
+  }
+  if ((phase & 2) && nj > 0) {
+    ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nj * R * R * 2);
     if (c->cfg.nms_radius > 0 && !c->nms_map_valid) return fail(c, "line path: the NMS'd score maps of this batch were not kept");
     const float* hsel = (c->cfg.nms_radius > 0 ? c->heat_nms : c->heat) + (size_t)i0 * R * R;
     launch_junction_scan(c->jmap, hsel, R, c->cfg.remove_borders, d_junc, capJ, d_njunc, d_jfound, c->d_njunc + 2 * c->Lmax, nj, st);
@@ -1449,7 +1459,8 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_c3a, hipEventDisableTiming) != hipSuccess) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1498,6 +1509,7 @@ void airfe_destroy(airfe_ctx* c) {
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_c3a) (void)hipEventDestroy(c->ev_c3a);
   delete c;
 }
 
@@ -1908,22 +1920,22 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
 // PLNet::infer over a device-resident batch, after the point branch ran on it (images 0 .. B-1 of the detector arena): lines of every
 // image, junctions of the first nj
 static int plnet_lines_batch(airfe_ctx* c, int B, int h, int w, double* d_lines, int capL, int* d_nlines, float* d_junc, int capJ,
-                             int* d_njunc, int nj, int* d_found, hipStream_t st) {
+                             int* d_njunc, int nj, int* d_found, hipStream_t st, int phase = 3) {
   if (!c->has_s0 || !c->has_s1) return fail(c, "the batched PLNet path needs the line branch (line.* in the detector pack) and cfg.plnet_s1_pack");
   if (c->prec == 2) return fail(c, "the batched PLNet path runs in fp16 / bf16 (the fp32 mode is one image per call)");
   if (B > c->Lmax) return fail(c, "batch exceeds the line-path arena");
   if (capL < 1 || !d_lines || !d_nlines) return fail(c, "detect_plnet_batch: no line output");
   if (nj < 0 || nj > B || (nj > 0 && (!d_junc || !d_njunc || capJ < 1))) return fail(c, "detect_plnet_batch: bad junction arguments");
-  if (line_branch_dev(c, st, 0, B, false)) return 1;
+  if ((phase & 1) && line_branch_dev(c, st, 0, B, false)) return 1;
   bool partial = false;
-  if (nj > 0 && !c->desc_dense_valid) {           // the point branch ran the descriptor head on the sampled cells only: the junction images'
+  if ((phase & 2) && nj > 0 && !c->desc_dense_valid) {   // the point branch ran the descriptor head on the sampled cells only: the junction images'
     dense_desc_head(c, nj, st);                   // dense maps now (the points have theirs already; c->desc is free to be rewritten)
     c->desc_dense_valid = true;
     partial = nj != c->last_B;
   }
   int* lfound = d_found ? d_found : c->d_nlines + c->Lmax;
   int* jfound = d_found ? d_found + B : c->d_njunc + c->Lmax;
-  const int rc = line_tail_dev(c, 0, B, nullptr, h, w, d_lines, capL, d_nlines, lfound, d_junc, capJ, d_njunc, jfound, nj, st);
+  const int rc = line_tail_dev(c, 0, B, nullptr, h, w, d_lines, capL, d_nlines, lfound, d_junc, capJ, d_njunc, jfound, nj, st, phase);
   if (partial) c->desc_dense_valid = false;       // (only the first nj images' dense maps exist)
   return rc;
 }
@@ -1948,23 +1960,37 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   if (!(c->stereo_one_pass && c->prec != 2 && 2 * B <= c->Dmax))
     return fail(c, "stereo_plnet_batch: needs the one-pass stereo detector (detector + LightGlue packs loaded, 2 B <= 2 max_batch, fp16 / bf16)");
-  c->force_nms_map = true;
-  int rc = detect_dev2(c, d_left, d_right, B, h, w, stride, img_stride, d_featL, d_featR, cap, d_nL, d_nR, st);
-  c->force_nms_map = false;
-  if (rc) return 1;
-  // lines of the 2 B images (left 0 .. B-1, right B .. 2B-1), junctions of the left ones (feature_detector.cc:100-101).  The line path and
-  // the matcher both start from the detector's results and share nothing else (line arena / candidate list / score and descriptor maps
-  // against the matcher arena): the line path goes to the context's second stream and the two run side by side — a step is ~200 launches,
-  // each with a ramp and a tail that the other chain's workgroups fill.
   // (With stage timers on anything behind the encoder the chains run one after the other: a stage's event pair must not span the other chain.)
   const uint32_t enc_only = (1u << ST_PREPROCESS) | (1u << ST_CONV1A) | (1u << ST_CONV3X3_C64);
-  if (!c->overlap_lines || (c->prof_mask & ~enc_only) != 0) {
+  const bool overlap = c->overlap_lines && (c->prof_mask & ~enc_only) == 0;
+  c->force_nms_map = true;
+  c->mark_c3a = overlap;
+  int rc = detect_dev2(c, d_left, d_right, B, h, w, stride, img_stride, d_featL, d_featR, cap, d_nL, d_nR, st);
+  c->force_nms_map = false;
+  c->mark_c3a = false;
+  if (rc) return 1;
+  // lines of the 2 B images (left 0 .. B-1, right B .. 2B-1), junctions of the left ones (feature_detector.cc:100-101).
+  // AIRFE_OVERLAP_LINES=1 puts the line path on the context's second stream beside the matcher (they share nothing but the detector's
+  // results; +2 % from filled launch ramps and tails).  NOT the default: tools/experiments/plnet_determinism.py (120 steps at the bench size
+  // against the first one) found the MATCHER's scores of ONE pair off by 1e-3 (once by 0.8, with a different match count) in ~10 % of the
+  // steps when the line path's workgroups run beside it, and never (0 of 340) on one stream — the same class of schedule-dependent fault as
+  // the one DESIGN.md 2.2 describes, not yet located.  (AIRFE_OVERLAP_EARLY=1 additionally starts the line branch behind conv3a, beside
+  // the rest of the encoder: measured slower, it disturbs the encoder's persistent kernels.)
+  if (!overlap) {
     if (plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, st)) return 1;
     return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
   }
-  HIPCHK(c, hipEventRecord(c->ev_fork, st));
-  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-  rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2);
+  static const bool early = getenv("AIRFE_OVERLAP_EARLY") && atoi(getenv("AIRFE_OVERLAP_EARLY")) != 0;
+  HIPCHK(c, hipEventRecord(c->ev_fork, st));                  // behind the point branch
+  if (early) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_c3a, 0));
+    rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2, 1);
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    if (!rc) rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2, 2);
+  } else {
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2);
+  }
   if (!rc) rc = lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));      // (also after an error: the caller's stream never runs ahead of the side stream)
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));

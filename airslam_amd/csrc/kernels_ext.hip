@@ -211,32 +211,34 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) { ret
 #endif
 constexpr int S1_U = 8, S1_NB = S1_NBUF;
 static_assert(2 * S1_U * (2 * S1_NB - 1) <= S1_WPAD, "the weight tables' padding must cover the prefetch past the last row");
-// one weight: scalar row pointer + 32-bit lane offset (bytes) + immediate.  Spelled as asm because hipcc materialises a 64-bit vector
-// address per (row, lane) for the C++ form and hoists all ~90 of them out of the tile loop: 430-640 bytes of scratch per lane.  The
-// compiler does not count these loads: s1_wait() below is the wait, tied to the registers it releases.
-template <int IMM>
-__device__ __forceinline__ float s1_ldw(const float* row, unsigned lane_bytes) {
-  float v;
-  asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=&v"(v) : "v"(lane_bytes), "s"(row), "n"(IMM) : "memory");
-  return v;
-}
-template <int N>
-__device__ __forceinline__ void s1_wait(float (&w)[8]) {    // at most N vector-memory operations still in flight; w[] is usable afterwards
-  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]) : "n"(N) : "memory");
-}
-__device__ __forceinline__ void s1_fetch8(float (&w)[8], const float* row0, unsigned lane_bytes) {   // rows row0, +2, .., +14 (128 floats each)
-  const float* r1 = row0 + 8 * 128;
-  w[0] = s1_ldw<0>(row0, lane_bytes); w[1] = s1_ldw<1024>(row0, lane_bytes); w[2] = s1_ldw<2048>(row0, lane_bytes); w[3] = s1_ldw<3072>(row0, lane_bytes);
-  w[4] = s1_ldw<0>(r1, lane_bytes); w[5] = s1_ldw<1024>(r1, lane_bytes); w[6] = s1_ldw<2048>(r1, lane_bytes); w[7] = s1_ldw<3072>(r1, lane_bytes);
-}
+// Weights come through BUFFER loads: a resource descriptor in four scalar registers that never change, a 32-bit lane offset, the row
+// as part of that offset.  Two other forms were tried first.  (1) Plain pointer loads: hipcc materialises a 64-bit vector address per
+// (row, lane) and hoists all ~90 of them out of the tile loop: 430-640 bytes of scratch per lane.  (2) `global_load_dword v, v_off, s[base]`
+// spelled as asm with a freshly computed scalar base per group of loads and hand-placed `s_waitcnt vmcnt(24)`: fast, parity-green — and
+// WRONG under load: tools/experiments/plnet_determinism.py (the keyframe step at the bench size, outputs of 60 runs against the first)
+// found a different line set in 1 % of the runs alone and in 30-45 % with the matcher running beside it; the same loads with
+// `vmcnt(0)` before every trip: 0 of 60, compiler-managed loads: 0 of 380.  The scalar base registers were rewritten while earlier loads
+// that name them were still queued — no hazard hipcc's own code would run into (it keeps such registers apart), and none it can see
+// inside an asm block.  Lesson kept: no hand-scheduled memory operations whose operands live in registers that are recycled.
+template <int K>
+struct S1Wt {                              // the transposed weight table of one layer as a buffer resource
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ explicit S1Wt(const float* wt)
+      : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, (K + S1_WPAD) * 128 * 4, 0x00020000)) {}
+  // lane_off: this lane's byte offset inside a row pair (a vector register that never changes); row_off: the row's byte offset, uniform
+  // (the scalar offset operand: kept out of the vector registers, where hipcc would hoist one copy per distinct row out of the tile loop)
+  __device__ __forceinline__ float ld(unsigned lane_off, unsigned row_off) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, 0));
+  }
+};
 
 template <int K, bool PRESET = false>
-__device__ __forceinline__ void s1_dense(const float* __restrict__ wt /*[K + S1_WPAD][128]*/, const float* bias /*LDS (a global load here would be
-                                         the one vector-memory operation the compiler counts: it drains the queue at every loop entry)*/,
+__device__ __forceinline__ void s1_dense(const float* __restrict__ wt /*[K + S1_WPAD][128]*/, const float* bias /*LDS*/,
                                          const float* xin /*LDS [K][S1_LP]*/, f32x16& acc, int f0, int lane) {
   constexpr int U = S1_U, NB = S1_NB, TRIPS = K / (2 * U);
   static_assert(K % (2 * U) == 0 && U == 8, "K must be a multiple of 16");
   const int i = lane & 31, kk = lane >> 5;
+  const S1Wt<K> W(wt);
   const unsigned lb = (unsigned)(kk * 128 + f0 + i) * 4u;
   const float* xp = xin + kk * S1_LP + i;
   if constexpr (!PRESET) {                 // (PRESET: the caller has put bias + the junction terms into acc)
@@ -245,7 +247,9 @@ __device__ __forceinline__ void s1_dense(const float* __restrict__ wt /*[K + S1_
   }
   float wb[NB][U];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) s1_fetch8(wb[b], wt + b * 2 * U * 128, lb);
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int u = 0; u < U; ++u) wb[b][u] = W.ld(lb, (unsigned)(b * 2 * U + 2 * u) * 512u);
 #pragma unroll 1
   for (int t0 = 0; t0 < TRIPS; t0 += NB) {
 #pragma unroll
@@ -255,16 +259,16 @@ __device__ __forceinline__ void s1_dense(const float* __restrict__ wt /*[K + S1_
         float xb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) xb[u] = xp[(k0 + 2 * u) * S1_LP];
-        s1_wait<(NB - 1) * U>(wb[b]);       // the NB - 1 younger fetches may still be in flight
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = mfma_32x32x2(wb[b][u], xb[u], acc);
-        __builtin_amdgcn_sched_barrier(0);  // the refill stays BEHIND the MFMAs that read the buffer
-        s1_fetch8(wb[b], wt + (size_t)(k0 + NB * 2 * U) * 128, lb);     // (past the end: the table's S1_WPAD zero rows, never used)
+        __builtin_amdgcn_sched_barrier(0);  // the refill stays BEHIND the MFMAs that read the buffer (hoisted, it needs a second set of registers)
+        const unsigned nrow = (unsigned)__builtin_amdgcn_readfirstlane((k0 + NB * 2 * U) * 512);
+#pragma unroll
+        for (int u = 0; u < U; ++u) wb[b][u] = W.ld(lb, nrow + (unsigned)u * 1024u);     // (past the end: the table's S1_WPAD zero rows, never used)
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the fetches past the end must not land in registers that have moved on
 }
 
 #ifdef S1_TIMING
@@ -428,12 +432,12 @@ __global__ __launch_bounds__(256, PRE ? 4 : 2) void plnet_s1_kernel(const float*
     // sampling: thread = (channel n, half of the tile's lines)
     if constexpr (PRE) {
       // thin / aux blocks: 30 points per line and block, a point's 4 channels are 16 bytes of the pixel-major copy: one (line, block, point)
-      // per thread and trip = 4 taps of 16 bytes; two rounds of S1_SB trips whose taps are in flight together (a dependent global access
+      // per thread and trip = 4 taps of 16 bytes; rounds of S1_SB trips whose taps are in flight together (a dependent global access
       // costs 1-2 us in this kernel).  The LOI blocks do not exist here: their share of layer 0 is the junction projection.
       constexpr int ITEMS = (S1_LT / 2) * 60;
-      static_assert(2 * S1_SB * 128 >= ITEMS, "two rounds must cover a group's thin / aux items");
+      constexpr int ROUNDS = (ITEMS + S1_SB * 128 - 1) / (S1_SB * 128);
 #pragma unroll 1
-      for (int rnd = 0; rnd < 2; ++rnd) {
+      for (int rnd = 0; rnd < ROUNDS; ++rnd) {
         BilTap bt[S1_SB];
         float4 a00[S1_SB], a10[S1_SB], a01[S1_SB], a11[S1_SB];
         int dst[S1_SB];

@@ -6,9 +6,6 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-# per-kernel durations and counters are taken with the line path and the matcher on ONE stream (side by side, as the un-profiled run has
-# them, every kernel's span and counters include the other chain's workgroups); the bench line of the profiled run says so
-export AIRFE_OVERLAP_LINES=${AIRFE_OVERLAP_LINES:-0}
 CMD="python bench.py --steps 5 --warmup 2 --cpu-pairs 0 --no-profile ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 python tools/rocpd_summary.py $OUT/kt/kt_results.db $OUT/kernel_stats.csv
