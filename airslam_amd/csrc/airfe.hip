@@ -169,6 +169,7 @@ struct airfe_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;         // airfe_stereo_plnet_batch_dev: the line branch runs here while the matcher runs on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_c3a = nullptr;
+  int ovl_cut = 0; hipStream_t ovl_main = nullptr; bool ovl_hopped = false;   // fault hunting (AIRFE_OVERLAP_CUT): stretches <= cut stay on the caller's stream
   bool mark_c3a = false;                 // detect_dev2 records ev_c3a behind conv3a (the line branch's only input from the encoder)
   bool overlap_lines = false;            // AIRFE_OVERLAP_LINES=1: line path beside the matcher (see airfe_stereo_plnet_batch_dev: not the default)
   std::vector<void*> allocs;
@@ -1245,6 +1246,20 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   return 0;
 }
 
+// Fault hunting (AIRFE_OVERLAP_CUT = k with AIRFE_OVERLAP_LINES = 1): the line path's stretches 1 .. k are queued on the caller's stream
+// (ahead of the matcher: they run before it), the rest on the side stream beside the matcher.  Stretches: 1 3x3 line conv, 2 head + decode
+// + junction NMS, 3 junction top-300 + match, 4 wireframe, 5 junction rows + LOI gather GEMM + projections, 6 stage 1, 7 line filter.
+static hipStream_t line_stream(airfe_ctx* c, int stretch, hipStream_t st) {
+  if (!c->ovl_main || c->ovl_cut <= 0) return st;
+  if (stretch <= c->ovl_cut) return c->ovl_main;
+  if (!c->ovl_hopped) {                      // first stretch on the side stream: it starts behind everything queued on the caller's so far
+    (void)hipEventRecord(c->ev_fork, c->ovl_main);
+    (void)hipStreamWaitEvent(st, c->ev_fork, 0);
+    c->ovl_hopped = true;
+  }
+  return st;
+}
+
 // PLNet stage-0 LINE branch of images [i0, i0 + nb) of the batch the detector just ran on: fills stage slots 0 .. nb-1 with the Appendix
 // A.1 tensors in the contract's own layouts, so that everything downstream (wireframe dedup, stage 1, filters) is the code the golden
 // tests pin.  chw: also the contract's CHW loi_features of slot 0 (the inspection hook; the line path samples the head rows directly).
@@ -1270,11 +1285,12 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
     launch_gemm_f32(g, st);
   } else {
     // conv3a features (zero-bordered NHWC, still in the arena for the whole batch) -> [nb * 128*128][128]
-    run_conv(c, c->cL1, c->a3a + (size_t)i0 * (F + 2) * (F + 2) * 128, c->l_feat, nb, F, F, 0, 0, st);
+    run_conv(c, c->cL1, c->a3a + (size_t)i0 * (F + 2) * (F + 2) * 128, c->l_feat, nb, F, F, 0, 0, line_stream(c, 1, st));
     static const bool fuse_dec = !(getenv("AIRFE_FUSE_DEC") && atoi(getenv("AIRFE_FUSE_DEC")) == 0);
     if (!fused && fuse_dec) {        // the 17-channel head and its decode in one pass over the line features (kernels_s0.hip)
       ProfScope ps(c, ST_PL_DECODE, st, 2.0 * nb * F * F * 128 * 17, (double)nb * F * F * (256 + 92));
-      launch_s0_head_decode(c->prec, c->l_feat, c->cLh_dec.w, c->cLh_dec.b, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, c->l_ta8, nb, SG_STRIDE, st);
+      launch_s0_head_decode(c->prec, c->l_feat, c->cLh_dec.w, c->cLh_dec.b, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, c->l_ta8, nb, SG_STRIDE,
+                            line_stream(c, 2, st));
       head_done = true;
     } else {
       const LinW& hw = fused ? c->cLh : c->cLh_dec;
@@ -1298,10 +1314,11 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
     launch_s0_decode(c->l_dec, 32, 0, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, nullptr, c->l_ta8, nb, SG_STRIDE, st);
   // get_junctions: top-300 of the suppressed junction map (score descending, raster ascending on ties)
   const int ccap = F * F;
-  launch_candidates(c->l_jnms, nb, F, F, 1e-30f, 0, c->l_cand, c->l_cand_cnt, ccap, st);
-  launch_select_list(c->l_cand, c->l_cand_cnt, ccap, nb, F, 300, 320, c->l_sel, c->l_nsel, st);
-  launch_s0_juncs(c->l_sel, c->l_nsel, c->l_joff, d + SG_JUNCS, 300, 320, nb, SG_STRIDE, st);
-  launch_s0_j2l(d + SG_LP, d + SG_JUNCS, 300, NP, 10.0f, d + SG_KEEP, d + SG_MIN, d + SG_MAX, nb, SG_STRIDE, chw ? 1 : 0, st);
+  hipStream_t s3 = line_stream(c, 3, st);
+  launch_candidates(c->l_jnms, nb, F, F, 1e-30f, 0, c->l_cand, c->l_cand_cnt, ccap, s3);
+  launch_select_list(c->l_cand, c->l_cand_cnt, ccap, nb, F, 300, 320, c->l_sel, c->l_nsel, s3);
+  launch_s0_juncs(c->l_sel, c->l_nsel, c->l_joff, d + SG_JUNCS, 300, 320, nb, SG_STRIDE, s3);
+  launch_s0_j2l(d + SG_LP, d + SG_JUNCS, 300, NP, 10.0f, d + SG_KEEP, d + SG_MIN, d + SG_MAX, nb, SG_STRIDE, chw ? 1 : 0, s3);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1319,34 +1336,36 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
   float* d = c->s0_stage;
   const float ws = (float)w / (float)R, hs = (float)h / (float)R;
   if (phase & 1) {
-  if (nj > 0) launch_zero16(c->jmap, (size_t)nj * R * R, st);
+  hipStream_t s4 = line_stream(c, 4, st);
+  if (nj > 0) launch_zero16(c->jmap, (size_t)nj * R * R, s4);
   {
   ProfScope ps(c, ST_PL_STAGE1, st, 0, (double)nb * 49152 * 12);
   launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
-                   c->wf_counts, nb, SG_STRIDE, st);
+                   c->wf_counts, nb, SG_STRIDE, s4);
   if (loi_chw) {                    // host-supplied contract tensors: all 496 features per line from the CHW blocks
     launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, loi_chw, 0, nullptr, nullptr, d + SG_THIN, d + SG_AUX,
                     c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
   } else {
     if (c->line_sparse) {           // the LOI head at the junctions' tap rows only
       const int M = nb * 1200, Mp = (M + 255) / 256 * 256;
-      launch_s1_junc_rows(d + SG_JUNCS, 300, c->l_ridx, nb, SG_STRIDE, st);
-      if (Mp > M) HIPCHK(c, hipMemsetAsync(c->l_ridx + M, 0, (size_t)(Mp - M) * 4, st));
+      hipStream_t s5 = line_stream(c, 5, st);
+      launch_s1_junc_rows(d + SG_JUNCS, 300, c->l_ridx, nb, SG_STRIDE, s5);
+      if (Mp > M) HIPCHK(c, hipMemsetAsync(c->l_ridx + M, 0, (size_t)(Mp - M) * 4, s5));
       GemmArgs g;
       g.X1 = c->l_feat; g.ld1 = 128; g.K1 = 128; g.Wp = c->cLh_loi.w; g.bias = c->cLh_loi.b; g.rowidx = c->l_ridx;
       g.M = Mp; g.N = 128; g.cb_total = c->cLh_loi.cbt; g.epi = EPI_STORE_F32; g.out = c->l_lrows; g.ldo = 128;
-      launch_gemm8(c->prec, 128, false, g, st);
-      launch_s1_junc_proj(d + SG_JUNCS, nullptr, 0, 0, c->l_lrows, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, st);
+      launch_gemm8(c->prec, 128, false, g, s5);
+      launch_s1_junc_proj(d + SG_JUNCS, nullptr, 0, 0, c->l_lrows, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, s5);
     } else {
       launch_s1_junc_proj(d + SG_JUNCS, c->l_head, (size_t)128 * 128 * 160, 160, nullptr, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, st);
     }
     launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, nullptr, 0, c->s1_jfeat, c->l_ta8, d + SG_THIN,
-                    d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
+                    d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, line_stream(c, 6, st));
   }
   }
   ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nb * R * R);
   launch_line_filter(c->s1_la, c->s1_sc, c->wf_counts, c->cfg.remove_borders, c->cfg.line_threshold, c->cfg.line_length_threshold, ws, hs, R,
-                     c->jmap, nj, d_lines, capL, d_nlines, d_lfound, LINE_CAP, nb, st);
+                     c->jmap, nj, d_lines, capL, d_nlines, d_lfound, LINE_CAP, nb, line_stream(c, 7, st));
   }
   if ((phase & 2) && nj > 0) {
     ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nj * R * R * 2);
@@ -1981,6 +2000,10 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint
     return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
   }
   static const bool early = getenv("AIRFE_OVERLAP_EARLY") && atoi(getenv("AIRFE_OVERLAP_EARLY")) != 0;
+  // AIRFE_OVERLAP_PHASE (fault hunting): 1 = only the lines part beside the matcher (the junction part after the join), 2 = only the junction
+  // part beside it (the lines part before the fork), 11..15 = only ONE stretch of the lines part: see line_branch_dev / line_tail_dev
+  static const int only = getenv("AIRFE_OVERLAP_PHASE") ? atoi(getenv("AIRFE_OVERLAP_PHASE")) : 0;
+  if (only == 2 && plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, st, 1)) return 1;
   HIPCHK(c, hipEventRecord(c->ev_fork, st));                  // behind the point branch
   if (early) {
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_c3a, 0));
@@ -1989,11 +2012,17 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint
     if (!rc) rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2, 2);
   } else {
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2);
+    static const int cut = getenv("AIRFE_OVERLAP_CUT") ? atoi(getenv("AIRFE_OVERLAP_CUT")) : 0;
+    c->ovl_cut = cut; c->ovl_main = cut > 0 ? st : nullptr; c->ovl_hopped = false;
+    rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2, only == 1 || cut > 0 ? 1 : (only == 2 ? 2 : 3));
+    if (cut > 0 && !c->ovl_hopped) { (void)hipEventRecord(c->ev_fork, st); (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0); }
+    c->ovl_cut = 0; c->ovl_main = nullptr;
+    if (cut > 0 && !rc) rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2, 2);
   }
   if (!rc) rc = lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));      // (also after an error: the caller's stream never runs ahead of the side stream)
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+  if (!rc && only == 1) rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, st, 2);
   return rc;
 }
 
