@@ -86,6 +86,12 @@ SIGNATURES = {
     "airfe_debug_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "airfe_debug_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_void_p]),
+    "airfe_debug_trace": (C.c_int, [C.c_void_p, C.c_int]),
+    "airfe_debug_trace_stop": (C.c_int, [C.c_void_p, C.c_int]),
+    "airfe_debug_trace_buffer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "airfe_debug_trace_slots": (C.c_int, [C.c_void_p]),
+    "airfe_debug_trace_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    "airfe_debug_trace_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "airfe_debug_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p]),
 }

@@ -400,6 +400,38 @@ class Context:
     def sync(self):
         self._chk(self._l.airfe_sync(self._h), "airfe_sync")
 
+    # ---- fault hunting: checksums of the matcher's state behind every launch (airfe_debug_trace*)
+    def trace(self, on=True):
+        self._chk(self._l.airfe_debug_trace(self._h, 1 if on else 0), "airfe_debug_trace")
+
+    def trace_stop(self, slot=-1):
+        self._chk(self._l.airfe_debug_trace_stop(self._h, slot), "airfe_debug_trace_stop")
+
+    def trace_buffer(self, slot, dtype):
+        """The whole buffer slot `slot` of the last matcher call covers, as a flat numpy array of `dtype`."""
+        _, _, units, uw = self.trace_slots()[slot]
+        out = np.zeros(units * uw * 4 // np.dtype(dtype).itemsize, dtype)
+        self._chk(self._l.airfe_debug_trace_buffer(self._h, slot, out.ctypes.data, out.nbytes), "airfe_debug_trace_buffer")
+        return out
+
+    def trace_slots(self):
+        """[(name, first unit, units, words per unit)] of the last matcher call."""
+        out = []
+        for i in range(self._l.airfe_debug_trace_slots(self._h)):
+            name = C.create_string_buffer(64)
+            off, units, uw = C.c_uint(), C.c_uint(), C.c_uint()
+            self._chk(self._l.airfe_debug_trace_slot(self._h, i, name, 64, C.byref(off), C.byref(units), C.byref(uw)), "airfe_debug_trace_slot")
+            out.append((name.value.decode(), off.value, units.value, uw.value))
+        return out
+
+    def trace_read(self, table=False, stream=None):
+        """(digests [slots] u64, unit table u64 or None) of the last matcher call; synchronises the stream."""
+        slots = self.trace_slots()
+        dig = np.zeros(len(slots), np.uint64)
+        tab = np.zeros(slots[-1][1] + slots[-1][2], np.uint64) if (table and slots) else None
+        self._chk(self._l.airfe_debug_trace_read(self._h, stream, dig.ctypes.data, tab.ctypes.data if tab is not None else None), "airfe_debug_trace_read")
+        return dig, tab
+
 
 # ------------------------------------------------------------------------------------ reference-shaped façade
 class FeatureDetector:

@@ -11,6 +11,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libairfe.so")
 SOURCES = ["airfe.hip", "kernels_mm.hip", "kernels_conv64r.hip", "kernels_conv128r.hip", "kernels_gemm8.hip", "kernels_gemmr.hip", "kernels_img.hip", "kernels_sel.hip", "kernels_nms512.hip", "kernels_lg.hip", "kernels_attn.hip", "kernels_lgblockf.hip", "kernels_ext.hip", "kernels_s0.hip", "kernels_f32.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# Per-file flags.  -fno-slp-vectorize: the SLP vectoriser packs incidental scalar fp32 arithmetic of these (latency- / HBM-bound) kernels into
+# v_pk_*_f32 with cross-half `op_sel` selections — the instruction form behind round 2's irreproducible rotary element (common.h, rotate_pairs;
+# tests/test_no_scratch_cpu.py::test_no_packed_f32_cross_half_selects keeps every translation unit free of it).
+EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in ("kernels_lg.hip", "kernels_img.hip", "kernels_s0.hip", "kernels_f32.hip")}
 
 
 def _stale(target: str, deps) -> bool:
@@ -33,8 +37,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+        if force or _stale(obj, [src, os.path.abspath(__file__)] + headers):
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -177,6 +177,7 @@ struct airfe_ctx {
   int mprec = 1;                 // matcher storage type (cfg.matcher_precision)
   int pack_prec = 0;             // storage type make_linear packs for (set by each load_* before it packs)
   int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
+  size_t arena_rows = 0;         // token rows of the matcher arena, slack included (alloc_matcher_arena)
   int Dmax = 1;                  // images the detector arena holds: 2 x Bmax when a stereo step detects left and right as one batch
   bool has_sp = false, has_lg = false;
   uint8_t* pl_stage = nullptr;   // staging of airfe_assign_points_to_lines / airfe_match_lines
@@ -294,6 +295,16 @@ struct airfe_ctx {
   unsigned char* jmap = nullptr;
   double* d_lines = nullptr;
   int *d_nlines = nullptr /*[Lmax] kept | [Lmax] found*/, *d_njunc = nullptr /*[Lmax] kept | [Lmax] found | [Lmax][64] scan scratch*/;
+
+  // fault hunting (airfe_debug_trace*): checksums of the matcher's state behind every launch of lightglue_dev
+  struct TraceSlot { std::string name; unsigned off, units, unit_words; const void* p; size_t words; };
+  bool trace_on = false, trace_halt = false;
+  int trace_stop = -1;           // >= 0: the forward pass returns right behind this slot (its buffer stays as that launch left it)
+  unsigned long long *trace_tab = nullptr, *trace_dig = nullptr;
+  unsigned* trace_off = nullptr;
+  size_t trace_cap = 0;
+  std::vector<TraceSlot> trace_slots;
+  std::vector<unsigned> trace_off_h;
 
   // per-stage hipEvent timers (airfe_profile_*): events are recorded on the launch stream only
   struct Mark { int stage; hipEvent_t a, b; double flops, bytes; };
@@ -664,6 +675,7 @@ int alloc_matcher_arena(airfe_ctx* c) {
   // projections folded into the block) land one or more whole sequences past the real data,
   // and attention's last key tile reads up to 63 rows past a sequence.  All of it stays inside this zero-initialised slack.
   const size_t M = (size_t)(S + 2 + 128 / Np) * Np + 256;
+  c->arena_rows = M;
   c->x32 = dalloc<float>(c, M * 256);
   c->xb = dalloc<uint16_t>(c, M * 256);
   c->qb = dalloc<uint16_t>(c, M * 256);
@@ -1069,6 +1081,29 @@ int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
   return detect_dev2(c, d_gray, nullptr, B, h, w, stride, img_stride, d_feat, nullptr, cap, d_n, nullptr, st);
 }
 
+// airfe_debug_trace: checksum `words` 32-bit words of p in units of unit_words (slot = one call; no-op unless tracing)
+void trace(airfe_ctx* c, hipStream_t st, const char* what, size_t li, const char* blk, const void* p, size_t words, unsigned unit_words) {
+  if (!c->trace_on) return;
+  const unsigned off = c->trace_slots.empty() ? 0u : c->trace_slots.back().off + c->trace_slots.back().units;
+  const unsigned units = (unsigned)(words / unit_words);
+  if (c->trace_slots.size() >= 1024 || (size_t)off + units > c->trace_cap) return;
+  launch_trace_hash(p, unit_words, units, c->trace_tab + off, st);
+  c->trace_slots.push_back({std::string("L") + std::to_string(li) + "." + blk + "." + what, off, units, unit_words, p, words});
+  if ((int)c->trace_slots.size() - 1 == c->trace_stop) c->trace_halt = true;
+}
+int trace_finish(airfe_ctx* c, hipStream_t st) {
+  if (c->trace_on && !c->trace_slots.empty()) {
+    c->trace_off_h.clear();
+    for (const auto& t : c->trace_slots) c->trace_off_h.push_back(t.off);
+    c->trace_off_h.push_back(c->trace_slots.back().off + c->trace_slots.back().units);
+    HIPCHK(c, hipMemcpyAsync(c->trace_off, c->trace_off_h.data(), c->trace_off_h.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    launch_trace_digest(c->trace_tab, c->trace_off, (int)c->trace_slots.size(), c->trace_dig, st);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+#define TRACE_HALT do { if (c->trace_halt) return trace_finish(c, st); } while (0)
+
 void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1, const uint16_t* x2, int ld2, int M,
                 int epi, int act, void* out, int ldo, hipStream_t st, bool trans = false, void* out2 = nullptr,
                 float* x32 = nullptr, const float* rc = nullptr, const float* rs = nullptr) {
@@ -1137,6 +1172,15 @@ void lg_ffn(airfe_ctx* c, const LinW& f0, const float* g, const float* b, const 
   run_linear(c, f3, c->hb, 512, 512, nullptr, 0, M, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
 }
 
+// The surplus rows behind the last real token (alloc_matcher_arena's slack) go through every block like real ones: their residual
+// stream would keep growing from step to step (x += f(x), never re-initialised) until the 2-byte shadow overflows — and the last
+// sequence's final key tile multiplies those rows' V by probability 0, which is NaN once they are not finite.  Back to zero per call.
+void reset_slack_rows(airfe_ctx* c, int M, hipStream_t st) {
+  if ((size_t)M >= c->arena_rows) return;
+  launch_zero16(c->x32 + (size_t)M * 256, (c->arena_rows - (size_t)M) * 256 * sizeof(float), st);
+  launch_zero16(c->xb + (size_t)M * 256, (c->arena_rows - (size_t)M) * 256 * sizeof(uint16_t), st);
+}
+
 // LightGlue forward on B pairs whose feature rows live on the device
 int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1, const int* n1, int B, int cap, int ld,
                   int kp_off, int normalize, int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, float* scores_out,
@@ -1155,7 +1199,23 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   pa.linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.5f);
   pa.wr = c->lg_wr; pa.B = B; pa.cap = cap; pa.Np = Np;
   pa.x32 = c->x32; pa.xb = c->xb; pa.rot_cos = c->rot_cos; pa.rot_sin = c->rot_sin; pa.lens = c->lens;
-  { ProfScope ps(c, ST_LG_PREPARE, st, 0, (double)M * (1036 + 1536 + 256)); launch_lg_prepare(c->mprec, pa, st); }
+  if (c->trace_on) c->trace_slots.clear();
+  c->trace_halt = false;
+  const size_t Mw = (size_t)M * 128;                     // 32-bit words of a [M][256] 2-byte buffer
+  auto tr_x = [&](size_t li, const char* blk) {
+    trace(c, st, "x32", li, blk, c->x32, (size_t)M * 256, 4096);
+    trace(c, st, "xb", li, blk, c->xb, Mw, 2048);
+  };
+  auto tr_qkv = [&](size_t li, const char* blk, bool k) {
+    trace(c, st, "q", li, blk, c->qb, Mw, 512);
+    if (k) trace(c, st, "k", li, blk, c->kb, Mw, 512);
+    trace(c, st, "vt", li, blk, c->vtb, Mw, (unsigned)Np / 2);
+  };
+  { ProfScope ps(c, ST_LG_PREPARE, st, 0, (double)M * (1036 + 1536 + 256)); launch_lg_prepare(c->mprec, pa, st); reset_slack_rows(c, M, st); }
+  tr_x(0, "prep");
+  trace(c, st, "rc", 0, "prep", c->rot_cos, (size_t)M * 32, 512);
+  trace(c, st, "rs", 0, "prep", c->rot_sin, (size_t)M * 32, 512);
+  TRACE_HALT;
   // The fused block (kernels_lgblockf.hip) streams 0.9 MB of weights per 128-token workgroup whatever the batch, so below 3200
   // tokens (4 pairs of 400) the four separate launches are quicker: 1.82 vs 1.85 ms per step at 3 pairs, 2.01 vs 1.98 at 4,
   // 2.65 vs 2.45 at 8 (profiles/r01d_small_batch_sweeps.txt).
@@ -1168,33 +1228,71 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     const LgLayer& l = c->lg[li];
     const LgLayer* nl = li + 1 < c->lg.size() ? &c->lg[li + 1] : nullptr;
     // ---- self block
-    if (!fold_s || li == 0) run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, c->rot_cos, c->rot_sin, st);
+    if (!fold_s || li == 0) { run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, c->rot_cos, c->rot_sin, st); tr_qkv(li, "self.qkv", true); }
+    TRACE_HALT;
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); run_attention(c, c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
+    trace(c, st, "o", li, "self.attn", c->ob, Mw, 2048);
+    TRACE_HALT;
     if (fused_block) {
       lg_blockf(c, l.out, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st, 0, fold_c ? &l.cqk : nullptr, fold_c ? &l.cv : nullptr, false);
+      tr_x(li, "self.block");
+      TRACE_HALT;
+      if (fold_c) tr_qkv(li, "self.block", false);
+      TRACE_HALT;
     } else {
       run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
+      trace(c, st, "msg", li, "self.out", c->msg, Mw, 2048);
+      TRACE_HALT;
       lg_ffn(c, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
+      tr_x(li, "self.ffn");
+      TRACE_HALT;
     }
     // ---- cross block (one shared projection for q and k; the two sides swap roles)
-    if (!fold_c) run_qkv(c, l.cqk, l.cv, Mg, c->qb, nullptr, nullptr, nullptr, st);
+    if (!fold_c) { run_qkv(c, l.cqk, l.cv, Mg, c->qb, nullptr, nullptr, nullptr, st); tr_qkv(li, "cross.qkv", false); }
+    TRACE_HALT;
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); run_attention(c, c->mprec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
+    trace(c, st, "o", li, "cross.attn", c->ob, Mw, 2048);
+    TRACE_HALT;
     if (fused_block) {
       const bool fn = fold_s && nl;
       lg_blockf(c, l.cout, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st, 0, fn ? &nl->qk : nullptr, fn ? &nl->v : nullptr, true);
+      tr_x(li, "cross.block");
+      TRACE_HALT;
+      if (fn) tr_qkv(li, "cross.block", true);
+      TRACE_HALT;
     } else {
       run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
+      trace(c, st, "msg", li, "cross.out", c->msg, Mw, 2048);
+      TRACE_HALT;
       lg_ffn(c, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st);
+      tr_x(li, "cross.ffn");
+      TRACE_HALT;
     }
   }
+  const size_t LF = c->lg.size();
   run_linear(c, c->lg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
+  trace(c, st, "md", LF, "final", c->mdb, Mw, 2048);
+  TRACE_HALT;
   ProfScope ps(c, ST_LG_ASSIGN, st, 2.0 * B * Np * (double)Np * 256, (double)B * Np * Np * 4 * 6);
   launch_rowdot256(c->x32, c->lg_mw, c->lg_mb, c->zbuf, M, st);
+  trace(c, st, "z", LF, "final", c->zbuf, (size_t)M, 16);
+  TRACE_HALT;
   launch_sim(c->mprec, c->mdb, c->simbuf, B, Np, st);
+  trace(c, st, "sim", LF, "final", c->simbuf, (size_t)B * Np * Np, 16u * (unsigned)Np);
+  TRACE_HALT;
   launch_lg_assign(c->simbuf, c->zbuf, c->lens, B, Np, mcap, 0.1f, c->rowlse, c->collse, scores_out, c->rowarg, c->rowval,
                    c->colarg, d_idx, d_score, d_nmatch, st);
-  HIPCHK(c, hipGetLastError());
-  return 0;
+  trace(c, st, "rowlse", LF, "assign", c->rowlse, (size_t)B * Np, (unsigned)Np);
+  TRACE_HALT;
+  trace(c, st, "collse", LF, "assign", c->collse, (size_t)B * Np, (unsigned)Np);
+  TRACE_HALT;
+  trace(c, st, "rowval", LF, "assign", c->rowval, (size_t)B * Np, (unsigned)Np);
+  TRACE_HALT;
+  trace(c, st, "rowarg", LF, "assign", c->rowarg, (size_t)B * Np, (unsigned)Np);
+  TRACE_HALT;
+  trace(c, st, "colarg", LF, "assign", c->colarg, (size_t)B * Np, (unsigned)Np);
+  TRACE_HALT;
+  return trace_finish(c, st);
 }
 
 // SuperGlue forward on B pairs of device feature matrices (259-float rows) -> decode outputs [B][Lz]
@@ -1209,6 +1307,7 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   const float linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.7f);   // point_matcher.cc:58
   // keypoint encoder: from block_min tokens on, its two large layers (98 of 108 kFLOP per keypoint) run as MFMA GEMMs
   const bool kenc_gemm = c->sg_kenc_gemm == 1 || (c->sg_kenc_gemm < 0 && Mg >= c->block_min);
+  reset_slack_rows(c, M, st);
   launch_sg_prepare(c->mprec, f0, f1, n0, n1, AIRFE_FEAT_DIM, normalize, cx, cy, linv, c->sg_kenc, B, cap, Np, c->x32, c->xb,
                     c->lens, kenc_gemm ? c->msg : nullptr, st);
   if (kenc_gemm) {
@@ -1556,6 +1655,55 @@ int airfe_profile_read(airfe_ctx* c, double* ms, double* flops, double* bytes, i
     c->ev_pool.push_back(m.a); c->ev_pool.push_back(m.b);
   }
   c->marks.clear();
+  return 0;
+}
+
+/* fault hunting: checksums of the matcher's state behind every launch of the LightGlue forward (x32, xb, q, k, v^T, attention output, ...)
+   in units of 16 token rows; off by default.  airfe_debug_trace_read synchronises the context's stream. */
+int airfe_debug_trace(airfe_ctx* c, int on) {
+  if (!c) return 1;
+  if (on && !c->trace_tab) {
+    c->trace_cap = (size_t)3 << 20;
+    c->trace_tab = dalloc<unsigned long long>(c, c->trace_cap);
+    c->trace_dig = dalloc<unsigned long long>(c, 1024);
+    c->trace_off = dalloc<unsigned>(c, 1025);
+    if (!c->trace_tab || !c->trace_dig || !c->trace_off) return fail(c, "device allocation failed (trace)");
+  }
+  c->trace_on = on != 0;
+  c->trace_slots.clear();
+  return 0;
+}
+int airfe_debug_trace_stop(airfe_ctx* c, int slot) {
+  if (!c) return 1;
+  c->trace_stop = slot;
+  return 0;
+}
+int airfe_debug_trace_buffer(airfe_ctx* c, int slot, void* host, size_t bytes) {
+  if (!c || slot < 0 || slot >= (int)c->trace_slots.size()) return fail(c, "trace_buffer: no such slot");
+  const auto& t = c->trace_slots[(size_t)slot];
+  if (bytes > t.words * 4) return fail(c, "trace_buffer: more bytes than the slot covers");
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(host, t.p, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+int airfe_debug_trace_slots(airfe_ctx* c) { return c ? (int)c->trace_slots.size() : 0; }
+int airfe_debug_trace_slot(airfe_ctx* c, int i, char* name, int name_cap, unsigned* off, unsigned* units, unsigned* unit_words) {
+  if (!c || i < 0 || i >= (int)c->trace_slots.size()) return 1;
+  const auto& t = c->trace_slots[(size_t)i];
+  if (name && name_cap > 0) { strncpy(name, t.name.c_str(), (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+  if (off) *off = t.off;
+  if (units) *units = t.units;
+  if (unit_words) *unit_words = t.unit_words;
+  return 0;
+}
+int airfe_debug_trace_read(airfe_ctx* c, void* stream, unsigned long long* digests, unsigned long long* table) {
+  if (!c || !c->trace_tab) return fail(c, "trace is off");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  HIPCHK(c, hipStreamSynchronize(st));
+  const size_t n = c->trace_slots.size();
+  if (n == 0) return 0;
+  if (digests) HIPCHK(c, hipMemcpy(digests, c->trace_dig, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (table) HIPCHK(c, hipMemcpy(table, c->trace_tab, ((size_t)c->trace_slots.back().off + c->trace_slots.back().units) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -162,12 +162,26 @@ __device__ __forceinline__ float rows_sum(float v) {
 
 // LightGlue rotary embedding on the four (even, odd) pairs of v[0..7]: one definition for every GEMM epilogue, so that the
 // kernels launch_gemm may pick for the same linear stay bit-identical.
+//
+// Written as SINGLE v_mul_f32 / v_fma_f32 instructions on purpose.  From the plain C form hipcc's vectoriser makes v_pk_mul_f32 /
+// v_pk_fma_f32, and for pair 1 — whose cos / sin sit in the HIGH half of a register pair — with op_sel cross selections
+// (`v_pk_mul_f32 .. op_sel:[1,1] op_sel_hi:[0,1]`, `v_pk_fma_f32 .. op_sel:[0,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]`).  Exactly that
+// element (feature 8 g + 2 of a lane's run: the EVEN element of pair 1, lanes 48-63 only, its odd partner right) came out wrong
+// in one 16-token tile of the first layer's q | k projection in 0.13 % of the 64-pair steps on a quiet GPU and in 4 % with another
+// stream's kernels beside it: the round-2 "matcher race" (tools/experiments/matcher_trace.py names the launch, the tile and the
+// element; profiles/r03_matcher_trace.txt).  The same element failed in lg_blockf's folded projection in round 2, where the
+// tables came from global loads instead of LDS.  No missing wait count or documented hazard in the ISA; the products and sums
+// below are the same ones in the same order, so the bits do not change.
 __device__ __forceinline__ void rotate_pairs(float* v, const f32x4& c, const f32x4& s) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float x0 = v[2 * i], x1 = v[2 * i + 1];
-    v[2 * i] = x0 * c[i] - x1 * s[i];
-    v[2 * i + 1] = x1 * c[i] + x0 * s[i];
+    float t0, t1, r0, r1;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(v[2 * i + 1]), "v"(s[i]));
+    asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(r0) : "v"(v[2 * i]), "v"(c[i]), "v"(t0));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(v[2 * i]), "v"(s[i]));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r1) : "v"(v[2 * i + 1]), "v"(c[i]), "v"(t1));
+    v[2 * i] = r0;
+    v[2 * i + 1] = r1;
   }
 }
 

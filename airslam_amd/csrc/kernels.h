@@ -173,6 +173,9 @@ void launch_lg_assign(const float* sim, const float* z, const int* lens, int B, 
                       int32_t* idx, float* score, int* nmatch, hipStream_t st);
 
 // filter_matches alone on finished log-assignment matrices [B][Np][Np] (test hook)
+// fault hunting (airfe_debug_trace): checksums of `units` units of `unit_words` 32-bit words each; per-slot digests
+void launch_trace_hash(const void* p, unsigned unit_words, unsigned units, unsigned long long* out, hipStream_t st);
+void launch_trace_digest(const unsigned long long* tab, const unsigned* off, int slots, unsigned long long* dig, hipStream_t st);
 void launch_lg_filter_scores(const float* scores, const int* lens, int B, int Np, int cap, float thr, int* rowarg, float* rowval,
                              int* colarg, int32_t* idx, float* score, int* nmatch, hipStream_t st);
 

@@ -542,4 +542,45 @@ void launch_lg_filter_scores(const float* scores, const int* lens, int B, int Np
   hipLaunchKernelGGL(lg_filter_kernel, dim3(B), dim3(1024), 0, st, lens, Np, cap, thr, rowarg, rowval, colarg, idx, score, nmatch);
 }
 
+// =============================================================================== fault hunting: state checksums
+// Position-dependent 64-bit checksum of every `unit_words`-word unit of a buffer (airfe_debug_trace): sums are commutative, so the result
+// does not depend on how the threads are scheduled.  One workgroup per unit.
+__global__ __launch_bounds__(256) void trace_hash_kernel(const uint32_t* __restrict__ p, unsigned unit_words, unsigned long long* __restrict__ out) {
+  const uint32_t* base = p + (size_t)blockIdx.x * unit_words;
+  unsigned long long h = 0;
+  for (unsigned i = threadIdx.x; i < unit_words; i += 256) {
+    unsigned long long x = ((unsigned long long)base[i] + 1ull) * 0x9E3779B97F4A7C15ull + (unsigned long long)i * 0xC2B2AE3D27D4EB4Full;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    h += x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+  __shared__ unsigned long long part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+// per-slot digest of the unit checksums: slot i covers units [off[i], off[i+1])
+__global__ __launch_bounds__(256) void trace_digest_kernel(const unsigned long long* __restrict__ tab, const unsigned* __restrict__ off, unsigned long long* __restrict__ dig) {
+  const unsigned a = off[blockIdx.x], b = off[blockIdx.x + 1];
+  unsigned long long h = 0;
+  for (unsigned i = a + threadIdx.x; i < b; i += 256) {
+    unsigned long long x = (tab[i] ^ ((unsigned long long)(i - a) * 0xC2B2AE3D27D4EB4Full)) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 31;
+    h += x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+  __shared__ unsigned long long part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) dig[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+void launch_trace_hash(const void* p, unsigned unit_words, unsigned units, unsigned long long* out, hipStream_t st) {
+  hipLaunchKernelGGL(trace_hash_kernel, dim3(units), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(p), unit_words, out);
+}
+void launch_trace_digest(const unsigned long long* tab, const unsigned* off, int slots, unsigned long long* dig, hipStream_t st) {
+  hipLaunchKernelGGL(trace_digest_kernel, dim3(slots), dim3(256), 0, st, tab, off, dig);
+}
+
 }  // namespace airfe

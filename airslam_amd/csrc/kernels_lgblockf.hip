@@ -392,21 +392,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
         if constexpr (FOLD == 2) {
           const f32x4 cs = *reinterpret_cast<const f32x4*>(a.rot_cos + (size_t)row * 32 + tp * 16 + g * 4);
           const f32x4 sn = *reinterpret_cast<const f32x4*>(a.rot_sin + (size_t)row * 32 + tp * 16 + g * 4);
-          // The rotation is spelled out in single (non-packed) instructions.  rotate_pairs() compiled here to v_pk_mul_f32 / v_pk_fma_f32
-          // with op_sel operand swaps fed straight from the two table loads, and in 3-60 % of the launches (depending on the surrounding
-          // schedule) ONE rotated feature of the LAST 16-token tile of a pass came out wrong — always the same lane group, never in the
-          // separate-launch path, no missing wait to be found in the ISA.  400 of 400 runs are bit-identical with the form below
-          // (tests/test_gpu_lightglue.py::test_folded_projections_are_deterministic keeps watching); same products, same fma: same bits.
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float t0, t1, r0, r1;
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(v[2 * i + 1]), "v"(sn[i]));
-            asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(r0) : "v"(v[2 * i]), "v"(cs[i]), "v"(t0));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(v[2 * i]), "v"(sn[i]));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r1) : "v"(v[2 * i + 1]), "v"(cs[i]), "v"(t1));
-            v[2 * i] = r0;
-            v[2 * i + 1] = r1;
-          }
+          rotate_pairs(v, cs, sn);                               // (single instructions, not packed math: see common.h)
         }
         // no row guard: the rows of a ragged last pass are garbage tokens of "sequences" S, S + 1 whose outputs land in the arena's slack
         // (alloc_matcher_arena), exactly like the surplus rows of the separate launches

@@ -226,6 +226,19 @@ int airfe_debug_preprocess(airfe_ctx* ctx, const uint8_t* gray, int h, int w, in
 int airfe_debug_conv3x3(airfe_ctx* ctx, const float* x, int B, int cin, int H, int W, const float* w, const float* b,
                         int cout, int pool, float* y);
 int airfe_debug_gemm(airfe_ctx* ctx, const float* x, int M, int K, const float* w, const float* b, int N, int relu, float* y);
+/* fault hunting (tools/experiments/matcher_trace.py): position-dependent 64-bit checksums of the LightGlue forward's state behind EVERY launch
+ * (src/light_glue.cpp:120-170 is one opaque engine call; here it is ~60 launches) — residual stream, token shadow, q / k / v^T, attention
+ * output, descriptors, similarity, assignment vectors — in units of 16 token rows (v^T: one feature row).  airfe_debug_trace(ctx, 1) switches it on
+ * for the following matcher calls (+~2 ms per 64-pair step); _slots / _slot describe the slots of the last call (name, first unit, units,
+ * 32-bit words per unit); _read synchronises `stream` (NULL: the context's) and copies one digest per slot and / or the whole unit table. */
+int airfe_debug_trace(airfe_ctx* ctx, int on);
+/* slot >= 0: the forward pass returns right behind that slot's launch, so that its buffer can be read as the launch left it
+ * (airfe_debug_trace_buffer: the first `bytes` bytes of the slot's buffer to the host); -1: run to the end */
+int airfe_debug_trace_stop(airfe_ctx* ctx, int slot);
+int airfe_debug_trace_buffer(airfe_ctx* ctx, int slot, void* host, size_t bytes);
+int airfe_debug_trace_slots(airfe_ctx* ctx);
+int airfe_debug_trace_slot(airfe_ctx* ctx, int i, char* name, int name_cap, unsigned* off, unsigned* units, unsigned* unit_words);
+int airfe_debug_trace_read(airfe_ctx* ctx, void* stream, unsigned long long* digests, unsigned long long* table);
 
 #ifdef __cplusplus
 }

@@ -114,38 +114,6 @@ def test_stereo_plnet_batch_equals_points_path_plus_lines():
     diag("stereo_plnet_batch", lines=str(nlh.tolist()), junctions=str(njh.tolist()), matches=str(nm.cpu().numpy().tolist()))
 
 
-def test_keyframe_step_is_deterministic_at_the_bench_size():
-    """64 stereo pairs through airfe_stereo_plnet_batch_dev, 150 times: every output equals the first run's bit for bit.  A single-shot
-    parity test cannot see a schedule-dependent fault: the stage-1 kernel's hand-scheduled weight loads (hand-placed `s_waitcnt`) passed
-    every parity test and gave a different line set in ~1 % of the steps at this size (tools/experiments/plnet_determinism.py)."""
-    import torch
-    B = 64
-    ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(GOLDEN, "plnet_s1.airfe"),
-                      lightglue=weights.synthetic_lightglue(1234), max_batch=B, enc_chunk=64)
-    ls, rs = synth.stereo_batch(B, 480, 752, 1000)
-    L, R = torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda()
-    z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device="cuda")
-
-    def run():
-        o = dict(fl=z(B, 400, 259), fr=z(B, 400, 259), nl=z(B, dt=torch.int32), nr=z(B, dt=torch.int32), lines=z(2 * B, 1024, 4, dt=torch.float64),
-                 nlines=z(2 * B, dt=torch.int32), junc=z(B, 1024, 259), njunc=z(B, dt=torch.int32), idx=z(B, 400, 2, dt=torch.int32), sc=z(B, 400),
-                 nm=z(B, dt=torch.int32), found=z(3 * B, dt=torch.int32))
-        ctx.stereo_plnet_batch_dev(L, R, o["fl"], o["fr"], o["nl"], o["nr"], o["lines"], o["nlines"], o["junc"], o["njunc"], o["idx"], o["sc"],
-                                   o["nm"], o["found"])
-        ctx.sync()
-        return o
-    ref = run()
-    assert int(ref["nlines"].min()) >= 100 and int(ref["njunc"].min()) >= 50 and int(ref["nm"].min()) >= 40
-    bad = {}
-    for i in range(150):
-        o = run()
-        for k in ref:
-            if not torch.equal(ref[k], o[k]):
-                bad.setdefault(k, []).append(i)
-    ctx.close()
-    assert not bad, {k: v[:5] for k, v in bad.items()}
-
-
 def test_plnet_batch_refuses_what_it_cannot_do():
     import torch
     ctx = _ctx()

@@ -176,16 +176,3 @@ def test_superglue_cfg5_max_size_fp16():
     i0, i1, m0, m1 = ctx.match_superglue(f0, f1)
     assert i0.shape == (1024,) and i1.shape == (1000,)            # lengths h-1, w-1: super_glue.cpp:357-358
     ctx.close()
-
-
-@pytest.mark.parametrize("fused", [0, 1])
-def test_superglue_is_deterministic(fused, monkeypatch):
-    """60 forward passes (GNN, register-resident cooperative Sinkhorn with its inter-workgroup rendezvous, decode): one result."""
-    import hashlib
-    monkeypatch.setenv("AIRFE_FUSE_LG_BLOCK", str(fused))
-    w = weights.synthetic_superglue(1234, n_layers=18)
-    ctx = api.Context(superglue=w, matcher=1, max_batch=2, sinkhorn_iters=100)
-    _, _, f0, f1 = _sg_pair(400, 380, 77)
-    seen = {hashlib.md5(ctx.superglue_scores(f0, f1).tobytes()).hexdigest() for _ in range(60)}
-    assert len(seen) == 1
-    ctx.close()
