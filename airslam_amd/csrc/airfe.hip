@@ -168,10 +168,8 @@ struct airfe_ctx {
   std::string err;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;         // airfe_stereo_plnet_batch_dev: the line branch runs here while the matcher runs on the caller's stream
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_c3a = nullptr;
-  int ovl_cut = 0; hipStream_t ovl_main = nullptr; bool ovl_hopped = false;   // fault hunting (AIRFE_OVERLAP_CUT): stretches <= cut stay on the caller's stream
-  bool mark_c3a = false;                 // detect_dev2 records ev_c3a behind conv3a (the line branch's only input from the encoder)
-  bool overlap_lines = false;            // AIRFE_OVERLAP_LINES=1: line path beside the matcher (see airfe_stereo_plnet_batch_dev: not the default)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap_lines = true;             // line path on stream2 beside the matcher (airfe_stereo_plnet_batch_dev); AIRFE_OVERLAP_LINES=0: one stream
   std::vector<void*> allocs;
   int prec = 0;                  // detector storage type
   int mprec = 1;                 // matcher storage type (cfg.matcher_precision)
@@ -190,19 +188,11 @@ struct airfe_ctx {
   int block_min = 3200;          // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
   bool qkv_pair = true;          // q|k and v of a layer in one streaming launch (AIRFE_QKV_PAIR=0: two launches)
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
-  int lgb_tokens = 0;            // AIRFE_LGB_TOKENS: tokens per lg_blockf workgroup (128 or 112; 0 = by token count)
-  int attn_occ = 3;              // AIRFE_ATTN_OCC: attention32_kernel variant compiled for 2 (no spills) or 3 waves per SIMD
   int sg_kenc_gemm = -1;         // AIRFE_SG_KENC_GEMM=0/1: SuperGlue keypoint encoder's large layers as scalar loops / GEMMs (default: by token count)
-  bool fuse_head = true;         // AIRFE_FUSE_HEAD=0: detector head as GEMM + separate soft-max / depth-to-space kernel (A/B runs)
-  bool sparse_desc = true;       // AIRFE_SPARSE_DESC=0: the descriptor head over every cell at every batch size (A/B runs)
   bool desc_dense_valid = true;  // c->desc holds the dense map of the last batch (else: the gather GEMM's rows)
   int last_B = 0;
   int* desc_idx = nullptr;       // row list of the descriptor head's gather GEMM
-  bool stereo_one_pass = true;   // AIRFE_STEREO_ONE_PASS=0: airfe_stereo_batch_dev detects left and right as two batches (A/B runs)
   bool fold_qkv = true;          // AIRFE_FOLD_QKV=0: q | k | v projections as launches of their own (A/B runs)
-  bool nms_v1 = false;           // AIRFE_NMS_V1=1: the five-launch LDS-tiled simple_nms (A/B runs)
-  bool attn_v1 = false;          // AIRFE_ATTN_V1=1: the round-1 16x16x32 attention kernel (A/B runs)
-  bool fuse_conv1a = true;       // conv1a computed inside the conv1b kernel; AIRFE_FUSE_CONV1A=0 selects the two-kernel form (A/B runs)
 
   // detector weights
   float *c1a_w = nullptr, *c1a_b = nullptr;
@@ -210,7 +200,7 @@ struct airfe_ctx {
   LinW cPb, cDb;
   // detector arena
   float* img32 = nullptr;
-  uint16_t *a1a = nullptr, *a1b = nullptr, *a2a = nullptr, *a2b = nullptr, *a3a = nullptr, *a3b = nullptr, *a4a = nullptr,
+  uint16_t *a1b = nullptr, *a2a = nullptr, *a2b = nullptr, *a3a = nullptr, *a3b = nullptr, *a4a = nullptr,
            *a4b = nullptr, *aPa = nullptr, *aDa = nullptr;
   float *logits = nullptr, *heat = nullptr, *heat_nms = nullptr, *nms_tmp = nullptr, *desc = nullptr;
   unsigned char* nms_mask = nullptr;   // max_mask + supp_mask planes of the per-pool NMS launches
@@ -221,6 +211,8 @@ struct airfe_ctx {
   int tab_w = -1, tab_h = -1;
   // BoW vocabulary tree
   float *bow_desc = nullptr, *bow_weight = nullptr, *bow_outw = nullptr;
+  std::vector<double> bow_weight_h;   // the vocabulary's WordValue weights as the reference holds them (double): the host entry returns these
+  int* bow_outn = nullptr;            // leaf node per feature of the last host call
   int *bow_first = nullptr, *bow_nch = nullptr, *bow_word = nullptr;
   unsigned* bow_out = nullptr;
   int bow_nodes = 0;
@@ -553,7 +545,6 @@ int load_superpoint(airfe_ctx* c, const char* path) {
 
   const int B = c->Dmax, ch = c->chunk, R = AIRFE_INTERNAL_SIZE;
   c->img32 = dalloc<float>(c, (size_t)ch * (R + 2) * (R + 2));
-  c->a1a = dalloc<uint16_t>(c, (size_t)ch * (R + 2) * (R + 2) * 64);
   c->a1b = dalloc<uint16_t>(c, (size_t)ch * (R / 2 + 2) * (R / 2 + 2) * 64);
   c->a2a = dalloc<uint16_t>(c, (size_t)ch * (R / 2 + 2) * (R / 2 + 2) * 64);
   c->a2b = dalloc<uint16_t>(c, (size_t)B * (R / 4 + 2) * (R / 4 + 2) * 64);
@@ -579,7 +570,7 @@ int load_superpoint(airfe_ctx* c, const char* path) {
   std::vector<float> lut(256);
   for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);
   c->lut = dupload(c, lut);
-  if (!c->img32 || !c->a1a || !c->a1b || !c->a2a || !c->a2b || !c->a3a || !c->a3b || !c->a4a || !c->a4b || !c->aPa ||
+  if (!c->img32 || !c->a1b || !c->a2a || !c->a2b || !c->a3a || !c->a3b || !c->a4a || !c->a4b || !c->aPa ||
       !c->aDa || !c->logits || !c->desc || !c->heat || !c->heat_nms || !c->nms_tmp || !c->xtab || !c->ytab || !c->lut ||
       !c->cand || !c->cand_cnt)
     return fail(c, "device allocation failed (detector arena)");
@@ -767,7 +758,7 @@ int load_superglue(airfe_ctx* c, const char* path) {
   c->sg_u = dalloc<float>(c, pl); c->sg_v = dalloc<float>(c, pl); c->sg_Z = dalloc<float>(c, pl * c->Lz);
   c->sg_max0 = dalloc<float>(c, pl); c->sg_ms0 = dalloc<float>(c, pl); c->sg_ms1 = dalloc<float>(c, pl);
   c->sg_idx0 = dalloc<int>(c, pl); c->sg_idx1 = dalloc<int>(c, pl);
-  c->sg_cnt = dalloc<unsigned>(c, (size_t)P * 16);
+  c->sg_cnt = dalloc<unsigned>(c, (size_t)P * 16 + 16);      // + the Sinkhorn kernel's fail word (sg_cnt + P * 16)
   c->sg_xch = dalloc<float>(c, pl * 64);
   c->sg_out0 = dalloc<int32_t>(c, pl); c->sg_out1 = dalloc<int32_t>(c, pl);
   if (!c->sg_u || !c->sg_v || !c->sg_Z || !c->sg_max0 || !c->sg_ms0 || !c->sg_ms1 || !c->sg_idx0 || !c->sg_idx1 ||
@@ -824,7 +815,7 @@ int ensure_tables(airfe_ctx* c, int h, int w) {
   const auto xt = resize_table(AIRFE_INTERNAL_SIZE, w), yt = resize_table(AIRFE_INTERNAL_SIZE, h);
   // the image size changed: a pre-process of the previous size may still be reading the tables on a CALLER's stream (the *_dev entry
   // points), so the whole device is drained before they are rewritten — once per size change, not per call
-  if (c->tab_w != 0) HIPCHK(c, hipDeviceSynchronize());
+  if (c->tab_w != -1) HIPCHK(c, hipDeviceSynchronize());   // (-1: no table yet, nothing can be reading it)
   HIPCHK(c, hipMemcpyAsync(c->xtab, xt.data(), xt.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->ytab, yt.data(), yt.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // host vectors go out of scope
@@ -972,7 +963,7 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
         ProfScope ps(c, ST_PREPROCESS, st, 0, (double)cb * ((double)h * w + (double)R * R * 4));
         launch_preprocess(src, cb, h, w, stride, img_stride, c->xtab, c->ytab, c->lut, c->img32, R, R, st);
       }
-      if (c->fuse_conv1a) {
+      {
         // conv1a (Cin = 1) fused into the persistent conv1b kernel: its 64-channel full-resolution output never
         // reaches HBM (kernels_conv64r.hip).  FLOPs/bytes below are the algorithmic ones of conv1a + conv1b.
         ConvArgs a;
@@ -982,18 +973,11 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
         const double px = (double)cb * R * R;
         ProfScope ps(c, ST_CONV3X3_C64, st, 2.0 * px * 9 * 64 + 2.0 * px * 64 * 64 * 9, px * 4 + px / 4 * 128 + 9.0 * 64 * 64 * 2);
         launch_conv64r(c->prec, a, st);
-      } else {
-        {
-          ProfScope ps(c, ST_CONV1A, st, 2.0 * cb * R * R * 9 * 64, (double)cb * R * R * (4 + 128));
-          launch_conv1a(c->prec, c->img32, c->c1a_w, c->c1a_b, c->a1a, cb, R, R, st);
-        }
-        run_conv(c, c->c1b, c->a1a, c->a1b, cb, R, R, 1, 1, st);
       }
       run_conv(c, c->c2a, c->a1b, c->a2a, cb, R / 2, R / 2, 0, 1, st);
       run_conv(c, c->c2b, c->a2a, c->a2b + (size_t)c0 * (R / 4 + 2) * (R / 4 + 2) * 64, cb, R / 2, R / 2, 1, 1, st);
     }
     run_conv(c, c->c3a, c->a2b, c->a3a, B, R / 4, R / 4, 0, 1, st);
-    if (c->mark_c3a) HIPCHK(c, hipEventRecord(c->ev_c3a, st));
     run_conv(c, c->c3b, c->a3a, c->a3b, B, R / 4, R / 4, 1, 1, st);
     run_conv(c, c->c4a, c->a3b, c->a4a, B, R / 8, R / 8, 0, 1, st);
     run_conv(c, c->c4b, c->a4a, c->a4b, B, R / 8, R / 8, 0, 1, st);
@@ -1005,20 +989,16 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
       g.X1 = c->aPa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cPb.w; g.bias = c->cPb.b;
       g.M = cells; g.N = 65; g.cb_total = c->cPb.cbt; g.epi = EPI_STORE_F32; g.out = c->logits; g.ldo = 72;
       g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-      if (c->fuse_head) {       // soft-max + depth-to-space in the GEMM's epilogue, at EVERY batch size (one summation order): no logits in memory
-        g.epi = EPI_SOFTMAX_D2S; g.out = c->heat; g.d2s_hc = R / 8; g.d2s_wc = R / 8;
-        ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 256));
-        launch_gemm8(c->prec, 256, false, g, st);
-      } else {
-        { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 288)); launch_gemm(c->prec, 256, false, g, st); }
-        { ProfScope ps(c, ST_HEAD_ELTWISE, st, 0, (double)cells * (260 + 256)); launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st); }
-      }
+      // soft-max + depth-to-space in the GEMM's epilogue, at EVERY batch size (one summation order): no logits in memory
+      g.epi = EPI_SOFTMAX_D2S; g.out = c->heat; g.d2s_hc = R / 8; g.d2s_wc = R / 8;
+      ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 256));
+      launch_gemm8(c->prec, 256, false, g, st);
     }
     // The descriptor head convDb (1x1, 256 -> 256) is only ever READ at the <= 4 cells each keypoint samples: large batches run it as a
     // gather GEMM over those rows after the top-K (below) — 1600 of 4096 cells per image at 400 keypoints, and 1.6 instead of 4 MB
     // of fp32 written.  The dense map stays for small batches (the batch-1 line path samples junction descriptors from it) and
     // for the inspection hook, which rebuilds it on demand.  Same kernel, same K order: the rows are bit-identical either way.
-    sparse_desc = c->sparse_desc && B > 2 && cap * 4 <= (R / 8) * (R / 8) && cap <= 1024;
+    sparse_desc = B > 2 && cap * 4 <= (R / 8) * (R / 8) && cap <= 1024;
     if (!sparse_desc) dense_desc_head(c, B, st);
     c->desc_dense_valid = !sparse_desc;
     c->last_B = B;
@@ -1026,16 +1006,12 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
   const int ccap = R * R;
   {
     ProfScope ps(c, ST_NMS, st, 0, (double)B * R * R * 8);
-    if (c->cfg.nms_radius == 4 && R % 64 == 0) {          // (the tiled kernel moves 4-pixel vectors: R = 512 always qualifies)
+    if (c->cfg.nms_radius == 4) {                        // the reference's radius: simple_nms in registers (kernels_nms512.hip; R = 512)
       // the dense NMS'd map is consumed only by the batch-1 line path (junction scores) and the inspection hook: large batches skip
       // its 1 MB / image write (airfe_debug_detector_maps rebuilds it on demand)
       c->nms_map_valid = B <= 2 || c->force_nms_map;
-      if (c->nms_v1 || R != 512)
-        launch_nms4_candidates(c->heat, c->nms_map_valid ? c->heat_nms : nullptr, c->nms_mask, B, R, R, c->cfg.keypoint_threshold,
+      launch_nms512_candidates(c->heat, c->nms_map_valid ? c->heat_nms : nullptr, c->nms_mask, B, c->cfg.keypoint_threshold,
                                c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
-      else
-        launch_nms512_candidates(c->heat, c->nms_map_valid ? c->heat_nms : nullptr, c->nms_mask, B, c->cfg.keypoint_threshold,
-                                 c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
     } else if (c->cfg.nms_radius > 0) {
       c->nms_map_valid = true;
       launch_simple_nms(c->heat, c->heat_nms, c->nms_tmp, B, R, R, c->cfg.nms_radius, st);
@@ -1122,8 +1098,7 @@ void run_attention(airfe_ctx* c, int prec, const uint16_t* Q, const uint16_t* K,
   // `scale` (1/sqrt(d_head)) and log2 e are already inside q and k (ATT_QK_FOLD), so the kernels exponentiate the raw products:
   // the round-1 kernel is told scale * log2 e = 1
   (void)scale;
-  if (c->attn_v1) launch_attention(prec, Q, K, Vt, O, lens, S, H, Np, cross, 0.6931471805599453f, st);
-  else launch_attention32(prec, Q, K, Vt, O, lens, S, H, Np, cross, c->attn_occ, st);
+  launch_attention32(prec, Q, K, Vt, O, lens, S, H, Np, cross, st);
 }
 
 // The attention inputs of one layer: head-major q|k (`qk`, rotary when rc != nullptr; q -> qout, k -> kout, or both roles in qout
@@ -1153,7 +1128,7 @@ void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, co
   a.attn = c->ob; a.xb = c->xb; a.x32 = c->x32; a.wo = out.w; a.w1 = f0.w; a.w2 = f3.w;
   a.bo = out.b; a.b1 = f0.b; a.gamma = g; a.beta = b; a.b2 = f3.b; a.M = M;
   // one workgroup per CU and pass: ceil(M / T) workgroups run in rounds of 256, a round lasts ~T — take the T with the smaller product
-  a.tokens_per_wg = c->lgb_tokens ? c->lgb_tokens : (((M + 111) / 112 + 255) / 256 * 112 < ((M + 127) / 128 + 255) / 256 * 128 ? 112 : 128);
+  a.tokens_per_wg = ((M + 111) / 112 + 255) / 256 * 112 < ((M + 127) / 128 + 255) / 256 * 128 ? 112 : 128;
   double fl = 2.0 * M * (256.0 * 256 + 512.0 * 512 + 512.0 * 256), by = (double)M * (512 + 512 + 1024 + 512 + 1024) + 917504.0;
   if (nqk && nv) {            // the next attention layer's projections ride along (kernels_lgblockf.hip, FOLD)
     a.nqk_w = nqk->w; a.nqk_b = nqk->b; a.nqk_n = nqk->N; a.nv_w = nv->w; a.nv_b = nv->b;
@@ -1338,26 +1313,13 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   }
   run_linear(c, c->sg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
   launch_sim(c->mprec, c->mdb, c->simbuf, B, Np, st);
-  launch_sg_sinkhorn(c->simbuf, c->lens, B, Np, c->Lz, c->sg_alpha, c->cfg.sinkhorn_iters, c->sg_u, c->sg_v, c->sg_Z, c->sg_cnt, c->sg_xch, st);
+  launch_sg_sinkhorn(c->simbuf, c->lens, B, Np, c->Lz, c->sg_alpha, c->cfg.sinkhorn_iters, c->sg_u, c->sg_v, c->sg_Z, c->sg_cnt, c->sg_cnt + (size_t)c->Pmax * 16, c->sg_xch, st);
   launch_sg_decode(c->sg_Z, c->lens, B, Np, c->Lz, 0.2f, c->sg_idx0, c->sg_max0, c->sg_idx1, c->sg_out0, c->sg_out1, c->sg_ms0,
                    c->sg_ms1, st);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 
-// Fault hunting (AIRFE_OVERLAP_CUT = k with AIRFE_OVERLAP_LINES = 1): the line path's stretches 1 .. k are queued on the caller's stream
-// (ahead of the matcher: they run before it), the rest on the side stream beside the matcher.  Stretches: 1 3x3 line conv, 2 head + decode
-// + junction NMS, 3 junction top-300 + match, 4 wireframe, 5 junction rows + LOI gather GEMM + projections, 6 stage 1, 7 line filter.
-static hipStream_t line_stream(airfe_ctx* c, int stretch, hipStream_t st) {
-  if (!c->ovl_main || c->ovl_cut <= 0) return st;
-  if (stretch <= c->ovl_cut) return c->ovl_main;
-  if (!c->ovl_hopped) {                      // first stretch on the side stream: it starts behind everything queued on the caller's so far
-    (void)hipEventRecord(c->ev_fork, c->ovl_main);
-    (void)hipStreamWaitEvent(st, c->ev_fork, 0);
-    c->ovl_hopped = true;
-  }
-  return st;
-}
 
 // PLNet stage-0 LINE branch of images [i0, i0 + nb) of the batch the detector just ran on: fills stage slots 0 .. nb-1 with the Appendix
 // A.1 tensors in the contract's own layouts, so that everything downstream (wireframe dedup, stage 1, filters) is the code the golden
@@ -1384,12 +1346,12 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
     launch_gemm_f32(g, st);
   } else {
     // conv3a features (zero-bordered NHWC, still in the arena for the whole batch) -> [nb * 128*128][128]
-    run_conv(c, c->cL1, c->a3a + (size_t)i0 * (F + 2) * (F + 2) * 128, c->l_feat, nb, F, F, 0, 0, line_stream(c, 1, st));
+    run_conv(c, c->cL1, c->a3a + (size_t)i0 * (F + 2) * (F + 2) * 128, c->l_feat, nb, F, F, 0, 0, st);
     static const bool fuse_dec = !(getenv("AIRFE_FUSE_DEC") && atoi(getenv("AIRFE_FUSE_DEC")) == 0);
     if (!fused && fuse_dec) {        // the 17-channel head and its decode in one pass over the line features (kernels_s0.hip)
       ProfScope ps(c, ST_PL_DECODE, st, 2.0 * nb * F * F * 128 * 17, (double)nb * F * F * (256 + 92));
       launch_s0_head_decode(c->prec, c->l_feat, c->cLh_dec.w, c->cLh_dec.b, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, c->l_ta8, nb, SG_STRIDE,
-                            line_stream(c, 2, st));
+                            st);
       head_done = true;
     } else {
       const LinW& hw = fused ? c->cLh : c->cLh_dec;
@@ -1413,7 +1375,7 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
     launch_s0_decode(c->l_dec, 32, 0, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, nullptr, c->l_ta8, nb, SG_STRIDE, st);
   // get_junctions: top-300 of the suppressed junction map (score descending, raster ascending on ties)
   const int ccap = F * F;
-  hipStream_t s3 = line_stream(c, 3, st);
+  hipStream_t s3 = st;
   launch_candidates(c->l_jnms, nb, F, F, 1e-30f, 0, c->l_cand, c->l_cand_cnt, ccap, s3);
   launch_select_list(c->l_cand, c->l_cand_cnt, ccap, nb, F, 300, 320, c->l_sel, c->l_nsel, s3);
   launch_s0_juncs(c->l_sel, c->l_nsel, c->l_joff, d + SG_JUNCS, 300, 320, nb, SG_STRIDE, s3);
@@ -1435,7 +1397,7 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
   float* d = c->s0_stage;
   const float ws = (float)w / (float)R, hs = (float)h / (float)R;
   if (phase & 1) {
-  hipStream_t s4 = line_stream(c, 4, st);
+  hipStream_t s4 = st;
   if (nj > 0) launch_zero16(c->jmap, (size_t)nj * R * R, s4);
   {
   ProfScope ps(c, ST_PL_STAGE1, st, 0, (double)nb * 49152 * 12);
@@ -1447,7 +1409,7 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
   } else {
     if (c->line_sparse) {           // the LOI head at the junctions' tap rows only
       const int M = nb * 1200, Mp = (M + 255) / 256 * 256;
-      hipStream_t s5 = line_stream(c, 5, st);
+      hipStream_t s5 = st;
       launch_s1_junc_rows(d + SG_JUNCS, 300, c->l_ridx, nb, SG_STRIDE, s5);
       if (Mp > M) HIPCHK(c, hipMemsetAsync(c->l_ridx + M, 0, (size_t)(Mp - M) * 4, s5));
       GemmArgs g;
@@ -1459,12 +1421,12 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
       launch_s1_junc_proj(d + SG_JUNCS, c->l_head, (size_t)128 * 128 * 160, 160, nullptr, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, st);
     }
     launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, nullptr, 0, c->s1_jfeat, c->l_ta8, d + SG_THIN,
-                    d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, line_stream(c, 6, st));
+                    d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
   }
   }
   ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nb * R * R);
   launch_line_filter(c->s1_la, c->s1_sc, c->wf_counts, c->cfg.remove_borders, c->cfg.line_threshold, c->cfg.line_length_threshold, ws, hs, R,
-                     c->jmap, nj, d_lines, capL, d_nlines, d_lfound, LINE_CAP, nb, line_stream(c, 7, st));
+                     c->jmap, nj, d_lines, capL, d_nlines, d_lfound, LINE_CAP, nb, st);
   }
   if ((phase & 2) && nj > 0) {
     ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nj * R * R * 2);
@@ -1564,21 +1526,12 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (getenv("AIRFE_QKV_PAIR")) c->qkv_pair = atoi(getenv("AIRFE_QKV_PAIR")) != 0;
   if (getenv("AIRFE_GEMMR_WGS")) c->gemmr_wgs = atoi(getenv("AIRFE_GEMMR_WGS"));
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
-  if (getenv("AIRFE_LGB_TOKENS")) c->lgb_tokens = atoi(getenv("AIRFE_LGB_TOKENS")) == 112 ? 112 : (atoi(getenv("AIRFE_LGB_TOKENS")) == 128 ? 128 : 0);
-  if (getenv("AIRFE_ATTN_OCC")) c->attn_occ = atoi(getenv("AIRFE_ATTN_OCC")) == 3 ? 3 : 2;
   if (getenv("AIRFE_SG_KENC_GEMM")) c->sg_kenc_gemm = atoi(getenv("AIRFE_SG_KENC_GEMM")) != 0;
-  if (getenv("AIRFE_FUSE_HEAD")) c->fuse_head = atoi(getenv("AIRFE_FUSE_HEAD")) != 0;
-  if (getenv("AIRFE_SPARSE_DESC")) c->sparse_desc = atoi(getenv("AIRFE_SPARSE_DESC")) != 0;
-  if (getenv("AIRFE_STEREO_ONE_PASS")) c->stereo_one_pass = atoi(getenv("AIRFE_STEREO_ONE_PASS")) != 0;
   if (getenv("AIRFE_FOLD_QKV")) c->fold_qkv = atoi(getenv("AIRFE_FOLD_QKV")) != 0;
-  c->nms_v1 = getenv("AIRFE_NMS_V1") && atoi(getenv("AIRFE_NMS_V1")) != 0;
-  c->attn_v1 = getenv("AIRFE_ATTN_V1") && atoi(getenv("AIRFE_ATTN_V1")) != 0;
-  c->fuse_conv1a = !(getenv("AIRFE_FUSE_CONV1A") && atoi(getenv("AIRFE_FUSE_CONV1A")) == 0);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_c3a, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1587,7 +1540,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   }
   if (getenv("AIRFE_OVERLAP_LINES")) c->overlap_lines = atoi(getenv("AIRFE_OVERLAP_LINES")) != 0;
   // a context with a detector AND the stereo matcher runs airfe_stereo_batch_dev over left + right images as one detector batch
-  c->Dmax = (c->stereo_one_pass && c->prec != 2 && cfg->superpoint_pack && cfg->lightglue_pack) ? 2 * c->Bmax : c->Bmax;
+  c->Dmax = (c->prec != 2 && cfg->superpoint_pack && cfg->lightglue_pack) ? 2 * c->Bmax : c->Bmax;
   c->Lmax = c->Dmax;
   int rc = 0;
   if (cfg->superpoint_pack) rc = load_superpoint(c, cfg->superpoint_pack);
@@ -1627,7 +1580,6 @@ void airfe_destroy(airfe_ctx* c) {
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-  if (c->ev_c3a) (void)hipEventDestroy(c->ev_c3a);
   delete c;
 }
 
@@ -1707,10 +1659,11 @@ int airfe_debug_trace_read(airfe_ctx* c, void* stream, unsigned long long* diges
   return 0;
 }
 
+static int sinkhorn_failed(airfe_ctx* c);
 int airfe_sync(airfe_ctx* c) {
   if (!c) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+  return sinkhorn_failed(c);         // (the batch entry points are asynchronous: a Sinkhorn time-out of an earlier call surfaces here)
 }
 
 int airfe_detect_points_batch_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride,
@@ -1747,8 +1700,9 @@ int airfe_bow_load(airfe_ctx* c, const float* node_desc, const int32_t* first_ch
   std::vector<int> fc(first_child, first_child + n_nodes), nc(n_children, n_children + n_nodes), wi(word_id, word_id + n_nodes);
   c->bow_desc = dupload(c, d); c->bow_weight = dupload(c, w);
   c->bow_first = dupload(c, fc); c->bow_nch = dupload(c, nc); c->bow_word = dupload(c, wi);
-  c->bow_out = dalloc<unsigned>(c, 1024); c->bow_outw = dalloc<float>(c, 1024);
-  if (!c->bow_desc || !c->bow_weight || !c->bow_first || !c->bow_nch || !c->bow_word || !c->bow_out || !c->bow_outw)
+  c->bow_out = dalloc<unsigned>(c, 1024); c->bow_outw = dalloc<float>(c, 1024); c->bow_outn = dalloc<int>(c, 1024);
+  c->bow_weight_h.assign(weight, weight + n_nodes);
+  if (!c->bow_desc || !c->bow_weight || !c->bow_first || !c->bow_nch || !c->bow_word || !c->bow_out || !c->bow_outw || !c->bow_outn)
     return fail(c, "device allocation failed (vocabulary)");
   c->bow_nodes = n_nodes;
   return 0;
@@ -1759,7 +1713,7 @@ int airfe_bow_transform_dev(airfe_ctx* c, const float* d_feat, int N, uint32_t* 
   if (!c->bow_nodes) return fail(c, "bow_transform: no vocabulary loaded (airfe_bow_load)");
   if (N < 0 || (N > 0 && (!d_feat || !d_word || !d_weight))) return fail(c, "bow_transform: bad argument");
   launch_bow_transform(d_feat, AIRFE_FEAT_DIM, 3, N, c->bow_desc, c->bow_first, c->bow_nch, c->bow_word, c->bow_weight, d_word, d_weight,
-                       stream ? (hipStream_t)stream : c->stream);
+                       d_weight == c->bow_outw ? c->bow_outn : nullptr, stream ? (hipStream_t)stream : c->stream);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1770,12 +1724,12 @@ int airfe_bow_transform(airfe_ctx* c, const float* feat, int N, uint32_t* word_o
   if (N < 0 || N > c->Np || N > 1024 || !feat || !word_of_features) return fail(c, "bow_transform: bad argument / more features than max_keypoints");
   HIPCHK(c, hipMemcpyAsync(c->st_feat0, feat, (size_t)N * AIRFE_FEAT_DIM * 4, hipMemcpyHostToDevice, c->stream));
   if (airfe_bow_transform_dev(c, c->st_feat0, N, c->bow_out, c->bow_outw, c->stream)) return 1;
-  std::vector<float> w(N);
+  std::vector<int> node(N);
   HIPCHK(c, hipMemcpyAsync(word_of_features, c->bow_out, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(w.data(), c->bow_outw, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(node.data(), c->bow_outn, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (weight_of_features)
-    for (int i = 0; i < N; ++i) weight_of_features[i] = (double)w[i];
+  if (weight_of_features)        // WordValue is a double in the reference (3rdparty/DBoW2 BowVector.h): the leaf's own weight, not a float round trip
+    for (int i = 0; i < N; ++i) weight_of_features[i] = c->bow_weight_h[(size_t)node[i]];
   return 0;
 }
 
@@ -1839,12 +1793,8 @@ int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_
   const size_t R = AIRFE_INTERNAL_SIZE;
   if (heat_raw) HIPCHK(c, hipMemcpy(heat_raw, c->heat, (size_t)B * R * R * 4, hipMemcpyDeviceToHost));
   if (heat_nms && c->cfg.nms_radius > 0 && !c->nms_map_valid) {      // the batch path skipped the dense map: rebuild it from the heat maps
-    if (c->nms_v1 || R != 512 || c->cfg.nms_radius != 4)
-      launch_nms4_candidates(c->heat, c->heat_nms, c->nms_mask, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt,
-                             R * R, c->stream);
-    else
-      launch_nms512_candidates(c->heat, c->heat_nms, c->nms_mask, (int)B, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt,
-                               R * R, c->stream);
+    launch_nms512_candidates(c->heat, c->heat_nms, c->nms_mask, (int)B, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt,
+                             R * R, c->stream);          // (the map is only ever skipped on the radius-4 path)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->nms_map_valid = true;
   }
@@ -1936,7 +1886,7 @@ int airfe_stereo_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d
                            float* d_score, int mcap, int* d_nmatch, void* stream) {
   if (!c) return 1;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  if (c->stereo_one_pass && c->prec != 2 && 2 * B <= c->Dmax) {        // left and right images as ONE detector batch
+  if (c->prec != 2 && 2 * B <= c->Dmax) {        // left and right images as ONE detector batch
     if (detect_dev2(c, d_left, d_right, B, h, w, stride, img_stride, d_featL, d_featR, cap, d_nL, d_nR, st)) return 1;
   } else {
     if (detect_dev(c, d_left, B, h, w, stride, img_stride, d_featL, cap, d_nL, st)) return 1;
@@ -2125,52 +2075,31 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint
                                  float* d_score, int mcap, int* d_nmatch, void* stream) {
   if (!c) return 1;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  if (!(c->stereo_one_pass && c->prec != 2 && 2 * B <= c->Dmax))
+  if (!(c->prec != 2 && 2 * B <= c->Dmax))
     return fail(c, "stereo_plnet_batch: needs the one-pass stereo detector (detector + LightGlue packs loaded, 2 B <= 2 max_batch, fp16 / bf16)");
   // (With stage timers on anything behind the encoder the chains run one after the other: a stage's event pair must not span the other chain.)
   const uint32_t enc_only = (1u << ST_PREPROCESS) | (1u << ST_CONV1A) | (1u << ST_CONV3X3_C64);
   const bool overlap = c->overlap_lines && (c->prof_mask & ~enc_only) == 0;
   c->force_nms_map = true;
-  c->mark_c3a = overlap;
   int rc = detect_dev2(c, d_left, d_right, B, h, w, stride, img_stride, d_featL, d_featR, cap, d_nL, d_nR, st);
   c->force_nms_map = false;
-  c->mark_c3a = false;
   if (rc) return 1;
   // lines of the 2 B images (left 0 .. B-1, right B .. 2B-1), junctions of the left ones (feature_detector.cc:100-101).
-  // AIRFE_OVERLAP_LINES=1 puts the line path on the context's second stream beside the matcher (they share nothing but the detector's
-  // results; +2 % from filled launch ramps and tails).  NOT the default: tools/experiments/plnet_determinism.py (120 steps at the bench size
-  // against the first one) found the MATCHER's scores of ONE pair off by 1e-3 (once by 0.8, with a different match count) in ~10 % of the
-  // steps when the line path's workgroups run beside it, and never (0 of 340) on one stream — the same class of schedule-dependent fault as
-  // the one DESIGN.md 2.2 describes, not yet located.  (AIRFE_OVERLAP_EARLY=1 additionally starts the line branch behind conv3a, beside
-  // the rest of the encoder: measured slower, it disturbs the encoder's persistent kernels.)
+  // The line path and the matcher share nothing but the detector's results: the line path runs on the context's second stream beside
+  // LightGlue on the caller's (+2 % from filled launch ramps and tails; fork behind the point branch, join behind both).  Round 2 kept this
+  // off: with the line path's workgroups beside it the matcher's scores were irreproducible in ~10 % of the steps — traced in round 3 to ONE
+  // packed-math instruction form in the rotary epilogue (common.h, rotate_pairs), which also failed, 50x more rarely, on one stream.
+  // With that form gone: 0 deviations in 3500 overlapped and 5000 single-stream steps (profiles/r03_matcher_trace.txt).
   if (!overlap) {
     if (plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, st)) return 1;
     return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
   }
-  static const bool early = getenv("AIRFE_OVERLAP_EARLY") && atoi(getenv("AIRFE_OVERLAP_EARLY")) != 0;
-  // AIRFE_OVERLAP_PHASE (fault hunting): 1 = only the lines part beside the matcher (the junction part after the join), 2 = only the junction
-  // part beside it (the lines part before the fork), 11..15 = only ONE stretch of the lines part: see line_branch_dev / line_tail_dev
-  static const int only = getenv("AIRFE_OVERLAP_PHASE") ? atoi(getenv("AIRFE_OVERLAP_PHASE")) : 0;
-  if (only == 2 && plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, st, 1)) return 1;
   HIPCHK(c, hipEventRecord(c->ev_fork, st));                  // behind the point branch
-  if (early) {
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_c3a, 0));
-    rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2, 1);
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    if (!rc) rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2, 2);
-  } else {
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    static const int cut = getenv("AIRFE_OVERLAP_CUT") ? atoi(getenv("AIRFE_OVERLAP_CUT")) : 0;
-    c->ovl_cut = cut; c->ovl_main = cut > 0 ? st : nullptr; c->ovl_hopped = false;
-    rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2, only == 1 || cut > 0 ? 1 : (only == 2 ? 2 : 3));
-    if (cut > 0 && !c->ovl_hopped) { (void)hipEventRecord(c->ev_fork, st); (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0); }
-    c->ovl_cut = 0; c->ovl_main = nullptr;
-    if (cut > 0 && !rc) rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2, 2);
-  }
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+  rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2);
   if (!rc) rc = lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));      // (also after an error: the caller's stream never runs ahead of the side stream)
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
-  if (!rc && only == 1) rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, st, 2);
   return rc;
 }
 
@@ -2229,6 +2158,17 @@ int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* line
   return 0;
 }
 
+// The register-resident Sinkhorn kernel raises a device word when one of its bounded rendezvous spins timed out (that pair's Z is NaN): read
+// after a synchronisation, cleared once reported.
+static int sinkhorn_failed(airfe_ctx* c) {
+  if (!c->has_sg || !c->sg_cnt) return 0;
+  unsigned f = 0;
+  unsigned* flag = c->sg_cnt + (size_t)c->Pmax * 16;
+  if (hipMemcpy(&f, flag, 4, hipMemcpyDeviceToHost) != hipSuccess || f == 0) return 0;
+  (void)hipMemset(flag, 0, 4);
+  return fail(c, "SuperGlue: a Sinkhorn rendezvous timed out (workgroups of the cooperative launch not co-resident?): the scores of that call are NaN");
+}
+
 static int sg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx0, int32_t* idx1, double* ms0,
                    double* ms1, float* scores_full) {
   if (!c) return 1;
@@ -2240,6 +2180,7 @@ static int sg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n
   HIPCHK(c, hipMemcpyAsync(c->st_n1, &n1, 4, hipMemcpyHostToDevice, c->stream));
   if (superglue_dev(c, c->st_feat0, c->st_n0, c->st_feat1, c->st_n1, 1, c->Np, 0, c->stream)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (sinkhorn_failed(c)) return 1;
   if (idx0) {
     std::vector<float> m0(n0), m1(n1);
     HIPCHK(c, hipMemcpy(idx0, c->sg_out0, (size_t)n0 * 4, hipMemcpyDeviceToHost));

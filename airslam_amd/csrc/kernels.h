@@ -96,10 +96,6 @@ void launch_conv64r(int prec, const ConvArgs& a, hipStream_t st);
 void launch_conv128r(int prec, const ConvArgs& a, hipStream_t st);
 // persistent tap-streamed variant for CIN == 128, COUT % 128 == 0 (launch_conv3x3 dispatches to it)
 
-// conv1a: fp32 image [B][H+2][W+2] (zero border) -> 2-byte [B][H+2][W+2][64], 3x3, Cin=1, ReLU
-void launch_conv1a(int prec, const float* img, const float* w /*[64][9]*/, const float* bias, uint16_t* out,
-                   int B, int H, int W, hipStream_t st);
-
 // cv::resize(INTER_LINEAR, 8-bit fixed point) + /255 -> fp32 [B][RH+2][RW+2] interior
 void launch_preprocess(const uint8_t* src, int B, int h, int w, int stride, size_t img_stride,
                        const int* xtab /*[RW][4]: x0,x1,a0,a1*/, const int* ytab /*[RH][4]*/, const float* lut /*[256]*/,
@@ -116,12 +112,9 @@ void launch_softmax_d2s(const float* logits, int ldl, float* heat, int B, int HC
 void launch_l2norm256(float* d, int rows, hipStream_t st);
 // SuperPoint simple_nms(radius) on fp32 [B][H][W]; tmp: 3 maps of the same size
 void launch_simple_nms(const float* heat, float* out, float* tmp, int B, int H, int W, int radius, hipStream_t st);
-// simple_nms(4): out = NMS'd map, and the detect_point candidates (score >= thr inside the border box)
-// are appended to cand [B][cand_cap] (49-bit keys) / cand_cnt [B]
-// one launch per max-pool over 64x32 tiles with a 4-pixel halo; mask = 2 bytes per pixel of scratch; out may be nullptr (no dense map)
-void launch_nms4_candidates(const float* heat, float* out, unsigned char* mask, int B, int H, int W, float thr, int border,
-                            unsigned long long* cand, int* cand_cnt, int cand_cap, hipStream_t st);
-// the same on the 512 x 512 map as three register-resident launches (kernels_nms512.hip); planes = 2 x [B][64][64] 64-bit words
+// simple_nms(4) on the 512 x 512 map as three register-resident launches (kernels_nms512.hip): out = NMS'd map (may be nullptr: no dense
+// map), and the detect_point candidates (score >= thr inside the border box) are appended to cand [B][cand_cap] (49-bit keys) /
+// cand_cnt [B]; planes = 2 x [B][64][64] 64-bit words
 void launch_nms512_candidates(const float* heat, float* out, void* planes, int B, float thr, int border, unsigned long long* cand,
                               int* cand_cnt, int cand_cap, hipStream_t st);
 // candidates from a finished map (NMS off, or radius != 4 through the multi-pass launch_simple_nms)
@@ -153,13 +146,11 @@ struct LgPrepArgs {
   int* lens;                          // [2B]
 };
 void launch_lg_prepare(int prec, const LgPrepArgs& a, hipStream_t st);
-// flash attention over head-major Q,K [S][H][Np][64] and Vt [S][H][64][Np]; cross => kv sequence s^1
-void launch_attention(int prec, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O /*[S][Np][256]*/,
-                      const int* lens, int S, int H, int Np, int cross, float scale, hipStream_t st);
-// the same on the 32x32x16 MFMA, one query per lane (kernels_attn.hip) — the default; the 16x16x32 kernel above stays for A/B runs
-// q and k arrive PRE-SCALED by sqrt(scale * log2 e) each (folded into their projection weights: ATT_QK_FOLD in airfe.hip)
+// flash attention over head-major Q,K [S][H][Np][64] and Vt [S][H][64][Np] -> O [S][Np][256]; cross => kv sequence s^1; on the 32x32x16
+// MFMA, one query per lane (kernels_attn.hip).  q and k arrive PRE-SCALED by sqrt(scale * log2 e) each (folded into their projection
+// weights: ATT_QK_FOLD in airfe.hip)
 void launch_attention32(int prec, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, const int* lens,
-                        int S, int H, int Np, int cross, int occ /* waves per SIMD the kernel is compiled for: 2 or 3 */, hipStream_t st);
+                        int S, int H, int Np, int cross, hipStream_t st);
 // in-place LayerNorm(512, eps) + exact GELU on 2-byte [M][512]
 void launch_ln_gelu(int prec, uint16_t* h, const float* gamma, const float* beta, int M, hipStream_t st);
 // z[M] = logsigmoid-ready matchability: dot(x32[m], w) + b
@@ -263,14 +254,15 @@ void launch_sg_prepare(int prec, const float* f0, const float* f1, const int* n0
 // counters: B * 16 unsigned of scratch (one 64-byte line per pair) for the fused kernel's per-pair rendezvous; nullptr = the launch-per-half-iteration form
 // xch: B * 64 * Lz floats of scratch (the register-resident kernel's per-iteration exchange of column partials); nullptr = streaming kernels only
 void launch_sg_sinkhorn(const float* sim, const int* lens, int B, int Np, int Lz, float alpha, int iters, float* u, float* v,
-                        float* Z, unsigned* counters, float* xch, hipStream_t st);
+                        float* Z, unsigned* counters /*B x 16 words*/, unsigned* fail_flag /*raised on a rendezvous time-out*/, float* xch,
+                        hipStream_t st);
 void launch_sg_decode(const float* Z, const int* lens, int B, int Np, int Lz, float thr, int* idx0, float* max0, int* idx1,
                       int32_t* out0, int32_t* out1, float* ms0, float* ms1, hipStream_t st);
 
 // ---- BoW quantisation: TemplatedVocabulary::transform per feature (tree descent by nearest child descriptor); feature i's descriptor
 //      starts at feat + i * ld + off; out_word = word id or UINT_MAX when the leaf's weight is <= 0
 void launch_bow_transform(const float* feat, int ld, int off, int N, const float* node_desc, const int* first_child,
-                          const int* n_children, const int* word_id, const float* weight, unsigned* out_word, float* out_weight,
+                          const int* n_children, const int* word_id, const float* weight, unsigned* out_word, float* out_weight, int* out_node /*leaf node per feature, may be nullptr*/,
                           hipStream_t st);
 
 // ---- point <-> line association (AssignPointsToLines, src/line_processor.cc:68-120) as CSR: row_ptr [L+1], entries

@@ -314,16 +314,11 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
 }
 
 void launch_attention32(int prec, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, const int* lens,
-                        int S, int H, int Np, int cross, int occ, hipStream_t st) {
+                        int S, int H, int Np, int cross, hipStream_t st) {
   const int nqb = (Np + 127) / 128;
   dim3 grid((unsigned)(nqb * H * S));                 // 1-D, decoded XCD-aware by the kernel; S * H % 8 == 0
-  if (occ == 3) {
-    if (prec == 1) hipLaunchKernelGGL((attention32_kernel<PF16, 3>), grid, dim3(256), 0, st, Q, K, Vt, O, lens, H, Np, cross, nqb);
-    else hipLaunchKernelGGL((attention32_kernel<PBF16, 3>), grid, dim3(256), 0, st, Q, K, Vt, O, lens, H, Np, cross, nqb);
-  } else {
-    if (prec == 1) hipLaunchKernelGGL((attention32_kernel<PF16, 2>), grid, dim3(256), 0, st, Q, K, Vt, O, lens, H, Np, cross, nqb);
-    else hipLaunchKernelGGL((attention32_kernel<PBF16, 2>), grid, dim3(256), 0, st, Q, K, Vt, O, lens, H, Np, cross, nqb);
-  }
+  if (prec == 1) hipLaunchKernelGGL((attention32_kernel<PF16, 3>), grid, dim3(256), 0, st, Q, K, Vt, O, lens, H, Np, cross, nqb);
+  else hipLaunchKernelGGL((attention32_kernel<PBF16, 3>), grid, dim3(256), 0, st, Q, K, Vt, O, lens, H, Np, cross, nqb);
 }
 
 }  // namespace airfe

@@ -897,149 +897,18 @@ __global__ void sg_scores_kernel(const float* __restrict__ sim, const int* __res
       sg_coupling(sim + (size_t)b * Np * Np, Np, n0, n1, alpha, i, j) + u[(size_t)b * Lz + i] + v[(size_t)b * Lz + j] - norm;
 }
 
-// The whole of log_optimal_transport in ONE launch: G workgroups per pair (G * pairs ~ 256, so every CU works), each owning a slice of the
-// rows in the u half-iteration and a slice of the columns in the v half-iteration; u and v are exchanged through global memory and the
-// G workgroups of a pair meet at a monotonic per-pair counter after every half-iteration (agent-scope release / acquire as
-// MI355X_MICROARCH.md 'Workgroup dispatch ... inter-workgroup visibility' prescribes: plain stores -> __syncthreads -> lane-0 release
-// fence -> asm vmcnt(0) -> relaxed atomic arrive; one relaxed poll loop -> acquire fence -> __syncthreads -> plain loads).
-// History: 2 x iters launches per step, each reading the couplings twice for all pairs: ~25 ms per 64 pairs at N = 400; ONE workgroup
-// per pair (no inter-workgroup traffic at all): 21 ms — a single workgroup is latency-bound on its 643 KB matrix, and at N = 1024
-// with 16 pairs it was 2x SLOWER than the launches.  All G x pairs workgroups are co-resident by construction (grid <= 128 on 256
-// CUs); every spin is bounded all the same, a timeout poisons the pair's output with NaN instead of hanging.
-template <int MAXC>
-__global__ __launch_bounds__(512) void sg_sinkhorn_fused_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np, int Lz,
-                                                               float alpha, int iters, int G, float* __restrict__ ug, float* __restrict__ vg,
-                                                               float* __restrict__ Z, unsigned* __restrict__ counters) {
-  constexpr int NW = 8, NT = 512;
-  __shared__ float u[1040], v[1040];
-  __shared__ float pm[NW][64], psum[NW][64];
-  __shared__ int s_fail;
-  const int b = blockIdx.x / G, g = blockIdx.x - b * G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
-  const float* S = sim + (size_t)b * Np * Np;
-  float* ub = ug + (size_t)b * Lz;
-  float* vb = vg + (size_t)b * Lz;
-  unsigned* cnt = counters + b * 16;                      // one 64-byte line per pair
-  const float norm = -logf((float)(n0 + n1));
-  const float lmu_last = logf((float)n1) + norm, lnu_last = logf((float)n0) + norm;
-  const int rper = (n0 + 1 + G - 1) / G, r_lo = g * rper, r_hi = min(r_lo + rper, n0 + 1);      // this workgroup's rows
-  const int cper = (n1 + 1 + G - 1) / G, c_lo = g * cper, c_hi = min(c_lo + cper, n1 + 1);      // ... and columns
-  for (int i = tid; i < 1040; i += NT) { u[i] = 0.f; v[i] = 0.f; }
-  if (tid == 0) s_fail = 0;
-  __syncthreads();
-  unsigned target = 0;
-  auto rendezvous = [&]() {                               // all G workgroups of this pair have published their slice
-    target += (unsigned)G;
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int spins = 0;
-      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 18)) { s_fail = 1; break; }        // ~0.3 s: never reached unless a partner workgroup is not resident
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-  };
-  const int nchunk = (n1 + 1 + 63) >> 6;
-  for (int it = 0; it < iters && !s_fail; ++it) {
-    // ---- u[i] = log_mu[i] - logsumexp_j(C[i][j] + v[j]) for this workgroup's rows; one wave per row, the row in registers
-    // (RU rows per wave and pass: the loads of all of them are in flight together — one row at a time left the wave waiting a full
-    //  L2 / MALL round trip per row, the kernel was latency-bound at ~2 us per row)
-    constexpr int RU = MAXC > 8 ? 2 : 4;
-    for (int i0 = r_lo + wv * RU; i0 < r_hi; i0 += NW * RU) {
-      float x[RU][MAXC];
-      float mx[RU], sm[RU];
-#pragma unroll
-      for (int q = 0; q < RU; ++q) {
-        const int i = i0 + q;
-        mx[q] = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < MAXC; ++k) {
-          const int j = lane + 64 * k;
-          x[q][k] = -INFINITY;
-          if (i < r_hi && k < nchunk && j <= n1) x[q][k] = ((i < n0 && j < n1) ? S[(size_t)i * Np + j] : alpha) + v[j];
-          mx[q] = fmaxf(mx[q], x[q][k]);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < RU; ++q) mx[q] = wave_max(mx[q]);
-#pragma unroll
-      for (int q = 0; q < RU; ++q) {
-        sm[q] = 0.f;
-#pragma unroll
-        for (int k = 0; k < MAXC; ++k)
-          if (k < nchunk) sm[q] += __expf(x[q][k] - mx[q]);          // exp(-inf) = 0 for the padding slots
-      }
-#pragma unroll
-      for (int q = 0; q < RU; ++q) sm[q] = wave_sum(sm[q]);
-      if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < RU; ++q)
-          if (i0 + q < r_hi) ub[i0 + q] = ((i0 + q < n0) ? norm : lmu_last) - (mx[q] + logf(sm[q]));
-      }
-    }
-    if (G > 1) rendezvous(); else __syncthreads();
-    for (int i = tid; i <= n0; i += NT) u[i] = ub[i];
-    __syncthreads();
-    // ---- v[j] = log_nu[j] - logsumexp_i(C[i][j] + u[i]) for this workgroup's columns: 64 columns x 8 row slices per pass
-    for (int j0 = c_lo; j0 < c_hi; j0 += 64) {
-      const int j = j0 + lane;
-      float m = -INFINITY, sm = 0.f;
-      if (j < c_hi) {
-        for (int i0 = wv; i0 <= n0; i0 += NW * 16) {         // this slice's rows i0, i0 + NW, ... in chunks of 16 values
-          float x[16];
-          float cm = -INFINITY;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int i = i0 + NW * r;
-            x[r] = -INFINITY;
-            if (i <= n0) x[r] = ((i < n0 && j < n1) ? S[(size_t)i * Np + j] : alpha) + u[i];
-            cm = fmaxf(cm, x[r]);
-          }
-          const float mn = fmaxf(m, cm);
-          float cs = 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) cs += __expf(x[r] - mn);
-          sm = sm * __expf(m - mn) + cs;                     // m = -inf on the first chunk: exp(-inf) = 0, sm was 0
-          m = mn;
-        }
-      }
-      pm[wv][lane] = m;
-      psum[wv][lane] = sm;
-      __syncthreads();
-      if (wv == 0 && j < c_hi) {
-        float M = pm[0][lane];
-#pragma unroll
-        for (int q = 1; q < NW; ++q) M = fmaxf(M, pm[q][lane]);
-        float T = 0.f;
-#pragma unroll
-        for (int q = 0; q < NW; ++q) T += psum[q][lane] * __expf(pm[q][lane] - M);     // empty slices: sum 0, exp(-inf - M) = 0
-        vb[j] = ((j < n1) ? norm : lnu_last) - (M + logf(T));
-      }
-      __syncthreads();
-    }
-    if (G > 1) rendezvous(); else __syncthreads();
-    for (int j = tid; j <= n1; j += NT) v[j] = vb[j];
-    __syncthreads();
-  }
-  // ---- Z = C + u + v - norm for this workgroup's rows (cols 0..n1)
-  const float poison = s_fail ? NAN : 0.f;
-  for (int i = r_lo + wv; i < r_hi; i += NW)
-    for (int j = lane; j <= n1; j += 64)
-      Z[((size_t)b * Lz + i) * Lz + j] = ((i < n0 && j < n1) ? S[(size_t)i * Np + j] : alpha) + u[i] + v[j] - norm + poison;
-}
-
+// The whole of log_optimal_transport in ONE launch.  History: 2 x iters launches per step, each reading the couplings twice for all pairs
+// (the sg_sinkhorn_row / _col kernels above, still the fallback): ~25 ms per 64 pairs at N = 400; ONE workgroup per pair (no inter-workgroup
+// traffic at all): 21 ms — a single workgroup is latency-bound on its 643 KB matrix; G workgroups per pair streaming the matrix from L2 and
+// meeting at a counter: 13.6 ms (retired: it was launched non-cooperatively, i.e. it ASSUMED co-residency of its workgroups); below: 1.46 ms.
 // Register-resident form: the couplings of a pair never leave the register files of the G workgroups that share it.  Workgroup g owns
 // a slice of the ROWS (wave w the rows r_lo + w, + 8, ...; lane l the columns l, l + 64, ...: RW x MAXC values per lane, 91 at N = 400,
 // 153 at N = 1024), loaded once.  The u half-iteration is wave-local (a row is one wave: two wave reductions, u[i] stays in that wave);
 // the v half-iteration reduces each column over the wave's own rows in registers, over the 8 waves through LDS, and over the G
 // workgroups through ONE exchange of (max, sum) pairs per column and iteration — one rendezvous per iteration, ~6 KB per workgroup,
 // instead of re-reading 643 KB of couplings twice.  The launch is COOPERATIVE (the runtime guarantees that all workgroups are
-// resident, or refuses the launch and the streaming kernel above runs); spins are bounded all the same.
+// resident, or refuses the launch and the per-iteration launches run); spins are bounded all the same: a timeout poisons that pair's
+// output with NaN AND raises *fail_flag, which the host entry points check after their synchronisation (airfe.hip: sg_host).
 template <int CTRL>
 __device__ __forceinline__ float sk_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
@@ -1064,7 +933,7 @@ __device__ __forceinline__ float sk_wave_sum(float v) {
 template <int RW, int MAXC>
 __global__ __launch_bounds__(512) void sg_sinkhorn_reg_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np, int Lz,
                                                              float alpha, int iters, int G, float2* __restrict__ xch,
-                                                             float* __restrict__ Z, unsigned* __restrict__ counters) {
+                                                             float* __restrict__ Z, unsigned* __restrict__ counters, unsigned* __restrict__ fail_flag) {
   constexpr int NW = 8, NT = 512, NC = 64 * MAXC;
   __shared__ float pm[NW][NC], ps[NW][NC];
   __shared__ float vs[NC];
@@ -1205,45 +1074,39 @@ __global__ __launch_bounds__(512) void sg_sinkhorn_reg_kernel(const float* __res
 
 template <int RW, int MAXC>
 static bool try_sinkhorn_reg(const float* sim, const int* lens, int B, int Np, int Lz, float alpha, int iters, float2* xch, float* Z,
-                             unsigned* counters, hipStream_t st) {
+                             unsigned* counters, unsigned* fail_flag, hipStream_t st) {
   int G = (Np + 1 + 8 * RW - 1) / (8 * RW);
   if (G > 16 || Np + 1 > 64 * MAXC || Lz < 64 * MAXC) return false;
-  static int max_wgs = -1;                                   // co-resident workgroups of this instantiation on this device
-  if (max_wgs < 0) {
-    int dev = 0, per_cu = 0;
+  static int max_wgs[64];                                    // co-resident workgroups of this instantiation, per device ordinal (0 = not asked yet)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (max_wgs[dev] == 0) {
+    int per_cu = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sg_sinkhorn_reg_kernel<RW, MAXC>, 512, 0) != hipSuccess)
-      max_wgs = 0;
+      max_wgs[dev] = -1;
     else
-      max_wgs = per_cu * prop.multiProcessorCount;
+      max_wgs[dev] = std::max(per_cu * prop.multiProcessorCount, 1);
   }
-  if (B * G > max_wgs) return false;
+  if (B * G > max_wgs[dev]) return false;
   (void)hipMemsetAsync(counters, 0, (size_t)B * 64, st);
-  void* args[] = {(void*)&sim, (void*)&lens, (void*)&Np, (void*)&Lz, (void*)&alpha, (void*)&iters, (void*)&G, (void*)&xch, (void*)&Z, (void*)&counters};
+  void* args[] = {(void*)&sim, (void*)&lens, (void*)&Np, (void*)&Lz, (void*)&alpha, (void*)&iters, (void*)&G, (void*)&xch, (void*)&Z, (void*)&counters,
+                  (void*)&fail_flag};
   const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&sg_sinkhorn_reg_kernel<RW, MAXC>), dim3(B * G), dim3(512), args, 0, st);
   if (e != hipSuccess) { (void)hipGetLastError(); return false; }
   return true;
 }
 
+// counters: B x 64 bytes of rendezvous counters; fail_flag: one word, raised (never cleared here) when a rendezvous timed out
 void launch_sg_sinkhorn(const float* sim, const int* lens, int B, int Np, int Lz, float alpha, int iters, float* u, float* v,
-                        float* Z, unsigned* counters, float* xch, hipStream_t st) {
-  static const bool unfused = getenv("AIRFE_SINKHORN_UNFUSED") && atoi(getenv("AIRFE_SINKHORN_UNFUSED")) != 0;   // A/B runs
-  static const bool noreg = getenv("AIRFE_SINKHORN_STREAM") && atoi(getenv("AIRFE_SINKHORN_STREAM")) != 0;
-  if (!unfused && !noreg && counters && xch) {
+                        float* Z, unsigned* counters, unsigned* fail_flag, float* xch, hipStream_t st) {
+  if (counters && xch && fail_flag) {
     float2* x2 = reinterpret_cast<float2*>(xch);
-    if (Np + 1 <= 448 && try_sinkhorn_reg<13, 7>(sim, lens, B, Np, Lz, alpha, iters, x2, Z, counters, st)) return;
-    if (Np + 1 <= 1088 && try_sinkhorn_reg<9, 17>(sim, lens, B, Np, Lz, alpha, iters, x2, Z, counters, st)) return;
+    if (Np + 1 <= 448 && try_sinkhorn_reg<13, 7>(sim, lens, B, Np, Lz, alpha, iters, x2, Z, counters, fail_flag, st)) return;
+    if (Np + 1 <= 1088 && try_sinkhorn_reg<9, 17>(sim, lens, B, Np, Lz, alpha, iters, x2, Z, counters, fail_flag, st)) return;
   }
-  if (!unfused && Np <= 1024 && counters && B <= 128) {
-    int G = 1;
-    while (G < 16 && B * G * 2 <= 128) G *= 2;         // workgroups per pair: at ~140 registers ONE 8-wave workgroup fits a CU, so the grid stays
-                                                       // at <= 128 workgroups — every one is resident even if half the CUs are busy elsewhere
-    (void)hipMemsetAsync(counters, 0, (size_t)B * 64, st);
-    if (Np + 1 <= 512) hipLaunchKernelGGL((sg_sinkhorn_fused_kernel<8>), dim3(B * G), dim3(512), 0, st, sim, lens, Np, Lz, alpha, iters, G, u, v, Z, counters);
-    else hipLaunchKernelGGL((sg_sinkhorn_fused_kernel<17>), dim3(B * G), dim3(512), 0, st, sim, lens, Np, Lz, alpha, iters, G, u, v, Z, counters);
-    return;
-  }
+  // what does not fit the register files, or a device that cannot hold the cooperative grid (a partition, a busy GPU): one launch per half-iteration
   (void)hipMemsetAsync(u, 0, (size_t)B * Lz * 4, st);
   (void)hipMemsetAsync(v, 0, (size_t)B * Lz * 4, st);
   for (int it = 0; it < iters; ++it) {
@@ -1343,10 +1206,12 @@ __global__ __launch_bounds__(256) void bow_transform_kernel(const float* __restr
                                                             const float* __restrict__ node_desc, const int* __restrict__ first_child,
                                                             const int* __restrict__ n_children, const int* __restrict__ word_id,
                                                             const float* __restrict__ weight, unsigned* __restrict__ out_word,
-                                                            float* __restrict__ out_weight) {
+                                                            float* __restrict__ out_weight, int* __restrict__ out_node) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= N) return;
-  const float4 f = *reinterpret_cast<const float4*>(feat + (size_t)i * ld + off + lane * 4);
+  // (a feature row starts at float 259 i + 3: only 4-byte aligned, so four scalar loads, not a float4)
+  const float* fp = feat + (size_t)i * ld + off + lane * 4;
+  const float4 f = make_float4(fp[0], fp[1], fp[2], fp[3]);
   int node = 0;
   for (int nc = n_children[0]; nc > 0; nc = n_children[node]) {
     const int c0 = first_child[node];
@@ -1364,15 +1229,16 @@ __global__ __launch_bounds__(256) void bow_transform_kernel(const float* __restr
     const float w = weight[node];
     out_word[i] = w > 0.f ? (unsigned)word_id[node] : 0xFFFFFFFFu;      // database.cc:77-83: stopped words -> UINT_MAX
     out_weight[i] = w;
+    if (out_node) out_node[i] = node;
   }
 }
 
 void launch_bow_transform(const float* feat, int ld, int off, int N, const float* node_desc, const int* first_child,
                           const int* n_children, const int* word_id, const float* weight, unsigned* out_word, float* out_weight,
-                          hipStream_t st) {
+                          int* out_node, hipStream_t st) {
   if (N < 1) return;
   hipLaunchKernelGGL(bow_transform_kernel, dim3((N + 3) / 4), dim3(256), 0, st, feat, ld, off, N, node_desc, first_child, n_children,
-                     word_id, weight, out_word, out_weight);
+                     word_id, weight, out_word, out_weight, out_node);
 }
 
 // =============================================================================== point <-> line association

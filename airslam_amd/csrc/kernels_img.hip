@@ -107,56 +107,6 @@ void launch_preprocess(const uint8_t* src, int B, int h, int w, int stride, size
                      reinterpret_cast<const int4*>(xtab), reinterpret_cast<const int4*>(ytab), lut, out, RH, RW);
 }
 
-// =============================================================================== conv1a
-// Cin = 1: K = 9 is hopeless as a GEMM (AI ~ 9 F/B) -> fp32 VALU, 8 output channels per thread,
-// 8 consecutive threads write the 128 contiguous bytes of one pixel.
-template <class P>
-__global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ img, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, uint16_t* __restrict__ out,
-                                                     int B, int H, int W) {
-  const int cg = threadIdx.x & 7;
-  float wr[8][9], br[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    br[c] = bias[cg * 8 + c];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) wr[c][k] = w[(cg * 8 + c) * 9 + k];
-  }
-  const long total = (long)B * H * W;
-  const long step = ((long)gridDim.x * blockDim.x) >> 3;
-  for (long pix = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; pix < total; pix += step) {
-    const int b = (int)(pix / ((long)H * W));
-    const int rem = (int)(pix - (long)b * H * W);
-    const int y = rem / W, x = rem - y * W;
-    const float* ip = img + ((size_t)b * (H + 2) + y) * (W + 2) + x;
-    float in[9];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) in[ky * 3 + kx] = ip[(size_t)ky * (W + 2) + kx];
-    float v[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float s = br[c];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) s = fmaf(wr[c][k], in[k], s);
-      v[c] = fmaxf(s, 0.f);
-    }
-    *reinterpret_cast<uint4*>(out + (((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + cg * 8) = pack8<P>(v);
-  }
-}
-
-void launch_conv1a(int prec, const float* img, const float* w, const float* bias, uint16_t* out, int B, int H, int W,
-                   hipStream_t st) {
-  const long total = (long)B * H * W;
-  long blocks = (total * 8 + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  if (prec == 1)
-    hipLaunchKernelGGL(conv1a_kernel<PF16>, dim3((unsigned)blocks), dim3(256), 0, st, img, w, bias, out, B, H, W);
-  else
-    hipLaunchKernelGGL(conv1a_kernel<PBF16>, dim3((unsigned)blocks), dim3(256), 0, st, img, w, bias, out, B, H, W);
-}
-
 // =============================================================================== detector head
 // softmax over 65 logits, drop the dustbin, 8x8 depth-to-space (SuperPoint head)
 __global__ void softmax_d2s_kernel(const float* __restrict__ logits, int ldl, float* __restrict__ heat, int ncell,

@@ -24,6 +24,14 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+def latest_profile(suffix):
+    """newest committed profiles/rNN_<suffix> (counter passes are separate runs: tools/gpu_profile.sh), or None"""
+    import glob
+    import re
+    c = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)) if re.match(r"r\d\d_" + re.escape(suffix) + "$", os.path.basename(f))]
+    return sorted(c)[-1] if c else None
+
+
 DOMINANT_STAGE = "conv3x3_cin64"   # largest single share of a step; its events stay on inside the timed region
 PEAK_MFMA_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
@@ -202,7 +210,7 @@ def side_workloads(args, rank, world, local, dev):
                "data": "synthetic",
                "config": {"workload": what + "; seeded synthetic weights (reference ONNX files are absent)", "pairs_per_step_per_gpu": B,
                           "detector": "plnet (batch-1 host API)" if args.plnet_host else "superpoint", "matcher": args.matcher, "matches_mean": n_match[0]},
-               "roofline": None, "cpu_baseline": None}
+               "roofline": None, "cpu_baseline": None, "collective": args.collective}
         if args.plnet_host:
             out["config"]["lines_last_frame"] = lines_n[0]
         if stages:
@@ -215,8 +223,8 @@ def side_workloads(args, rank, world, local, dev):
             if fl_tot > 0 and ms_tot > 0:
                 ach = fl_tot / (ms_tot * 1e-3) / 1e12
                 util, usrc = None, None
-            pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_summary.json")
-            if os.path.exists(pf):      # counter-derived MFMA utilisation of the encoder kernels (separate --pmc pass, tools/pmc_summary.py)
+            pf = latest_profile("pmc_summary.json")
+            if pf:      # counter-derived MFMA utilisation of the encoder kernels (separate --pmc pass, tools/pmc_summary.py)
                 with open(pf) as fh:
                     ks = json.load(fh)["kernels"]
                 enc = {k: v for k, v in ks.items() if ("conv64r_kernel" in k or "conv128r_kernel" in k) and "mfma_util" in v}
@@ -225,7 +233,7 @@ def side_workloads(args, rank, world, local, dev):
                     util = {"encoder_time_weighted": sum(v["mfma_util"] * v["counters_per_launch"]["GRBM_GUI_ACTIVE"] * v["launches_sampled"]
                                                          for v in enc.values()) / wsum,
                             "per_kernel": {k.split("(")[0].replace("void airfe::", ""): round(v["mfma_util"], 3) for k, v in enc.items()}}
-                    usrc = "profiles/r02_pmc_summary.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)"
+                    usrc = "profiles/" + os.path.basename(pf) + ": SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)"
             out["roofline"] = {"bound": "mfma", "mfma_util_counters": util, "mfma_util_source": usrc, "kernel": "all bracketed matrix stages of one step (algorithmic FLOPs / their event time)",
                                    "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS, "traffic": None}
         print(json.dumps(out))
@@ -255,23 +263,43 @@ def main():
                     help="plnet (default): PLNet::infer on both images (points + line branch + stage 1 + line filter, junctions on the left), the "
                          "reference's keyframe step; superpoint: the point-only step")
     ap.add_argument("--plnet-host", action="store_true", help="PLNet + matcher through the batch-1 HOST API instead (PCIe and one sync per call included)")
-    ap.add_argument("--workload", default="stereo", choices=["stereo", "loop"],
-                    help="loop: matcher only, replaying a map file's feature records (loop closure, map_refiner.cc:213-230)")
+    ap.add_argument("--workload", default="stereo", choices=["stereo", "track", "loop"],
+                    help="track: the NORMAL-frame step of the VO loop (map_builder.cc:94-101: Detect(left, features) = PLNet points + lines on the new "
+                         "frame, then MatchingPoints(last_keyframe, frame)); loop: matcher only, replaying a map file's feature records (loop closure, "
+                         "map_refiner.cc:213-230)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--stage-steps", type=int, default=3, help="extra untimed steps for the per-stage table")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU under torch.distributed.run, exactly what the
+    # contract's own launch line does) instead of silently measuring one GPU.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     from airslam_amd import api, dist as adist, synth, weights
 
     rank, world, local = adist.init_from_env(os.environ.get("AIRFE_DIST_BACKEND"))   # default: nccl (= RCCL) on GPUs
     if os.environ.get("AIRFE_ONE_DEVICE"):     # test hook: several ranks share GPU 0 (with AIRFE_DIST_BACKEND=gloo; RCCL refuses that)
         local = 0
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
+    args.collective = ({"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
+                        "per_step": "one packed gather of the match lists to rank 0 (airslam_amd/dist.py)"} if world > 1 else None)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B, H, W, K = args.pairs, args.height, args.width, args.max_keypoints
 
+    if args.workload == "track" and (args.plnet_host or args.matcher == "superglue"):
+        raise SystemExit("--workload track runs the device-resident PLNet / SuperPoint + LightGlue path")
     if args.plnet_host or args.matcher == "superglue" or args.workload == "loop":
         return side_workloads(args, rank, world, local, dev)
 
@@ -302,8 +330,26 @@ def main():
     def points_step():
         ctx.stereo_batch_dev(L, R, fl, fr, nl, nr, idx, sc, nm, stream=sh)
 
-    def step():
+    track = args.workload == "track"
+    if track:
+        # the last keyframe's features (map_builder.cc:100 `_last_keyframe_feature->GetAllFeatures()`): the left images, detected once;
+        # the "new frames" are the right images (the same scenes seen from a shifted camera)
         if plnet:
+            ctx.detect_plnet_batch_dev(L, fl, nl, lines[:B], nlines[:B], None, None, found[:B], stream=sh)
+        else:
+            ctx.detect_batch_dev(L, fl, nl, stream=sh)
+        torch.cuda.synchronize(dev)
+
+    def step():
+        if track:
+            # Detect(image_left, features) on a normal frame = PLNet::infer(points + lines, no junctions: feature_detector.cc:36-60) on ONE
+            # image, then MatchingPoints(features_last_keyframe, left_features) (map_builder.cc:94-101)
+            if plnet:
+                ctx.detect_plnet_batch_dev(R, fr, nr, lines[B:], nlines[B:], None, None, found[B:2 * B], stream=sh)
+            else:
+                ctx.detect_batch_dev(R, fr, nr, stream=sh)
+            ctx.match_lightglue_batch_dev(fl, nl, fr, nr, idx, sc, nm, stream=sh)
+        elif plnet:
             ctx.stereo_plnet_batch_dev(L, R, fl, fr, nl, nr, lines, nlines, junc, njunc, idx, sc, nm, found, stream=sh)
         else:
             points_step()
@@ -343,7 +389,7 @@ def main():
         ctx.profile(False)
     barrier()
     points_only = None
-    if plnet:                          # the point-only step (Detect(left, right, features) with use_superpoint = 1) on the same context and inputs
+    if plnet and not track:            # the point-only step (Detect(left, right, features) with use_superpoint = 1) on the same context and inputs
         for _ in range(args.warmup):
             points_step()
         barrier()
@@ -359,9 +405,11 @@ def main():
         total_pairs = B * args.steps * world
         ms_step = dt / args.steps * 1e3
         out = {
-            "metric": "stereo detect+match pairs/sec (" + ("2x PLNet @512x512 internal: points + lines, junctions on the left" if plnet
+            "metric": ("tracked frames/sec (normal-frame step: 1x " + ("PLNet @512x512 internal: points + lines" if plnet else "SuperPoint-VGG detect")
+                       + " on the new frame + LightGlue against the last keyframe)") if track else
+                      "stereo detect+match pairs/sec (" + ("2x PLNet @512x512 internal: points + lines, junctions on the left" if plnet
                                                           else "2x SuperPoint-VGG detect @512x512 internal") + " + LightGlue match)",
-            "value": total_pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": total_pairs / dt, "unit": "frames/s" if track else "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype if args.dtype == args.matcher_dtype else f"{args.dtype} (encoder) + {args.matcher_dtype} (matcher), fp32 accumulate",
             "data": "synthetic",
@@ -371,7 +419,11 @@ def main():
                        "pairs_per_step_per_gpu": B, "internal_resolution": 512, "parallelism": f"frame-sharded x{world}",
                        "keypoints_left_right_mean": [float(nl.float().mean()), float(nr.float().mean())],
                        "matches_mean": float(nm.float().mean()), "detector": args.detector},
+            "collective": args.collective,
         }
+        if track:
+            out["config"]["workload"] = (f"{B} synthetic {W}x{H} uint8 frames per step per GPU, resident in HBM, each matched against its last keyframe's "
+                                         f"features (map_builder.cc:94-101); max_keypoints={K}; seeded synthetic weights (reference ONNX files are absent)")
         if plnet:
             fh_ = found.cpu().numpy()
             if (fh_[:2 * B] > CL).any() or (fh_[2 * B:] > CJ).any():
@@ -380,20 +432,24 @@ def main():
                                           "output/plnet_s1.onnx, line_threshold / line_length_threshold at the reference's 0.75 / 50")
             out["config"]["lines_mean"] = float(nlines.float().mean())
             out["config"]["junctions_mean_left"] = float(njunc.float().mean())
+            if track:
+                out["config"]["lines_mean"] = float(nlines[B:].float().mean())
+                del out["config"]["junctions_mean_left"]
+        if plnet and not track:
             out["config"]["points_only_pairs_per_s"] = points_only
             out["config"]["points_only_note"] = ("the point-only step (2x detect + LightGlue, airfe_stereo_batch_dev: `--detector superpoint`) timed on the "
                                                  "same context and inputs over the same number of steps")
         if dom:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
             traffic, tsrc = None, None
-            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_hbm_traffic.json")
-            if os.path.exists(tf):      # measured in separate --pmc passes (never together with other tracing), see profiles/README.md
+            tf = latest_profile("hbm_traffic.json")
+            if tf:      # measured in separate --pmc passes (never together with other tracing), see profiles/README.md
                 with open(tf) as fh:
                     traffic = json.load(fh).get("conv3x3_cin64_stage", {}).get("hbm_bytes_per_launch")
-                tsrc = "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+                tsrc = "profiles/" + os.path.basename(tf) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
             util, usrc = None, None
-            pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_summary.json")
-            if os.path.exists(pf):      # counter-derived MFMA utilisation of the encoder kernels (separate --pmc pass, tools/pmc_summary.py)
+            pf = latest_profile("pmc_summary.json")
+            if pf:      # counter-derived MFMA utilisation of the encoder kernels (separate --pmc pass, tools/pmc_summary.py)
                 with open(pf) as fh:
                     ks = json.load(fh)["kernels"]
                 enc = {k: v for k, v in ks.items() if ("conv64r_kernel" in k or "conv128r_kernel" in k) and "mfma_util" in v}
@@ -402,7 +458,7 @@ def main():
                     util = {"encoder_time_weighted": sum(v["mfma_util"] * v["counters_per_launch"]["GRBM_GUI_ACTIVE"] * v["launches_sampled"]
                                                          for v in enc.values()) / wsum,
                             "per_kernel": {k.split("(")[0].replace("void airfe::", ""): round(v["mfma_util"], 3) for k, v in enc.items()}}
-                    usrc = "profiles/r02_pmc_summary.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)"
+                    usrc = "profiles/" + os.path.basename(pf) + ": SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)"
             out["roofline"] = {"bound": "mfma", "mfma_util_counters": util, "mfma_util_source": usrc, "kernel": "conv64r_kernel (conv1a fused into conv1b + pool, conv2a, conv2b + pool, conv3a)",
                                "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
                                "traffic": traffic, "traffic_source": tsrc,
@@ -415,7 +471,7 @@ def main():
                                  "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] else None,
                                  "algo_gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
                              for k, v in stages.items() if v["launches"]}
-        if world == 1 and args.cpu_pairs > 0:
+        if world == 1 and args.cpu_pairs > 0 and not track:
             out["cpu_baseline"] = cpu_baseline(sp, lg, H, W, args.cpu_pairs, K, s1=weights.load_pack(s1_path) if plnet else None)
         print(json.dumps(out))
     ctx.close()

@@ -183,6 +183,7 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* ctx, const uint8_t* d_left, const ui
                                  size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, double* d_lines,
                                  int capL, int* d_nlines, float* d_juncL, int capJ, int* d_njuncL, int* d_found, int32_t* d_idx,
                                  float* d_score, int mcap, int* d_nmatch, void* stream);
+/* synchronises the context's own stream; also reports (once) a Sinkhorn rendezvous time-out of an earlier SuperGlue call */
 int airfe_sync(airfe_ctx* ctx);
 
 /* ---- per-stage hipEvent timers (measurement; SURVEY.md §5 "tracing") ----------------------------------- */

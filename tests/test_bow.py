@@ -55,8 +55,8 @@ def test_bow_transform_vs_oracle(k, L, n):
     diag(f"bow_{k}_{L}_{n}", n=n, clear=int(clear.sum()), stopped=int((rw == 0xFFFFFFFF).sum()), distinct_words=len(set(rw.tolist())))
     assert clear.mean() > 0.98
     np.testing.assert_array_equal(words[clear], rw[clear])
-    np.testing.assert_allclose(w[clear], rwt[clear].astype(np.float32), rtol=1e-6)
+    np.testing.assert_array_equal(w[clear], rwt[clear])             # the vocabulary's own doubles (WordValue is a double in the reference), no float round trip
     if clear.all():
-        assert ref_post.frame_to_bow(words, w.astype(np.float32).astype(np.float64))[1] == ref_post.frame_to_bow(rw, rwt)[1]
+        assert ref_post.frame_to_bow(words, w) == ref_post.frame_to_bow(rw, rwt)
     assert (rw == 0xFFFFFFFF).any() or n < 50                # stopped words are exercised
     ctx.close()

@@ -84,3 +84,21 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_bench_gpus_n_starts_n_ranks_and_checks_the_world_size():
+    """bench.py --gpus N: (a) with a launcher that started a different number of ranks it refuses instead of printing a mislabelled line;
+    (b) with no launcher it starts N ranks itself (torch.distributed.run) — without a GPU each of them then stops at the product's
+    "needs a GPU" exit, which is enough to see that two ranks came up (the GPU form of this test: tests/test_gpu_bench_contract.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but the launcher started 1 rank(s)" in r.stderr
+    if torch.cuda.is_available():
+        return
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, AIRFE_DIST_BACKEND="gloo"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-1500:]

@@ -51,3 +51,22 @@ def test_side_workload_lines(args):
         assert d["config"]["lines_last_frame"] >= 50          # the structured synthetic line head: lines survive the reference's thresholds
     elif "superpoint" in args:
         assert d["config"]["detector"] == "superpoint" and "lines_mean" not in d["config"] and d["config"]["matches_mean"] > 50
+
+
+def test_track_workload_line():
+    """the normal-frame step (map_builder.cc:94-101): 1x PLNet (points + lines) on the new frame + LightGlue against the last keyframe"""
+    d = _run("--workload", "track", "--pairs", "8", "--steps", "3", "--warmup", "1")
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["value"] > 0 and "tracked frames" in d["metric"]
+    assert d["config"]["matches_mean"] > 50 and d["config"]["lines_mean"] >= 50 and "junctions_mean_left" not in d["config"]
+    assert d["cpu_baseline"] is None if "cpu_baseline" in d else True
+
+
+def test_gpus_2_launches_two_ranks_itself(monkeypatch):
+    """`python bench.py --gpus 2` without a launcher must start two ranks (torch.distributed.run underneath) and say so: here both ranks share
+    GPU 0 and talk over gloo (RCCL refuses two ranks on one device); the gather of the match lists to rank 0 runs every step."""
+    monkeypatch.setenv("AIRFE_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("AIRFE_ONE_DEVICE", "1")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    d = _run("--gpus", "2", "--pairs", "4", "--steps", "2", "--warmup", "1", "--cpu-pairs", "0", "--no-profile")
+    assert d["n_gpus"] == 2 and d["collective"]["ranks"] == 2 and d["collective"]["backend"] == "gloo"
+    assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]

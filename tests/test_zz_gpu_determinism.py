@@ -92,11 +92,16 @@ def test_superglue_is_deterministic(fused, monkeypatch):
     ctx.close()
 
 
-def test_keyframe_step_is_deterministic_at_the_bench_size():
-    """64 stereo pairs through airfe_stereo_plnet_batch_dev, 150 times: every output equals the first run's bit for bit.  A single-shot
-    parity test cannot see a schedule-dependent fault: the stage-1 kernel's hand-scheduled weight loads (hand-placed `s_waitcnt`) passed
-    every parity test and gave a different line set in ~1 % of the steps at this size (tools/experiments/plnet_determinism.py)."""
+@pytest.mark.parametrize("overlap", [1, 0], ids=["line_path_beside_the_matcher", "one_stream"])
+def test_keyframe_step_is_deterministic_at_the_bench_size(overlap, monkeypatch):
+    """64 stereo pairs through airfe_stereo_plnet_batch_dev (the default bench step), 500 times in each stream arrangement — the line path
+    on the context's second stream beside the matcher (the default) and everything on one stream: every output equals the first run's bit
+    for bit.  History: round 2 ended red here (1 run of 150 with different match scores); round 3 traced it with per-launch state checksums
+    (airfe_debug_trace, tools/experiments/matcher_trace.py) to ONE element of the first q | k projection's rotary epilogue, computed by a
+    packed-math instruction form that is banned since (tests/test_no_scratch_cpu.py::test_no_packed_f32_cross_half_selects).  Before that the
+    stage-1 kernel's hand-placed `s_waitcnt` gave a different line set in ~1 % of the steps.  A single-shot parity test sees neither."""
     import torch
+    monkeypatch.setenv("AIRFE_OVERLAP_LINES", str(overlap))
     B = 64
     ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(GOLDEN, "plnet_s1.airfe"),
                       lightglue=weights.synthetic_lightglue(1234), max_batch=B, enc_chunk=64)
@@ -104,19 +109,22 @@ def test_keyframe_step_is_deterministic_at_the_bench_size():
     L, R = torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda()
     z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device="cuda")
 
-    def run():
-        o = dict(fl=z(B, 400, 259), fr=z(B, 400, 259), nl=z(B, dt=torch.int32), nr=z(B, dt=torch.int32), lines=z(2 * B, 1024, 4, dt=torch.float64),
-                 nlines=z(2 * B, dt=torch.int32), junc=z(B, 1024, 259), njunc=z(B, dt=torch.int32), idx=z(B, 400, 2, dt=torch.int32), sc=z(B, 400),
-                 nm=z(B, dt=torch.int32), found=z(3 * B, dt=torch.int32))
+    def bufs():
+        return dict(fl=z(B, 400, 259), fr=z(B, 400, 259), nl=z(B, dt=torch.int32), nr=z(B, dt=torch.int32), lines=z(2 * B, 1024, 4, dt=torch.float64),
+                    nlines=z(2 * B, dt=torch.int32), junc=z(B, 1024, 259), njunc=z(B, dt=torch.int32), idx=z(B, 400, 2, dt=torch.int32), sc=z(B, 400),
+                    nm=z(B, dt=torch.int32), found=z(3 * B, dt=torch.int32))
+
+    def run(o):
         ctx.stereo_plnet_batch_dev(L, R, o["fl"], o["fr"], o["nl"], o["nr"], o["lines"], o["nlines"], o["junc"], o["njunc"], o["idx"], o["sc"],
                                    o["nm"], o["found"])
         ctx.sync()
         return o
-    ref = run()
+    ref = run(bufs())
     assert int(ref["nlines"].min()) >= 100 and int(ref["njunc"].min()) >= 50 and int(ref["nm"].min()) >= 40
     bad = {}
-    for i in range(150):
-        o = run()
+    two = [bufs(), bufs()]                 # (two output sets in turn: a run never writes into the buffers it is compared with)
+    for i in range(500):
+        o = run(two[i & 1])
         for k in ref:
             if not torch.equal(ref[k], o[k]):
                 bad.setdefault(k, []).append(i)

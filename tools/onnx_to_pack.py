@@ -101,30 +101,51 @@ def match_by_graph_order(m, spec):
     return out, problems
 
 
+def linear_layout(m):
+    """initializer name -> the tensor in Linear's [N][K] layout: a MatMul's weight operand is stored [K][N] (x @ W) and a Gemm's is unless
+    transB — for a SQUARE weight a name-and-shape match alone would silently take the transposed matrix."""
+    out = dict(m.initializers)
+    for n in m.nodes:
+        if n.op == "MatMul" and len(n.inputs) == 2 and n.inputs[1] in m.initializers and m.initializers[n.inputs[1]].ndim == 2:
+            out[n.inputs[1]] = np.ascontiguousarray(m.initializers[n.inputs[1]].T)
+        elif n.op == "Gemm" and len(n.inputs) >= 2 and n.inputs[1] in m.initializers and not n.attrs.get("transB", 0):
+            out[n.inputs[1]] = np.ascontiguousarray(m.initializers[n.inputs[1]].T)
+    return out
+
+
 def convert(kind: str, onnx_path: str, out_path: str) -> None:
     m = onnx_lite.load(onnx_path)
     spec = SPECS[kind]()
     out, missing = {}, []
+    inits = linear_layout(m) if kind != "plnet_s1" else m.initializers
     for name, shape in spec:
         if kind == "plnet_s1" and name == "sample_t":
             cands = [v.reshape(-1) for v in m.initializers.values() if v.size == 30 and v.dtype == np.float32
                      and v.reshape(-1)[0] < 0.5]
             out[name] = cands[0] if cands else weights.linspace_t()
             continue
-        if name in m.initializers and tuple(m.initializers[name].shape) == tuple(shape):
-            out[name] = m.initializers[name].astype(np.float32)
+        if name in inits and tuple(inits[name].shape) == tuple(shape):
+            out[name] = inits[name].astype(np.float32)
             continue
-        cands = [k for k, v in m.initializers.items() if k.endswith(name) and tuple(v.shape) == tuple(shape)]
+        cands = [k for k, v in inits.items() if k.endswith(name) and tuple(v.shape) == tuple(shape)]
         if len(cands) == 1:
-            out[name] = m.initializers[cands[0]].astype(np.float32)
+            out[name] = inits[cands[0]].astype(np.float32)
         else:
             missing.append((name, shape, cands))
     if missing and kind != "plnet_s1":
-        out, problems = match_by_graph_order(m, spec)                      # names are no help: go by graph order
+        # Names are no (or only partial) help: go by graph order.  Many tensors share a shape (LightGlue's out_proj / to_qk / to_v / to_out are
+        # all [256, 256]), so graph order alone could silently permute them if the export's topological order differed from the spec's: every
+        # tensor that WAS placed by name must be the very tensor graph order puts in that slot, or the pack is refused.
+        by_name = out
+        out, problems = match_by_graph_order(m, spec)
+        for name, t in by_name.items():
+            if name in out and not np.array_equal(np.asarray(out[name], np.float32).reshape(-1), np.asarray(t, np.float32).reshape(-1)):
+                problems.append(f"{name}: the tensor with that name is not the one graph order assigns (export order differs from the spec order)")
         if problems:
             for pr in problems:
                 print(f"graph-order matching: {pr}", file=sys.stderr)
             raise SystemExit(f"{len(missing)} tensors could not be matched by name and graph-order matching failed too")
+        print(f"{len(missing)} tensors placed by graph order; {len(by_name)} name matches agree with it")
         missing = []
     if missing:
         for name, shape, cands in missing:
