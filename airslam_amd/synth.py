@@ -50,6 +50,18 @@ def stereo_batch(b: int, h: int, w: int, seed: int):
     return ls, rs
 
 
+def stereo_sequence(n: int, h: int, w: int, seed: int, scene_len: int = 40):
+    """n stereo frames of a camera panning over synthetic scenes (a new scene every `scene_len` frames): the stand-in for a dataset sequence
+    (EuRoC MH_01 is external, src/dataset.cc:20-21 reads cam0 / cam1 image folders).  Yields (left, right) uint8 [h, w]."""
+    cur, l0, r0 = -1, None, None
+    for i in range(n):
+        scene, j = divmod(i, scene_len)
+        if scene != cur:
+            l0, r0 = stereo_pair(h, w, seed + 101 * scene)
+            cur = scene
+        yield np.roll(l0, (2 * j, 3 * j), axis=(0, 1)), np.roll(r0, (2 * j, 3 * j), axis=(0, 1))
+
+
 def plnet_stage0_lines(seed: int, n_lines: int = 400, fh: int = 128, fw: int = 128, jn: int = 300):
     """Stand-in for the line-branch outputs of plnet_s0.onnx.
     Shapes/dtypes follow the contract read off src/plnet.cpp:453-507; the VALUES are synthetic."""

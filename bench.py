@@ -43,7 +43,7 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=
     `n_pairs` pairs (median of >= 20 after 3 warm-ups).  s1 (the stage-1 weights) selects the PLNet step: one trunk
     pass per image feeding the point heads AND the line branch, wireframe_matcher, stage 1, line filter, junctions on the left."""
     from airslam_amd import synth
-    from oracle import ref_nets, ref_post
+    from oracle import ref_chain, ref_nets, ref_post
     torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads than this only adds sync overhead at batch 1
     base = synth.stereo_pair(h, w, 100)
     pairs = [(np.roll(base[0], 7 * i, axis=1), np.roll(base[1], 7 * i, axis=1)) for i in range(n_pairs + warm)]   # inputs ready before the clock
@@ -57,20 +57,10 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=
                 heat, desc = ref_nets.superpoint_forward(sp, x[None])
                 feats.append(ref_post.keypoints_decoder(ref_post.simple_nms(heat[0], 4), desc[0], 0.004, 4, max_kp, ws, hs))
                 continue
-            with torch.no_grad():
-                taps = {}
-                f = ref_nets.superpoint_trunk(sp, torch.from_numpy(x)[None, None], taps)
-                heat, desc = (t.numpy() for t in ref_nets.superpoint_heads(sp, f))
-            nms = ref_post.simple_nms(heat[0], 4)
-            feats.append(ref_post.keypoints_decoder(nms, desc[0], 0.004, 4, max_kp, ws, hs))
-            s0 = ref_nets.plnet_s0_lines(sp, x, f3a=taps["conv3a"])
-            keep, inv, pr = ref_post.wireframe_matcher(s0["iskeep"], s0["idx_junc_to_end_min"], s0["idx_junc_to_end_max"])
-            la, sc = ref_nets.plnet_s1_forward(s1, s0["juncs_pred"], s0["lines_pred"], pr, inv, keep, s0["loi_features"][0],
-                                               s0["loi_features_thin"][0], s0["loi_features_aux"][0])
-            lines, jmap = ref_post.line_filter(la, sc, 4, line_threshold, line_length_threshold)
-            lines = ref_post.rescale_lines(lines, ws, hs)
-            if side == 0:                                   # junctions on the left image only (feature_detector.cc:100-101)
-                ref_post.junction_detector(nms, desc[0], jmap, 4, ws, hs)
+            # PLNet::infer end to end (src/plnet.cpp:221-244): one trunk pass feeding the point heads and the line branch, wireframe_matcher,
+            # stage 1, line filter; junctions on the left image only (feature_detector.cc:100-101)
+            feats.append(ref_chain.plnet_infer(sp, s1, img, want_junctions=side == 0, top_k=max_kp, line_threshold=line_threshold,
+                                               line_length_threshold=line_length_threshold)["features"])
         k = 0
         if feats[0].shape[0] and feats[1].shape[0]:
             a = ref_post.normalize_keypoints(feats[0], w, h, 0.5)

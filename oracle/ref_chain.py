@@ -1,0 +1,32 @@
+"""TEST INFRASTRUCTURE — never imported by the product (airslam_amd/), only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline.
+
+The whole of `PLNet::infer` (src/plnet.cpp:221-244) as ONE fp32 CPU chain built from the restatements of this package — the reference runs
+it as: process_image (:246-270) -> stage-0 engine (:453-466; body: ref_nets, parity unpinned, file absent upstream) -> detect_point +
+extract_descriptors (:309-417) -> wireframe_matcher (:272-307) -> stage-1 engine (:468-514; real weights, pinned by tests/golden) -> line
+filter (:519-558) -> junction_detector (:425-448) -> rescale to the input image (:560-582)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ref_nets, ref_post
+
+
+def plnet_infer(sp: dict, s1: dict, image: np.ndarray, want_junctions: bool = False, threshold: float = 0.004, border: int = 4,
+                top_k: int = 400, line_threshold: float = 0.75, line_length_threshold: float = 50.0, nms_radius: int = 4):
+    """-> dict(features [N, 259], lines [L, 4] float64 in image coordinates, junctions [J, 259] or None, n_candidates, scores_line)"""
+    x, ws, hs = ref_post.process_image(image)
+    with torch.no_grad():
+        taps = {}
+        f = ref_nets.superpoint_trunk(sp, torch.from_numpy(x)[None, None], taps)       # one trunk pass feeds the point heads and the line branch
+        heat, desc = (t.numpy() for t in ref_nets.superpoint_heads(sp, f))
+    nms = ref_post.simple_nms(heat[0], nms_radius) if nms_radius > 0 else heat[0]
+    feats = ref_post.keypoints_decoder(nms, desc[0], threshold, border, top_k, ws, hs)
+    s0 = ref_nets.plnet_s0_lines(sp, x, f3a=taps["conv3a"])
+    keep, inv, pairs = ref_post.wireframe_matcher(s0["iskeep"], s0["idx_junc_to_end_min"], s0["idx_junc_to_end_max"])
+    la, sc = ref_nets.plnet_s1_forward(s1, s0["juncs_pred"], s0["lines_pred"], pairs, inv, keep, s0["loi_features"][0],
+                                       s0["loi_features_thin"][0], s0["loi_features_aux"][0])
+    lines512, jmap = ref_post.line_filter(la, sc, border, line_threshold, line_length_threshold)
+    lines = ref_post.rescale_lines(lines512, ws, hs)
+    junc = ref_post.junction_detector(nms, desc[0], jmap, border, ws, hs) if want_junctions else None
+    return dict(features=feats, lines=lines, junctions=junc, n_candidates=int(la.shape[0]), scores_line=sc, stage0=s0)
