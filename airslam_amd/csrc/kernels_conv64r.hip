@@ -56,6 +56,7 @@ constexpr bool SCHED = C64R_SCHED;
 #ifndef C64R_EARLY_EPI
 #define C64R_EARLY_EPI 1
 #endif
+
 constexpr int C64R_PATCH = 20 * 20;                // fused conv1a: fp32 image patch per tile (halo 2)
 constexpr int C64R_CONST_OFF = 2 * C64R_TILE_STRIDE + 3 * C64R_PATCH * 4;   // conv1a A fragments (4 KiB) + bias (256 B)
 
@@ -252,6 +253,8 @@ __global__ __launch_bounds__(2048 / RW, 1) void conv64r_kernel(ConvArgs a, int t
     __syncthreads();
   }
 
+  // (s_setprio for one wave half, or alternating per combo, does not help: younger high -8 % on the stage, alternating -37 %, older high
+  //  within noise — profiles/r03_probe3_priority_ab_and_conv64r_timers.txt)
   int pb3 = 0, pb1 = 1;                                // i % 3 and (i + 1) % 3
 #ifdef C64R_TIMING
   long long t_top = 0, t_mma = 0, t_wait = 0, t_bar = 0, t_epi = 0, tp_ = wall_clock64();

@@ -102,3 +102,34 @@ def test_fp32_line_branch():
     diag("fp32_line_branch", **out)
     assert (d <= 1e-4).mean() >= 0.99
     assert abs(out["kept_dev"] - out["kept_ref"]) <= 0.005 * out["kept_ref"]
+
+
+def test_fp32_sequence_every_output_vs_the_oracle():
+    """BASELINE configs[1] in small: 8 frames of the synthetic stereo sequence through PLNet + LightGlue in fp32, EVERY output of every frame
+    against the all-oracle chain (tools/seq_fp32_parity.py is the 200-frame run behind profiles/r03_seq_fp32_parity.json)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("seq_fp32_parity", os.path.join(root, "tools", "seq_fp32_parity.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    ctx, sp, lg = _ctx()
+    s1 = weights.load_pack(os.path.join(GOLDEN, "plnet_s1.airfe"))
+    pm = api.PointMatcher(ctx, 752, 480, 0)
+    rows = []
+    for left, right in synth.stereo_sequence(8, 480, 752, 4100, scene_len=4):
+        fl, ll, jl = ctx.detect_plnet(left, None, want_junctions=True)
+        fr, lr, _ = ctx.detect_plnet(right, None, want_junctions=False)
+        _, mm = pm.MatchingPoints(np.asfortranarray(fl.T), np.asfortranarray(fr.T))
+        dev = dict(fl=fl, fr=fr, ll=ll, lr=lr, jl=jl, m=np.asarray([(a, b) for a, b, _ in mm], np.int32).reshape(-1, 2),
+                   ms=np.asarray([1.0 - d for _, _, d in mm], np.float32))
+        rows.append(tool.compare(dev, tool.oracle_frame(sp, s1, lg, left, right)))
+    agg = {k: (min(r[k] for r in rows if k in r), max(r[k] for r in rows if k in r)) for k in sorted({k for r in rows for k in r})}
+    diag("fp32_sequence", **{k: str(v) for k, v in agg.items()})
+    for r in rows:
+        assert r["kp_l_count_equal"] == 1 and r["kp_r_count_equal"] == 1
+        assert r["kp_l_within_1px"] >= 0.995 and r["kp_r_within_1px"] >= 0.995          # north star: <= 1 px (fp32: the same set but for a score tie at the top-K boundary)
+        assert r["desc_l_max_cosine_dist"] <= 1e-3 and r["desc_r_max_cosine_dist"] <= 1e-3   # north star: <= 1e-3 cosine (fp32: ~1e-6)
+        assert r["matches_ref"] >= 40 and r["match_jaccard"] >= 0.97
+        assert r["lines_l_ref"] >= 50 and r["lines_l_dev_hit"] >= 0.98 and r["lines_l_ref_hit"] >= 0.98 and r["lines_r_dev_hit"] >= 0.98 and r["lines_r_ref_hit"] >= 0.98
+        assert r["junc_ref"] >= 30 and r["junc_within_1px"] >= 0.98 and abs(r["junc_dev"] - r["junc_ref"]) <= 0.02 * r["junc_ref"]
+    assert sum(r["match_sets_identical"] for r in rows) >= 6                            # identical match sets on (nearly) every frame

@@ -44,31 +44,44 @@ def line_hits(a, b, tol=1.0):
 
 
 def compare(dev, ref):
-    """one frame: device outputs vs oracle outputs -> dict of numbers"""
+    """one frame: device outputs vs oracle outputs -> dict of numbers.  Keypoints are paired by POSITION, not by row: inside the top-K two
+    keypoints whose scores differ by less than the heat map's tolerance may swap rows, which is not an error (detect_point's order is by
+    score); matches are compared as coordinate quadruples for the same reason."""
     out = {}
     for side in ("l", "r"):
         fd, fo = dev["f" + side], ref["f" + side]
-        same_n = fd.shape[0] == fo.shape[0]
-        out[f"kp_{side}_count_equal"] = float(same_n)
-        if same_n and len(fd):
-            out[f"kp_{side}_identical"] = float(np.array_equal(fd[:, 1:3], fo[:, 1:3]))
-            out[f"kp_{side}_max_px"] = float(np.abs(fd[:, 1:3] - fo[:, 1:3]).max())
-            out[f"score_{side}_max_abs"] = float(np.abs(fd[:, 0] - fo[:, 0]).max())
-            num = (fd[:, 3:] * fo[:, 3:]).sum(1)
-            den = np.linalg.norm(fd[:, 3:], axis=1) * np.linalg.norm(fo[:, 3:], axis=1)
-            out[f"desc_{side}_max_cosine_dist"] = float((1.0 - num / np.maximum(den, 1e-30)).max())
+        out[f"kp_{side}_count_equal"] = float(fd.shape[0] == fo.shape[0])
+        if len(fd) and len(fo):
+            d = np.linalg.norm(fd[:, None, 1:3] - fo[None, :, 1:3], axis=2)
+            nn = d.argmin(1)
+            dist = d[np.arange(len(fd)), nn]
+            out[f"kp_{side}_same_rows"] = float(fd.shape == fo.shape and np.array_equal(fd[:, 1:3], fo[:, 1:3]))
+            out[f"kp_{side}_within_1px"] = float((dist <= 1.0).mean())
+            out[f"kp_{side}_max_px"] = float(dist.max())
+            ok = dist <= 1.0
+            out[f"score_{side}_max_abs"] = float(np.abs(fd[ok, 0] - fo[nn[ok], 0]).max()) if ok.any() else 0.0
+            num = (fd[ok, 3:] * fo[nn[ok], 3:]).sum(1)
+            den = np.linalg.norm(fd[ok, 3:], axis=1) * np.linalg.norm(fo[nn[ok], 3:], axis=1)
+            out[f"desc_{side}_max_cosine_dist"] = float((1.0 - num / np.maximum(den, 1e-30)).max()) if ok.any() else 0.0
         out[f"lines_{side}_dev"] = len(dev["l" + side]); out[f"lines_{side}_ref"] = len(ref["l" + side])
         out[f"lines_{side}_dev_hit"] = line_hits(dev["l" + side], ref["l" + side]); out[f"lines_{side}_ref_hit"] = line_hits(ref["l" + side], dev["l" + side])
     jd, jo = dev["jl"], ref["jl"]
     out["junc_dev"] = len(jd); out["junc_ref"] = len(jo)
     out["junc_within_1px"] = float((np.linalg.norm(jd[:, None, 1:3] - jo[None, :, 1:3], axis=2).min(1) <= 1.0).mean()) if len(jd) and len(jo) else float(len(jd) == len(jo))
-    sd, so = {tuple(x) for x in dev["m"].tolist()}, {tuple(x) for x in ref["m"].tolist()}
-    out["matches_dev"] = len(sd); out["matches_ref"] = len(so)
-    out["match_sets_identical"] = float(sd == so)
-    out["match_jaccard"] = len(sd & so) / max(len(sd | so), 1)
-    if sd == so and len(sd):
-        od = {tuple(k): v for k, v in zip(dev["m"].tolist(), dev["ms"].tolist())}
-        out["match_score_max_abs"] = float(max(abs(od[tuple(k)] - v) for k, v in zip(ref["m"].tolist(), ref["ms"].tolist())))
+
+    def quads(r):          # a match as (xl, yl, xr, yr) in quarter pixels: independent of the row order of the keypoints
+        m = r["m"]
+        if len(m) == 0:
+            return {}
+        q = np.concatenate([r["fl"][m[:, 0], 1:3], r["fr"][m[:, 1], 1:3]], axis=1).astype(np.float64)
+        return {tuple(np.round(x * 4).astype(np.int64).tolist()): float(s) for x, s in zip(q, r["ms"])}
+    qd, qo = quads(dev), quads(ref)
+    out["matches_dev"] = len(qd); out["matches_ref"] = len(qo)
+    out["match_sets_identical"] = float(qd.keys() == qo.keys())
+    out["match_jaccard"] = len(qd.keys() & qo.keys()) / max(len(qd.keys() | qo.keys()), 1)
+    common = qd.keys() & qo.keys()
+    if common:
+        out["match_score_max_abs"] = float(max(abs(qd[k] - qo[k]) for k in common))
     return out
 
 
@@ -101,13 +114,18 @@ def main():
                 print(f"oracle frame {i}: {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
         if args.cache:
             os.makedirs(os.path.dirname(os.path.abspath(args.cache)), exist_ok=True)
-            flat = {f"{k}_{i}": (r[k].astype(np.float16) if k in ("fl", "fr", "jl") else r[k]) for i, r in enumerate(refs) for k in keys}
+            flat = {}
+            for i, r in enumerate(refs):          # descriptors in fp16 to keep the file small (cosine ~1e-7 from that); score / x / y stay fp32
+                for k in keys:
+                    if k in ("fl", "fr", "jl"):
+                        flat[f"{k}_{i}_sxy"] = r[k][:, :3].astype(np.float32)
+                        flat[f"{k}_{i}_d"] = r[k][:, 3:].astype(np.float16)
+                    else:
+                        flat[f"{k}_{i}"] = r[k]
             np.savez_compressed(args.cache, frames=args.frames, seed=args.seed, **flat)
     else:
-        refs = [{k: np.asarray(cache[f"{k}_{i}"]) for k in keys} for i in range(args.frames)]
-        for r in refs:                      # (features are cached in fp16 to keep the file small: positions and scores are exact in fp16 only to
-            for k in ("fl", "fr", "jl"):     #  ~1e-3 relative; the descriptor / score gates below are widened accordingly when a cache is used)
-                r[k] = r[k].astype(np.float32)
+        refs = [{k: (np.concatenate([cache[f"{k}_{i}_sxy"], cache[f"{k}_{i}_d"].astype(np.float32)], axis=1) if k in ("fl", "fr", "jl")
+                     else np.asarray(cache[f"{k}_{i}"])) for k in keys} for i in range(args.frames)]
     oracle_s = time.time() - t0
     if args.oracle_only:
         print(f"oracle: {args.frames} frames in {oracle_s:.0f} s")
@@ -115,14 +133,15 @@ def main():
     from airslam_amd import api
     ctx = api.Context(superpoint=sp, lightglue=lg, plnet_s1=s1_path, precision=2, matcher_precision=2, max_batch=2, enc_chunk=2, max_keypoints=K,
                       image_width=W, image_height=H)
-    det, pm = api.FeatureDetector(ctx), api.PointMatcher(ctx, W, H, 0)
+    pm = api.PointMatcher(ctx, W, H, 0)
     rows = []
     t1 = time.time()
     for i, (left, right) in enumerate(synth.stereo_sequence(args.frames, H, W, args.seed)):
         fl, ll, jl = ctx.detect_plnet(left, None, want_junctions=True)
         fr, lr, _ = ctx.detect_plnet(right, None, want_junctions=False)
-        idx, sc = ctx.match_lightglue(fl, fr)
-        dev = dict(fl=fl, fr=fr, ll=ll, lr=lr, jl=jl, m=np.asarray(idx, np.int32).reshape(-1, 2), ms=np.asarray(sc, np.float32))
+        _, mm = pm.MatchingPoints(np.asfortranarray(fl.T), np.asfortranarray(fr.T))     # [259, N] as the reference's Eigen matrices
+        dev = dict(fl=fl, fr=fr, ll=ll, lr=lr, jl=jl, m=np.asarray([(a, b) for a, b, _ in mm], np.int32).reshape(-1, 2),
+                   ms=np.asarray([1.0 - d for _, _, d in mm], np.float32))
         rows.append(compare(dev, refs[i]))
     dev_s = time.time() - t1
     ctx.close()
