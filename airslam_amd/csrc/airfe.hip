@@ -957,11 +957,14 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
     if (encode_f32(c, d_gray, B, h, w, stride, img_stride, st)) return 1;
   } else {
     for (int c0 = 0, cb = 0; c0 < B; c0 += cb) {
-      cb = std::min(c->chunk, (c0 < Bs ? Bs : B) - c0);                 // a chunk never straddles the two sources
-      const uint8_t* src = c0 < Bs ? d_gray + (size_t)c0 * img_stride : d_gray1 + (size_t)(c0 - Bs) * img_stride;
-      {
+      cb = std::min(c->chunk, B - c0);
+      {                                                                  // a chunk may straddle the two sources: one pre-process launch per source
         ProfScope ps(c, ST_PREPROCESS, st, 0, (double)cb * ((double)h * w + (double)R * R * 4));
-        launch_preprocess(src, cb, h, w, stride, img_stride, c->xtab, c->ytab, c->lut, c->img32, R, R, st);
+        const int n0 = std::min(std::max(Bs - c0, 0), cb);              // images of this chunk that come from d_gray
+        if (n0 > 0) launch_preprocess(d_gray + (size_t)c0 * img_stride, n0, h, w, stride, img_stride, c->xtab, c->ytab, c->lut, c->img32, R, R, st);
+        if (cb > n0)
+          launch_preprocess(d_gray1 + (size_t)(c0 + n0 - Bs) * img_stride, cb - n0, h, w, stride, img_stride, c->xtab, c->ytab, c->lut,
+                            c->img32 + (size_t)n0 * (R + 2) * (R + 2), R, R, st);
       }
       {
         // conv1a (Cin = 1) fused into the persistent conv1b kernel: its 64-channel full-resolution output never
@@ -1480,7 +1483,7 @@ void airfe_default_cfg(airfe_cfg* cfg) {
   cfg->device = 0;
   cfg->precision = 1;              // fp16 storage: what the reference builds its engines with (super_point.cpp:97, plnet.cpp:216)
   cfg->max_batch = 2;
-  cfg->enc_chunk = 64;   // measured: per-launch fixed costs dominate below ~16 images (16: -3 %, 32: -1.7 % against 64); no Infinity-Cache benefit from small chunks
+  cfg->enc_chunk = 64;   // measured: per-launch fixed costs dominate below ~16 images (16: -3 %, 32: -1.7 % against 64, 128: +1.7 % on the conv64 stage); no Infinity-Cache benefit from small chunks
   cfg->max_keypoints = 400;        // configs/visual_odometry/vo_euroc.yaml:3-5
   cfg->keypoint_threshold = 0.004f;
   cfg->remove_borders = 4;
@@ -1541,6 +1544,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (getenv("AIRFE_OVERLAP_LINES")) c->overlap_lines = atoi(getenv("AIRFE_OVERLAP_LINES")) != 0;
   // a context with a detector AND the stereo matcher runs airfe_stereo_batch_dev over left + right images as one detector batch
   c->Dmax = (c->prec != 2 && cfg->superpoint_pack && cfg->lightglue_pack) ? 2 * c->Bmax : c->Bmax;
+  c->chunk = std::min(std::max(cfg->enc_chunk, 1), c->Dmax);   // (a stereo step's 2 B images may go through the first layers as ONE chunk)
   c->Lmax = c->Dmax;
   int rc = 0;
   if (cfg->superpoint_pack) rc = load_superpoint(c, cfg->superpoint_pack);
