@@ -888,6 +888,7 @@ int lightglue_dev_f32(airfe_ctx* c, const float* f0, const int* n0, const float*
   pa.linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.5f);
   pa.wr = c->lg_wr; pa.B = B; pa.cap = cap; pa.Np = Np;
   pa.x32 = c->x32; pa.xb = c->xb; pa.rot_cos = c->rot_cos; pa.rot_sin = c->rot_sin; pa.lens = c->lens;
+  pa.slack_rows = (int)(c->arena_rows - (size_t)M);      // the slack rows go back to zero with the same launch (see reset_slack_rows)
   launch_lg_prepare(1, pa, st);
   auto lin = [&](const airfe_ctx::F32Lin& w, const float* x1, int ld1, int K1, const float* x2, int ld2, float* y, int ldy, int acc, float scale = 1.f) {
     GemmF32Args g;
@@ -1189,7 +1190,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     if (k) trace(c, st, "k", li, blk, c->kb, Mw, 512);
     trace(c, st, "vt", li, blk, c->vtb, Mw, (unsigned)Np / 2);
   };
-  { ProfScope ps(c, ST_LG_PREPARE, st, 0, (double)M * (1036 + 1536 + 256)); launch_lg_prepare(c->mprec, pa, st); reset_slack_rows(c, M, st); }
+  { ProfScope ps(c, ST_LG_PREPARE, st, 0, (double)M * (1036 + 1536 + 256)); launch_lg_prepare(c->mprec, pa, st); }
   tr_x(0, "prep");
   trace(c, st, "rc", 0, "prep", c->rot_cos, (size_t)M * 32, 512);
   trace(c, st, "rs", 0, "prep", c->rot_sin, (size_t)M * 32, 512);

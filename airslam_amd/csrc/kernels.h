@@ -144,6 +144,7 @@ struct LgPrepArgs {
   float* x32; uint16_t* xb;           // [2B][Np][256]
   float* rot_cos; float* rot_sin;     // [2B][Np][32]
   int* lens;                          // [2B]
+  int slack_rows = 0;                 // token rows behind the last sequence that are reset to zero as well (the arena's slack, airfe.hip)
 };
 void launch_lg_prepare(int prec, const LgPrepArgs& a, hipStream_t st);
 // flash attention over head-major Q,K [S][H][Np][64] and Vt [S][H][64][Np] -> O [S][Np][256]; cross => kv sequence s^1; on the 32x32x16

@@ -15,6 +15,18 @@ template <class P>
 __global__ __launch_bounds__(256) void lg_prepare_kernel(LgPrepArgs a) {
   const int s = blockIdx.y, n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= a.Np) return;
+  if (s >= 2 * a.B) {                                    // the arena's slack rows behind the last sequence: back to zero (see reset_slack_rows)
+    const int r = (s - 2 * a.B) * a.Np + n;
+    if (r < a.slack_rows) {
+      const size_t row = (size_t)2 * a.B * a.Np + r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a.x32[row * 256 + lane + 64 * j] = 0.f;
+        a.xb[row * 256 + lane + 64 * j] = 0;
+      }
+    }
+    return;
+  }
   const int b = s >> 1, side = s & 1;
   const int len = side ? a.n1[b] : a.n0[b];
   if (n == 0 && lane == 0) a.lens[s] = len;
@@ -55,7 +67,7 @@ __global__ __launch_bounds__(256) void lg_prepare_kernel(LgPrepArgs a) {
 }
 
 void launch_lg_prepare(int prec, const LgPrepArgs& a, hipStream_t st) {
-  dim3 grid((a.Np + 3) / 4, 2 * a.B);
+  dim3 grid((a.Np + 3) / 4, 2 * a.B + (a.slack_rows + a.Np - 1) / a.Np);
   if (prec == 1) hipLaunchKernelGGL(lg_prepare_kernel<PF16>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(lg_prepare_kernel<PBF16>, grid, dim3(256), 0, st, a);
 }
