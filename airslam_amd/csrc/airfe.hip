@@ -306,11 +306,11 @@ struct airfe_ctx {
 };
 
 enum Stage {
-  ST_PREPROCESS = 0, ST_CONV1A, ST_CONV3X3_C64, ST_CONV3X3_C128, ST_HEAD_GEMM, ST_HEAD_ELTWISE, ST_NMS, ST_SELECT,
+  ST_PREPROCESS = 0, ST_CONV1_FUSED /* conv1a + conv1b + pool: the dominant kernel, its own stage */, ST_CONV3X3_C64, ST_CONV3X3_C128, ST_HEAD_GEMM, ST_HEAD_ELTWISE, ST_NMS, ST_SELECT,
   ST_SAMPLE, ST_LG_PREPARE, ST_LG_GEMM, ST_LG_ATTENTION, ST_LG_LNGELU, ST_LG_ASSIGN, ST_PL_DECODE, ST_PL_STAGE1, ST_PL_FILTER, ST_COUNT
 };
 static const char* kStageNames[ST_COUNT] = {
-  "preprocess", "conv1a", "conv3x3_cin64", "conv3x3_cin128", "head_gemm", "head_eltwise", "simple_nms", "select_topk",
+  "preprocess", "conv1_fused", "conv3x3_cin64", "conv3x3_cin128", "head_gemm", "head_eltwise", "simple_nms", "select_topk",
   "sample_desc", "lg_prepare", "lg_gemm", "lg_attention", "lg_ln_gelu", "lg_assign", "plnet_s0_decode", "plnet_stage1", "plnet_filter"};
 
 struct ProfScope {
@@ -975,7 +975,7 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
         a.pool = 1; a.out_pad = 1; a.relu = 1;
         a.img = c->img32; a.w1a = c->c1a_w; a.b1a = c->c1a_b;
         const double px = (double)cb * R * R;
-        ProfScope ps(c, ST_CONV3X3_C64, st, 2.0 * px * 9 * 64 + 2.0 * px * 64 * 64 * 9, px * 4 + px / 4 * 128 + 9.0 * 64 * 64 * 2);
+        ProfScope ps(c, ST_CONV1_FUSED, st, 2.0 * px * 9 * 64 + 2.0 * px * 64 * 64 * 9, px * 4 + px / 4 * 128 + 9.0 * 64 * 64 * 2);
         launch_conv64r(c->prec, a, st);
       }
       run_conv(c, c->c2a, c->a1b, c->a2a, cb, R / 2, R / 2, 0, 1, st);
@@ -2083,7 +2083,7 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint
   if (!(c->prec != 2 && 2 * B <= c->Dmax))
     return fail(c, "stereo_plnet_batch: needs the one-pass stereo detector (detector + LightGlue packs loaded, 2 B <= 2 max_batch, fp16 / bf16)");
   // (With stage timers on anything behind the encoder the chains run one after the other: a stage's event pair must not span the other chain.)
-  const uint32_t enc_only = (1u << ST_PREPROCESS) | (1u << ST_CONV1A) | (1u << ST_CONV3X3_C64);
+  const uint32_t enc_only = (1u << ST_PREPROCESS) | (1u << ST_CONV1_FUSED) | (1u << ST_CONV3X3_C64);
   const bool overlap = c->overlap_lines && (c->prof_mask & ~enc_only) == 0;
   c->force_nms_map = true;
   int rc = detect_dev2(c, d_left, d_right, B, h, w, stride, img_stride, d_featL, d_featR, cap, d_nL, d_nR, st);

@@ -32,7 +32,8 @@ def latest_profile(suffix):
     return sorted(c)[-1] if c else None
 
 
-DOMINANT_STAGE = "conv3x3_cin64"   # largest single share of a step; its events stay on inside the timed region
+DOMINANT_STAGE = "conv1_fused"   # the dominant KERNEL (conv64r_kernel<POOL, FUSE1A>: conv1a + conv1b + pool, ~21 % of a step) is a stage of
+                                # its own: its launches keep their HIP events inside the timed region
 PEAK_MFMA_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
@@ -436,8 +437,10 @@ def main():
             tf = latest_profile("hbm_traffic.json")
             if tf:      # measured in separate --pmc passes (never together with other tracing), see profiles/README.md
                 with open(tf) as fh:
-                    traffic = json.load(fh).get("conv3x3_cin64_stage", {}).get("hbm_bytes_per_launch")
-                tsrc = "profiles/" + os.path.basename(tf) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+                    rec = json.load(fh).get("conv1_fused", {})
+                if rec.get("hbm_bytes_per_launch") and rec.get("images_per_launch"):      # per image x the images one launch covers in THIS run
+                    traffic = rec["hbm_bytes_per_launch"] / rec["images_per_launch"] * (2.0 * B * args.steps / max(dom["launches"], 1))
+                tsrc = "profiles/" + os.path.basename(tf) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch of that kernel, scaled to this run's images per launch)"
             util, usrc = None, None
             pf = latest_profile("pmc_summary.json")
             if pf:      # counter-derived MFMA utilisation of the encoder kernels (separate --pmc pass, tools/pmc_summary.py)
@@ -450,7 +453,7 @@ def main():
                                                          for v in enc.values()) / wsum,
                             "per_kernel": {k.split("(")[0].replace("void airfe::", ""): round(v["mfma_util"], 3) for k, v in enc.items()}}
                     usrc = "profiles/" + os.path.basename(pf) + ": SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)"
-            out["roofline"] = {"bound": "mfma", "mfma_util_counters": util, "mfma_util_source": usrc, "kernel": "conv64r_kernel (conv1a fused into conv1b + pool, conv2a, conv2b + pool, conv3a)",
+            out["roofline"] = {"bound": "mfma", "mfma_util_counters": util, "mfma_util_source": usrc, "kernel": "conv64r_kernel<POOL, FUSE1A> (conv1a + conv1b + 2x2 max-pool in one launch over an encoder chunk)",
                                "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
                                "traffic": traffic, "traffic_source": tsrc,
                                "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1), "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
