@@ -17,7 +17,7 @@ HOT = {
     "kernels_conv64r.hip": ["conv64r_kernel"],
     "kernels_conv128r.hip": ["conv128r_kernel"],
     "kernels_gemmr.hip": ["gemmr_kernel", "gemmr_pair_kernel"],
-    "kernels_ext.hip": ["sg_sinkhorn_fused_kernel", "sg_sinkhorn_reg_kernel", "plnet_s1_kernel", "s1_junc_proj_kernel"],
+    "kernels_ext.hip": ["sg_sinkhorn_reg_kernel", "plnet_s1_kernel", "s1_junc_proj_kernel"],
     "kernels_s0.hip": ["s0_j2l_grid_kernel", "s0_decode_kernel"],
     "kernels_nms512.hip": ["nms512_kernel"],
 }
