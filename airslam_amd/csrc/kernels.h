@@ -12,7 +12,7 @@ enum Epi {
   EPI_RESID = 2,      // x32[M][ldo] += bias + acc ; out = 2-byte copy of x32
   EPI_HEADS = 3,      // bias (+rotary) -> 2-byte head-major [S][H][Np][64]; feature/256 selects out/out2
   EPI_HEADS_T = 4,    // (TRANS kernels) bias -> 2-byte [S][H][64][Np]
-  EPI_SOFTMAX_D2S = 5 // gemm8 only, N = 65: bias, soft-max over the 65 logits of a row (= cell), drop the dustbin, 8x8 depth-to-space ->
+  EPI_SOFTMAX_D2S = 5 // launch_gemm8 only (its streaming head kernel), K = 256, N = 65: bias, soft-max over the 65 logits of a row (= cell), drop the dustbin, 8x8 depth-to-space ->
                       // fp32 score map [B][8 d2s_hc][8 d2s_wc] (the SuperPoint detector head in the GEMM's epilogue)
 };
 enum Act { ACT_NONE = 0, ACT_RELU = 1 };

@@ -7,6 +7,9 @@
 // linears were plainly bandwidth-bound (176 MB moved for a 15 GFLOP GEMM = the measured 44 us).  256-feature passes
 // halve the X re-reads (one pass for N = 256, two for N = 512) and raise the MFMA : ds_read ratio to 8 : 3.
 // The DMA wait sits before this iteration's output stores, so stores never sit between a DMA and its wait.
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -166,53 +169,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs a, int K, int qu
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk it+1 has landed (and last iteration's stores retired)
     __syncthreads();
-    if (!TRANS && s == NS - 1 && a.epi == EPI_SOFTMAX_D2S) {
-      // The detector head in the epilogue: a row is a cell, its 65 logits are features 0..63 (this wave's first four tiles: lane (l15, g)
-      // holds 8 tp + .. of them, tp = 0, 1) and the dustbin, feature 64 (fifth tile, lane g = 0, element 0).  Soft-max across the four g
-      // lanes of the row, then each lane writes its two 8-pixel runs of the cell's 8x8 block (dy = 4 tp + g).  The logits never exist
-      // in memory (0.6 KB per cell written and read back by the separate kernel).
-      if (wn == 0) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int row = m0 + wm * 64 + m * 16 + l15;
-          float v[2][8];
-#pragma unroll
-          for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[tp][e] = acc[m][2 * tp][e] + a.bias[tp * 32 + g * 8 + e];
-              v[tp][4 + e] = acc[m][2 * tp + 1][e] + a.bias[tp * 32 + g * 8 + 4 + e];
-            }
-          const float dust = (g == 0) ? acc[m][4][0] + a.bias[64] : -INFINITY;
-          float mx = dust;
-#pragma unroll
-          for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[tp][e]);
-          mx = fmaxf(mx, __shfl_xor(mx, 16));
-          mx = fmaxf(mx, __shfl_xor(mx, 32));
-          float sum = expf(dust - mx);                        // exp(-inf) = 0 on the lanes that do not hold the dustbin
-#pragma unroll
-          for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              v[tp][e] = expf(v[tp][e] - mx);
-              sum += v[tp][e];
-            }
-          sum += __shfl_xor(sum, 16);
-          sum += __shfl_xor(sum, 32);
-          const float inv = 1.0f / sum;
-          const int per = a.d2s_hc * a.d2s_wc, b = row / per, rem = row - b * per, cy = rem / a.d2s_wc, cx = rem - cy * a.d2s_wc;
-          float* o = reinterpret_cast<float*>(a.out) + ((size_t)b * a.d2s_hc * 8 + (size_t)cy * 8) * (a.d2s_wc * 8) + cx * 8;
-#pragma unroll
-          for (int tp = 0; tp < 2; ++tp) {
-            float* r = o + (size_t)(tp * 4 + g) * (a.d2s_wc * 8);
-            *reinterpret_cast<float4*>(r) = make_float4(v[tp][0] * inv, v[tp][1] * inv, v[tp][2] * inv, v[tp][3] * inv);
-            *reinterpret_cast<float4*>(r + 4) = make_float4(v[tp][4] * inv, v[tp][5] * inv, v[tp][6] * inv, v[tp][7] * inv);
-          }
-        }
-      }
-    } else if (s == NS - 1) {
+    if (s == NS - 1) {
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         const int cb = 4 * (quad0 + it / NS) + wn * 2 + hb;
@@ -270,8 +227,115 @@ static void gemm8_launch_t(int K, const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kfn, dim3((unsigned)mb, (unsigned)gy), dim3(512), LDS, st, a, K, nquads / gy);
 }
 
+// ================================================================================ detector head as a STREAMING kernel (round 3)
+// convPb (1x1, 256 -> 65) + soft-max over the 65 logits of a cell + 8x8 depth-to-space: 512 B in and 256 B out per cell for 33 kFLOP — HBM
+// work.  As a 256 x 128 tile GEMM with a three-stage ring (gemm8_kernel with a soft-max epilogue, rounds 1-2) it ran at 2.1 TB/s, one workgroup per CU and four K chunks per
+// tile being all fill and drain (190 us per 128 images, MFMA-busy 0.12).  Here the 65 x 256 head sits in LDS as MFMA A fragments
+// (fragment-major, 40 KB, read conflict-free), every wave streams tiles of 16 cells straight from global memory into B fragments, one tile
+// ahead, and writes the score map from its accumulators: no staging of activations, no barrier in the loop, three waves per SIMD.
+// Same fragments, same k order (eight 32-wide steps, ascending), bias after the sum and the soft-max expressions of the tiled kernel's former
+// epilogue: the same bits (profiles/r03_probe11_*: md5 of the score maps and features equal; stage 0.38 -> 0.31 ms per step).
+template <class P>
+__global__ __launch_bounds__(256, 3) void head_softmax_d2s_kernel(const uint16_t* __restrict__ X /*[ncell][256]*/, const uint16_t* __restrict__ Wp,
+                                                                  const float* __restrict__ bias /*[65..]*/, float* __restrict__ heat, int ntiles,
+                                                                  int hc, int wc) {
+  __shared__ __attribute__((aligned(16))) char wl[5 * 8 * 1024];      // [tile u][k-step][lane] 16-byte fragments
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  {
+    // tile u = 0..3: rows 16 u + l15 of the first 64-feature slab group, u = 4: row l15 of the second (feature 64 = the dustbin, lane row 0)
+    const char* wbase = reinterpret_cast<const char*>(Wp);
+    for (int f = wave; f < 40; f += 4) {
+      const int u = f >> 3, ks = f & 7;
+      const int cb = u >> 2, rr = (u & 3) * 16 + l15;
+      const uint4 v = *reinterpret_cast<const uint4*>(wbase + ((size_t)cb * 4 + (ks >> 1)) * SLAB_BYTES + rr * 128 + ((((ks & 1) * 4 + g) ^ swz128(rr)) << 4));
+      *reinterpret_cast<uint4*>(wl + (f * 64 + lane) * 16) = v;
+    }
+  }
+  float bv[2][8];
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[tp][e] = bias[tp * 32 + g * 8 + e];
+  const float bdust = bias[64];
+  __syncthreads();
+
+  const int nw = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  typename P::vec8 xn[8];
+  auto fetch = [&](int t) {
+    const uint16_t* xr = X + ((size_t)t * 16 + l15) * 256 + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) xn[ks] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(xr + ks * 32));
+  };
+  if (tile < ntiles) fetch(tile);
+  const int per = hc * wc;
+  for (; tile < ntiles; tile += nw) {
+    typename P::vec8 xf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) xf[ks] = xn[ks];
+    if (tile + nw < ntiles) fetch(tile + nw);
+    f32x4 acc[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int woff = lane * 16;                                // opaque per tile: otherwise hipcc hoists the 40 loop-invariant fragment reads out of
+    asm volatile("" : "+v"(woff));                       // the loop (160 registers: 428 bytes of scratch per lane at three waves per SIMD)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int u = 0; u < 5; ++u) acc[u] = P::mfma(lds_frag<P>(wl, (u * 8 + ks) * 1024 + woff), xf[ks], acc[u]);
+    // ---- the epilogue of gemm8's EPI_SOFTMAX_D2S, expression by expression
+    const int row = tile * 16 + l15;
+    float v[2][8];
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[tp][e] = acc[2 * tp][e] + bv[tp][e];
+        v[tp][4 + e] = acc[2 * tp + 1][e] + bv[tp][4 + e];
+      }
+    const float dust = (g == 0) ? acc[4][0] + bdust : -INFINITY;
+    float mx = dust;
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[tp][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = expf(dust - mx);
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[tp][e] = expf(v[tp][e] - mx);
+        sum += v[tp][e];
+      }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    const int b = row / per, rem = row - b * per, cy = rem / wc, cx = rem - cy * wc;
+    float* o = heat + ((size_t)b * hc * 8 + (size_t)cy * 8) * (wc * 8) + cx * 8;
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      float* r = o + (size_t)(tp * 4 + g) * (wc * 8);
+      *reinterpret_cast<float4*>(r) = make_float4(v[tp][0] * inv, v[tp][1] * inv, v[tp][2] * inv, v[tp][3] * inv);
+      *reinterpret_cast<float4*>(r + 4) = make_float4(v[tp][4] * inv, v[tp][5] * inv, v[tp][6] * inv, v[tp][7] * inv);
+    }
+  }
+}
+
 // requires M % 256 == 0, K % 64 == 0, K1 % 64 == 0
 void launch_gemm8(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st) {
+  if (a.epi == EPI_SOFTMAX_D2S) {                          // the detector head: its own streaming kernel (above); K = 256, N = 65, rows = cells
+    if (trans || K != 256 || a.N != 65 || a.X2 || a.rowidx || a.ld1 != 256 || a.M % 16 != 0) {           // (airfe.hip builds no other form)
+      fprintf(stderr, "airfe: EPI_SOFTMAX_D2S is the detector head only (K = 256, N = 65, dense rows)\n");
+      abort();
+    }
+    const int ntiles = a.M / 16;
+    const int wgs = std::min((ntiles + 3) / 4, 256 * 4);      // persistent: four 4-wave workgroups per CU (40 KB of LDS each)
+    if (prec == 1) hipLaunchKernelGGL(head_softmax_d2s_kernel<PF16>, dim3(wgs), dim3(256), 0, st, a.X1, a.Wp, a.bias, reinterpret_cast<float*>(a.out), ntiles, a.d2s_hc, a.d2s_wc);
+    else hipLaunchKernelGGL(head_softmax_d2s_kernel<PBF16>, dim3(wgs), dim3(256), 0, st, a.X1, a.Wp, a.bias, reinterpret_cast<float*>(a.out), ntiles, a.d2s_hc, a.d2s_wc);
+    return;
+  }
   if (prec == 1) {
     if (trans) gemm8_launch_t<PF16, true>(K, a, st); else gemm8_launch_t<PF16, false>(K, a, st);
   } else {

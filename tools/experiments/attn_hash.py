@@ -27,4 +27,9 @@ fl, fr, nl, nr, idx, sc, nm = z(B, 400, 259), z(B, 400, 259), z(B, dt=torch.int3
 ctx.stereo_batch_dev(L, R, fl, fr, nl, nr, idx, sc, nm)
 ctx.sync()
 out.append("stereo16 sc %s idx %s nm %s" % tuple(hashlib.md5(t.cpu().numpy().tobytes()).hexdigest()[:12] for t in (sc, idx, nm)))
+heat, _, _ = ctx.detector_maps(4)
+out.append("heat4 %s fl %s" % (hashlib.md5(np.ascontiguousarray(heat).tobytes()).hexdigest()[:12], hashlib.md5(fl.cpu().numpy().tobytes()).hexdigest()[:12]))
+one = ctx.detect_points(ls[0])
+h1, _, _ = ctx.detector_maps(1)
+out.append("heat1 %s feat1 %s" % (hashlib.md5(np.ascontiguousarray(h1).tobytes()).hexdigest()[:12], hashlib.md5(one.tobytes()).hexdigest()[:12]))
 print(" | ".join(out))
