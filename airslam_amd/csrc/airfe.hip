@@ -1178,6 +1178,10 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   pa.linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.5f);
   pa.wr = c->lg_wr; pa.B = B; pa.cap = cap; pa.Np = Np;
   pa.x32 = c->x32; pa.xb = c->xb; pa.rot_cos = c->rot_cos; pa.rot_sin = c->rot_sin; pa.lens = c->lens;
+  // the arena's slack rows go back to zero with the same launch (see reset_slack_rows; ADVICE r03: this line had moved to the fp32
+  // path only, so that the 2-byte path's slack rows kept their running residual from call to call)
+  // (only the rows a kernel of THIS call can touch: the 112- / 128-row rounding of the matrix kernels + one key tile)
+  pa.slack_rows = (int)std::min(c->arena_rows - (size_t)M, (size_t)512);
   if (c->trace_on) c->trace_slots.clear();
   c->trace_halt = false;
   const size_t Mw = (size_t)M * 128;                     // 32-bit words of a [M][256] 2-byte buffer

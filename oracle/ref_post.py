@@ -5,9 +5,12 @@ Each function cites the reference file:line it follows (paths under
 /root/reference).  Arithmetic is carried out in float32 op by op wherever the
 C++ does float arithmetic, so results match the C++ up to FMA contraction.
 
-PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for
-this path, and cannot be compiled here (TensorRT, OpenCV,
-Eigen absent).  These restatements are pinned only by reading the code.
+PINNED TO THE REFERENCE'S OWN CODE (round 4): the reference ships no tests, golden vectors or fixtures for this path,
+but its host code compiles: oracle/Makefile builds /root/reference's src/{feature_detector.cc, point_matcher.cc, plnet.cpp, super_point.cpp,
+light_glue.cpp, super_glue.cpp} and line_processor.cc:1-180 UNCHANGED into oracle/_ref/libairslam_ref.so (stand-ins only for Eigen, OpenCV,
+yaml-cpp and TensorRT, whose engines become a callback), and tests/test_ref_pin_cpu.py holds every function below that has a counterpart there
+to it bit for bit — live, and through the committed outputs tests/golden/ref_pin.npz.  Still pinned by reading only: resize_linear_u8 /
+remap_linear_u8 (OpenCV absent), simple_nms (inside the absent ONNX graphs), bow_transform (DBoW2's template, not compiled).
 """
 from __future__ import annotations
 
@@ -223,10 +226,37 @@ def extract_descriptors(desc_chw: np.ndarray, xs: np.ndarray, ys: np.ndarray, s:
     v = (v + (d[:, iy_ne, ix_ne] * ne[None]).astype(F)).astype(F)
     v = (v + (d[:, iy_sw, ix_sw] * sw_[None]).astype(F)).astype(F)
     v = (v + (d[:, iy_se, ix_se] * se[None]).astype(F)).astype(F)      # [256, N]
-    nrm = np.sqrt(np.sum((v * v).astype(F), axis=0, dtype=F)).astype(F)
+    nrm = np.sqrt(_eigen_sse2_sum((v * v).astype(F))).astype(F)
     # Eigen >= 3.3 colwise().normalize(): `if (squaredNorm() > 0) derived() /= sqrt(...)` — a zero column stays zero
     v = np.where(nrm[None] > 0, (v / np.where(nrm > 0, nrm, F(1))[None]).astype(F), v).astype(F)
     return np.ascontiguousarray(v.T)
+
+
+def _eigen_sse2_sum(sq: np.ndarray) -> np.ndarray:
+    """Column sums of sq [n, N] float32 in the order Eigen 3.3 reduces a contiguous dynamic-size float column on SSE2 (Redux.h,
+    LinearVectorizedTraversal: two 4-lane accumulators over pairs of packets, res0 += res1, a trailing packet, predux = (a0 + a2) + (a1 + a3),
+    scalar tail) — what `colwise().normalize()` (src/plnet.cpp:415) does in the reference's build (no -march: SSE2 packets).  The same order
+    is restated in shim/stubs/Eigen/Core, which oracle/_ref is compiled against; pinned against that build by tests/test_ref_pin_cpu.py."""
+    n = sq.shape[0]
+    if n < 4:
+        out = np.zeros(sq.shape[1:], F)
+        for k in range(n):
+            out = (out + sq[k]).astype(F)
+        return out
+    a2, a1 = n // 8 * 8, n // 4 * 4
+    r0 = sq[0:4].astype(F).copy()
+    if a1 > 4:
+        r1 = sq[4:8].astype(F).copy()
+        for k in range(8, a2, 8):
+            r0 = (r0 + sq[k:k + 4]).astype(F)
+            r1 = (r1 + sq[k + 4:k + 8]).astype(F)
+        r0 = (r0 + r1).astype(F)
+        if a1 > a2:
+            r0 = (r0 + sq[a2:a2 + 4]).astype(F)
+    res = ((r0[0] + r0[2]).astype(F) + (r0[1] + r0[3]).astype(F)).astype(F)
+    for k in range(a1, n):
+        res = (res + sq[k]).astype(F)
+    return res
 
 
 def keypoints_decoder(heat, desc_chw, threshold, border, top_k, w_scale=F(1), h_scale=F(1)):
@@ -328,6 +358,14 @@ def normalize_keypoints(feat: np.ndarray, width: int, height: int, scale: float)
 _FLT_MAX = np.finfo(np.float32).max
 
 
+def _expf(x: np.ndarray) -> np.ndarray:
+    """`std::exp(float)` = glibc's expf (src/light_glue.cpp:248, src/super_glue.cpp:299): correctly rounded in practice (< 0.502 ulp), which numpy's
+    own float32 exp is not (it is a 1-ulp SIMD routine: it decides `exp(s) > threshold` differently one ulp beside log(threshold)).  The double
+    exponential rounded once to float32 reproduces glibc bit for bit on every value tests/test_ref_pin_cpu.py feeds both."""
+    with np.errstate(over="ignore", under="ignore", invalid="ignore"):
+        return np.exp(np.asarray(x, F).astype(np.float64)).astype(F)
+
+
 def _first_max_above_floor(m: np.ndarray, axis: int):
     """The reference's arg-max loops: `max = -FLT_MAX; if (v > max) {max = v; arg = j}` — first maximum wins, and an entry
     that does not EXCEED -FLT_MAX (-inf, -FLT_MAX itself, NaN) never becomes the maximum.  Returns (arg, max, found)."""
@@ -353,7 +391,7 @@ def filter_matches(scores: np.ndarray, threshold: float = 0.1):
     crow, _, _ = _first_max_above_floor(s, 0)
     rows = np.arange(n0)
     mutual = crow[rcol] == rows
-    e = np.exp(rval.astype(F)).astype(F)
+    e = _expf(rval)
     ok = mutual & (e > F(threshold))
     idx = np.stack([rows[ok], rcol[ok]], axis=1).astype(np.int32)
     return idx, e[ok].astype(F)
@@ -373,7 +411,7 @@ def superglue_decode(scores: np.ndarray, threshold: float = 0.2):
     mutual0 = idx1[idx0] == np.arange(h - 1)
     mutual1 = idx0[idx1] == np.arange(w - 1)
     with np.errstate(under="ignore"):
-        ms0 = np.where(mutual0, np.exp(max0.astype(F)).astype(F), F(0)).astype(F)
+        ms0 = np.where(mutual0, _expf(max0), F(0)).astype(F)
     ms1 = np.where(mutual1, ms0[idx1], F(0)).astype(F)
     valid0 = mutual0 & (ms0 > F(threshold))
     valid1 = mutual1 & valid0[idx1]

@@ -1,0 +1,2 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Empty stand-in: src/line_processor.cc:1-180 uses nothing of timer.h.
+#pragma once

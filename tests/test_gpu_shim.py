@@ -29,7 +29,7 @@ def test_shim_wrappers_on_the_gpu(libpath, tmp_path):
     left.tofile(str(tmp_path / "l.raw")); right.tofile(str(tmp_path / "r.raw"))
     exe = str(tmp_path / "shim_gpu")
     srcs = [os.path.join(ROOT, "shim", "src", f) for f in ("plnet.cpp", "super_point.cpp", "light_glue.cpp", "super_glue.cpp")]
-    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", f"-I{ROOT}/shim/stubs", f"-I{ROOT}/shim/include", f"-I{ROOT}/include", *srcs,
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", f"-I{ROOT}/shim/stubs", f"-I{ROOT}/shim/stubs/noref", f"-I{ROOT}/shim/include", f"-I{ROOT}/include", *srcs,
                         os.path.join(ROOT, "shim", "gpu_main.cpp"), "-o", exe, f"-L{os.path.dirname(libpath)}", "-lairfe",
                         f"-Wl,-rpath,{os.path.dirname(libpath)}"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr

@@ -11,7 +11,7 @@ from conftest import ROOT
 def test_shim_compiles_links_and_fails_cleanly_without_gpu(libpath, tmp_path):
     exe = str(tmp_path / "shim_smoke")
     srcs = [os.path.join(ROOT, "shim", "src", f) for f in ("plnet.cpp", "super_point.cpp", "light_glue.cpp", "super_glue.cpp")]
-    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", f"-I{ROOT}/shim/stubs", f"-I{ROOT}/shim/include", f"-I{ROOT}/include",
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", f"-I{ROOT}/shim/stubs", f"-I{ROOT}/shim/stubs/noref", f"-I{ROOT}/shim/include", f"-I{ROOT}/include",
            *srcs, os.path.join(ROOT, "shim", "smoke_main.cpp"), "-o", exe, f"-L{os.path.dirname(libpath)}", "-lairfe",
            f"-Wl,-rpath,{os.path.dirname(libpath)}"]
     r = subprocess.run(cmd, capture_output=True, text=True)

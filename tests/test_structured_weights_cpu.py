@@ -69,7 +69,7 @@ def _filter_matches_loops(scores, threshold=0.1):
     idx, sc = [], []
     for r in range(n0):
         if r == col_max[row_max[r][0]][0]:
-            e = np.exp(np.float32(row_max[r][1]))
+            e = ref_post._expf(np.float32(row_max[r][1]))          # std::exp(float) = glibc expf, not numpy's float32 exp (ref_post._expf)
             if e > np.float32(threshold):
                 idx.append((r, row_max[r][0])); sc.append(e)
     return np.array(idx, np.int32).reshape(-1, 2), np.array(sc, np.float32)
@@ -94,7 +94,7 @@ def _decode_loops(z, thr=0.2):
     mutual0 = [i1[i0[i]] == i for i in range(h - 1)]
     mutual1 = [i0[i1[j]] == j for j in range(w - 1)]
     with np.errstate(under="ignore"):
-        ms0 = [np.exp(np.float32(v0[i])) if mutual0[i] else np.float32(0) for i in range(h - 1)]
+        ms0 = [ref_post._expf(np.float32(v0[i])) if mutual0[i] else np.float32(0) for i in range(h - 1)]
     ms1 = [ms0[i1[j]] if mutual1[j] else np.float32(0) for j in range(w - 1)]
     valid0 = [mutual0[i] and ms0[i] > np.float32(thr) for i in range(h - 1)]
     valid1 = [mutual1[j] and valid0[i1[j]] for j in range(w - 1)]
@@ -111,7 +111,7 @@ def hand_built_score_matrices():
     s = np.full((6, 7), -20.0, np.float32)
     s[0, 2] = s[0, 4] = -0.5                     # tie inside a row: the first maximum (col 2) wins
     s[3, 2] = -0.5                               # tie inside column 2 between rows 0 and 3: row 0 wins -> row 3 not mutual
-    s[1, 1] = lt                                 # exp(log 0.1) vs 0.1: decided by float32 exp, whatever it yields
+    s[1, 1] = lt                                 # exp(log 0.1) vs 0.1: decided by glibc's expf (pinned against the compiled reference below)
     s[2, 5] = np.nextafter(lt, np.float32(0))    # one ulp above the threshold
     s[4, 6] = np.nextafter(lt, np.float32(-100)) # one ulp below
     s[5, :] = -np.inf                            # a row with nothing above -FLT_MAX: keeps (col 0, score 0.0f) -> exp = 1
@@ -179,3 +179,35 @@ def test_synthetic_superpoint_descriptors_are_matchable():
         c = v.T @ v
         off = c[~np.eye(300, dtype=bool)]
         assert lo < off.mean() < hi, (structured, off.mean())
+
+
+# ---- the same matrices through the REFERENCE'S OWN filter_matches / decode (oracle/_ref, compiled from src/light_glue.cpp / src/super_glue.cpp)
+from oracle import ref_lib  # noqa: E402
+
+_needs_ref = pytest.mark.skipif(not ref_lib.available(), reason="oracle/_ref is not built")
+
+
+@_needs_ref
+@pytest.mark.parametrize("name", list(hand_built_score_matrices()))
+def test_hand_built_matrices_through_the_compiled_reference(name):
+    s = hand_built_score_matrices()[name]
+    idx, sc = ref_post.filter_matches(s, 0.1)
+    ridx, rsc = ref_lib.filter_matches(s, 0.1)
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(sc, rsc)
+    z = np.full((s.shape[0] + 1, s.shape[1] + 1), 5.0, np.float32)
+    z[:-1, :-1] = s
+    i0, i1, m0, m1 = ref_post.superglue_decode(z, 0.2)
+    r0, r1, rm0, rm1 = ref_lib.superglue_decode(z)
+    np.testing.assert_array_equal(i0, r0)
+    np.testing.assert_array_equal(i1, r1)
+    np.testing.assert_array_equal(m0, rm0.astype(np.float64))
+    np.testing.assert_array_equal(m1, rm1.astype(np.float64))
+
+
+@_needs_ref
+def test_cpu_sinkhorn_of_the_reference():
+    """log_optimal_transport (src/super_glue.cpp:369-435, dead code there): the restatement follows it to float32 summation order."""
+    rng = np.random.default_rng(5)
+    s = rng.normal(0, 1, (12, 9)).astype(np.float32)
+    np.testing.assert_allclose(ref_post.log_optimal_transport(s, 2.3457, 20), ref_lib.log_optimal_transport(s, 2.3457, 20), atol=2e-5, rtol=0)
