@@ -5,6 +5,13 @@
 
 namespace airfe {
 
+// `std::exp(float)` as the reference's host code computes it (glibc expf: correctly rounded in practice) for the two places where an exponential
+// becomes an OUTPUT or meets a THRESHOLD (filter_matches src/light_glue.cpp:248-249, decode src/super_glue.cpp:299,355).  OCML's expf is a 1-ulp
+// routine: beside the compiled reference (oracle/_ref, tests/test_gpu_ref_pin.py) it differed in the last bit of 7 % of the match scores.  The
+// double exponential rounded once gives glibc's bits; the call sites see at most 1024 values per pair.
+__device__ __forceinline__ float expf_like_glibc(float x) { return (float)exp((double)x); }
+
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;

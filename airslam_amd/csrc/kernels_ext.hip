@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(1024) void sg_decode_kernel(const int* __restrict__
   const int* i1 = idx1 + (size_t)b * Lz;
   if (tid < n0) {
     const bool mutual = i1[i0[tid]] == tid;
-    const float m = mutual ? expf(max0[(size_t)b * Lz + tid]) : 0.f;
+    const float m = mutual ? expf_like_glibc(max0[(size_t)b * Lz + tid]) : 0.f;
     const bool valid = mutual && m > thr;
     s_ms0[tid] = m;
     s_valid0[tid] = valid;

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(1024) void lg_filter_kernel(const int* __restrict__
   float e = 0.f;
   if (tid < n0) {
     col = rowarg[(size_t)b * Np + tid];
-    e = expf(rowval[(size_t)b * Np + tid]);
+    e = expf_like_glibc(rowval[(size_t)b * Np + tid]);
     ok = (colarg[(size_t)b * Np + col] == tid) && (e > thr);
   }
   const unsigned long long bal = __ballot(ok);
