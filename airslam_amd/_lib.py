@@ -72,6 +72,7 @@ SIGNATURES = {
                                                C.c_void_p]),
     "airfe_debug_plnet_j2l": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "airfe_sync": (C.c_int, [C.c_void_p]),
+    "airfe_superglue_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "airfe_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "airfe_profile_stages": (C.c_int, []),
     "airfe_profile_stage_name": (C.c_char_p, [C.c_int]),

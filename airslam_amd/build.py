@@ -30,6 +30,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "airfe.h"))
+    headers.append(os.path.join(HERE, "..", "include", "airfe_debug.h"))
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = []
     jobs = []

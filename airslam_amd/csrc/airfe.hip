@@ -2,6 +2,7 @@
 // build, src/plnet.cpp:24-196), persistent device arena (replaces the per-call BufferManager of
 // 3rdparty/tensorrtbuffer/include/buffers.h:237-417) and the detect / match pipelines behind the C ABI.
 #include "../../include/airfe.h"
+#include "../../include/airfe_debug.h"
 
 #include <hip/hip_runtime.h>
 
@@ -175,6 +176,7 @@ struct airfe_ctx {
   int mprec = 1;                 // matcher storage type (cfg.matcher_precision)
   int pack_prec = 0;             // storage type make_linear packs for (set by each load_* before it packs)
   int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
+  bool trace_overflow = false;   // a trace slot was dropped (table full): trace_finish fails instead of mis-numbering launches
   size_t arena_rows = 0;         // token rows of the matcher arena, slack included (alloc_matcher_arena)
   int Dmax = 1;                  // images the detector arena holds: 2 x Bmax when a stereo step detects left and right as one batch
   bool has_sp = false, has_lg = false;
@@ -1066,12 +1068,17 @@ void trace(airfe_ctx* c, hipStream_t st, const char* what, size_t li, const char
   if (!c->trace_on) return;
   const unsigned off = c->trace_slots.empty() ? 0u : c->trace_slots.back().off + c->trace_slots.back().units;
   const unsigned units = (unsigned)(words / unit_words);
-  if (c->trace_slots.size() >= 1024 || (size_t)off + units > c->trace_cap) return;
+  if (units == 0) return;                                          // nothing to hash (and a 0-sized grid is a launch error)
+  if (c->trace_slots.size() >= 1024 || (size_t)off + units > c->trace_cap) { c->trace_overflow = true; return; }   // reported by trace_finish
   launch_trace_hash(p, unit_words, units, c->trace_tab + off, st);
   c->trace_slots.push_back({std::string("L") + std::to_string(li) + "." + blk + "." + what, off, units, unit_words, p, words});
   if ((int)c->trace_slots.size() - 1 == c->trace_stop) c->trace_halt = true;
 }
 int trace_finish(airfe_ctx* c, hipStream_t st) {
+  if (c->trace_on && c->trace_overflow) {
+    c->trace_overflow = false;
+    return fail(c, "airfe_debug_trace: slot / unit table overflow — slots were dropped, slot indices do not name the launches of a full run");
+  }
   if (c->trace_on && !c->trace_slots.empty()) {
     c->trace_off_h.clear();
     for (const auto& t : c->trace_slots) c->trace_off_h.push_back(t.off);
@@ -1182,7 +1189,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   // path only, so that the 2-byte path's slack rows kept their running residual from call to call)
   // (only the rows a kernel of THIS call can touch: the 112- / 128-row rounding of the matrix kernels + one key tile)
   pa.slack_rows = (int)std::min(c->arena_rows - (size_t)M, (size_t)512);
-  if (c->trace_on) c->trace_slots.clear();
+  if (c->trace_on) { c->trace_slots.clear(); c->trace_overflow = false; }
   c->trace_halt = false;
   const size_t Mw = (size_t)M * 128;                     // 32-bit words of a [M][256] 2-byte buffer
   auto tr_x = [&](size_t li, const char* blk) {
@@ -1196,6 +1203,9 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   };
   { ProfScope ps(c, ST_LG_PREPARE, st, 0, (double)M * (1036 + 1536 + 256)); launch_lg_prepare(c->mprec, pa, st); }
   tr_x(0, "prep");
+  // the arena's slack rows as this call starts (must be zero: ADVICE r03 / test_slack_rows_are_reset_on_every_call) and, at the end, as it leaves them
+  const size_t slack_words = (size_t)(pa.slack_rows / 16 * 16) * 256;
+  if (slack_words) trace(c, st, "x32slack", 0, "prep", c->x32 + (size_t)M * 256, slack_words, 4096);
   trace(c, st, "rc", 0, "prep", c->rot_cos, (size_t)M * 32, 512);
   trace(c, st, "rs", 0, "prep", c->rot_sin, (size_t)M * 32, 512);
   TRACE_HALT;
@@ -1255,6 +1265,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   const size_t LF = c->lg.size();
   run_linear(c, c->lg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
   trace(c, st, "md", LF, "final", c->mdb, Mw, 2048);
+  if (slack_words) trace(c, st, "x32slack", LF, "final", c->x32 + (size_t)M * 256, slack_words, 4096);
   TRACE_HALT;
   ProfScope ps(c, ST_LG_ASSIGN, st, 2.0 * B * Np * (double)Np * 256, (double)B * Np * Np * 4 * 6);
   launch_rowdot256(c->x32, c->lg_mw, c->lg_mb, c->zbuf, M, st);
@@ -1504,6 +1515,16 @@ void airfe_default_cfg(airfe_cfg* cfg) {
 
 const char* airfe_last_error(const airfe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
+// Every entry that takes a context makes the context's device current first: a process may hold contexts on several devices (cfg.device)
+// and the calling thread's current device is whatever the application left it at.
+static inline int enter_device(airfe_ctx* c) {
+  int d = -1;
+  if (hipGetDevice(&d) == hipSuccess && d == c->cfg.device) return 0;
+  if (hipSetDevice(c->cfg.device) != hipSuccess) return fail(c, "hipSetDevice(cfg.device) failed");
+  return 0;
+}
+#define AIRFE_ENTER(c) do { if (!(c)) return 1; if (enter_device(c)) return 1; } while (0)
+
 int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (!cfg || !out) return fail(nullptr, "airfe_create: null argument");
   *out = nullptr;
@@ -1593,7 +1614,7 @@ void airfe_destroy(airfe_ctx* c) {
 }
 
 int airfe_profile_enable(airfe_ctx* c, int on) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   HIPCHK(c, hipDeviceSynchronize());             // the events may have been recorded on a caller's stream (the *_dev entry points)
   for (auto& m : c->marks) { c->ev_pool.push_back(m.a); c->ev_pool.push_back(m.b); }
   c->marks.clear();
@@ -1605,7 +1626,7 @@ int airfe_profile_stages(void) { return ST_COUNT; }
 const char* airfe_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
 
 int airfe_profile_read(airfe_ctx* c, double* ms, double* flops, double* bytes, int* launches) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   HIPCHK(c, hipDeviceSynchronize());
   for (int i = 0; i < ST_COUNT; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
   for (auto& m : c->marks) {
@@ -1622,7 +1643,7 @@ int airfe_profile_read(airfe_ctx* c, double* ms, double* flops, double* bytes, i
 /* fault hunting: checksums of the matcher's state behind every launch of the LightGlue forward (x32, xb, q, k, v^T, attention output, ...)
    in units of 16 token rows; off by default.  airfe_debug_trace_read synchronises the context's stream. */
 int airfe_debug_trace(airfe_ctx* c, int on) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (on && !c->trace_tab) {
     c->trace_cap = (size_t)3 << 20;
     c->trace_tab = dalloc<unsigned long long>(c, c->trace_cap);
@@ -1635,11 +1656,12 @@ int airfe_debug_trace(airfe_ctx* c, int on) {
   return 0;
 }
 int airfe_debug_trace_stop(airfe_ctx* c, int slot) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   c->trace_stop = slot;
   return 0;
 }
 int airfe_debug_trace_buffer(airfe_ctx* c, int slot, void* host, size_t bytes) {
+  if (c && enter_device(c)) return 1;
   if (!c || slot < 0 || slot >= (int)c->trace_slots.size()) return fail(c, "trace_buffer: no such slot");
   const auto& t = c->trace_slots[(size_t)slot];
   if (bytes > t.words * 4) return fail(c, "trace_buffer: more bytes than the slot covers");
@@ -1658,6 +1680,7 @@ int airfe_debug_trace_slot(airfe_ctx* c, int i, char* name, int name_cap, unsign
   return 0;
 }
 int airfe_debug_trace_read(airfe_ctx* c, void* stream, unsigned long long* digests, unsigned long long* table) {
+  if (c && enter_device(c)) return 1;
   if (!c || !c->trace_tab) return fail(c, "trace is off");
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   HIPCHK(c, hipStreamSynchronize(st));
@@ -1670,19 +1693,25 @@ int airfe_debug_trace_read(airfe_ctx* c, void* stream, unsigned long long* diges
 
 static int sinkhorn_failed(airfe_ctx* c);
 int airfe_sync(airfe_ctx* c) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return sinkhorn_failed(c);         // (the batch entry points are asynchronous: a Sinkhorn time-out of an earlier call surfaces here)
 }
 
+int airfe_superglue_status(airfe_ctx* c, void* stream) {
+  AIRFE_ENTER(c);
+  HIPCHK(c, hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+  return sinkhorn_failed(c);
+}
+
 int airfe_detect_points_batch_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride,
                                   float* d_feat, int cap, int* d_n, void* stream) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   return detect_dev(c, d_gray, B, h, w, stride, img_stride, d_feat, cap, d_n, stream ? (hipStream_t)stream : c->stream);
 }
 
 int airfe_detect_points(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, float* feat, int cap, int* n) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
   if (upload_image(c, gray, h, w, stride)) return 1;
   if (detect_dev(c, c->st_img, 1, h, w, stride, (size_t)h * stride, c->st_feat0, c->Np, c->st_n0, c->stream)) return 1;
@@ -1697,7 +1726,7 @@ int airfe_detect_points(airfe_ctx* c, const uint8_t* gray, int h, int w, int str
 /* ---- BoW quantisation behind the path: Database::FrameToBow's per-feature tree descent --------------- */
 int airfe_bow_load(airfe_ctx* c, const float* node_desc, const int32_t* first_child, const int32_t* n_children, const int32_t* word_id,
                    const double* weight, int n_nodes) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (!node_desc || !first_child || !n_children || !word_id || !weight || n_nodes < 1) return fail(c, "bow_load: bad argument");
   for (int i = 0; i < n_nodes; ++i) {                    // the device follows these indices: validate them here, once
     if (n_children[i] < 0 || (n_children[i] > 0 && (first_child[i] <= i || first_child[i] + n_children[i] > n_nodes)))
@@ -1718,7 +1747,7 @@ int airfe_bow_load(airfe_ctx* c, const float* node_desc, const int32_t* first_ch
 }
 
 int airfe_bow_transform_dev(airfe_ctx* c, const float* d_feat, int N, uint32_t* d_word, float* d_weight, void* stream) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (!c->bow_nodes) return fail(c, "bow_transform: no vocabulary loaded (airfe_bow_load)");
   if (N < 0 || (N > 0 && (!d_feat || !d_word || !d_weight))) return fail(c, "bow_transform: bad argument");
   launch_bow_transform(d_feat, AIRFE_FEAT_DIM, 3, N, c->bow_desc, c->bow_first, c->bow_nch, c->bow_word, c->bow_weight, d_word, d_weight,
@@ -1728,7 +1757,7 @@ int airfe_bow_transform_dev(airfe_ctx* c, const float* d_feat, int N, uint32_t* 
 }
 
 int airfe_bow_transform(airfe_ctx* c, const float* feat, int N, uint32_t* word_of_features, double* weight_of_features) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (N == 0) return 0;                                  // database.cc:60
   if (N < 0 || N > c->Np || N > 1024 || !feat || !word_of_features) return fail(c, "bow_transform: bad argument / more features than max_keypoints");
   HIPCHK(c, hipMemcpyAsync(c->st_feat0, feat, (size_t)N * AIRFE_FEAT_DIM * 4, hipMemcpyHostToDevice, c->stream));
@@ -1744,7 +1773,7 @@ int airfe_bow_transform(airfe_ctx* c, const float* feat, int N, uint32_t* word_o
 
 /* ---- rectification in front of the path: Camera::UndistortImage, src/camera.cc:161-182 ------------- */
 int airfe_set_rectify_maps(airfe_ctx* c, int side, const float* mapx, const float* mapy, int h, int w) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (side < 0 || side > 1 || !mapx || !mapy || h < 1 || w < 1) return fail(c, "set_rectify_maps: bad argument");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t n = (size_t)h * w;
@@ -1765,7 +1794,7 @@ int airfe_set_rectify_maps(airfe_ctx* c, int side, const float* mapx, const floa
 
 int airfe_rectify_batch_dev(airfe_ctx* c, int side, const uint8_t* d_raw, int B, int h, int w, int stride, size_t img_stride,
                             uint8_t* d_rect, int rstride, size_t rimg_stride, void* stream) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (side < 0 || side > 1 || !c->rmap[side][0]) return fail(c, "rectify: no maps set for this side (airfe_set_rectify_maps)");
   if (h != c->rmap_h[side] || w != c->rmap_w[side]) return fail(c, "rectify: image size differs from the maps'");
   if (stride < w || rstride < w) return fail(c, "rectify: stride smaller than the width");
@@ -1779,7 +1808,7 @@ int airfe_rectify_batch_dev(airfe_ctx* c, int side, const uint8_t* d_raw, int B,
    image never leaves the device on its way into the detector */
 int airfe_rectify_detect_points(airfe_ctx* c, int side, const uint8_t* raw, int h, int w, int stride, uint8_t* rect_out, float* feat,
                                 int cap, int* n) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (feat && cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
   if (upload_image(c, raw, h, w, stride)) return 1;
   if (ensure_block(c, c->st_rect, c->st_rect_bytes, (size_t)h * w)) return 1;
@@ -1797,6 +1826,7 @@ int airfe_rectify_detect_points(airfe_ctx* c, int side, const uint8_t* raw, int 
 }
 
 int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_nms, float* desc) {
+  if (c && enter_device(c)) return 1;
   if (!c || !c->has_sp || B > c->Dmax) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t R = AIRFE_INTERNAL_SIZE;
@@ -1825,7 +1855,7 @@ int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_
 
 static int lg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx, float* score, int cap,
                    int* nmatch, float* scores_full) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (n0 < 1 || n1 < 1) { if (nmatch) *nmatch = 0; return 0; }   // point_matcher.cc:53-55
   if (n0 > c->cfg.max_keypoints || n1 > c->cfg.max_keypoints) return fail(c, "keypoint count exceeds max_keypoints");
   HIPCHK(c, hipMemcpyAsync(c->st_feat0, f0, (size_t)n0 * 258 * 4, hipMemcpyHostToDevice, c->stream));
@@ -1854,15 +1884,18 @@ static int lg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n
 
 int airfe_match_lightglue(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx, float* score,
                           int cap, int* nmatch) {
+  if (c && enter_device(c)) return 1;
   return lg_host(c, f0, n0, f1, n1, idx, score, cap, nmatch, nullptr);
 }
 
 int airfe_debug_lightglue_scores(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, float* scores) {
+  if (c && enter_device(c)) return 1;
   return lg_host(c, f0, n0, f1, n1, nullptr, nullptr, 0, nullptr, scores);
 }
 
 /* filter_matches (src/light_glue.cpp:214-266) alone on one HOST score matrix [n0][n1] */
 int airfe_debug_lg_filter(airfe_ctx* c, const float* scores, int n0, int n1, int32_t* idx, float* score, int cap, int* nmatch) {
+  if (c && enter_device(c)) return 1;
   if (!c || !c->has_arena) return fail(c, "debug_lg_filter: no matcher loaded");
   if (n0 < 1 || n1 < 1 || n0 > c->cfg.max_keypoints || n1 > c->cfg.max_keypoints || !scores || !idx || !score || !nmatch)
     return fail(c, "debug_lg_filter: bad argument");
@@ -1885,7 +1918,7 @@ int airfe_debug_lg_filter(airfe_ctx* c, const float* scores, int n0, int n1, int
 
 int airfe_match_lightglue_batch_dev(airfe_ctx* c, const float* d_f0, const int* d_n0, const float* d_f1, const int* d_n1,
                                     int B, int cap, int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, void* stream) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   return lightglue_dev(c, d_f0, d_n0, d_f1, d_n1, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr,
                        stream ? (hipStream_t)stream : c->stream);
 }
@@ -1893,7 +1926,7 @@ int airfe_match_lightglue_batch_dev(airfe_ctx* c, const float* d_f0, const int* 
 int airfe_stereo_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
                            size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, int32_t* d_idx,
                            float* d_score, int mcap, int* d_nmatch, void* stream) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   if (c->prec != 2 && 2 * B <= c->Dmax) {        // left and right images as ONE detector batch
     if (detect_dev2(c, d_left, d_right, B, h, w, stride, img_stride, d_featL, d_featR, cap, d_nL, d_nR, st)) return 1;
@@ -1906,7 +1939,7 @@ int airfe_stereo_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d
 
 int airfe_assign_points_to_lines(airfe_ctx* c, const double* lines, int L, const float* feat, int N, int32_t* row_ptr,
                                  int32_t* pt_idx, double* pt_dist, int cap, int* total) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (L < 0 || N < 0 || cap < 0 || !row_ptr || !total) return fail(c, "assign_points_to_lines: bad argument");
   *total = 0;
   if (L == 0) { row_ptr[0] = 0; return 0; }
@@ -1939,7 +1972,7 @@ int airfe_assign_points_to_lines(airfe_ctx* c, const double* lines, int L, const
 
 int airfe_match_lines(airfe_ctx* c, const int32_t* row_ptr0, const int32_t* pt_idx0, int L0, int point_num0, const int32_t* row_ptr1,
                       const int32_t* pt_idx1, int L1, int point_num1, const int32_t* matches, int M, int32_t* line_matches) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (L0 < 0 || L1 < 0 || M < 0 || point_num0 < 0 || point_num1 < 0 || (L0 > 0 && !line_matches)) return fail(c, "match_lines: bad argument");
   for (int i = 0; i < L0; ++i) line_matches[i] = -1;                                  // line_processor.cc:127-131
   if (point_num0 == 0 || point_num1 == 0 || L0 == 0 || L1 == 0) return 0;            // :132
@@ -2009,7 +2042,7 @@ static int upload_stage0(airfe_ctx* c, const airfe_plnet_stage0* s0, hipStream_t
 int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, const airfe_plnet_stage0* s0, float* feat,
                        int cap, int* n, double* lines, int capL, int* nlines, float* junc, int capJ, int* njunc,
                        int want_junctions) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (nlines) *nlines = 0;
   if (njunc) *njunc = 0;
   if (airfe_detect_points(c, gray, h, w, stride, feat, cap, n)) return 1;      // point branch: plnet.cpp:560
@@ -2069,7 +2102,7 @@ static int plnet_lines_batch(airfe_ctx* c, int B, int h, int w, double* d_lines,
 int airfe_detect_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat,
                                  int cap, int* d_n, double* d_lines, int capL, int* d_nlines, float* d_junc, int capJ, int* d_njunc,
                                  int junction_images, int* d_found, void* stream) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   c->force_nms_map = junction_images > 0;         // junction scores are read from the NMS'd maps
   const int rc = detect_dev(c, d_gray, B, h, w, stride, img_stride, d_feat, cap, d_n, st);
@@ -2082,7 +2115,7 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint
                                  size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, double* d_lines,
                                  int capL, int* d_nlines, float* d_juncL, int capJ, int* d_njuncL, int* d_found, int32_t* d_idx,
                                  float* d_score, int mcap, int* d_nmatch, void* stream) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   if (!(c->prec != 2 && 2 * B <= c->Dmax))
     return fail(c, "stereo_plnet_batch: needs the one-pass stereo detector (detector + LightGlue packs loaded, 2 B <= 2 max_batch, fp16 / bf16)");
@@ -2098,7 +2131,7 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint
   // LightGlue on the caller's (+2 % from filled launch ramps and tails; fork behind the point branch, join behind both).  Round 2 kept this
   // off: with the line path's workgroups beside it the matcher's scores were irreproducible in ~10 % of the steps — traced in round 3 to ONE
   // packed-math instruction form in the rotary epilogue (common.h, rotate_pairs), which also failed, 50x more rarely, on one stream.
-  // With that form gone: 0 deviations in 3500 overlapped and 5000 single-stream steps (profiles/r03_matcher_trace.txt).
+  // With that form gone: 0 deviations in 3500 overlapped and 5000 single-stream steps (profiles/r03_matcher_trace_probe1.txt, _probe2.txt).
   if (!overlap) {
     if (plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, st)) return 1;
     return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
@@ -2115,6 +2148,7 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint
 /* the on-device stage-0 line branch of the LAST detected image, copied out in the Appendix A.1 layouts (NULL = skip) */
 int airfe_debug_plnet_stage0(airfe_ctx* c, float* juncs_pred, float* lines_pred, float* iskeep, float* idx_min, float* idx_max,
                              float* loi, float* thin, float* aux, float* jloc, float* joff) {
+  if (c && enter_device(c)) return 1;
   if (!c || !c->has_s0 || !c->has_s1) return fail(c, "debug_plnet_stage0: line branch / stage 1 not loaded");
   hipStream_t st = c->stream;
   if (line_branch_dev(c, st, 0, 1, true)) return 1;
@@ -2133,6 +2167,7 @@ int airfe_debug_plnet_stage0(airfe_ctx* c, float* juncs_pred, float* lines_pred,
 /* the junction-to-line match of the LAST detected image as the line path runs it (fast = 1: cell search, exact where it is consumed) or
    as the inspection hook exports it (fast = 0: every proposal against every junction): iskeep, idx_junc_to_end_min / _max [3*128*128] */
 int airfe_debug_plnet_j2l(airfe_ctx* c, int fast, float* iskeep, float* idx_min, float* idx_max) {
+  if (c && enter_device(c)) return 1;
   if (!c || !c->has_s0 || !c->has_s1) return fail(c, "debug_plnet_j2l: line branch / stage 1 not loaded");
   hipStream_t st = c->stream;
   if (line_branch_dev(c, st, 0, 1, fast == 0)) return 1;
@@ -2147,6 +2182,7 @@ int airfe_debug_plnet_j2l(airfe_ctx* c, int fast, float* iskeep, float* idx_min,
 
 /* stage-1 alone on HOST stage-0 tensors: lines_adjusted [M2][4] + scores_line [M2] (parity vs the real plnet_s1.onnx) */
 int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* lines_adjusted, float* scores_line, int cap, int* m2) {
+  if (c && enter_device(c)) return 1;
   if (!c || !c->has_s1 || !s0) return fail(c, "debug_plnet_s1: stage-1 not loaded");
   hipStream_t st = c->stream;
   if (upload_stage0(c, s0, st)) return 1;
@@ -2180,7 +2216,7 @@ static int sinkhorn_failed(airfe_ctx* c) {
 
 static int sg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx0, int32_t* idx1, double* ms0,
                    double* ms1, float* scores_full) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (n0 < 1 || n1 < 1) return fail(c, "airfe_match_superglue: empty input (MatchingPoints early-outs before calling infer)");
   if (n0 > c->cfg.max_keypoints || n1 > c->cfg.max_keypoints) return fail(c, "keypoint count exceeds max_keypoints");
   HIPCHK(c, hipMemcpyAsync(c->st_feat0, f0, (size_t)n0 * 259 * 4, hipMemcpyHostToDevice, c->stream));
@@ -2206,11 +2242,13 @@ static int sg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n
 
 int airfe_match_superglue(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx0, int32_t* idx1,
                           double* ms0, double* ms1) {
+  if (c && enter_device(c)) return 1;
   return sg_host(c, f0, n0, f1, n1, idx0, idx1, ms0, ms1, nullptr);
 }
 
 /* decode (src/super_glue.cpp:339-367) alone on one HOST score matrix Z [n0+1][n1+1] */
 int airfe_debug_sg_decode(airfe_ctx* c, const float* Z, int n0, int n1, int32_t* idx0, int32_t* idx1, double* ms0, double* ms1) {
+  if (c && enter_device(c)) return 1;
   if (!c || !c->has_sg) return fail(c, "debug_sg_decode: SuperGlue not loaded");
   if (n0 < 1 || n1 < 1 || n0 > c->cfg.max_keypoints || n1 > c->cfg.max_keypoints || !Z || !idx0 || !idx1 || !ms0 || !ms1)
     return fail(c, "debug_sg_decode: bad argument");
@@ -2234,7 +2272,7 @@ int airfe_debug_sg_decode(airfe_ctx* c, const float* Z, int n0, int n1, int32_t*
    the device): d_idx0 / d_idx1 [B][cap] (-1 = unmatched), d_ms0 / d_ms1 [B][cap] floats.  No reference counterpart (batch-1 there). */
 int airfe_match_superglue_batch_dev(airfe_ctx* c, const float* d_f0, const int* d_n0, const float* d_f1, const int* d_n1, int B, int cap,
                                     int32_t* d_idx0, int32_t* d_idx1, float* d_ms0, float* d_ms1, void* stream) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   if (superglue_dev(c, d_f0, d_n0, d_f1, d_n1, B, cap, 1, st)) return 1;
   const size_t sp = (size_t)c->Lz * 4, dp = (size_t)cap * 4, wb = (size_t)std::min(cap, c->Lz) * 4;
@@ -2247,11 +2285,13 @@ int airfe_match_superglue_batch_dev(airfe_ctx* c, const float* d_f0, const int* 
 
 /* full SuperGlue output `scores` [n0+1][n1+1] (binding A.5) for one HOST pair */
 int airfe_debug_superglue_scores(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, float* scores) {
+  if (c && enter_device(c)) return 1;
   return sg_host(c, f0, n0, f1, n1, nullptr, nullptr, nullptr, nullptr, scores);
 }
 
 // ---- kernel-level test hooks ------------------------------------------------------------------------------
 int airfe_debug_preprocess(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, float* out) {
+  if (c && enter_device(c)) return 1;
   if (!c || !c->has_sp) return fail(c, "debug_preprocess: detector not loaded");
   const size_t bytes = (size_t)h * stride;
   if (upload_image(c, gray, h, w, stride) || ensure_tables(c, h, w)) return 1;
@@ -2264,7 +2304,7 @@ int airfe_debug_preprocess(airfe_ctx* c, const uint8_t* gray, int h, int w, int 
 
 int airfe_debug_conv3x3(airfe_ctx* c, const float* x, int B, int cin, int H, int W, const float* w, const float* b, int cout,
                         int pool, float* y) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if ((cin != 64 && cin != 128) || cout % 64 || W % 16 || H % 16) return fail(c, "debug_conv3x3: unsupported shape");
   const int prec = c->prec;
   std::vector<uint16_t> xin((size_t)B * (H + 2) * (W + 2) * cin, 0);
@@ -2307,7 +2347,7 @@ int airfe_debug_conv3x3(airfe_ctx* c, const float* x, int B, int cin, int H, int
 }
 
 int airfe_debug_gemm(airfe_ctx* c, const float* x, int M, int K, const float* w, const float* b, int N, int relu, float* y) {
-  if (!c) return 1;
+  AIRFE_ENTER(c);
   if (K != 128 && K != 256 && K != 512) return fail(c, "debug_gemm: K must be 128, 256 or 512");
   const int prec = c->prec, Mp = (M + 127) / 128 * 128, Np8 = (N + 7) / 8 * 8;
   std::vector<uint16_t> xin((size_t)Mp * K, 0);

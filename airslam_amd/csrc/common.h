@@ -5,6 +5,21 @@
 
 namespace airfe {
 
+// Function attributes (hipFuncSetAttribute) and occupancy answers are per DEVICE, not per process: launchers keep one of these per kernel
+// instantiation instead of a `static bool` (two contexts on two devices in one process — cfg.device invites it — would have left the second
+// device's kernels without their dynamic-LDS limit).
+struct PerDeviceOnce {
+  bool done[64] = {};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
+
 // `std::exp(float)` as the reference's host code computes it (glibc expf: correctly rounded in practice) for the two places where an exponential
 // becomes an OUTPUT or meets a THRESHOLD (filter_matches src/light_glue.cpp:248-249, decode src/super_glue.cpp:299,355).  OCML's expf is a 1-ulp
 // routine: beside the compiled reference (oracle/_ref, tests/test_gpu_ref_pin.py) it differed in the last bit of 7 % of the match scores.  The
@@ -176,7 +191,7 @@ __device__ __forceinline__ float rows_sum(float v) {
 // element (feature 8 g + 2 of a lane's run: the EVEN element of pair 1, lanes 48-63 only, its odd partner right) came out wrong
 // in one 16-token tile of the first layer's q | k projection in 0.13 % of the 64-pair steps on a quiet GPU and in 4 % with another
 // stream's kernels beside it: the round-2 "matcher race" (tools/experiments/matcher_trace.py names the launch, the tile and the
-// element; profiles/r03_matcher_trace.txt).  The same element failed in lg_blockf's folded projection in round 2, where the
+// element; profiles/r03_matcher_trace_probe1.txt, _probe2.txt).  The same element failed in lg_blockf's folded projection in round 2, where the
 // tables came from global loads instead of LDS.  No missing wait count or documented hazard in the ISA; the products and sums
 // below are the same ones in the same order, so the bits do not change.
 __device__ __forceinline__ void rotate_pairs(float* v, const f32x4& c, const f32x4& s) {

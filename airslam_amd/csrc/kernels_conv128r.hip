@@ -168,11 +168,10 @@ __global__ __launch_bounds__(512, 1) void conv128r_kernel(ConvArgs a, int tiles_
 
 template <class P, bool POOL>
 static void conv128r_launch_t(const ConvArgs& a, hipStream_t st) {
-  static bool attr_done = false;
+  static PerDeviceOnce attr_once;
   auto kfn = conv128r_kernel<P, POOL>;
-  if (!attr_done) {
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, C128R_LDS);
-    attr_done = true;
   }
   const int tiles_x = a.W / 16, tiles_y = a.H / 8;
   const int ntiles = tiles_x * tiles_y * a.B;

@@ -453,11 +453,10 @@ template <class P, bool POOL, bool FUSE1A>
 static void conv64r_launch_t(const ConvArgs& a, hipStream_t st) {
   constexpr int RW = C64R_RW;
   constexpr int LDS = C64R_CONST_OFF + 4096 + 256;
-  static bool attr_done = false;
+  static PerDeviceOnce attr_once;
   auto kfn = conv64r_kernel<P, POOL, FUSE1A, RW>;
-  if (!attr_done) {
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
   }
   const int tiles_x = a.W / 16, tiles_y = a.H / 16;
   const int ntiles = tiles_x * tiles_y * a.B;

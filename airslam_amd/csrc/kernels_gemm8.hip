@@ -214,11 +214,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs a, int K, int qu
 template <class P, bool TRANS>
 static void gemm8_launch_t(int K, const GemmArgs& a, hipStream_t st) {
   constexpr int LDS = 2 * G8_STAGE;
-  static bool attr_done = false;
+  static PerDeviceOnce attr_once;
   auto kfn = gemm8_kernel<P, TRANS>;
-  if (!attr_done) {
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
   }
   const int mb = a.M / 256;
   const int nquads = (a.cb_total + 3) / 4;       // the weight buffer is packed with a multiple of 4 feature blocks

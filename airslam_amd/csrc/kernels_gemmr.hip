@@ -190,11 +190,10 @@ __global__ __launch_bounds__(512, 1) void gemmr_pair_kernel(GemmArgs a, GemmArgs
 template <class P, bool ROT>
 static void gemmr_pair_launch_t(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
   constexpr int LDS = ROT ? 6 * (GR_XBYTES + GR_RBYTES) : 8 * GR_XBYTES;
-  static bool attr_done = false;
+  static PerDeviceOnce attr_once;
   auto kfn = gemmr_pair_kernel<P, ROT>;
-  if (!attr_done) {
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
   }
   const int ng_a = a.cb_total / 4, ngroups = ng_a + 1;
   const int nwg = std::max(a.gr_wgs / (8 * ngroups), 1) * (8 * ngroups);   // 256 for two groups, 240 for three
@@ -204,11 +203,10 @@ static void gemmr_pair_launch_t(const GemmArgs& a, const GemmArgs& b, hipStream_
 template <class P, bool TRANS, bool ROT>
 static void gemmr_launch_t(const GemmArgs& a, hipStream_t st) {
   constexpr int LDS = ROT ? 6 * (GR_XBYTES + GR_RBYTES) : 8 * GR_XBYTES;
-  static bool attr_done = false;
+  static PerDeviceOnce attr_once;
   auto kfn = gemmr_kernel<P, TRANS, ROT>;
-  if (!attr_done) {
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
   }
   const int ngroups = a.cb_total / 4;
   const int nwg = std::max(a.gr_wgs / (8 * ngroups), 1) * (8 * ngroups);

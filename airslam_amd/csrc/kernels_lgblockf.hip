@@ -455,11 +455,10 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
 
 template <class P, int NMT, bool RELU, int FOLD = 0>
 static void launch_f(const LgBlockFArgs& a, hipStream_t st) {
-  static bool attr_done = false;
+  static PerDeviceOnce attr_once;
   auto kfn = lg_blockf_kernel<P, NMT, RELU, FOLD>;
-  if (!attr_done) {
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS);
-    attr_done = true;
   }
   hipLaunchKernelGGL(kfn, dim3((unsigned)((a.M + 16 * NMT - 1) / (16 * NMT))), dim3(512), LF_LDS, st, a);
 }

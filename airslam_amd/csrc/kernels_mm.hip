@@ -155,11 +155,10 @@ template <class P, int CIN, int MR, bool POOL>
 static void conv_launch_t(const ConvArgs& a, hipStream_t st) {
   constexpr int TH = 4 * MR;
   constexpr int LDS = (TH + 2) * 18 * CIN * 2 + 2 * SLAB_BYTES;
-  static bool attr_done = false;
+  static PerDeviceOnce attr_once;
   auto kfn = conv3x3_kernel<P, CIN, MR, POOL>;
-  if (!attr_done) {
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
   }
   const int tiles_x = a.W / 16, tiles_y = a.H / TH;
   const int cbt = a.COUT / 64;
@@ -369,11 +368,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a, int K, int pai
 template <class P, bool TRANS>
 static void gemm_launch_t(int K, const GemmArgs& a, hipStream_t st) {
   constexpr int LDS = 2 * 32768;
-  static bool attr_done = false;
+  static PerDeviceOnce attr_once;
   auto kfn = gemm_kernel<P, TRANS>;
-  if (!attr_done) {
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
   }
   const int mb = a.M / 128;
   const int npairs = (a.cb_total + 1) / 2;      // the weight buffer is packed with an even number of feature blocks

@@ -38,7 +38,7 @@ PEAK_MFMA_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROAR
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=0.75, line_length_threshold=50.0):
+def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=0.75, line_length_threshold=50.0, gpu_nmatch=None):
     """The CPU oracle (PyTorch-CPU fp32 networks + numpy restatement of the reference's C++ post-processing) timed on
     the host cores, on a bounded sample of the same workload: `warm` untimed pairs, then the MEDIAN per-pair time of
     `n_pairs` pairs (median of >= 20 after 3 warm-ups).  s1 (the stage-1 weights) selects the PLNet step: one trunk
@@ -46,8 +46,9 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=
     from airslam_amd import synth
     from oracle import ref_chain, ref_nets, ref_post
     torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads than this only adds sync overhead at batch 1
-    base = synth.stereo_pair(h, w, 100)
-    pairs = [(np.roll(base[0], 7 * i, axis=1), np.roll(base[1], 7 * i, axis=1)) for i in range(n_pairs + warm)]   # inputs ready before the clock
+    # the SAME images rank 0 puts on the GPU (synth.stereo_batch(B, h, w, 1000)): its first n_pairs + warm pairs, ready before the clock
+    ls, rs = synth.stereo_batch(n_pairs + warm, h, w, 1000)
+    pairs = list(zip(ls, rs))
     times, nmatch = [], []
     for i, (left, right) in enumerate(pairs):
         t0 = time.perf_counter()
@@ -72,7 +73,12 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=
             times.append(time.perf_counter() - t0)
             nmatch.append(k)
     med = float(np.median(times))
-    return dict(value=1.0 / med, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+    agree = None
+    if gpu_nmatch is not None and len(gpu_nmatch) >= warm + n_pairs:     # same pairs on both sides: the match counts are a (coarse) parity signal
+        g = np.asarray(gpu_nmatch[warm:warm + n_pairs], np.float64)
+        agree = dict(cpu_matches_mean=float(np.mean(nmatch)), gpu_matches_mean_same_pairs=float(g.mean()),
+                     max_abs_count_diff=int(np.abs(g - np.asarray(nmatch)).max()))
+    return dict(value=1.0 / med, unit="pairs/s", cores=torch.get_num_threads(), kind="port", same_pairs_as_gpu=agree,
                 sample=f"median of {n_pairs} synthetic {w}x{h} stereo pairs after {warm} warm-ups ({sum(times):.1f} s), fp32 PyTorch-CPU "
                        f"oracle + numpy post-processing ({'PLNet points + lines + junctions' if s1 is not None else 'SuperPoint'} + LightGlue), "
                        f"{float(np.mean(nmatch)):.0f} matches per pair")
@@ -235,7 +241,7 @@ def side_workloads(args, rank, world, local, dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE under a launcher, else 1")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
@@ -262,6 +268,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--stage-steps", type=int, default=3, help="extra untimed steps for the per-stage table")
     args = ap.parse_args()
+    gpus_given = args.gpus is not None
+    if not gpus_given:               # `torchrun --nproc-per-node=8 bench.py` without --gpus: the launcher's world size is the answer
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
 
     # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU under torch.distributed.run, exactly what the
     # contract's own launch line does) instead of silently measuring one GPU.
@@ -280,7 +289,7 @@ def main():
     rank, world, local = adist.init_from_env(os.environ.get("AIRFE_DIST_BACKEND"))   # default: nccl (= RCCL) on GPUs
     if os.environ.get("AIRFE_ONE_DEVICE"):     # test hook: several ranks share GPU 0 (with AIRFE_DIST_BACKEND=gloo; RCCL refuses that)
         local = 0
-    if world != args.gpus:
+    if gpus_given and world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     args.collective = ({"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
                         "per_step": "one packed gather of the match lists to rank 0 (airslam_amd/dist.py)"} if world > 1 else None)
@@ -405,6 +414,9 @@ def main():
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype if args.dtype == args.matcher_dtype else f"{args.dtype} (encoder) + {args.matcher_dtype} (matcher), fp32 accumulate",
             "data": "synthetic",
+            "parity_dtype": ("fp16 storage / fp32 accumulate: the reference's own engine type (kFP16, src/super_point.cpp:97, src/light_glue.cpp:115) and the only "
+                             "2-byte type inside the north-star tolerances (descriptors 4e-4 cosine, LightGlue 0.03 of 0.05); bf16 FAILS them (2e-2 cosine, "
+                             "0.25 log-assignment: DESIGN.md §1) and is selectable with --dtype bf16 --matcher-dtype bf16 only as a non-compliant speed run"),
             "config": {"workload": f"{B} synthetic {W}x{H} uint8 stereo pairs per step per GPU, resident in HBM; "
                                    f"max_keypoints={K}, nms_radius=4, LightGlue 9 layers; seeded synthetic weights "
                                    f"(reference ONNX files are absent)",
@@ -466,7 +478,11 @@ def main():
                                  "algo_gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
                              for k, v in stages.items() if v["launches"]}
         if world == 1 and args.cpu_pairs > 0 and not track:
-            out["cpu_baseline"] = cpu_baseline(sp, lg, H, W, args.cpu_pairs, K, s1=weights.load_pack(s1_path) if plnet else None)
+            out["cpu_baseline"] = cpu_baseline(sp, lg, H, W, args.cpu_pairs, K, s1=weights.load_pack(s1_path) if plnet else None,
+                                               gpu_nmatch=nm.cpu().numpy())
+            cb = out["cpu_baseline"]["same_pairs_as_gpu"]
+            if cb and args.dtype == "fp16" and args.matcher_dtype == "fp16":       # a bench whose outputs drifted from the oracle's is not a bench
+                assert cb["max_abs_count_diff"] <= max(12, 0.15 * cb["cpu_matches_mean"]), f"GPU and CPU-oracle match counts disagree on the same pairs: {cb}"
         print(json.dumps(out))
     ctx.close()
     if world > 1:

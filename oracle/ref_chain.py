@@ -29,4 +29,4 @@ def plnet_infer(sp: dict, s1: dict, image: np.ndarray, want_junctions: bool = Fa
     lines512, jmap = ref_post.line_filter(la, sc, border, line_threshold, line_length_threshold)
     lines = ref_post.rescale_lines(lines512, ws, hs)
     junc = ref_post.junction_detector(nms, desc[0], jmap, border, ws, hs) if want_junctions else None
-    return dict(features=feats, lines=lines, junctions=junc, n_candidates=int(la.shape[0]), scores_line=sc, stage0=s0)
+    return dict(features=feats, lines=lines, junctions=junc, n_candidates=int(la.shape[0]), scores_line=sc, lines_adjusted=la, stage0=s0)

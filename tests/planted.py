@@ -67,3 +67,23 @@ def fragile_rows(scores, tol, thr=0.1):
         if abs(rval[i] - lt) <= tol or (rval[i] > lt - tol and (rgap[i] <= 2 * tol or cgap[rcol[i]] <= 2 * tol)):
             out.add(i)
     return out
+
+
+def decision_margins(scores, thr=0.1):
+    """Per row of a log-assignment matrix: how far (in score units) the nearest entry change is that flips the row's filter_matches decision —
+    min(|row max - log thr|, half the gap to the runner-up of its row, half the gap to the runner-up of its column).  A row on which the device
+    and the oracle DISAGREE must have a margin below twice the measured score error: disagreements are then explained, not exempted."""
+    s = np.where(np.isfinite(scores), scores, -1e30).astype(np.float64)
+    n0, n1 = s.shape
+    if n0 == 0 or n1 == 0:
+        return np.zeros(n0)
+    rcol = s.argmax(1)
+    rval = s[np.arange(n0), rcol]
+
+    def gap(m, axis):
+        if m.shape[axis] < 2:
+            return np.full(m.shape[1 - axis], np.inf)
+        part = np.sort(m, axis=axis)
+        return part.take(-1, axis) - part.take(-2, axis)
+    rgap, cgap = gap(s, 1), gap(s, 0)
+    return np.minimum(np.abs(rval - np.log(thr)), np.minimum(rgap, cgap[rcol]) / 2)

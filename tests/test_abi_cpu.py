@@ -10,10 +10,19 @@ import pytest
 from conftest import ROOT, gpu_available
 
 
-def _header_symbols():
-    src = open(os.path.join(ROOT, "include", "airfe.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(airfe_[a-z0-9_]+)\s*\(", src)))
+def _header_symbols(name=None):
+    """every function include/*.h declares (the boundary airfe.h + the test hooks airfe_debug.h)"""
+    out = set()
+    for h in ([name] if name else sorted(os.listdir(os.path.join(ROOT, "include")))):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        out |= set(re.findall(r"\b(airfe_[a-z0-9_]+)\s*\(", src))
+    return sorted(out)
+
+
+def test_debug_hooks_are_not_in_the_product_header():
+    assert not [n for n in _header_symbols("airfe.h") if n.startswith("airfe_debug_")]
+    assert all(n.startswith("airfe_debug_") for n in _header_symbols("airfe_debug.h"))
 
 
 def test_library_exports_every_declared_symbol(libpath):

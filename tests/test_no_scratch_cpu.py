@@ -83,7 +83,7 @@ def test_no_packed_f32_cross_half_selects():
     exactly that of the rotary epilogue (pair 1 of a lane's four (even, odd) pairs has its cos / sin in the high half of a register pair):
     `v_pk_mul_f32 .. op_sel:[1,1] op_sel_hi:[0,1]` + `v_pk_fma_f32 .. op_sel:[0,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]` — and that one element
     (lanes 48-63, the even element of pair 1) came out wrong in one 16-token tile of a launch in 0.1-4 % of the 64-pair steps: round 2's
-    "matcher race" (tools/experiments/matcher_trace.py, profiles/r03_matcher_trace.txt).  The broadcast forms (`op_sel_hi` only), thousands
+    "matcher race" (tools/experiments/matcher_trace.py, profiles/r03_matcher_trace_probe1.txt, _probe2.txt).  The broadcast forms (`op_sel_hi` only), thousands
     in the GELU / LayerNorm code, never deviated in ~10 000 traced steps.  rotate_pairs() is written in single instructions since; this
     keeps the pattern from coming back through the vectoriser anywhere else."""
     _compile_all()

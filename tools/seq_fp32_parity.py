@@ -5,8 +5,8 @@ map_builder.cc:85-86 per frame: Detect(left, right, features, lines, junctions) 
 ONNX files are absent, so the sequence is synthetic (airslam_amd.synth.stereo_sequence) and both sides run the same seeded weights (stage 1:
 the reference's real plnet_s1 weights).
 
-    python tools/seq_fp32_parity.py --oracle-only --frames 200 --cache tools/_cache/seq_oracle_200.npz     # CPU only: the oracle's outputs
-    python tools/seq_fp32_parity.py --frames 200 --cache tools/_cache/seq_oracle_200.npz --out profiles/r03_seq_fp32_parity.json   # on the GPU
+    python tools/seq_fp32_parity.py --oracle-only --frames 200 --cache /tmp/airfe_cache/seq_oracle_200.npz     # CPU only: the oracle's outputs
+    python tools/seq_fp32_parity.py --frames 200 --cache /tmp/airfe_cache/seq_oracle_200.npz --out profiles/r03_seq_fp32_parity.json   # on the GPU
 
 Without --cache the oracle runs live (about 2 s per frame on 32 host threads).  The oracle is the CHECKER here, as in tests/."""
 import argparse
