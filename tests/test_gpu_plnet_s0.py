@@ -114,7 +114,7 @@ def test_lines_end_to_end_vs_the_all_oracle_chain(seed):
     # 50 px, whether the other side has junctions within 1 px of both its endpoints at all (the top-300 junction set itself differs in a few places
     # between fp16 and fp32).  A line that is confidently a line (score margin > 0.1, length margin > 3 px) AND whose junctions both exist on the
     # other side may NOT be missing: such a loss would be a defect, not rounding at a threshold.
-    def explain(own_la, own_sc, own_lines, other_lines, other_juncs512):
+    def explain(own_la, own_sc, own_lines, other_lines, other_juncs512, other_la, other_sc):
         kept = [u for u in range(len(own_sc)) if own_sc[u] >= np.float32(0.75) and
                 np.float32((own_la[u, 2] - own_la[u, 0]) * 4) ** 2 + np.float32((own_la[u, 3] - own_la[u, 1]) * 4) ** 2 >= np.float32(2500.0)]
         assert len(kept) == len(own_lines)
@@ -128,19 +128,32 @@ def test_lines_end_to_end_vs_the_all_oracle_chain(seed):
             e = own_la[u].reshape(2, 2) * 4
             length = float(np.linalg.norm(e[1] - e[0]))
             jd = [float(np.linalg.norm(other_juncs512 - e[k][None], axis=1).min()) for k in (0, 1)]
-            out.append(dict(score_margin=float(own_sc[u]) - 0.75, length_margin=length - 50.0, junction_dist=max(jd)))
+            # the SAME candidate on the other side (both end junctions within 1 px, either orientation): its score there, or None when the other
+            # side has no such candidate at all (the proposal was not kept there / its junction pair differs)
+            oe = other_la.reshape(-1, 2, 2) * 4
+            d1 = np.maximum(np.linalg.norm(oe[:, 0] - e[0][None], axis=1), np.linalg.norm(oe[:, 1] - e[1][None], axis=1))
+            d2 = np.maximum(np.linalg.norm(oe[:, 0] - e[1][None], axis=1), np.linalg.norm(oe[:, 1] - e[0][None], axis=1))
+            dmin = np.minimum(d1, d2)
+            k = int(dmin.argmin()) if len(dmin) else -1
+            other = float(other_sc[k]) if k >= 0 and dmin[k] <= 1.0 else None
+            out.append(dict(score_margin=float(own_sc[u]) - 0.75, length_margin=length - 50.0, junction_dist=max(jd), score_on_the_other_side=other))
         return out
     s0d = ctx.debug_plnet_stage0()
     lad, scd = ctx.debug_plnet_s1(s0d)
     lost = explain(ref["lines_adjusted"], ref["scores_line"], ref_post.line_filter(ref["lines_adjusted"], ref["scores_line"], 4, 0.75, 50.0)[0],
-                   ref_post.line_filter(lad, scd, 4, 0.75, 50.0)[0], s0d["juncs_pred"] * 4)
+                   ref_post.line_filter(lad, scd, 4, 0.75, 50.0)[0], s0d["juncs_pred"] * 4, lad, scd)
     extra = explain(lad, scd, ref_post.line_filter(lad, scd, 4, 0.75, 50.0)[0],
-                    ref_post.line_filter(ref["lines_adjusted"], ref["scores_line"], 4, 0.75, 50.0)[0], ref["stage0"]["juncs_pred"] * 4)
-    confident = [d for d in lost + extra if d["score_margin"] > 0.1 and d["length_margin"] > 3.0 and d["junction_dist"] <= 1.0]
+                    ref_post.line_filter(ref["lines_adjusted"], ref["scores_line"], 4, 0.75, 50.0)[0], ref["stage0"]["juncs_pred"] * 4,
+                    ref["lines_adjusted"], ref["scores_line"])
+    # a confidently-a-line candidate that EXISTS on the other side too but was scored below the threshold there: the stage-1 score moved by more than
+    # its margin between fp16 and fp32 stage-0 tensors
+    confident = [d for d in lost + extra if d["score_margin"] > 0.1 and d["length_margin"] > 3.0 and d["junction_dist"] <= 1.0
+                 and d["score_on_the_other_side"] is not None]
     diag(f"plnet_lines_e2e_why_{seed}", oracle_only=len(lost), device_only=len(extra),
          at_the_score_threshold=sum(d["score_margin"] <= 0.1 for d in lost + extra), at_the_length_threshold=sum(d["length_margin"] <= 3.0 for d in lost + extra),
          junction_moved=sum(d["junction_dist"] > 1.0 for d in lost + extra), confident_and_missing=len(confident),
-         margins=[[round(d["score_margin"], 3), round(d["length_margin"], 1), round(d["junction_dist"], 2)] for d in lost + extra])
+         margins=[[round(d["score_margin"], 3), round(d["length_margin"], 1), round(d["junction_dist"], 2),
+                   None if d["score_on_the_other_side"] is None else round(d["score_on_the_other_side"], 3)] for d in lost + extra])
     assert len(rl) >= 100 and len(rj) >= 50
     assert abs(len(lines) - len(rl)) <= 0.03 * len(rl)
     assert hit_dev >= 0.95 and hit_ref >= 0.95
