@@ -71,6 +71,10 @@ SIGNATURES = {
                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                C.c_void_p]),
     "airfe_debug_plnet_j2l": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "airfe_assign_points_to_lines_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "airfe_match_lines_batch_dev": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "airfe_sync": (C.c_int, [C.c_void_p]),
     "airfe_superglue_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "airfe_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

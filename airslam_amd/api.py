@@ -372,6 +372,40 @@ class Context:
             juncL.shape[1], njuncL.data_ptr(), found_t.data_ptr() if found_t is not None else None, idx_t.data_ptr(), score_t.data_ptr(),
             idx_t.shape[1], nm_t.data_ptr(), self._stream(stream)), "airfe_stereo_plnet_batch_dev")
 
+    def assign_points_to_lines_batch_dev(self, lines_t, nlines_t, feat_t, n_t, row_ptr_t, pt_idx_t, pt_dist_t, total_t=None, stream=None):
+        """AssignPointsToLines (src/line_processor.cc:68-120) over B device-resident frames: lines [B][capL][4] f64 + nlines [B], feat [B][cap][259] + n [B]
+        -> CSR per frame row_ptr [B][capL + 1] i32, pt_idx [B][capE] i32, pt_dist [B][capE] f64, total [B] i32 (entries found; > capE = overflow)."""
+        b, capl = lines_t.shape[0], lines_t.shape[1]
+        self._chk(self._l.airfe_assign_points_to_lines_batch_dev(
+            self._h, lines_t.data_ptr(), nlines_t.data_ptr(), capl, feat_t.data_ptr(), n_t.data_ptr(), feat_t.shape[1], b, row_ptr_t.data_ptr(),
+            pt_idx_t.data_ptr(), pt_dist_t.data_ptr(), pt_idx_t.shape[1], total_t.data_ptr() if total_t is not None else None, self._stream(stream)),
+            "airfe_assign_points_to_lines_batch_dev")
+
+    def match_lines_batch_dev(self, row_ptr0_t, pt_idx0_t, nlines0_t, n0_t, row_ptr1_t, pt_idx1_t, nlines1_t, n1_t, matches_t, nmatch_t, line_matches_t,
+                              stereo_filter=None, feat0_t=None, feat1_t=None, stream=None):
+        """MatchLines (src/line_processor.cc:122-180) over B frame pairs from the relations above and the matcher's lists matches [B][mcap][2] / nmatch [B]
+        -> line_matches [B][capL] i32.  stereo_filter = (min_x_diff, max_x_diff, max_y_diff): the band of Frame::AddRightFeatures (src/frame.cc:147-160)."""
+        b, capl = line_matches_t.shape
+        f3 = (C.c_double * 3)(*stereo_filter) if stereo_filter is not None else None
+        self._chk(self._l.airfe_match_lines_batch_dev(
+            self._h, row_ptr0_t.data_ptr(), pt_idx0_t.data_ptr(), nlines0_t.data_ptr(), n0_t.data_ptr(), row_ptr1_t.data_ptr(), pt_idx1_t.data_ptr(),
+            nlines1_t.data_ptr(), n1_t.data_ptr(), capl, pt_idx0_t.shape[1], matches_t.data_ptr(), nmatch_t.data_ptr(), matches_t.shape[1], b,
+            C.cast(f3, C.c_void_p) if f3 is not None else None, feat0_t.data_ptr() if feat0_t is not None else None,
+            feat1_t.data_ptr() if feat1_t is not None else None, feat0_t.shape[1] if feat0_t is not None else 0, line_matches_t.data_ptr(),
+            self._stream(stream)), "airfe_match_lines_batch_dev")
+
+    def rectify_batch_dev(self, side, raw_t, rect_t, stream=None):
+        """cv::remap of Camera::UndistortImage (camera.cc:161-182) over B device-resident raw images [B][h][w] u8 -> rect_t (same shape)."""
+        b, h, w = raw_t.shape
+        self._chk(self._l.airfe_rectify_batch_dev(self._h, side, raw_t.data_ptr(), b, h, w, raw_t.stride(1), raw_t.stride(0), rect_t.data_ptr(),
+                                                  rect_t.stride(1), rect_t.stride(0), self._stream(stream)), "airfe_rectify_batch_dev")
+
+    def bow_transform_dev(self, feat_t, word_t, weight_t, stream=None):
+        """TemplatedVocabulary::transform per feature row of feat_t [..., 259] (device) -> word_t u32 / weight_t f32, one per row."""
+        n = feat_t.numel() // FEAT
+        self._chk(self._l.airfe_bow_transform_dev(self._h, feat_t.data_ptr(), n, word_t.data_ptr(), weight_t.data_ptr(), self._stream(stream)),
+                  "airfe_bow_transform_dev")
+
     def _stream(self, stream):
         # the ctx runs on its own non-blocking stream: order it after whatever torch queued on ITS streams
         if stream is None:

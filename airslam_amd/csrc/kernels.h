@@ -268,11 +268,33 @@ void launch_bow_transform(const float* feat, int ld, int off, int N, const float
 
 // ---- point <-> line association (AssignPointsToLines, src/line_processor.cc:68-120) as CSR: row_ptr [L+1], entries
 //      (point index ascending, distance) per line; counts [L] is scratch
-void launch_assign_points_to_lines(const double* lines, int L, const float* feat, int N, int* counts, int* row_ptr, int* pt_idx,
-                                   double* pt_dist, int cap, hipStream_t st);
-// MatchLines (src/line_processor.cc:122-172) on two CSR point-line relations and the point matches; scratch: bits [L][ceil(M/32)],
-// vote [L0][L1], row_loc [L0]
-void launch_match_lines(const int* row_ptr0, const int* pt_idx0, int L0, const int* row_ptr1, const int* pt_idx1, int L1, const int* matches,
-                        int nmatch, unsigned* bits0, unsigned* bits1, int* vote, int* row_loc, int* line_matches, hipStream_t st);
+// AssignPointsToLines / MatchLines over B frames (frame pairs) whose lines, features and counts live on the device (kernels_ext.hip)
+struct PlAssignArgs {
+  const double* lines = nullptr;      // [B][capL][4]
+  const int* nlines = nullptr;        // [B]
+  const float* feat = nullptr;        // [B][cap][259]
+  const int* npts = nullptr;          // [B]
+  int capL = 0, cap = 0, capE = 0;
+  int* counts = nullptr;              // scratch [B][capL]
+  int* row_ptr = nullptr;             // [B][capL + 1]
+  int* pt_idx = nullptr;              // [B][capE]
+  double* pt_dist = nullptr;          // [B][capE]
+  int* total = nullptr;               // [B] entries found (may exceed capE: overflow), or nullptr
+};
+void launch_assign_points_to_lines(const PlAssignArgs& a, int B, hipStream_t st);
+struct MlArgs {
+  const int *row_ptr0 = nullptr, *pt_idx0 = nullptr, *nlines0 = nullptr, *npts0 = nullptr;
+  const int *row_ptr1 = nullptr, *pt_idx1 = nullptr, *nlines1 = nullptr, *npts1 = nullptr;
+  const int* matches = nullptr;       // [B][mcap][2]
+  const int* nmatch = nullptr;        // [B]
+  int capL = 0, capE = 0, mcap = 0, W = 0, cap = 0;
+  int filter_on = 0;                  // Frame::AddRightFeatures' disparity band (src/frame.cc:147-160) on feat0 / feat1 [B][cap][259]
+  double min_x_diff = 0, max_x_diff = 0, max_y_diff = 0;
+  const float *feat0 = nullptr, *feat1 = nullptr;
+  unsigned *bits0 = nullptr, *bits1 = nullptr;      // scratch [B][capL][W]
+  int *vote = nullptr, *row_loc = nullptr;          // scratch [B][capL][capL], [B][capL]
+  int* line_matches = nullptr;        // [B][capL]
+};
+void launch_match_lines(const MlArgs& a, int B, hipStream_t st);
 
 }  // namespace airfe

@@ -1273,16 +1273,21 @@ __device__ __forceinline__ bool point_on_line(double lx1, double ly1, double lx2
   return side1 <= 9 || side2 <= 9 || ((side1 < line_side + side2) && (side2 < line_side + side1));
 }
 
-// one wave per line; pass 0 counts, pass 1 writes at row_ptr[line] (ballot + prefix keeps ascending point order)
+// one wave per line; pass 0 counts, pass 1 writes at row_ptr[line] (ballot + prefix keeps ascending point order).  blockIdx.y = frame: every
+// array is `frame stride` apart, line / point counts are read from the device (the PLNet batch entries leave them there)
 template <bool WRITE>
-__global__ __launch_bounds__(256) void pl_assign_kernel(const double* __restrict__ lines, int L, const float* __restrict__ feat,
-                                                        int N, int* __restrict__ counts, const int* __restrict__ row_ptr,
-                                                        int* __restrict__ pt_idx, double* __restrict__ pt_dist, int cap) {
+__global__ __launch_bounds__(256) void pl_assign_kernel(PlAssignArgs a) {
+  const int b = blockIdx.y;
+  const int L = min(a.nlines[b], a.capL), N = min(a.npts[b], a.cap);
   const int line = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (line >= L) return;
+  const double* lines = a.lines + (size_t)b * a.capL * 4;
+  const float* feat = a.feat + (size_t)b * a.cap * 259;
   const double lx1 = lines[line * 4 + 0], ly1 = lines[line * 4 + 1], lx2 = lines[line * 4 + 2], ly2 = lines[line * 4 + 3];
   int cnt = 0;
-  const int base = WRITE ? row_ptr[line] : 0;
+  const int base = WRITE ? a.row_ptr[(size_t)b * (a.capL + 1) + line] : 0;
+  int* pt_idx = a.pt_idx + (size_t)b * a.capE;
+  double* pt_dist = a.pt_dist + (size_t)b * a.capE;
   for (int j0 = 0; j0 < N; j0 += 64) {
     const int j = j0 + lane;
     float d = 0.f;
@@ -1291,17 +1296,21 @@ __global__ __launch_bounds__(256) void pl_assign_kernel(const double* __restrict
     const unsigned long long m = __ballot(hit);
     if (WRITE && hit) {
       const int pos = base + cnt + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < cap) { pt_idx[pos] = j; pt_dist[pos] = (double)d; }
+      if (pos < a.capE) { pt_idx[pos] = j; pt_dist[pos] = (double)d; }
     }
     cnt += __popcll(m);
   }
-  if (!WRITE && lane == 0) counts[line] = cnt;
+  if (!WRITE && lane == 0) a.counts[(size_t)b * a.capL + line] = cnt;
 }
 
-// exclusive scan of counts[L] -> row_ptr[L+1] (L is a few hundred: one workgroup, serial per 256-chunk carry)
-__global__ __launch_bounds__(256) void pl_scan_kernel(const int* __restrict__ counts, int L, int* __restrict__ row_ptr) {
+// exclusive scan of counts[L] -> row_ptr[L+1] per frame (L is a few hundred: one workgroup per frame, serial per 256-chunk carry)
+__global__ __launch_bounds__(256) void pl_scan_kernel(PlAssignArgs a) {
   __shared__ int buf[256];
   __shared__ int carry;
+  const int b = blockIdx.x;
+  const int L = min(a.nlines[b], a.capL);
+  const int* counts = a.counts + (size_t)b * a.capL;
+  int* row_ptr = a.row_ptr + (size_t)b * (a.capL + 1);
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   for (int i0 = 0; i0 < L; i0 += 256) {
@@ -1320,35 +1329,50 @@ __global__ __launch_bounds__(256) void pl_scan_kernel(const int* __restrict__ co
     if (threadIdx.x == 255) carry += buf[255];
     __syncthreads();
   }
-  if (threadIdx.x == 0) row_ptr[L] = carry;
+  if (threadIdx.x == 0) {
+    row_ptr[L] = carry;
+    if (a.total) a.total[b] = carry;
+  }
 }
 
-void launch_assign_points_to_lines(const double* lines, int L, const float* feat, int N, int* counts, int* row_ptr, int* pt_idx,
-                                   double* pt_dist, int cap, hipStream_t st) {
-  if (L <= 0) return;
-  const dim3 grid((L + 3) / 4);
-  hipLaunchKernelGGL(pl_assign_kernel<false>, grid, dim3(256), 0, st, lines, L, feat, N, counts, row_ptr, pt_idx, pt_dist, cap);
-  hipLaunchKernelGGL(pl_scan_kernel, dim3(1), dim3(256), 0, st, counts, L, row_ptr);
-  hipLaunchKernelGGL(pl_assign_kernel<true>, grid, dim3(256), 0, st, lines, L, feat, N, counts, row_ptr, pt_idx, pt_dist, cap);
+void launch_assign_points_to_lines(const PlAssignArgs& a, int B, hipStream_t st) {
+  if (B <= 0 || a.capL <= 0) return;
+  const dim3 grid((a.capL + 3) / 4, B);
+  hipLaunchKernelGGL(pl_assign_kernel<false>, grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(pl_scan_kernel, dim3(B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(pl_assign_kernel<true>, grid, dim3(256), 0, st, a);
 }
 
 // =============================================================================== MatchLines (src/line_processor.cc:122-172)
 // The voting matrix M[l0][l1] = number of point matches (q, t) with q on line l0 of frame 0 and t on line l1 of frame 1 is an
 // integer "GEMM" over the matches: one bit per (line, match) says whether the match's point lies on the line, and M is the
 // popcount of the AND of two bit rows.  All index work: exact.
-__global__ __launch_bounds__(256) void ml_bits_kernel(const int* __restrict__ row_ptr, const int* __restrict__ pt_idx, const int* __restrict__ matches,
-                                                      int side, int nmatch, int W, unsigned* __restrict__ bits) {
-  const int l = blockIdx.x, b = row_ptr[l], e = row_ptr[l + 1];
-  for (int w = threadIdx.x; w < W; w += blockDim.x) {
+__global__ __launch_bounds__(256) void ml_bits_kernel(MlArgs a, int side) {
+  const int b = blockIdx.y, l = blockIdx.x;
+  const int L = min((side ? a.nlines1 : a.nlines0)[b], a.capL);
+  if (l >= L) return;
+  const int* row_ptr = (side ? a.row_ptr1 : a.row_ptr0) + (size_t)b * (a.capL + 1);
+  const int* pt_idx = (side ? a.pt_idx1 : a.pt_idx0) + (size_t)b * a.capE;
+  const int* matches = a.matches + (size_t)b * a.mcap * 2;
+  const int nmatch = min(a.nmatch[b], a.mcap);
+  unsigned* bits = (side ? a.bits1 : a.bits0) + ((size_t)b * a.capL + l) * a.W;
+  const int rb = row_ptr[l], re = row_ptr[l + 1];
+  for (int w = threadIdx.x; w < a.W; w += blockDim.x) {
     unsigned word = 0;
     for (int k = 0; k < 32; ++k) {
       const int m = w * 32 + k;
       if (m >= nmatch) break;
+      if (a.filter_on) {           // Frame::AddRightFeatures, src/frame.cc:147-160: stereo matches outside the camera's disparity band are dropped first
+        const float* f0 = a.feat0 + ((size_t)b * a.cap + matches[2 * m]) * 259;
+        const float* f1 = a.feat1 + ((size_t)b * a.cap + matches[2 * m + 1]) * 259;
+        const double dx = (double)fabsf(f0[1] - f1[1]), dy = (double)fabsf(f0[2] - f1[2]);
+        if (!(dx > a.min_x_diff && dx < a.max_x_diff && dy <= a.max_y_diff)) continue;
+      }
       const int p = matches[2 * m + side];
-      for (int r = b; r < e; ++r)
+      for (int r = rb; r < re; ++r)
         if (pt_idx[r] == p) { word |= 1u << k; break; }        // a std::map key occurs once per line
     }
-    bits[(size_t)l * W + w] = word;
+    bits[w] = word;
   }
 }
 
@@ -1369,49 +1393,55 @@ __device__ __forceinline__ void ml_first_max(int& v, int& i, int* sv, int* si) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void ml_vote_rowmax_kernel(const unsigned* __restrict__ bits0, const unsigned* __restrict__ bits1, int L1, int W,
-                                                             int* __restrict__ vote, int* __restrict__ row_loc, int* __restrict__ line_matches) {
+__global__ __launch_bounds__(256) void ml_vote_rowmax_kernel(MlArgs a) {
   __shared__ int sv[256], si[256];
-  const int l0 = blockIdx.x;
-  const unsigned* r0 = bits0 + (size_t)l0 * W;
+  const int b = blockIdx.y, l0 = blockIdx.x;
+  const int L0 = min(a.nlines0[b], a.capL), L1 = min(a.nlines1[b], a.capL);
+  if (l0 >= L0) return;
+  const unsigned* r0 = a.bits0 + ((size_t)b * a.capL + l0) * a.W;
+  int* vote = a.vote + (size_t)b * a.capL * a.capL;
   int bv = -1, bi = 0x7fffffff;
   for (int l1 = threadIdx.x; l1 < L1; l1 += blockDim.x) {
-    const unsigned* r1 = bits1 + (size_t)l1 * W;
+    const unsigned* r1 = a.bits1 + ((size_t)b * a.capL + l1) * a.W;
     int v = 0;
-    for (int w = 0; w < W; ++w) v += __popc(r0[w] & r1[w]);
-    vote[(size_t)l0 * L1 + l1] = v;
+    for (int w = 0; w < a.W; ++w) v += __popc(r0[w] & r1[w]);
+    vote[(size_t)l0 * a.capL + l1] = v;
     if (v > bv) { bv = v; bi = l1; }                             // l1 ascends within a thread: strict > keeps the first
   }
   ml_first_max(bv, bi, sv, si);
-  if (threadIdx.x == 0) { row_loc[l0] = bi; line_matches[l0] = -1; }
+  if (threadIdx.x == 0) { a.row_loc[(size_t)b * a.capL + l0] = bi; a.line_matches[(size_t)b * a.capL + l0] = -1; }
 }
 
-__global__ __launch_bounds__(256) void ml_colmax_kernel(const int* __restrict__ vote, const int* __restrict__ row_loc, const int* __restrict__ row_ptr0,
-                                                        const int* __restrict__ row_ptr1, int L0, int L1, int* __restrict__ line_matches) {
+__global__ __launch_bounds__(256) void ml_colmax_kernel(MlArgs a) {
   __shared__ int sv[256], si[256];
-  const int j = blockIdx.x;
+  const int b = blockIdx.y, j = blockIdx.x;
+  const int L0 = min(a.nlines0[b], a.capL), L1 = min(a.nlines1[b], a.capL);
+  if (j >= L1 || L0 == 0 || a.npts0[b] == 0 || a.npts1[b] == 0) return;          // src/line_processor.cc:132
+  const int* vote = a.vote + (size_t)b * a.capL * a.capL;
+  const int* row_ptr0 = a.row_ptr0 + (size_t)b * (a.capL + 1);
+  const int* row_ptr1 = a.row_ptr1 + (size_t)b * (a.capL + 1);
   int bv = -1, bi = 0x7fffffff;
   for (int i = threadIdx.x; i < L0; i += blockDim.x) {
-    const int v = vote[(size_t)i * L1 + j];
+    const int v = vote[(size_t)i * a.capL + j];
     if (v > bv) { bv = v; bi = i; }
   }
   ml_first_max(bv, bi, sv, si);
   if (threadIdx.x == 0) {
-    if (bv < 2 || row_loc[bi] != j) return;                      // :171
+    if (bv < 2 || a.row_loc[(size_t)b * a.capL + bi] != j) return;          // :171
     const int n0 = row_ptr0[bi + 1] - row_ptr0[bi], n1 = row_ptr1[j + 1] - row_ptr1[j];
     const float score = __fdiv_rn((float)(bv * bv), (float)min(n0, n1));        // :174 float / size_t -> float division
     if ((double)score < 0.8) return;                             // :175
-    line_matches[bi] = j;                                        // distinct j cannot name the same row: row_loc[bi] == j
+    a.line_matches[(size_t)b * a.capL + bi] = j;                 // distinct j cannot name the same row: row_loc[bi] == j
   }
 }
 
-void launch_match_lines(const int* row_ptr0, const int* pt_idx0, int L0, const int* row_ptr1, const int* pt_idx1, int L1, const int* matches,
-                        int nmatch, unsigned* bits0, unsigned* bits1, int* vote, int* row_loc, int* line_matches, hipStream_t st) {
-  const int W = (nmatch + 31) / 32 > 0 ? (nmatch + 31) / 32 : 1;
-  hipLaunchKernelGGL(ml_bits_kernel, dim3(L0), dim3(256), 0, st, row_ptr0, pt_idx0, matches, 0, nmatch, W, bits0);
-  hipLaunchKernelGGL(ml_bits_kernel, dim3(L1), dim3(256), 0, st, row_ptr1, pt_idx1, matches, 1, nmatch, W, bits1);
-  hipLaunchKernelGGL(ml_vote_rowmax_kernel, dim3(L0), dim3(256), 0, st, bits0, bits1, L1, W, vote, row_loc, line_matches);
-  hipLaunchKernelGGL(ml_colmax_kernel, dim3(L1), dim3(256), 0, st, vote, row_loc, row_ptr0, row_ptr1, L0, L1, line_matches);
+void launch_match_lines(const MlArgs& a, int B, hipStream_t st) {
+  if (B <= 0 || a.capL <= 0) return;
+  const dim3 grid(a.capL, B);
+  hipLaunchKernelGGL(ml_bits_kernel, grid, dim3(256), 0, st, a, 0);
+  hipLaunchKernelGGL(ml_bits_kernel, grid, dim3(256), 0, st, a, 1);
+  hipLaunchKernelGGL(ml_vote_rowmax_kernel, grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ml_colmax_kernel, grid, dim3(256), 0, st, a);
 }
 
 }  // namespace airfe

@@ -261,10 +261,12 @@ def main():
                     help="plnet (default): PLNet::infer on both images (points + line branch + stage 1 + line filter, junctions on the left), the "
                          "reference's keyframe step; superpoint: the point-only step")
     ap.add_argument("--plnet-host", action="store_true", help="PLNet + matcher through the batch-1 HOST API instead (PCIe and one sync per call included)")
-    ap.add_argument("--workload", default="stereo", choices=["stereo", "track", "loop"],
+    ap.add_argument("--workload", default="stereo", choices=["stereo", "track", "loop", "frontend"],
                     help="track: the NORMAL-frame step of the VO loop (map_builder.cc:94-101: Detect(left, features) = PLNet points + lines on the new "
                          "frame, then MatchingPoints(last_keyframe, frame)); loop: matcher only, replaying a map file's feature records (loop closure, "
-                         "map_refiner.cc:213-230)")
+                         "map_refiner.cc:213-230); frontend: the WHOLE per-keyframe front end, device-resident — rectify both raw images (camera.cc:161-182), "
+                         "the stereo step, AssignPointsToLines on both frames + MatchLines with the stereo band (frame.cc:125,147-184), BoW words of the "
+                         "left features (bow/database.cc:57-89)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--stage-steps", type=int, default=3, help="extra untimed steps for the per-stage table")
     args = ap.parse_args()
@@ -331,6 +333,25 @@ def main():
     def points_step():
         ctx.stereo_batch_dev(L, R, fl, fr, nl, nr, idx, sc, nm, stream=sh)
 
+    frontend = args.workload == "frontend"
+    if frontend:
+        if not plnet:
+            raise SystemExit("--workload frontend runs the PLNet detector (lines are what the extra stages work on)")
+        # rectification maps of a mildly distorted stereo rig (the construction stays reference code: camera.cc:60-75); raw = the synthetic images
+        yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+        r2 = ((xx - W / 2) ** 2 + (yy - H / 2) ** 2) / float(W * W)
+        for side, sgn in ((0, 1.0), (1, -1.0)):
+            ctx.set_rectify_maps(side, (xx + sgn * 0.7 + (xx - W / 2) * 0.02 * r2).astype(np.float32), (yy + 0.3 * sgn + (yy - H / 2) * 0.02 * r2).astype(np.float32))
+        ctx.bow_load(weights.synthetic_vocabulary(1234))
+        rawL, rawR = L, R
+        L, R = torch.empty_like(rawL), torch.empty_like(rawR)
+        CE = 16 * CL
+        rel = [dict(rp=torch.zeros((B, CL + 1), dtype=torch.int32, device=dev), pi=torch.zeros((B, CE), dtype=torch.int32, device=dev),
+                    pd=torch.zeros((B, CE), dtype=torch.float64, device=dev), tot=torch.zeros((B,), dtype=torch.int32, device=dev)) for _ in range(2)]
+        line_matches = torch.zeros((B, CL), dtype=torch.int32, device=dev)
+        words = torch.zeros((B, K), dtype=torch.int32, device=dev); wweights = torch.zeros((B, K), device=dev)
+        band = (1.0, 200.0, 5.0)           # Camera::MinXDiff / MaxXDiff / MaxYDiff of a rig like EuRoC's (frame.cc:143-145)
+
     track = args.workload == "track"
     if track:
         # the last keyframe's features (map_builder.cc:100 `_last_keyframe_feature->GetAllFeatures()`): the left images, detected once;
@@ -350,6 +371,15 @@ def main():
             else:
                 ctx.detect_batch_dev(R, fr, nr, stream=sh)
             ctx.match_lightglue_batch_dev(fl, nl, fr, nr, idx, sc, nm, stream=sh)
+        elif frontend:
+            ctx.rectify_batch_dev(0, rawL, L, stream=sh)
+            ctx.rectify_batch_dev(1, rawR, R, stream=sh)
+            ctx.stereo_plnet_batch_dev(L, R, fl, fr, nl, nr, lines, nlines, junc, njunc, idx, sc, nm, found, stream=sh)
+            ctx.assign_points_to_lines_batch_dev(lines[:B], nlines[:B], fl, nl, rel[0]["rp"], rel[0]["pi"], rel[0]["pd"], rel[0]["tot"], stream=sh)
+            ctx.assign_points_to_lines_batch_dev(lines[B:], nlines[B:], fr, nr, rel[1]["rp"], rel[1]["pi"], rel[1]["pd"], rel[1]["tot"], stream=sh)
+            ctx.match_lines_batch_dev(rel[0]["rp"], rel[0]["pi"], nlines[:B], nl, rel[1]["rp"], rel[1]["pi"], nlines[B:], nr, idx, nm, line_matches,
+                                      stereo_filter=band, feat0_t=fl, feat1_t=fr, stream=sh)
+            ctx.bow_transform_dev(fl, words, wweights, stream=sh)
         elif plnet:
             ctx.stereo_plnet_batch_dev(L, R, fl, fr, nl, nr, lines, nlines, junc, njunc, idx, sc, nm, found, stream=sh)
         else:
@@ -390,7 +420,7 @@ def main():
         ctx.profile(False)
     barrier()
     points_only = None
-    if plnet and not track:            # the point-only step (Detect(left, right, features) with use_superpoint = 1) on the same context and inputs
+    if plnet and not track and not frontend:            # the point-only step (Detect(left, right, features) with use_superpoint = 1) on the same context and inputs
         for _ in range(args.warmup):
             points_step()
         barrier()
@@ -439,7 +469,17 @@ def main():
             if track:
                 out["config"]["lines_mean"] = float(nlines[B:].float().mean())
                 del out["config"]["junctions_mean_left"]
-        if plnet and not track:
+        if frontend:
+            lm = line_matches.cpu().numpy(); nlh = nlines.cpu().numpy()
+            if (rel[0]["tot"].cpu().numpy() > CE).any() or (rel[1]["tot"].cpu().numpy() > CE).any():
+                raise SystemExit("bench: point-line relation capacity overflow")
+            out["metric"] = ("keyframe front ends/sec, device-resident end to end: rectify x2 + 2x PLNet (points, lines, junctions on the left) + LightGlue + "
+                             "AssignPointsToLines x2 + MatchLines (stereo band) + BoW words of the left features")
+            out["unit"] = "stereo keyframes/s"
+            out["config"]["workload"] += "; + rectification of both raw images, point-line association, stereo line matching, BoW quantisation (synthetic vocabulary, 10^4 words)"
+            out["config"]["points_on_lines_mean_left"] = float(rel[0]["tot"].float().mean())
+            out["config"]["stereo_line_matches_mean"] = float(np.mean([(lm[b, :nlh[b]] >= 0).sum() for b in range(B)]))
+        if plnet and not track and not frontend:
             out["config"]["points_only_pairs_per_s"] = points_only
             out["config"]["points_only_note"] = ("the point-only step (2x detect + LightGlue, airfe_stereo_batch_dev: `--detector superpoint`) timed on the "
                                                  "same context and inputs over the same number of steps")
@@ -477,7 +517,7 @@ def main():
                                  "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] else None,
                                  "algo_gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
                              for k, v in stages.items() if v["launches"]}
-        if world == 1 and args.cpu_pairs > 0 and not track:
+        if world == 1 and args.cpu_pairs > 0 and not track and not frontend:
             out["cpu_baseline"] = cpu_baseline(sp, lg, H, W, args.cpu_pairs, K, s1=weights.load_pack(s1_path) if plnet else None,
                                                gpu_nmatch=nm.cpu().numpy())
             cb = out["cpu_baseline"]["same_pairs_as_gpu"]

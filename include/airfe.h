@@ -183,6 +183,22 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* ctx, const uint8_t* d_left, const ui
                                  size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, double* d_lines,
                                  int capL, int* d_nlines, float* d_juncL, int capJ, int* d_njuncL, int* d_found, int32_t* d_idx,
                                  float* d_score, int mcap, int* d_nmatch, void* stream);
+/* NEW (no reference counterpart as a batch; the per-frame functions are AssignPointsToLines / MatchLines, src/line_processor.cc:68-180, called
+ * right behind Detect / MatchingPoints at src/frame.cc:125,177,184): the same two functions over B device-resident frames, reading the outputs of
+ * airfe_detect_plnet_batch_dev / airfe_stereo_plnet_batch_dev / airfe_match_lightglue_batch_dev IN PLACE.  Per frame the results are the bits
+ * airfe_assign_points_to_lines / airfe_match_lines return for it.
+ *   relation as CSR per frame: d_row_ptr [B][capL + 1], d_pt_idx [B][capE], d_pt_dist [B][capE] doubles (ascending point index per line, like the
+ *   reference's std::map<int, double>); d_total (may be NULL) [B] = entries found: a value above capE is an overflow (entries beyond capE are dropped) */
+int airfe_assign_points_to_lines_batch_dev(airfe_ctx* ctx, const double* d_lines, const int* d_nlines, int capL, const float* d_feat, const int* d_n,
+                                           int cap, int B, int32_t* d_row_ptr, int32_t* d_pt_idx, double* d_pt_dist, int capE, int* d_total,
+                                           void* stream);
+/*   d_matches [B][mcap][2] + d_nmatch [B]: the matcher's (idx0, idx1) lists; filter3 (HOST, may be NULL) = {min_x_diff, max_x_diff, max_y_diff}: the
+ *   disparity band Frame::AddRightFeatures applies to the stereo matches before MatchLines (src/frame.cc:147-160), evaluated on d_feat0 / d_feat1
+ *   [B][cap][259]; d_line_matches [B][capL]: index of the matched line of frame 1 or -1, for the first d_nlines0[b] lines of every frame */
+int airfe_match_lines_batch_dev(airfe_ctx* ctx, const int32_t* d_row_ptr0, const int32_t* d_pt_idx0, const int* d_nlines0, const int* d_n0,
+                                const int32_t* d_row_ptr1, const int32_t* d_pt_idx1, const int* d_nlines1, const int* d_n1, int capL, int capE,
+                                const int32_t* d_matches, const int* d_nmatch, int mcap, int B, const double* filter3, const float* d_feat0,
+                                const float* d_feat1, int cap, int32_t* d_line_matches, void* stream);
 /* synchronises the context's own stream; also reports (once) a Sinkhorn rendezvous time-out of an earlier SuperGlue call */
 int airfe_sync(airfe_ctx* ctx);
 /* SuperGlue's error channel for callers of the asynchronous *_dev entries who synchronise their OWN stream: synchronises `stream` (the one the

@@ -70,3 +70,13 @@ def test_gpus_2_launches_two_ranks_itself(monkeypatch):
     d = _run("--gpus", "2", "--pairs", "4", "--steps", "2", "--warmup", "1", "--cpu-pairs", "0", "--no-profile")
     assert d["n_gpus"] == 2 and d["collective"]["ranks"] == 2 and d["collective"]["backend"] == "gloo"
     assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_frontend_workload_line():
+    """the whole per-keyframe front end, device-resident: rectify -> PLNet x2 -> LightGlue -> AssignPointsToLines x2 -> MatchLines -> BoW"""
+    d = _run("--workload", "frontend", "--pairs", "8", "--steps", "3", "--warmup", "1")
+    assert d["unit"] == "stereo keyframes/s" and d["n_gpus"] == 1 and d["value"] > 0 and "AssignPointsToLines" in d["metric"]
+    assert d["config"]["matches_mean"] > 30 and d["config"]["lines_mean"] >= 30
+    assert d["config"]["points_on_lines_mean_left"] > 50 and d["config"]["stereo_line_matches_mean"] >= 3
+    for st in ("rectify", "line_assoc", "bow", "plnet_stage1", "lg_gemm"):
+        assert st in d["stages"], st
