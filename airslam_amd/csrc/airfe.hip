@@ -176,6 +176,12 @@ struct airfe_ctx {
   int mprec = 1;                 // matcher storage type (cfg.matcher_precision)
   int pack_prec = 0;             // storage type make_linear packs for (set by each load_* before it packs)
   int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
+  int lgb_tokens = 0;            // AIRFE_LGB_TOKENS: forces the fused block's tokens per workgroup (32 / 64 / 112 / 128)
+  // batch-1 host entries: ONE pinned host block and contiguous device blocks, so that a call is one H2D and one D2H (the reference's
+  // BufferManager does a cudaMalloc + one synchronous memcpy per binding and call: 3rdparty/tensorrtbuffer/include/buffers.h:237-417)
+  uint8_t* pin = nullptr;        // hipHostMalloc'ed
+  size_t pin_bytes = 0;
+  uint8_t *io_in = nullptr, *io_out = nullptr;   // device: [n0 n1 .. | feat0 | feat1] and [nmatch .. | idx | score]
   bool trace_overflow = false;   // a trace slot was dropped (table full): trace_finish fails instead of mis-numbering launches
   size_t arena_rows = 0;         // token rows of the matcher arena, slack included (alloc_matcher_arena)
   int Dmax = 1;                  // images the detector arena holds: 2 x Bmax when a stereo step detects left and right as one batch
@@ -189,7 +195,9 @@ struct airfe_ctx {
   int Lmax = 1;                  // images the line-path arena holds (= Dmax)
   bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
   int gemm_small_max = 4096, gemm8_min = 16000, gemmr_min = 8192, gemmr_wgs = 256;   // GemmArgs::small_max / g8_min / gr_min / gr_wgs (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M, AIRFE_GEMMR_MIN_M, AIRFE_GEMMR_WGS)
-  int block_min = 3200;          // tokens from which the fused LightGlue block beats its four launches (AIRFE_BLOCK_MIN_M)
+  int block_min = 0;             // tokens from which the fused LightGlue block is used (AIRFE_BLOCK_MIN_M).  Round 4: with 32- / 64-token passes for small
+                                 // token counts the fused kernel wins at EVERY size (profiles/r04_lg_small_batch_sweep.txt: 1 pair 0.70 vs 0.78 ms, 4 pairs 0.75 vs 1.20);
+                                 // with 112- / 128-token passes only (rounds 1-3) the four separate launches were quicker below 3200 tokens
   bool qkv_pair = true;          // q|k and v of a layer in one streaming launch (AIRFE_QKV_PAIR=0: two launches)
   int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
   int sg_kenc_gemm = -1;         // AIRFE_SG_KENC_GEMM=0/1: SuperGlue keypoint encoder's large layers as scalar loops / GEMMs (default: by token count)
@@ -1142,6 +1150,11 @@ void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, co
   a.bo = out.b; a.b1 = f0.b; a.gamma = g; a.beta = b; a.b2 = f3.b; a.M = M;
   // one workgroup per CU and pass: ceil(M / T) workgroups run in rounds of 256, a round lasts ~T — take the T with the smaller product
   a.tokens_per_wg = ((M + 111) / 112 + 255) / 256 * 112 < ((M + 127) / 128 + 255) / 256 * 128 ? 112 : 128;
+  // small token counts (the batch-1 calls of the SLAM loop: 800 tokens): 112-token passes would occupy 8 of the 256 CUs — 32- / 64-token passes
+  // spread the same rows over 4x / 2x as many workgroups as long as that is still ONE round
+  if (M <= 256 * 32) a.tokens_per_wg = 32;
+  else if (M <= 256 * 64) a.tokens_per_wg = 64;
+  if (c->lgb_tokens > 0) a.tokens_per_wg = c->lgb_tokens;          // AIRFE_LGB_TOKENS (measurement switch)
   double fl = 2.0 * M * (256.0 * 256 + 512.0 * 512 + 512.0 * 256), by = (double)M * (512 + 512 + 1024 + 512 + 1024) + 917504.0;
   if (nqk && nv) {            // the next attention layer's projections ride along (kernels_lgblockf.hip, FOLD)
     a.nqk_w = nqk->w; a.nqk_b = nqk->b; a.nqk_n = nqk->N; a.nv_w = nv->w; a.nv_b = nv->b;
@@ -1211,9 +1224,9 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   trace(c, st, "rc", 0, "prep", c->rot_cos, (size_t)M * 32, 512);
   trace(c, st, "rs", 0, "prep", c->rot_sin, (size_t)M * 32, 512);
   TRACE_HALT;
-  // The fused block (kernels_lgblockf.hip) streams 0.9 MB of weights per 128-token workgroup whatever the batch, so below 3200
-  // tokens (4 pairs of 400) the four separate launches are quicker: 1.82 vs 1.85 ms per step at 3 pairs, 2.01 vs 1.98 at 4,
-  // 2.65 vs 2.45 at 8 (profiles/r01d_small_batch_sweeps.txt).
+  // The fused block (kernels_lgblockf.hip) streams 0.9 MB of weights per workgroup whatever the batch: with 112- / 128-token passes only, the four
+  // separate launches were quicker below 3200 tokens (profiles/r01d_small_batch_sweeps.txt); with 32- / 64-token passes for small token counts
+  // (lg_blockf() picks them) the fused form wins everywhere (profiles/r04_lg_small_batch_sweep.txt) and block_min is 0.
   const bool fused_block = c->fuse_lg_block == 1 || (c->fuse_lg_block < 0 && Mg >= c->block_min);
   // With the fused block the projections of the NEXT attention layer are computed inside it (FOLD): only the very first q | k | v
   // projection is a launch of its own.
@@ -1482,12 +1495,27 @@ int ensure_stage_img(airfe_ctx* c, size_t bytes) { return ensure_block(c, c->st_
 
 // host image -> c->st_img with the SAME row pitch: exactly (h - 1) * stride + w bytes are read (a cv::Mat ROI / numpy view has no
 // bytes behind its last row's w-th pixel that are ours to read)
+// the pinned host block (grows by replacement; the stream is idle whenever a host entry starts: they all end with a synchronisation)
+int ensure_pin(airfe_ctx* c, size_t bytes) {
+  if (bytes <= c->pin_bytes) return 0;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  uint8_t* p = nullptr;
+  HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&p), bytes, hipHostMallocDefault));
+  if (c->pin) (void)hipHostFree(c->pin);
+  c->pin = p;
+  c->pin_bytes = bytes;
+  return 0;
+}
+
 int upload_image(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride) {
   if (!gray || h < 1 || w < 1) return fail(c, "empty image");     // plnet.cpp:247
   if (stride < w) return fail(c, "image stride smaller than its width");
   const size_t bytes = (size_t)(h - 1) * stride + w;
   if (ensure_stage_img(c, (size_t)h * stride)) return 1;
-  HIPCHK(c, hipMemcpyAsync(c->st_img, gray, bytes, hipMemcpyHostToDevice, c->stream));
+  // through the pinned block: a pageable hipMemcpyAsync is staged by the runtime in chunks, synchronously (measured: 2.4x the time)
+  if (ensure_pin(c, bytes)) return 1;
+  memcpy(c->pin, gray, bytes);
+  HIPCHK(c, hipMemcpyAsync(c->st_img, c->pin, bytes, hipMemcpyHostToDevice, c->stream));
   return 0;
 }
 
@@ -1557,6 +1585,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (getenv("AIRFE_QKV_PAIR")) c->qkv_pair = atoi(getenv("AIRFE_QKV_PAIR")) != 0;
   if (getenv("AIRFE_GEMMR_WGS")) c->gemmr_wgs = atoi(getenv("AIRFE_GEMMR_WGS"));
   if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
+  if (getenv("AIRFE_LGB_TOKENS")) c->lgb_tokens = atoi(getenv("AIRFE_LGB_TOKENS"));
   if (getenv("AIRFE_SG_KENC_GEMM")) c->sg_kenc_gemm = atoi(getenv("AIRFE_SG_KENC_GEMM")) != 0;
   if (getenv("AIRFE_FOLD_QKV")) c->fold_qkv = atoi(getenv("AIRFE_FOLD_QKV")) != 0;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1581,15 +1610,20 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (!rc && cfg->plnet_s1_pack) rc = load_plnet_s1(c, cfg->plnet_s1_pack);
   if (!rc) {
     const size_t capf = (size_t)c->Np * AIRFE_FEAT_DIM;
-    c->st_feat0 = dalloc<float>(c, capf);
-    c->st_feat1 = dalloc<float>(c, capf);
-    c->st_score = dalloc<float>(c, c->Np);
-    c->st_idx = dalloc<int32_t>(c, (size_t)c->Np * 2);
-    c->st_n0 = dalloc<int>(c, 1);
-    c->st_n1 = dalloc<int>(c, 1);
-    c->st_nm = dalloc<int>(c, 1);
-    if (!c->st_feat0 || !c->st_feat1 || !c->st_score || !c->st_idx || !c->st_n0 || !c->st_n1 || !c->st_nm)
-      rc = fail(c, "device allocation failed (staging)");
+    c->io_in = dalloc<uint8_t>(c, 64 + 2 * capf * 4);
+    c->io_out = dalloc<uint8_t>(c, 64 + (size_t)c->Np * 12);
+    if (!c->io_in || !c->io_out) rc = fail(c, "device allocation failed (staging)");
+    else {
+      c->st_n0 = reinterpret_cast<int*>(c->io_in);
+      c->st_n1 = c->st_n0 + 1;
+      c->st_feat0 = reinterpret_cast<float*>(c->io_in + 64);
+      c->st_feat1 = c->st_feat0 + capf;
+      c->st_nm = reinterpret_cast<int*>(c->io_out);
+      c->st_idx = reinterpret_cast<int32_t*>(c->io_out + 64);
+      c->st_score = reinterpret_cast<float*>(c->io_out + 64 + (size_t)c->Np * 8);
+      if (hipHostMalloc(reinterpret_cast<void**>(&c->pin), 64 + 2 * capf * 4, hipHostMallocDefault) != hipSuccess) rc = fail(c, "hipHostMalloc failed (staging)");
+      else c->pin_bytes = 64 + 2 * capf * 4;
+    }
   }
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(c, "device error during weight upload");
   if (rc) {
@@ -1606,6 +1640,7 @@ void airfe_destroy(airfe_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   (void)hipDeviceSynchronize();
   for (void* p : c->allocs) (void)hipFree(p);
+  if (c->pin) (void)hipHostFree(c->pin);
   for (auto& m : c->marks) { (void)hipEventDestroy(m.a); (void)hipEventDestroy(m.b); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1717,10 +1752,13 @@ int airfe_detect_points(airfe_ctx* c, const uint8_t* gray, int h, int w, int str
   if (cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
   if (upload_image(c, gray, h, w, stride)) return 1;
   if (detect_dev(c, c->st_img, 1, h, w, stride, (size_t)h * stride, c->st_feat0, c->Np, c->st_n0, c->stream)) return 1;
-  int nn = 0;
-  HIPCHK(c, hipMemcpyAsync(&nn, c->st_n0, 4, hipMemcpyDeviceToHost, c->stream));
+  // one D2H of [count | max_keypoints feature rows] into the pinned block (st_n0 and st_feat0 are one device block), rows copied out after the sync
+  const size_t out_bytes = 64 + (size_t)c->cfg.max_keypoints * AIRFE_FEAT_DIM * 4;
+  if (ensure_pin(c, out_bytes)) return 1;
+  HIPCHK(c, hipMemcpyAsync(c->pin, c->io_in, out_bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (nn > 0) HIPCHK(c, hipMemcpy(feat, c->st_feat0, (size_t)nn * AIRFE_FEAT_DIM * 4, hipMemcpyDeviceToHost));
+  const int nn = std::min(*reinterpret_cast<const int*>(c->pin), c->cfg.max_keypoints);
+  if (nn > 0) memcpy(feat, c->pin + 64, (size_t)nn * AIRFE_FEAT_DIM * 4);
   *n = nn;
   return 0;
 }
@@ -1863,21 +1901,28 @@ static int lg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n
   AIRFE_ENTER(c);
   if (n0 < 1 || n1 < 1) { if (nmatch) *nmatch = 0; return 0; }   // point_matcher.cc:53-55
   if (n0 > c->cfg.max_keypoints || n1 > c->cfg.max_keypoints) return fail(c, "keypoint count exceeds max_keypoints");
-  HIPCHK(c, hipMemcpyAsync(c->st_feat0, f0, (size_t)n0 * 258 * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->st_feat1, f1, (size_t)n1 * 258 * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->st_n0, &n0, 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->st_n1, &n1, 4, hipMemcpyHostToDevice, c->stream));
-  if (lightglue_dev(c, c->st_feat0, c->st_n0, c->st_feat1, c->st_n1, 1, c->Np, 258, 0, 0, c->st_idx, c->st_score, c->Np,
+  // ONE H2D: [n0 n1 | n0 rows of f0 | n1 rows of f1] assembled in the pinned block (f1 sits right behind f0's rows on the device too)
+  const size_t b0 = (size_t)n0 * 258 * 4, b1 = (size_t)n1 * 258 * 4;
+  if (ensure_pin(c, 64 + b0 + b1)) return 1;
+  reinterpret_cast<int*>(c->pin)[0] = n0;
+  reinterpret_cast<int*>(c->pin)[1] = n1;
+  memcpy(c->pin + 64, f0, b0);
+  memcpy(c->pin + 64 + b0, f1, b1);
+  HIPCHK(c, hipMemcpyAsync(c->io_in, c->pin, 64 + b0 + b1, hipMemcpyHostToDevice, c->stream));
+  const float* d_f1 = c->st_feat0 + (size_t)n0 * 258;
+  if (lightglue_dev(c, c->st_feat0, c->st_n0, d_f1, c->st_n1, 1, c->Np, 258, 0, 0, c->st_idx, c->st_score, c->Np,
                     c->st_nm, scores_full ? c->st_scores_full : nullptr, c->stream))
     return 1;
-  int nm = 0;
-  HIPCHK(c, hipMemcpyAsync(&nm, c->st_nm, 4, hipMemcpyDeviceToHost, c->stream));
+  // ONE D2H: [nmatch | idx | score] (a few KB whatever the count), the rows copied out after the synchronisation
+  const size_t ob = 64 + (size_t)c->Np * 12;
+  HIPCHK(c, hipMemcpyAsync(c->pin, c->io_out, ob, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  int nm = *reinterpret_cast<const int*>(c->pin);
   if (idx && score) {
     nm = std::min(nm, cap);
     if (nm > 0) {
-      HIPCHK(c, hipMemcpy(idx, c->st_idx, (size_t)nm * 8, hipMemcpyDeviceToHost));
-      HIPCHK(c, hipMemcpy(score, c->st_score, (size_t)nm * 4, hipMemcpyDeviceToHost));
+      memcpy(idx, c->pin + 64, (size_t)nm * 8);
+      memcpy(score, c->pin + 64 + (size_t)c->Np * 8, (size_t)nm * 4);
     }
   }
   if (nmatch) *nmatch = nm;

@@ -466,31 +466,30 @@ static void launch_f(const LgBlockFArgs& a, hipStream_t st) {
 // Tokens per workgroup: one workgroup fits a CU (136 KiB of LDS), so a launch is ceil(M / tokens) workgroups in rounds of 256.
 // 51200 tokens (64 pairs) in 128-token passes are 400 workgroups = a full round + a 56 % round; in 112-token passes 458 = two rounds
 // that are each 1/8 shorter.  a.tokens_per_wg = 112 needs M rows + 111 of slack behind the last pass (the matcher arena has it).
+template <class P, bool RELU, int FOLD>
+static void launch_nmt(const LgBlockFArgs& a, hipStream_t st) {
+  switch (a.tokens_per_wg) {
+    case 32: launch_f<P, 2, RELU, FOLD>(a, st); break;      // small token counts (batch 1: 800 tokens = 25 workgroups instead of 7)
+    case 64: launch_f<P, 4, RELU, FOLD>(a, st); break;
+    case 112: launch_f<P, 7, RELU, FOLD>(a, st); break;
+    default: launch_f<P, 8, RELU, FOLD>(a, st); break;
+  }
+}
+
 void launch_lg_blockf(int prec, const LgBlockFArgs& a, hipStream_t st) {
   if (a.relu) {
-    if (a.tokens_per_wg == 112) {
-      if (prec == 1) launch_f<PF16, 7, true>(a, st); else launch_f<PBF16, 7, true>(a, st);
-    } else {
-      if (prec == 1) launch_f<PF16, 8, true>(a, st); else launch_f<PBF16, 8, true>(a, st);
-    }
+    if (prec == 1) launch_nmt<PF16, true, 0>(a, st); else launch_nmt<PBF16, true, 0>(a, st);
     return;
   }
   if (a.nqk_w) {                                       // with the next layer's projections folded in
-    const bool t7 = a.tokens_per_wg == 112;
     if (a.nqk_n == 512) {
-      if (prec == 1) { if (t7) launch_f<PF16, 7, false, 2>(a, st); else launch_f<PF16, 8, false, 2>(a, st); }
-      else { if (t7) launch_f<PBF16, 7, false, 2>(a, st); else launch_f<PBF16, 8, false, 2>(a, st); }
+      if (prec == 1) launch_nmt<PF16, false, 2>(a, st); else launch_nmt<PBF16, false, 2>(a, st);
     } else {
-      if (prec == 1) { if (t7) launch_f<PF16, 7, false, 1>(a, st); else launch_f<PF16, 8, false, 1>(a, st); }
-      else { if (t7) launch_f<PBF16, 7, false, 1>(a, st); else launch_f<PBF16, 8, false, 1>(a, st); }
+      if (prec == 1) launch_nmt<PF16, false, 1>(a, st); else launch_nmt<PBF16, false, 1>(a, st);
     }
     return;
   }
-  if (a.tokens_per_wg == 112) {
-    if (prec == 1) launch_f<PF16, 7, false>(a, st); else launch_f<PBF16, 7, false>(a, st);
-  } else {
-    if (prec == 1) launch_f<PF16, 8, false>(a, st); else launch_f<PBF16, 8, false>(a, st);
-  }
+  if (prec == 1) launch_nmt<PF16, false, 0>(a, st); else launch_nmt<PBF16, false, 0>(a, st);
 }
 
 }  // namespace airfe
