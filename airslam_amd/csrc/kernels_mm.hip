@@ -10,6 +10,8 @@
 //     (j = lane&15, g = lane>>4) then holds 8 contiguous output features of pixel j per tile pair,
 //     i.e. the epilogue (bias, ReLU, 2x2 max-pool, rotary, residual, ...) works on whole feature
 //     runs of one pixel and stores 16-byte vectors.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -183,7 +185,9 @@ void launch_conv3x3(int prec, const ConvArgs& a, hipStream_t st) {
     return;
   }
   if (a.CIN == 128 && (a.COUT % 128) == 0 && a.relu && (a.H % 8) == 0 && (a.W % 16) == 0) {
-    launch_conv128r(prec, a, st);      // persistent kernel, filters resident in registers (kernels_conv128r.hip)
+    static const int ksplit = getenv("AIRFE_CONV128K") ? atoi(getenv("AIRFE_CONV128K")) : 0;      // A/B switch: the k-split form (kernels_conv128k.hip)
+    if (ksplit) launch_conv128k(prec, a, st);
+    else launch_conv128r(prec, a, st);      // persistent kernel, filters resident in registers (kernels_conv128r.hip)
     return;
   }
   if (prec == 1) conv_launch_p<PF16>(a, st); else conv_launch_p<PBF16>(a, st);
