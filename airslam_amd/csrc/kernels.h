@@ -94,7 +94,6 @@ void launch_conv3x3(int prec, const ConvArgs& a, hipStream_t st);
 // persistent weight-stationary variant for CIN == COUT == 64 (launch_conv3x3 dispatches to it)
 void launch_conv64r(int prec, const ConvArgs& a, hipStream_t st);
 void launch_conv128r(int prec, const ConvArgs& a, hipStream_t st);
-void launch_conv128k(int prec, const ConvArgs& a, hipStream_t st);      // k-split form (kernels_conv128k.hip)
 // persistent tap-streamed variant for CIN == 128, COUT % 128 == 0 (launch_conv3x3 dispatches to it)
 
 // cv::resize(INTER_LINEAR, 8-bit fixed point) + /255 -> fp32 [B][RH+2][RW+2] interior

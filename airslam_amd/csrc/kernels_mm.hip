@@ -185,9 +185,7 @@ void launch_conv3x3(int prec, const ConvArgs& a, hipStream_t st) {
     return;
   }
   if (a.CIN == 128 && (a.COUT % 128) == 0 && a.relu && (a.H % 8) == 0 && (a.W % 16) == 0) {
-    static const int ksplit = getenv("AIRFE_CONV128K") ? atoi(getenv("AIRFE_CONV128K")) : 0;      // A/B switch: the k-split form (kernels_conv128k.hip)
-    if (ksplit) launch_conv128k(prec, a, st);
-    else launch_conv128r(prec, a, st);      // persistent kernel, filters resident in registers (kernels_conv128r.hip)
+    launch_conv128r(prec, a, st);      // persistent kernel, filters resident in registers (kernels_conv128r.hip)
     return;
   }
   if (prec == 1) conv_launch_p<PF16>(a, st); else conv_launch_p<PBF16>(a, st);
