@@ -2160,10 +2160,15 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
   AIRFE_ENTER(c);
   if (nlines) *nlines = 0;
   if (njunc) *njunc = 0;
-  if (airfe_detect_points(c, gray, h, w, stride, feat, cap, n)) return 1;      // point branch: plnet.cpp:560
-  if (!s0 && !c->has_s0) return 0;            // no line branch available: points only (the shim says so, loudly, at build())
+  const bool lines_on = (s0 || c->has_s0);
+  if (!lines_on) return airfe_detect_points(c, gray, h, w, stride, feat, cap, n);   // no line branch available: points only (the shim says so, loudly, at build())
   if (!c->has_s1) return fail(c, "PLNet stage-1 weights were not loaded (cfg.plnet_s1_pack)");
+  if (cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
+  // Everything is QUEUED before the first synchronisation (round 4; before: the point branch was synchronised and copied out first): image up,
+  // point branch (plnet.cpp:560), line branch + tail, then [count | feature rows] and the three line / junction counts come back in one wait.
   hipStream_t st = c->stream;
+  if (upload_image(c, gray, h, w, stride)) return 1;
+  if (detect_dev(c, c->st_img, 1, h, w, stride, (size_t)h * stride, c->st_feat0, c->Np, c->st_n0, st)) return 1;
   if (s0) {
     if (upload_stage0(c, s0, st)) return 1;
   } else if (line_branch_dev(c, st, 0, 1, false)) {   // the stage-0 line branch on the device: nothing crosses PCIe (the reference moves
@@ -2174,18 +2179,34 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
   if (line_tail_dev(c, 0, 1, s0 ? c->s0_loi : nullptr, h, w, c->d_lines, LINE_CAP, nl_d, nl_d + c->Lmax, c->junc_feat, JUNC_CAP, nj_d, njf_d,
                     want_junctions ? 1 : 0, st))
     return 1;
-  int nl = 0, nj = 0, njf = 0;
-  HIPCHK(c, hipMemcpyAsync(&nl, nl_d, 4, hipMemcpyDeviceToHost, st));
+  const size_t fbytes = 64 + (size_t)c->cfg.max_keypoints * AIRFE_FEAT_DIM * 4;
+  if (ensure_pin(c, fbytes + 64)) return 1;
+  int* cnt = reinterpret_cast<int*>(c->pin + fbytes);            // pinned: {lines kept, junctions, junctions found}
+  cnt[0] = cnt[1] = cnt[2] = 0;
+  HIPCHK(c, hipMemcpyAsync(c->pin, c->io_in, fbytes, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(cnt, nl_d, 4, hipMemcpyDeviceToHost, st));
   if (want_junctions) {
-    HIPCHK(c, hipMemcpyAsync(&nj, nj_d, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(&njf, njf_d, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(cnt + 1, nj_d, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(cnt + 2, njf_d, 4, hipMemcpyDeviceToHost, st));
   }
   HIPCHK(c, hipStreamSynchronize(st));
+  const int nn = std::min(*reinterpret_cast<const int*>(c->pin), c->cfg.max_keypoints);
+  if (nn > 0) memcpy(feat, c->pin + 64, (size_t)nn * AIRFE_FEAT_DIM * 4);
+  *n = nn;
+  const int nl = cnt[0], nj = cnt[1], njf = cnt[2];
   // the reference has no junction limit (junction_detector, plnet.cpp:425-448): more than the arena holds is an ERROR, not a shorter list
   if (njf > JUNC_CAP) return fail(c, "detect_plnet: more junctions than the device arena holds (JUNC_CAP)");
   if (nl > capL || nj > capJ) return fail(c, "detect_plnet: lines / junctions do not fit the caller's buffers (capL, capJ)");
-  if (nl > 0 && lines) HIPCHK(c, hipMemcpy(lines, c->d_lines, (size_t)nl * 32, hipMemcpyDeviceToHost));
-  if (nj > 0 && junc) HIPCHK(c, hipMemcpy(junc, c->junc_feat, (size_t)nj * AIRFE_FEAT_DIM * 4, hipMemcpyDeviceToHost));
+  // second (and last) round trip: the line and junction rows, whose counts are known only now, through the pinned block
+  const size_t lb = (nl > 0 && lines) ? (size_t)nl * 32 : 0, jb = (nj > 0 && junc) ? (size_t)nj * AIRFE_FEAT_DIM * 4 : 0;
+  if (lb + jb) {
+    if (ensure_pin(c, lb + jb)) return 1;
+    if (lb) HIPCHK(c, hipMemcpyAsync(c->pin, c->d_lines, lb, hipMemcpyDeviceToHost, st));
+    if (jb) HIPCHK(c, hipMemcpyAsync(c->pin + lb, c->junc_feat, jb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (lb) memcpy(lines, c->pin, lb);
+    if (jb) memcpy(junc, c->pin + lb, jb);
+  }
   if (nlines) *nlines = nl;
   if (njunc) *njunc = nj;
   return 0;

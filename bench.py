@@ -84,6 +84,63 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=
                        f"{float(np.mean(nmatch)):.0f} matches per pair")
 
 
+def latency_b1(args, rank, world, local, dev):
+    """--workload b1: what ONE stereo keyframe costs through the reference-shaped batch-1 host API — the regime AirSLAM's feature thread runs in
+    (map_builder.cc:83-109: Detect(left, right, features, lines, junctions) + MatchingPoints, one pair at a time, host buffers in and out, one
+    synchronisation per call).  Prints p50 / p99 / mean of the pair and of its three calls; `value` = 1000 / p50 (pairs/s of a single stream)."""
+    from airslam_amd import api, synth, weights
+    H, W, K = args.height, args.width, args.max_keypoints
+    root = os.path.dirname(os.path.abspath(__file__))
+    sg = args.matcher == "superglue"
+    mw = weights.synthetic_superglue(1234) if sg else weights.synthetic_lightglue(1234)
+    plnet = args.detector == "plnet"
+    ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234) if plnet else weights.synthetic_superpoint(1234),
+                      plnet_s1=os.path.join(root, "tests", "golden", "plnet_s1.airfe") if plnet else None,
+                      device=local, precision=1 if args.dtype == "fp16" else 0, matcher_precision=1 if args.matcher_dtype == "fp16" else 0,
+                      max_batch=2, enc_chunk=2, max_keypoints=K, image_width=W, image_height=H, matcher=1 if sg else 0,
+                      **(dict(superglue=mw) if sg else dict(lightglue=mw)))
+    det, pm = api.FeatureDetector(ctx), api.PointMatcher(ctx, W, H, 1 if sg else 0)
+    pairs = [synth.stereo_pair(H, W, 1000 + i) for i in range(8)]
+    t_l, t_r, t_m, nmatch, nlines = [], [], [], [], []
+    for i in range(args.warmup + args.steps):
+        left, right = pairs[i % len(pairs)]
+        acc = []
+        t0 = time.perf_counter()
+        if plnet:
+            ok, fl, jl = det.DetectLines(left, None, acc, junction_detection=True)       # left: points + lines + junctions
+            t1 = time.perf_counter()
+            ok2, fr, _ = det.DetectLines(right, None, [], junction_detection=False)      # right: no junctions (feature_detector.cc:100-101)
+        else:
+            ok, fl = det.Detect(left)
+            t1 = time.perf_counter()
+            ok2, fr = det.Detect(right)
+        t2 = time.perf_counter()
+        n, _ = pm.MatchingPoints(fl, fr)
+        t3 = time.perf_counter()
+        if i >= args.warmup:
+            t_l.append(t1 - t0); t_r.append(t2 - t1); t_m.append(t3 - t2); nmatch.append(n); nlines.append(len(acc))
+    pair = np.array(t_l) + np.array(t_r) + np.array(t_m)
+
+    def pct(a):
+        a = np.asarray(a) * 1e3
+        return {"p50": float(np.percentile(a, 50)), "p99": float(np.percentile(a, 99)), "mean": float(a.mean())}
+
+    out = {"metric": "batch-1 stereo keyframe latency through the host API (" + ("PLNet points + lines, junctions on the left" if plnet else "SuperPoint")
+                     + " x2 + " + ("SuperGlue" if sg else "LightGlue") + "; host images in, host matrices out, PCIe and one synchronisation per call included)",
+           "value": 1e3 / pct(pair)["p50"], "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": pct(pair)["p50"],
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": args.dtype if args.dtype == args.matcher_dtype else f"{args.dtype} (encoder) + {args.matcher_dtype} (matcher), fp32 accumulate",
+           "data": "synthetic",
+           "latency_ms": {"pair": pct(pair), "detect_left": pct(t_l), "detect_right": pct(t_r), "match": pct(t_m)},
+           "config": {"workload": f"ONE synthetic {W}x{H} stereo pair per step through the reference-shaped host API (airslam_amd.api.FeatureDetector / PointMatcher "
+                                  f"over the C ABI's batch-1 entries), max_keypoints={K}; seeded synthetic weights (reference ONNX files are absent)",
+                      "matches_mean": float(np.mean(nmatch)), "lines_mean_left": float(np.mean(nlines)), "detector": args.detector, "matcher": args.matcher},
+           "roofline": None, "cpu_baseline": None, "collective": None}
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+
+
 def side_workloads(args, rank, world, local, dev):
     """The other configurations of BASELINE.json behind the same contract (one JSON line, K timed steps between barriers):
     SuperGlue as the matcher (configs[4]; SuperPoint detector), PLNet through the batch-1 host API (--plnet-host), the matcher-only loop-closure
@@ -261,10 +318,11 @@ def main():
                     help="plnet (default): PLNet::infer on both images (points + line branch + stage 1 + line filter, junctions on the left), the "
                          "reference's keyframe step; superpoint: the point-only step")
     ap.add_argument("--plnet-host", action="store_true", help="PLNet + matcher through the batch-1 HOST API instead (PCIe and one sync per call included)")
-    ap.add_argument("--workload", default="stereo", choices=["stereo", "track", "loop", "frontend"],
+    ap.add_argument("--workload", default="stereo", choices=["stereo", "track", "loop", "frontend", "b1"],
                     help="track: the NORMAL-frame step of the VO loop (map_builder.cc:94-101: Detect(left, features) = PLNet points + lines on the new "
                          "frame, then MatchingPoints(last_keyframe, frame)); loop: matcher only, replaying a map file's feature records (loop closure, "
-                         "map_refiner.cc:213-230); frontend: the WHOLE per-keyframe front end, device-resident — rectify both raw images (camera.cc:161-182), "
+                         "map_refiner.cc:213-230); b1: LATENCY of one stereo keyframe through the batch-1 host API, as the SLAM loop calls it (map_builder.cc:83-109): "
+                         "p50 / p99 over --steps pairs, PLNet + LightGlue, host images in, host matrices out; frontend: the WHOLE per-keyframe front end, device-resident — rectify both raw images (camera.cc:161-182), "
                          "the stereo step, AssignPointsToLines on both frames + MatchLines with the stereo band (frame.cc:125,147-184), BoW words of the "
                          "left features (bow/database.cc:57-89)")
     ap.add_argument("--no-profile", action="store_true")
@@ -303,6 +361,8 @@ def main():
 
     if args.workload == "track" and (args.plnet_host or args.matcher == "superglue"):
         raise SystemExit("--workload track runs the device-resident PLNet / SuperPoint + LightGlue path")
+    if args.workload == "b1":
+        return latency_b1(args, rank, world, local, dev)
     if args.plnet_host or args.matcher == "superglue" or args.workload == "loop":
         return side_workloads(args, rank, world, local, dev)
 

@@ -80,3 +80,12 @@ def test_frontend_workload_line():
     assert d["config"]["points_on_lines_mean_left"] > 50 and d["config"]["stereo_line_matches_mean"] >= 3
     for st in ("rectify", "line_assoc", "bow", "plnet_stage1", "lg_gemm"):
         assert st in d["stages"], st
+
+
+def test_b1_latency_line():
+    """--workload b1: one stereo keyframe at a time through the batch-1 host API, latency percentiles"""
+    d = _run("--workload", "b1", "--steps", "20", "--warmup", "3")
+    assert d["unit"] == "pairs/s" and d["steps"] == 20 and "latency" in d["metric"]
+    lat = d["latency_ms"]
+    assert lat["pair"]["p50"] > 0 and lat["pair"]["p99"] >= lat["pair"]["p50"] and abs(d["value"] - 1e3 / lat["pair"]["p50"]) < 1e-6 * d["value"]
+    assert d["config"]["matches_mean"] > 50 and d["config"]["lines_mean_left"] >= 50
