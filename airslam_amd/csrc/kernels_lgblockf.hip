@@ -23,6 +23,16 @@
 // run at 75-80 % of the MFMA rate (a pure MFMA stream: 85 % with two waves per SIMD); the GELU phase is VALU-bound (see lf_gelu2).
 #include "common.h"
 #include "kernels.h"
+#ifdef LF_TIMING   // per-phase wall-clock timers of wave 0 (tools/lf_timing.py; a measurement build, never the shipped library)
+__device__ unsigned long long lf_dbg[16];
+#define LF_T(i) { const long long now_ = wall_clock64(); if (L.wave == 0 && L.lane == 0) atomicAdd(&lf_dbg[i], (unsigned long long)(now_ - tp_)); tp_ = now_; }
+extern "C" void airfe_dbg_lf(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(lf_dbg), z, sizeof(z)); }
+  else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lf_dbg), 16 * sizeof(unsigned long long));
+}
+#else
+#define LF_T(i)
+#endif
 
 namespace airfe {
 
@@ -117,8 +127,59 @@ struct LfNoHook { __device__ __forceinline__ void operator()(int) const {} };
 template <class P, int NT, int NMT, class Hook = LfNoHook, bool SWAP = false>
 __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (&cur)[NT][2], const char* w0, const char* w1, int nslab,
                                        const char* n0, const char* n1, const char* breg, int pitch, int l15, int g, Hook hook = Hook()) {
-  typename P::vec8 nxt[NT][2];
   const char* brow = breg + l15 * pitch;
+  if constexpr (NMT <= 4) {
+    // Small token tiles (32 / 64 tokens per workgroup: 1-16 pairs per call).  A slab feeds only 4 NT NMT MFMAs (~0.1-0.25 us of matrix pipe) but
+    // the phase timers say a slab STEP takes 0.6-0.85 us (profiles/r04_lf_blockf_phase_timers.txt): one slab ahead, the GEMMs wait an L2 round trip
+    // per slab.  Here ALL of a GEMM's remaining slabs are requested up front (nslab is 4 or 8: the trip is unrolled completely so that every
+    // fragment has its own registers and the compiler's wait counts stay exact — a runtime loop over a register ring made it wait for everything
+    // at the back edge: r04 probe 1 measured no gain from that form), then consumed in order.  Same MFMAs in the same order: bit-identical.
+    typename P::vec8 ring[8][NT][2];
+    auto fetch = [&](int k, typename P::vec8 (&dst)[NT][2]) {
+      const char* p0 = k == nslab ? n0 : w0 + k * SLAB_BYTES;
+      const char* p1 = k == nslab ? n1 : w1 + k * SLAB_BYTES;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        dst[t][0] = lf_ldg<P>(p0 + t * 2048);
+        dst[t][1] = lf_ldg<P>(p1 + t * 2048);
+      }
+    };
+    constexpr int AHEAD = (NT == 4 ? 4 : 8) / (NMT > 2 ? 2 : 1);   // 32-token tiles: 4 slabs of the 64-feature GEMM (128 registers) / all 8 of a 32-feature one in flight; 64-token tiles: half (registers)
+#pragma unroll
+    for (int d = 1; d <= AHEAD; ++d)
+      if (d <= nslab) fetch(d, ring[d - 1]);
+    __builtin_amdgcn_sched_barrier(0);      // keep the requests up here (hipcc sinks loads towards their first use)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < nslab) {
+        hook(s);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int boff = (((s * 8 + h * 4 + g) ^ l15) << 4);
+          typename P::vec8 bf[NMT];
+#pragma unroll
+          for (int j = 0; j < NMT; ++j) bf[j] = lds_frag<P>(brow, boff + j * 16 * pitch);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < NMT; ++j) {
+              if constexpr (SWAP) acc[t][j] = P::mfma(bf[j], cur[t][h], acc[t][j]);
+              else acc[t][j] = P::mfma(cur[t][h], bf[j], acc[t][j]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          cur[t][0] = ring[s % AHEAD][t][0];
+          cur[t][1] = ring[s % AHEAD][t][1];
+        }
+        if (s + 1 + AHEAD <= nslab) fetch(s + 1 + AHEAD, ring[s % AHEAD]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    return;
+  }
+  typename P::vec8 nxt[NT][2];
 #pragma unroll 1
   for (int s = 0; s < nslab; ++s) {
     const bool last = s + 1 == nslab;
@@ -173,6 +234,10 @@ struct LfLane {                       // per-lane constants of the whole kernel
 template <class P, int NMT, bool RELU, int FOLD>
 __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const LfLane& L, int row0) {
   const int lane = L.lane, wave = L.wave, l15 = L.l15, g = L.g, wf = L.wf, cb = L.cb, tp = L.tp, fo0 = L.fo0, fo1 = L.fo1;
+#ifdef LF_TIMING
+  long long tp_ = wall_clock64();
+  if (wave == 0 && lane == 0) atomicAdd(&lf_dbg[15], 1ull);
+#endif
   typename P::vec8 c2[2][2], c4[4][2];                            // A fragments in flight: 32-feature GEMMs / the 64-feature one
   lf_first<P, 2>(c2, L.wob + fo0, L.wob + fo1);
   f32x4 bo2[2], b14[4];                                           // biases of the first two GEMMs: fetched with the attn tile
@@ -182,6 +247,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   for (int t = 0; t < 4; ++t) b14[t] = *reinterpret_cast<const f32x4*>(a.b1 + wf * 64 + (t >> 1) * 32 + g * 8 + (t & 1) * 4);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  LF_T(0)
 
   // ---- msg = Wo attn + bo -> R1
   {
@@ -205,6 +271,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
     }
   }
   __syncthreads();                                                // msg complete, attn dead
+  LF_T(1)
 
   // ---- h = W1 cat(x, msg) + b1: the msg half first; the x tile's DMA into R0 is issued behind the msg half's LAST weight
   // prefetch — vmcnt retires in order, so issued any earlier every wait for weights would also wait for the HBM-latency DMA
@@ -215,8 +282,10 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
     for (int m = 0; m < NMT; ++m) h[t][m] = b14[t];
   lf_mma<P, 4, NMT>(h, c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R1, 512, l15, g,
                     [&](int s) { if (s == 3) lf_stage_rows(a.xb, row0, NMT, LF_R0, wave, lane); });
+  LF_T(2)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  LF_T(3)
   lf_mma<P, 4, NMT>(h, c4, L.w1b + fo0, L.w1b + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R0, 512, l15, g);
 
   // LayerNorm scale / shift of this wave's 64 features: fetched now, used after the next barrier
@@ -249,7 +318,9 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
       if (g == 0) st[wf * 128 + m * 16 + l15] = make_float2(s1, s2);
     }
   }
+  LF_T(4)
   __syncthreads();                                                // sums visible; x and msg tiles dead
+  LF_T(5)
   // ffn.3's first weight fragments are fetched now, the fp32 residual rows half way: their latency hides under the GELU arithmetic
   const int co = cb * 64 + tp * 32 + g * 8;
   float* xr0 = a.x32 + (size_t)(row0 + l15) * 256 + co;
@@ -320,7 +391,9 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
     }
   }
   if constexpr (!EARLY_W2) lf_first<P, 2>(c2, L.w2b + fo0, L.w2b + fo1);
+  LF_T(6)
   __syncthreads();
+  LF_T(7)
 
   // ---- x += W2 h + b2
   constexpr bool KEEP_X = FOLD != 0 && NMT < 8;                   // 128-token passes have no registers to spare: they re-read their x rows
@@ -346,6 +419,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
       *reinterpret_cast<uint4*>(a.xb + row * 256 + co) = xp;
     }
   }
+  LF_T(8)
   if constexpr (FOLD != 0) {
     __syncthreads();                                              // every wave is done with the h tile
     {
@@ -359,6 +433,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
       }
     }
     __syncthreads();                                              // the new x tile [16 NMT][256] is complete in R0
+    LF_T(9)
     const int H = a.H, Np = a.Np;
     // q / k units: 32 features each, (cb', tp') = (id >> 1, id & 1); this wave takes id = wf (and wf + 8 of the 512-feature q | k)
     constexpr int NQ = FOLD == 2 ? 2 : 1;
@@ -400,6 +475,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
         *reinterpret_cast<uint4*>(ob + (((size_t)sq * H + hh) * Np + nn) * 64 + d) = pack8<P>(v);
       }
     }
+    LF_T(10)
     // V unit id = wf, transposed: lane (l15 = feature column, g) holds 4 consecutive tokens per accumulator
     {
       float bt[2];
@@ -424,6 +500,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
         }
       }
     }
+    LF_T(11)
   }
 }
 
