@@ -1279,28 +1279,31 @@ template <bool WRITE>
 __global__ __launch_bounds__(256) void pl_assign_kernel(PlAssignArgs a) {
   const int b = blockIdx.y;
   const int L = min(a.nlines[b], a.capL), N = min(a.npts[b], a.cap);
-  const int line = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (line >= L) return;
+  const int lane = threadIdx.x & 63;
   const double* lines = a.lines + (size_t)b * a.capL * 4;
   const float* feat = a.feat + (size_t)b * a.cap * 259;
-  const double lx1 = lines[line * 4 + 0], ly1 = lines[line * 4 + 1], lx2 = lines[line * 4 + 2], ly2 = lines[line * 4 + 3];
-  int cnt = 0;
-  const int base = WRITE ? a.row_ptr[(size_t)b * (a.capL + 1) + line] : 0;
   int* pt_idx = a.pt_idx + (size_t)b * a.capE;
   double* pt_dist = a.pt_dist + (size_t)b * a.capE;
-  for (int j0 = 0; j0 < N; j0 += 64) {
-    const int j = j0 + lane;
-    float d = 0.f;
-    bool hit = false;
-    if (j < N) hit = point_on_line(lx1, ly1, lx2, ly2, (double)feat[(size_t)j * 259 + 1], (double)feat[(size_t)j * 259 + 2], d);
-    const unsigned long long m = __ballot(hit);
-    if (WRITE && hit) {
-      const int pos = base + cnt + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < a.capE) { pt_idx[pos] = j; pt_dist[pos] = (double)d; }
+  // a frame's lines are dealt out over the grid's x dimension (the line COUNT lives on the device: the grid is sized for ~256 lines per frame and
+  // walks further with its stride — a capL-sized grid of mostly empty workgroups cost more than the work)
+  for (int line = blockIdx.x * 4 + (threadIdx.x >> 6); line < L; line += gridDim.x * 4) {
+    const double lx1 = lines[line * 4 + 0], ly1 = lines[line * 4 + 1], lx2 = lines[line * 4 + 2], ly2 = lines[line * 4 + 3];
+    int cnt = 0;
+    const int base = WRITE ? a.row_ptr[(size_t)b * (a.capL + 1) + line] : 0;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+      const int j = j0 + lane;
+      float d = 0.f;
+      bool hit = false;
+      if (j < N) hit = point_on_line(lx1, ly1, lx2, ly2, (double)feat[(size_t)j * 259 + 1], (double)feat[(size_t)j * 259 + 2], d);
+      const unsigned long long m = __ballot(hit);
+      if (WRITE && hit) {
+        const int pos = base + cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < a.capE) { pt_idx[pos] = j; pt_dist[pos] = (double)d; }
+      }
+      cnt += __popcll(m);
     }
-    cnt += __popcll(m);
+    if (!WRITE && lane == 0) a.counts[(size_t)b * a.capL + line] = cnt;
   }
-  if (!WRITE && lane == 0) a.counts[(size_t)b * a.capL + line] = cnt;
 }
 
 // exclusive scan of counts[L] -> row_ptr[L+1] per frame (L is a few hundred: one workgroup per frame, serial per 256-chunk carry)
@@ -1337,7 +1340,7 @@ __global__ __launch_bounds__(256) void pl_scan_kernel(PlAssignArgs a) {
 
 void launch_assign_points_to_lines(const PlAssignArgs& a, int B, hipStream_t st) {
   if (B <= 0 || a.capL <= 0) return;
-  const dim3 grid((a.capL + 3) / 4, B);
+  const dim3 grid(std::min((a.capL + 3) / 4, 64), B);
   hipLaunchKernelGGL(pl_assign_kernel<false>, grid, dim3(256), 0, st, a);
   hipLaunchKernelGGL(pl_scan_kernel, dim3(B), dim3(256), 0, st, a);
   hipLaunchKernelGGL(pl_assign_kernel<true>, grid, dim3(256), 0, st, a);
@@ -1348,16 +1351,17 @@ void launch_assign_points_to_lines(const PlAssignArgs& a, int B, hipStream_t st)
 // integer "GEMM" over the matches: one bit per (line, match) says whether the match's point lies on the line, and M is the
 // popcount of the AND of two bit rows.  All index work: exact.
 __global__ __launch_bounds__(256) void ml_bits_kernel(MlArgs a, int side) {
-  const int b = blockIdx.y, l = blockIdx.x;
+  const int b = blockIdx.y;
   const int L = min((side ? a.nlines1 : a.nlines0)[b], a.capL);
-  if (l >= L) return;
   const int* row_ptr = (side ? a.row_ptr1 : a.row_ptr0) + (size_t)b * (a.capL + 1);
   const int* pt_idx = (side ? a.pt_idx1 : a.pt_idx0) + (size_t)b * a.capE;
   const int* matches = a.matches + (size_t)b * a.mcap * 2;
   const int nmatch = min(a.nmatch[b], a.mcap);
+  // one WAVE per line (4 lines per workgroup), a lane per 32-match word; lines dealt out with the grid's stride
+  for (int l = blockIdx.x * 4 + (threadIdx.x >> 6); l < L; l += gridDim.x * 4) {
   unsigned* bits = (side ? a.bits1 : a.bits0) + ((size_t)b * a.capL + l) * a.W;
   const int rb = row_ptr[l], re = row_ptr[l + 1];
-  for (int w = threadIdx.x; w < a.W; w += blockDim.x) {
+  for (int w = threadIdx.x & 63; w < a.W; w += 64) {
     unsigned word = 0;
     for (int k = 0; k < 32; ++k) {
       const int m = w * 32 + k;
@@ -1373,6 +1377,7 @@ __global__ __launch_bounds__(256) void ml_bits_kernel(MlArgs a, int side) {
         if (pt_idx[r] == p) { word |= 1u << k; break; }        // a std::map key occurs once per line
     }
     bits[w] = word;
+  }
   }
 }
 
@@ -1395,51 +1400,52 @@ __device__ __forceinline__ void ml_first_max(int& v, int& i, int* sv, int* si) {
 
 __global__ __launch_bounds__(256) void ml_vote_rowmax_kernel(MlArgs a) {
   __shared__ int sv[256], si[256];
-  const int b = blockIdx.y, l0 = blockIdx.x;
+  const int b = blockIdx.y;
   const int L0 = min(a.nlines0[b], a.capL), L1 = min(a.nlines1[b], a.capL);
-  if (l0 >= L0) return;
-  const unsigned* r0 = a.bits0 + ((size_t)b * a.capL + l0) * a.W;
   int* vote = a.vote + (size_t)b * a.capL * a.capL;
-  int bv = -1, bi = 0x7fffffff;
-  for (int l1 = threadIdx.x; l1 < L1; l1 += blockDim.x) {
-    const unsigned* r1 = a.bits1 + ((size_t)b * a.capL + l1) * a.W;
-    int v = 0;
-    for (int w = 0; w < a.W; ++w) v += __popc(r0[w] & r1[w]);
-    vote[(size_t)l0 * a.capL + l1] = v;
-    if (v > bv) { bv = v; bi = l1; }                             // l1 ascends within a thread: strict > keeps the first
+  for (int l0 = blockIdx.x; l0 < L0; l0 += gridDim.x) {          // (L0 is workgroup-uniform: every thread takes the same trips, barriers are safe)
+    const unsigned* r0 = a.bits0 + ((size_t)b * a.capL + l0) * a.W;
+    int bv = -1, bi = 0x7fffffff;
+    for (int l1 = threadIdx.x; l1 < L1; l1 += blockDim.x) {
+      const unsigned* r1 = a.bits1 + ((size_t)b * a.capL + l1) * a.W;
+      int v = 0;
+      for (int w = 0; w < a.W; ++w) v += __popc(r0[w] & r1[w]);
+      vote[(size_t)l0 * a.capL + l1] = v;
+      if (v > bv) { bv = v; bi = l1; }                           // l1 ascends within a thread: strict > keeps the first
+    }
+    ml_first_max(bv, bi, sv, si);
+    if (threadIdx.x == 0) { a.row_loc[(size_t)b * a.capL + l0] = bi; a.line_matches[(size_t)b * a.capL + l0] = -1; }
   }
-  ml_first_max(bv, bi, sv, si);
-  if (threadIdx.x == 0) { a.row_loc[(size_t)b * a.capL + l0] = bi; a.line_matches[(size_t)b * a.capL + l0] = -1; }
 }
 
 __global__ __launch_bounds__(256) void ml_colmax_kernel(MlArgs a) {
   __shared__ int sv[256], si[256];
-  const int b = blockIdx.y, j = blockIdx.x;
+  const int b = blockIdx.y;
   const int L0 = min(a.nlines0[b], a.capL), L1 = min(a.nlines1[b], a.capL);
-  if (j >= L1 || L0 == 0 || a.npts0[b] == 0 || a.npts1[b] == 0) return;          // src/line_processor.cc:132
+  if (L0 == 0 || a.npts0[b] == 0 || a.npts1[b] == 0) return;                      // src/line_processor.cc:132
   const int* vote = a.vote + (size_t)b * a.capL * a.capL;
   const int* row_ptr0 = a.row_ptr0 + (size_t)b * (a.capL + 1);
   const int* row_ptr1 = a.row_ptr1 + (size_t)b * (a.capL + 1);
-  int bv = -1, bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < L0; i += blockDim.x) {
-    const int v = vote[(size_t)i * a.capL + j];
-    if (v > bv) { bv = v; bi = i; }
-  }
-  ml_first_max(bv, bi, sv, si);
-  if (threadIdx.x == 0) {
-    if (bv < 2 || a.row_loc[(size_t)b * a.capL + bi] != j) return;          // :171
-    const int n0 = row_ptr0[bi + 1] - row_ptr0[bi], n1 = row_ptr1[j + 1] - row_ptr1[j];
-    const float score = __fdiv_rn((float)(bv * bv), (float)min(n0, n1));        // :174 float / size_t -> float division
-    if ((double)score < 0.8) return;                             // :175
-    a.line_matches[(size_t)b * a.capL + bi] = j;                 // distinct j cannot name the same row: row_loc[bi] == j
+  for (int j = blockIdx.x; j < L1; j += gridDim.x) {
+    int bv = -1, bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < L0; i += blockDim.x) {
+      const int v = vote[(size_t)i * a.capL + j];
+      if (v > bv) { bv = v; bi = i; }
+    }
+    ml_first_max(bv, bi, sv, si);
+    if (threadIdx.x == 0 && bv >= 2 && a.row_loc[(size_t)b * a.capL + bi] == j) {          // :171
+      const int n0 = row_ptr0[bi + 1] - row_ptr0[bi], n1 = row_ptr1[j + 1] - row_ptr1[j];
+      const float score = __fdiv_rn((float)(bv * bv), (float)min(n0, n1));        // :174 float / size_t -> float division
+      if (!((double)score < 0.8)) a.line_matches[(size_t)b * a.capL + bi] = j;    // :175; distinct j cannot name the same row: row_loc[bi] == j
+    }
   }
 }
 
 void launch_match_lines(const MlArgs& a, int B, hipStream_t st) {
   if (B <= 0 || a.capL <= 0) return;
-  const dim3 grid(a.capL, B);
-  hipLaunchKernelGGL(ml_bits_kernel, grid, dim3(256), 0, st, a, 0);
-  hipLaunchKernelGGL(ml_bits_kernel, grid, dim3(256), 0, st, a, 1);
+  const dim3 gbits(std::min((a.capL + 3) / 4, 64), B), grid(std::min(a.capL, 256), B);      // sized for ~256 lines per frame; the kernels walk further with the stride
+  hipLaunchKernelGGL(ml_bits_kernel, gbits, dim3(256), 0, st, a, 0);
+  hipLaunchKernelGGL(ml_bits_kernel, gbits, dim3(256), 0, st, a, 1);
   hipLaunchKernelGGL(ml_vote_rowmax_kernel, grid, dim3(256), 0, st, a);
   hipLaunchKernelGGL(ml_colmax_kernel, grid, dim3(256), 0, st, a);
 }

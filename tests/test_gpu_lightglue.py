@@ -342,3 +342,22 @@ def test_slack_rows_are_reset_on_every_call():
         ctx.trace_stop(-1)
         ctx.trace(False)
         ctx.close()
+
+
+def test_fused_block_tile_sizes_give_the_same_bits():
+    """lg_blockf picks 32-token passes up to 8192 tokens, 64 up to 16384, else 112 / 128 (round 4: the batch-1 .. batch-16 calls), and the small tiles
+    keep all weight slabs of a GEMM in flight.  A token's arithmetic does not depend on the tile it sits in: every tile size must give the SAME BITS
+    (AIRFE_LGB_TOKENS forces one)."""
+    _, _, a, b = _pair(400, 317, 11)
+    ref = None
+    for tokens in ("32", "64", "112", "128"):
+        ctx, _, _ = context("lg", env={"AIRFE_FUSE_LG_BLOCK": "1", "AIRFE_LGB_TOKENS": tokens}, max_batch=4)
+        s = ctx.lightglue_scores(a, b)
+        idx, sc = ctx.match_lightglue(a, b)
+        if ref is None:
+            ref = (s, idx, sc)
+            assert len(idx) >= 100
+        else:
+            np.testing.assert_array_equal(s, ref[0])
+            np.testing.assert_array_equal(idx, ref[1])
+            np.testing.assert_array_equal(sc, ref[2])
