@@ -1200,8 +1200,14 @@ void launch_sg_decode(const float* Z, const int* lens, int B, int Np, int Lz, fl
 // TemplatedVocabulary::transform(feature, word_id, weight) (3rdparty/DBoW2/include/DBoW2/TemplatedVocabulary.h:1313-1352) for every
 // feature of a frame, as Database::FrameToBow calls it (src/bow/database.cc:57-89): descend the vocabulary tree, at every node
 // taking the child whose 256-d descriptor is nearest in squared L2 distance (FSuperpoint::distance, src/bow/FSuperpoint.cc:45-49),
-// FIRST minimum on ties (strict '<'), until a leaf; emit the leaf's word id and weight.  One wave per feature: the feature sits in
-// registers (4 floats per lane), every candidate child is one coalesced 1 KiB row read.
+// FIRST minimum on ties (strict '<'), until a leaf; emit the leaf's word id and weight.
+//
+// The distance is summed in the ORDER the reference's build sums it, so that near-ties between children fall the way they fall there
+// (oracle/_ref, tests/test_gpu_ref_pin.py): Eigen reduces a 256-float `(a - b).squaredNorm()` on SSE2 as two 4-lane packet accumulators —
+// chain j (0..7) adds the squares of elements j, j + 8, j + 16, ... one after the other — then r0 += r1 and (a0 + a2) + (a1 + a3)
+// (oracle/ref_post.py::_eigen_sse2_sum).  One wave per feature: lane = 8 * child + chain, eight children per pass; a lane keeps its 32
+// feature elements in registers and walks its chain sequentially (every product and sum rounded on its own: no contraction).  One load
+// instruction of the wave reads 8 rows x 32 B; the upper levels of the tree stay in L2.
 __global__ __launch_bounds__(256) void bow_transform_kernel(const float* __restrict__ feat, int ld, int off, int N,
                                                             const float* __restrict__ node_desc, const int* __restrict__ first_child,
                                                             const int* __restrict__ n_children, const int* __restrict__ word_id,
@@ -1209,19 +1215,43 @@ __global__ __launch_bounds__(256) void bow_transform_kernel(const float* __restr
                                                             float* __restrict__ out_weight, int* __restrict__ out_node) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= N) return;
-  // (a feature row starts at float 259 i + 3: only 4-byte aligned, so four scalar loads, not a float4)
-  const float* fp = feat + (size_t)i * ld + off + lane * 4;
-  const float4 f = make_float4(fp[0], fp[1], fp[2], fp[3]);
+  const int chain = lane & 7, slot = lane >> 3;
+  const float* fp = feat + (size_t)i * ld + off + chain;
+  float f[32];
+#pragma unroll
+  for (int m = 0; m < 32; ++m) f[m] = fp[8 * m];
   int node = 0;
   for (int nc = n_children[0]; nc > 0; nc = n_children[node]) {
     const int c0 = first_child[node];
     float best = INFINITY;
     int bi = c0;
-    for (int c = 0; c < nc; ++c) {
-      const float4 d = *reinterpret_cast<const float4*>(node_desc + (size_t)(c0 + c) * 256 + lane * 4);
-      const float dx = f.x - d.x, dy = f.y - d.y, dz = f.z - d.z, dw = f.w - d.w;
-      const float dist = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw);
-      if (dist < best) { best = dist; bi = c0 + c; }
+    for (int cb = 0; cb < nc; cb += 8) {
+      const int c = cb + slot;
+      float acc = INFINITY;
+      if (c < nc) {
+        const float* dp = node_desc + (size_t)(c0 + c) * 256 + chain;
+        float d[32];
+#pragma unroll
+        for (int m = 0; m < 32; ++m) d[m] = dp[8 * m];
+        const float t0 = __fsub_rn(f[0], d[0]);
+        acc = __fmul_rn(t0, t0);
+        asm volatile("" : "+v"(acc));
+#pragma unroll
+        for (int m = 1; m < 32; ++m) {
+          const float t = __fsub_rn(f[m], d[m]);
+          float sq = __fmul_rn(t, t);
+          asm volatile("" : "+v"(sq));                       // opaque to hipcc, which fuses sq + acc into an FMA even through __fmul_rn (see rounded_mul below)
+          acc = __fadd_rn(acc, sq);
+        }
+      }
+      acc = __fadd_rn(acc, __shfl_down(acc, 4));           // chains 0..3: r0[j] + r1[j]
+      const float a02 = __fadd_rn(acc, __shfl_down(acc, 2));  // chain 0: a0 + a2; chain 1: a1 + a3
+      const float dist = __fadd_rn(a02, __shfl_down(a02, 1)); // chain 0: (a0 + a2) + (a1 + a3)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {                         // children of this pass in order, strict '<' (TemplatedVocabulary.h:1336)
+        const float dk = __shfl(dist, 8 * k);
+        if (cb + k < nc && dk < best) { best = dk; bi = c0 + cb + k; }
+      }
     }
     node = bi;
   }

@@ -204,6 +204,7 @@ float airslam_ref_point_line_distance(const float* line4, const float* point2) {
 
 const char* airslam_ref_sources() {
   return "src/feature_detector.cc src/point_matcher.cc src/plnet.cpp src/super_point.cpp src/light_glue.cpp src/super_glue.cpp "
-         "src/line_processor.cc:1-180";
+         "src/line_processor.cc:1-180 3rdparty/DBoW2/include/DBoW2/TemplatedVocabulary.h 3rdparty/DBoW2/src/{BowVector,FeatureVector,ScoringObject}.cpp "
+         "src/bow/FSuperpoint.cc";
 }
 }  // extern "C"

@@ -213,5 +213,21 @@ def match_lines(off0, pidx0, off1, pidx1, query, train, point_num0: int, point_n
     return out[:nl0].copy()
 
 
+def bow_frame_to_bow(voc: dict, feat: np.ndarray):
+    """Database::FrameToBow's per-feature part (src/bow/database.cc:57-89) on the vendored DBoW2 compiled unchanged (oracle/ref_bow.cpp): feat [N][259]
+    -> (word_of_features uint32 [N] (UINT_MAX: stopped word), weight_of_features f64 [N], BowVector as (ids uint32 [K], values f64 [K]))."""
+    feat = np.ascontiguousarray(feat, np.float32).reshape(-1, 259)
+    n = len(feat)
+    desc = np.ascontiguousarray(voc["desc"], np.float32); fc = np.ascontiguousarray(voc["first_child"], np.int32)
+    nc = np.ascontiguousarray(voc["n_children"], np.int32); wi = np.ascontiguousarray(voc["word_id"], np.int32)
+    w = np.ascontiguousarray(voc["weight"], np.float64)
+    words = np.zeros(max(n, 1), np.uint32); wts = np.zeros(max(n, 1), np.float64); ids = np.zeros(max(n, 1), np.uint32); vals = np.zeros(max(n, 1), np.float64)
+    fn = lib().airslam_ref_bow_frame_to_bow
+    fn.restype = C.c_int
+    k = fn(_fp(desc), _ip(fc), _ip(nc), _ip(wi), _dp(w), len(desc), int(voc.get("k", 10)), int(voc.get("L", 4)), _fp(feat), n,
+           words.ctypes.data_as(C.c_void_p), _dp(wts), ids.ctypes.data_as(C.c_void_p), _dp(vals))
+    return words[:n].copy(), wts[:n].copy(), ids[:k].copy(), vals[:k].copy()
+
+
 def sources() -> str:
     return lib().airslam_ref_sources().decode()

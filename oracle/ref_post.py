@@ -10,7 +10,8 @@ but its host code compiles: oracle/Makefile builds /root/reference's src/{featur
 light_glue.cpp, super_glue.cpp} and line_processor.cc:1-180 UNCHANGED into oracle/_ref/libairslam_ref.so (stand-ins only for Eigen, OpenCV,
 yaml-cpp and TensorRT, whose engines become a callback), and tests/test_ref_pin_cpu.py holds every function below that has a counterpart there
 to it bit for bit — live, and through the committed outputs tests/golden/ref_pin.npz.  Still pinned by reading only: resize_linear_u8 /
-remap_linear_u8 (OpenCV absent), simple_nms (inside the absent ONNX graphs), bow_transform (DBoW2's template, not compiled).
+remap_linear_u8 (OpenCV absent), simple_nms (inside the absent ONNX graphs).  bow_transform / frame_to_bow are pinned to the vendored DBoW2 +
+src/bow/FSuperpoint.cc compiled unchanged (oracle/ref_bow.cpp).
 """
 from __future__ import annotations
 
@@ -83,9 +84,11 @@ def bow_transform(voc: dict, desc: np.ndarray, return_margin: bool = False):
         node = 0
         while voc["n_children"][node] > 0:
             c0, nc = int(voc["first_child"][node]), int(voc["n_children"][node])
-            diff = voc["desc"][c0:c0 + nc].astype(np.float64) - d[i].astype(np.float64)[None]
-            dist = (diff * diff).sum(1)
-            j = int(np.argmin(dist))                                   # first minimum
+            # FSuperpoint::distance: `diff = a - b; return diff.transpose() * diff;` in float (Matrix<float, 256, 1>), the inner product reduced in
+            # Eigen's packet order (_eigen_sse2_sum), widened to double only on return — pinned against the compiled DBoW2 (tests/test_ref_pin_cpu.py)
+            diff = (d[i][None] - voc["desc"][c0:c0 + nc].astype(F)).astype(F)
+            dist = _eigen_sse2_sum(np.ascontiguousarray((diff * diff).astype(F).T)).astype(np.float64)
+            j = int(np.argmin(dist))                                   # first minimum (`if (d < best_d)`, TemplatedVocabulary.h:1336)
             if nc > 1:
                 s2 = np.partition(dist, 1)[:2]
                 margin[i] = min(margin[i], (s2[1] - s2[0]) / max(s2[1], 1e-30))
@@ -104,7 +107,9 @@ def frame_to_bow(words: np.ndarray, weights: np.ndarray):
         if w > 0:
             bow[wid] = bow.get(wid, 0.0) + w
             wf.setdefault(wid, []).append(i)
-    tot = sum(abs(v) for v in bow.values())
+    tot = 0.0
+    for k in sorted(bow):                      # BowVector::normalize walks the std::map in ascending word id (3rdparty/DBoW2/src/BowVector.cpp)
+        tot += abs(bow[k])
     if tot > 0:
         bow = {k: v / tot for k, v in bow.items()}
     return dict(sorted(bow.items())), dict(sorted(wf.items()))

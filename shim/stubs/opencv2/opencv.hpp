@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <vector>
 
 typedef unsigned char uchar;
@@ -83,6 +84,7 @@ struct Mat {
     rows = r; cols = c; step = (size_t)c; data = own->data();
   }
   bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+  void release() { own.reset(); data = nullptr; rows = cols = 0; step = 0; }
   int type() const { return CV_8UC1; }
   int channels() const { return 1; }
   size_t elemSize() const { return 1; }
@@ -140,6 +142,31 @@ inline void resize(const Mat& src, Mat& dst, Size dsize, double = 0, double = 0,
   }
   dst = out;
 }
+
+// cv::FileStorage / cv::FileNode: declared so that DBoW2's TemplatedVocabulary.h (its virtual save / load) compiles unchanged; nothing is stored —
+// isOpened() is false, so TemplatedVocabulary::load(filename) throws like it does for a missing file (oracle/ref_bow.cpp builds the tree in memory)
+struct FileNode {
+  FileNode operator[](const char*) const { return FileNode(); }
+  FileNode operator[](const std::string&) const { return FileNode(); }
+  FileNode operator[](int) const { return FileNode(); }
+  size_t size() const { return 0; }
+  operator int() const { return 0; }
+  operator double() const { return 0.0; }
+  operator std::string() const { return std::string(); }
+};
+struct FileStorage {
+  enum { READ = 0, WRITE = 1 };
+  FileStorage() {}
+  FileStorage(const std::string&, int) {}
+  bool isOpened() const { return false; }
+  void release() {}
+  FileNode operator[](const char*) const { return FileNode(); }
+  FileNode operator[](const std::string&) const { return FileNode(); }
+};
+template <class T>
+inline FileStorage& operator<<(FileStorage& fs, const T&) { return fs; }
+template <class M>
+inline void eigen2cv(const M&, Mat& dst) { dst = Mat(); }     // FSuperpoint::toMat32F (k-means training helper): float matrices are not modelled
 
 // declared like OpenCV's; the definition (shim/stubs/mini_opencv.cpp) aborts with a message — the F-RANSAC of
 // PointMatcher::MatchingPoints(outlier_rejection = true) is OpenCV's and out of scope

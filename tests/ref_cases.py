@@ -10,6 +10,7 @@ Families (what in the reference each one goes through — all of it compiled unc
            junction map, detect_point, extract_descriptors, junction_detector, rescales
   lg / sg  PointMatcher::MatchingPoints -> NormalizeKeypoints, process_input, filter_matches / decode, the DMatch loops
   lines    AssignPointsToLines, MatchLines
+  bow      TemplatedVocabulary::transform per feature + BowVector::addWeight / normalize, as Database::FrameToBow runs them (vendored DBoW2 + FSuperpoint.cc)
 """
 from __future__ import annotations
 
@@ -231,6 +232,33 @@ def lines_case(name: str) -> dict:
     return dict(name=name, lines0=l0, feat0=f0, lines1=l1, feat1=f1, query=query, train=train)
 
 
+# ================================================================================================================ BoW
+BOW = {"k10_L4_400": (10, 4, 400, 91), "k8_L3_1024": (8, 3, 1024, 92), "k3_L2_1": (3, 2, 1, 93), "exact_ties": (2, 2, 4, 94)}
+
+
+def bow_case(name: str) -> dict:
+    """A vocabulary tree (airslam_amd.weights.synthetic_vocabulary: voc/point_voc_L4.bin is absent upstream) + feature rows near its leaves; `exact_ties`
+    is a hand-built tree in which a descriptor is EXACTLY as far from two children (the first must win) and a leaf is a stopped word (weight 0)."""
+    from airslam_amd import weights
+    k, L, n, seed = BOW[name]
+    if name == "exact_ties":
+        e = np.eye(256, dtype=F)
+        voc = dict(desc=np.stack([0 * e[0], e[0], e[1], e[0] + e[2], e[0] - e[2]]).astype(F), first_child=np.array([1, 3, 0, 0, 0], np.int32),
+                   n_children=np.array([2, 2, 0, 0, 0], np.int32), word_id=np.array([0, 0, 7, 3, 4], np.int32), weight=np.array([0, 0, 2.0, 0.0, 1.5]), k=2, L=2)
+        feat = np.zeros((4, 259), F)
+        feat[:, 3:] = np.stack([e[1], e[0] + F(0.5) * e[2], e[0] - F(0.5) * e[2], F(0.5) * (e[0] + e[1])])
+        return dict(name=name, voc=voc, feat=feat)
+    voc = weights.synthetic_vocabulary(1234, k=k, L=L)
+    rng = np.random.default_rng(seed)
+    leaves = np.nonzero(voc["n_children"] == 0)[0]
+    pick = leaves[rng.integers(0, len(leaves), n)]
+    d = (voc["desc"][pick] + (rng.random((n, 256), dtype=F) - F(0.5)) * F(0.5)).astype(F)
+    feat = np.zeros((n, 259), F)
+    feat[:, 0] = rng.random(n, dtype=F)
+    feat[:, 3:] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(F)
+    return dict(name=name, voc=voc, feat=feat)
+
+
 # ================================================================================================================ runners
 def _scales(image):
     h, w = image.shape
@@ -294,6 +322,9 @@ def run_ref(family: str, case: dict, tmp: str) -> dict:
         o1, i1, d1 = ref_lib.assign_points_to_lines(case["lines1"], case["feat1"])
         lm = ref_lib.match_lines(o0, i0, o1, i1, case["query"], case["train"], len(case["feat0"]), len(case["feat1"]))
         return dict(off0=o0, idx0=i0, dist0=d0, off1=o1, idx1=i1, dist1=d1, line_matches=lm)
+    if family == "bow":
+        w, wt, ids, vals = ref_lib.bow_frame_to_bow(case["voc"], case["feat"])
+        return dict(word_of_features=w, weight_of_features=wt, bow_ids=ids, bow_values=vals)
     raise KeyError(family)
 
 
@@ -349,11 +380,15 @@ def run_post(family: str, case: dict) -> dict:
         o0, i0, d0 = csr(r0); o1, i1, d1 = csr(r1)
         lm = ref_post.match_lines(r0, r1, list(zip(case["query"].tolist(), case["train"].tolist())), len(case["feat0"]), len(case["feat1"]))
         return dict(off0=o0, idx0=i0, dist0=d0, off1=o1, idx1=i1, dist1=d1, line_matches=np.array(lm, np.int32))
+    if family == "bow":
+        w, wt = ref_post.bow_transform(case["voc"], case["feat"][:, 3:])
+        bow, _ = ref_post.frame_to_bow(w, wt)
+        return dict(word_of_features=w, weight_of_features=wt, bow_ids=np.array(list(bow), np.uint32), bow_values=np.array(list(bow.values()), np.float64))
     raise KeyError(family)
 
 
 FAMILIES = {"detect": (DETECT, detect_case), "plnet": (PLNET, plnet_case), "lg": (MATCH, lambda n: match_case(n, "lg")),
-            "sg": (MATCH, lambda n: match_case(n, "sg")), "lines": (LINES, lines_case)}
+            "sg": (MATCH, lambda n: match_case(n, "sg")), "lines": (LINES, lines_case), "bow": (BOW, bow_case)}
 # descriptors go through Eigen's colwise().normalize(): the summation order of squaredNorm() is Eigen's own (SSE packets in a real-Eigen build,
 # index order in the stand-in) and numpy's pairwise — the ONE place where the restatement may differ from the compiled reference, by summation order
 DESC_TOL = 2e-6

@@ -51,12 +51,11 @@ def test_bow_transform_vs_oracle(k, L, n):
     f = _voc_features(voc, n, 5 * n + k)
     words, w = ctx.bow_transform(f)
     rw, rwt, margin = ref_post.bow_transform(voc, f[:, 3:], return_margin=True)
-    clear = margin > 1e-4                                    # the rest are decided by float summation order (Eigen's own is unspecified)
-    diag(f"bow_{k}_{L}_{n}", n=n, clear=int(clear.sum()), stopped=int((rw == 0xFFFFFFFF).sum()), distinct_words=len(set(rw.tolist())))
-    assert clear.mean() > 0.98
-    np.testing.assert_array_equal(words[clear], rw[clear])
-    np.testing.assert_array_equal(w[clear], rwt[clear])             # the vocabulary's own doubles (WordValue is a double in the reference), no float round trip
-    if clear.all():
-        assert ref_post.frame_to_bow(words, w) == ref_post.frame_to_bow(rw, rwt)
+    diag(f"bow_{k}_{L}_{n}", n=n, near_ties=int((margin <= 1e-4).sum()), stopped=int((rw == 0xFFFFFFFF).sum()), distinct_words=len(set(rw.tolist())))
+    # every feature, near-ties included: the kernel sums the distance in the order the reference's build does (kernels_ext.hip), the oracle is
+    # pinned to that build (tests/test_ref_pin_cpu.py, family `bow`)
+    np.testing.assert_array_equal(words, rw)
+    np.testing.assert_array_equal(w, rwt)                           # the vocabulary's own doubles (WordValue is a double in the reference), no float round trip
+    assert ref_post.frame_to_bow(words, w) == ref_post.frame_to_bow(rw, rwt)
     assert (rw == 0xFFFFFFFF).any() or n < 50                # stopped words are exercised
     ctx.close()

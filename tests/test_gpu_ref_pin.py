@@ -182,3 +182,21 @@ def test_line_kernels_equal_the_reference_fixtures(name):
         rels.append(rel)
     lm = ctx.match_lines(rels[0], rels[1], list(zip(case["query"].tolist(), case["train"].tolist())), len(case["feat0"]), len(case["feat1"]))
     np.testing.assert_array_equal(np.array(lm, np.int32), want["line_matches"])
+
+
+@pytest.mark.parametrize("name", list(rc.BOW))
+def test_bow_kernel_equals_the_reference_fixtures(name):
+    """airfe_bow_transform against what the vendored DBoW2 + src/bow/FSuperpoint.cc, compiled unchanged, returned for the same tree and features
+    (TemplatedVocabulary.h:1313-1352 as Database::FrameToBow calls it, database.cc:57-89) — exact ties and near-ties included."""
+    from oracle import ref_post
+    case, want = rc.bow_case(name), _fixture("bow", name)
+    n = len(case["feat"])
+    ctx = api.Context(superpoint=None, max_batch=2, max_keypoints=max(n, 16))
+    ctx.bow_load(case["voc"])
+    words, w = ctx.bow_transform(case["feat"])
+    np.testing.assert_array_equal(words, want["word_of_features"])
+    np.testing.assert_array_equal(w, want["weight_of_features"])
+    bow, _ = ref_post.frame_to_bow(words, w)
+    np.testing.assert_array_equal(np.array(list(bow), np.uint32), want["bow_ids"])
+    np.testing.assert_allclose(np.array(list(bow.values())), want["bow_values"], rtol=0, atol=1e-16)
+    ctx.close()
