@@ -187,6 +187,39 @@ class Context:
                                              C.byref(nj), int(want_junctions)), "airfe_detect_plnet")
         return feat[:n.value].copy(), lines[:nl.value].copy(), junc[:nj.value].copy()
 
+    def stereo_keyframe(self, left: np.ndarray, right: np.ndarray, match: bool = True, want_junctions: bool = True, cap_lines: int = 4096,
+                        cap_junc: int = 2048):
+        """ONE stereo keyframe in one call (airfe_stereo_keyframe ≙ map_builder.cc:85-86): -> dict(featL, featR [n,259], linesL, linesR [L,4] float64,
+        juncL [K,259], idx [m,2] int32, score [m]) — idx / score absent with match=False."""
+        imgs = []
+        for g in (left, right):
+            g = np.asarray(g)
+            if g.ndim != 2 or g.dtype != np.uint8 or g.size == 0:
+                raise AirfeError("empty image")
+            imgs.append(g)
+        if imgs[0].shape != imgs[1].shape:
+            raise AirfeError("stereo_keyframe: left and right images differ in size")
+        if any(g.strides[1] != 1 or g.strides[0] < g.shape[1] for g in imgs) or imgs[0].strides[0] != imgs[1].strides[0]:
+            imgs = [np.ascontiguousarray(g) for g in imgs]
+        k = self._kf_bufs.get((cap_lines, cap_junc)) if hasattr(self, "_kf_bufs") else None
+        if k is None:
+            cap = self.np_rows
+            k = dict(fl=np.empty((cap, FEAT), np.float32), fr=np.empty((cap, FEAT), np.float32), ll=np.empty((cap_lines, 4), np.float64),
+                     lr=np.empty((cap_lines, 4), np.float64), jl=np.empty((cap_junc, FEAT), np.float32), idx=np.empty((cap, 2), np.int32),
+                     sc=np.empty((cap,), np.float32), n=(C.c_int * 6)())
+            self._kf_bufs = {(cap_lines, cap_junc): k}
+        n = k["n"]
+        p = lambda i: C.cast(C.byref(n, 4 * i), C.POINTER(C.c_int))
+        self._chk(self._l.airfe_stereo_keyframe(self._h, imgs[0].ctypes.data, imgs[1].ctypes.data, imgs[0].shape[0], imgs[0].shape[1], imgs[0].strides[0],
+                                                k["fl"].ctypes.data, k["fr"].ctypes.data, self.np_rows, p(0), p(1), k["ll"].ctypes.data, k["lr"].ctypes.data,
+                                                cap_lines, p(2), p(3), k["jl"].ctypes.data if want_junctions else None, cap_junc, p(4),
+                                                k["idx"].ctypes.data if match else None, k["sc"].ctypes.data, self.np_rows, p(5)), "airfe_stereo_keyframe")
+        out = dict(featL=k["fl"][:n[0]].copy(), featR=k["fr"][:n[1]].copy(), linesL=k["ll"][:n[2]].copy(), linesR=k["lr"][:n[3]].copy(),
+                   juncL=k["jl"][:n[4]].copy())
+        if match:
+            out["idx"], out["score"] = k["idx"][:n[5]].copy(), k["sc"][:n[5]].copy()
+        return out
+
     def debug_plnet_stage0(self):
         """The on-device stage-0 line branch of the last detected image: dict in synth.plnet_stage0_lines' layout + jloc / joff."""
         n = 3 * 128 * 128
@@ -493,6 +526,19 @@ class FeatureDetector:
             return False, np.zeros((FEAT, 0), np.float32, order="F"), np.zeros((FEAT, 0), np.float32, order="F")
         lines.extend(tuple(r) for r in l)
         return True, np.asfortranarray(f.T), np.asfortranarray(j.T)
+
+    def DetectKeyframe(self, left: np.ndarray, right: np.ndarray, left_lines: list, right_lines: list):
+        """Detect(image_left, image_right, left_features, right_features, left_lines, right_lines, junctions) (feature_detector.cc:97-108) as ONE
+        device pass over both images (Context.stereo_keyframe without the match) -> (ok, left_features, right_features, junctions)."""
+        try:
+            k = self._ctx.stereo_keyframe(left, right, match=False)
+        except (AirfeError, TypeError):
+            print("Failed when extracting point features !")
+            z = np.zeros((FEAT, 0), np.float32, order="F")
+            return False, z, z.copy(), z.copy()
+        left_lines.extend(tuple(r) for r in k["linesL"])
+        right_lines.extend(tuple(r) for r in k["linesR"])
+        return True, np.asfortranarray(k["featL"].T), np.asfortranarray(k["featR"].T), np.asfortranarray(k["juncL"].T)
 
     def DetectStereo(self, left: np.ndarray, right: np.ndarray):
         okl, fl = self.Detect(left)

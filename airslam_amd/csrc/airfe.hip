@@ -234,6 +234,7 @@ struct airfe_ctx {
   uint8_t* st_rect = nullptr; size_t st_rect_bytes = 0;
   // host-API staging
   uint8_t* st_img = nullptr; size_t st_img_bytes = 0;
+  uint8_t* kf_blk = nullptr; size_t kf_bytes = 0;   // airfe_stereo_keyframe's device block (grows on demand)
   float *st_feat0 = nullptr, *st_feat1 = nullptr, *st_score = nullptr;
   int *st_n0 = nullptr, *st_n1 = nullptr, *st_nm = nullptr;
   int32_t* st_idx = nullptr;
@@ -2247,18 +2248,17 @@ int airfe_detect_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int
   return plnet_lines_batch(c, B, h, w, d_lines, capL, d_nlines, d_junc, capJ, d_njunc, junction_images, d_found, st);
 }
 
-int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
-                                 size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, double* d_lines,
-                                 int capL, int* d_nlines, float* d_juncL, int capJ, int* d_njuncL, int* d_found, int32_t* d_idx,
-                                 float* d_score, int mcap, int* d_nmatch, void* stream) {
-  AIRFE_ENTER(c);
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+// (d_idx == nullptr: detection only — the stereo overload of Detect without the MatchingPoints that follows it)
+static int stereo_plnet_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
+                            size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, double* d_lines,
+                            int capL, int* d_nlines, float* d_juncL, int capJ, int* d_njuncL, int* d_found, int32_t* d_idx,
+                            float* d_score, int mcap, int* d_nmatch, hipStream_t st) {
   if (!(c->prec != 2 && 2 * B <= c->Dmax))
     return fail(c, "stereo_plnet_batch: needs the one-pass stereo detector (detector + LightGlue packs loaded, 2 B <= 2 max_batch, fp16 / bf16)");
   // (With stage timers on anything behind the encoder the chains run one after the other: a stage's event pair must not span the other chain.)
   const uint32_t enc_only = (1u << ST_PREPROCESS) | (1u << ST_CONV1_FUSED) | (1u << ST_CONV3X3_C64);
   const bool overlap = c->overlap_lines && (c->prof_mask & ~enc_only) == 0;
-  c->force_nms_map = true;
+  c->force_nms_map = d_juncL != nullptr;          // junction scores are read from the NMS'd maps
   int rc = detect_dev2(c, d_left, d_right, B, h, w, stride, img_stride, d_featL, d_featR, cap, d_nL, d_nR, st);
   c->force_nms_map = false;
   if (rc) return 1;
@@ -2268,17 +2268,106 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint
   // off: with the line path's workgroups beside it the matcher's scores were irreproducible in ~10 % of the steps — traced in round 3 to ONE
   // packed-math instruction form in the rotary epilogue (common.h, rotate_pairs), which also failed, 50x more rarely, on one stream.
   // With that form gone: 0 deviations in 3500 overlapped and 5000 single-stream steps (profiles/r03_matcher_trace_probe1.txt, _probe2.txt).
+  if (!d_idx) return plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, d_juncL ? B : 0, d_found, st);
   if (!overlap) {
-    if (plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, st)) return 1;
+    if (plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, d_juncL ? B : 0, d_found, st)) return 1;
     return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
   }
   HIPCHK(c, hipEventRecord(c->ev_fork, st));                  // behind the point branch
   HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-  rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, B, d_found, c->stream2);
+  rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, d_juncL ? B : 0, d_found, c->stream2);
   if (!rc) rc = lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));      // (also after an error: the caller's stream never runs ahead of the side stream)
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   return rc;
+}
+
+int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
+                                 size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, double* d_lines,
+                                 int capL, int* d_nlines, float* d_juncL, int capJ, int* d_njuncL, int* d_found, int32_t* d_idx,
+                                 float* d_score, int mcap, int* d_nmatch, void* stream) {
+  AIRFE_ENTER(c);
+  if (!d_idx || !d_score || !d_nmatch) return fail(c, "stereo_plnet_batch: no match output");
+  return stereo_plnet_dev(c, d_left, d_right, B, h, w, stride, img_stride, d_featL, d_featR, cap, d_nL, d_nR, d_lines, capL, d_nlines, d_juncL, capJ,
+                          d_njuncL, d_found, d_idx, d_score, mcap, d_nmatch, stream ? (hipStream_t)stream : c->stream);
+}
+
+// ONE stereo keyframe through host buffers (batch 1, the regime of AirSLAM's feature thread): what map_builder.cc:85-86 does in two façade calls —
+// Detect(left, right, features, lines, junctions) = PLNet::infer twice (feature_detector.cc:97-108), then MatchingPoints(left, right) — as ONE
+// queue of device work: both images go up in one copy, the detector runs over them as a batch of two, the line path of both runs on the second
+// stream beside LightGlue, and everything comes back in two copies (the counted rows, then the line / junction rows whose counts are known only then).
+// Per image and per pair the results are the bits the separate entries return (tests/test_gpu_keyframe.py).  match_idx == NULL: detection only.
+int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* right, int h, int w, int stride, float* featL, float* featR, int cap,
+                          int* nL, int* nR, double* linesL, double* linesR, int capL, int* nlinesL, int* nlinesR, float* juncL, int capJ,
+                          int* njuncL, int32_t* match_idx, float* match_score, int mcap, int* nmatch) {
+  AIRFE_ENTER(c);
+  if (!left || !right || h < 1 || w < 1) return fail(c, "empty image");
+  if (stride < w) return fail(c, "image stride smaller than its width");
+  if (!featL || !featR || !nL || !nR || !linesL || !linesR || !nlinesL || !nlinesR || capL < 1)
+    return fail(c, "stereo_keyframe: bad argument");
+  if (cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
+  const bool match = match_idx != nullptr;
+  if (match && (!match_score || !nmatch || mcap < c->cfg.max_keypoints)) return fail(c, "stereo_keyframe: match buffers smaller than max_keypoints");
+  const bool want_j = juncL != nullptr;
+  if (want_j && (!njuncL || capJ < 1)) return fail(c, "stereo_keyframe: bad junction arguments");
+  if (!(c->prec != 2 && 2 <= c->Dmax)) return fail(c, "stereo_keyframe: needs a detector arena of two images (max_batch >= 2, or detector + LightGlue packs), fp16 / bf16");
+  *nL = *nR = *nlinesL = *nlinesR = 0;
+  if (njuncL) *njuncL = 0;
+  if (nmatch) *nmatch = 0;
+  hipStream_t st = c->stream;
+  const int Np = c->cfg.max_keypoints, capLd = std::min(capL, LINE_CAP), capJd = std::min(std::max(capJ, 1), JUNC_CAP);
+  // device block: [counts 64 B | featL | featR | idx | score] — the part that comes back in the first copy — then [lines 2 x capLd | junctions]
+  const size_t fb = (size_t)Np * AIRFE_FEAT_DIM * 4, head = 64 + 2 * fb + (size_t)Np * 12;
+  const size_t lb = (size_t)capLd * 32, total = head + 2 * lb + (size_t)capJd * AIRFE_FEAT_DIM * 4;
+  if (ensure_block(c, c->kf_blk, c->kf_bytes, total)) return 1;
+  int* cnt = reinterpret_cast<int*>(c->kf_blk);                 // {nL, nR, nlines[2], nmatch, njunc, found: lines[2] junc[1]}
+  float *d_fL = reinterpret_cast<float*>(c->kf_blk + 64), *d_fR = reinterpret_cast<float*>(c->kf_blk + 64 + fb);
+  int32_t* d_idx = reinterpret_cast<int32_t*>(c->kf_blk + 64 + 2 * fb);
+  float* d_sc = reinterpret_cast<float*>(c->kf_blk + 64 + 2 * fb + (size_t)Np * 8);
+  double* d_ln = reinterpret_cast<double*>(c->kf_blk + head);
+  float* d_jn = reinterpret_cast<float*>(c->kf_blk + head + 2 * lb);
+  // both images through the pinned block in one copy (same row pitch; the right image starts at h * stride)
+  const size_t ib = (size_t)(h - 1) * stride + w, pitch = (size_t)h * stride;
+  if (ensure_stage_img(c, 2 * pitch)) return 1;
+  if (ensure_pin(c, std::max(pitch + ib, head))) return 1;
+  memcpy(c->pin, left, ib);
+  memcpy(c->pin + pitch, right, ib);
+  HIPCHK(c, hipMemsetAsync(cnt, 0, 64, st));
+  HIPCHK(c, hipMemcpyAsync(c->st_img, c->pin, pitch + ib, hipMemcpyHostToDevice, st));
+  if (stereo_plnet_dev(c, c->st_img, c->st_img + pitch, 1, h, w, stride, pitch, d_fL, d_fR, Np, cnt, cnt + 1, d_ln, capLd, cnt + 2, want_j ? d_jn : nullptr,
+                       capJd, want_j ? cnt + 5 : nullptr, cnt + 6, match ? d_idx : nullptr, d_sc, Np, cnt + 4, st))
+    return 1;
+  HIPCHK(c, hipMemcpyAsync(c->pin, c->kf_blk, match ? head : 64 + 2 * fb, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  const int* hc = reinterpret_cast<const int*>(c->pin);
+  const int n0 = std::min(hc[0], Np), n1 = std::min(hc[1], Np), nl0 = hc[2], nl1 = hc[3], nm = std::min(hc[4], Np), nj = hc[5];
+  const int fl0 = hc[6], fl1 = hc[7], fj = hc[8];
+  if (n0 > 0) memcpy(featL, c->pin + 64, (size_t)n0 * AIRFE_FEAT_DIM * 4);
+  if (n1 > 0) memcpy(featR, c->pin + 64 + fb, (size_t)n1 * AIRFE_FEAT_DIM * 4);
+  *nL = n0; *nR = n1;
+  if (match) {
+    if (nm > 0) {
+      memcpy(match_idx, c->pin + 64 + 2 * fb, (size_t)nm * 8);
+      memcpy(match_score, c->pin + 64 + 2 * fb + (size_t)Np * 8, (size_t)nm * 4);
+    }
+    *nmatch = nm;
+  }
+  if (want_j && fj > JUNC_CAP) return fail(c, "stereo_keyframe: more junctions than the device arena holds (JUNC_CAP)");
+  if (fl0 > capLd || fl1 > capLd || (want_j && fj > capJd)) return fail(c, "stereo_keyframe: lines / junctions do not fit the caller's buffers (capL, capJ)");
+  const size_t b0 = (size_t)nl0 * 32, b1 = (size_t)nl1 * 32, bj = want_j ? (size_t)nj * AIRFE_FEAT_DIM * 4 : 0;
+  if (b0 + b1 + bj) {
+    if (ensure_pin(c, b0 + b1 + bj)) return 1;
+    if (b0) HIPCHK(c, hipMemcpyAsync(c->pin, d_ln, b0, hipMemcpyDeviceToHost, st));
+    if (b1) HIPCHK(c, hipMemcpyAsync(c->pin + b0, d_ln + (size_t)capLd * 4, b1, hipMemcpyDeviceToHost, st));
+    if (bj) HIPCHK(c, hipMemcpyAsync(c->pin + b0 + b1, d_jn, bj, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (b0) memcpy(linesL, c->pin, b0);
+    if (b1) memcpy(linesR, c->pin + b0, b1);
+    if (bj) memcpy(juncL, c->pin + b0 + b1, bj);
+  }
+  *nlinesL = nl0; *nlinesR = nl1;
+  if (njuncL) *njuncL = want_j ? nj : 0;
+  return 0;
 }
 
 /* the on-device stage-0 line branch of the LAST detected image, copied out in the Appendix A.1 layouts (NULL = skip) */

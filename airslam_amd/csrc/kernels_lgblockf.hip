@@ -24,11 +24,13 @@
 #include "common.h"
 #include "kernels.h"
 #ifdef LF_TIMING   // per-phase wall-clock timers of wave 0 (tools/lf_timing.py; a measurement build, never the shipped library)
-__device__ unsigned long long lf_dbg[16];
-#define LF_T(i) { const long long now_ = wall_clock64(); if (L.wave == 0 && L.lane == 0) atomicAdd(&lf_dbg[i], (unsigned long long)(now_ - tp_)); tp_ = now_; }
+// -DLF_TWICE on top: every workgroup runs its pass a second time (results are garbage: x += ... twice) with its timers in slots 16..31 — the same
+// instructions on the same data, but fetched from a warm instruction cache: what the straight-line, executed-once code of a pass costs in fetches.
+__device__ unsigned long long lf_dbg[32];
+#define LF_T(i) { const long long now_ = wall_clock64(); if (L.wave == 0 && L.lane == 0) atomicAdd(&lf_dbg[L.tb + i], (unsigned long long)(now_ - tp_)); tp_ = now_; }
 extern "C" void airfe_dbg_lf(unsigned long long* out, int reset) {
-  if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(lf_dbg), z, sizeof(z)); }
-  else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lf_dbg), 16 * sizeof(unsigned long long));
+  if (reset) { unsigned long long z[32] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(lf_dbg), z, sizeof(z)); }
+  else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lf_dbg), 32 * sizeof(unsigned long long));
 }
 #else
 #define LF_T(i)
@@ -221,6 +223,9 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
 
 struct LfLane {                       // per-lane constants of the whole kernel
   int lane, wave, l15, g, wf, cb, tp, fo0, fo1;
+#ifdef LF_TIMING
+  int tb;
+#endif
   const char *wob, *w1b, *w2b;
 };
 
@@ -236,7 +241,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   const int lane = L.lane, wave = L.wave, l15 = L.l15, g = L.g, wf = L.wf, cb = L.cb, tp = L.tp, fo0 = L.fo0, fo1 = L.fo1;
 #ifdef LF_TIMING
   long long tp_ = wall_clock64();
-  if (wave == 0 && lane == 0) atomicAdd(&lf_dbg[15], 1ull);
+  if (wave == 0 && lane == 0) atomicAdd(&lf_dbg[L.tb + 15], 1ull);
 #endif
   typename P::vec8 c2[2][2], c4[4][2];                            // A fragments in flight: 32-feature GEMMs / the 64-feature one
   lf_first<P, 2>(c2, L.wob + fo0, L.wob + fo1);
@@ -527,7 +532,16 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
 
   const int row0 = blockIdx.x * (16 * NMT);
   lf_stage_rows(a.attn, row0, NMT, LF_R0, L.wave, L.lane);
+#ifdef LF_TIMING
+  L.tb = 0;
+#endif
   lf_pass<P, NMT, RELU, FOLD>(a, smem, L, row0);
+#ifdef LF_TWICE
+  __syncthreads();
+  L.tb = 16;
+  lf_stage_rows(a.attn, row0, NMT, LF_R0, L.wave, L.lane);
+  lf_pass<P, NMT, RELU, FOLD>(a, smem, L, row0);
+#endif
 }
 
 template <class P, int NMT, bool RELU, int FOLD = 0>

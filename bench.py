@@ -85,9 +85,10 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=
 
 
 def latency_b1(args, rank, world, local, dev):
-    """--workload b1: what ONE stereo keyframe costs through the reference-shaped batch-1 host API — the regime AirSLAM's feature thread runs in
-    (map_builder.cc:83-109: Detect(left, right, features, lines, junctions) + MatchingPoints, one pair at a time, host buffers in and out, one
-    synchronisation per call).  Prints p50 / p99 / mean of the pair and of its three calls; `value` = 1000 / p50 (pairs/s of a single stream)."""
+    """--workload b1: what ONE stereo keyframe costs through the batch-1 host API — the regime AirSLAM's feature thread runs in
+    (map_builder.cc:83-109: Detect(left, right, features, lines, junctions) + MatchingPoints, one pair at a time, host buffers in and out).
+    Prints p50 / p99 / mean of the keyframe as one call (airfe_stereo_keyframe), as the reference's two calls and as three (infer, infer, match);
+    `value` = 1000 / p50 of the one-call form (pairs/s of a single stream)."""
     from airslam_amd import api, synth, weights
     H, W, K = args.height, args.width, args.max_keypoints
     root = os.path.dirname(os.path.abspath(__file__))
@@ -101,7 +102,8 @@ def latency_b1(args, rank, world, local, dev):
                       **(dict(superglue=mw) if sg else dict(lightglue=mw)))
     det, pm = api.FeatureDetector(ctx), api.PointMatcher(ctx, W, H, 1 if sg else 0)
     pairs = [synth.stereo_pair(H, W, 1000 + i) for i in range(8)]
-    t_l, t_r, t_m, nmatch, nlines = [], [], [], [], []
+    t_l, t_r, t_m, t_k, t_d2, t_m2, nmatch, nlines = [], [], [], [], [], [], [], []
+    fused = plnet and not sg                                       # airfe_stereo_keyframe: the PLNet + LightGlue keyframe (map_builder.cc:85-86)
     for i in range(args.warmup + args.steps):
         left, right = pairs[i % len(pairs)]
         acc = []
@@ -117,23 +119,39 @@ def latency_b1(args, rank, world, local, dev):
         t2 = time.perf_counter()
         n, _ = pm.MatchingPoints(fl, fr)
         t3 = time.perf_counter()
+        if fused:
+            k = ctx.stereo_keyframe(left, right)                                         # the same keyframe as ONE call
+            t4 = time.perf_counter()
+            okk, fl2, fr2, _ = det.DetectKeyframe(left, right, [], [])                   # ... and as the reference's own two calls
+            t5 = time.perf_counter()
+            n2, _ = pm.MatchingPoints(fl2, fr2)
+            t6 = time.perf_counter()
+            assert len(k["idx"]) == n == n2 and len(k["linesL"]) == len(acc)
         if i >= args.warmup:
             t_l.append(t1 - t0); t_r.append(t2 - t1); t_m.append(t3 - t2); nmatch.append(n); nlines.append(len(acc))
+            if fused:
+                t_k.append(t4 - t3); t_d2.append(t5 - t4); t_m2.append(t6 - t5)
     pair = np.array(t_l) + np.array(t_r) + np.array(t_m)
 
     def pct(a):
         a = np.asarray(a) * 1e3
         return {"p50": float(np.percentile(a, 50)), "p99": float(np.percentile(a, 99)), "mean": float(a.mean())}
 
-    out = {"metric": "batch-1 stereo keyframe latency through the host API (" + ("PLNet points + lines, junctions on the left" if plnet else "SuperPoint")
-                     + " x2 + " + ("SuperGlue" if sg else "LightGlue") + "; host images in, host matrices out, PCIe and one synchronisation per call included)",
-           "value": 1e3 / pct(pair)["p50"], "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": pct(pair)["p50"],
+    lat = {"pair": pct(t_k) if fused else pct(pair), "three_calls": {"pair": pct(pair), "detect_left": pct(t_l), "detect_right": pct(t_r), "match": pct(t_m)}}
+    if fused:
+        lat["two_calls"] = {"pair": pct(np.array(t_d2) + np.array(t_m2)), "detect_stereo": pct(t_d2), "match": pct(t_m2)}
+    head = lat["pair"]["p50"]
+    out = {"metric": "batch-1 stereo keyframe latency, host images in / host matrices out, PCIe and synchronisation included ("
+                     + ("PLNet points + lines, junctions on the left" if plnet else "SuperPoint") + " x2 + " + ("SuperGlue" if sg else "LightGlue") + "): "
+                     + ("ONE call (airfe_stereo_keyframe = map_builder.cc:85-86); latency_ms also has the same keyframe as the reference's two calls "
+                        "(stereo Detect overload + MatchingPoints) and as three (PLNet::infer twice + MatchingPoints), identical results" if fused
+                        else "three reference-shaped calls (detect, detect, MatchingPoints)"),
+           "value": 1e3 / head, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype if args.dtype == args.matcher_dtype else f"{args.dtype} (encoder) + {args.matcher_dtype} (matcher), fp32 accumulate",
-           "data": "synthetic",
-           "latency_ms": {"pair": pct(pair), "detect_left": pct(t_l), "detect_right": pct(t_r), "match": pct(t_m)},
-           "config": {"workload": f"ONE synthetic {W}x{H} stereo pair per step through the reference-shaped host API (airslam_amd.api.FeatureDetector / PointMatcher "
-                                  f"over the C ABI's batch-1 entries), max_keypoints={K}; seeded synthetic weights (reference ONNX files are absent)",
+           "data": "synthetic", "latency_ms": lat,
+           "config": {"workload": f"ONE synthetic {W}x{H} stereo pair per step through the batch-1 host API (airslam_amd.api over the C ABI's host-buffer entries), "
+                                  f"max_keypoints={K}; seeded synthetic weights (reference ONNX files are absent)",
                       "matches_mean": float(np.mean(nmatch)), "lines_mean_left": float(np.mean(nlines)), "detector": args.detector, "matcher": args.matcher},
            "roofline": None, "cpu_baseline": None, "collective": None}
     if rank == 0:

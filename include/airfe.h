@@ -93,6 +93,19 @@ int airfe_has_line_branch(const airfe_ctx* ctx); /* 1 when the detector pack car
 int airfe_detect_plnet(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int stride, const airfe_plnet_stage0* stage0,
                        float* feat, int cap, int* n, double* lines, int capL, int* nlines, float* junc, int capJ,
                        int* njunc, int want_junctions);
+/* ONE stereo keyframe through host buffers — the batch-1 entry for what src/map_builder.cc:85-86 does in two facade calls:
+ *   _feature_detector->Detect(left, right, left_features, right_features, left_lines, right_lines, junctions)   (feature_detector.cc:97-108:
+ *   PLNet::infer on the left image with junctions, on the right one without) and _point_matcher->MatchingPoints(left_features, right_features,
+ *   stereo_matches, false) (point_matcher.cc:50-107 with LightGlue).
+ * Both images go up in one copy, the detector runs over them as one batch of two, the line path runs beside LightGlue, the results come back in
+ * two copies.  Per image / per pair the outputs are the bits airfe_detect_plnet x2 + airfe_match_lightglue (on NormalizeKeypoints'ed rows) return:
+ *   featL / featR [cap >= max_keypoints][259] rows {score, x, y, desc[256]} + *nL / *nR;  linesL / linesR [capL][4] doubles + counts;
+ *   juncL [capJ][259] + *njuncL (NULL: no junction detection);  match_idx [mcap >= max_keypoints][2] (left, right), match_score (the reference's
+ *   DMatch::distance is 1 - score), *nmatch — match_idx == NULL: detection only (the 7-argument Detect overload alone).
+ * Needs a detector arena of two images (cfg.max_batch >= 2, or the detector and LightGlue packs both loaded) and fp16 / bf16 arithmetic. */
+int airfe_stereo_keyframe(airfe_ctx* ctx, const uint8_t* left, const uint8_t* right, int h, int w, int stride, float* featL, float* featR, int cap,
+                          int* nL, int* nR, double* linesL, double* linesR, int capL, int* nlinesL, int* nlinesR, float* juncL, int capJ,
+                          int* njuncL, int32_t* match_idx, float* match_score, int mcap, int* nmatch);
 
 /* ≙ SuperPointLightGlue::infer (src/light_glue.cpp:120-170).  f0/f1: [n][258] rows = (x,y already normalised by
  *   PointMatcher::NormalizeKeypoints, d0..d255) — the contiguous temporary Eigen makes for bottomRows(258)

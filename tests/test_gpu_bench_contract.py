@@ -89,3 +89,5 @@ def test_b1_latency_line():
     lat = d["latency_ms"]
     assert lat["pair"]["p50"] > 0 and lat["pair"]["p99"] >= lat["pair"]["p50"] and abs(d["value"] - 1e3 / lat["pair"]["p50"]) < 1e-6 * d["value"]
     assert d["config"]["matches_mean"] > 50 and d["config"]["lines_mean_left"] >= 50
+    # the one-call keyframe is the headline; the reference's two- and three-call forms of the same keyframe are beside it
+    assert lat["three_calls"]["pair"]["p50"] > lat["two_calls"]["pair"]["p50"] > lat["pair"]["p50"] > 0

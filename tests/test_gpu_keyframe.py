@@ -1,0 +1,84 @@
+"""airfe_stereo_keyframe: ONE call for what map_builder.cc:85-86 does in two façade calls (Detect(left, right, ..., junctions) = PLNet::infer twice,
+feature_detector.cc:97-108, then MatchingPoints) — both images as one detector batch, the line path beside LightGlue.  Per image and per pair it must
+return the bits the separate batch-1 entries return: it is a different QUEUE of the same kernels, not a different computation."""
+import os
+
+import numpy as np
+import pytest
+
+from airslam_amd import api, synth, weights
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(W, H, **kw):
+    return api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(GOLDEN, "plnet_s1.airfe"),
+                       lightglue=weights.synthetic_lightglue(1234), max_batch=2, enc_chunk=2, max_keypoints=400, image_width=W, image_height=H,
+                       precision=1, matcher_precision=1, **kw)
+
+
+@pytest.mark.parametrize("W,H,seed", [(752, 480, 1000), (752, 480, 1003), (640, 480, 7)])
+def test_one_call_equals_the_three_calls(W, H, seed):
+    left, right = synth.stereo_pair(H, W, seed)
+    ctx = _ctx(W, H)
+    det, pm = api.FeatureDetector(ctx), api.PointMatcher(ctx, W, H, 0)
+    ll, lr = [], []
+    ok, fl, jl = det.DetectLines(left, None, ll, junction_detection=True)
+    ok2, fr, _ = det.DetectLines(right, None, lr, junction_detection=False)
+    n, matches = pm.MatchingPoints(fl, fr)
+    assert ok and ok2 and n > 50 and len(ll) >= 50 and len(lr) >= 50 and jl.shape[1] >= 50
+    for rep in range(2):                                                           # (twice: the second call reuses every block the first one grew)
+        k = ctx.stereo_keyframe(left, right)
+        np.testing.assert_array_equal(k["featL"], fl.T)
+        np.testing.assert_array_equal(k["featR"], fr.T)
+        np.testing.assert_array_equal(k["linesL"], np.array(ll))
+        np.testing.assert_array_equal(k["linesR"], np.array(lr))
+        np.testing.assert_array_equal(k["juncL"], jl.T)
+        np.testing.assert_array_equal(k["idx"], np.array([(m[0], m[1]) for m in matches], np.int32))
+        np.testing.assert_array_equal((np.float32(1.0) - k["score"]).astype(np.float32), np.array([m[2] for m in matches], np.float32))
+    # the two-call form (the 7-argument Detect overload + MatchingPoints)
+    l2, r2 = [], []
+    ok, fl2, fr2, jl2 = det.DetectKeyframe(left, right, l2, r2)
+    assert ok and l2 == ll and r2 == lr
+    np.testing.assert_array_equal(fl2, fl)
+    np.testing.assert_array_equal(fr2, fr)
+    np.testing.assert_array_equal(jl2, jl)
+    # without junction detection: same points and lines
+    k = ctx.stereo_keyframe(left, right, match=False, want_junctions=False)
+    assert "idx" not in k and len(k["juncL"]) == 0
+    np.testing.assert_array_equal(k["featL"], fl.T)
+    np.testing.assert_array_equal(k["linesR"], np.array(lr))
+    ctx.close()
+
+
+def test_strided_views_and_argument_errors():
+    W, H = 752, 480
+    left, right = synth.stereo_pair(H, W, 1001)
+    ctx = _ctx(W, H)
+    want = ctx.stereo_keyframe(left, right)
+    big = np.zeros((H, 2 * W + 64), np.uint8)                                      # both images as views into one wider buffer (cv::Mat ROIs)
+    big[:, :W] = left
+    big[:, W + 64:] = right
+    got = ctx.stereo_keyframe(big[:, :W], big[:, W + 64:])
+    for key in want:
+        np.testing.assert_array_equal(got[key], want[key])
+    with pytest.raises(api.AirfeError):
+        ctx.stereo_keyframe(left, right[:-8])
+    with pytest.raises(api.AirfeError):
+        ctx.stereo_keyframe(left, np.zeros((0, 0), np.uint8))
+    with pytest.raises(api.AirfeError, match="do not fit"):
+        ctx.stereo_keyframe(left, right, cap_lines=8)
+    # and the context is usable afterwards
+    again = ctx.stereo_keyframe(left, right)
+    np.testing.assert_array_equal(again["idx"], want["idx"])
+    ctx.close()
+
+
+def test_needs_an_arena_of_two_images():
+    ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(GOLDEN, "plnet_s1.airfe"), max_batch=1, max_keypoints=400,
+                      image_width=752, image_height=480, precision=1)
+    left, right = synth.stereo_pair(480, 752, 1000)
+    with pytest.raises(api.AirfeError, match="arena of two images"):
+        ctx.stereo_keyframe(left, right, match=False)
+    ctx.close()

@@ -2,7 +2,8 @@
 Needs a build of kernels_lgblockf.hip with -DLF_TIMING linked as airslam_amd/libairfe_T.so.tmp:
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DLF_TIMING -c airslam_amd/csrc/kernels_lgblockf.hip -o /tmp/lf_T.o
     hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_T.so.tmp /tmp/lf_T.o <the other objects of airslam_amd/csrc/build>
-    python tools/lf_timing.py [pairs ...]        (on an MI355X; it copies the variant over libairfe.so of the working copy)"""
+    python tools/lf_timing.py [pairs ...]        (on an MI355X; it copies the variant over libairfe.so of the working copy)
+With -DLF_TIMING -DLF_TWICE every workgroup runs its pass twice and the second run's timers are printed beside the first's (LF_TWICE=1 in the environment)."""
 import ctypes as C, os, subprocess, sys
 import numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
@@ -23,7 +24,7 @@ for pairs in [int(v) for v in sys.argv[1:]] or [1, 8, 64]:
     for _ in range(3):
         ctx.match_lightglue_batch_dev(a, n, b, n, idx, sc, nm)
     ctx.sync()
-    out = (C.c_ulonglong * 16)()
+    out = (C.c_ulonglong * 32)()
     lib = _lib.lib()
     lib.airfe_dbg_lf(out, 1)
     reps = 5
@@ -32,8 +33,9 @@ for pairs in [int(v) for v in sys.argv[1:]] or [1, 8, 64]:
     ctx.sync()
     lib.airfe_dbg_lf(out, 0)
     t = np.array(out[:12], dtype=np.float64); wgs = float(out[15])
-    print(f"\n{pairs} pairs ({pairs * 800} tokens): {int(wgs / reps / 18)} workgroups per launch, 18 launches per forward; per workgroup, wave 0 (us):")
+    t2 = np.array(out[16:28], dtype=np.float64); twice = out[31] > 0
+    print(f"\n{pairs} pairs ({pairs * 800} tokens): {int(wgs / reps / 18)} workgroups per launch, 18 launches per forward; per workgroup, wave 0 (us)" + (" | the same pass run again by the same workgroup:" if twice else ":"))
     for i, nme in enumerate(names):
-        print(f"  {nme:75s} {t[i] / wgs / 100.0:7.2f}")
-    print(f"  {'total':75s} {t.sum() / wgs / 100.0:7.2f}")
+        print(f"  {nme:75s} {t[i] / wgs / 100.0:7.2f}" + (f" | {t2[i] / wgs / 100.0:7.2f}" if twice else ""))
+    print(f"  {'total':75s} {t.sum() / wgs / 100.0:7.2f}" + (f" | {t2.sum() / wgs / 100.0:7.2f}" if twice else ""))
     ctx.close()
