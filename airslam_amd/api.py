@@ -201,23 +201,21 @@ class Context:
             raise AirfeError("stereo_keyframe: left and right images differ in size")
         if any(g.strides[1] != 1 or g.strides[0] < g.shape[1] for g in imgs) or imgs[0].strides[0] != imgs[1].strides[0]:
             imgs = [np.ascontiguousarray(g) for g in imgs]
-        k = self._kf_bufs.get((cap_lines, cap_junc)) if hasattr(self, "_kf_bufs") else None
-        if k is None:
-            cap = self.np_rows
-            k = dict(fl=np.empty((cap, FEAT), np.float32), fr=np.empty((cap, FEAT), np.float32), ll=np.empty((cap_lines, 4), np.float64),
-                     lr=np.empty((cap_lines, 4), np.float64), jl=np.empty((cap_junc, FEAT), np.float32), idx=np.empty((cap, 2), np.int32),
-                     sc=np.empty((cap,), np.float32), n=(C.c_int * 6)())
-            self._kf_bufs = {(cap_lines, cap_junc): k}
-        n = k["n"]
+        # fresh output arrays, filled by the library directly (like the reference's caller-owned Eigen matrices): the slices returned below own them
+        cap = self.np_rows
+        fl, fr = np.empty((cap, FEAT), np.float32), np.empty((cap, FEAT), np.float32)
+        ll, lr = np.empty((cap_lines, 4), np.float64), np.empty((cap_lines, 4), np.float64)
+        jl = np.empty((cap_junc if want_junctions else 0, FEAT), np.float32)
+        idx, sc = np.empty((cap if match else 0, 2), np.int32), np.empty((cap if match else 0,), np.float32)
+        n = (C.c_int * 6)()
         p = lambda i: C.cast(C.byref(n, 4 * i), C.POINTER(C.c_int))
         self._chk(self._l.airfe_stereo_keyframe(self._h, imgs[0].ctypes.data, imgs[1].ctypes.data, imgs[0].shape[0], imgs[0].shape[1], imgs[0].strides[0],
-                                                k["fl"].ctypes.data, k["fr"].ctypes.data, self.np_rows, p(0), p(1), k["ll"].ctypes.data, k["lr"].ctypes.data,
-                                                cap_lines, p(2), p(3), k["jl"].ctypes.data if want_junctions else None, cap_junc, p(4),
-                                                k["idx"].ctypes.data if match else None, k["sc"].ctypes.data, self.np_rows, p(5)), "airfe_stereo_keyframe")
-        out = dict(featL=k["fl"][:n[0]].copy(), featR=k["fr"][:n[1]].copy(), linesL=k["ll"][:n[2]].copy(), linesR=k["lr"][:n[3]].copy(),
-                   juncL=k["jl"][:n[4]].copy())
+                                                fl.ctypes.data, fr.ctypes.data, cap, p(0), p(1), ll.ctypes.data, lr.ctypes.data, cap_lines, p(2), p(3),
+                                                jl.ctypes.data if want_junctions else None, cap_junc, p(4), idx.ctypes.data if match else None,
+                                                sc.ctypes.data, cap, p(5)), "airfe_stereo_keyframe")
+        out = dict(featL=fl[:n[0]], featR=fr[:n[1]], linesL=ll[:n[2]], linesR=lr[:n[3]], juncL=jl[:n[4]])
         if match:
-            out["idx"], out["score"] = k["idx"][:n[5]].copy(), k["sc"][:n[5]].copy()
+            out["idx"], out["score"] = idx[:n[5]], sc[:n[5]]
         return out
 
     def debug_plnet_stage0(self):

@@ -82,3 +82,28 @@ def test_needs_an_arena_of_two_images():
     with pytest.raises(api.AirfeError, match="arena of two images"):
         ctx.stereo_keyframe(left, right, match=False)
     ctx.close()
+
+
+def test_graph_replay_gives_the_same_bits(monkeypatch):
+    """AIRFE_KF_GRAPH=1: call 1 runs plainly, call 2 captures the queue as a hipGraph, later calls replay it — on other images, with other entries of the same
+    context in between (their host-side flags must not leak into the replay, nor the replay's into them)."""
+    W, H = 752, 480
+    pairs = [synth.stereo_pair(H, W, 1000 + i) for i in range(3)]
+    plain = _ctx(W, H)
+    want = [plain.stereo_keyframe(*p) for p in pairs]
+    want_pts = plain.detect_points(pairs[1][0])
+    plain.close()
+    monkeypatch.setenv("AIRFE_KF_GRAPH", "1")
+    ctx = _ctx(W, H)
+    for i in range(7):
+        got = ctx.stereo_keyframe(*pairs[i % 3])
+        for key in want[i % 3]:
+            np.testing.assert_array_equal(got[key], want[i % 3][key], err_msg=f"call {i} {key}")
+        if i in (2, 4):
+            np.testing.assert_array_equal(ctx.detect_points(pairs[1][0]), want_pts)
+    # another configuration (no junctions, no match) re-captures
+    for i in range(3):
+        got = ctx.stereo_keyframe(*pairs[i], match=False, want_junctions=False)
+        np.testing.assert_array_equal(got["featR"], want[i]["featR"])
+        np.testing.assert_array_equal(got["linesL"], want[i]["linesL"])
+    ctx.close()
