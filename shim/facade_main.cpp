@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "airfe_keyframe.h"
 #include "feature_detector.h"
 #include "point_matcher.h"
 #include "read_configs.h"
@@ -108,6 +109,31 @@ int main(int argc, char** argv) {
   Features empty;
   empty.resize(259, 0);
   if (pm.MatchingPoints(empty, fr, matches, false) != 0) return 13;      // src/point_matcher.cc:53-55
+  // the one-call keyframe (shim/include/airfe_keyframe.h) beside the two facade calls it stands for (overload 6 + MatchingPoints): PLNet + LightGlue only
+  if (!cfgs.plnet_config.use_superpoint && cfgs.point_matcher_config.matcher == 0) {
+    AirfeStereoKeyframe kf(cfgs.plnet_config, cfgs.point_matcher_config);
+    if (!kf.build()) return 14;
+    Features a, b, j;
+    std::vector<Eigen::Vector4d> la, lb;
+    std::vector<cv::DMatch> km;
+    for (int rep = 0; rep < 2; ++rep) {
+      la.clear(); lb.clear();
+      if (!kf.Process(left, right, a, b, la, lb, j, km)) return 15;
+    }
+    dump_features(od + "/k_featl.bin", a);
+    dump_features(od + "/k_featr.bin", b);
+    dump_lines(od + "/k_linesl.bin", la);
+    dump_lines(od + "/k_linesr.bin", lb);
+    dump_features(od + "/k_junc.bin", j);
+    std::vector<int> kq, kt;
+    std::vector<float> kd;
+    for (const auto& m : km) { kq.push_back(m.queryIdx); kt.push_back(m.trainIdx); kd.push_back(m.distance); }
+    dump(od + "/k_query.bin", kq.data(), kq.size());
+    dump(od + "/k_train.bin", kt.data(), kt.size());
+    dump(od + "/k_dist.bin", kd.data(), kd.size());
+    cv::Mat none2;
+    if (kf.Process(none2, right, a, b, la, lb, j, km)) return 16;
+  }
   std::printf("facade gpu: use_superpoint %d matcher %d: %ld/%ld keypoints, %d matches\n", cfgs.plnet_config.use_superpoint,
               cfgs.point_matcher_config.matcher, (long)fl.cols(), (long)fr.cols(), n);
   return 0;

@@ -140,3 +140,12 @@ def test_reference_facade_on_the_gpu_equals_the_c_abi(models, tmp_path, use_sp, 
     eq(rd("m_query.bin", np.int32), np.array([m[0] for m in matches], np.int32))
     eq(rd("m_train.bin", np.int32), np.array([m[1] for m in matches], np.int32))
     eq(rd("m_dist.bin", np.float32), np.array([m[2] for m in matches], np.float32))
+    if not use_sp and matcher == 0:
+        # the one-call keyframe class (shim/include/airfe_keyframe.h) == the two facade calls it stands for.  (The facade's matcher context is built for
+        # 1024 keypoints, the keyframe's for max_keypoints = 400: the arena size does not enter the arithmetic.)
+        eq(rd("k_featl.bin", np.float32, 259), pfl); eq(rd("k_featr.bin", np.float32, 259), pfr)
+        eq(rd("k_linesl.bin", np.float64, 4), pll); eq(rd("k_linesr.bin", np.float64, 4), plr)
+        eq(rd("k_junc.bin", np.float32, 259), pjl)
+        eq(rd("k_query.bin", np.int32), rd("m_query.bin", np.int32))
+        eq(rd("k_train.bin", np.int32), rd("m_train.bin", np.int32))
+        eq(rd("k_dist.bin", np.float32), rd("m_dist.bin", np.float32))
