@@ -218,6 +218,23 @@ class Context:
             out["idx"], out["score"] = idx[:n[5]], sc[:n[5]]
         return out
 
+    def track_frame(self, gray: np.ndarray, ref_feat=None):
+        """ONE tracked frame in one call (airfe_track_frame ≙ map_builder.cc:94-101): points of `gray` + LightGlue against the last keyframe's features
+        (`ref_feat` [n,259]: uploaded when given, kept on the device when None) -> (feat [n,259], idx [m,2] (reference, new), score [m])."""
+        gray = np.asarray(gray)
+        if gray.ndim != 2 or gray.dtype != np.uint8 or gray.size == 0:
+            raise AirfeError("empty image")
+        if gray.strides[1] != 1 or gray.strides[0] < gray.shape[1]:
+            gray = np.ascontiguousarray(gray)
+        cap = self.np_rows
+        feat, idx, sc = np.empty((cap, FEAT), np.float32), np.empty((cap, 2), np.int32), np.empty((cap,), np.float32)
+        n, nm = C.c_int(0), C.c_int(0)
+        ref = None if ref_feat is None else np.ascontiguousarray(ref_feat, dtype=np.float32).reshape(-1, FEAT)
+        self._chk(self._l.airfe_track_frame(self._h, gray.ctypes.data, gray.shape[0], gray.shape[1], gray.strides[0],
+                                            None if ref is None else ref.ctypes.data, 0 if ref is None else len(ref), feat.ctypes.data, cap, C.byref(n),
+                                            idx.ctypes.data, sc.ctypes.data, cap, C.byref(nm)), "airfe_track_frame")
+        return feat[:n.value], idx[:nm.value], sc[:nm.value]
+
     def debug_plnet_stage0(self):
         """The on-device stage-0 line branch of the last detected image: dict in synth.plnet_stage0_lines' layout + jloc / joff."""
         n = 3 * 128 * 128

@@ -255,6 +255,8 @@ struct airfe_ctx {
   // host-API staging
   uint8_t* st_img = nullptr; size_t st_img_bytes = 0;
   uint8_t* kf_blk = nullptr; size_t kf_bytes = 0;   // airfe_stereo_keyframe's device block (grows on demand)
+  uint8_t *tk_blk = nullptr, *ref_blk = nullptr; size_t tk_bytes = 0, ref_bytes = 0;   // airfe_track_frame: outputs; the last keyframe's features
+  int ref_n = -1;
   bool kf_graph_on = false;                         // AIRFE_KF_GRAPH
   KfGraph kf_graph;
   float *st_feat0 = nullptr, *st_feat1 = nullptr, *st_score = nullptr;
@@ -2462,6 +2464,71 @@ int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* righ
   }
   *nlinesL = nl0; *nlinesR = nl1;
   if (njuncL) *njuncL = want_j ? nj : 0;
+  return 0;
+}
+
+// ONE tracked frame through host buffers (batch 1): what map_builder.cc:94-101 does for every frame that is not a keyframe —
+//     _feature_detector->Detect(image_left_rect, left_features);
+//     _point_matcher->MatchingPoints(features_last_keyframe, left_features, matches, true);      (the F-RANSAC behind it stays the reference's)
+// — as one queue: the last keyframe's features live on the device (uploaded when ref_feat != NULL, i.e. once per keyframe, not once per frame), the
+// new frame's feature rows come back on the side stream while LightGlue runs.  Bits: those of airfe_detect_points + airfe_match_lightglue.
+int airfe_track_frame(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, const float* ref_feat, int n_ref, float* feat, int cap, int* n,
+                      int32_t* match_idx, float* match_score, int mcap, int* nmatch) {
+  AIRFE_ENTER(c);
+  if (!gray || h < 1 || w < 1) return fail(c, "empty image");
+  if (stride < w) return fail(c, "image stride smaller than its width");
+  if (!feat || !n || !match_idx || !match_score || !nmatch) return fail(c, "track_frame: bad argument");
+  if (cap < c->cfg.max_keypoints || mcap < c->cfg.max_keypoints) return fail(c, "feature / match capacity < max_keypoints");
+  if (!c->has_lg) return fail(c, "track_frame: LightGlue weights were not loaded (cfg.lightglue_pack)");
+  if (c->mprec == 2 || c->prec == 2) return fail(c, "track_frame runs in fp16 / bf16");
+  const int Np = c->cfg.max_keypoints;
+  if (ref_feat && (n_ref < 0 || n_ref > Np)) return fail(c, "track_frame: reference keypoint count exceeds max_keypoints");
+  *n = 0; *nmatch = 0;
+  hipStream_t st = c->stream;
+  const size_t fb = (size_t)Np * AIRFE_FEAT_DIM * 4, early = 64 + fb, late = early + 64;
+  // device block: [counts | new rows | idx | score] and the reference block [count | reference rows] (kept from call to call)
+  if (ensure_block(c, c->tk_blk, c->tk_bytes, 64 + fb + (size_t)Np * 12)) return 1;
+  if (ensure_block(c, c->ref_blk, c->ref_bytes, 64 + fb)) return 1;
+  int* cnt = reinterpret_cast<int*>(c->tk_blk);                       // {n_new, -, nmatch}
+  float* d_new = reinterpret_cast<float*>(c->tk_blk + 64);
+  int32_t* d_idx = reinterpret_cast<int32_t*>(c->tk_blk + 64 + fb);
+  float* d_sc = reinterpret_cast<float*>(c->tk_blk + 64 + fb + (size_t)Np * 8);
+  int* d_nref = reinterpret_cast<int*>(c->ref_blk);
+  float* d_ref = reinterpret_cast<float*>(c->ref_blk + 64);
+  const size_t ib = (size_t)(h - 1) * stride + w, ioff = (ib + 63) / 64 * 64;
+  if (ensure_stage_img(c, (size_t)h * stride)) return 1;
+  if (ensure_pin(c, std::max(ioff + 64 + fb, late + (size_t)Np * 12))) return 1;
+  memcpy(c->pin, gray, ib);
+  HIPCHK(c, hipMemsetAsync(cnt, 0, 64, st));
+  HIPCHK(c, hipMemcpyAsync(c->st_img, c->pin, ib, hipMemcpyHostToDevice, st));
+  if (ref_feat) {
+    *reinterpret_cast<int*>(c->pin + ioff) = n_ref;
+    if (n_ref > 0) memcpy(c->pin + ioff + 64, ref_feat, (size_t)n_ref * AIRFE_FEAT_DIM * 4);
+    HIPCHK(c, hipMemcpyAsync(c->ref_blk, c->pin + ioff, 64 + (size_t)n_ref * AIRFE_FEAT_DIM * 4, hipMemcpyHostToDevice, st));
+    c->ref_n = n_ref;
+  } else if (c->ref_n < 0) {
+    return fail(c, "track_frame: no reference features were ever given (ref_feat == NULL on the first call)");
+  }
+  if (detect_dev(c, c->st_img, 1, h, w, stride, (size_t)h * stride, d_new, Np, cnt, st)) return 1;
+  HIPCHK(c, hipEventRecord(c->ev_fork, st));                         // the new rows go home on the side stream, beside the matcher
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+  HIPCHK(c, hipMemcpyAsync(c->pin, c->tk_blk, early, hipMemcpyDeviceToHost, c->stream2));
+  HIPCHK(c, hipEventRecord(c->ev_feat, c->stream2));
+  if (lightglue_dev(c, d_ref, d_nref, d_new, cnt, 1, Np, AIRFE_FEAT_DIM, 1, 1, d_idx, d_sc, Np, cnt + 2, nullptr, st)) return 1;
+  HIPCHK(c, hipMemcpyAsync(c->pin + early, cnt, 64, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(c->pin + late, d_idx, (size_t)Np * 12, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipEventSynchronize(c->ev_feat));
+  const int nn = std::min(*reinterpret_cast<const int*>(c->pin), Np);
+  if (nn > 0) memcpy(feat, c->pin + 64, (size_t)nn * AIRFE_FEAT_DIM * 4);
+  *n = nn;
+  HIPCHK(c, hipStreamSynchronize(st));
+  if (nn < 1 || c->ref_n < 1) return 0;                              // point_matcher.cc:53-55
+  const int nm = std::min(reinterpret_cast<const int*>(c->pin + early)[2], Np);
+  if (nm > 0) {
+    memcpy(match_idx, c->pin + late, (size_t)nm * 8);
+    memcpy(match_score, c->pin + late + (size_t)Np * 8, (size_t)nm * 4);
+  }
+  *nmatch = nm;
   return 0;
 }
 

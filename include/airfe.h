@@ -106,6 +106,13 @@ int airfe_detect_plnet(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int st
 int airfe_stereo_keyframe(airfe_ctx* ctx, const uint8_t* left, const uint8_t* right, int h, int w, int stride, float* featL, float* featR, int cap,
                           int* nL, int* nR, double* linesL, double* linesR, int capL, int* nlinesL, int* nlinesR, float* juncL, int capJ,
                           int* njuncL, int32_t* match_idx, float* match_score, int mcap, int* nmatch);
+/* ONE tracked (non-keyframe) frame through host buffers — src/map_builder.cc:94-101: Detect(image_left_rect, left_features) followed by
+ * MatchingPoints(features_last_keyframe, left_features, matches, true) (the F-matrix RANSAC behind the matcher, point_matcher.cc:95-104, stays the
+ * reference's).  ref_feat [n_ref][259] = the last keyframe's features: uploaded when given, KEPT on the device when NULL (pass them once per keyframe);
+ * feat / *n = the new frame's features; match_idx [mcap][2] = (reference index, new index), match_score, *nmatch.  Same bits as airfe_detect_points +
+ * airfe_match_lightglue on NormalizeKeypoints'ed rows.  Needs the detector and LightGlue packs in one context, fp16 / bf16. */
+int airfe_track_frame(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int stride, const float* ref_feat, int n_ref, float* feat, int cap, int* n,
+                      int32_t* match_idx, float* match_score, int mcap, int* nmatch);
 
 /* ≙ SuperPointLightGlue::infer (src/light_glue.cpp:120-170).  f0/f1: [n][258] rows = (x,y already normalised by
  *   PointMatcher::NormalizeKeypoints, d0..d255) — the contiguous temporary Eigen makes for bottomRows(258)

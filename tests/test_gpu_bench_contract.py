@@ -91,3 +91,4 @@ def test_b1_latency_line():
     assert d["config"]["matches_mean"] > 50 and d["config"]["lines_mean_left"] >= 50
     # the one-call keyframe is the headline; the reference's two- and three-call forms of the same keyframe are beside it
     assert lat["three_calls"]["pair"]["p50"] > lat["two_calls"]["pair"]["p50"] > lat["pair"]["p50"] > 0
+    assert lat["tracked_frame"]["two_calls"]["p50"] > lat["tracked_frame"]["one_call"]["p50"] > 0

@@ -107,3 +107,34 @@ def test_graph_replay_gives_the_same_bits(monkeypatch):
         np.testing.assert_array_equal(got["featR"], want[i]["featR"])
         np.testing.assert_array_equal(got["linesL"], want[i]["linesL"])
     ctx.close()
+
+
+def test_track_frame_equals_detect_plus_match():
+    """airfe_track_frame ≙ map_builder.cc:94-101: Detect(image, features) + MatchingPoints(features_last_keyframe, features) as one call, the keyframe's
+    features kept on the device between frames."""
+    W, H = 752, 480
+    ctx = _ctx(W, H)
+    det, pm = api.FeatureDetector(ctx), api.PointMatcher(ctx, W, H, 0)
+    key, _ = synth.stereo_pair(H, W, 1000)
+    frames = [synth.stereo_pair(H, W, 1000)[1], synth.stereo_pair(H, W, 1001)[0], synth.stereo_pair(H, W, 1000)[0]]
+    ok, fk = det.Detect(key)
+    assert ok and fk.shape[1] >= 100
+    for i, img in enumerate(frames):
+        ok, f = det.Detect(img)
+        n, matches = pm.MatchingPoints(fk, f)
+        feat, idx, sc = ctx.track_frame(img, ref_feat=fk.T if i == 0 else None)      # reference uploaded once, then kept on the device
+        np.testing.assert_array_equal(feat, f.T)
+        np.testing.assert_array_equal(idx, np.array([(m[0], m[1]) for m in matches], np.int32).reshape(-1, 2))
+        np.testing.assert_array_equal((np.float32(1.0) - sc).astype(np.float32), np.array([m[2] for m in matches], np.float32))
+        assert i == 1 or n > 50                                                      # (frame 1 is another scene: few or no matches is fine)
+    # a new keyframe replaces the reference; an empty reference gives no matches (point_matcher.cc:53-55)
+    ok, f2 = det.Detect(frames[1])
+    feat, idx, sc = ctx.track_frame(frames[1], ref_feat=f2.T)
+    assert len(feat) >= len(idx) >= 100 and (idx[:, 0] == idx[:, 1]).all()          # a frame against itself: every match is (i, i)
+    feat, idx, sc = ctx.track_frame(frames[1], ref_feat=np.zeros((0, 259), np.float32))
+    assert len(idx) == 0 and len(feat) >= 100
+    ctx.close()
+    fresh = _ctx(W, H)
+    with pytest.raises(api.AirfeError, match="no reference features"):
+        fresh.track_frame(key)
+    fresh.close()
