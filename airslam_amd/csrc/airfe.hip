@@ -1,392 +1,9 @@
-// airfe — host side of libairfe.so: context, weight-pack loading and slab packing (≙ TensorRT engine
-// build, src/plnet.cpp:24-196), persistent device arena (replaces the per-call BufferManager of
-// 3rdparty/tensorrtbuffer/include/buffers.h:237-417) and the detect / match pipelines behind the C ABI.
-#include "../../include/airfe.h"
-#include "../../include/airfe_debug.h"
+// airfe — context life cycle, host staging and the C ABI of libairfe.so (include/airfe.h, include/airfe_debug.h); the pipelines behind it live in
+// airfe_load.hip / airfe_detect.hip / airfe_match.hip (see airfe_host.h).
+#include "airfe_host.h"
 
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "kernels.h"
-#include "common.h"
-
-using namespace airfe;
-
-namespace {
-
+namespace airfe_host {
 thread_local std::string g_err;
-
-struct Tensor {
-  std::vector<int> dims;
-  std::vector<float> data;
-};
-typedef std::map<std::string, Tensor> Pack;
-
-bool load_pack(const char* path, Pack& out, std::string& err) {
-  FILE* f = fopen(path, "rb");
-  if (!f) { err = std::string("cannot open weight pack ") + path; return false; }
-  fseek(f, 0, SEEK_END);
-  const long fsize = ftell(f);                     // every tensor's element count is bounded by what is left of the file
-  fseek(f, 0, SEEK_SET);
-  char magic[8];
-  uint32_t count = 0;
-  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "AIRFEPK1", 8) == 0 && fread(&count, 4, 1, f) == 1;
-  for (uint32_t i = 0; ok && i < count; ++i) {
-    uint32_t nl = 0, nd = 0;
-    ok = fread(&nl, 4, 1, f) == 1 && nl < 4096;
-    if (!ok) break;
-    std::string name(nl, '\0');
-    ok = fread(&name[0], 1, nl, f) == nl && fread(&nd, 4, 1, f) == 1 && nd <= 8;
-    if (!ok) break;
-    Tensor t;
-    size_t n = 1;
-    for (uint32_t d = 0; d < nd; ++d) {
-      uint32_t v = 0;
-      ok = ok && fread(&v, 4, 1, f) == 1;
-      t.dims.push_back((int)v);
-      if (v > 0x7FFFFFFFu || (v != 0 && n > (size_t)0x7FFFFFFFFFFFull / v)) ok = false;      // dims are untrusted
-      else n *= v;
-    }
-    const long pos = ftell(f);
-    if (!ok || pos < 0 || fsize < pos || n > (size_t)(fsize - pos) / 4) { ok = false; break; }
-    t.data.resize(n);
-    ok = fread(t.data.data(), 4, n, f) == n;
-    out[name] = std::move(t);
-  }
-  fclose(f);
-  if (!ok) err = std::string("malformed weight pack ") + path;
-  return ok;
-}
-
-// ---- 2-byte conversions (round to nearest even) on the host
-uint16_t f2bf(float f) {
-  uint32_t u;
-  memcpy(&u, &f, 4);
-  if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-uint16_t f2h(float f) {
-  uint32_t x;
-  memcpy(&x, &f, 4);
-  const uint32_t sign = (x >> 16) & 0x8000u;
-  int32_t e = (int32_t)((x >> 23) & 0xFF) - 127 + 15;
-  uint32_t m = x & 0x7FFFFFu;
-  if (((x >> 23) & 0xFF) == 0xFF) return (uint16_t)(sign | 0x7C00u | (m ? 0x200u : 0));
-  if (e >= 31) return (uint16_t)(sign | 0x7C00u);
-  if (e <= 0) {
-    if (e < -10) return (uint16_t)sign;
-    m |= 0x800000u;
-    const int shift = 14 - e;
-    uint32_t r = m >> shift;
-    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
-    if (rem > half || (rem == half && (r & 1u))) ++r;
-    return (uint16_t)(sign | r);
-  }
-  uint32_t r = ((uint32_t)e << 10) | (m >> 13);
-  const uint32_t rem = m & 0x1FFFu;
-  if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
-  return (uint16_t)(sign | r);
-}
-inline uint16_t cvt2(float f, int prec) { return prec == 1 ? f2h(f) : f2bf(f); }
-float h2f(uint16_t h) {
-  const uint32_t s = (uint32_t)(h & 0x8000u) << 16;
-  int e = (h >> 10) & 31;
-  uint32_t m = h & 0x3FFu;
-  uint32_t u;
-  if (e == 0) {
-    if (!m) u = s;
-    else {
-      e = 1;
-      while (!(m & 0x400u)) { m <<= 1; --e; }
-      m &= 0x3FFu;
-      u = s | ((uint32_t)(e + 112) << 23) | (m << 13);
-    }
-  } else if (e == 31) u = s | 0x7F800000u | (m << 13);
-  else u = s | ((uint32_t)(e + 112) << 23) | (m << 13);
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
-inline float back2(uint16_t v, int prec) {
-  if (prec == 1) return h2f(v);
-  uint32_t u = (uint32_t)v << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
-
-// ---- slab packer: [cbt][nslab] slabs of [64 rows][64 k], rows in MFMA order, swz128 chunk swizzle
-std::vector<uint16_t> pack_slabs(int cbt, int nslab, int prec, const std::function<float(int, int, int)>& get) {
-  std::vector<uint16_t> out((size_t)cbt * nslab * 4096, 0);
-  for (int cb = 0; cb < cbt; ++cb)
-    for (int s = 0; s < nslab; ++s) {
-      uint16_t* slab = out.data() + ((size_t)cb * nslab + s) * 4096;
-      for (int rr = 0; rr < 64; ++rr) {
-        const int feat = cb * 64 + slab_row_to_feature(rr);
-        for (int k = 0; k < 64; ++k) {
-          const int byte = rr * 128 + ((((k >> 3) ^ ((rr >> 1) & 7))) << 4) + (k & 7) * 2;
-          slab[byte >> 1] = cvt2(get(feat, s, k), prec);
-        }
-      }
-    }
-  return out;
-}
-
-// sqrt(scale * log2 e), scale = 1/sqrt(d_head) = 0.125: folded into BOTH the q and the k projection (weights and biases; rotary is
-// linear, so it commutes), so that q.k comes out of the attention MFMA as log2(e) * (q.k) / 8, ready for v_exp_f32 — the product of two
-// packed operands, each rounded once, exactly like the unscaled q and k were
-constexpr float ATT_QK_FOLD = 0.42466090014400953f;
-
-struct ConvW { uint16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; };
-struct LinW { uint16_t* w = nullptr; float* b = nullptr; int K = 0, N = 0, cbt = 0; };
-struct LgLayer {
-  LinW qk, v, out, ffn0, ffn3, cqk, cv, cout, cffn0, cffn3;
-  float *ln_g = nullptr, *ln_b = nullptr, *cln_g = nullptr, *cln_b = nullptr;
-};
-struct SgLayer { LinW qk, v, merge, mlp0, mlp3; };
-constexpr int LINE_CAP = 45056;     // unique candidate lines per image: 300 junctions give at most 300 * 299 / 2 = 44850 (min, max) pairs
-constexpr int KEEP_CAP = 3 * 128 * 128;
-constexpr int JUNC_CAP = 2048;
-// One image's stage-0 line tensors (SURVEY.md Appendix A.1 layouts) inside its stage block, in floats; the CHW loi_features of the
-// batch-1 / host-supplied path live in their own block (s0_loi): the batched path samples them from the head GEMM's rows instead.
-constexpr size_t SG_JUNCS = 0, SG_LP = 600, SG_KEEP = SG_LP + (size_t)KEEP_CAP * 4, SG_MIN = SG_KEEP + KEEP_CAP, SG_MAX = SG_MIN + KEEP_CAP,
-                 SG_THIN = SG_MAX + KEEP_CAP, SG_AUX = SG_THIN + 4 * 128 * 128, SG_STRIDE = (SG_AUX + 4 * 128 * 128 + 63) / 64 * 64;
-
-}  // namespace
-
-// airfe_stereo_keyframe's captured queue (one configuration at a time) and the host-side flags that describe what the queue leaves on the device
-struct airfe_ctx;
-struct KfState {
-  bool nms_map_valid, desc_normalised, desc_dense_valid, line_sparse; int last_B;
-  void save(const airfe_ctx* c);
-  void restore(airfe_ctx* c) const;
-};
-struct KfGraph {
-  struct Key {
-    int h, w, stride, capL, capJ; bool want_j, match; const void *pin, *blk, *img;
-    bool operator==(const Key& o) const {
-      return h == o.h && w == o.w && stride == o.stride && capL == o.capL && capJ == o.capJ && want_j == o.want_j && match == o.match && pin == o.pin &&
-             blk == o.blk && img == o.img;
-    }
-  } key{};
-  hipGraphExec_t exec = nullptr;
-  int seen = 0;
-  KfState state{};
-  void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; seen = 0; }
-};
-struct airfe_ctx {
-  airfe_cfg cfg;
-  std::string err;
-  hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;         // airfe_stereo_plnet_batch_dev: the line branch runs here while the matcher runs on the caller's stream
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_feat = nullptr;
-  bool overlap_lines = true;             // line path on stream2 beside the matcher (airfe_stereo_plnet_batch_dev); AIRFE_OVERLAP_LINES=0: one stream
-  std::vector<void*> allocs;
-  int prec = 0;                  // detector storage type
-  int mprec = 1;                 // matcher storage type (cfg.matcher_precision)
-  int pack_prec = 0;             // storage type make_linear packs for (set by each load_* before it packs)
-  int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
-  int lgb_tokens = 0;            // AIRFE_LGB_TOKENS: forces the fused block's tokens per workgroup (32 / 64 / 112 / 128)
-  // batch-1 host entries: ONE pinned host block and contiguous device blocks, so that a call is one H2D and one D2H (the reference's
-  // BufferManager does a cudaMalloc + one synchronous memcpy per binding and call: 3rdparty/tensorrtbuffer/include/buffers.h:237-417)
-  uint8_t* pin = nullptr;        // hipHostMalloc'ed
-  size_t pin_bytes = 0;
-  uint8_t *io_in = nullptr, *io_out = nullptr;   // device: [n0 n1 .. | feat0 | feat1] and [nmatch .. | idx | score]
-  bool trace_overflow = false;   // a trace slot was dropped (table full): trace_finish fails instead of mis-numbering launches
-  size_t arena_rows = 0;         // token rows of the matcher arena, slack included (alloc_matcher_arena)
-  int Dmax = 1;                  // images the detector arena holds: 2 x Bmax when a stereo step detects left and right as one batch
-  bool has_sp = false, has_lg = false;
-  uint8_t* pl_stage = nullptr;   // staging of airfe_assign_points_to_lines / airfe_match_lines
-  size_t pl_bytes = 0;
-  uint8_t* pl_scratch = nullptr; // scratch of their *_batch_dev forms (counts, bit rows, vote matrices)
-  size_t pl_scratch_bytes = 0;
-  bool nms_map_valid = true;     // heat_nms holds the last batch's NMS'd maps (large batches skip writing them)
-  bool force_nms_map = false;    // the batched PLNet path reads junction scores from them: written at every batch size while set
-  int Lmax = 1;                  // images the line-path arena holds (= Dmax)
-  bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
-  int gemm_small_max = 4096, gemm8_min = 16000, gemmr_min = 8192, gemmr_wgs = 256;   // GemmArgs::small_max / g8_min / gr_min / gr_wgs (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M, AIRFE_GEMMR_MIN_M, AIRFE_GEMMR_WGS)
-  int block_min = 0;             // tokens from which the fused LightGlue block is used (AIRFE_BLOCK_MIN_M).  Round 4: with 32- / 64-token passes for small
-                                 // token counts the fused kernel wins at EVERY size (profiles/r04_lg_small_batch_sweep.txt: 1 pair 0.70 vs 0.78 ms, 4 pairs 0.75 vs 1.20);
-                                 // with 112- / 128-token passes only (rounds 1-3) the four separate launches were quicker below 3200 tokens
-  bool qkv_pair = true;          // q|k and v of a layer in one streaming launch (AIRFE_QKV_PAIR=0: two launches)
-  int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
-  int sg_kenc_gemm = -1;         // AIRFE_SG_KENC_GEMM=0/1: SuperGlue keypoint encoder's large layers as scalar loops / GEMMs (default: by token count)
-  bool desc_dense_valid = true;  // c->desc holds the dense map of the last batch (else: the gather GEMM's rows)
-  int last_B = 0;
-  int* desc_idx = nullptr;       // row list of the descriptor head's gather GEMM
-  bool fold_qkv = true;          // AIRFE_FOLD_QKV=0: q | k | v projections as launches of their own (A/B runs)
-
-  // detector weights
-  float *c1a_w = nullptr, *c1a_b = nullptr;
-  ConvW c1b, c2a, c2b, c3a, c3b, c4a, c4b, cPa, cDa;
-  LinW cPb, cDb;
-  // detector arena
-  float* img32 = nullptr;
-  uint16_t *a1b = nullptr, *a2a = nullptr, *a2b = nullptr, *a3a = nullptr, *a3b = nullptr, *a4a = nullptr,
-           *a4b = nullptr, *aPa = nullptr, *aDa = nullptr;
-  float *logits = nullptr, *heat = nullptr, *heat_nms = nullptr, *nms_tmp = nullptr, *desc = nullptr;
-  unsigned char* nms_mask = nullptr;   // max_mask + supp_mask planes of the per-pool NMS launches
-  int *xtab = nullptr, *ytab = nullptr;
-  float* lut = nullptr;
-  unsigned long long* cand = nullptr;   // [Bmax][512*512] detect_point candidate keys
-  int* cand_cnt = nullptr;
-  int tab_w = -1, tab_h = -1;
-  // BoW vocabulary tree
-  float *bow_desc = nullptr, *bow_weight = nullptr, *bow_outw = nullptr;
-  std::vector<double> bow_weight_h;   // the vocabulary's WordValue weights as the reference holds them (double): the host entry returns these
-  int* bow_outn = nullptr;            // leaf node per feature of the last host call
-  int *bow_first = nullptr, *bow_nch = nullptr, *bow_word = nullptr;
-  unsigned* bow_out = nullptr;
-  int bow_nodes = 0;
-  // rectification maps of Camera (camera.cc:60-75), one pair per side, and the rectified-image staging
-  float* rmap[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-  int rmap_h[2] = {0, 0}, rmap_w[2] = {0, 0};
-  uint8_t* st_rect = nullptr; size_t st_rect_bytes = 0;
-  // host-API staging
-  uint8_t* st_img = nullptr; size_t st_img_bytes = 0;
-  uint8_t* kf_blk = nullptr; size_t kf_bytes = 0;   // airfe_stereo_keyframe's device block (grows on demand)
-  uint8_t *tk_blk = nullptr, *ref_blk = nullptr; size_t tk_bytes = 0, ref_bytes = 0;   // airfe_track_frame: outputs; the last keyframe's features
-  int ref_n = -1;
-  bool kf_graph_on = false;                         // AIRFE_KF_GRAPH
-  KfGraph kf_graph;
-  float *st_feat0 = nullptr, *st_feat1 = nullptr, *st_score = nullptr;
-  int *st_n0 = nullptr, *st_n1 = nullptr, *st_nm = nullptr;
-  int32_t* st_idx = nullptr;
-  float* st_scores_full = nullptr;
-
-  // LightGlue
-  std::vector<LgLayer> lg;
-  LinW lg_final;
-  float *lg_wr = nullptr, *lg_mw = nullptr;
-  float lg_mb = 0.f;
-  float *x32 = nullptr, *rot_cos = nullptr, *rot_sin = nullptr, *zbuf = nullptr, *simbuf = nullptr, *rowlse = nullptr,
-        *collse = nullptr, *rowval = nullptr;
-  uint16_t *xb = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *ob = nullptr, *msg = nullptr, *hb = nullptr,
-           *mdb = nullptr;
-  int *lens = nullptr, *rowarg = nullptr, *colarg = nullptr;
-  bool has_arena = false;
-
-  // SuperGlue
-  bool has_sg = false;
-  std::vector<SgLayer> sg;
-  LinW sg_final;
-  float sg_alpha = 1.f;
-  const float* sg_kenc[10] = {nullptr};
-  LinW sg_k3, sg_k4;             // keypoint-encoder layers 3 (128 -> 256) and 4 (256 -> 256) for the GEMM path
-  int Lz = 0;
-  float *sg_u = nullptr, *sg_v = nullptr, *sg_Z = nullptr, *sg_max0 = nullptr, *sg_ms0 = nullptr, *sg_ms1 = nullptr;
-  int *sg_idx0 = nullptr, *sg_idx1 = nullptr;
-  float* sg_xch = nullptr;       // [P][2][16][Lz] (max, sum) column partials of the register-resident Sinkhorn kernel
-  unsigned* sg_cnt = nullptr;    // per-pair rendezvous counters of the fused Sinkhorn kernel
-  int32_t *sg_out0 = nullptr, *sg_out1 = nullptr;
-
-  // fp32 correctness path (cfg.precision = 2 / matcher_precision = 2): fp32 weights and activations, kernels_f32.hip
-  struct F32Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; };
-  struct F32Lin { float* w = nullptr; float* b = nullptr; int K = 0, N = 0; };
-  struct F32LgLayer { F32Lin qkv, out, ffn0, ffn3, cqk, cv, cout, cffn0, cffn3; float *ln_g, *ln_b, *cln_g, *cln_b; };
-  F32Conv f_c1b, f_c2a, f_c2b, f_c3a, f_c3b, f_c4a, f_c4b, f_cPa, f_cDa, f_cL1;
-  F32Lin f_cPb, f_cDb, f_cLh, f_lgfinal;
-  std::vector<F32LgLayer> f_lg;
-  int f_B = 0;                   // images per pass of the fp32 encoder (its activations are 4 bytes: 2 images at a time)
-  float *f1a = nullptr, *f1b = nullptr, *fp1 = nullptr, *f2a = nullptr, *f2b = nullptr, *fp2 = nullptr, *f3a = nullptr, *f3b = nullptr,
-        *fp3 = nullptr, *f4a = nullptr, *f4b = nullptr, *fPa = nullptr, *fDa = nullptr, *fL1 = nullptr;
-  float *m_qkv = nullptr, *m_ctx = nullptr, *m_msg = nullptr, *m_h = nullptr, *m_md = nullptr;
-  // PLNet stage-0 line branch (HAWP-style head on the shared trunk; weights ride in the detector pack as line.*)
-  bool has_s0 = false;
-  ConvW cL1;                     // line.conv1: 3x3 128 -> 128 on the conv3a features
-  LinW cLh;                      // line.head : 1x1 128 -> 145 = loi (128) | md0-2 dis res | jloc0-1 | joffx joffy | thin0-3 | aux0-3
-  LinW cLh_loi, cLh_dec;         // the same rows as two heads: the 128 LOI channels (run on the junctions' tap rows only) and the 17 decoded ones
-  bool line_sparse = false;      // the last line_branch_dev ran the split heads (else: the fused head over one image, l_head)
-  float* l_dec = nullptr;        // [Lmax][128*128][32]: the 17-channel head
-  int* l_ridx = nullptr;         // [Lmax * 1200 (+ pad)]: tap rows of the junctions
-  float* l_lrows = nullptr;      // [Lmax * 1200 (+ pad)][128]: LOI features of those rows
-  uint16_t* l_feat = nullptr;    // [Lmax][128*128][128] 2-byte
-  float *l_ta8 = nullptr /*[Lmax][128*128][8] thin | aux pixel-major*/, *l_head = nullptr, *l_jloc = nullptr, *l_jnms = nullptr, *l_joff = nullptr, *l_sel = nullptr;
-  int* l_nsel = nullptr;
-  unsigned long long* l_cand = nullptr;   // [Lmax][128*128] junction candidates (its own list: the line branch may run beside the point branch's tail)
-  int* l_cand_cnt = nullptr;
-  // PLNet stage 1 + line path
-  bool has_s1 = false;
-  const float* s1_w[11] = {nullptr};
-  int *wf_table = nullptr, *wf_keep = nullptr, *wf_pairs = nullptr, *wf_rep = nullptr, *wf_counts = nullptr;
-  float *s1_la = nullptr, *s1_sc = nullptr, *s1_jfeat = nullptr /*[Lmax][300][256]*/, *s0_stage = nullptr /*[Lmax][SG_STRIDE]*/, *s0_loi = nullptr /*CHW [128][128][128], one image*/,
-        *junc_feat = nullptr;
-  unsigned char* jmap = nullptr;
-  double* d_lines = nullptr;
-  int *d_nlines = nullptr /*[Lmax] kept | [Lmax] found*/, *d_njunc = nullptr /*[Lmax] kept | [Lmax] found | [Lmax][64] scan scratch*/;
-
-  // fault hunting (airfe_debug_trace*): checksums of the matcher's state behind every launch of lightglue_dev
-  struct TraceSlot { std::string name; unsigned off, units, unit_words; const void* p; size_t words; };
-  bool trace_on = false, trace_halt = false;
-  int trace_stop = -1;           // >= 0: the forward pass returns right behind this slot (its buffer stays as that launch left it)
-  unsigned long long *trace_tab = nullptr, *trace_dig = nullptr;
-  unsigned* trace_off = nullptr;
-  size_t trace_cap = 0;
-  std::vector<TraceSlot> trace_slots;
-  std::vector<unsigned> trace_off_h;
-
-  // per-stage hipEvent timers (airfe_profile_*): events are recorded on the launch stream only
-  struct Mark { int stage; hipEvent_t a, b; double flops, bytes; };
-  uint32_t prof_mask = 0;        // bit i = stage i is bracketed by events
-  std::vector<Mark> marks;
-  std::vector<hipEvent_t> ev_pool;
-};
-void KfState::save(const airfe_ctx* c) {
-  nms_map_valid = c->nms_map_valid; desc_normalised = c->desc_normalised; desc_dense_valid = c->desc_dense_valid; line_sparse = c->line_sparse; last_B = c->last_B;
-}
-void KfState::restore(airfe_ctx* c) const {
-  c->nms_map_valid = nms_map_valid; c->desc_normalised = desc_normalised; c->desc_dense_valid = desc_dense_valid; c->line_sparse = line_sparse; c->last_B = last_B;
-}
-
-enum Stage {
-  ST_PREPROCESS = 0, ST_CONV1_FUSED /* conv1a + conv1b + pool: the dominant kernel, its own stage */, ST_CONV3X3_C64, ST_CONV3X3_C128, ST_HEAD_GEMM, ST_HEAD_ELTWISE, ST_NMS, ST_SELECT,
-  ST_SAMPLE, ST_LG_PREPARE, ST_LG_GEMM, ST_LG_ATTENTION, ST_LG_LNGELU, ST_LG_ASSIGN, ST_PL_DECODE, ST_PL_STAGE1, ST_PL_FILTER, ST_LINE_ASSOC, ST_RECTIFY, ST_BOW, ST_COUNT
-};
-static const char* kStageNames[ST_COUNT] = {
-  "preprocess", "conv1_fused", "conv3x3_cin64", "conv3x3_cin128", "head_gemm", "head_eltwise", "simple_nms", "select_topk",
-  "sample_desc", "lg_prepare", "lg_gemm", "lg_attention", "lg_ln_gelu", "lg_assign", "plnet_s0_decode", "plnet_stage1", "plnet_filter", "line_assoc", "rectify", "bow"};
-
-struct ProfScope {
-  airfe_ctx* c; hipStream_t st; bool on; airfe_ctx::Mark m;
-  ProfScope(airfe_ctx* c_, int stage, hipStream_t st_, double flops, double bytes) : c(c_), st(st_), on((c_->prof_mask >> stage) & 1u) {
-    if (!on) return;
-    auto get = [&]() {
-      hipEvent_t e;
-      if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
-      else (void)hipEventCreate(&e);
-      return e;
-    };
-    m.stage = stage; m.flops = flops; m.bytes = bytes; m.a = get(); m.b = get();
-    (void)hipEventRecord(m.a, st);
-  }
-  ~ProfScope() {
-    if (!on) return;
-    (void)hipEventRecord(m.b, st);
-    c->marks.push_back(m);
-  }
-};
-
-namespace {
-
-#define HIPCHK(ctx, expr)                                                                         \
-  do {                                                                                            \
-    hipError_t e_ = (expr);                                                                       \
-    if (e_ != hipSuccess) {                                                                       \
-      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                             \
-      g_err = (ctx)->err;                                                                         \
-      return 1;                                                                                   \
-    }                                                                                             \
-  } while (0)
 
 int fail(airfe_ctx* c, const std::string& m) {
   if (c) c->err = m;
@@ -394,1123 +11,16 @@ int fail(airfe_ctx* c, const std::string& m) {
   return 1;
 }
 
-template <class T>
-T* dalloc(airfe_ctx* c, size_t n, bool zero = true) {
-  void* p = nullptr;
-  if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
-  if (zero) (void)hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T));
-  c->allocs.push_back(p);
-  return reinterpret_cast<T*>(p);
+}  // namespace airfe_host
+
+void KfState::save(const airfe_ctx* c) {
+  nms_map_valid = c->nms_map_valid; desc_normalised = c->desc_normalised; desc_dense_valid = c->desc_dense_valid; line_sparse = c->line_sparse; last_B = c->last_B;
 }
-template <class T>
-T* dupload(airfe_ctx* c, const std::vector<T>& v) {
-  T* p = dalloc<T>(c, v.size(), false);
-  if (p && !v.empty()) (void)hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-  return p;
+void KfState::restore(airfe_ctx* c) const {
+  c->nms_map_valid = nms_map_valid; c->desc_normalised = desc_normalised; c->desc_dense_valid = desc_dense_valid; c->line_sparse = line_sparse; c->last_B = last_B;
 }
 
-const Tensor* need(const Pack& p, const std::string& name, std::string& err) {
-  auto it = p.find(name);
-  if (it == p.end()) { err = "weight pack is missing tensor " + name; return nullptr; }
-  return &it->second;
-}
-
-bool make_conv(airfe_ctx* c, const Pack& p, const std::string& name, int cin, int cout, ConvW& out, std::string& err) {
-  const Tensor* w = need(p, name + ".weight", err);
-  const Tensor* b = need(p, name + ".bias", err);
-  if (!w || !b) return false;
-  if ((int)w->data.size() != cout * cin * 9 || (int)b->data.size() != cout) { err = name + ": unexpected shape"; return false; }
-  const int nci = cin / 64;
-  const float* wd = w->data.data();
-  auto slabs = pack_slabs(cout / 64, 9 * nci, c->prec, [&](int feat, int s, int k) {
-    const int tap = s / nci, cc = s % nci, ci = cc * 64 + k;
-    return wd[((size_t)feat * cin + ci) * 9 + tap];
-  });
-  out.w = dupload(c, slabs);
-  out.b = dupload(c, b->data);
-  out.cin = cin;
-  out.cout = cout;
-  return out.w && out.b;
-}
-
-// Linear y = W x + b with W [N][K] row-major; `src_row(feature)` lets callers permute / select output rows
-bool make_linear(airfe_ctx* c, const float* W, const float* bias, int K, int N, LinW& out, float scale = 1.f,
-                 const std::function<int(int)>* src_row = nullptr, const std::function<int(int)>* src_col = nullptr) {
-  const int Kp = (K + 63) / 64 * 64, cbt = (N + 63) / 64;
-  const int cbp = (cbt + 3) & ~3;        // the GEMMs consume feature blocks in pairs / quads (128- / 256-feature tiles): zero pad
-  auto slabs = pack_slabs(cbp, Kp / 64, c->pack_prec, [&](int feat, int s, int k) {
-    const int kk = s * 64 + k;
-    if (feat >= N || kk >= K) return 0.f;
-    const int r = src_row ? (*src_row)(feat) : feat;
-    const int cc = src_col ? (*src_col)(kk) : kk;
-    return W[(size_t)r * K + cc] * scale;
-  });
-  std::vector<float> bp((size_t)cbp * 64, 0.f);
-  for (int f = 0; f < N; ++f) bp[f] = bias[src_row ? (*src_row)(f) : f] * scale;
-  out.w = dupload(c, slabs);
-  out.b = dupload(c, bp);
-  out.K = Kp;
-  out.N = N;
-  out.cbt = cbt;
-  return out.w && out.b;
-}
-
-bool make_linear_named(airfe_ctx* c, const Pack& p, const std::string& name, int K, int N, LinW& out, std::string& err,
-                       float scale = 1.f) {
-  const Tensor* w = need(p, name + ".weight", err);
-  const Tensor* b = need(p, name + ".bias", err);
-  if (!w || !b) return false;
-  if ((int)w->data.size() != N * K || (int)b->data.size() != N) { err = name + ": unexpected shape"; return false; }
-  return make_linear(c, w->data.data(), b->data.data(), K, N, out, scale);
-}
-
-// OpenCV resize() INTER_LINEAR coefficient table (imgproc/src/resize.cpp) -> [d][4] = s0, s1, a0, a1
-std::vector<int> resize_table(int dsize, int ssize) {
-  std::vector<int> t((size_t)dsize * 4);
-  const double scale = (double)ssize / dsize;
-  for (int d = 0; d < dsize; ++d) {
-    float f = (float)((d + 0.5) * scale - 0.5);
-    int s = (int)floorf(f);
-    f -= (float)s;
-    if (s < 0) { f = 0.f; s = 0; }
-    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
-    t[d * 4 + 0] = s;
-    t[d * 4 + 1] = std::min(s + 1, ssize - 1);
-    t[d * 4 + 2] = (int)lrintf((1.f - f) * 2048.f);
-    t[d * 4 + 3] = (int)lrintf(f * 2048.f);
-  }
-  return t;
-}
-
-// ---- fp32 correctness path: weights as fp32, convolutions as [9][Cin][Cout]
-bool f32_conv(airfe_ctx* c, const Pack& p, const std::string& name, int cin, int cout, airfe_ctx::F32Conv& out, std::string& err) {
-  const Tensor* w = need(p, name + ".weight", err);
-  const Tensor* b = need(p, name + ".bias", err);
-  if (!w || !b) return false;
-  if ((int)w->data.size() != cout * cin * 9 || (int)b->data.size() != cout) { err = name + ": unexpected shape"; return false; }
-  std::vector<float> t((size_t)9 * cin * cout);
-  for (int co = 0; co < cout; ++co)
-    for (int ci = 0; ci < cin; ++ci)
-      for (int tap = 0; tap < 9; ++tap) t[((size_t)tap * cin + ci) * cout + co] = w->data[((size_t)co * cin + ci) * 9 + tap];
-  out.w = dupload(c, t); out.b = dupload(c, b->data); out.cin = cin; out.cout = cout;
-  return out.w && out.b;
-}
-bool f32_lin(airfe_ctx* c, const float* W, const float* bias, int K, int N, airfe_ctx::F32Lin& out, const std::function<int(int)>* src_row = nullptr) {
-  std::vector<float> w((size_t)N * K), b(N);
-  for (int n = 0; n < N; ++n) {
-    const int r = src_row ? (*src_row)(n) : n;
-    memcpy(&w[(size_t)n * K], W + (size_t)r * K, (size_t)K * 4);
-    b[n] = bias[r];
-  }
-  out.w = dupload(c, w); out.b = dupload(c, b); out.K = K; out.N = N;
-  return out.w && out.b;
-}
-bool f32_lin_named(airfe_ctx* c, const Pack& p, const std::string& name, int K, int N, airfe_ctx::F32Lin& out, std::string& err) {
-  const Tensor* w = need(p, name + ".weight", err);
-  const Tensor* b = need(p, name + ".bias", err);
-  if (!w || !b) return false;
-  if ((int)w->data.size() != N * K || (int)b->data.size() != N) { err = name + ": unexpected shape"; return false; }
-  return f32_lin(c, w->data.data(), b->data.data(), K, N, out);
-}
-
-int load_superpoint_f32(airfe_ctx* c, const Pack& p) {
-  std::string err;
-  bool ok = f32_conv(c, p, "conv1b", 64, 64, c->f_c1b, err) && f32_conv(c, p, "conv2a", 64, 64, c->f_c2a, err) &&
-            f32_conv(c, p, "conv2b", 64, 64, c->f_c2b, err) && f32_conv(c, p, "conv3a", 64, 128, c->f_c3a, err) &&
-            f32_conv(c, p, "conv3b", 128, 128, c->f_c3b, err) && f32_conv(c, p, "conv4a", 128, 128, c->f_c4a, err) &&
-            f32_conv(c, p, "conv4b", 128, 128, c->f_c4b, err) && f32_conv(c, p, "convPa", 128, 256, c->f_cPa, err) &&
-            f32_conv(c, p, "convDa", 128, 256, c->f_cDa, err) && f32_lin_named(c, p, "convPb", 256, 65, c->f_cPb, err) &&
-            f32_lin_named(c, p, "convDb", 256, 256, c->f_cDb, err);
-  if (ok && p.count("line.conv1.weight"))
-    ok = f32_conv(c, p, "line.conv1", 128, 128, c->f_cL1, err) && f32_lin_named(c, p, "line.head", 128, 145, c->f_cLh, err);
-  if (!ok) return fail(c, err.empty() ? "device allocation failed while loading fp32 detector weights" : err);
-  const int R = AIRFE_INTERNAL_SIZE;
-  const size_t FB = c->f_B = std::min(c->Bmax, 2);
-  auto sq = [](size_t n) { return n * n; };
-  c->f1a = dalloc<float>(c, FB * sq(R + 2) * 64); c->f1b = dalloc<float>(c, FB * sq(R + 2) * 64);
-  c->fp1 = dalloc<float>(c, FB * sq(R / 2 + 2) * 64); c->f2a = dalloc<float>(c, FB * sq(R / 2 + 2) * 64); c->f2b = dalloc<float>(c, FB * sq(R / 2 + 2) * 64);
-  c->fp2 = dalloc<float>(c, FB * sq(R / 4 + 2) * 64); c->f3a = dalloc<float>(c, FB * sq(R / 4 + 2) * 128); c->f3b = dalloc<float>(c, FB * sq(R / 4 + 2) * 128);
-  c->fp3 = dalloc<float>(c, FB * sq(R / 8 + 2) * 128); c->f4a = dalloc<float>(c, FB * sq(R / 8 + 2) * 128); c->f4b = dalloc<float>(c, FB * sq(R / 8 + 2) * 128);
-  c->fPa = dalloc<float>(c, FB * sq(R / 8) * 256); c->fDa = dalloc<float>(c, FB * sq(R / 8) * 256);
-  c->fL1 = dalloc<float>(c, sq(R / 4) * 128);
-  if (!c->f1a || !c->f1b || !c->fp1 || !c->f2a || !c->f2b || !c->fp2 || !c->f3a || !c->f3b || !c->fp3 || !c->f4a || !c->f4b || !c->fPa ||
-      !c->fDa || !c->fL1)
-    return fail(c, "device allocation failed (fp32 detector arena)");
-  return 0;
-}
-
-int load_lightglue_f32(airfe_ctx* c, const Pack& p, int L) {
-  std::string err;
-  c->f_lg.resize(L);
-  bool ok = true;
-  // Wqkv output index = h*192 + d*3 + {q,k,v}  ->  rows [q(h,d) | k(h,d) | v(h,d)]
-  std::function<int(int)> qkv_row = [](int f) { const int sel = f >> 8, hd = f & 255; return (hd >> 6) * 192 + (hd & 63) * 3 + sel; };
-  for (int i = 0; i < L && ok; ++i) {
-    auto& l = c->f_lg[i];
-    const std::string s = "transformers." + std::to_string(i) + ".self_attn", x = "transformers." + std::to_string(i) + ".cross_attn";
-    const Tensor *wq = need(p, s + ".Wqkv.weight", err), *bq = need(p, s + ".Wqkv.bias", err);
-    const Tensor *g1 = need(p, s + ".ffn.1.weight", err), *b1 = need(p, s + ".ffn.1.bias", err);
-    const Tensor *g2 = need(p, x + ".ffn.1.weight", err), *b2 = need(p, x + ".ffn.1.bias", err);
-    if (!wq || !bq || !g1 || !b1 || !g2 || !b2) { ok = false; break; }
-    ok = f32_lin(c, wq->data.data(), bq->data.data(), 256, 768, l.qkv, &qkv_row) && f32_lin_named(c, p, s + ".out_proj", 256, 256, l.out, err) &&
-         f32_lin_named(c, p, s + ".ffn.0", 512, 512, l.ffn0, err) && f32_lin_named(c, p, s + ".ffn.3", 512, 256, l.ffn3, err) &&
-         f32_lin_named(c, p, x + ".to_qk", 256, 256, l.cqk, err) && f32_lin_named(c, p, x + ".to_v", 256, 256, l.cv, err) &&
-         f32_lin_named(c, p, x + ".to_out", 256, 256, l.cout, err) && f32_lin_named(c, p, x + ".ffn.0", 512, 512, l.cffn0, err) &&
-         f32_lin_named(c, p, x + ".ffn.3", 512, 256, l.cffn3, err);
-    l.ln_g = dupload(c, g1->data); l.ln_b = dupload(c, b1->data); l.cln_g = dupload(c, g2->data); l.cln_b = dupload(c, b2->data);
-  }
-  ok = ok && f32_lin_named(c, p, "log_assignment." + std::to_string(L - 1) + ".final_proj", 256, 256, c->f_lgfinal, err);
-  if (!ok) return fail(c, err.empty() ? "device allocation failed while loading fp32 LightGlue weights" : err);
-  const size_t M = (size_t)(2 * c->Pmax + 2 + 128 / c->Np) * c->Np + 256;
-  c->m_qkv = dalloc<float>(c, M * 768); c->m_ctx = dalloc<float>(c, M * 256); c->m_msg = dalloc<float>(c, M * 256);
-  c->m_h = dalloc<float>(c, M * 512); c->m_md = dalloc<float>(c, M * 256);
-  if (!c->m_qkv || !c->m_ctx || !c->m_msg || !c->m_h || !c->m_md) return fail(c, "device allocation failed (fp32 matcher arena)");
-  return 0;
-}
-
-int load_superpoint(airfe_ctx* c, const char* path) {
-  c->pack_prec = c->prec == 2 ? 1 : c->prec;
-  Pack p;
-  std::string err;
-  if (!load_pack(path, p, err)) return fail(c, err);
-  const Tensor* w1 = need(p, "conv1a.weight", err);
-  const Tensor* b1 = need(p, "conv1a.bias", err);
-  if (!w1 || !b1 || w1->data.size() != 64 * 9) return fail(c, err.empty() ? "conv1a: unexpected shape" : err);
-  c->c1a_w = dupload(c, w1->data);
-  c->c1a_b = dupload(c, b1->data);
-  bool ok = make_conv(c, p, "conv1b", 64, 64, c->c1b, err) && make_conv(c, p, "conv2a", 64, 64, c->c2a, err) &&
-            make_conv(c, p, "conv2b", 64, 64, c->c2b, err) && make_conv(c, p, "conv3a", 64, 128, c->c3a, err) &&
-            make_conv(c, p, "conv3b", 128, 128, c->c3b, err) && make_conv(c, p, "conv4a", 128, 128, c->c4a, err) &&
-            make_conv(c, p, "conv4b", 128, 128, c->c4b, err) && make_conv(c, p, "convPa", 128, 256, c->cPa, err) &&
-            make_conv(c, p, "convDa", 128, 256, c->cDa, err) &&
-            make_linear_named(c, p, "convPb", 256, 65, c->cPb, err) && make_linear_named(c, p, "convDb", 256, 256, c->cDb, err);
-  if (!ok) return fail(c, err.empty() ? "device allocation failed while packing SuperPoint weights" : err);
-
-  const int B = c->Dmax, ch = c->chunk, R = AIRFE_INTERNAL_SIZE;
-  c->img32 = dalloc<float>(c, (size_t)ch * (R + 2) * (R + 2));
-  c->a1b = dalloc<uint16_t>(c, (size_t)ch * (R / 2 + 2) * (R / 2 + 2) * 64);
-  c->a2a = dalloc<uint16_t>(c, (size_t)ch * (R / 2 + 2) * (R / 2 + 2) * 64);
-  c->a2b = dalloc<uint16_t>(c, (size_t)B * (R / 4 + 2) * (R / 4 + 2) * 64);
-  c->a3a = dalloc<uint16_t>(c, (size_t)B * (R / 4 + 2) * (R / 4 + 2) * 128);
-  c->a3b = dalloc<uint16_t>(c, (size_t)B * (R / 8 + 2) * (R / 8 + 2) * 128);
-  c->a4a = dalloc<uint16_t>(c, (size_t)B * (R / 8 + 2) * (R / 8 + 2) * 128);
-  c->a4b = dalloc<uint16_t>(c, (size_t)B * (R / 8 + 2) * (R / 8 + 2) * 128);
-  const size_t cells = (size_t)B * (R / 8) * (R / 8);
-  c->aPa = dalloc<uint16_t>(c, cells * 256);
-  c->aDa = dalloc<uint16_t>(c, cells * 256);
-  c->logits = dalloc<float>(c, cells * 72);
-  c->desc = dalloc<float>(c, cells * 256);
-  c->desc_idx = dalloc<int>(c, (size_t)B * 1024 * 4 + 256);
-  c->heat = dalloc<float>(c, (size_t)B * R * R);
-  c->heat_nms = dalloc<float>(c, (size_t)B * R * R);
-  c->nms_mask = dalloc<unsigned char>(c, (size_t)2 * B * R * R);
-  const bool multipass_nms = c->cfg.nms_radius > 0 && c->cfg.nms_radius != 4;
-  c->nms_tmp = dalloc<float>(c, multipass_nms ? (size_t)4 * B * R * R : 1);
-  c->cand = dalloc<unsigned long long>(c, (size_t)B * R * R, false);
-  c->cand_cnt = dalloc<int>(c, B);
-  c->xtab = dalloc<int>(c, (size_t)R * 4);
-  c->ytab = dalloc<int>(c, (size_t)R * 4);
-  std::vector<float> lut(256);
-  for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);
-  c->lut = dupload(c, lut);
-  if (!c->img32 || !c->a1b || !c->a2a || !c->a2b || !c->a3a || !c->a3b || !c->a4a || !c->a4b || !c->aPa ||
-      !c->aDa || !c->logits || !c->desc || !c->heat || !c->heat_nms || !c->nms_tmp || !c->xtab || !c->ytab || !c->lut ||
-      !c->cand || !c->cand_cnt)
-    return fail(c, "device allocation failed (detector arena)");
-  c->has_sp = true;
-  if (p.count("line.conv1.weight")) {       // a PLNet stage-0 pack: the line branch rides along
-    const Tensor *hw = need(p, "line.head.weight", err), *hb = need(p, "line.head.bias", err);
-    if (!hw || !hb || hw->data.size() != 145 * 128 || hb->data.size() != 145) return fail(c, err.empty() ? "line.head: unexpected shape" : err);
-    std::function<int(int)> dec_row = [](int f) { return 128 + f; };
-    if (!make_conv(c, p, "line.conv1", 128, 128, c->cL1, err) || !make_linear(c, hw->data.data(), hb->data.data(), 128, 145, c->cLh) ||
-        !make_linear(c, hw->data.data(), hb->data.data(), 128, 128, c->cLh_loi) ||
-        !make_linear(c, hw->data.data(), hb->data.data(), 128, 17, c->cLh_dec, 1.f, &dec_row))
-      return fail(c, err.empty() ? "device allocation failed while packing the line branch" : err);
-    const size_t npx = (size_t)c->Lmax * 128 * 128;                 // one slot per image of the largest detector batch
-    c->l_feat = dalloc<uint16_t>(c, npx * 128);
-    c->l_head = dalloc<float>(c, (size_t)128 * 128 * 160);          // the fused head: one image (fp32 mode, inspection hook)
-    c->l_dec = dalloc<float>(c, npx * 32);
-    c->l_ridx = dalloc<int>(c, (size_t)c->Lmax * 1200 + 256);
-    c->l_lrows = dalloc<float>(c, ((size_t)c->Lmax * 1200 + 256) * 128);
-    c->l_jloc = dalloc<float>(c, npx);
-    c->l_jnms = dalloc<float>(c, npx);
-    c->l_joff = dalloc<float>(c, 2 * npx);
-    c->l_ta8 = dalloc<float>(c, 8 * npx);
-    c->l_sel = dalloc<float>(c, (size_t)c->Lmax * 320 * AIRFE_FEAT_DIM);
-    c->l_nsel = dalloc<int>(c, c->Lmax);
-    c->l_cand = dalloc<unsigned long long>(c, (size_t)c->Lmax * 128 * 128, false);
-    c->l_cand_cnt = dalloc<int>(c, c->Lmax);
-    if (!c->l_feat || !c->l_ta8 || !c->l_head || !c->l_dec || !c->l_ridx || !c->l_lrows || !c->l_jloc || !c->l_jnms || !c->l_joff || !c->l_sel || !c->l_nsel || !c->l_cand || !c->l_cand_cnt)
-      return fail(c, "device allocation failed (line branch arena)");
-    c->has_s0 = true;
-  }
-  if (c->prec == 2 && load_superpoint_f32(c, p)) return 1;
-  return 0;
-}
-
-int alloc_matcher_arena(airfe_ctx* c);
-
-int load_lightglue(airfe_ctx* c, const char* path) {
-  c->pack_prec = c->mprec == 2 ? 1 : c->mprec;
-  Pack p;
-  std::string err;
-  if (!load_pack(path, p, err)) return fail(c, err);
-  int L = 0;
-  while (p.count("transformers." + std::to_string(L) + ".self_attn.Wqkv.weight")) ++L;
-  if (L == 0) return fail(c, "LightGlue pack has no transformer layers");
-  const Tensor* wr = need(p, "posenc.Wr.weight", err);
-  if (!wr || wr->data.size() != 64) return fail(c, "posenc.Wr.weight missing or wrong shape");
-  c->lg_wr = dupload(c, wr->data);
-  c->lg.resize(L);
-  bool ok = true;
-  for (int i = 0; i < L && ok; ++i) {
-    LgLayer& l = c->lg[i];
-    const std::string s = "transformers." + std::to_string(i) + ".self_attn";
-    const std::string x = "transformers." + std::to_string(i) + ".cross_attn";
-    const Tensor* wqkv = need(p, s + ".Wqkv.weight", err);
-    const Tensor* bqkv = need(p, s + ".Wqkv.bias", err);
-    if (!wqkv || !bqkv || wqkv->data.size() != 768 * 256) { ok = false; break; }
-    // Wqkv output index = h*192 + d*3 + {q,k,v}  (qkv.unflatten(-1,(H,-1,3)))  ->  [q(h,d) | k(h,d)] and v(h,d)
-    std::function<int(int)> qk_row = [](int f) { const int sel = f >> 8, hd = f & 255; return (hd >> 6) * 192 + (hd & 63) * 3 + sel; };
-    std::function<int(int)> v_row = [](int f) { return (f >> 6) * 192 + (f & 63) * 3 + 2; };
-    ok = ok && make_linear(c, wqkv->data.data(), bqkv->data.data(), 256, 512, l.qk, ATT_QK_FOLD, &qk_row);
-    ok = ok && make_linear(c, wqkv->data.data(), bqkv->data.data(), 256, 256, l.v, 1.f, &v_row);
-    ok = ok && make_linear_named(c, p, s + ".out_proj", 256, 256, l.out, err);
-    ok = ok && make_linear_named(c, p, s + ".ffn.0", 512, 512, l.ffn0, err);
-    ok = ok && make_linear_named(c, p, s + ".ffn.3", 512, 256, l.ffn3, err);
-    ok = ok && make_linear_named(c, p, x + ".to_qk", 256, 256, l.cqk, err, ATT_QK_FOLD);
-    ok = ok && make_linear_named(c, p, x + ".to_v", 256, 256, l.cv, err);
-    ok = ok && make_linear_named(c, p, x + ".to_out", 256, 256, l.cout, err);
-    ok = ok && make_linear_named(c, p, x + ".ffn.0", 512, 512, l.cffn0, err);
-    ok = ok && make_linear_named(c, p, x + ".ffn.3", 512, 256, l.cffn3, err);
-    const Tensor *g1 = need(p, s + ".ffn.1.weight", err), *b1 = need(p, s + ".ffn.1.bias", err);
-    const Tensor *g2 = need(p, x + ".ffn.1.weight", err), *b2 = need(p, x + ".ffn.1.bias", err);
-    if (!g1 || !b1 || !g2 || !b2) { ok = false; break; }
-    l.ln_g = dupload(c, g1->data); l.ln_b = dupload(c, b1->data);
-    l.cln_g = dupload(c, g2->data); l.cln_b = dupload(c, b2->data);
-  }
-  const std::string a = "log_assignment." + std::to_string(L - 1);
-  ok = ok && make_linear_named(c, p, a + ".final_proj", 256, 256, c->lg_final, err, 0.25f /* d^-1/4, d = 256 */);
-  const Tensor *mw = need(p, a + ".matchability.weight", err), *mb = need(p, a + ".matchability.bias", err);
-  if (!ok || !mw || !mb) return fail(c, err.empty() ? "LightGlue weight packing failed" : err);
-  c->lg_mw = dupload(c, mw->data);
-  c->lg_mb = mb->data[0];
-  if (alloc_matcher_arena(c)) return 1;
-  if (c->mprec == 2 && load_lightglue_f32(c, p, L)) return 1;
-  c->has_lg = true;
-  return 0;
-}
-
-int alloc_matcher_arena(airfe_ctx* c) {
-  if (c->has_arena) return 0;
-  const int S = 2 * c->Pmax, Np = c->Np;
-  // Token rows: S sequences of Np, PLUS slack.  The GEMMs run over M rounded up to 128 rows and the fused block in passes of 112 on
-  // top of that: the up-to-238 surplus rows are garbage tokens of "sequences" S, S+1, .. whose head-major outputs (incl. the
-  // projections folded into the block) land one or more whole sequences past the real data,
-  // and attention's last key tile reads up to 63 rows past a sequence.  All of it stays inside this zero-initialised slack.
-  const size_t M = (size_t)(S + 2 + 128 / Np) * Np + 256;
-  c->arena_rows = M;
-  c->x32 = dalloc<float>(c, M * 256);
-  c->xb = dalloc<uint16_t>(c, M * 256);
-  c->qb = dalloc<uint16_t>(c, M * 256);
-  c->kb = dalloc<uint16_t>(c, M * 256);
-  c->vtb = dalloc<uint16_t>(c, M * 256);
-  c->ob = dalloc<uint16_t>(c, M * 256);
-  c->msg = dalloc<uint16_t>(c, M * 256);
-  c->hb = dalloc<uint16_t>(c, M * 512);
-  c->mdb = dalloc<uint16_t>(c, M * 256);
-  c->rot_cos = dalloc<float>(c, M * 32);
-  c->rot_sin = dalloc<float>(c, M * 32);
-  c->zbuf = dalloc<float>(c, M);
-  c->lens = dalloc<int>(c, S);
-  c->simbuf = dalloc<float>(c, (size_t)c->Pmax * Np * Np);
-  c->st_scores_full = dalloc<float>(c, (size_t)Np * Np);
-  c->rowlse = dalloc<float>(c, (size_t)c->Pmax * Np);
-  c->collse = dalloc<float>(c, (size_t)c->Pmax * Np);
-  c->rowval = dalloc<float>(c, (size_t)c->Pmax * Np);
-  c->rowarg = dalloc<int>(c, (size_t)c->Pmax * Np);
-  c->colarg = dalloc<int>(c, (size_t)c->Pmax * Np);
-  if (!c->x32 || !c->xb || !c->qb || !c->kb || !c->vtb || !c->ob || !c->msg || !c->hb || !c->mdb || !c->rot_cos ||
-      !c->rot_sin || !c->zbuf || !c->lens || !c->simbuf || !c->rowlse || !c->collse || !c->rowval || !c->rowarg ||
-      !c->colarg || !c->st_scores_full)
-    return fail(c, "device allocation failed (matcher arena)");
-  c->has_arena = true;
-  return 0;
-}
-
-// y = W x + b stored transposed [K][N] fp32 for the thread-per-neuron VALU kernels
-float* upload_transposed(airfe_ctx* c, const Tensor& w, int N, int K, int pad_rows = 0) {
-  std::vector<float> t((size_t)N * (K + pad_rows), 0.f);
-  for (int n = 0; n < N; ++n)
-    for (int k = 0; k < K; ++k) t[(size_t)k * N + n] = w.data[(size_t)n * K + k];
-  return dupload(c, t);
-}
-
-int load_superglue(airfe_ctx* c, const char* path) {
-  c->pack_prec = c->mprec;
-  Pack p;
-  std::string err;
-  if (!load_pack(path, p, err)) return fail(c, err);
-  int L = 0;
-  while (p.count("gnn.layers." + std::to_string(L) + ".attn.merge.weight")) ++L;
-  if (L == 0) return fail(c, "SuperGlue pack has no GNN layers");
-  const int enc[6] = {3, 32, 64, 128, 256, 256};
-  for (int i = 0; i < 5; ++i) {
-    const Tensor* w = need(p, "kenc.encoder." + std::to_string(i) + ".weight", err);
-    const Tensor* b = need(p, "kenc.encoder." + std::to_string(i) + ".bias", err);
-    if (!w || !b || (int)w->data.size() != enc[i] * enc[i + 1]) return fail(c, err.empty() ? "kenc: unexpected shape" : err);
-    c->sg_kenc[2 * i] = upload_transposed(c, *w, enc[i + 1], enc[i]);
-    c->sg_kenc[2 * i + 1] = dupload(c, b->data);
-  }
-  // the two large layers also as packed MFMA operands (large batches: launch_sg_prepare with h128, then two GEMMs)
-  if (!make_linear_named(c, p, "kenc.encoder.3", 128, 256, c->sg_k3, err) || !make_linear_named(c, p, "kenc.encoder.4", 256, 256, c->sg_k4, err))
-    return fail(c, err.empty() ? "kenc: packing failed" : err);
-  // MultiHeadedAttention views channels as (dim, heads): channel = d*4 + h  ->  our head-major h*64 + d
-  std::function<int(int)> hm = [](int f) { return (f & 63) * 4 + (f >> 6); };
-  c->sg.resize(L);
-  bool ok = true;
-  for (int i = 0; i < L && ok; ++i) {
-    SgLayer& l = c->sg[i];
-    const std::string g = "gnn.layers." + std::to_string(i);
-    const Tensor *wq = need(p, g + ".attn.proj.0.weight", err), *bq = need(p, g + ".attn.proj.0.bias", err);
-    const Tensor *wk = need(p, g + ".attn.proj.1.weight", err), *bk = need(p, g + ".attn.proj.1.bias", err);
-    const Tensor *wv = need(p, g + ".attn.proj.2.weight", err), *bv = need(p, g + ".attn.proj.2.bias", err);
-    const Tensor *wm = need(p, g + ".attn.merge.weight", err), *bm = need(p, g + ".attn.merge.bias", err);
-    if (!wq || !bq || !wk || !bk || !wv || !bv || !wm || !bm) { ok = false; break; }
-    std::vector<float> wqk(512 * 256), bqk(512);
-    for (int f = 0; f < 256; ++f) {
-      memcpy(&wqk[(size_t)f * 256], &wq->data[(size_t)hm(f) * 256], 1024);
-      memcpy(&wqk[(size_t)(256 + f) * 256], &wk->data[(size_t)hm(f) * 256], 1024);
-      bqk[f] = bq->data[hm(f)];
-      bqk[256 + f] = bk->data[hm(f)];
-    }
-    ok = ok && make_linear(c, wqk.data(), bqk.data(), 256, 512, l.qk, ATT_QK_FOLD);
-    ok = ok && make_linear(c, wv->data.data(), bv->data.data(), 256, 256, l.v, 1.f, &hm);
-    ok = ok && make_linear(c, wm->data.data(), bm->data.data(), 256, 256, l.merge, 1.f, nullptr, &hm);
-    ok = ok && make_linear_named(c, p, g + ".mlp.0", 512, 512, l.mlp0, err);
-    ok = ok && make_linear_named(c, p, g + ".mlp.3", 512, 256, l.mlp3, err);
-  }
-  ok = ok && make_linear_named(c, p, "final_proj", 256, 256, c->sg_final, err, 0.25f /* scores / 256^.5 split over both sides */);
-  const Tensor* bs = need(p, "bin_score", err);
-  if (!ok || !bs) return fail(c, err.empty() ? "SuperGlue weight packing failed" : err);
-  c->sg_alpha = bs->data[0];
-  if (alloc_matcher_arena(c)) return 1;
-  const int P = c->Pmax;
-  c->Lz = c->Np + 64;
-  const size_t pl = (size_t)P * c->Lz;
-  c->sg_u = dalloc<float>(c, pl); c->sg_v = dalloc<float>(c, pl); c->sg_Z = dalloc<float>(c, pl * c->Lz);
-  c->sg_max0 = dalloc<float>(c, pl); c->sg_ms0 = dalloc<float>(c, pl); c->sg_ms1 = dalloc<float>(c, pl);
-  c->sg_idx0 = dalloc<int>(c, pl); c->sg_idx1 = dalloc<int>(c, pl);
-  c->sg_cnt = dalloc<unsigned>(c, (size_t)P * 16 + 16);      // + the Sinkhorn kernel's fail word (sg_cnt + P * 16)
-  c->sg_xch = dalloc<float>(c, pl * 64);
-  c->sg_out0 = dalloc<int32_t>(c, pl); c->sg_out1 = dalloc<int32_t>(c, pl);
-  if (!c->sg_u || !c->sg_v || !c->sg_Z || !c->sg_max0 || !c->sg_ms0 || !c->sg_ms1 || !c->sg_idx0 || !c->sg_idx1 ||
-      !c->sg_out0 || !c->sg_out1 || !c->sg_cnt || !c->sg_xch)
-    return fail(c, "device allocation failed (SuperGlue arena)");
-  c->has_sg = true;
-  return 0;
-}
-
-int load_plnet_s1(airfe_ctx* c, const char* path) {
-  Pack p;
-  std::string err;
-  if (!load_pack(path, p, err)) return fail(c, err);
-  struct L { const char* name; int n, k; } ls[4] = {{"fc2.0", 128, 496}, {"fc2.2", 128, 128}, {"fc2.4", 128, 128}, {"fc2_res.0", 128, 240}};
-  for (int i = 0; i < 4; ++i) {
-    const Tensor* w = need(p, std::string(ls[i].name) + ".weight", err);
-    const Tensor* b = need(p, std::string(ls[i].name) + ".bias", err);
-    if (!w || !b || (int)w->data.size() != ls[i].n * ls[i].k) return fail(c, err.empty() ? "plnet_s1: unexpected shape" : err);
-    c->s1_w[2 * i] = upload_transposed(c, *w, ls[i].n, ls[i].k, S1_WPAD);
-    c->s1_w[2 * i + 1] = dupload(c, b->data);
-  }
-  const Tensor *wh = need(p, "fc2_head.weight", err), *bh = need(p, "fc2_head.bias", err), *tt = need(p, "sample_t", err);
-  if (!wh || !bh || !tt || wh->data.size() != 256 || tt->data.size() != 30) return fail(c, err.empty() ? "plnet_s1 head: unexpected shape" : err);
-  c->s1_w[8] = dupload(c, wh->data);
-  c->s1_w[9] = dupload(c, bh->data);
-  c->s1_w[10] = dupload(c, tt->data);
-  const size_t L = (size_t)c->Lmax;
-  c->wf_table = dalloc<int>(c, L * 300 * 300, false);
-  if (c->wf_table) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->wf_table), 0x7FFFFFFF, L * 300 * 300, c->stream));
-  c->wf_keep = dalloc<int>(c, L * KEEP_CAP);
-  c->wf_pairs = dalloc<int>(c, L * LINE_CAP * 2);
-  c->wf_rep = dalloc<int>(c, L * LINE_CAP);
-  c->wf_counts = dalloc<int>(c, L * LINE_CNT_LD);      // per image: M1, M2, then the per-workgroup counts of wf_count_kernel
-  c->s1_la = dalloc<float>(c, L * LINE_CAP * 4);
-  c->s1_sc = dalloc<float>(c, L * LINE_CAP);
-  c->s1_jfeat = dalloc<float>(c, L * 300 * 256);
-  c->s0_stage = dalloc<float>(c, L * SG_STRIDE);
-  c->s0_loi = dalloc<float>(c, (size_t)128 * 128 * 128);
-  c->jmap = dalloc<unsigned char>(c, L * AIRFE_INTERNAL_SIZE * AIRFE_INTERNAL_SIZE);
-  c->d_lines = dalloc<double>(c, (size_t)LINE_CAP * 4);
-  c->d_nlines = dalloc<int>(c, 2 * L);
-  c->d_njunc = dalloc<int>(c, L * (2 + 64));
-  c->junc_feat = dalloc<float>(c, (size_t)JUNC_CAP * AIRFE_FEAT_DIM);
-  for (int i = 0; i < 11; ++i) if (!c->s1_w[i]) return fail(c, "device allocation failed (plnet_s1 weights)");
-  if (!c->wf_table || !c->wf_keep || !c->wf_pairs || !c->wf_rep || !c->wf_counts || !c->s1_la || !c->s1_sc || !c->s1_jfeat || !c->s0_stage || !c->s0_loi ||
-      !c->jmap || !c->d_lines || !c->d_nlines || !c->d_njunc || !c->junc_feat)
-    return fail(c, "device allocation failed (line path arena)");
-  c->has_s1 = true;
-  return 0;
-}
-
-int ensure_tables(airfe_ctx* c, int h, int w) {
-  if (c->tab_w == w && c->tab_h == h) return 0;
-  const auto xt = resize_table(AIRFE_INTERNAL_SIZE, w), yt = resize_table(AIRFE_INTERNAL_SIZE, h);
-  // the image size changed: a pre-process of the previous size may still be reading the tables on a CALLER's stream (the *_dev entry
-  // points), so the whole device is drained before they are rewritten — once per size change, not per call
-  if (c->tab_w != -1) HIPCHK(c, hipDeviceSynchronize());   // (-1: no table yet, nothing can be reading it)
-  HIPCHK(c, hipMemcpyAsync(c->xtab, xt.data(), xt.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->ytab, yt.data(), yt.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));   // host vectors go out of scope
-  c->tab_w = w;
-  c->tab_h = h;
-  return 0;
-}
-
-void run_conv(airfe_ctx* c, const ConvW& w, const uint16_t* x, uint16_t* y, int B, int H, int W, int pool, int out_pad,
-              hipStream_t st) {
-  ConvArgs a;
-  a.X = x; a.Wp = w.w; a.bias = w.b; a.Y = y;
-  a.B = B; a.H = H; a.W = W; a.CIN = w.cin; a.COUT = w.cout;
-  a.pool = pool; a.out_pad = out_pad; a.relu = 1;
-  const double px = (double)B * H * W;
-  const double ob = px / (pool ? 4 : 1) * w.cout * 2;
-  ProfScope ps(c, w.cin == 64 ? ST_CONV3X3_C64 : ST_CONV3X3_C128, st, 2.0 * px * w.cin * w.cout * 9,
-               px * w.cin * 2 + ob + 9.0 * w.cin * w.cout * 2);
-  launch_conv3x3(c->prec, a, st);
-}
-
-// ---- fp32 correctness path: the SuperPoint-VGG encoder + heads up to the dense logits / descriptor maps (what follows — soft-max,
-// NMS, top-K, descriptor sampling — is fp32 in every mode and shared)
-void f32_conv(const airfe_ctx::F32Conv& w, const float* x, float* y, int B, int H, int W, int opad, hipStream_t st) {
-  launch_conv3x3_f32(x, w.w, w.b, y, B, H, W, w.cin, w.cout, opad, st);
-}
-int encode_f32(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, hipStream_t st) {
-  const int R = AIRFE_INTERNAL_SIZE;
-  for (int c0 = 0; c0 < B; c0 += c->f_B) {
-    const int cb = std::min(c->f_B, B - c0);
-    launch_preprocess(d_gray + (size_t)c0 * img_stride, cb, h, w, stride, img_stride, c->xtab, c->ytab, c->lut, c->img32, R, R, st);
-    launch_conv1a_f32(c->img32, c->c1a_w, c->c1a_b, c->f1a, cb, R, R, st);
-    f32_conv(c->f_c1b, c->f1a, c->f1b, cb, R, R, 1, st);
-    launch_maxpool2_f32(c->f1b, c->fp1, cb, R, R, 64, st);
-    f32_conv(c->f_c2a, c->fp1, c->f2a, cb, R / 2, R / 2, 1, st);
-    f32_conv(c->f_c2b, c->f2a, c->f2b, cb, R / 2, R / 2, 1, st);
-    launch_maxpool2_f32(c->f2b, c->fp2, cb, R / 2, R / 2, 64, st);
-    f32_conv(c->f_c3a, c->fp2, c->f3a, cb, R / 4, R / 4, 1, st);
-    f32_conv(c->f_c3b, c->f3a, c->f3b, cb, R / 4, R / 4, 1, st);
-    launch_maxpool2_f32(c->f3b, c->fp3, cb, R / 4, R / 4, 128, st);
-    f32_conv(c->f_c4a, c->fp3, c->f4a, cb, R / 8, R / 8, 1, st);
-    f32_conv(c->f_c4b, c->f4a, c->f4b, cb, R / 8, R / 8, 1, st);
-    f32_conv(c->f_cPa, c->f4b, c->fPa, cb, R / 8, R / 8, 0, st);
-    f32_conv(c->f_cDa, c->f4b, c->fDa, cb, R / 8, R / 8, 0, st);
-    const int cells = cb * (R / 8) * (R / 8);
-    const size_t cell0 = (size_t)c0 * (R / 8) * (R / 8);
-    GemmF32Args g;
-    g.X1 = c->fPa; g.ld1 = 256; g.K1 = 256; g.K = 256; g.W = c->f_cPb.w; g.bias = c->f_cPb.b; g.M = cells; g.N = 65;
-    g.Y = c->logits + cell0 * 72; g.ldy = 72;
-    launch_gemm_f32(g, st);
-    g.X1 = c->fDa; g.W = c->f_cDb.w; g.bias = c->f_cDb.b; g.N = 256; g.Y = c->desc + cell0 * 256; g.ldy = 256;
-    launch_gemm_f32(g, st);
-  }
-  launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st);
-  c->desc_normalised = false;
-  HIPCHK(c, hipGetLastError());
-  return 0;
-}
-
-// LightGlue forward in fp32 (same call contract as lightglue_dev): q|k|v from ONE [768][256] projection with the rows regrouped
-// head-major, rotary, exact soft-max attention, out-projection, FFN (LayerNorm, erf GELU), residual; the assignment tail is the
-// shared fp32 code
-int lightglue_dev_f32(airfe_ctx* c, const float* f0, const int* n0, const float* f1, const int* n1, int B, int cap, int ld, int kp_off,
-                      int normalize, int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, float* scores_out, hipStream_t st) {
-  const int S = 2 * B, Np = c->Np, M = S * Np;
-  LgPrepArgs pa;
-  pa.f0 = f0; pa.f1 = f1; pa.n0 = n0; pa.n1 = n1; pa.ld = ld; pa.kp_off = kp_off; pa.normalize = normalize;
-  pa.cx = (float)(c->cfg.image_width / 2);
-  pa.cy = (float)(c->cfg.image_height / 2);
-  pa.linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.5f);
-  pa.wr = c->lg_wr; pa.B = B; pa.cap = cap; pa.Np = Np;
-  pa.x32 = c->x32; pa.xb = c->xb; pa.rot_cos = c->rot_cos; pa.rot_sin = c->rot_sin; pa.lens = c->lens;
-  pa.slack_rows = (int)(c->arena_rows - (size_t)M);      // the slack rows go back to zero with the same launch (see reset_slack_rows)
-  launch_lg_prepare(1, pa, st);
-  auto lin = [&](const airfe_ctx::F32Lin& w, const float* x1, int ld1, int K1, const float* x2, int ld2, float* y, int ldy, int acc, float scale = 1.f) {
-    GemmF32Args g;
-    g.X1 = x1; g.ld1 = ld1; g.K1 = K1; g.X2 = x2; g.ld2 = ld2; g.W = w.w; g.bias = w.b; g.Y = y; g.ldy = ldy;
-    g.M = M; g.N = w.N; g.K = w.K; g.accumulate = acc; g.scale = scale;
-    launch_gemm_f32(g, st);
-  };
-  auto ffn = [&](const airfe_ctx::F32Lin& f0w, const float* g, const float* b, const airfe_ctx::F32Lin& f3w) {
-    lin(f0w, c->x32, 256, 256, c->m_msg, 256, c->m_h, 512, 0);
-    launch_ln_gelu_f32(c->m_h, g, b, M, st);
-    lin(f3w, c->m_h, 512, 512, nullptr, 0, c->x32, 256, 1);
-  };
-  for (const auto& l : c->f_lg) {
-    lin(l.qkv, c->x32, 256, 256, nullptr, 0, c->m_qkv, 768, 0);
-    launch_rotary_f32(c->m_qkv, 768, c->rot_cos, c->rot_sin, M, st);
-    launch_attention_f32(c->m_qkv, 768, c->m_qkv + 256, 768, c->m_qkv + 512, 768, c->m_ctx, c->lens, S, 4, Np, 0, 0.125f, st);
-    lin(l.out, c->m_ctx, 256, 256, nullptr, 0, c->m_msg, 256, 0);
-    ffn(l.ffn0, l.ln_g, l.ln_b, l.ffn3);
-    lin(l.cqk, c->x32, 256, 256, nullptr, 0, c->m_qkv, 768, 0);
-    lin(l.cv, c->x32, 256, 256, nullptr, 0, c->m_qkv + 512, 768, 0);
-    launch_attention_f32(c->m_qkv, 768, c->m_qkv, 768, c->m_qkv + 512, 768, c->m_ctx, c->lens, S, 4, Np, 1, 0.125f, st);
-    lin(l.cout, c->m_ctx, 256, 256, nullptr, 0, c->m_msg, 256, 0);
-    ffn(l.cffn0, l.cln_g, l.cln_b, l.cffn3);
-  }
-  lin(c->f_lgfinal, c->x32, 256, 256, nullptr, 0, c->m_md, 256, 0, 0.25f);      // d^-1/4 on both sides, d = 256
-  launch_rowdot256(c->x32, c->lg_mw, c->lg_mb, c->zbuf, M, st);
-  for (int b = 0; b < B; ++b) {                                                   // sim[b] = md[2b] . md[2b+1]^T
-    GemmF32Args g;
-    g.X1 = c->m_md + (size_t)(2 * b) * Np * 256; g.ld1 = 256; g.K1 = 256; g.K = 256; g.W = c->m_md + (size_t)(2 * b + 1) * Np * 256;
-    g.Y = c->simbuf + (size_t)b * Np * Np; g.ldy = Np; g.M = Np; g.N = Np;
-    launch_gemm_f32(g, st);
-  }
-  launch_lg_assign(c->simbuf, c->zbuf, c->lens, B, Np, mcap, 0.1f, c->rowlse, c->collse, scores_out, c->rowarg, c->rowval, c->colarg, d_idx,
-                   d_score, d_nmatch, st);
-  HIPCHK(c, hipGetLastError());
-  return 0;
-}
-
-// convDb over every cell of the batch -> c->desc [B][64][64][256] fp32, un-normalised
-void dense_desc_head(airfe_ctx* c, int B, hipStream_t st) {
-  const int R = AIRFE_INTERNAL_SIZE, cells = B * (R / 8) * (R / 8);
-  GemmArgs g;
-  g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b;
-  g.M = cells; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
-  g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-  { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024)); launch_gemm(c->prec, 256, false, g, st); }
-  // F.normalize of the dense map is applied lazily: sample_desc_kernel normalises just the 4 taps each keypoint reads
-  // (same operations, same bits) — a dense pass moved 8 MB/image to serve 400 x 4 cell reads.
-  c->desc_normalised = false;
-}
-
-// Detector over ONE batch of B images, or — d_gray1 != nullptr — over the 2 B images of B stereo pairs in one pass (images 0 .. B-1 from
-// d_gray, B .. 2B-1 from d_gray1; features to d_feat / d_feat1): every whole-batch kernel then runs once over twice the tiles instead
-// of twice (half the launches, prologues and tails of the second half of the network; per-image results do not depend on the batch).
-int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int Bs, int h, int w, int stride, size_t img_stride,
-                float* d_feat, float* d_feat1, int cap, int* d_n, int* d_n1, hipStream_t st) {
-  if (!c->has_sp) return fail(c, "detector weights were not loaded (cfg.superpoint_pack)");
-  const int B = d_gray1 ? 2 * Bs : Bs;
-  if (Bs < 1 || Bs > c->Bmax || B > c->Dmax) return fail(c, "batch exceeds cfg.max_batch");
-  // Two sources / two destinations that are in fact ONE array (the batch-1 keyframe entry lays left and right out back to back): the per-side
-  // launches below become one launch over the 2 Bs images — per image the same work, so the same bits.
-  const bool src_contig = d_gray1 && d_gray1 == d_gray + (size_t)Bs * img_stride;
-  const bool dst_contig = d_gray1 && d_feat1 == d_feat + (size_t)Bs * cap * AIRFE_FEAT_DIM && d_n1 == d_n + Bs;
-  if (h < 1 || w < 1) return fail(c, "empty image");
-  if (cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
-  if (ensure_tables(c, h, w)) return 1;
-  const int R = AIRFE_INTERNAL_SIZE;
-  bool sparse_desc = false;
-  if (c->prec == 2) {
-    if (d_gray1) return fail(c, "detect_dev2: the fp32 path takes one source");
-    if (encode_f32(c, d_gray, B, h, w, stride, img_stride, st)) return 1;
-  } else {
-    for (int c0 = 0, cb = 0; c0 < B; c0 += cb) {
-      cb = std::min(c->chunk, B - c0);
-      {                                                                  // a chunk may straddle the two sources: one pre-process launch per source
-        ProfScope ps(c, ST_PREPROCESS, st, 0, (double)cb * ((double)h * w + (double)R * R * 4));
-        int n0 = std::min(std::max(Bs - c0, 0), cb);                    // images of this chunk that come from d_gray
-        if (src_contig) n0 = cb;                                        // (the second source lies right behind the first: one launch)
-        if (n0 > 0) launch_preprocess(d_gray + (size_t)c0 * img_stride, n0, h, w, stride, img_stride, c->xtab, c->ytab, c->lut, c->img32, R, R, st);
-        if (cb > n0)
-          launch_preprocess(d_gray1 + (size_t)(c0 + n0 - Bs) * img_stride, cb - n0, h, w, stride, img_stride, c->xtab, c->ytab, c->lut,
-                            c->img32 + (size_t)n0 * (R + 2) * (R + 2), R, R, st);
-      }
-      {
-        // conv1a (Cin = 1) fused into the persistent conv1b kernel: its 64-channel full-resolution output never
-        // reaches HBM (kernels_conv64r.hip).  FLOPs/bytes below are the algorithmic ones of conv1a + conv1b.
-        ConvArgs a;
-        a.Wp = c->c1b.w; a.bias = c->c1b.b; a.Y = c->a1b; a.B = cb; a.H = R; a.W = R; a.CIN = 64; a.COUT = 64;
-        a.pool = 1; a.out_pad = 1; a.relu = 1;
-        a.img = c->img32; a.w1a = c->c1a_w; a.b1a = c->c1a_b;
-        const double px = (double)cb * R * R;
-        ProfScope ps(c, ST_CONV1_FUSED, st, 2.0 * px * 9 * 64 + 2.0 * px * 64 * 64 * 9, px * 4 + px / 4 * 128 + 9.0 * 64 * 64 * 2);
-        launch_conv64r(c->prec, a, st);
-      }
-      run_conv(c, c->c2a, c->a1b, c->a2a, cb, R / 2, R / 2, 0, 1, st);
-      run_conv(c, c->c2b, c->a2a, c->a2b + (size_t)c0 * (R / 4 + 2) * (R / 4 + 2) * 64, cb, R / 2, R / 2, 1, 1, st);
-    }
-    run_conv(c, c->c3a, c->a2b, c->a3a, B, R / 4, R / 4, 0, 1, st);
-    run_conv(c, c->c3b, c->a3a, c->a3b, B, R / 4, R / 4, 1, 1, st);
-    run_conv(c, c->c4a, c->a3b, c->a4a, B, R / 8, R / 8, 0, 1, st);
-    run_conv(c, c->c4b, c->a4a, c->a4b, B, R / 8, R / 8, 0, 1, st);
-    run_conv(c, c->cPa, c->a4b, c->aPa, B, R / 8, R / 8, 0, 0, st);
-    run_conv(c, c->cDa, c->a4b, c->aDa, B, R / 8, R / 8, 0, 0, st);
-    const int cells = B * (R / 8) * (R / 8);
-    {
-      GemmArgs g;
-      g.X1 = c->aPa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cPb.w; g.bias = c->cPb.b;
-      g.M = cells; g.N = 65; g.cb_total = c->cPb.cbt; g.epi = EPI_STORE_F32; g.out = c->logits; g.ldo = 72;
-      g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-      // soft-max + depth-to-space in the GEMM's epilogue, at EVERY batch size (one summation order): no logits in memory
-      g.epi = EPI_SOFTMAX_D2S; g.out = c->heat; g.d2s_hc = R / 8; g.d2s_wc = R / 8;
-      ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 256));
-      launch_gemm8(c->prec, 256, false, g, st);
-    }
-    // The descriptor head convDb (1x1, 256 -> 256) is only ever READ at the <= 4 cells each keypoint samples: large batches run it as a
-    // gather GEMM over those rows after the top-K (below) — 1600 of 4096 cells per image at 400 keypoints, and 1.6 instead of 4 MB
-    // of fp32 written.  The dense map stays for small batches (the batch-1 line path samples junction descriptors from it) and
-    // for the inspection hook, which rebuilds it on demand.  Same kernel, same K order: the rows are bit-identical either way.
-    sparse_desc = B > 2 && cap * 4 <= (R / 8) * (R / 8) && cap <= 1024;
-    if (!sparse_desc) dense_desc_head(c, B, st);
-    c->desc_dense_valid = !sparse_desc;
-    c->last_B = B;
-  }
-  const int ccap = R * R;
-  {
-    ProfScope ps(c, ST_NMS, st, 0, (double)B * R * R * 8);
-    if (c->cfg.nms_radius == 4) {                        // the reference's radius: simple_nms in registers (kernels_nms512.hip; R = 512)
-      // the dense NMS'd map is consumed only by the batch-1 line path (junction scores) and the inspection hook: large batches skip
-      // its 1 MB / image write (airfe_debug_detector_maps rebuilds it on demand)
-      c->nms_map_valid = B <= 2 || c->force_nms_map;
-      launch_nms512_candidates(c->heat, c->nms_map_valid ? c->heat_nms : nullptr, c->nms_mask, B, c->cfg.keypoint_threshold,
-                               c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
-    } else if (c->cfg.nms_radius > 0) {
-      c->nms_map_valid = true;
-      launch_simple_nms(c->heat, c->heat_nms, c->nms_tmp, B, R, R, c->cfg.nms_radius, st);
-      launch_candidates(c->heat_nms, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
-    } else {
-      launch_candidates(c->heat, B, R, R, c->cfg.keypoint_threshold, c->cfg.remove_borders, c->cand, c->cand_cnt, ccap, st);
-    }
-  }
-  const int nhalf = (d_gray1 && !dst_contig) ? 2 : 1;
-  const int Bh = nhalf == 2 ? Bs : B;                                    // images per destination
-  for (int half = 0; half < nhalf; ++half) {                             // the two feature destinations: one launch each
-    const int b0 = half * Bs;
-    ProfScope ps(c, ST_SELECT, st, 0, (double)Bh * 8192 * 8);
-    launch_select_list(c->cand + (size_t)b0 * ccap, c->cand_cnt + b0, ccap, Bh, R, c->cfg.max_keypoints, cap, half ? d_feat1 : d_feat,
-                       half ? d_n1 : d_n, st);
-  }
-  if (sparse_desc) {
-    const int M = B * cap * 4, Mp = (M + 255) / 256 * 256;
-    for (int half = 0; half < nhalf; ++half)
-      launch_desc_cells(half ? d_feat1 : d_feat, half ? d_n1 : d_n, cap, Bh, half * Bs, R / 8, R / 8, c->desc_idx + (size_t)half * Bs * cap * 4, st);
-    if (Mp > M) HIPCHK(c, hipMemsetAsync(c->desc_idx + M, 0, (size_t)(Mp - M) * 4, st));
-    GemmArgs g;
-    g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b; g.rowidx = c->desc_idx;
-    g.M = Mp; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
-    ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * Mp * 256 * 256, (double)Mp * (512 + 1024));
-    launch_gemm8(c->prec, 256, false, g, st);
-  }
-  for (int half = 0; half < nhalf; ++half) {
-    const int b0 = half * Bs;
-    ProfScope ps(c, ST_SAMPLE, st, 0, (double)Bh * c->cfg.max_keypoints * (4096 + 1036));
-    if (sparse_desc)
-      launch_sample_desc(c->desc + (size_t)b0 * cap * 4 * 256, Bh, R / 8, R / 8, half ? d_feat1 : d_feat, half ? d_n1 : d_n, cap, (float)w / (float)R,
-                         (float)h / (float)R, 1, st, 1);
-    else
-      launch_sample_desc(c->desc + (size_t)b0 * (R / 8) * (R / 8) * 256, Bh, R / 8, R / 8, half ? d_feat1 : d_feat, half ? d_n1 : d_n, cap,
-                         (float)w / (float)R, (float)h / (float)R, c->desc_normalised ? 0 : 1, st);
-  }
-  HIPCHK(c, hipGetLastError());
-  return 0;
-}
-
-int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat,
-               int cap, int* d_n, hipStream_t st) {
-  return detect_dev2(c, d_gray, nullptr, B, h, w, stride, img_stride, d_feat, nullptr, cap, d_n, nullptr, st);
-}
-
-// airfe_debug_trace: checksum `words` 32-bit words of p in units of unit_words (slot = one call; no-op unless tracing)
-void trace(airfe_ctx* c, hipStream_t st, const char* what, size_t li, const char* blk, const void* p, size_t words, unsigned unit_words) {
-  if (!c->trace_on) return;
-  const unsigned off = c->trace_slots.empty() ? 0u : c->trace_slots.back().off + c->trace_slots.back().units;
-  const unsigned units = (unsigned)(words / unit_words);
-  if (units == 0) return;                                          // nothing to hash (and a 0-sized grid is a launch error)
-  if (c->trace_slots.size() >= 1024 || (size_t)off + units > c->trace_cap) { c->trace_overflow = true; return; }   // reported by trace_finish
-  launch_trace_hash(p, unit_words, units, c->trace_tab + off, st);
-  c->trace_slots.push_back({std::string("L") + std::to_string(li) + "." + blk + "." + what, off, units, unit_words, p, words});
-  if ((int)c->trace_slots.size() - 1 == c->trace_stop) c->trace_halt = true;
-}
-int trace_finish(airfe_ctx* c, hipStream_t st) {
-  if (c->trace_on && c->trace_overflow) {
-    c->trace_overflow = false;
-    return fail(c, "airfe_debug_trace: slot / unit table overflow — slots were dropped, slot indices do not name the launches of a full run");
-  }
-  if (c->trace_on && !c->trace_slots.empty()) {
-    c->trace_off_h.clear();
-    for (const auto& t : c->trace_slots) c->trace_off_h.push_back(t.off);
-    c->trace_off_h.push_back(c->trace_slots.back().off + c->trace_slots.back().units);
-    HIPCHK(c, hipMemcpyAsync(c->trace_off, c->trace_off_h.data(), c->trace_off_h.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    launch_trace_digest(c->trace_tab, c->trace_off, (int)c->trace_slots.size(), c->trace_dig, st);
-  }
-  HIPCHK(c, hipGetLastError());
-  return 0;
-}
-#define TRACE_HALT do { if (c->trace_halt) return trace_finish(c, st); } while (0)
-
-void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1, const uint16_t* x2, int ld2, int M,
-                int epi, int act, void* out, int ldo, hipStream_t st, bool trans = false, void* out2 = nullptr,
-                float* x32 = nullptr, const float* rc = nullptr, const float* rs = nullptr) {
-  GemmArgs g;
-  g.X1 = x1; g.ld1 = ld1; g.K1 = K1; g.X2 = x2; g.ld2 = ld2;
-  g.Wp = w.w; g.bias = w.b; g.M = M; g.N = w.N; g.cb_total = w.cbt;
-  g.epi = epi; g.act = act; g.out = out; g.out2 = out2; g.ldo = ldo; g.x32 = x32;
-  g.rot_cos = rc; g.rot_sin = rs; g.Np = c->Np; g.H = 4;
-  g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-  ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * w.K * w.N, (double)M * (w.K + w.N) * 2 + (double)w.K * w.N * 2);
-  launch_gemm(c->mprec, w.K, trans, g, st);
-}
-
-void run_attention(airfe_ctx* c, int prec, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, const int* lens, int S,
-                   int H, int Np, int cross, float scale, hipStream_t st) {
-  // `scale` (1/sqrt(d_head)) and log2 e are already inside q and k (ATT_QK_FOLD), so the kernels exponentiate the raw products:
-  // the round-1 kernel is told scale * log2 e = 1
-  (void)scale;
-  launch_attention32(prec, Q, K, Vt, O, lens, S, H, Np, cross, st);
-}
-
-// The attention inputs of one layer: head-major q|k (`qk`, rotary when rc != nullptr; q -> qout, k -> kout, or both roles in qout
-// for the cross block's shared projection) and transposed V (`v`).  One streaming launch where kernels_gemmr.hip applies (large
-// token counts), else the two linears separately — same arithmetic either way.
-void run_qkv(airfe_ctx* c, const LinW& qk, const LinW& v, int M, void* qout, void* kout, const float* rc, const float* rs, hipStream_t st) {
-  GemmArgs a, b;
-  a.X1 = c->xb; a.ld1 = 256; a.K1 = 256; a.Wp = qk.w; a.bias = qk.b; a.M = M; a.N = qk.N; a.cb_total = qk.cbt;
-  a.epi = EPI_HEADS; a.out = qout; a.out2 = kout; a.rot_cos = rc; a.rot_sin = rs; a.Np = c->Np; a.H = 4;
-  b.X1 = c->xb; b.ld1 = 256; b.K1 = 256; b.Wp = v.w; b.bias = v.b; b.M = M; b.N = v.N; b.cb_total = v.cbt;
-  b.epi = EPI_HEADS_T; b.out = c->vtb; b.Np = c->Np; b.H = 4;
-  a.gr_wgs = b.gr_wgs = c->gemmr_wgs;
-  if (c->qkv_pair && M >= c->gemmr_min && qk.K == 256 && v.K == 256 && gemmr_pair_applicable(a, b)) {
-    ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * 256.0 * (qk.N + v.N), (double)M * (256 + qk.N + v.N) * 2 + 256.0 * (qk.N + v.N) * 2);
-    launch_gemmr_pair(c->mprec, a, b, st);
-    return;
-  }
-  run_linear(c, qk, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS, ACT_NONE, qout, 0, st, false, kout, nullptr, rc, rs);
-  run_linear(c, v, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
-}
-
-// out-proj + FFN + residual of one block as ONE kernel (kernels_lgblockf.hip); flops/bytes are the algorithmic ones
-void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st, int relu = 0,
-               const LinW* nqk = nullptr, const LinW* nv = nullptr, bool rotary = false) {
-  LgBlockFArgs a;
-  a.relu = relu;
-  a.attn = c->ob; a.xb = c->xb; a.x32 = c->x32; a.wo = out.w; a.w1 = f0.w; a.w2 = f3.w;
-  a.bo = out.b; a.b1 = f0.b; a.gamma = g; a.beta = b; a.b2 = f3.b; a.M = M;
-  // one workgroup per CU and pass: ceil(M / T) workgroups run in rounds of 256, a round lasts ~T — take the T with the smaller product
-  a.tokens_per_wg = ((M + 111) / 112 + 255) / 256 * 112 < ((M + 127) / 128 + 255) / 256 * 128 ? 112 : 128;
-  // small token counts (the batch-1 calls of the SLAM loop: 800 tokens): 112-token passes would occupy 8 of the 256 CUs — 32- / 64-token passes
-  // spread the same rows over 4x / 2x as many workgroups as long as that is still ONE round
-  if (M <= 256 * 32) a.tokens_per_wg = 32;
-  else if (M <= 256 * 64) a.tokens_per_wg = 64;
-  if (c->lgb_tokens > 0) a.tokens_per_wg = c->lgb_tokens;          // AIRFE_LGB_TOKENS (measurement switch)
-  double fl = 2.0 * M * (256.0 * 256 + 512.0 * 512 + 512.0 * 256), by = (double)M * (512 + 512 + 1024 + 512 + 1024) + 917504.0;
-  if (nqk && nv) {            // the next attention layer's projections ride along (kernels_lgblockf.hip, FOLD)
-    a.nqk_w = nqk->w; a.nqk_b = nqk->b; a.nqk_n = nqk->N; a.nv_w = nv->w; a.nv_b = nv->b;
-    a.rot_cos = rotary ? c->rot_cos : nullptr; a.rot_sin = rotary ? c->rot_sin : nullptr;
-    a.q_out = c->qb; a.k_out = c->kb; a.vt_out = c->vtb; a.Np = c->Np; a.H = 4;
-    fl += 2.0 * M * 256.0 * (nqk->N + nv->N);
-    by += (double)M * (nqk->N + nv->N) * 2 + 256.0 * (nqk->N + nv->N) * 2;
-  }
-  ProfScope ps(c, ST_LG_GEMM, st, fl, by);
-  launch_lg_blockf(c->mprec, a, st);
-}
-
-void lg_ffn(airfe_ctx* c, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st) {
-  run_linear(c, f0, c->xb, 256, 256, c->msg, 256, M, EPI_STORE, ACT_NONE, c->hb, 512, st);
-  { ProfScope ps(c, ST_LG_LNGELU, st, 0, (double)M * 2048); launch_ln_gelu(c->mprec, c->hb, g, b, M, st); }
-  run_linear(c, f3, c->hb, 512, 512, nullptr, 0, M, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
-}
-
-// The surplus rows behind the last real token (alloc_matcher_arena's slack) go through every block like real ones: their residual
-// stream would keep growing from step to step (x += f(x), never re-initialised) until the 2-byte shadow overflows — and the last
-// sequence's final key tile multiplies those rows' V by probability 0, which is NaN once they are not finite.  Back to zero per call.
-void reset_slack_rows(airfe_ctx* c, int M, hipStream_t st) {
-  if ((size_t)M >= c->arena_rows) return;
-  launch_zero16(c->x32 + (size_t)M * 256, (c->arena_rows - (size_t)M) * 256 * sizeof(float), st);
-  launch_zero16(c->xb + (size_t)M * 256, (c->arena_rows - (size_t)M) * 256 * sizeof(uint16_t), st);
-}
-
-// LightGlue forward on B pairs whose feature rows live on the device
-int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1, const int* n1, int B, int cap, int ld,
-                  int kp_off, int normalize, int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, float* scores_out,
-                  hipStream_t st) {
-  if (!c->has_lg) return fail(c, "LightGlue weights were not loaded (cfg.lightglue_pack)");
-  if (B < 1 || B > c->Pmax) return fail(c, "pair batch exceeds cfg.max_batch / 2");
-  if (cap > c->Np) return fail(c, "feature capacity exceeds the matcher arena (max_keypoints)");
-  if (c->mprec == 2) return lightglue_dev_f32(c, f0, n0, f1, n1, B, cap, ld, kp_off, normalize, d_idx, d_score, mcap, d_nmatch, scores_out, st);
-  const int S = 2 * B, Np = c->Np, M = S * Np;
-  const int Mg = (M + 127) / 128 * 128;          // rows the matrix kernels run over (surplus rows: arena slack, see alloc_matcher_arena)
-  LgPrepArgs pa;
-  pa.f0 = f0; pa.f1 = f1; pa.n0 = n0; pa.n1 = n1; pa.ld = ld; pa.kp_off = kp_off; pa.normalize = normalize;
-  // PointMatcher::NormalizeKeypoints (src/point_matcher.cc:39-48): integer width/2, L_inv = 1.0/max(w,h)*scale
-  pa.cx = (float)(c->cfg.image_width / 2);
-  pa.cy = (float)(c->cfg.image_height / 2);
-  pa.linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.5f);
-  pa.wr = c->lg_wr; pa.B = B; pa.cap = cap; pa.Np = Np;
-  pa.x32 = c->x32; pa.xb = c->xb; pa.rot_cos = c->rot_cos; pa.rot_sin = c->rot_sin; pa.lens = c->lens;
-  // the arena's slack rows go back to zero with the same launch (see reset_slack_rows; ADVICE r03: this line had moved to the fp32
-  // path only, so that the 2-byte path's slack rows kept their running residual from call to call)
-  // (only the rows a kernel of THIS call can touch: the 112- / 128-row rounding of the matrix kernels + one key tile)
-  pa.slack_rows = (int)std::min(c->arena_rows - (size_t)M, (size_t)512);
-  if (c->trace_on) { c->trace_slots.clear(); c->trace_overflow = false; }
-  c->trace_halt = false;
-  const size_t Mw = (size_t)M * 128;                     // 32-bit words of a [M][256] 2-byte buffer
-  auto tr_x = [&](size_t li, const char* blk) {
-    trace(c, st, "x32", li, blk, c->x32, (size_t)M * 256, 4096);
-    trace(c, st, "xb", li, blk, c->xb, Mw, 2048);
-  };
-  auto tr_qkv = [&](size_t li, const char* blk, bool k) {
-    trace(c, st, "q", li, blk, c->qb, Mw, 512);
-    if (k) trace(c, st, "k", li, blk, c->kb, Mw, 512);
-    trace(c, st, "vt", li, blk, c->vtb, Mw, (unsigned)Np / 2);
-  };
-  { ProfScope ps(c, ST_LG_PREPARE, st, 0, (double)M * (1036 + 1536 + 256)); launch_lg_prepare(c->mprec, pa, st); }
-  tr_x(0, "prep");
-  // the arena's slack rows as this call starts (must be zero: ADVICE r03 / test_slack_rows_are_reset_on_every_call) and, at the end, as it leaves them
-  const size_t slack_words = (size_t)(pa.slack_rows / 16 * 16) * 256;
-  if (slack_words) trace(c, st, "x32slack", 0, "prep", c->x32 + (size_t)M * 256, slack_words, 4096);
-  trace(c, st, "rc", 0, "prep", c->rot_cos, (size_t)M * 32, 512);
-  trace(c, st, "rs", 0, "prep", c->rot_sin, (size_t)M * 32, 512);
-  TRACE_HALT;
-  // The fused block (kernels_lgblockf.hip) streams 0.9 MB of weights per workgroup whatever the batch: with 112- / 128-token passes only, the four
-  // separate launches were quicker below 3200 tokens (profiles/r01d_small_batch_sweeps.txt); with 32- / 64-token passes for small token counts
-  // (lg_blockf() picks them) the fused form wins everywhere (profiles/r04_lg_small_batch_sweep.txt) and block_min is 0.
-  const bool fused_block = c->fuse_lg_block == 1 || (c->fuse_lg_block < 0 && Mg >= c->block_min);
-  // With the fused block the projections of the NEXT attention layer are computed inside it (FOLD): only the very first q | k | v
-  // projection is a launch of its own.
-  const bool fold = fused_block && c->fold_qkv;
-  const bool fold_c = fold, fold_s = fold;
-  for (size_t li = 0; li < c->lg.size(); ++li) {
-    const LgLayer& l = c->lg[li];
-    const LgLayer* nl = li + 1 < c->lg.size() ? &c->lg[li + 1] : nullptr;
-    // ---- self block
-    if (!fold_s || li == 0) { run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, c->rot_cos, c->rot_sin, st); tr_qkv(li, "self.qkv", true); }
-    TRACE_HALT;
-    { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); run_attention(c, c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
-    trace(c, st, "o", li, "self.attn", c->ob, Mw, 2048);
-    TRACE_HALT;
-    if (fused_block) {
-      lg_blockf(c, l.out, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st, 0, fold_c ? &l.cqk : nullptr, fold_c ? &l.cv : nullptr, false);
-      tr_x(li, "self.block");
-      TRACE_HALT;
-      if (fold_c) tr_qkv(li, "self.block", false);
-      TRACE_HALT;
-    } else {
-      run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
-      trace(c, st, "msg", li, "self.out", c->msg, Mw, 2048);
-      TRACE_HALT;
-      lg_ffn(c, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
-      tr_x(li, "self.ffn");
-      TRACE_HALT;
-    }
-    // ---- cross block (one shared projection for q and k; the two sides swap roles)
-    if (!fold_c) { run_qkv(c, l.cqk, l.cv, Mg, c->qb, nullptr, nullptr, nullptr, st); tr_qkv(li, "cross.qkv", false); }
-    TRACE_HALT;
-    { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); run_attention(c, c->mprec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
-    trace(c, st, "o", li, "cross.attn", c->ob, Mw, 2048);
-    TRACE_HALT;
-    if (fused_block) {
-      const bool fn = fold_s && nl;
-      lg_blockf(c, l.cout, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st, 0, fn ? &nl->qk : nullptr, fn ? &nl->v : nullptr, true);
-      tr_x(li, "cross.block");
-      TRACE_HALT;
-      if (fn) tr_qkv(li, "cross.block", true);
-      TRACE_HALT;
-    } else {
-      run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
-      trace(c, st, "msg", li, "cross.out", c->msg, Mw, 2048);
-      TRACE_HALT;
-      lg_ffn(c, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st);
-      tr_x(li, "cross.ffn");
-      TRACE_HALT;
-    }
-  }
-  const size_t LF = c->lg.size();
-  run_linear(c, c->lg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
-  trace(c, st, "md", LF, "final", c->mdb, Mw, 2048);
-  if (slack_words) trace(c, st, "x32slack", LF, "final", c->x32 + (size_t)M * 256, slack_words, 4096);
-  TRACE_HALT;
-  ProfScope ps(c, ST_LG_ASSIGN, st, 2.0 * B * Np * (double)Np * 256, (double)B * Np * Np * 4 * 6);
-  launch_rowdot256(c->x32, c->lg_mw, c->lg_mb, c->zbuf, M, st);
-  trace(c, st, "z", LF, "final", c->zbuf, (size_t)M, 16);
-  TRACE_HALT;
-  launch_sim(c->mprec, c->mdb, c->simbuf, B, Np, st);
-  trace(c, st, "sim", LF, "final", c->simbuf, (size_t)B * Np * Np, 16u * (unsigned)Np);
-  TRACE_HALT;
-  launch_lg_assign(c->simbuf, c->zbuf, c->lens, B, Np, mcap, 0.1f, c->rowlse, c->collse, scores_out, c->rowarg, c->rowval,
-                   c->colarg, d_idx, d_score, d_nmatch, st);
-  trace(c, st, "rowlse", LF, "assign", c->rowlse, (size_t)B * Np, (unsigned)Np);
-  TRACE_HALT;
-  trace(c, st, "collse", LF, "assign", c->collse, (size_t)B * Np, (unsigned)Np);
-  TRACE_HALT;
-  trace(c, st, "rowval", LF, "assign", c->rowval, (size_t)B * Np, (unsigned)Np);
-  TRACE_HALT;
-  trace(c, st, "rowarg", LF, "assign", c->rowarg, (size_t)B * Np, (unsigned)Np);
-  TRACE_HALT;
-  trace(c, st, "colarg", LF, "assign", c->colarg, (size_t)B * Np, (unsigned)Np);
-  TRACE_HALT;
-  return trace_finish(c, st);
-}
-
-// SuperGlue forward on B pairs of device feature matrices (259-float rows) -> decode outputs [B][Lz]
-int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1, const int* n1, int B, int cap, int normalize,
-                  hipStream_t st) {
-  if (!c->has_sg) return fail(c, "SuperGlue weights were not loaded (cfg.superglue_pack)");
-  if (B < 1 || B > c->Pmax) return fail(c, "pair batch exceeds cfg.max_batch");
-  if (cap > c->Np) return fail(c, "feature capacity exceeds the matcher arena (max_keypoints)");
-  const int S = 2 * B, Np = c->Np, M = S * Np;
-  const int Mg = (M + 127) / 128 * 128;
-  const float cx = (float)(c->cfg.image_width / 2), cy = (float)(c->cfg.image_height / 2);
-  const float linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.7f);   // point_matcher.cc:58
-  // keypoint encoder: from block_min tokens on, its two large layers (98 of 108 kFLOP per keypoint) run as MFMA GEMMs
-  const bool kenc_gemm = c->sg_kenc_gemm == 1 || (c->sg_kenc_gemm < 0 && Mg >= c->block_min);
-  reset_slack_rows(c, M, st);
-  launch_sg_prepare(c->mprec, f0, f1, n0, n1, AIRFE_FEAT_DIM, normalize, cx, cy, linv, c->sg_kenc, B, cap, Np, c->x32, c->xb,
-                    c->lens, kenc_gemm ? c->msg : nullptr, st);
-  if (kenc_gemm) {
-    if (Mg > M) {          // the surplus rows of the 128-row rounding: zero inputs, so that the residual add leaves x = b4-ish garbage, not a running sum
-      HIPCHK(c, hipMemsetAsync(c->msg + (size_t)M * 128, 0, (size_t)(Mg - M) * 128 * 2, st));
-      HIPCHK(c, hipMemsetAsync(c->x32 + (size_t)M * 256, 0, (size_t)(Mg - M) * 256 * 4, st));
-    }
-    run_linear(c, c->sg_k3, c->msg, 128, 128, nullptr, 0, Mg, EPI_STORE, ACT_RELU, c->hb, 256, st);
-    run_linear(c, c->sg_k4, c->hb, 256, 256, nullptr, 0, Mg, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
-  }
-  const bool fused_block = c->fuse_lg_block == 1 || (c->fuse_lg_block < 0 && Mg >= c->block_min);
-  int li = 0;
-  for (const SgLayer& l : c->sg) {
-    const int cross = li & 1;      // names = ['self','cross'] * 9
-    ++li;
-    run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, nullptr, nullptr, st);
-    {
-      ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048);
-      run_attention(c, c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, cross, 0.125f, st);
-    }
-    if (fused_block) {          // merge + mlp.0 + ReLU + mlp.3 + residual as ONE kernel (the LightGlue block kernel with ReLU for LN + GELU)
-      lg_blockf(c, l.merge, l.mlp0, nullptr, nullptr, l.mlp3, Mg, st, 1);
-      continue;
-    }
-    run_linear(c, l.merge, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
-    run_linear(c, l.mlp0, c->xb, 256, 256, c->msg, 256, Mg, EPI_STORE, ACT_RELU, c->hb, 512, st);
-    run_linear(c, l.mlp3, c->hb, 512, 512, nullptr, 0, Mg, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
-  }
-  run_linear(c, c->sg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
-  launch_sim(c->mprec, c->mdb, c->simbuf, B, Np, st);
-  launch_sg_sinkhorn(c->simbuf, c->lens, B, Np, c->Lz, c->sg_alpha, c->cfg.sinkhorn_iters, c->sg_u, c->sg_v, c->sg_Z, c->sg_cnt, c->sg_cnt + (size_t)c->Pmax * 16, c->sg_xch, st);
-  launch_sg_decode(c->sg_Z, c->lens, B, Np, c->Lz, 0.2f, c->sg_idx0, c->sg_max0, c->sg_idx1, c->sg_out0, c->sg_out1, c->sg_ms0,
-                   c->sg_ms1, st);
-  HIPCHK(c, hipGetLastError());
-  return 0;
-}
-
-
-// PLNet stage-0 LINE branch of images [i0, i0 + nb) of the batch the detector just ran on: fills stage slots 0 .. nb-1 with the Appendix
-// A.1 tensors in the contract's own layouts, so that everything downstream (wireframe dedup, stage 1, filters) is the code the golden
-// tests pin.  chw: also the contract's CHW loi_features of slot 0 (the inspection hook; the line path samples the head rows directly).
-int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
-  if (!c->has_s0) return fail(c, "the detector pack carries no line branch (line.* tensors)");
-  if (!c->s0_stage) return fail(c, "the line path arena is not allocated (cfg.plnet_s1_pack)");
-  if (nb < 1 || nb > c->Lmax || i0 < 0 || i0 + nb > c->Dmax) return fail(c, "line branch: image range outside the arena");
-  const int NP = KEEP_CAP, F = 128;
-  float* d = c->s0_stage;
-  // Two forms of the 1x1 head.  FUSED (fp32 mode, inspection hook; one image): all 145 channels at every pixel -> l_head [128*128][160].
-  // SPLIT (everything else): the 17 decoded channels at every pixel, decoded in the same pass (or, AIRFE_FUSE_DEC=0, -> l_dec [nb][128*128][32]
-  // and a decode pass of its own); the 128 LOI channels — read only at the four
-  // bilinear taps of the <= 300 junctions — by a gather GEMM over those <= 1200 rows per image once the junctions are known (line_tail_dev):
-  // the fused head wrote 1.07 GB of LOI features per 128 images to read 7 % of them.  Same kernel, same K order: the same bits.
-  const bool fused = c->prec == 2 || chw;
-  if (fused && (nb != 1 || i0 != 0)) return fail(c, "the fused line head (fp32 mode, inspection hook) runs one image at a time");
-  c->line_sparse = !fused;
-  bool head_done = false;
-  if (c->prec == 2) {
-    launch_conv3x3_f32(c->f3a, c->f_cL1.w, c->f_cL1.b, c->fL1, 1, F, F, 128, 128, 0, st);
-    GemmF32Args g;
-    g.X1 = c->fL1; g.ld1 = 128; g.K1 = 128; g.K = 128; g.W = c->f_cLh.w; g.bias = c->f_cLh.b; g.M = F * F; g.N = 145; g.Y = c->l_head; g.ldy = 160;
-    launch_gemm_f32(g, st);
-  } else {
-    // conv3a features (zero-bordered NHWC, still in the arena for the whole batch) -> [nb * 128*128][128]
-    run_conv(c, c->cL1, c->a3a + (size_t)i0 * (F + 2) * (F + 2) * 128, c->l_feat, nb, F, F, 0, 0, st);
-    static const bool fuse_dec = !(getenv("AIRFE_FUSE_DEC") && atoi(getenv("AIRFE_FUSE_DEC")) == 0);
-    if (!fused && fuse_dec) {        // the 17-channel head and its decode in one pass over the line features (kernels_s0.hip)
-      ProfScope ps(c, ST_PL_DECODE, st, 2.0 * nb * F * F * 128 * 17, (double)nb * F * F * (256 + 92));
-      launch_s0_head_decode(c->prec, c->l_feat, c->cLh_dec.w, c->cLh_dec.b, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, c->l_ta8, nb, SG_STRIDE,
-                            st);
-      head_done = true;
-    } else {
-      const LinW& hw = fused ? c->cLh : c->cLh_dec;
-      GemmArgs g;
-      g.X1 = c->l_feat; g.ld1 = 128; g.K1 = 128; g.Wp = hw.w; g.bias = hw.b;
-      g.M = nb * F * F; g.N = hw.N; g.cb_total = hw.cbt; g.epi = EPI_STORE_F32; g.out = fused ? c->l_head : c->l_dec; g.ldo = fused ? 160 : 32;
-      g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-      if (!fused) g.small_max = 1 << 30;      // one 64-feature block: the no-LDS kernel computes 64 columns per row instead of the tiled kernels' 256
-      ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * nb * F * F * 128 * hw.N, (double)nb * F * F * (256 + 4.0 * g.ldo));
-      launch_gemm(c->prec, 128, false, g, st);
-    }
-  }
-  // head rows read once, 49152 proposals + maps written; the j2l match reads them again
-  ProfScope ps(c, ST_PL_DECODE, st, 0, (double)nb * (128.0 * 128 * (17 * 4 + 3 * 16 + 11 * 4) + 3.0 * 49152 * (16 + 12)));
-  if (head_done) {
-    // (lines_pred, jloc, jnms, joff and the pixel-major thin | aux are already there)
-  } else if (fused)
-    launch_s0_decode(c->l_head, 160, 128, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, chw ? c->s0_loi : nullptr, c->l_ta8, nb,
-                     SG_STRIDE, st);
-  else
-    launch_s0_decode(c->l_dec, 32, 0, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, nullptr, c->l_ta8, nb, SG_STRIDE, st);
-  // get_junctions: top-300 of the suppressed junction map (score descending, raster ascending on ties)
-  const int ccap = F * F;
-  hipStream_t s3 = st;
-  launch_candidates(c->l_jnms, nb, F, F, 1e-30f, 0, c->l_cand, c->l_cand_cnt, ccap, s3);
-  launch_select_list(c->l_cand, c->l_cand_cnt, ccap, nb, F, 300, 320, c->l_sel, c->l_nsel, s3);
-  launch_s0_juncs(c->l_sel, c->l_nsel, c->l_joff, d + SG_JUNCS, 300, 320, nb, SG_STRIDE, s3);
-  launch_s0_j2l(d + SG_LP, d + SG_JUNCS, 300, NP, 10.0f, d + SG_KEEP, d + SG_MIN, d + SG_MAX, nb, SG_STRIDE, chw ? 1 : 0, s3);
-  HIPCHK(c, hipGetLastError());
-  return 0;
-}
-
-// Everything behind the stage-0 tensors for stage slots 0 .. nb-1 (= images i0 .. i0+nb-1 of the detector batch): wireframe_matcher,
-// stage 1, the line / junction filter (plnet.cpp:272-307, 468-558) and, for the first nj of them, junction_detector + descriptors
-// (plnet.cpp:425-448).  LOI features: the head GEMM's rows (loi == nullptr) or a CHW block.  Results go to DEVICE buffers:
-// d_lines [nb][capL][4], d_nlines / d_lfound [nb], d_junc [nj][capJ][259], d_njunc / d_jfound [nj] (found > cap = the caller's overflow).
-// phase: 1 = the lines (needs nothing of the point branch), 2 = the junctions (score maps, descriptor maps of the point branch), 3 = both.
-int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int w, double* d_lines, int capL, int* d_nlines, int* d_lfound,
-                  float* d_junc, int capJ, int* d_njunc, int* d_jfound, int nj, hipStream_t st, int phase = 3) {
-  if (!c->has_s1) return fail(c, "PLNet stage-1 weights were not loaded (cfg.plnet_s1_pack)");
-  if (nb < 1 || nb > c->Lmax || nj < 0 || nj > nb) return fail(c, "line path: image range outside the arena");
-  const int R = AIRFE_INTERNAL_SIZE, NP = KEEP_CAP;
-  float* d = c->s0_stage;
-  const float ws = (float)w / (float)R, hs = (float)h / (float)R;
-  if (phase & 1) {
-  hipStream_t s4 = st;
-  if (nj > 0) launch_zero16(c->jmap, (size_t)nj * R * R, s4);
-  {
-  ProfScope ps(c, ST_PL_STAGE1, st, 0, (double)nb * 49152 * 12);
-  launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
-                   c->wf_counts, nb, SG_STRIDE, s4);
-  if (loi_chw) {                    // host-supplied contract tensors: all 496 features per line from the CHW blocks
-    launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, loi_chw, 0, nullptr, nullptr, d + SG_THIN, d + SG_AUX,
-                    c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
-  } else {
-    if (c->line_sparse) {           // the LOI head at the junctions' tap rows only
-      const int M = nb * 1200, Mp = (M + 255) / 256 * 256;
-      hipStream_t s5 = st;
-      launch_s1_junc_rows(d + SG_JUNCS, 300, c->l_ridx, nb, SG_STRIDE, s5);
-      if (Mp > M) HIPCHK(c, hipMemsetAsync(c->l_ridx + M, 0, (size_t)(Mp - M) * 4, s5));
-      GemmArgs g;
-      g.X1 = c->l_feat; g.ld1 = 128; g.K1 = 128; g.Wp = c->cLh_loi.w; g.bias = c->cLh_loi.b; g.rowidx = c->l_ridx;
-      g.M = Mp; g.N = 128; g.cb_total = c->cLh_loi.cbt; g.epi = EPI_STORE_F32; g.out = c->l_lrows; g.ldo = 128;
-      launch_gemm8(c->prec, 128, false, g, s5);
-      launch_s1_junc_proj(d + SG_JUNCS, nullptr, 0, 0, c->l_lrows, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, s5);
-    } else {
-      launch_s1_junc_proj(d + SG_JUNCS, c->l_head, (size_t)128 * 128 * 160, 160, nullptr, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, st);
-    }
-    launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, nullptr, 0, c->s1_jfeat, c->l_ta8, d + SG_THIN,
-                    d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
-  }
-  }
-  ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nb * R * R);
-  launch_line_filter(c->s1_la, c->s1_sc, c->wf_counts, c->cfg.remove_borders, c->cfg.line_threshold, c->cfg.line_length_threshold, ws, hs, R,
-                     c->jmap, nj, d_lines, capL, d_nlines, d_lfound, LINE_CAP, nb, st);
-  }
-  if ((phase & 2) && nj > 0) {
-    ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nj * R * R * 2);
-    if (c->cfg.nms_radius > 0 && !c->nms_map_valid) return fail(c, "line path: the NMS'd score maps of this batch were not kept");
-    const float* hsel = (c->cfg.nms_radius > 0 ? c->heat_nms : c->heat) + (size_t)i0 * R * R;
-    launch_junction_scan(c->jmap, hsel, R, c->cfg.remove_borders, d_junc, capJ, d_njunc, d_jfound, c->d_njunc + 2 * c->Lmax, nj, st);
-    if (!c->desc_dense_valid) return fail(c, "line path: the dense descriptor map of this batch was not made");
-    launch_sample_desc(c->desc + (size_t)i0 * (R / 8) * (R / 8) * 256, nj, R / 8, R / 8, d_junc, d_njunc, capJ, ws, hs,
-                       c->desc_normalised ? 0 : 1, st);
-  }
-  HIPCHK(c, hipGetLastError());
-  return 0;
-}
+namespace {
 
 // grow-on-demand staging block: the previous block is freed (it used to stay in `allocs` until destroy)
 int ensure_block(airfe_ctx* c, uint8_t*& blk, size_t& have, size_t bytes) {

@@ -144,12 +144,12 @@ struct LgPrepArgs {
   float* x32; uint16_t* xb;           // [2B][Np][256]
   float* rot_cos; float* rot_sin;     // [2B][Np][32]
   int* lens;                          // [2B]
-  int slack_rows = 0;                 // token rows behind the last sequence that are reset to zero as well (the arena's slack, airfe.hip)
+  int slack_rows = 0;                 // token rows behind the last sequence that are reset to zero as well (the arena's slack, airfe_load.hip: alloc_matcher_arena)
 };
 void launch_lg_prepare(int prec, const LgPrepArgs& a, hipStream_t st);
 // flash attention over head-major Q,K [S][H][Np][64] and Vt [S][H][64][Np] -> O [S][Np][256]; cross => kv sequence s^1; on the 32x32x16
 // MFMA, one query per lane (kernels_attn.hip).  q and k arrive PRE-SCALED by sqrt(scale * log2 e) each (folded into their projection
-// weights: ATT_QK_FOLD in airfe.hip)
+// weights: ATT_QK_FOLD in airfe_host.h)
 void launch_attention32(int prec, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, const int* lens,
                         int S, int H, int Np, int cross, hipStream_t st);
 // in-place LayerNorm(512, eps) + exact GELU on 2-byte [M][512]

@@ -60,7 +60,7 @@ __device__ __forceinline__ void att_glds16(const void* sbase, unsigned voff, uns
 constexpr float ATT_PSUM_MAX = 16384.0f;   // a lane's partial row sum above this sends the tile through the re-centring path
 
 // The soft-max scale is NOT applied here: sqrt(scale * log2 e) is folded into the packed q and k projection weights
-// (airfe.hip: ATT_QK_FOLD), so the accumulators already hold s = log2(e) * q.k / sqrt(d).  The running shift m of the online
+// (airfe_host.h: ATT_QK_FOLD), so the accumulators already hold s = log2(e) * q.k / sqrt(d).  The running shift m of the online
 // soft-max enters through the C operand of the first MFMA of every score chain (a 16-register broadcast of -m that changes only
 // when the shift does), so a tile's probabilities are ONE v_exp_f32 per score: p = 2^(s - m), no fma, no per-tile row maximum.
 // m is exact after the first tile (explicit maximum there); afterwards it is stale by design — soft-max is shift-invariant, the

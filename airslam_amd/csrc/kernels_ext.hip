@@ -768,7 +768,7 @@ struct SgPrepArgs {
 
 // SPLIT: only the three small layers (3 -> 32 -> 64 -> 128: 10 of the 108 kFLOP per keypoint) run here; the kernel writes the 128
 // hidden features (2-byte) and x = the descriptor, and the two large layers (128 -> 256 + ReLU, 256 -> 256 added to x) follow as MFMA
-// GEMMs (airfe.hip).  As scalar FMA loops all five layers took 0.29 ms per 51200 keypoints, latency-bound on LDS broadcast reads.
+// GEMMs (airfe_match.hip).  As scalar FMA loops all five layers took 0.29 ms per 51200 keypoints, latency-bound on LDS broadcast reads.
 template <class P, bool SPLIT>
 __global__ __launch_bounds__(256) void sg_prepare_kernel(SgPrepArgs a) {
   __shared__ float bufa[KE_LT][256], bufb[KE_LT][256];

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, 3) void head_softmax_d2s_kernel(const uint16_t
 // requires M % 256 == 0, K % 64 == 0, K1 % 64 == 0
 void launch_gemm8(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st) {
   if (a.epi == EPI_SOFTMAX_D2S) {                          // the detector head: its own streaming kernel (above); K = 256, N = 65, rows = cells
-    if (trans || K != 256 || a.N != 65 || a.X2 || a.rowidx || a.ld1 != 256 || a.M % 16 != 0) {           // (airfe.hip builds no other form)
+    if (trans || K != 256 || a.N != 65 || a.X2 || a.rowidx || a.ld1 != 256 || a.M % 16 != 0) {           // (airfe_detect.hip builds no other form)
       fprintf(stderr, "airfe: EPI_SOFTMAX_D2S is the detector head only (K = 256, N = 65, dense rows)\n");
       abort();
     }

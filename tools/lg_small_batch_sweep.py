@@ -1,6 +1,6 @@
 """LightGlue forward time at small pair counts, fused block (32- / 64-token passes) against the four separate launches per block:
     python tools/lg_small_batch_sweep.py            (on an MI355X; prints one line per (pairs, form))
-Decides GemmArgs/block_min (airfe.hip): from which token count the fused kernel is the quicker form."""
+Decides GemmArgs/block_min (airfe_match.hip: lg_blockf, lightglue_dev): from which token count the fused kernel is the quicker form."""
 import os
 import subprocess
 import sys
