@@ -138,3 +138,24 @@ def test_track_frame_equals_detect_plus_match():
     with pytest.raises(api.AirfeError, match="no reference features"):
         fresh.track_frame(key)
     fresh.close()
+
+
+def test_no_keypoints_at_all():
+    """a detector that finds nothing (threshold above every score): the one-call entries return empty features, no matches (point_matcher.cc:53-55),
+    whatever lines there are — and do not hang on zero-length sequences"""
+    W, H = 752, 480
+    left, right = synth.stereo_pair(H, W, 1000)
+    ctx = _ctx(W, H, keypoint_threshold=2.0)
+    k = ctx.stereo_keyframe(left, right)
+    assert len(k["featL"]) == 0 and len(k["featR"]) == 0 and len(k["idx"]) == 0 and len(k["score"]) == 0
+    feat, idx, sc = ctx.track_frame(left, ref_feat=np.zeros((0, 259), np.float32))
+    assert len(feat) == 0 and len(idx) == 0
+    ctx.close()
+    ok_ctx = _ctx(W, H)
+    want = ok_ctx.stereo_keyframe(left, right)
+    feat, idx, sc = ok_ctx.track_frame(left, ref_feat=want["featL"])
+    np.testing.assert_array_equal(feat, want["featL"])
+    assert len(idx) >= 100 and (idx[:, 0] == idx[:, 1]).all()
+    feat, idx, sc = ok_ctx.track_frame(left, ref_feat=np.zeros((0, 259), np.float32))     # an empty reference: features, no matches
+    assert len(feat) == len(want["featL"]) and len(idx) == 0
+    ok_ctx.close()
