@@ -159,3 +159,21 @@ def test_no_keypoints_at_all():
     feat, idx, sc = ok_ctx.track_frame(left, ref_feat=np.zeros((0, 259), np.float32))     # an empty reference: features, no matches
     assert len(feat) == len(want["featL"]) and len(idx) == 0
     ok_ctx.close()
+
+
+def test_one_call_entries_are_deterministic_over_many_calls():
+    """two streams, copies beside kernels, blocks reused from call to call: 300 keyframes and 300 tracked frames, alternating between two image pairs,
+    must return the first call's bits every time"""
+    W, H = 752, 480
+    ctx = _ctx(W, H)
+    pairs = [synth.stereo_pair(H, W, 1000), synth.stereo_pair(H, W, 1002)]
+    want = [ctx.stereo_keyframe(*p) for p in pairs]
+    want_t = [ctx.track_frame(p[1], ref_feat=want[0]["featL"]) for p in pairs]
+    for i in range(300):
+        k = ctx.stereo_keyframe(*pairs[i & 1])
+        for key in want[i & 1]:
+            assert np.array_equal(k[key], want[i & 1][key]), (i, key)
+        t = ctx.track_frame(pairs[i & 1][1], ref_feat=want[0]["featL"] if i % 7 == 0 else None)
+        for a, b in zip(t, want_t[i & 1]):
+            assert np.array_equal(a, b), i
+    ctx.close()
