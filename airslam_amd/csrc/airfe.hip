@@ -148,6 +148,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   }
   if (getenv("AIRFE_OVERLAP_LINES")) c->overlap_lines = atoi(getenv("AIRFE_OVERLAP_LINES")) != 0;
   if (getenv("AIRFE_KF_GRAPH")) c->kf_graph_on = atoi(getenv("AIRFE_KF_GRAPH")) != 0;
+  if (getenv("AIRFE_KF_SPEC_ROWS")) c->kf_spec_lines = c->kf_spec_juncs = std::max(atoi(getenv("AIRFE_KF_SPEC_ROWS")), 1);   // (tests: force the second round trip)
   // a context with a detector AND the stereo matcher runs airfe_stereo_batch_dev over left + right images as one detector batch
   c->Dmax = (c->prec != 2 && cfg->superpoint_pack && cfg->lightglue_pack) ? 2 * c->Bmax : c->Bmax;
   c->chunk = std::min(std::max(cfg->enc_chunk, 1), c->Dmax);   // (a stereo step's 2 B images may go through the first layers as ONE chunk)
@@ -802,7 +803,8 @@ int airfe_detect_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int
 static int stereo_plnet_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
                             size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, double* d_lines,
                             int capL, int* d_nlines, float* d_juncL, int capJ, int* d_njuncL, int* d_found, int32_t* d_idx,
-                            float* d_score, int mcap, int* d_nmatch, hipStream_t st, const std::function<int(hipStream_t)>* after_detect = nullptr) {
+                            float* d_score, int mcap, int* d_nmatch, hipStream_t st, const std::function<int(hipStream_t)>* after_detect = nullptr,
+                            const std::function<int(hipStream_t)>* after_lines = nullptr) {
   if (!(c->prec != 2 && 2 * B <= c->Dmax))
     return fail(c, "stereo_plnet_batch: needs the one-pass stereo detector (detector + LightGlue packs loaded, 2 B <= 2 max_batch, fp16 / bf16)");
   // (With stage timers on anything behind the encoder the chains run one after the other: a stage's event pair must not span the other chain.)
@@ -820,9 +822,14 @@ static int stereo_plnet_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* 
   // With that form gone: 0 deviations in 3500 overlapped and 5000 single-stream steps (profiles/r03_matcher_trace_probe1.txt, _probe2.txt).
   // after_detect (the host entry's early copy of the feature rows): on the side stream where there is one, so that it runs beside the matcher
   if (after_detect && (!d_idx || !overlap) && (*after_detect)(st)) return 1;
-  if (!d_idx) return plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, d_juncL ? B : 0, d_found, st);
+  // after_lines (the host entry's copy of the first line / junction rows): behind the line path, on its stream
+  if (!d_idx) {
+    if (plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, d_juncL ? B : 0, d_found, st)) return 1;
+    return after_lines ? (*after_lines)(st) : 0;
+  }
   if (!overlap) {
     if (plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, d_juncL ? B : 0, d_found, st)) return 1;
+    if (after_lines && (*after_lines)(st)) return 1;
     return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
   }
   HIPCHK(c, hipEventRecord(c->ev_fork, st));                  // behind the point branch
@@ -834,6 +841,7 @@ static int stereo_plnet_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* 
   const bool lg_first = B <= 4;
   if (!rc && lg_first) rc = lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
   if (!rc) rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, d_juncL ? B : 0, d_found, c->stream2);
+  if (!rc && after_lines && (*after_lines)(c->stream2)) rc = 1;
   if (!rc && !lg_first) rc = lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));      // (also after an error: the caller's stream never runs ahead of the side stream)
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
@@ -888,10 +896,13 @@ int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* righ
   const size_t ib = (size_t)(h - 1) * stride + w, pitch = (size_t)h * stride;
   // pinned block: [counts | featL | featR] — copied back on the side stream as soon as the detector is done, beside the matcher — then the final
   // [counts] and [idx | score]
-  const size_t early = 64 + 2 * fb, late = early + 64;
+  // then, from the side stream behind the line path (also beside the matcher), the FIRST capS line rows of either image and capJS junction rows:
+  // the usual keyframe (a few hundred lines and junctions) needs no second round trip for them
+  const int capS = std::min(capLd, c->kf_spec_lines), capJS = want_j ? std::min(capJd, c->kf_spec_juncs) : 0;
+  const size_t early = 64 + 2 * fb, late = early + 64, spec = late + (size_t)Np * 12, spec_l = (size_t)capS * 32, spec_j = (size_t)capJS * AIRFE_FEAT_DIM * 4;
   if (ensure_stage_img(c, 2 * pitch)) return 1;
   // (sized for the line / junction rows of the second round trip too: the block must not move between calls, a captured graph holds its address)
-  if (ensure_pin(c, std::max(std::max(pitch + ib, late + (size_t)Np * 12), 2 * lb + (size_t)capJd * AIRFE_FEAT_DIM * 4))) return 1;
+  if (ensure_pin(c, std::max(std::max(pitch + ib, spec + 2 * spec_l + spec_j), 2 * lb + (size_t)capJd * AIRFE_FEAT_DIM * 4))) return 1;
   memcpy(c->pin, left, ib);
   memcpy(c->pin + pitch, right, ib);
   const std::function<int(hipStream_t)> early_copy = [&](hipStream_t s2) -> int {
@@ -899,11 +910,17 @@ int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* righ
     HIPCHK(c, hipEventRecord(c->ev_feat, s2));
     return 0;
   };
+  const std::function<int(hipStream_t)> rows_copy = [&](hipStream_t s2) -> int {
+    HIPCHK(c, hipMemcpyAsync(c->pin + spec, d_ln, spec_l, hipMemcpyDeviceToHost, s2));
+    HIPCHK(c, hipMemcpyAsync(c->pin + spec + spec_l, d_ln + (size_t)capLd * 4, spec_l, hipMemcpyDeviceToHost, s2));
+    if (spec_j) HIPCHK(c, hipMemcpyAsync(c->pin + spec + 2 * spec_l, d_jn, spec_j, hipMemcpyDeviceToHost, s2));
+    return 0;
+  };
   auto queue_all = [&]() -> int {
     HIPCHK(c, hipMemsetAsync(cnt, 0, 64, st));
     HIPCHK(c, hipMemcpyAsync(c->st_img, c->pin, pitch + ib, hipMemcpyHostToDevice, st));
     if (stereo_plnet_dev(c, c->st_img, c->st_img + pitch, 1, h, w, stride, pitch, d_fL, d_fR, Np, cnt, cnt + 1, d_ln, capLd, cnt + 2,
-                         want_j ? d_jn : nullptr, capJd, want_j ? cnt + 5 : nullptr, cnt + 6, match ? d_idx : nullptr, d_sc, Np, cnt + 4, st, &early_copy))
+                         want_j ? d_jn : nullptr, capJd, want_j ? cnt + 5 : nullptr, cnt + 6, match ? d_idx : nullptr, d_sc, Np, cnt + 4, st, &early_copy, &rows_copy))
       return 1;
     HIPCHK(c, hipMemcpyAsync(c->pin + early, cnt, 64, hipMemcpyDeviceToHost, st));
     if (match) HIPCHK(c, hipMemcpyAsync(c->pin + late, d_idx, (size_t)Np * 12, hipMemcpyDeviceToHost, st));
@@ -962,7 +979,11 @@ int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* righ
   if (want_j && fj > JUNC_CAP) return fail(c, "stereo_keyframe: more junctions than the device arena holds (JUNC_CAP)");
   if (fl0 > capLd || fl1 > capLd || (want_j && fj > capJd)) return fail(c, "stereo_keyframe: lines / junctions do not fit the caller's buffers (capL, capJ)");
   const size_t b0 = (size_t)nl0 * 32, b1 = (size_t)nl1 * 32, bj = want_j ? (size_t)nj * AIRFE_FEAT_DIM * 4 : 0;
-  if (b0 + b1 + bj) {
+  if (nl0 <= capS && nl1 <= capS && (!want_j || nj <= capJS)) {      // the rows are already here
+    if (b0) memcpy(linesL, c->pin + spec, b0);
+    if (b1) memcpy(linesR, c->pin + spec + spec_l, b1);
+    if (bj) memcpy(juncL, c->pin + spec + 2 * spec_l, bj);
+  } else if (b0 + b1 + bj) {
     if (ensure_pin(c, b0 + b1 + bj)) return 1;
     if (b0) HIPCHK(c, hipMemcpyAsync(c->pin, d_ln, b0, hipMemcpyDeviceToHost, st));
     if (b1) HIPCHK(c, hipMemcpyAsync(c->pin + b0, d_ln + (size_t)capLd * 4, b1, hipMemcpyDeviceToHost, st));

@@ -153,6 +153,7 @@ struct airfe_ctx {
   uint8_t* kf_blk = nullptr; size_t kf_bytes = 0;   // airfe_stereo_keyframe's device block (grows on demand)
   uint8_t *tk_blk = nullptr, *ref_blk = nullptr; size_t tk_bytes = 0, ref_bytes = 0;   // airfe_track_frame: outputs; the last keyframe's features
   int ref_n = -1;
+  int kf_spec_lines = 1024, kf_spec_juncs = 512;   // line / junction rows airfe_stereo_keyframe copies back before it knows the counts (AIRFE_KF_SPEC_ROWS)
   bool kf_graph_on = false;                         // AIRFE_KF_GRAPH
   KfGraph kf_graph;
   float *st_feat0 = nullptr, *st_feat1 = nullptr, *st_score = nullptr;

@@ -177,3 +177,21 @@ def test_one_call_entries_are_deterministic_over_many_calls():
         for a, b in zip(t, want_t[i & 1]):
             assert np.array_equal(a, b), i
     ctx.close()
+
+
+def test_rows_beyond_the_speculative_copy_take_the_second_round_trip(monkeypatch):
+    """the entry copies the first 1024 line rows per image and 512 junction rows back before it knows the counts; more than that (here: more than 64,
+    AIRFE_KF_SPEC_ROWS) is fetched in a second round trip — same results either way"""
+    W, H = 752, 480
+    left, right = synth.stereo_pair(H, W, 1003)
+    ctx = _ctx(W, H)
+    want = ctx.stereo_keyframe(left, right)
+    ctx.close()
+    assert len(want["linesL"]) > 64 and len(want["juncL"]) > 64
+    monkeypatch.setenv("AIRFE_KF_SPEC_ROWS", "64")
+    ctx = _ctx(W, H)
+    for _ in range(2):
+        got = ctx.stereo_keyframe(left, right)
+        for key in want:
+            np.testing.assert_array_equal(got[key], want[key])
+    ctx.close()
