@@ -191,9 +191,9 @@ void launch_sim(int prec, const uint16_t* md, float* sim, int B, int Np, hipStre
 // =============================================================================== assignment + filter
 
 // wave per row: log-sum-exp over j < n1
-__global__ void lg_rowlse_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np,
-                                 float* __restrict__ rowlse) {
-  const int b = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void lg_rowlse_body(int bx, const float* __restrict__ sim, const int* __restrict__ lens, int Np,
+                                               float* __restrict__ rowlse) {
+  const int b = blockIdx.y, i = bx * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
   if (i >= n0) return;
   const float* r = sim + ((size_t)b * Np + i) * Np;
@@ -209,10 +209,11 @@ __global__ void lg_rowlse_kernel(const float* __restrict__ sim, const int* __res
 // 64 columns x 16 row slices per workgroup: log-sum-exp over i < n0 (coalesced across the block's columns; a single thread per
 // column walked its 400 rows as one dependent chain of L2 loads and took longer than the similarity GEMM; four slices: 54 us)
 constexpr int LG_CS = 16;                     // row slices of the column kernels
-__global__ __launch_bounds__(64 * LG_CS) void lg_collse_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np,
-                                                               float* __restrict__ collse) {
+constexpr int LG_MERGE_MAX_B = 8;             // up to this many pairs the row and the column kernel of a stage share a launch
+__device__ __forceinline__ void lg_collse_body(int bx, const float* __restrict__ sim, const int* __restrict__ lens, int Np,
+                                               float* __restrict__ collse) {
   __shared__ float part[LG_CS][64];
-  const int b = blockIdx.y, jj = threadIdx.x & 63, q = threadIdx.x >> 6, j = blockIdx.x * 64 + jj;
+  const int b = blockIdx.y, jj = threadIdx.x & 63, q = threadIdx.x >> 6, j = bx * 64 + jj;
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
   const bool live = j < n1;
   const float* c = sim + (size_t)b * Np * Np + j;
@@ -237,16 +238,30 @@ __global__ __launch_bounds__(64 * LG_CS) void lg_collse_kernel(const float* __re
     collse[(size_t)b * Np + j] = mx + logf(tot);
   }
 }
+__global__ void lg_rowlse_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np, float* __restrict__ rowlse) {
+  lg_rowlse_body(blockIdx.x, sim, lens, Np, rowlse);
+}
+__global__ __launch_bounds__(64 * LG_CS) void lg_collse_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np, float* __restrict__ collse) {
+  lg_collse_body(blockIdx.x, sim, lens, Np, collse);
+}
+// row and column log-sum-exp as ONE launch for small batches (round 4: a dependent launch costs ~4.7 us whatever it does, and the batch-1 matcher has 48 of them):
+// workgroups [0, nrb) take 16 rows each (a wave per row), the rest 64 columns each.  Same bodies as the two kernels above, which large batches keep
+// (there the four-row workgroups fill the chip better: 0.13 against 0.17 ms per 64 pairs).
+__global__ __launch_bounds__(64 * LG_CS) void lg_lse_kernel(const float* __restrict__ sim, const int* __restrict__ lens, int Np, int nrb,
+                                                            float* __restrict__ rowlse, float* __restrict__ collse) {
+  if ((int)blockIdx.x < nrb) lg_rowlse_body(blockIdx.x, sim, lens, Np, rowlse);
+  else lg_collse_body(blockIdx.x - nrb, sim, lens, Np, collse);
+}
 
 __device__ __forceinline__ float lg_score(float sv, float rl, float cl, float c0, float c1) {
   return ((sv - rl) + (sv - cl)) + (c0 + c1);
 }
 
 // wave per row: scores (optionally materialised) + row arg-max, first maximum wins
-__global__ void lg_rowarg_kernel(const float* __restrict__ sim, const float* __restrict__ z, const int* __restrict__ lens,
-                                 int Np, const float* __restrict__ rowlse, const float* __restrict__ collse,
-                                 float* __restrict__ scores_out, int* __restrict__ rowarg, float* __restrict__ rowval) {
-  const int b = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void lg_rowarg_body(int bx, const float* __restrict__ sim, const float* __restrict__ z, const int* __restrict__ lens,
+                                               int Np, const float* __restrict__ rowlse, const float* __restrict__ collse,
+                                               float* __restrict__ scores_out, int* __restrict__ rowarg, float* __restrict__ rowval) {
+  const int b = blockIdx.y, i = bx * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
   if (i >= n0) return;
   const float* r = sim + ((size_t)b * Np + i) * Np;
@@ -276,12 +291,12 @@ __global__ void lg_rowarg_kernel(const float* __restrict__ sim, const float* __r
 
 // 64 columns x 4 row slices per workgroup: column arg-max over rows, first maximum wins (strict '>' inside a slice, lowest row
 // index between slices); z holds log-sigmoid matchabilities.
-__global__ __launch_bounds__(64 * LG_CS) void lg_colarg_kernel(const float* __restrict__ sim, const float* __restrict__ z,
-                                                               const int* __restrict__ lens, int Np, const float* __restrict__ rowlse,
-                                                               const float* __restrict__ collse, int* __restrict__ colarg) {
+__device__ __forceinline__ void lg_colarg_body(int bx, const float* __restrict__ sim, const float* __restrict__ z,
+                                               const int* __restrict__ lens, int Np, const float* __restrict__ rowlse,
+                                               const float* __restrict__ collse, int* __restrict__ colarg) {
   __shared__ float pbest[64 * LG_CS];
   __shared__ int pidx[64 * LG_CS];
-  const int b = blockIdx.y, jj = threadIdx.x & 63, q = threadIdx.x >> 6, j = blockIdx.x * 64 + jj;
+  const int b = blockIdx.y, jj = threadIdx.x & 63, q = threadIdx.x >> 6, j = bx * 64 + jj;
   const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
   const float* z0 = z + (size_t)(2 * b) * Np;
   const bool live = j < n1;
@@ -309,6 +324,24 @@ __global__ __launch_bounds__(64 * LG_CS) void lg_colarg_kernel(const float* __re
     }
     colarg[(size_t)b * Np + j] = (bi == 0x7FFFFFFF) ? 0 : bi;
   }
+}
+__global__ void lg_rowarg_kernel(const float* __restrict__ sim, const float* __restrict__ z, const int* __restrict__ lens, int Np,
+                                 const float* __restrict__ rowlse, const float* __restrict__ collse, float* __restrict__ scores_out,
+                                 int* __restrict__ rowarg, float* __restrict__ rowval) {
+  lg_rowarg_body(blockIdx.x, sim, z, lens, Np, rowlse, collse, scores_out, rowarg, rowval);
+}
+__global__ __launch_bounds__(64 * LG_CS) void lg_colarg_kernel(const float* __restrict__ sim, const float* __restrict__ z, const int* __restrict__ lens,
+                                                               int Np, const float* __restrict__ rowlse, const float* __restrict__ collse,
+                                                               int* __restrict__ colarg) {
+  lg_colarg_body(blockIdx.x, sim, z, lens, Np, rowlse, collse, colarg);
+}
+// row and column arg-max as one launch (see lg_lse_kernel)
+__global__ __launch_bounds__(64 * LG_CS) void lg_arg_kernel(const float* __restrict__ sim, const float* __restrict__ z, const int* __restrict__ lens,
+                                                            int Np, int nrb, const float* __restrict__ rowlse, const float* __restrict__ collse,
+                                                            float* __restrict__ scores_out, int* __restrict__ rowarg, float* __restrict__ rowval,
+                                                            int* __restrict__ colarg) {
+  if ((int)blockIdx.x < nrb) lg_rowarg_body(blockIdx.x, sim, z, lens, Np, rowlse, collse, scores_out, rowarg, rowval);
+  else lg_colarg_body(blockIdx.x - nrb, sim, z, lens, Np, rowlse, collse, colarg);
 }
 
 // one 1024-thread workgroup per pair: mutual check + exp(score) > thr, ordered compaction (ascending row)
@@ -348,11 +381,17 @@ __global__ __launch_bounds__(1024) void lg_filter_kernel(const int* __restrict__
 void launch_lg_assign(const float* sim, const float* z, const int* lens, int B, int Np, int cap, float thr, float* rowlse,
                       float* collse, float* scores_out, int* rowarg, float* rowval, int* colarg, int32_t* idx,
                       float* score, int* nmatch, hipStream_t st) {
-  hipLaunchKernelGGL(lg_rowlse_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, sim, lens, Np, rowlse);
-  hipLaunchKernelGGL(lg_collse_kernel, dim3((Np + 63) / 64, B), dim3(64 * LG_CS), 0, st, sim, lens, Np, collse);
-  hipLaunchKernelGGL(lg_rowarg_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, sim, z, lens, Np, rowlse, collse,
-                     scores_out, rowarg, rowval);
-  hipLaunchKernelGGL(lg_colarg_kernel, dim3((Np + 63) / 64, B), dim3(64 * LG_CS), 0, st, sim, z, lens, Np, rowlse, collse, colarg);
+  if (B <= LG_MERGE_MAX_B) {           // the batch-1 .. batch-8 calls of the SLAM loop: two launches instead of four
+    const int nrb = (Np + LG_CS - 1) / LG_CS, ncb = (Np + 63) / 64;     // LG_CS waves per workgroup: a row each / 64 columns per workgroup
+    hipLaunchKernelGGL(lg_lse_kernel, dim3(nrb + ncb, B), dim3(64 * LG_CS), 0, st, sim, lens, Np, nrb, rowlse, collse);
+    hipLaunchKernelGGL(lg_arg_kernel, dim3(nrb + ncb, B), dim3(64 * LG_CS), 0, st, sim, z, lens, Np, nrb, rowlse, collse, scores_out, rowarg, rowval,
+                       colarg);
+  } else {
+    hipLaunchKernelGGL(lg_rowlse_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, sim, lens, Np, rowlse);
+    hipLaunchKernelGGL(lg_collse_kernel, dim3((Np + 63) / 64, B), dim3(64 * LG_CS), 0, st, sim, lens, Np, collse);
+    hipLaunchKernelGGL(lg_rowarg_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, sim, z, lens, Np, rowlse, collse, scores_out, rowarg, rowval);
+    hipLaunchKernelGGL(lg_colarg_kernel, dim3((Np + 63) / 64, B), dim3(64 * LG_CS), 0, st, sim, z, lens, Np, rowlse, collse, colarg);
+  }
   hipLaunchKernelGGL(lg_filter_kernel, dim3(B), dim3(1024), 0, st, lens, Np, cap, thr, rowarg, rowval, colarg, idx, score,
                      nmatch);
 }
@@ -360,10 +399,9 @@ void launch_lg_assign(const float* sim, const float* z, const int* lens, int B, 
 // filter_matches alone on finished score matrices [B][Np][Np] (test hook: hand-built ties, -inf, threshold-exact values)
 void launch_lg_filter_scores(const float* scores, const int* lens, int B, int Np, int cap, float thr, int* rowarg, float* rowval,
                              int* colarg, int32_t* idx, float* score, int* nmatch, hipStream_t st) {
-  hipLaunchKernelGGL(lg_rowarg_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, st, scores, (const float*)nullptr, lens, Np,
-                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, rowarg, rowval);
-  hipLaunchKernelGGL(lg_colarg_kernel, dim3((Np + 63) / 64, B), dim3(64 * LG_CS), 0, st, scores, (const float*)nullptr, lens, Np,
-                     (const float*)nullptr, (const float*)nullptr, colarg);
+  const int nrb = (Np + LG_CS - 1) / LG_CS, ncb = (Np + 63) / 64;
+  hipLaunchKernelGGL(lg_arg_kernel, dim3(nrb + ncb, B), dim3(64 * LG_CS), 0, st, scores, (const float*)nullptr, lens, Np, nrb, (const float*)nullptr,
+                     (const float*)nullptr, (float*)nullptr, rowarg, rowval, colarg);
   hipLaunchKernelGGL(lg_filter_kernel, dim3(B), dim3(1024), 0, st, lens, Np, cap, thr, rowarg, rowval, colarg, idx, score, nmatch);
 }
 
