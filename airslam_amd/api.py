@@ -188,9 +188,11 @@ class Context:
         return feat[:n.value].copy(), lines[:nl.value].copy(), junc[:nj.value].copy()
 
     def stereo_keyframe(self, left: np.ndarray, right: np.ndarray, match: bool = True, want_junctions: bool = True, cap_lines: int = 4096,
-                        cap_junc: int = 2048):
+                        cap_junc: int = 2048, track: bool = False, ref_feat=None):
         """ONE stereo keyframe in one call (airfe_stereo_keyframe ≙ map_builder.cc:85-86): -> dict(featL, featR [n,259], linesL, linesR [L,4] float64,
-        juncL [K,259], idx [m,2] int32, score [m]) — idx / score absent with match=False."""
+        juncL [K,259], idx [m,2] int32, score [m]) — idx / score absent with match=False.  track=True (airfe_stereo_keyframe_tracked): also the temporal
+        match of map_builder.cc:96 against the last keyframe's features (`ref_feat` [n,259]: uploaded when given, else the ones on the device) in the SAME
+        LightGlue forward -> track_idx [t,2] (reference, left), track_score [t]."""
         imgs = []
         for g in (left, right):
             g = np.asarray(g)
@@ -209,13 +211,21 @@ class Context:
         idx, sc = np.empty((cap if match else 0, 2), np.int32), np.empty((cap if match else 0,), np.float32)
         n = (C.c_int * 6)()
         p = lambda i: C.cast(C.byref(n, 4 * i), C.POINTER(C.c_int))
-        self._chk(self._l.airfe_stereo_keyframe(self._h, imgs[0].ctypes.data, imgs[1].ctypes.data, imgs[0].shape[0], imgs[0].shape[1], imgs[0].strides[0],
-                                                fl.ctypes.data, fr.ctypes.data, cap, p(0), p(1), ll.ctypes.data, lr.ctypes.data, cap_lines, p(2), p(3),
-                                                jl.ctypes.data if want_junctions else None, cap_junc, p(4), idx.ctypes.data if match else None,
-                                                sc.ctypes.data, cap, p(5)), "airfe_stereo_keyframe")
+        args = (self._h, imgs[0].ctypes.data, imgs[1].ctypes.data, imgs[0].shape[0], imgs[0].shape[1], imgs[0].strides[0],
+                fl.ctypes.data, fr.ctypes.data, cap, p(0), p(1), ll.ctypes.data, lr.ctypes.data, cap_lines, p(2), p(3),
+                jl.ctypes.data if want_junctions else None, cap_junc, p(4), idx.ctypes.data if match else None, sc.ctypes.data, cap, p(5))
+        if track:
+            ref = None if ref_feat is None else np.ascontiguousarray(ref_feat, dtype=np.float32).reshape(-1, FEAT)
+            tidx, tsc, nt = np.empty((cap, 2), np.int32), np.empty((cap,), np.float32), C.c_int(0)
+            self._chk(self._l.airfe_stereo_keyframe_tracked(*args, None if ref is None else ref.ctypes.data, 0 if ref is None else len(ref), tidx.ctypes.data,
+                                                            tsc.ctypes.data, C.byref(nt)), "airfe_stereo_keyframe_tracked")
+        else:
+            self._chk(self._l.airfe_stereo_keyframe(*args), "airfe_stereo_keyframe")
         out = dict(featL=fl[:n[0]], featR=fr[:n[1]], linesL=ll[:n[2]], linesR=lr[:n[3]], juncL=jl[:n[4]])
         if match:
             out["idx"], out["score"] = idx[:n[5]], sc[:n[5]]
+        if track:
+            out["track_idx"], out["track_score"] = tidx[:nt.value], tsc[:nt.value]
         return out
 
     def track_frame(self, gray: np.ndarray, ref_feat=None):

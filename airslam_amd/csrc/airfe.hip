@@ -804,7 +804,7 @@ static int stereo_plnet_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* 
                             size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, double* d_lines,
                             int capL, int* d_nlines, float* d_juncL, int capJ, int* d_njuncL, int* d_found, int32_t* d_idx,
                             float* d_score, int mcap, int* d_nmatch, hipStream_t st, const std::function<int(hipStream_t)>* after_detect = nullptr,
-                            const std::function<int(hipStream_t)>* after_lines = nullptr) {
+                            const std::function<int(hipStream_t)>* after_lines = nullptr, const LgSecondPair* x2 = nullptr) {
   if (!(c->prec != 2 && 2 * B <= c->Dmax))
     return fail(c, "stereo_plnet_batch: needs the one-pass stereo detector (detector + LightGlue packs loaded, 2 B <= 2 max_batch, fp16 / bf16)");
   // (With stage timers on anything behind the encoder the chains run one after the other: a stage's event pair must not span the other chain.)
@@ -830,7 +830,7 @@ static int stereo_plnet_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* 
   if (!overlap) {
     if (plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, d_juncL ? B : 0, d_found, st)) return 1;
     if (after_lines && (*after_lines)(st)) return 1;
-    return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
+    return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st, x2);
   }
   HIPCHK(c, hipEventRecord(c->ev_fork, st));                  // behind the point branch
   HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -839,10 +839,10 @@ static int stereo_plnet_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* 
   // path queued ahead of it kept the GPU's main queue idle for 80 us per batch-1 keyframe, tools/kf_timeline.py), at large ones the line path's
   // (there the line path is as long as the matcher and a late start would stick out behind it).
   const bool lg_first = B <= 4;
-  if (!rc && lg_first) rc = lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
+  if (!rc && lg_first) rc = lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st, x2);
   if (!rc) rc = plnet_lines_batch(c, 2 * B, h, w, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, d_juncL ? B : 0, d_found, c->stream2);
   if (!rc && after_lines && (*after_lines)(c->stream2)) rc = 1;
-  if (!rc && !lg_first) rc = lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
+  if (!rc && !lg_first) rc = lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st, x2);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));      // (also after an error: the caller's stream never runs ahead of the side stream)
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   return rc;
@@ -863,10 +863,20 @@ int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint
 // queue of device work: both images go up in one copy, the detector runs over them as a batch of two, the line path of both runs on the second
 // stream beside LightGlue, and everything comes back in two copies (the counted rows, then the line / junction rows whose counts are known only then).
 // Per image and per pair the results are the bits the separate entries return (tests/test_gpu_keyframe.py).  match_idx == NULL: detection only.
-int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* right, int h, int w, int stride, float* featL, float* featR, int cap,
-                          int* nL, int* nR, double* linesL, double* linesR, int capL, int* nlinesL, int* nlinesR, float* juncL, int capJ,
-                          int* njuncL, int32_t* match_idx, float* match_score, int mcap, int* nmatch) {
+// (track_idx != NULL: also MatchingPoints(features_last_keyframe, left_features) — map_builder.cc:96 — as the SECOND pair of the same LightGlue forward)
+static int stereo_keyframe_impl(airfe_ctx* c, const uint8_t* left, const uint8_t* right, int h, int w, int stride, float* featL, float* featR, int cap,
+                                int* nL, int* nR, double* linesL, double* linesR, int capL, int* nlinesL, int* nlinesR, float* juncL, int capJ,
+                                int* njuncL, int32_t* match_idx, float* match_score, int mcap, int* nmatch, const float* ref_feat, int n_ref,
+                                int32_t* track_idx, float* track_score, int* ntrack) {
   AIRFE_ENTER(c);
+  const bool track = track_idx != nullptr;
+  if (track) {
+    if (!match_idx || !track_score || !ntrack) return fail(c, "stereo_keyframe_tracked: bad argument");
+    if (c->Pmax < 2) return fail(c, "stereo_keyframe_tracked: needs cfg.max_batch >= 2 (two pairs per LightGlue forward)");
+    if (ref_feat && (n_ref < 0 || n_ref > c->cfg.max_keypoints)) return fail(c, "stereo_keyframe_tracked: reference keypoint count exceeds max_keypoints");
+    if (!ref_feat && c->ref_n < 0) return fail(c, "stereo_keyframe_tracked: no reference features were ever given");
+    *ntrack = 0;
+  }
   if (!left || !right || h < 1 || w < 1) return fail(c, "empty image");
   if (stride < w) return fail(c, "image stride smaller than its width");
   if (!featL || !featR || !nL || !nR || !linesL || !linesR || !nlinesL || !nlinesR || capL < 1)
@@ -883,13 +893,13 @@ int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* righ
   hipStream_t st = c->stream;
   const int Np = c->cfg.max_keypoints, capLd = std::min(capL, LINE_CAP), capJd = std::min(std::max(capJ, 1), JUNC_CAP);
   // device block: [counts 64 B | featL | featR | idx | score] — the part that comes back in the first copy — then [lines 2 x capLd | junctions]
-  const size_t fb = (size_t)Np * AIRFE_FEAT_DIM * 4, head = 64 + 2 * fb + (size_t)Np * 12;
+  const size_t fb = (size_t)Np * AIRFE_FEAT_DIM * 4, head = 64 + 2 * fb + (size_t)Np * 24;      // (idx | score of TWO pairs: stereo, then the temporal one)
   const size_t lb = (size_t)capLd * 32, total = head + 2 * lb + (size_t)capJd * AIRFE_FEAT_DIM * 4;
   if (ensure_block(c, c->kf_blk, c->kf_bytes, total)) return 1;
   int* cnt = reinterpret_cast<int*>(c->kf_blk);                 // {nL, nR, nlines[2], nmatch, njunc, found: lines[2] junc[1]}
   float *d_fL = reinterpret_cast<float*>(c->kf_blk + 64), *d_fR = reinterpret_cast<float*>(c->kf_blk + 64 + fb);
   int32_t* d_idx = reinterpret_cast<int32_t*>(c->kf_blk + 64 + 2 * fb);
-  float* d_sc = reinterpret_cast<float*>(c->kf_blk + 64 + 2 * fb + (size_t)Np * 8);
+  float* d_sc = reinterpret_cast<float*>(c->kf_blk + 64 + 2 * fb + (size_t)Np * 16);               // [2][Np] behind idx [2][Np][2]
   double* d_ln = reinterpret_cast<double*>(c->kf_blk + head);
   float* d_jn = reinterpret_cast<float*>(c->kf_blk + head + 2 * lb);
   // both images through the pinned block in one copy (same row pitch; the right image starts at h * stride)
@@ -899,7 +909,7 @@ int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* righ
   // then, from the side stream behind the line path (also beside the matcher), the FIRST capS line rows of either image and capJS junction rows:
   // the usual keyframe (a few hundred lines and junctions) needs no second round trip for them
   const int capS = std::min(capLd, c->kf_spec_lines), capJS = want_j ? std::min(capJd, c->kf_spec_juncs) : 0;
-  const size_t early = 64 + 2 * fb, late = early + 64, spec = late + (size_t)Np * 12, spec_l = (size_t)capS * 32, spec_j = (size_t)capJS * AIRFE_FEAT_DIM * 4;
+  const size_t early = 64 + 2 * fb, late = early + 64, spec = late + (size_t)Np * 24, spec_l = (size_t)capS * 32, spec_j = (size_t)capJS * AIRFE_FEAT_DIM * 4;
   if (ensure_stage_img(c, 2 * pitch)) return 1;
   // (sized for the line / junction rows of the second round trip too: the block must not move between calls, a captured graph holds its address)
   if (ensure_pin(c, std::max(std::max(pitch + ib, spec + 2 * spec_l + spec_j), 2 * lb + (size_t)capJd * AIRFE_FEAT_DIM * 4))) return 1;
@@ -910,6 +920,24 @@ int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* righ
     HIPCHK(c, hipEventRecord(c->ev_feat, s2));
     return 0;
   };
+  // the temporal pair (last keyframe -> left image) rides in the same LightGlue forward as pair 1; its reference features live in ref_blk (uploaded
+  // when given, kept otherwise: airfe_track_frame shares the block)
+  LgSecondPair x2{};
+  size_t ref_off = 0;
+  if (track) {
+    if (ensure_block(c, c->ref_blk, c->ref_bytes, 64 + fb)) return 1;
+    x2.f0 = reinterpret_cast<const float*>(c->ref_blk + 64); x2.n0 = reinterpret_cast<const int*>(c->ref_blk);
+    x2.f1 = d_fL; x2.n1 = cnt;
+    if (ref_feat) {
+      ref_off = (std::max(pitch + ib, spec + 2 * spec_l + spec_j) + 63) / 64 * 64;
+      if (ensure_pin(c, ref_off + 64 + fb)) return 1;
+      memcpy(c->pin, left, ib);                                   // (the block may have moved)
+      memcpy(c->pin + pitch, right, ib);
+      *reinterpret_cast<int*>(c->pin + ref_off) = n_ref;
+      if (n_ref > 0) memcpy(c->pin + ref_off + 64, ref_feat, (size_t)n_ref * AIRFE_FEAT_DIM * 4);
+      c->ref_n = n_ref;
+    }
+  }
   const std::function<int(hipStream_t)> rows_copy = [&](hipStream_t s2) -> int {
     HIPCHK(c, hipMemcpyAsync(c->pin + spec, d_ln, spec_l, hipMemcpyDeviceToHost, s2));
     HIPCHK(c, hipMemcpyAsync(c->pin + spec + spec_l, d_ln + (size_t)capLd * 4, spec_l, hipMemcpyDeviceToHost, s2));
@@ -919,11 +947,15 @@ int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* righ
   auto queue_all = [&]() -> int {
     HIPCHK(c, hipMemsetAsync(cnt, 0, 64, st));
     HIPCHK(c, hipMemcpyAsync(c->st_img, c->pin, pitch + ib, hipMemcpyHostToDevice, st));
+    if (track && ref_feat) HIPCHK(c, hipMemcpyAsync(c->ref_blk, c->pin + ref_off, 64 + (size_t)n_ref * AIRFE_FEAT_DIM * 4, hipMemcpyHostToDevice, st));
+    // (match counts: cnt[10] = stereo, cnt[11] = temporal — LightGlue writes d_nmatch[pair])
     if (stereo_plnet_dev(c, c->st_img, c->st_img + pitch, 1, h, w, stride, pitch, d_fL, d_fR, Np, cnt, cnt + 1, d_ln, capLd, cnt + 2,
-                         want_j ? d_jn : nullptr, capJd, want_j ? cnt + 5 : nullptr, cnt + 6, match ? d_idx : nullptr, d_sc, Np, cnt + 4, st, &early_copy, &rows_copy))
+                         want_j ? d_jn : nullptr, capJd, want_j ? cnt + 5 : nullptr, cnt + 6, match ? d_idx : nullptr, d_sc, Np, cnt + 10, st, &early_copy, &rows_copy,
+                         track ? &x2 : nullptr))
       return 1;
     HIPCHK(c, hipMemcpyAsync(c->pin + early, cnt, 64, hipMemcpyDeviceToHost, st));
-    if (match) HIPCHK(c, hipMemcpyAsync(c->pin + late, d_idx, (size_t)Np * 12, hipMemcpyDeviceToHost, st));
+    if (match) HIPCHK(c, hipMemcpyAsync(c->pin + late, d_idx, (size_t)Np * (track ? 24 : 16) , hipMemcpyDeviceToHost, st));
+    if (match && !track) HIPCHK(c, hipMemcpyAsync(c->pin + late + (size_t)Np * 16, d_sc, (size_t)Np * 4, hipMemcpyDeviceToHost, st));
     return 0;
   };
   // AIRFE_KF_GRAPH=1: the whole queue (~115 launches on two streams) is captured once per (image shape, outputs, buffers) as a hipGraph and replayed
@@ -933,7 +965,7 @@ int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* righ
   // not by the host's launch calls; the default stays the plain queue.)
   KfGraph& G = c->kf_graph;
   const KfGraph::Key key{h, w, stride, capLd, capJd, want_j, match, c->pin, c->kf_blk, c->st_img};
-  const bool graph_ok = c->kf_graph_on && c->prof_mask == 0 && !c->trace_on;
+  const bool graph_ok = c->kf_graph_on && c->prof_mask == 0 && !c->trace_on && !track;
   if (!(G.key == key)) { G.reset(); G.key = key; }
   bool replay = false;
   if (graph_ok && G.exec) {
@@ -967,14 +999,22 @@ int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* righ
   *nL = n0; *nR = n1;
   if (!replay) HIPCHK(c, hipStreamSynchronize(st));
   const int* hc = reinterpret_cast<const int*>(c->pin + early);
-  const int nl0 = hc[2], nl1 = hc[3], nm = std::min(hc[4], Np), nj = hc[5];
+  const int nl0 = hc[2], nl1 = hc[3], nm = std::min(hc[10], Np), nj = hc[5];
   const int fl0 = hc[6], fl1 = hc[7], fj = hc[8];
   if (match) {
     if (nm > 0) {
       memcpy(match_idx, c->pin + late, (size_t)nm * 8);
-      memcpy(match_score, c->pin + late + (size_t)Np * 8, (size_t)nm * 4);
+      memcpy(match_score, c->pin + late + (size_t)Np * 16, (size_t)nm * 4);
     }
-    *nmatch = nm;
+    *nmatch = (n0 > 0 && n1 > 0) ? nm : 0;                        // point_matcher.cc:53-55
+  }
+  if (track && n0 > 0 && c->ref_n > 0) {
+    const int nt = std::min(hc[11], Np);
+    if (nt > 0) {
+      memcpy(track_idx, c->pin + late + (size_t)Np * 8, (size_t)nt * 8);
+      memcpy(track_score, c->pin + late + (size_t)Np * 20, (size_t)nt * 4);
+    }
+    *ntrack = nt;
   }
   if (want_j && fj > JUNC_CAP) return fail(c, "stereo_keyframe: more junctions than the device arena holds (JUNC_CAP)");
   if (fl0 > capLd || fl1 > capLd || (want_j && fj > capJd)) return fail(c, "stereo_keyframe: lines / junctions do not fit the caller's buffers (capL, capJ)");
@@ -996,6 +1036,21 @@ int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* righ
   *nlinesL = nl0; *nlinesR = nl1;
   if (njuncL) *njuncL = want_j ? nj : 0;
   return 0;
+}
+
+int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* right, int h, int w, int stride, float* featL, float* featR, int cap,
+                          int* nL, int* nR, double* linesL, double* linesR, int capL, int* nlinesL, int* nlinesR, float* juncL, int capJ,
+                          int* njuncL, int32_t* match_idx, float* match_score, int mcap, int* nmatch) {
+  return stereo_keyframe_impl(c, left, right, h, w, stride, featL, featR, cap, nL, nR, linesL, linesR, capL, nlinesL, nlinesR, juncL, capJ, njuncL, match_idx,
+                              match_score, mcap, nmatch, nullptr, 0, nullptr, nullptr, nullptr);
+}
+int airfe_stereo_keyframe_tracked(airfe_ctx* c, const uint8_t* left, const uint8_t* right, int h, int w, int stride, float* featL, float* featR, int cap,
+                                  int* nL, int* nR, double* linesL, double* linesR, int capL, int* nlinesL, int* nlinesR, float* juncL, int capJ,
+                                  int* njuncL, int32_t* match_idx, float* match_score, int mcap, int* nmatch, const float* ref_feat, int n_ref,
+                                  int32_t* track_idx, float* track_score, int* ntrack) {
+  if (c && !track_idx) return fail(c, "stereo_keyframe_tracked: no output for the temporal matches");
+  return stereo_keyframe_impl(c, left, right, h, w, stride, featL, featR, cap, nL, nR, linesL, linesR, capL, nlinesL, nlinesR, juncL, capJ, njuncL, match_idx,
+                              match_score, mcap, nmatch, ref_feat, n_ref, track_idx, track_score, ntrack);
 }
 
 // ONE tracked frame through host buffers (batch 1): what map_builder.cc:94-101 does for every frame that is not a keyframe —

@@ -332,8 +332,9 @@ int trace_finish(airfe_ctx* c, hipStream_t st);
 void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1, const uint16_t* x2, int ld2, int M, int epi, int act, void* out,
                 int ldo, hipStream_t st, bool trans = false, void* out2 = nullptr, float* x32 = nullptr, const float* rc = nullptr, const float* rs = nullptr);
 void reset_slack_rows(airfe_ctx* c, int M, hipStream_t st);
+struct LgSecondPair { const float *f0, *f1; const int *n0, *n1; };      // a second pair for a B = 1 call (same ld / kp_off / normalize): outputs of pair 1 follow pair 0's
 int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1, const int* n1, int B, int cap, int ld, int kp_off, int normalize,
-                  int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, float* scores_out, hipStream_t st);
+                  int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, float* scores_out, hipStream_t st, const LgSecondPair* x2 = nullptr);
 int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1, const int* n1, int B, int cap, int normalize, hipStream_t st);
 
 }  // namespace airfe_host

@@ -167,20 +167,25 @@ void reset_slack_rows(airfe_ctx* c, int M, hipStream_t st) {
 // LightGlue forward on B pairs whose feature rows live on the device
 int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1, const int* n1, int B, int cap, int ld,
                   int kp_off, int normalize, int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, float* scores_out,
-                  hipStream_t st) {
+                  hipStream_t st, const LgSecondPair* x2) {
   if (!c->has_lg) return fail(c, "LightGlue weights were not loaded (cfg.lightglue_pack)");
   if (B < 1 || B > c->Pmax) return fail(c, "pair batch exceeds cfg.max_batch / 2");
   if (cap > c->Np) return fail(c, "feature capacity exceeds the matcher arena (max_keypoints)");
   if (c->mprec == 2) return lightglue_dev_f32(c, f0, n0, f1, n1, B, cap, ld, kp_off, normalize, d_idx, d_score, mcap, d_nmatch, scores_out, st);
+  LgPrepArgs pa;
+  if (x2) {                                      // the stereo and the temporal pair of one keyframe as a batch of two
+    if (B != 1 || c->Pmax < 2 || c->mprec == 2) return fail(c, "lightglue: a second pair needs B = 1, max_batch >= 2 and fp16 / bf16");
+    pa.f0x = x2->f0; pa.f1x = x2->f1; pa.n0x = x2->n0; pa.n1x = x2->n1;
+    B = 2;
+  }
   const int S = 2 * B, Np = c->Np, M = S * Np;
   const int Mg = (M + 127) / 128 * 128;          // rows the matrix kernels run over (surplus rows: arena slack, see alloc_matcher_arena)
-  LgPrepArgs pa;
   pa.f0 = f0; pa.f1 = f1; pa.n0 = n0; pa.n1 = n1; pa.ld = ld; pa.kp_off = kp_off; pa.normalize = normalize;
   // PointMatcher::NormalizeKeypoints (src/point_matcher.cc:39-48): integer width/2, L_inv = 1.0/max(w,h)*scale
   pa.cx = (float)(c->cfg.image_width / 2);
   pa.cy = (float)(c->cfg.image_height / 2);
   pa.linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.5f);
-  pa.wr = c->lg_wr; pa.B = B; pa.cap = cap; pa.Np = Np;
+  pa.wr = c->lg_wr; pa.B = x2 ? 1 : B; pa.cap = cap; pa.Np = Np;
   pa.x32 = c->x32; pa.xb = c->xb; pa.rot_cos = c->rot_cos; pa.rot_sin = c->rot_sin; pa.lens = c->lens;
   // the arena's slack rows go back to zero with the same launch (see reset_slack_rows; ADVICE r03: this line had moved to the fp32
   // path only, so that the 2-byte path's slack rows kept their running residual from call to call)

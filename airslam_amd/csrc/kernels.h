@@ -144,6 +144,8 @@ struct LgPrepArgs {
   float* x32; uint16_t* xb;           // [2B][Np][256]
   float* rot_cos; float* rot_sin;     // [2B][Np][32]
   int* lens;                          // [2B]
+  // a SECOND pair whose features live elsewhere (B must be 1; it becomes pair 1 of a batch of two: the stereo and the temporal match of one keyframe)
+  const float *f0x = nullptr, *f1x = nullptr; const int *n0x = nullptr, *n1x = nullptr;
   int slack_rows = 0;                 // token rows behind the last sequence that are reset to zero as well (the arena's slack, airfe_load.hip: alloc_matcher_arena)
 };
 void launch_lg_prepare(int prec, const LgPrepArgs& a, hipStream_t st);

@@ -15,10 +15,11 @@ template <class P>
 __global__ __launch_bounds__(256) void lg_prepare_kernel(LgPrepArgs a) {
   const int s = blockIdx.y, n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= a.Np) return;
-  if (s >= 2 * a.B) {                                    // the arena's slack rows behind the last sequence: back to zero (see reset_slack_rows)
-    const int r = (s - 2 * a.B) * a.Np + n;
+  const int Bt = a.f0x ? 2 : a.B;                        // pairs of this call
+  if (s >= 2 * Bt) {                                     // the arena's slack rows behind the last sequence: back to zero (see reset_slack_rows)
+    const int r = (s - 2 * Bt) * a.Np + n;
     if (r < a.slack_rows) {
-      const size_t row = (size_t)2 * a.B * a.Np + r;
+      const size_t row = (size_t)2 * Bt * a.Np + r;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         a.x32[row * 256 + lane + 64 * j] = 0.f;
@@ -28,13 +29,14 @@ __global__ __launch_bounds__(256) void lg_prepare_kernel(LgPrepArgs a) {
     return;
   }
   const int b = s >> 1, side = s & 1;
-  const int len = side ? a.n1[b] : a.n0[b];
+  const bool second = a.f0x && b == 1;
+  const int len = second ? (side ? *a.n1x : *a.n0x) : (side ? a.n1[b] : a.n0[b]);
   if (n == 0 && lane == 0) a.lens[s] = len;
   const size_t row = (size_t)s * a.Np + n;
   float* x32 = a.x32 + row * 256;
   uint16_t* xb = a.xb + row * 256;
   if (n < len) {
-    const float* f = (side ? a.f1 : a.f0) + ((size_t)b * a.cap + n) * a.ld;
+    const float* f = second ? (side ? a.f1x : a.f0x) + (size_t)n * a.ld : (side ? a.f1 : a.f0) + ((size_t)b * a.cap + n) * a.ld;
     float kx = f[a.kp_off], ky = f[a.kp_off + 1];
     if (a.normalize) {
       kx = __fmul_rn(__fsub_rn(kx, a.cx), a.linv);
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void lg_prepare_kernel(LgPrepArgs a) {
 }
 
 void launch_lg_prepare(int prec, const LgPrepArgs& a, hipStream_t st) {
-  dim3 grid((a.Np + 3) / 4, 2 * a.B + (a.slack_rows + a.Np - 1) / a.Np);
+  dim3 grid((a.Np + 3) / 4, 2 * (a.f0x ? 2 : a.B) + (a.slack_rows + a.Np - 1) / a.Np);
   if (prec == 1) hipLaunchKernelGGL(lg_prepare_kernel<PF16>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(lg_prepare_kernel<PBF16>, grid, dim3(256), 0, st, a);
 }

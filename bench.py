@@ -102,7 +102,7 @@ def latency_b1(args, rank, world, local, dev):
                       **(dict(superglue=mw) if sg else dict(lightglue=mw)))
     det, pm = api.FeatureDetector(ctx), api.PointMatcher(ctx, W, H, 1 if sg else 0)
     pairs = [synth.stereo_pair(H, W, 1000 + i) for i in range(8)]
-    t_l, t_r, t_m, t_k, t_d2, t_m2, t_t1, t_t2, nmatch, nlines = [], [], [], [], [], [], [], [], [], []
+    t_l, t_r, t_m, t_k, t_d2, t_m2, t_t1, t_t2, t_kt1, t_kt2, nmatch, nlines = [], [], [], [], [], [], [], [], [], [], [], []
     fused = plnet and not sg                                       # airfe_stereo_keyframe: the PLNet + LightGlue keyframe (map_builder.cc:85-86)
     for i in range(args.warmup + args.steps):
         left, right = pairs[i % len(pairs)]
@@ -137,10 +137,18 @@ def latency_b1(args, rank, world, local, dev):
             _, tidx, _ = ctx.track_frame(right, ref_feat=kf_ref.T if i % 8 == 0 else None)           # its features go up once, then stay on the device
             t9 = time.perf_counter()
             assert len(tidx) == nt
+            # a keyframe candidate also runs the temporal match (map_builder.cc:96): one call with both pairs in ONE LightGlue forward, against
+            # the one-call keyframe + a MatchingPoints call
+            kt = ctx.stereo_keyframe(left, right, track=True)                               # (reference = the features uploaded above)
+            t10 = time.perf_counter()
+            k2 = ctx.stereo_keyframe(left, right)
+            nt2, _ = pm.MatchingPoints(kf_ref, np.asfortranarray(k2["featL"].T))
+            t11 = time.perf_counter()
+            assert len(kt["track_idx"]) == nt2 and len(kt["idx"]) == len(k2["idx"])
         if i >= args.warmup:
             t_l.append(t1 - t0); t_r.append(t2 - t1); t_m.append(t3 - t2); nmatch.append(n); nlines.append(len(acc))
             if fused:
-                t_k.append(t4 - t3); t_d2.append(t5 - t4); t_m2.append(t6 - t5); t_t2.append(t8 - t7); t_t1.append(t9 - t8)
+                t_k.append(t4 - t3); t_d2.append(t5 - t4); t_m2.append(t6 - t5); t_t2.append(t8 - t7); t_t1.append(t9 - t8); t_kt1.append(t10 - t9); t_kt2.append(t11 - t10)
     pair = np.array(t_l) + np.array(t_r) + np.array(t_m)
 
     def pct(a):
@@ -151,6 +159,8 @@ def latency_b1(args, rank, world, local, dev):
     if fused:
         lat["two_calls"] = {"pair": pct(np.array(t_d2) + np.array(t_m2)), "detect_stereo": pct(t_d2), "match": pct(t_m2)}
         lat["tracked_frame"] = {"one_call": pct(t_t1), "two_calls": pct(t_t2)}        # airfe_track_frame vs Detect + MatchingPoints (points only)
+        # a keyframe WITH its temporal match (map_builder.cc:85-86 + :96): airfe_stereo_keyframe_tracked vs airfe_stereo_keyframe + MatchingPoints
+        lat["keyframe_with_temporal_match"] = {"one_call": pct(t_kt1), "keyframe_call_plus_match_call": pct(t_kt2)}
     head = lat["pair"]["p50"]
     out = {"metric": "batch-1 stereo keyframe latency, host images in / host matrices out, PCIe and synchronisation included ("
                      + ("PLNet points + lines, junctions on the left" if plnet else "SuperPoint") + " x2 + " + ("SuperGlue" if sg else "LightGlue") + "): "

@@ -106,6 +106,15 @@ int airfe_detect_plnet(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int st
 int airfe_stereo_keyframe(airfe_ctx* ctx, const uint8_t* left, const uint8_t* right, int h, int w, int stride, float* featL, float* featR, int cap,
                           int* nL, int* nR, double* linesL, double* linesR, int capL, int* nlinesL, int* nlinesR, float* juncL, int capJ,
                           int* njuncL, int32_t* match_idx, float* match_score, int mcap, int* nmatch);
+/* airfe_stereo_keyframe + the temporal match of the same frame: src/map_builder.cc:85-86 AND :96 — MatchingPoints(features_last_keyframe, left_features,
+ * matches, true) — which every keyframe candidate runs as well.  The two LightGlue calls are independent, so they ride in ONE forward as a batch of two pairs
+ * (at this size a forward costs the same for one pair as for two).  ref_feat [n_ref][259] = the last keyframe's features (NULL: the ones already on the device,
+ * shared with airfe_track_frame); track_idx [mcap][2] = (reference index, left index), track_score, *ntrack.  Everything else as airfe_stereo_keyframe; per
+ * pair the bits of two separate airfe_match_lightglue calls.  Needs cfg.max_batch >= 2. */
+int airfe_stereo_keyframe_tracked(airfe_ctx* ctx, const uint8_t* left, const uint8_t* right, int h, int w, int stride, float* featL, float* featR, int cap,
+                                  int* nL, int* nR, double* linesL, double* linesR, int capL, int* nlinesL, int* nlinesR, float* juncL, int capJ,
+                                  int* njuncL, int32_t* match_idx, float* match_score, int mcap, int* nmatch, const float* ref_feat, int n_ref,
+                                  int32_t* track_idx, float* track_score, int* ntrack);
 /* ONE tracked (non-keyframe) frame through host buffers — src/map_builder.cc:94-101: Detect(image_left_rect, left_features) followed by
  * MatchingPoints(features_last_keyframe, left_features, matches, true) (the F-matrix RANSAC behind the matcher, point_matcher.cc:95-104, stays the
  * reference's).  ref_feat [n_ref][259] = the last keyframe's features: uploaded when given, KEPT on the device when NULL (pass them once per keyframe);

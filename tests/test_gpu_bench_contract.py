@@ -92,3 +92,4 @@ def test_b1_latency_line():
     # the one-call keyframe is the headline; the reference's two- and three-call forms of the same keyframe are beside it
     assert lat["three_calls"]["pair"]["p50"] > lat["two_calls"]["pair"]["p50"] > lat["pair"]["p50"] > 0
     assert lat["tracked_frame"]["two_calls"]["p50"] > lat["tracked_frame"]["one_call"]["p50"] > 0
+    assert lat["keyframe_with_temporal_match"]["keyframe_call_plus_match_call"]["p50"] > lat["keyframe_with_temporal_match"]["one_call"]["p50"] > 0

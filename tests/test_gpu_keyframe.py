@@ -195,3 +195,32 @@ def test_rows_beyond_the_speculative_copy_take_the_second_round_trip(monkeypatch
         for key in want:
             np.testing.assert_array_equal(got[key], want[key])
     ctx.close()
+
+
+def test_keyframe_with_the_temporal_match_in_the_same_forward():
+    """airfe_stereo_keyframe_tracked: map_builder.cc:85-86 and :96 — the stereo pair (left, right) and the temporal pair (last keyframe, left) are two
+    independent MatchingPoints calls; here they are pairs 0 and 1 of ONE LightGlue forward.  Per pair: the bits of the separate calls."""
+    W, H = 752, 480
+    ctx = _ctx(W, H)
+    det, pm = api.FeatureDetector(ctx), api.PointMatcher(ctx, W, H, 0)
+    key_l, _ = synth.stereo_pair(H, W, 1000)
+    ok, fk = det.Detect(key_l)                                                       # "the last keyframe"
+    for i, seed in enumerate((1000, 1002, 1000)):
+        left, right = synth.stereo_pair(H, W, seed)
+        want = ctx.stereo_keyframe(left, right)
+        nt, tmatches = pm.MatchingPoints(fk, np.asfortranarray(want["featL"].T))
+        got = ctx.stereo_keyframe(left, right, track=True, ref_feat=fk.T if i == 0 else None)
+        for key in want:
+            np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+        np.testing.assert_array_equal(got["track_idx"], np.array([(m[0], m[1]) for m in tmatches], np.int32).reshape(-1, 2))
+        np.testing.assert_array_equal((np.float32(1.0) - got["track_score"]).astype(np.float32), np.array([m[2] for m in tmatches], np.float32))
+        assert i == 1 or nt > 50
+    # the reference stays on the device for airfe_track_frame too
+    feat, idx, sc = ctx.track_frame(key_l)
+    assert len(idx) >= 100 and (idx[:, 0] == idx[:, 1]).all()
+    ctx.close()
+    small = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(GOLDEN, "plnet_s1.airfe"), lightglue=weights.synthetic_lightglue(1234),
+                        max_batch=1, max_keypoints=400, image_width=W, image_height=H, precision=1, matcher_precision=1)
+    with pytest.raises(api.AirfeError, match="max_batch >= 2"):
+        small.stereo_keyframe(key_l, key_l, track=True, ref_feat=fk.T)
+    small.close()
