@@ -131,6 +131,21 @@ int main(int argc, char** argv) {
     dump(od + "/k_query.bin", kq.data(), kq.size());
     dump(od + "/k_train.bin", kt.data(), kt.size());
     dump(od + "/k_dist.bin", kd.data(), kd.size());
+    // ... and with the temporal match of map_builder.cc:96 in the same forward: here "the last keyframe" is the left image itself
+    {
+      Features a2, b2, j2;
+      std::vector<Eigen::Vector4d> la2, lb2;
+      std::vector<cv::DMatch> km2, tm, tm_ref;
+      if (!kf.Process(left, right, a2, b2, la2, lb2, j2, km2, &fl, &tm)) return 17;
+      if (km2.size() != km.size()) return 18;
+      pm.MatchingPoints(fl, a2, tm_ref, false);
+      std::vector<int> tq, tt, rq, rt;
+      std::vector<float> td, rd;
+      for (const auto& m : tm) { tq.push_back(m.queryIdx); tt.push_back(m.trainIdx); td.push_back(m.distance); }
+      for (const auto& m : tm_ref) { rq.push_back(m.queryIdx); rt.push_back(m.trainIdx); rd.push_back(m.distance); }
+      dump(od + "/t_query.bin", tq.data(), tq.size()); dump(od + "/t_train.bin", tt.data(), tt.size()); dump(od + "/t_dist.bin", td.data(), td.size());
+      dump(od + "/tr_query.bin", rq.data(), rq.size()); dump(od + "/tr_train.bin", rt.data(), rt.size()); dump(od + "/tr_dist.bin", rd.data(), rd.size());
+    }
     cv::Mat none2;
     if (kf.Process(none2, right, a, b, la, lb, j, km)) return 16;
   }

@@ -33,7 +33,7 @@ class AirfeStereoKeyframe {
     }
     airfe_cfg cfg;
     airfe_default_cfg(&cfg);
-    cfg.max_batch = 2;
+    cfg.max_batch = 2;                                          // two images per detector pass, two pairs per LightGlue forward
     cfg.enc_chunk = 2;
     cfg.max_keypoints = plnet_.max_keypoints;
     cfg.keypoint_threshold = plnet_.keypoint_threshold;
@@ -65,20 +65,36 @@ class AirfeStereoKeyframe {
     return true;
   }
 
-  // lines are APPENDED (plnet.cpp:544), features / junctions / matches replaced — like the two facade calls
+  // lines are APPENDED (plnet.cpp:544), features / junctions / matches replaced — like the two facade calls.
+  // last_keyframe_features + temporal_matches (both or neither): ALSO map_builder.cc:96, MatchingPoints(features_last_keyframe, left_features, matches, ..)
+  // up to its RANSAC, as the second pair of the same LightGlue forward; last_keyframe_features == nullptr with temporal_matches != nullptr re-uses the
+  // features given last time (they stay on the device).
   bool Process(const cv::Mat& image_left, const cv::Mat& image_right, Eigen::Matrix<float, 259, Eigen::Dynamic>& left_features,
                Eigen::Matrix<float, 259, Eigen::Dynamic>& right_features, std::vector<Eigen::Vector4d>& left_lines,
-               std::vector<Eigen::Vector4d>& right_lines, Eigen::Matrix<float, 259, Eigen::Dynamic>& junctions, std::vector<cv::DMatch>& matches) {
+               std::vector<Eigen::Vector4d>& right_lines, Eigen::Matrix<float, 259, Eigen::Dynamic>& junctions, std::vector<cv::DMatch>& matches,
+               const Eigen::Matrix<float, 259, Eigen::Dynamic>* last_keyframe_features = nullptr, std::vector<cv::DMatch>* temporal_matches = nullptr) {
     matches.clear();
+    if (temporal_matches) temporal_matches->clear();
     if (!ctx_ || image_left.empty() || image_right.empty() || image_left.rows != image_right.rows || image_left.cols != image_right.cols ||
         image_left.step != image_right.step) {
       std::cout << "Failed when extracting point features !" << std::endl;       // feature_detector.cc:104-106
       return false;
     }
-    int nl = 0, nr = 0, nll = 0, nlr = 0, nj = 0, nm = 0;
-    if (airfe_stereo_keyframe(ctx_, image_left.data, image_right.data, image_left.rows, image_left.cols, (int)image_left.step, fl_.data(), fr_.data(), cap_,
-                              &nl, &nr, ll_.data(), lr_.data(), (int)(ll_.size() / 4), &nll, &nlr, junc_.data(), (int)(junc_.size() / AIRFE_FEAT_DIM), &nj,
-                              idx_.data(), score_.data(), cap_, &nm) != 0) {
+    int nl = 0, nr = 0, nll = 0, nlr = 0, nj = 0, nm = 0, nt = 0;
+    int rc;
+    if (temporal_matches) {
+      tidx_.resize((size_t)cap_ * 2); tscore_.resize((size_t)cap_);
+      rc = airfe_stereo_keyframe_tracked(ctx_, image_left.data, image_right.data, image_left.rows, image_left.cols, (int)image_left.step, fl_.data(), fr_.data(),
+                                         cap_, &nl, &nr, ll_.data(), lr_.data(), (int)(ll_.size() / 4), &nll, &nlr, junc_.data(),
+                                         (int)(junc_.size() / AIRFE_FEAT_DIM), &nj, idx_.data(), score_.data(), cap_, &nm,
+                                         last_keyframe_features ? last_keyframe_features->data() : nullptr,
+                                         last_keyframe_features ? (int)last_keyframe_features->cols() : 0, tidx_.data(), tscore_.data(), &nt);
+    } else {
+      rc = airfe_stereo_keyframe(ctx_, image_left.data, image_right.data, image_left.rows, image_left.cols, (int)image_left.step, fl_.data(), fr_.data(), cap_,
+                                 &nl, &nr, ll_.data(), lr_.data(), (int)(ll_.size() / 4), &nll, &nlr, junc_.data(), (int)(junc_.size() / AIRFE_FEAT_DIM), &nj,
+                                 idx_.data(), score_.data(), cap_, &nm);
+    }
+    if (rc != 0) {
       std::cout << "Failed when extracting point features ! (" << airfe_last_error(ctx_) << ")" << std::endl;
       return false;
     }
@@ -90,6 +106,8 @@ class AirfeStereoKeyframe {
     if (nj) std::memcpy(junctions.data(), junc_.data(), (size_t)nj * AIRFE_FEAT_DIM * sizeof(float));
     for (int i = 0; i < nll; ++i) left_lines.emplace_back(ll_[4 * i], ll_[4 * i + 1], ll_[4 * i + 2], ll_[4 * i + 3]);
     for (int i = 0; i < nlr; ++i) right_lines.emplace_back(lr_[4 * i], lr_[4 * i + 1], lr_[4 * i + 2], lr_[4 * i + 3]);
+    if (temporal_matches)
+      for (int i = 0; i < nt; ++i) temporal_matches->emplace_back(tidx_[2 * i], tidx_[2 * i + 1], 1.0 - tscore_[i]);
     if (nl < 1 || nr < 1) return true;                                                                   // point_matcher.cc:53-55: no matches
     for (int i = 0; i < nm; ++i) matches.emplace_back(idx_[2 * i], idx_[2 * i + 1], 1.0 - score_[i]);   // point_matcher.cc:70
     return true;
@@ -100,8 +118,8 @@ class AirfeStereoKeyframe {
   PointMatcherConfig matcher_;
   airfe_ctx* ctx_ = nullptr;
   int cap_ = 0;
-  std::vector<float> fl_, fr_, junc_, score_;
+  std::vector<float> fl_, fr_, junc_, score_, tscore_;
   std::vector<double> ll_, lr_;
-  std::vector<int32_t> idx_;
+  std::vector<int32_t> idx_, tidx_;
 };
 #endif

@@ -149,3 +149,8 @@ def test_reference_facade_on_the_gpu_equals_the_c_abi(models, tmp_path, use_sp, 
         eq(rd("k_query.bin", np.int32), rd("m_query.bin", np.int32))
         eq(rd("k_train.bin", np.int32), rd("m_train.bin", np.int32))
         eq(rd("k_dist.bin", np.float32), rd("m_dist.bin", np.float32))
+        # the temporal match riding in the keyframe's forward == the facade's own MatchingPoints(last keyframe, left) on the same features
+        assert len(rd("t_query.bin", np.int32)) >= 50
+        eq(rd("t_query.bin", np.int32), rd("tr_query.bin", np.int32))
+        eq(rd("t_train.bin", np.int32), rd("tr_train.bin", np.int32))
+        eq(rd("t_dist.bin", np.float32), rd("tr_dist.bin", np.float32))
