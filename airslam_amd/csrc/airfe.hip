@@ -896,7 +896,7 @@ static int stereo_keyframe_impl(airfe_ctx* c, const uint8_t* left, const uint8_t
   const size_t fb = (size_t)Np * AIRFE_FEAT_DIM * 4, head = 64 + 2 * fb + (size_t)Np * 24;      // (idx | score of TWO pairs: stereo, then the temporal one)
   const size_t lb = (size_t)capLd * 32, total = head + 2 * lb + (size_t)capJd * AIRFE_FEAT_DIM * 4;
   if (ensure_block(c, c->kf_blk, c->kf_bytes, total)) return 1;
-  int* cnt = reinterpret_cast<int*>(c->kf_blk);                 // {nL, nR, nlines[2], nmatch, njunc, found: lines[2] junc[1]}
+  int* cnt = reinterpret_cast<int*>(c->kf_blk);                 // {nL, nR, nlines[2], -, njunc, found: lines[2] junc[1], -, nmatch: stereo, temporal}
   float *d_fL = reinterpret_cast<float*>(c->kf_blk + 64), *d_fR = reinterpret_cast<float*>(c->kf_blk + 64 + fb);
   int32_t* d_idx = reinterpret_cast<int32_t*>(c->kf_blk + 64 + 2 * fb);
   float* d_sc = reinterpret_cast<float*>(c->kf_blk + 64 + 2 * fb + (size_t)Np * 16);               // [2][Np] behind idx [2][Np][2]
@@ -961,8 +961,8 @@ static int stereo_keyframe_impl(airfe_ctx* c, const uint8_t* left, const uint8_t
   // AIRFE_KF_GRAPH=1: the whole queue (~115 launches on two streams) is captured once per (image shape, outputs, buffers) as a hipGraph and replayed
   // with one launch — the same kernels with the same arguments, so the same bits.  The first call of a configuration runs plainly (it grows blocks and
   // sets function attributes, which a capture cannot hold), the second captures, later ones replay.  Off while stage timers or the trace are on.
-  // (Measured: 1.18 against 1.21 ms per keyframe, profiles/r04_keyframe_graph_ab.txt — the queue is bound by the GPU's ~4.7 us per dependent launch,
-  // not by the host's launch calls; the default stays the plain queue.)
+  // (Measured: <= 1 % per keyframe, profiles/r04_keyframe_graph_ab.txt — the queue is bound by the GPU's ~4.7 us per dependent launch, not by the
+  // host's launch calls; the default stays the plain queue.)
   KfGraph& G = c->kf_graph;
   const KfGraph::Key key{h, w, stride, capLd, capJd, want_j, match, c->pin, c->kf_blk, c->st_img};
   const bool graph_ok = c->kf_graph_on && c->prof_mask == 0 && !c->trace_on && !track;
