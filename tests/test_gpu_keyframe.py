@@ -219,6 +219,14 @@ def test_keyframe_with_the_temporal_match_in_the_same_forward():
     feat, idx, sc = ctx.track_frame(key_l)
     assert len(idx) >= 100 and (idx[:, 0] == idx[:, 1]).all()
     ctx.close()
+    fresh = _ctx(W, H)
+    with pytest.raises(api.AirfeError, match="no reference features"):
+        fresh.stereo_keyframe(key_l, key_l, track=True)                              # nothing was ever uploaded
+    with pytest.raises(api.AirfeError, match="exceeds max_keypoints"):
+        fresh.stereo_keyframe(key_l, key_l, track=True, ref_feat=np.zeros((401, 259), np.float32))
+    got = fresh.stereo_keyframe(key_l, key_l, track=True, ref_feat=np.zeros((0, 259), np.float32))      # an empty keyframe: no temporal matches
+    assert len(got["track_idx"]) == 0 and len(got["idx"]) >= 100
+    fresh.close()
     small = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(GOLDEN, "plnet_s1.airfe"), lightglue=weights.synthetic_lightglue(1234),
                         max_batch=1, max_keypoints=400, image_width=W, image_height=H, precision=1, matcher_precision=1)
     with pytest.raises(api.AirfeError, match="max_batch >= 2"):
