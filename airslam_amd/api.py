@@ -193,6 +193,10 @@ class Context:
         juncL [K,259], idx [m,2] int32, score [m]) — idx / score absent with match=False.  track=True (airfe_stereo_keyframe_tracked): also the temporal
         match of map_builder.cc:96 against the last keyframe's features (`ref_feat` [n,259]: uploaded when given, else the ones on the device) in the SAME
         LightGlue forward -> track_idx [t,2] (reference, left), track_score [t]."""
+        if ref_feat is not None and not track:
+            raise AirfeError("stereo_keyframe: ref_feat is the temporal match's reference: pass track=True")
+        if track and not match:
+            raise AirfeError("stereo_keyframe: track=True needs match=True (the temporal pair rides in the stereo match's forward)")
         imgs = []
         for g in (left, right):
             g = np.asarray(g)
