@@ -9,6 +9,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libairfe.so")
 
 
+class Tuning(C.Structure):
+    """airfe_tuning (include/airfe.h): kernel-selection overrides, -1 = the library's choice"""
+    _fields_ = [(n, C.c_int) for n in (
+        "fuse_lg_block", "gemm_small_max_m", "gemm8_min_m", "gemmr_min_m", "gemmr_wgs", "qkv_pair", "block_min_m", "lgb_tokens", "sg_kenc_gemm",
+        "fold_qkv", "overlap_lines", "kf_graph", "kf_spec_rows", "fuse_dec", "assign_fused")] + [("reserved", C.c_int * 8)]
+
+
 class Cfg(C.Structure):
     _fields_ = [
         ("device", C.c_int), ("precision", C.c_int), ("max_batch", C.c_int), ("enc_chunk", C.c_int),
@@ -16,7 +23,8 @@ class Cfg(C.Structure):
         ("nms_radius", C.c_int), ("line_threshold", C.c_float), ("line_length_threshold", C.c_float),
         ("matcher", C.c_int), ("image_width", C.c_int), ("image_height", C.c_int), ("sinkhorn_iters", C.c_int),
         ("superpoint_pack", C.c_char_p), ("plnet_s1_pack", C.c_char_p), ("lightglue_pack", C.c_char_p),
-        ("superglue_pack", C.c_char_p), ("matcher_precision", C.c_int),
+        ("superglue_pack", C.c_char_p), ("matcher_precision", C.c_int), ("line_precision", C.c_int), ("check_launches", C.c_int),
+        ("tuning", C.POINTER(Tuning)),
     ]
 
 
@@ -29,6 +37,8 @@ class Stage0(C.Structure):
 # name -> (restype, argtypes); every symbol include/airfe.h declares
 SIGNATURES = {
     "airfe_default_cfg": (None, [C.POINTER(Cfg)]),
+    "airfe_default_tuning": (None, [C.POINTER(Tuning)]),
+    "airfe_debug_fail_next_launch": (C.c_int, [C.c_void_p, C.c_int]),
     "airfe_create": (C.c_int, [C.POINTER(Cfg), C.POINTER(C.c_void_p)]),
     "airfe_destroy": (None, [C.c_void_p]),
     "airfe_last_error": (C.c_char_p, [C.c_void_p]),

@@ -40,10 +40,20 @@ class AirfeError(RuntimeError):
 class Context:
     """One airfe_ctx: one device, one stream, one calling thread."""
 
-    def __init__(self, superpoint=None, lightglue=None, superglue=None, plnet_s1=None, **cfg):
+    def __init__(self, superpoint=None, lightglue=None, superglue=None, plnet_s1=None, tuning=None, **cfg):
+        """cfg: airfe_cfg fields; tuning: dict of airfe_tuning fields (kernel-selection overrides for A/B runs and tests; the library reads no environment)."""
         self._l = _lib.lib()
         c = _lib.Cfg()
         self._l.airfe_default_cfg(C.byref(c))
+        t = None
+        if tuning:
+            t = _lib.Tuning()
+            self._l.airfe_default_tuning(C.byref(t))
+            for k, v in tuning.items():
+                if k == "reserved" or not hasattr(t, k):
+                    raise TypeError(f"unknown airfe_tuning field {k!r}")
+                setattr(t, k, int(v))
+            c.tuning = C.pointer(t)
         for k, v in cfg.items():
             if not hasattr(c, k):
                 raise TypeError(f"unknown airfe_cfg field {k!r}")
@@ -62,6 +72,7 @@ class Context:
             for t in tmp:
                 os.unlink(t)
         self._h = h
+        c.tuning = None                # (read by airfe_create only)
         self.cfg = c
         self.max_keypoints = c.max_keypoints
         self.np_rows = (c.max_keypoints + 15) // 16 * 16
@@ -495,6 +506,11 @@ class Context:
 
     def sync(self):
         self._chk(self._l.airfe_sync(self._h), "airfe_sync")
+
+    def debug_fail_next_launch(self, stage):
+        """stage: a profiling stage name (profile_read's keys) or None to disarm — see include/airfe_debug.h"""
+        names = [self._l.airfe_profile_stage_name(i).decode() for i in range(self._l.airfe_profile_stages())]
+        self._chk(self._l.airfe_debug_fail_next_launch(self._h, -1 if stage is None else names.index(stage)), "airfe_debug_fail_next_launch")
 
     # ---- fault hunting: checksums of the matcher's state behind every launch (airfe_debug_trace*)
     def trace(self, on=True):

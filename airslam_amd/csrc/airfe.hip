@@ -11,7 +11,43 @@ int fail(airfe_ctx* c, const std::string& m) {
   return 1;
 }
 
+// the catch blocks of the C boundary end here: nothing in it may throw again
+int fail_noexcept(airfe_ctx* c, const char* what, const char* detail) noexcept {
+  try {
+    std::string m = std::string("airfe: C++ exception at the C boundary (") + what + "): " + (detail ? detail : "unknown");
+    if (c) c->err = m;
+    g_err = m;
+  } catch (...) {
+  }
+  return 1;
+}
+
+int launch_status(airfe_ctx* c) {
+  if (c->launch_err.empty()) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    return fail(c, std::string("kernel launch failed: ") + hipGetErrorString(e));
+  }
+  std::string m;
+  m.swap(c->launch_err);
+  return fail(c, m);
+}
+
 }  // namespace airfe_host
+
+void note_launch(airfe_ctx* c, int stage) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess || !c->launch_err.empty()) return;
+  try { c->launch_err = std::string(kStageNames[stage]) + ": kernel launch failed: " + hipGetErrorString(e); } catch (...) {}
+}
+namespace { __global__ void never_launched_kernel() {} }
+void fail_launch_now(hipStream_t st) { hipLaunchKernelGGL(never_launched_kernel, dim3(1), dim3(4096), 0, st); }      // 4096 threads per workgroup: hipErrorInvalidConfiguration
+
+// Every extern "C" entry is a function-try-block ending in AIRFE_CATCH: std::bad_alloc from a std::vector / std::string of the host-side
+// bookkeeping (or anything else thrown below) becomes a non-zero return + airfe_last_error(), never an exception crossing the C ABI.
+#define AIRFE_CATCH(c)                                                                                                   \
+  catch (const std::exception& e_) { return airfe_host::fail_noexcept((c), __func__, e_.what()); }                       \
+  catch (...) { return airfe_host::fail_noexcept((c), __func__, nullptr); }
 
 void KfState::save(const airfe_ctx* c) {
   nms_map_valid = c->nms_map_valid; desc_normalised = c->desc_normalised; desc_dense_valid = c->desc_dense_valid; line_sparse = c->line_sparse; last_B = c->last_B;
@@ -23,9 +59,11 @@ void KfState::restore(airfe_ctx* c) const {
 namespace {
 
 // grow-on-demand staging block: the previous block is freed (it used to stay in `allocs` until destroy)
-int ensure_block(airfe_ctx* c, uint8_t*& blk, size_t& have, size_t bytes) {
+// (user: a caller's stream the block's previous contents may still be in use on — the *_batch_dev entries run on the stream they are given)
+int ensure_block(airfe_ctx* c, uint8_t*& blk, size_t& have, size_t bytes, hipStream_t user = nullptr) {
   if (bytes <= have) return 0;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (user && user != c->stream) HIPCHK(c, hipStreamSynchronize(user));
   void* p = nullptr;
   HIPCHK(c, hipMalloc(&p, bytes));
   if (blk) {
@@ -53,6 +91,19 @@ int ensure_pin(airfe_ctx* c, size_t bytes) {
   c->pin_bytes = bytes;
   return 0;
 }
+
+// A host entry that returns with an error AFTER it queued work must not leave that work in flight: the next call memcpy's into the pinned block a
+// pending D2H may still write, and reference rows that were only partly uploaded must not be matched against.  Armed once queueing starts,
+// disarmed on success.
+struct DrainOnError {
+  airfe_ctx* c; bool armed = false, ref_uploaded = false;
+  ~DrainOnError() {
+    if (!armed) return;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream2);
+    if (ref_uploaded) c->ref_n = -1;
+  }
+};
 
 int upload_image(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride) {
   if (!gray || h < 1 || w < 1) return fail(c, "empty image");     // plnet.cpp:247
@@ -88,6 +139,15 @@ void airfe_default_cfg(airfe_cfg* cfg) {
   cfg->image_height = 480;
   cfg->sinkhorn_iters = 100;
   cfg->matcher_precision = 1;      // fp16, what the reference builds its matcher engines with (light_glue.cpp:115, super_glue.cpp:132)
+  cfg->line_precision = 2;         // fp32 operands in stage 1 (the reference's engine: fp16, plnet.cpp:216 — selectable)
+  cfg->check_launches = 0;
+  cfg->tuning = nullptr;
+}
+
+void airfe_default_tuning(airfe_tuning* t) {
+  if (!t) return;
+  int* p = reinterpret_cast<int*>(t);
+  for (size_t i = 0; i < sizeof(*t) / sizeof(int); ++i) p[i] = -1;
 }
 
 const char* airfe_last_error(const airfe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
@@ -102,7 +162,7 @@ static inline int enter_device(airfe_ctx* c) {
 }
 #define AIRFE_ENTER(c) do { if (!(c)) return 1; if (enter_device(c)) return 1; } while (0)
 
-int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
+int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) try {
   if (!cfg || !out) return fail(nullptr, "airfe_create: null argument");
   *out = nullptr;
   int ndev = 0;
@@ -116,7 +176,9 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if ((cfg->matcher_precision == 2 || (cfg->matcher_precision < 0 && cfg->precision == 2)) && cfg->superglue_pack)
     return fail(nullptr, "airfe_create: the fp32 mode covers SuperPoint / PLNet + LightGlue (BASELINE configs[1]); SuperGlue runs in fp16 / bf16");
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, "airfe_create: hipSetDevice failed");
-  airfe_ctx* c = new airfe_ctx();
+  // (owned by a guard until the very end: an exception below — a weight pack that does not fit the host's memory, say — must not leak the arena)
+  struct Guard { airfe_ctx* p; ~Guard() { if (p) airfe_destroy(p); } } guard{new airfe_ctx()};
+  airfe_ctx* c = guard.p;
   c->cfg = *cfg;
   c->prec = cfg->precision;
   c->mprec = cfg->matcher_precision < 0 ? cfg->precision : cfg->matcher_precision;
@@ -125,30 +187,37 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   c->chunk = std::min(std::max(cfg->enc_chunk, 1), c->Bmax);
   c->Pmax = c->Bmax;
   c->Np = (cfg->max_keypoints + 15) / 16 * 16;      // matcher rows per sequence: whole 16-token MFMA tiles, no further padding
-  c->fuse_lg_block = getenv("AIRFE_FUSE_LG_BLOCK") ? (atoi(getenv("AIRFE_FUSE_LG_BLOCK")) != 0) : -1;
-  if (getenv("AIRFE_SMALL_MAX_M")) c->gemm_small_max = atoi(getenv("AIRFE_SMALL_MAX_M"));
-  if (getenv("AIRFE_GEMM8_MIN_M")) c->gemm8_min = atoi(getenv("AIRFE_GEMM8_MIN_M"));
-  if (getenv("AIRFE_GEMMR_MIN_M")) c->gemmr_min = atoi(getenv("AIRFE_GEMMR_MIN_M"));
-  if (getenv("AIRFE_QKV_PAIR")) c->qkv_pair = atoi(getenv("AIRFE_QKV_PAIR")) != 0;
-  if (getenv("AIRFE_GEMMR_WGS")) c->gemmr_wgs = atoi(getenv("AIRFE_GEMMR_WGS"));
-  if (getenv("AIRFE_BLOCK_MIN_M")) c->block_min = atoi(getenv("AIRFE_BLOCK_MIN_M"));
-  if (getenv("AIRFE_LGB_TOKENS")) c->lgb_tokens = atoi(getenv("AIRFE_LGB_TOKENS"));
-  if (getenv("AIRFE_SG_KENC_GEMM")) c->sg_kenc_gemm = atoi(getenv("AIRFE_SG_KENC_GEMM")) != 0;
-  if (getenv("AIRFE_FOLD_QKV")) c->fold_qkv = atoi(getenv("AIRFE_FOLD_QKV")) != 0;
+  if (cfg->line_precision != 0 && cfg->line_precision != 1 && cfg->line_precision != 2) { return fail(nullptr, "airfe_create: line_precision must be 1 (fp16 operands) or 2 (fp32 operands)"); }
+  if (c->cfg.line_precision == 0) c->cfg.line_precision = 2;
+  c->cfg.tuning = nullptr;                       // (the caller's struct need not outlive this call)
+  if (const airfe_tuning* t = cfg->tuning) {     // kernel-selection overrides: -1 = keep the default
+    for (int r : t->reserved)
+      if (r != -1) { return fail(nullptr, "airfe_create: airfe_tuning.reserved must be -1 (use airfe_default_tuning)"); }
+    if (t->fuse_lg_block >= 0) c->fuse_lg_block = t->fuse_lg_block != 0;
+    if (t->gemm_small_max_m >= 0) c->gemm_small_max = t->gemm_small_max_m;
+    if (t->gemm8_min_m >= 0) c->gemm8_min = t->gemm8_min_m;
+    if (t->gemmr_min_m >= 0) c->gemmr_min = t->gemmr_min_m;
+    if (t->gemmr_wgs >= 0) c->gemmr_wgs = t->gemmr_wgs;
+    if (t->qkv_pair >= 0) c->qkv_pair = t->qkv_pair != 0;
+    if (t->block_min_m >= 0) c->block_min = t->block_min_m;
+    if (t->lgb_tokens >= 0) {
+      if (t->lgb_tokens != 32 && t->lgb_tokens != 64 && t->lgb_tokens != 112 && t->lgb_tokens != 128) { return fail(nullptr, "airfe_create: tuning.lgb_tokens must be 32, 64, 112 or 128"); }
+      c->lgb_tokens = t->lgb_tokens;
+    }
+    if (t->sg_kenc_gemm >= 0) c->sg_kenc_gemm = t->sg_kenc_gemm != 0;
+    if (t->fold_qkv >= 0) c->fold_qkv = t->fold_qkv != 0;
+    if (t->overlap_lines >= 0) c->overlap_lines = t->overlap_lines != 0;
+    if (t->kf_graph >= 0) c->kf_graph_on = t->kf_graph != 0;
+    if (t->kf_spec_rows >= 0) c->kf_spec_lines = c->kf_spec_juncs = std::max(t->kf_spec_rows, 1);   // (tests: force the second round trip)
+    if (t->fuse_dec >= 0) c->fuse_dec = t->fuse_dec != 0;
+    if (t->assign_fused >= 0) c->assign_fused = t->assign_fused != 0;
+  }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_feat, hipEventDisableTiming) != hipSuccess) {
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    delete c;
-    return fail(nullptr, "airfe_create: stream creation failed");
-  }
-  if (getenv("AIRFE_OVERLAP_LINES")) c->overlap_lines = atoi(getenv("AIRFE_OVERLAP_LINES")) != 0;
-  if (getenv("AIRFE_KF_GRAPH")) c->kf_graph_on = atoi(getenv("AIRFE_KF_GRAPH")) != 0;
-  if (getenv("AIRFE_KF_SPEC_ROWS")) c->kf_spec_lines = c->kf_spec_juncs = std::max(atoi(getenv("AIRFE_KF_SPEC_ROWS")), 1);   // (tests: force the second round trip)
+      hipEventCreateWithFlags(&c->ev_feat, hipEventDisableTiming) != hipSuccess)
+    return fail(nullptr, "airfe_create: stream creation failed");      // (the guard's airfe_destroy releases whatever was created)
   // a context with a detector AND the stereo matcher runs airfe_stereo_batch_dev over left + right images as one detector batch
   c->Dmax = (c->prec != 2 && cfg->superpoint_pack && cfg->lightglue_pack) ? 2 * c->Bmax : c->Bmax;
   c->chunk = std::min(std::max(cfg->enc_chunk, 1), c->Dmax);   // (a stereo step's 2 B images may go through the first layers as ONE chunk)
@@ -178,12 +247,12 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) {
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(c, "device error during weight upload");
   if (rc) {
     g_err = c->err;
-    airfe_destroy(c);
     return rc;
   }
+  guard.p = nullptr;
   *out = c;
   return 0;
-}
+} AIRFE_CATCH(nullptr)
 
 void airfe_destroy(airfe_ctx* c) {
   if (!c) return;
@@ -202,19 +271,19 @@ void airfe_destroy(airfe_ctx* c) {
   delete c;
 }
 
-int airfe_profile_enable(airfe_ctx* c, int on) {
+int airfe_profile_enable(airfe_ctx* c, int on) try {
   AIRFE_ENTER(c);
   HIPCHK(c, hipDeviceSynchronize());             // the events may have been recorded on a caller's stream (the *_dev entry points)
   for (auto& m : c->marks) { c->ev_pool.push_back(m.a); c->ev_pool.push_back(m.b); }
   c->marks.clear();
   c->prof_mask = on < 0 ? 0xFFFFFFFFu : (uint32_t)on;
   return 0;
-}
+} AIRFE_CATCH(c)
 
 int airfe_profile_stages(void) { return ST_COUNT; }
 const char* airfe_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
 
-int airfe_profile_read(airfe_ctx* c, double* ms, double* flops, double* bytes, int* launches) {
+int airfe_profile_read(airfe_ctx* c, double* ms, double* flops, double* bytes, int* launches) try {
   AIRFE_ENTER(c);
   HIPCHK(c, hipDeviceSynchronize());
   for (int i = 0; i < ST_COUNT; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
@@ -227,11 +296,11 @@ int airfe_profile_read(airfe_ctx* c, double* ms, double* flops, double* bytes, i
   }
   c->marks.clear();
   return 0;
-}
+} AIRFE_CATCH(c)
 
 /* fault hunting: checksums of the matcher's state behind every launch of the LightGlue forward (x32, xb, q, k, v^T, attention output, ...)
    in units of 16 token rows; off by default.  airfe_debug_trace_read synchronises the context's stream. */
-int airfe_debug_trace(airfe_ctx* c, int on) {
+int airfe_debug_trace(airfe_ctx* c, int on) try {
   AIRFE_ENTER(c);
   if (on && !c->trace_tab) {
     c->trace_cap = (size_t)3 << 20;
@@ -243,13 +312,13 @@ int airfe_debug_trace(airfe_ctx* c, int on) {
   c->trace_on = on != 0;
   c->trace_slots.clear();
   return 0;
-}
-int airfe_debug_trace_stop(airfe_ctx* c, int slot) {
+} AIRFE_CATCH(c)
+int airfe_debug_trace_stop(airfe_ctx* c, int slot) try {
   AIRFE_ENTER(c);
   c->trace_stop = slot;
   return 0;
-}
-int airfe_debug_trace_buffer(airfe_ctx* c, int slot, void* host, size_t bytes) {
+} AIRFE_CATCH(c)
+int airfe_debug_trace_buffer(airfe_ctx* c, int slot, void* host, size_t bytes) try {
   if (c && enter_device(c)) return 1;
   if (!c || slot < 0 || slot >= (int)c->trace_slots.size()) return fail(c, "trace_buffer: no such slot");
   const auto& t = c->trace_slots[(size_t)slot];
@@ -257,9 +326,9 @@ int airfe_debug_trace_buffer(airfe_ctx* c, int slot, void* host, size_t bytes) {
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(host, t.p, bytes, hipMemcpyDeviceToHost));
   return 0;
-}
+} AIRFE_CATCH(c)
 int airfe_debug_trace_slots(airfe_ctx* c) { return c ? (int)c->trace_slots.size() : 0; }
-int airfe_debug_trace_slot(airfe_ctx* c, int i, char* name, int name_cap, unsigned* off, unsigned* units, unsigned* unit_words) {
+int airfe_debug_trace_slot(airfe_ctx* c, int i, char* name, int name_cap, unsigned* off, unsigned* units, unsigned* unit_words) try {
   if (!c || i < 0 || i >= (int)c->trace_slots.size()) return 1;
   const auto& t = c->trace_slots[(size_t)i];
   if (name && name_cap > 0) { strncpy(name, t.name.c_str(), (size_t)name_cap - 1); name[name_cap - 1] = 0; }
@@ -267,8 +336,8 @@ int airfe_debug_trace_slot(airfe_ctx* c, int i, char* name, int name_cap, unsign
   if (units) *units = t.units;
   if (unit_words) *unit_words = t.unit_words;
   return 0;
-}
-int airfe_debug_trace_read(airfe_ctx* c, void* stream, unsigned long long* digests, unsigned long long* table) {
+} AIRFE_CATCH(c)
+int airfe_debug_trace_read(airfe_ctx* c, void* stream, unsigned long long* digests, unsigned long long* table) try {
   if (c && enter_device(c)) return 1;
   if (!c || !c->trace_tab) return fail(c, "trace is off");
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
@@ -278,28 +347,28 @@ int airfe_debug_trace_read(airfe_ctx* c, void* stream, unsigned long long* diges
   if (digests) HIPCHK(c, hipMemcpy(digests, c->trace_dig, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   if (table) HIPCHK(c, hipMemcpy(table, c->trace_tab, ((size_t)c->trace_slots.back().off + c->trace_slots.back().units) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return 0;
-}
+} AIRFE_CATCH(c)
 
 static int sinkhorn_failed(airfe_ctx* c);
-int airfe_sync(airfe_ctx* c) {
+int airfe_sync(airfe_ctx* c) try {
   AIRFE_ENTER(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return sinkhorn_failed(c);         // (the batch entry points are asynchronous: a Sinkhorn time-out of an earlier call surfaces here)
-}
+} AIRFE_CATCH(c)
 
-int airfe_superglue_status(airfe_ctx* c, void* stream) {
+int airfe_superglue_status(airfe_ctx* c, void* stream) try {
   AIRFE_ENTER(c);
   HIPCHK(c, hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
   return sinkhorn_failed(c);
-}
+} AIRFE_CATCH(c)
 
 int airfe_detect_points_batch_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride,
-                                  float* d_feat, int cap, int* d_n, void* stream) {
+                                  float* d_feat, int cap, int* d_n, void* stream) try {
   AIRFE_ENTER(c);
   return detect_dev(c, d_gray, B, h, w, stride, img_stride, d_feat, cap, d_n, stream ? (hipStream_t)stream : c->stream);
-}
+} AIRFE_CATCH(c)
 
-int airfe_detect_points(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, float* feat, int cap, int* n) {
+int airfe_detect_points(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, float* feat, int cap, int* n) try {
   AIRFE_ENTER(c);
   if (cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
   if (upload_image(c, gray, h, w, stride)) return 1;
@@ -313,11 +382,11 @@ int airfe_detect_points(airfe_ctx* c, const uint8_t* gray, int h, int w, int str
   if (nn > 0) memcpy(feat, c->pin + 64, (size_t)nn * AIRFE_FEAT_DIM * 4);
   *n = nn;
   return 0;
-}
+} AIRFE_CATCH(c)
 
 /* ---- BoW quantisation behind the path: Database::FrameToBow's per-feature tree descent --------------- */
 int airfe_bow_load(airfe_ctx* c, const float* node_desc, const int32_t* first_child, const int32_t* n_children, const int32_t* word_id,
-                   const double* weight, int n_nodes) {
+                   const double* weight, int n_nodes) try {
   AIRFE_ENTER(c);
   if (!node_desc || !first_child || !n_children || !word_id || !weight || n_nodes < 1) return fail(c, "bow_load: bad argument");
   for (int i = 0; i < n_nodes; ++i) {                    // the device follows these indices: validate them here, once
@@ -336,9 +405,9 @@ int airfe_bow_load(airfe_ctx* c, const float* node_desc, const int32_t* first_ch
     return fail(c, "device allocation failed (vocabulary)");
   c->bow_nodes = n_nodes;
   return 0;
-}
+} AIRFE_CATCH(c)
 
-int airfe_bow_transform_dev(airfe_ctx* c, const float* d_feat, int N, uint32_t* d_word, float* d_weight, void* stream) {
+int airfe_bow_transform_dev(airfe_ctx* c, const float* d_feat, int N, uint32_t* d_word, float* d_weight, void* stream) try {
   AIRFE_ENTER(c);
   if (!c->bow_nodes) return fail(c, "bow_transform: no vocabulary loaded (airfe_bow_load)");
   if (N < 0 || (N > 0 && (!d_feat || !d_word || !d_weight))) return fail(c, "bow_transform: bad argument");
@@ -348,9 +417,9 @@ int airfe_bow_transform_dev(airfe_ctx* c, const float* d_feat, int N, uint32_t* 
                        d_weight == c->bow_outw ? c->bow_outn : nullptr, st);
   HIPCHK(c, hipGetLastError());
   return 0;
-}
+} AIRFE_CATCH(c)
 
-int airfe_bow_transform(airfe_ctx* c, const float* feat, int N, uint32_t* word_of_features, double* weight_of_features) {
+int airfe_bow_transform(airfe_ctx* c, const float* feat, int N, uint32_t* word_of_features, double* weight_of_features) try {
   AIRFE_ENTER(c);
   if (N == 0) return 0;                                  // database.cc:60
   if (N < 0 || N > c->Np || N > 1024 || !feat || !word_of_features) return fail(c, "bow_transform: bad argument / more features than max_keypoints");
@@ -363,10 +432,10 @@ int airfe_bow_transform(airfe_ctx* c, const float* feat, int N, uint32_t* word_o
   if (weight_of_features)        // WordValue is a double in the reference (3rdparty/DBoW2 BowVector.h): the leaf's own weight, not a float round trip
     for (int i = 0; i < N; ++i) weight_of_features[i] = c->bow_weight_h[(size_t)node[i]];
   return 0;
-}
+} AIRFE_CATCH(c)
 
 /* ---- rectification in front of the path: Camera::UndistortImage, src/camera.cc:161-182 ------------- */
-int airfe_set_rectify_maps(airfe_ctx* c, int side, const float* mapx, const float* mapy, int h, int w) {
+int airfe_set_rectify_maps(airfe_ctx* c, int side, const float* mapx, const float* mapy, int h, int w) try {
   AIRFE_ENTER(c);
   if (side < 0 || side > 1 || !mapx || !mapy || h < 1 || w < 1) return fail(c, "set_rectify_maps: bad argument");
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -384,10 +453,10 @@ int airfe_set_rectify_maps(airfe_ctx* c, int side, const float* mapx, const floa
   c->rmap_h[side] = h;
   c->rmap_w[side] = w;
   return 0;
-}
+} AIRFE_CATCH(c)
 
 int airfe_rectify_batch_dev(airfe_ctx* c, int side, const uint8_t* d_raw, int B, int h, int w, int stride, size_t img_stride,
-                            uint8_t* d_rect, int rstride, size_t rimg_stride, void* stream) {
+                            uint8_t* d_rect, int rstride, size_t rimg_stride, void* stream) try {
   AIRFE_ENTER(c);
   if (side < 0 || side > 1 || !c->rmap[side][0]) return fail(c, "rectify: no maps set for this side (airfe_set_rectify_maps)");
   if (h != c->rmap_h[side] || w != c->rmap_w[side]) return fail(c, "rectify: image size differs from the maps'");
@@ -397,12 +466,12 @@ int airfe_rectify_batch_dev(airfe_ctx* c, int side, const uint8_t* d_raw, int B,
   launch_remap_linear(d_raw, B, h, w, stride, img_stride, c->rmap[side][0], c->rmap[side][1], d_rect, rstride, rimg_stride, st);
   HIPCHK(c, hipGetLastError());
   return 0;
-}
+} AIRFE_CATCH(c)
 
 /* raw HOST image -> rectified image (HOST, tight rows, may be NULL) + point features of the RECTIFIED image: the rectified
    image never leaves the device on its way into the detector */
 int airfe_rectify_detect_points(airfe_ctx* c, int side, const uint8_t* raw, int h, int w, int stride, uint8_t* rect_out, float* feat,
-                                int cap, int* n) {
+                                int cap, int* n) try {
   AIRFE_ENTER(c);
   if (feat && cap < c->cfg.max_keypoints) return fail(c, "feature capacity < max_keypoints");
   if (upload_image(c, raw, h, w, stride)) return 1;
@@ -418,9 +487,9 @@ int airfe_rectify_detect_points(airfe_ctx* c, int side, const uint8_t* raw, int 
   if (feat && nn > 0) HIPCHK(c, hipMemcpy(feat, c->st_feat0, (size_t)nn * AIRFE_FEAT_DIM * 4, hipMemcpyDeviceToHost));
   if (n) *n = nn;
   return 0;
-}
+} AIRFE_CATCH(c)
 
-int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_nms, float* desc) {
+int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_nms, float* desc) try {
   if (c && enter_device(c)) return 1;
   if (!c || !c->has_sp || B > c->Dmax) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -446,7 +515,7 @@ int airfe_debug_detector_maps(airfe_ctx* c, int B, float* heat_raw, float* heat_
     HIPCHK(c, hipMemcpy(desc, c->desc, (size_t)B * 64 * 64 * 256 * 4, hipMemcpyDeviceToHost));
   }
   return 0;
-}
+} AIRFE_CATCH(c)
 
 static int lg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx, float* score, int cap,
                    int* nmatch, float* scores_full) {
@@ -485,18 +554,18 @@ static int lg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n
 }
 
 int airfe_match_lightglue(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx, float* score,
-                          int cap, int* nmatch) {
+                          int cap, int* nmatch) try {
   if (c && enter_device(c)) return 1;
   return lg_host(c, f0, n0, f1, n1, idx, score, cap, nmatch, nullptr);
-}
+} AIRFE_CATCH(c)
 
-int airfe_debug_lightglue_scores(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, float* scores) {
+int airfe_debug_lightglue_scores(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, float* scores) try {
   if (c && enter_device(c)) return 1;
   return lg_host(c, f0, n0, f1, n1, nullptr, nullptr, 0, nullptr, scores);
-}
+} AIRFE_CATCH(c)
 
 /* filter_matches (src/light_glue.cpp:214-266) alone on one HOST score matrix [n0][n1] */
-int airfe_debug_lg_filter(airfe_ctx* c, const float* scores, int n0, int n1, int32_t* idx, float* score, int cap, int* nmatch) {
+int airfe_debug_lg_filter(airfe_ctx* c, const float* scores, int n0, int n1, int32_t* idx, float* score, int cap, int* nmatch) try {
   if (c && enter_device(c)) return 1;
   if (!c || !c->has_arena) return fail(c, "debug_lg_filter: no matcher loaded");
   if (n0 < 1 || n1 < 1 || n0 > c->cfg.max_keypoints || n1 > c->cfg.max_keypoints || !scores || !idx || !score || !nmatch)
@@ -516,18 +585,18 @@ int airfe_debug_lg_filter(airfe_ctx* c, const float* scores, int n0, int n1, int
   }
   *nmatch = nm;
   return 0;
-}
+} AIRFE_CATCH(c)
 
 int airfe_match_lightglue_batch_dev(airfe_ctx* c, const float* d_f0, const int* d_n0, const float* d_f1, const int* d_n1,
-                                    int B, int cap, int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, void* stream) {
+                                    int B, int cap, int32_t* d_idx, float* d_score, int mcap, int* d_nmatch, void* stream) try {
   AIRFE_ENTER(c);
   return lightglue_dev(c, d_f0, d_n0, d_f1, d_n1, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr,
                        stream ? (hipStream_t)stream : c->stream);
-}
+} AIRFE_CATCH(c)
 
 int airfe_stereo_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
                            size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, int32_t* d_idx,
-                           float* d_score, int mcap, int* d_nmatch, void* stream) {
+                           float* d_score, int mcap, int* d_nmatch, void* stream) try {
   AIRFE_ENTER(c);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   if (c->prec != 2 && 2 * B <= c->Dmax) {        // left and right images as ONE detector batch
@@ -537,10 +606,10 @@ int airfe_stereo_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d
     if (detect_dev(c, d_right, B, h, w, stride, img_stride, d_featR, cap, d_nR, st)) return 1;
   }
   return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st);
-}
+} AIRFE_CATCH(c)
 
 int airfe_assign_points_to_lines(airfe_ctx* c, const double* lines, int L, const float* feat, int N, int32_t* row_ptr,
-                                 int32_t* pt_idx, double* pt_dist, int cap, int* total) {
+                                 int32_t* pt_idx, double* pt_dist, int cap, int* total) try {
   AIRFE_ENTER(c);
   if (L < 0 || N < 0 || cap < 0 || !row_ptr || !total) return fail(c, "assign_points_to_lines: bad argument");
   *total = 0;
@@ -576,29 +645,32 @@ int airfe_assign_points_to_lines(airfe_ctx* c, const double* lines, int L, const
     HIPCHK(c, hipMemcpy(pt_dist, d_dist, (size_t)*total * 8, hipMemcpyDeviceToHost));
   }
   return 0;
-}
+} AIRFE_CATCH(c)
 
 // NEW (VERDICT r03 missing #5): the same over B frames whose lines and features are ALREADY on the device — the outputs of
 // airfe_detect_plnet_batch_dev / airfe_stereo_plnet_batch_dev, in place (the reference calls AssignPointsToLines right after Detect: src/frame.cc:125,177)
 int airfe_assign_points_to_lines_batch_dev(airfe_ctx* c, const double* d_lines, const int* d_nlines, int capL, const float* d_feat, const int* d_n,
                                            int cap, int B, int32_t* d_row_ptr, int32_t* d_pt_idx, double* d_pt_dist, int capE, int* d_total,
-                                           void* stream) {
+                                           void* stream) try {
   AIRFE_ENTER(c);
   if (B < 1 || capL < 1 || cap < 1 || capE < 1 || !d_lines || !d_nlines || !d_feat || !d_n || !d_row_ptr || !d_pt_idx || !d_pt_dist)
     return fail(c, "assign_points_to_lines_batch_dev: bad argument");
-  if (ensure_block(c, c->pl_scratch, c->pl_scratch_bytes, (size_t)B * capL * 4)) return 1;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  // scratch of THIS entry (airfe_match_lines_batch_dev has its own: the two may be in flight on different streams); it grows only behind a
+  // synchronisation of the stream it was last used on.  One stream at a time per entry and context — the contract of every *_dev entry (one ctx = one calling thread).
+  if (ensure_block(c, c->pl_scratch, c->pl_scratch_bytes, (size_t)B * capL * 4, c->pl_scratch_stream)) return 1;
+  c->pl_scratch_stream = st;
   PlAssignArgs a;
   a.lines = d_lines; a.nlines = d_nlines; a.feat = d_feat; a.npts = d_n; a.capL = capL; a.cap = cap; a.capE = capE;
   a.counts = reinterpret_cast<int*>(c->pl_scratch); a.row_ptr = d_row_ptr; a.pt_idx = d_pt_idx; a.pt_dist = d_pt_dist; a.total = d_total;
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   ProfScope ps(c, ST_LINE_ASSOC, st, 0, (double)B * ((double)capL * 32 + (double)cap * 8));
   launch_assign_points_to_lines(a, B, st);
   HIPCHK(c, hipGetLastError());
   return 0;
-}
+} AIRFE_CATCH(c)
 
 int airfe_match_lines(airfe_ctx* c, const int32_t* row_ptr0, const int32_t* pt_idx0, int L0, int point_num0, const int32_t* row_ptr1,
-                      const int32_t* pt_idx1, int L1, int point_num1, const int32_t* matches, int M, int32_t* line_matches) {
+                      const int32_t* pt_idx1, int L1, int point_num1, const int32_t* matches, int M, int32_t* line_matches) try {
   AIRFE_ENTER(c);
   if (L0 < 0 || L1 < 0 || M < 0 || point_num0 < 0 || point_num1 < 0 || (L0 > 0 && !line_matches)) return fail(c, "match_lines: bad argument");
   for (int i = 0; i < L0; ++i) line_matches[i] = -1;                                  // line_processor.cc:127-131
@@ -623,7 +695,7 @@ int airfe_match_lines(airfe_ctx* c, const int32_t* row_ptr0, const int32_t* pt_i
   // the batch entry's kernels with one frame pair: one line capacity for both sides, the relation capacity = the larger relation
   const int capL = std::max(L0, L1), capE = std::max(std::max(t0, t1), 1), mcap = std::max(M, 1);
   const int W = (mcap + 31) / 32;
-  const size_t words = 2 * (size_t)(capL + 1) + 2 * (size_t)capE + (size_t)mcap * 2 + 2 * (size_t)capL * W + (size_t)capL * capL + 2 * (size_t)capL + 8;
+  const size_t words = 2 * (size_t)(capL + 1) + 2 * (size_t)capE + (size_t)mcap * 2 + 2 * (size_t)capL * W + 2 * (size_t)capL + 8;
   if (ensure_block(c, c->pl_stage, c->pl_bytes, words * 4 + 64)) return 1;      // grows by replacing (and freeing) the previous block
   int* q = reinterpret_cast<int*>(c->pl_stage);
   int* d_rp0 = q; q += capL + 1;
@@ -633,7 +705,6 @@ int airfe_match_lines(airfe_ctx* c, const int32_t* row_ptr0, const int32_t* pt_i
   int* d_m = q; q += (size_t)mcap * 2;
   unsigned* d_b0 = reinterpret_cast<unsigned*>(q); q += (size_t)capL * W;
   unsigned* d_b1 = reinterpret_cast<unsigned*>(q); q += (size_t)capL * W;
-  int* d_vote = q; q += (size_t)capL * capL;
   int* d_rloc = q; q += capL;
   int* d_lm = q; q += capL;
   int* d_cnt = q;                                                        // {L0, L1, point_num0, point_num1, M}
@@ -649,13 +720,13 @@ int airfe_match_lines(airfe_ctx* c, const int32_t* row_ptr0, const int32_t* pt_i
   a.row_ptr0 = d_rp0; a.pt_idx0 = d_pi0; a.nlines0 = d_cnt; a.npts0 = d_cnt + 2;
   a.row_ptr1 = d_rp1; a.pt_idx1 = d_pi1; a.nlines1 = d_cnt + 1; a.npts1 = d_cnt + 3;
   a.matches = d_m; a.nmatch = d_cnt + 4; a.capL = capL; a.capE = capE; a.mcap = mcap; a.W = W;
-  a.bits0 = d_b0; a.bits1 = d_b1; a.vote = d_vote; a.row_loc = d_rloc; a.line_matches = d_lm;
+  a.bits0 = d_b0; a.bits1 = d_b1; a.row_loc = d_rloc; a.line_matches = d_lm;
   launch_match_lines(a, 1, st);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(line_matches, d_lm, (size_t)L0 * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   return 0;
-}
+} AIRFE_CATCH(c)
 
 // NEW: MatchLines over B frame pairs on the device, straight from the relations of airfe_assign_points_to_lines_batch_dev and the match lists of the
 // matcher's batch entries (src/frame.cc:184 calls it right behind the stereo match).  filter3 != NULL = {min_x_diff, max_x_diff, max_y_diff}: the
@@ -663,15 +734,18 @@ int airfe_match_lines(airfe_ctx* c, const int32_t* row_ptr0, const int32_t* pt_i
 int airfe_match_lines_batch_dev(airfe_ctx* c, const int32_t* d_row_ptr0, const int32_t* d_pt_idx0, const int* d_nlines0, const int* d_n0,
                                 const int32_t* d_row_ptr1, const int32_t* d_pt_idx1, const int* d_nlines1, const int* d_n1, int capL, int capE,
                                 const int32_t* d_matches, const int* d_nmatch, int mcap, int B, const double* filter3, const float* d_feat0,
-                                const float* d_feat1, int cap, int32_t* d_line_matches, void* stream) {
+                                const float* d_feat1, int cap, int32_t* d_line_matches, void* stream) try {
   AIRFE_ENTER(c);
   if (B < 1 || capL < 1 || capE < 1 || mcap < 1 || !d_row_ptr0 || !d_pt_idx0 || !d_nlines0 || !d_n0 || !d_row_ptr1 || !d_pt_idx1 || !d_nlines1 ||
       !d_n1 || !d_matches || !d_nmatch || !d_line_matches || (filter3 && (!d_feat0 || !d_feat1 || cap < 1)))
     return fail(c, "match_lines_batch_dev: bad argument");
   const int W = (mcap + 31) / 32;
-  const size_t words = 2 * (size_t)B * capL * W + (size_t)B * capL * capL + (size_t)B * capL;
-  if (ensure_block(c, c->pl_scratch, c->pl_scratch_bytes, words * 4)) return 1;
-  unsigned* q = reinterpret_cast<unsigned*>(c->pl_scratch);
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  // bit rows [2][B][capL][W] + row maxima [B][capL] (no vote matrix: the column pass recounts from the bit rows) — 7 MB at 64 frames x 1024 line slots
+  const size_t words = 2 * (size_t)B * capL * W + (size_t)B * capL;
+  if (ensure_block(c, c->ml_scratch, c->ml_scratch_bytes, words * 4, c->ml_scratch_stream)) return 1;
+  c->ml_scratch_stream = st;
+  unsigned* q = reinterpret_cast<unsigned*>(c->ml_scratch);
   MlArgs a;
   a.row_ptr0 = d_row_ptr0; a.pt_idx0 = d_pt_idx0; a.nlines0 = d_nlines0; a.npts0 = d_n0;
   a.row_ptr1 = d_row_ptr1; a.pt_idx1 = d_pt_idx1; a.nlines1 = d_nlines1; a.npts1 = d_n1;
@@ -679,15 +753,13 @@ int airfe_match_lines_batch_dev(airfe_ctx* c, const int32_t* d_row_ptr0, const i
   if (filter3) { a.filter_on = 1; a.min_x_diff = filter3[0]; a.max_x_diff = filter3[1]; a.max_y_diff = filter3[2]; a.feat0 = d_feat0; a.feat1 = d_feat1; }
   a.bits0 = q; q += (size_t)B * capL * W;
   a.bits1 = q; q += (size_t)B * capL * W;
-  a.vote = reinterpret_cast<int*>(q); q += (size_t)B * capL * capL;
   a.row_loc = reinterpret_cast<int*>(q);
   a.line_matches = d_line_matches;
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   ProfScope ps(c, ST_LINE_ASSOC, st, 0, (double)B * (double)capL * W * 8);
   launch_match_lines(a, B, st);
   HIPCHK(c, hipGetLastError());
   return 0;
-}
+} AIRFE_CATCH(c)
 
 int airfe_has_line_branch(const airfe_ctx* c) { return c && c->has_s0 && c->has_s1; }
 
@@ -708,7 +780,7 @@ static int upload_stage0(airfe_ctx* c, const airfe_plnet_stage0* s0, hipStream_t
 
 int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, const airfe_plnet_stage0* s0, float* feat,
                        int cap, int* n, double* lines, int capL, int* nlines, float* junc, int capJ, int* njunc,
-                       int want_junctions) {
+                       int want_junctions) try {
   AIRFE_ENTER(c);
   if (nlines) *nlines = 0;
   if (njunc) *njunc = 0;
@@ -762,7 +834,7 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
   if (nlines) *nlines = nl;
   if (njunc) *njunc = nj;
   return 0;
-}
+} AIRFE_CATCH(c)
 
 // PLNet::infer over a device-resident batch, after the point branch ran on it (images 0 .. B-1 of the detector arena): lines of every
 // image, junctions of the first nj
@@ -789,7 +861,7 @@ static int plnet_lines_batch(airfe_ctx* c, int B, int h, int w, double* d_lines,
 
 int airfe_detect_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat,
                                  int cap, int* d_n, double* d_lines, int capL, int* d_nlines, float* d_junc, int capJ, int* d_njunc,
-                                 int junction_images, int* d_found, void* stream) {
+                                 int junction_images, int* d_found, void* stream) try {
   AIRFE_ENTER(c);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   c->force_nms_map = junction_images > 0;         // junction scores are read from the NMS'd maps
@@ -797,7 +869,7 @@ int airfe_detect_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int
   c->force_nms_map = false;
   if (rc) return 1;
   return plnet_lines_batch(c, B, h, w, d_lines, capL, d_nlines, d_junc, capJ, d_njunc, junction_images, d_found, st);
-}
+} AIRFE_CATCH(c)
 
 // (d_idx == nullptr: detection only — the stereo overload of Detect without the MatchingPoints that follows it)
 static int stereo_plnet_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
@@ -851,12 +923,12 @@ static int stereo_plnet_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* 
 int airfe_stereo_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int B, int h, int w, int stride,
                                  size_t img_stride, float* d_featL, float* d_featR, int cap, int* d_nL, int* d_nR, double* d_lines,
                                  int capL, int* d_nlines, float* d_juncL, int capJ, int* d_njuncL, int* d_found, int32_t* d_idx,
-                                 float* d_score, int mcap, int* d_nmatch, void* stream) {
+                                 float* d_score, int mcap, int* d_nmatch, void* stream) try {
   AIRFE_ENTER(c);
   if (!d_idx || !d_score || !d_nmatch) return fail(c, "stereo_plnet_batch: no match output");
   return stereo_plnet_dev(c, d_left, d_right, B, h, w, stride, img_stride, d_featL, d_featR, cap, d_nL, d_nR, d_lines, capL, d_nlines, d_juncL, capJ,
                           d_njuncL, d_found, d_idx, d_score, mcap, d_nmatch, stream ? (hipStream_t)stream : c->stream);
-}
+} AIRFE_CATCH(c)
 
 // ONE stereo keyframe through host buffers (batch 1, the regime of AirSLAM's feature thread): what map_builder.cc:85-86 does in two façade calls —
 // Detect(left, right, features, lines, junctions) = PLNet::infer twice (feature_detector.cc:97-108), then MatchingPoints(left, right) — as ONE
@@ -873,6 +945,7 @@ static int stereo_keyframe_impl(airfe_ctx* c, const uint8_t* left, const uint8_t
   if (track) {
     if (!match_idx || !track_score || !ntrack) return fail(c, "stereo_keyframe_tracked: bad argument");
     if (c->Pmax < 2) return fail(c, "stereo_keyframe_tracked: needs cfg.max_batch >= 2 (two pairs per LightGlue forward)");
+    if (c->mprec == 2) return fail(c, "stereo_keyframe_tracked: the temporal pair rides in a 2-byte LightGlue forward (matcher_precision fp16 / bf16)");
     if (ref_feat && (n_ref < 0 || n_ref > c->cfg.max_keypoints)) return fail(c, "stereo_keyframe_tracked: reference keypoint count exceeds max_keypoints");
     if (!ref_feat && c->ref_n < 0) return fail(c, "stereo_keyframe_tracked: no reference features were ever given");
     *ntrack = 0;
@@ -935,9 +1008,9 @@ static int stereo_keyframe_impl(airfe_ctx* c, const uint8_t* left, const uint8_t
       memcpy(c->pin + pitch, right, ib);
       *reinterpret_cast<int*>(c->pin + ref_off) = n_ref;
       if (n_ref > 0) memcpy(c->pin + ref_off + 64, ref_feat, (size_t)n_ref * AIRFE_FEAT_DIM * 4);
-      c->ref_n = n_ref;
     }
   }
+  DrainOnError drain{c};
   const std::function<int(hipStream_t)> rows_copy = [&](hipStream_t s2) -> int {
     HIPCHK(c, hipMemcpyAsync(c->pin + spec, d_ln, spec_l, hipMemcpyDeviceToHost, s2));
     HIPCHK(c, hipMemcpyAsync(c->pin + spec + spec_l, d_ln + (size_t)capLd * 4, spec_l, hipMemcpyDeviceToHost, s2));
@@ -945,9 +1018,14 @@ static int stereo_keyframe_impl(airfe_ctx* c, const uint8_t* left, const uint8_t
     return 0;
   };
   auto queue_all = [&]() -> int {
+    drain.armed = true;
     HIPCHK(c, hipMemsetAsync(cnt, 0, 64, st));
     HIPCHK(c, hipMemcpyAsync(c->st_img, c->pin, pitch + ib, hipMemcpyHostToDevice, st));
-    if (track && ref_feat) HIPCHK(c, hipMemcpyAsync(c->ref_blk, c->pin + ref_off, 64 + (size_t)n_ref * AIRFE_FEAT_DIM * 4, hipMemcpyHostToDevice, st));
+    if (track && ref_feat) {
+      drain.ref_uploaded = true;       // (the reference count becomes valid with the queued upload; an error below takes it back)
+      HIPCHK(c, hipMemcpyAsync(c->ref_blk, c->pin + ref_off, 64 + (size_t)n_ref * AIRFE_FEAT_DIM * 4, hipMemcpyHostToDevice, st));
+      c->ref_n = n_ref;
+    }
     // (match counts: cnt[10] = stereo, cnt[11] = temporal — LightGlue writes d_nmatch[pair])
     if (stereo_plnet_dev(c, c->st_img, c->st_img + pitch, 1, h, w, stride, pitch, d_fL, d_fR, Np, cnt, cnt + 1, d_ln, capLd, cnt + 2,
                          want_j ? d_jn : nullptr, capJd, want_j ? cnt + 5 : nullptr, cnt + 6, match ? d_idx : nullptr, d_sc, Np, cnt + 10, st, &early_copy, &rows_copy,
@@ -958,7 +1036,7 @@ static int stereo_keyframe_impl(airfe_ctx* c, const uint8_t* left, const uint8_t
     if (match && !track) HIPCHK(c, hipMemcpyAsync(c->pin + late + (size_t)Np * 16, d_sc, (size_t)Np * 4, hipMemcpyDeviceToHost, st));
     return 0;
   };
-  // AIRFE_KF_GRAPH=1: the whole queue (~115 launches on two streams) is captured once per (image shape, outputs, buffers) as a hipGraph and replayed
+  // airfe_tuning::kf_graph = 1: the whole queue (~115 launches on two streams) is captured once per (image shape, outputs, buffers) as a hipGraph and replayed
   // with one launch — the same kernels with the same arguments, so the same bits.  The first call of a configuration runs plainly (it grows blocks and
   // sets function attributes, which a capture cannot hold), the second captures, later ones replay.  Off while stage timers or the trace are on.
   // (Measured: <= 1 % per keyframe, profiles/r04_keyframe_graph_ab.txt — the queue is bound by the GPU's ~4.7 us per dependent launch, not by the
@@ -1016,6 +1094,7 @@ static int stereo_keyframe_impl(airfe_ctx* c, const uint8_t* left, const uint8_t
     }
     *ntrack = nt;
   }
+  drain.ref_uploaded = false;           // (everything queued has completed: the reference rows are whole whatever is reported below)
   if (want_j && fj > JUNC_CAP) return fail(c, "stereo_keyframe: more junctions than the device arena holds (JUNC_CAP)");
   if (fl0 > capLd || fl1 > capLd || (want_j && fj > capJd)) return fail(c, "stereo_keyframe: lines / junctions do not fit the caller's buffers (capL, capJ)");
   const size_t b0 = (size_t)nl0 * 32, b1 = (size_t)nl1 * 32, bj = want_j ? (size_t)nj * AIRFE_FEAT_DIM * 4 : 0;
@@ -1035,23 +1114,24 @@ static int stereo_keyframe_impl(airfe_ctx* c, const uint8_t* left, const uint8_t
   }
   *nlinesL = nl0; *nlinesR = nl1;
   if (njuncL) *njuncL = want_j ? nj : 0;
+  drain.armed = false;
   return 0;
 }
 
 int airfe_stereo_keyframe(airfe_ctx* c, const uint8_t* left, const uint8_t* right, int h, int w, int stride, float* featL, float* featR, int cap,
                           int* nL, int* nR, double* linesL, double* linesR, int capL, int* nlinesL, int* nlinesR, float* juncL, int capJ,
-                          int* njuncL, int32_t* match_idx, float* match_score, int mcap, int* nmatch) {
+                          int* njuncL, int32_t* match_idx, float* match_score, int mcap, int* nmatch) try {
   return stereo_keyframe_impl(c, left, right, h, w, stride, featL, featR, cap, nL, nR, linesL, linesR, capL, nlinesL, nlinesR, juncL, capJ, njuncL, match_idx,
                               match_score, mcap, nmatch, nullptr, 0, nullptr, nullptr, nullptr);
-}
+} AIRFE_CATCH(c)
 int airfe_stereo_keyframe_tracked(airfe_ctx* c, const uint8_t* left, const uint8_t* right, int h, int w, int stride, float* featL, float* featR, int cap,
                                   int* nL, int* nR, double* linesL, double* linesR, int capL, int* nlinesL, int* nlinesR, float* juncL, int capJ,
                                   int* njuncL, int32_t* match_idx, float* match_score, int mcap, int* nmatch, const float* ref_feat, int n_ref,
-                                  int32_t* track_idx, float* track_score, int* ntrack) {
+                                  int32_t* track_idx, float* track_score, int* ntrack) try {
   if (c && !track_idx) return fail(c, "stereo_keyframe_tracked: no output for the temporal matches");
   return stereo_keyframe_impl(c, left, right, h, w, stride, featL, featR, cap, nL, nR, linesL, linesR, capL, nlinesL, nlinesR, juncL, capJ, njuncL, match_idx,
                               match_score, mcap, nmatch, ref_feat, n_ref, track_idx, track_score, ntrack);
-}
+} AIRFE_CATCH(c)
 
 // ONE tracked frame through host buffers (batch 1): what map_builder.cc:94-101 does for every frame that is not a keyframe —
 //     _feature_detector->Detect(image_left_rect, left_features);
@@ -1059,7 +1139,7 @@ int airfe_stereo_keyframe_tracked(airfe_ctx* c, const uint8_t* left, const uint8
 // — as one queue: the last keyframe's features live on the device (uploaded when ref_feat != NULL, i.e. once per keyframe, not once per frame), the
 // new frame's feature rows come back on the side stream while LightGlue runs.  Bits: those of airfe_detect_points + airfe_match_lightglue.
 int airfe_track_frame(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, const float* ref_feat, int n_ref, float* feat, int cap, int* n,
-                      int32_t* match_idx, float* match_score, int mcap, int* nmatch) {
+                      int32_t* match_idx, float* match_score, int mcap, int* nmatch) try {
   AIRFE_ENTER(c);
   if (!gray || h < 1 || w < 1) return fail(c, "empty image");
   if (stride < w) return fail(c, "image stride smaller than its width");
@@ -1084,16 +1164,17 @@ int airfe_track_frame(airfe_ctx* c, const uint8_t* gray, int h, int w, int strid
   const size_t ib = (size_t)(h - 1) * stride + w, ioff = (ib + 63) / 64 * 64;
   if (ensure_stage_img(c, (size_t)h * stride)) return 1;
   if (ensure_pin(c, std::max(ioff + 64 + fb, late + (size_t)Np * 12))) return 1;
+  if (!ref_feat && c->ref_n < 0) return fail(c, "track_frame: no reference features were ever given (ref_feat == NULL on the first call)");
   memcpy(c->pin, gray, ib);
+  DrainOnError drain{c, true};
   HIPCHK(c, hipMemsetAsync(cnt, 0, 64, st));
   HIPCHK(c, hipMemcpyAsync(c->st_img, c->pin, ib, hipMemcpyHostToDevice, st));
   if (ref_feat) {
     *reinterpret_cast<int*>(c->pin + ioff) = n_ref;
     if (n_ref > 0) memcpy(c->pin + ioff + 64, ref_feat, (size_t)n_ref * AIRFE_FEAT_DIM * 4);
+    drain.ref_uploaded = true;
     HIPCHK(c, hipMemcpyAsync(c->ref_blk, c->pin + ioff, 64 + (size_t)n_ref * AIRFE_FEAT_DIM * 4, hipMemcpyHostToDevice, st));
     c->ref_n = n_ref;
-  } else if (c->ref_n < 0) {
-    return fail(c, "track_frame: no reference features were ever given (ref_feat == NULL on the first call)");
   }
   if (detect_dev(c, c->st_img, 1, h, w, stride, (size_t)h * stride, d_new, Np, cnt, st)) return 1;
   HIPCHK(c, hipEventRecord(c->ev_fork, st));                         // the new rows go home on the side stream, beside the matcher
@@ -1108,6 +1189,7 @@ int airfe_track_frame(airfe_ctx* c, const uint8_t* gray, int h, int w, int strid
   if (nn > 0) memcpy(feat, c->pin + 64, (size_t)nn * AIRFE_FEAT_DIM * 4);
   *n = nn;
   HIPCHK(c, hipStreamSynchronize(st));
+  drain.armed = false;
   if (nn < 1 || c->ref_n < 1) return 0;                              // point_matcher.cc:53-55
   const int nm = std::min(reinterpret_cast<const int*>(c->pin + early)[2], Np);
   if (nm > 0) {
@@ -1116,11 +1198,11 @@ int airfe_track_frame(airfe_ctx* c, const uint8_t* gray, int h, int w, int strid
   }
   *nmatch = nm;
   return 0;
-}
+} AIRFE_CATCH(c)
 
 /* the on-device stage-0 line branch of the LAST detected image, copied out in the Appendix A.1 layouts (NULL = skip) */
 int airfe_debug_plnet_stage0(airfe_ctx* c, float* juncs_pred, float* lines_pred, float* iskeep, float* idx_min, float* idx_max,
-                             float* loi, float* thin, float* aux, float* jloc, float* joff) {
+                             float* loi, float* thin, float* aux, float* jloc, float* joff) try {
   if (c && enter_device(c)) return 1;
   if (!c || !c->has_s0 || !c->has_s1) return fail(c, "debug_plnet_stage0: line branch / stage 1 not loaded");
   hipStream_t st = c->stream;
@@ -1135,11 +1217,11 @@ int airfe_debug_plnet_stage0(airfe_ctx* c, float* juncs_pred, float* lines_pred,
   for (auto& e : cp)
     if (e.h) HIPCHK(c, hipMemcpy(e.h, e.dv, e.n * 4, hipMemcpyDeviceToHost));
   return 0;
-}
+} AIRFE_CATCH(c)
 
 /* the junction-to-line match of the LAST detected image as the line path runs it (fast = 1: cell search, exact where it is consumed) or
    as the inspection hook exports it (fast = 0: every proposal against every junction): iskeep, idx_junc_to_end_min / _max [3*128*128] */
-int airfe_debug_plnet_j2l(airfe_ctx* c, int fast, float* iskeep, float* idx_min, float* idx_max) {
+int airfe_debug_plnet_j2l(airfe_ctx* c, int fast, float* iskeep, float* idx_min, float* idx_max) try {
   if (c && enter_device(c)) return 1;
   if (!c || !c->has_s0 || !c->has_s1) return fail(c, "debug_plnet_j2l: line branch / stage 1 not loaded");
   hipStream_t st = c->stream;
@@ -1151,10 +1233,10 @@ int airfe_debug_plnet_j2l(airfe_ctx* c, int fast, float* iskeep, float* idx_min,
   if (idx_min) HIPCHK(c, hipMemcpy(idx_min, d + SG_MIN, NP * 4, hipMemcpyDeviceToHost));
   if (idx_max) HIPCHK(c, hipMemcpy(idx_max, d + SG_MAX, NP * 4, hipMemcpyDeviceToHost));
   return 0;
-}
+} AIRFE_CATCH(c)
 
 /* stage-1 alone on HOST stage-0 tensors: lines_adjusted [M2][4] + scores_line [M2] (parity vs the real plnet_s1.onnx) */
-int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* lines_adjusted, float* scores_line, int cap, int* m2) {
+int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* lines_adjusted, float* scores_line, int cap, int* m2) try {
   if (c && enter_device(c)) return 1;
   if (!c || !c->has_s1 || !s0) return fail(c, "debug_plnet_s1: stage-1 not loaded");
   hipStream_t st = c->stream;
@@ -1174,7 +1256,7 @@ int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* line
   }
   *m2 = k;
   return 0;
-}
+} AIRFE_CATCH(c)
 
 // The register-resident Sinkhorn kernel raises a device word when one of its bounded rendezvous spins timed out (that pair's Z is NaN): read
 // after a synchronisation, cleared once reported.
@@ -1214,13 +1296,13 @@ static int sg_host(airfe_ctx* c, const float* f0, int n0, const float* f1, int n
 }
 
 int airfe_match_superglue(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, int32_t* idx0, int32_t* idx1,
-                          double* ms0, double* ms1) {
+                          double* ms0, double* ms1) try {
   if (c && enter_device(c)) return 1;
   return sg_host(c, f0, n0, f1, n1, idx0, idx1, ms0, ms1, nullptr);
-}
+} AIRFE_CATCH(c)
 
 /* decode (src/super_glue.cpp:339-367) alone on one HOST score matrix Z [n0+1][n1+1] */
-int airfe_debug_sg_decode(airfe_ctx* c, const float* Z, int n0, int n1, int32_t* idx0, int32_t* idx1, double* ms0, double* ms1) {
+int airfe_debug_sg_decode(airfe_ctx* c, const float* Z, int n0, int n1, int32_t* idx0, int32_t* idx1, double* ms0, double* ms1) try {
   if (c && enter_device(c)) return 1;
   if (!c || !c->has_sg) return fail(c, "debug_sg_decode: SuperGlue not loaded");
   if (n0 < 1 || n1 < 1 || n0 > c->cfg.max_keypoints || n1 > c->cfg.max_keypoints || !Z || !idx0 || !idx1 || !ms0 || !ms1)
@@ -1239,12 +1321,12 @@ int airfe_debug_sg_decode(airfe_ctx* c, const float* Z, int n0, int n1, int32_t*
   for (int i = 0; i < n0; ++i) ms0[i] = (double)m0[i];
   for (int j = 0; j < n1; ++j) ms1[j] = (double)m1[j];
   return 0;
-}
+} AIRFE_CATCH(c)
 
 /* SuperGlue on B pairs of DEVICE feature matrices (259-float rows, original pixel coordinates; NormalizeKeypoints with scale 0.7 on
    the device): d_idx0 / d_idx1 [B][cap] (-1 = unmatched), d_ms0 / d_ms1 [B][cap] floats.  No reference counterpart (batch-1 there). */
 int airfe_match_superglue_batch_dev(airfe_ctx* c, const float* d_f0, const int* d_n0, const float* d_f1, const int* d_n1, int B, int cap,
-                                    int32_t* d_idx0, int32_t* d_idx1, float* d_ms0, float* d_ms1, void* stream) {
+                                    int32_t* d_idx0, int32_t* d_idx1, float* d_ms0, float* d_ms1, void* stream) try {
   AIRFE_ENTER(c);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   if (superglue_dev(c, d_f0, d_n0, d_f1, d_n1, B, cap, 1, st)) return 1;
@@ -1254,16 +1336,16 @@ int airfe_match_superglue_batch_dev(airfe_ctx* c, const float* d_f0, const int* 
   HIPCHK(c, hipMemcpy2DAsync(d_ms0, dp, c->sg_ms0, sp, wb, B, hipMemcpyDeviceToDevice, st));
   HIPCHK(c, hipMemcpy2DAsync(d_ms1, dp, c->sg_ms1, sp, wb, B, hipMemcpyDeviceToDevice, st));
   return 0;
-}
+} AIRFE_CATCH(c)
 
 /* full SuperGlue output `scores` [n0+1][n1+1] (binding A.5) for one HOST pair */
-int airfe_debug_superglue_scores(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, float* scores) {
+int airfe_debug_superglue_scores(airfe_ctx* c, const float* f0, int n0, const float* f1, int n1, float* scores) try {
   if (c && enter_device(c)) return 1;
   return sg_host(c, f0, n0, f1, n1, nullptr, nullptr, nullptr, nullptr, scores);
-}
+} AIRFE_CATCH(c)
 
 // ---- kernel-level test hooks ------------------------------------------------------------------------------
-int airfe_debug_preprocess(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, float* out) {
+int airfe_debug_preprocess(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride, float* out) try {
   if (c && enter_device(c)) return 1;
   if (!c || !c->has_sp) return fail(c, "debug_preprocess: detector not loaded");
   const size_t bytes = (size_t)h * stride;
@@ -1273,10 +1355,10 @@ int airfe_debug_preprocess(airfe_ctx* c, const uint8_t* gray, int h, int w, int 
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy2D(out, (size_t)R * 4, c->img32 + (R + 2) + 1, (size_t)(R + 2) * 4, (size_t)R * 4, R, hipMemcpyDeviceToHost));
   return 0;
-}
+} AIRFE_CATCH(c)
 
 int airfe_debug_conv3x3(airfe_ctx* c, const float* x, int B, int cin, int H, int W, const float* w, const float* b, int cout,
-                        int pool, float* y) {
+                        int pool, float* y) try {
   AIRFE_ENTER(c);
   if ((cin != 64 && cin != 128) || cout % 64 || W % 16 || H % 16) return fail(c, "debug_conv3x3: unsupported shape");
   const int prec = c->prec;
@@ -1317,9 +1399,16 @@ int airfe_debug_conv3x3(airfe_ctx* c, const float* x, int B, int cin, int H, int
           y[(((size_t)bb * cout + co) * Ho + yy) * Wo + xx] = back2(yo[(((size_t)bb * (Ho + 2) + yy + 1) * (Wo + 2) + xx + 1) * cout + co], prec);
   (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db);
   return 0;
-}
+} AIRFE_CATCH(c)
 
-int airfe_debug_gemm(airfe_ctx* c, const float* x, int M, int K, const float* w, const float* b, int N, int relu, float* y) {
+int airfe_debug_fail_next_launch(airfe_ctx* c, int stage) try {
+  AIRFE_ENTER(c);
+  if (stage < -1 || stage >= ST_COUNT) return fail(c, "debug_fail_next_launch: no such stage");
+  c->fail_stage = stage;
+  return 0;
+} AIRFE_CATCH(c)
+
+int airfe_debug_gemm(airfe_ctx* c, const float* x, int M, int K, const float* w, const float* b, int N, int relu, float* y) try {
   AIRFE_ENTER(c);
   if (K != 128 && K != 256 && K != 512) return fail(c, "debug_gemm: K must be 128, 256 or 512");
   const int prec = c->prec, Mp = (M + 127) / 128 * 128, Np8 = (N + 7) / 8 * 8;
@@ -1350,6 +1439,6 @@ int airfe_debug_gemm(airfe_ctx* c, const float* x, int M, int K, const float* w,
   }
   for (void* p : tmp.allocs) (void)hipFree(p);
   return rc;
-}
+} AIRFE_CATCH(c)
 
 }  // extern "C"

@@ -17,17 +17,20 @@ int ensure_tables(airfe_ctx* c, int h, int w) {
   return 0;
 }
 
-void run_conv(airfe_ctx* c, const ConvW& w, const uint16_t* x, uint16_t* y, int B, int H, int W, int pool, int out_pad,
-              hipStream_t st) {
+int run_conv(airfe_ctx* c, const ConvW& w, const uint16_t* x, uint16_t* y, int B, int H, int W, int pool, int out_pad,
+             hipStream_t st) {
   ConvArgs a;
   a.X = x; a.Wp = w.w; a.bias = w.b; a.Y = y;
   a.B = B; a.H = H; a.W = W; a.CIN = w.cin; a.COUT = w.cout;
   a.pool = pool; a.out_pad = out_pad; a.relu = 1;
   const double px = (double)B * H * W;
   const double ob = px / (pool ? 4 : 1) * w.cout * 2;
-  ProfScope ps(c, w.cin == 64 ? ST_CONV3X3_C64 : ST_CONV3X3_C128, st, 2.0 * px * w.cin * w.cout * 9,
-               px * w.cin * 2 + ob + 9.0 * w.cin * w.cout * 2);
-  launch_conv3x3(c->prec, a, st);
+  {
+    ProfScope ps(c, w.cin == 64 ? ST_CONV3X3_C64 : ST_CONV3X3_C128, st, 2.0 * px * w.cin * w.cout * 9,
+                 px * w.cin * 2 + ob + 9.0 * w.cin * w.cout * 2);
+    launch_conv3x3(c->prec, a, st);
+  }
+  return c->cfg.check_launches ? launch_status(c) : 0;       // (without the flag: once per pipeline, at its end)
 }
 
 // ---- fp32 correctness path: the SuperPoint-VGG encoder + heads up to the dense logits / descriptor maps (what follows — soft-max,
@@ -64,12 +67,11 @@ int encode_f32(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int str
   }
   launch_softmax_d2s(c->logits, 72, c->heat, B, R / 8, R / 8, st);
   c->desc_normalised = false;
-  HIPCHK(c, hipGetLastError());
-  return 0;
+  return launch_status(c);
 }
 
 // convDb over every cell of the batch -> c->desc [B][64][64][256] fp32, un-normalised
-void dense_desc_head(airfe_ctx* c, int B, hipStream_t st) {
+int dense_desc_head(airfe_ctx* c, int B, hipStream_t st) {
   const int R = AIRFE_INTERNAL_SIZE, cells = B * (R / 8) * (R / 8);
   GemmArgs g;
   g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b;
@@ -79,6 +81,7 @@ void dense_desc_head(airfe_ctx* c, int B, hipStream_t st) {
   // F.normalize of the dense map is applied lazily: sample_desc_kernel normalises just the 4 taps each keypoint reads
   // (same operations, same bits) — a dense pass moved 8 MB/image to serve 400 x 4 cell reads.
   c->desc_normalised = false;
+  return c->cfg.check_launches ? launch_status(c) : 0;
 }
 
 // Detector over ONE batch of B images, or — d_gray1 != nullptr — over the 2 B images of B stereo pairs in one pass (images 0 .. B-1 from
@@ -124,15 +127,15 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
         ProfScope ps(c, ST_CONV1_FUSED, st, 2.0 * px * 9 * 64 + 2.0 * px * 64 * 64 * 9, px * 4 + px / 4 * 128 + 9.0 * 64 * 64 * 2);
         launch_conv64r(c->prec, a, st);
       }
-      run_conv(c, c->c2a, c->a1b, c->a2a, cb, R / 2, R / 2, 0, 1, st);
-      run_conv(c, c->c2b, c->a2a, c->a2b + (size_t)c0 * (R / 4 + 2) * (R / 4 + 2) * 64, cb, R / 2, R / 2, 1, 1, st);
+      if (run_conv(c, c->c2a, c->a1b, c->a2a, cb, R / 2, R / 2, 0, 1, st)) return 1;
+      if (run_conv(c, c->c2b, c->a2a, c->a2b + (size_t)c0 * (R / 4 + 2) * (R / 4 + 2) * 64, cb, R / 2, R / 2, 1, 1, st)) return 1;
     }
-    run_conv(c, c->c3a, c->a2b, c->a3a, B, R / 4, R / 4, 0, 1, st);
-    run_conv(c, c->c3b, c->a3a, c->a3b, B, R / 4, R / 4, 1, 1, st);
-    run_conv(c, c->c4a, c->a3b, c->a4a, B, R / 8, R / 8, 0, 1, st);
-    run_conv(c, c->c4b, c->a4a, c->a4b, B, R / 8, R / 8, 0, 1, st);
-    run_conv(c, c->cPa, c->a4b, c->aPa, B, R / 8, R / 8, 0, 0, st);
-    run_conv(c, c->cDa, c->a4b, c->aDa, B, R / 8, R / 8, 0, 0, st);
+    if (run_conv(c, c->c3a, c->a2b, c->a3a, B, R / 4, R / 4, 0, 1, st)) return 1;
+    if (run_conv(c, c->c3b, c->a3a, c->a3b, B, R / 4, R / 4, 1, 1, st)) return 1;
+    if (run_conv(c, c->c4a, c->a3b, c->a4a, B, R / 8, R / 8, 0, 1, st)) return 1;
+    if (run_conv(c, c->c4b, c->a4a, c->a4b, B, R / 8, R / 8, 0, 1, st)) return 1;
+    if (run_conv(c, c->cPa, c->a4b, c->aPa, B, R / 8, R / 8, 0, 0, st)) return 1;
+    if (run_conv(c, c->cDa, c->a4b, c->aDa, B, R / 8, R / 8, 0, 0, st)) return 1;
     const int cells = B * (R / 8) * (R / 8);
     {
       GemmArgs g;
@@ -149,7 +152,7 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
     // of fp32 written.  The dense map stays for small batches (the batch-1 line path samples junction descriptors from it) and
     // for the inspection hook, which rebuilds it on demand.  Same kernel, same K order: the rows are bit-identical either way.
     sparse_desc = B > 2 && cap * 4 <= (R / 8) * (R / 8) && cap <= 1024;
-    if (!sparse_desc) dense_desc_head(c, B, st);
+    if (!sparse_desc && dense_desc_head(c, B, st)) return 1;
     c->desc_dense_valid = !sparse_desc;
     c->last_B = B;
   }
@@ -199,8 +202,7 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
       launch_sample_desc(c->desc + (size_t)b0 * (R / 8) * (R / 8) * 256, Bh, R / 8, R / 8, half ? d_feat1 : d_feat, half ? d_n1 : d_n, cap,
                          (float)w / (float)R, (float)h / (float)R, c->desc_normalised ? 0 : 1, st);
   }
-  HIPCHK(c, hipGetLastError());
-  return 0;
+  return launch_status(c);
 }
 
 int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat,
@@ -218,7 +220,7 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
   const int NP = KEEP_CAP, F = 128;
   float* d = c->s0_stage;
   // Two forms of the 1x1 head.  FUSED (fp32 mode, inspection hook; one image): all 145 channels at every pixel -> l_head [128*128][160].
-  // SPLIT (everything else): the 17 decoded channels at every pixel, decoded in the same pass (or, AIRFE_FUSE_DEC=0, -> l_dec [nb][128*128][32]
+  // SPLIT (everything else): the 17 decoded channels at every pixel, decoded in the same pass (or, airfe_tuning::fuse_dec = 0, -> l_dec [nb][128*128][32]
   // and a decode pass of its own); the 128 LOI channels — read only at the four
   // bilinear taps of the <= 300 junctions — by a gather GEMM over those <= 1200 rows per image once the junctions are known (line_tail_dev):
   // the fused head wrote 1.07 GB of LOI features per 128 images to read 7 % of them.  Same kernel, same K order: the same bits.
@@ -233,9 +235,8 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
     launch_gemm_f32(g, st);
   } else {
     // conv3a features (zero-bordered NHWC, still in the arena for the whole batch) -> [nb * 128*128][128]
-    run_conv(c, c->cL1, c->a3a + (size_t)i0 * (F + 2) * (F + 2) * 128, c->l_feat, nb, F, F, 0, 0, st);
-    static const bool fuse_dec = !(getenv("AIRFE_FUSE_DEC") && atoi(getenv("AIRFE_FUSE_DEC")) == 0);
-    if (!fused && fuse_dec) {        // the 17-channel head and its decode in one pass over the line features (kernels_s0.hip)
+    if (run_conv(c, c->cL1, c->a3a + (size_t)i0 * (F + 2) * (F + 2) * 128, c->l_feat, nb, F, F, 0, 0, st)) return 1;
+    if (!fused && c->fuse_dec) {        // the 17-channel head and its decode in one pass over the line features (kernels_s0.hip)
       ProfScope ps(c, ST_PL_DECODE, st, 2.0 * nb * F * F * 128 * 17, (double)nb * F * F * (256 + 92));
       launch_s0_head_decode(c->prec, c->l_feat, c->cLh_dec.w, c->cLh_dec.b, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, c->l_ta8, nb, SG_STRIDE,
                             st);
@@ -251,6 +252,7 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
       launch_gemm(c->prec, 128, false, g, st);
     }
   }
+  {
   // head rows read once, 49152 proposals + maps written; the j2l match reads them again
   ProfScope ps(c, ST_PL_DECODE, st, 0, (double)nb * (128.0 * 128 * (17 * 4 + 3 * 16 + 11 * 4) + 3.0 * 49152 * (16 + 12)));
   if (head_done) {
@@ -267,8 +269,8 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
   launch_select_list(c->l_cand, c->l_cand_cnt, ccap, nb, F, 300, 320, c->l_sel, c->l_nsel, s3);
   launch_s0_juncs(c->l_sel, c->l_nsel, c->l_joff, d + SG_JUNCS, 300, 320, nb, SG_STRIDE, s3);
   launch_s0_j2l(d + SG_LP, d + SG_JUNCS, 300, NP, 10.0f, d + SG_KEEP, d + SG_MIN, d + SG_MAX, nb, SG_STRIDE, chw ? 1 : 0, s3);
-  HIPCHK(c, hipGetLastError());
-  return 0;
+  }
+  return launch_status(c);
 }
 
 // Everything behind the stage-0 tensors for stage slots 0 .. nb-1 (= images i0 .. i0+nb-1 of the detector batch): wireframe_matcher,
@@ -324,8 +326,7 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
     launch_sample_desc(c->desc + (size_t)i0 * (R / 8) * (R / 8) * 256, nj, R / 8, R / 8, d_junc, d_njunc, capJ, ws, hs,
                        c->desc_normalised ? 0 : 1, st);
   }
-  HIPCHK(c, hipGetLastError());
-  return 0;
+  return launch_status(c);
 }
 
 }  // namespace airfe_host

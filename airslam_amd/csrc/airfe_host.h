@@ -83,16 +83,20 @@ struct KfGraph {
 struct airfe_ctx {
   airfe_cfg cfg;
   std::string err;
+  std::string launch_err;        // cfg.check_launches: the first failed launch since the last report, with its stage's name (launch_status())
+  int fail_stage = -1;           // airfe_debug_fail_next_launch: the next ProfScope of this stage makes a deliberately invalid launch first (tests)
+  bool fuse_dec = true;          // airfe_tuning::fuse_dec
+  int assign_fused = 1;          // airfe_tuning::assign_fused
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;         // airfe_stereo_plnet_batch_dev: the line branch runs here while the matcher runs on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_feat = nullptr;
-  bool overlap_lines = true;             // line path on stream2 beside the matcher (airfe_stereo_plnet_batch_dev); AIRFE_OVERLAP_LINES=0: one stream
+  bool overlap_lines = true;             // line path on stream2 beside the matcher (airfe_stereo_plnet_batch_dev); airfe_tuning::overlap_lines = 0: one stream
   std::vector<void*> allocs;
   int prec = 0;                  // detector storage type
   int mprec = 1;                 // matcher storage type (cfg.matcher_precision)
   int pack_prec = 0;             // storage type make_linear packs for (set by each load_* before it packs)
   int Bmax = 1, chunk = 1, Np = 64, Pmax = 1;
-  int lgb_tokens = 0;            // AIRFE_LGB_TOKENS: forces the fused block's tokens per workgroup (32 / 64 / 112 / 128)
+  int lgb_tokens = 0;            // airfe_tuning::lgb_tokens: forces the fused block's tokens per workgroup (32 / 64 / 112 / 128)
   // batch-1 host entries: ONE pinned host block and contiguous device blocks, so that a call is one H2D and one D2H (the reference's
   // BufferManager does a cudaMalloc + one synchronous memcpy per binding and call: 3rdparty/tensorrtbuffer/include/buffers.h:237-417)
   uint8_t* pin = nullptr;        // hipHostMalloc'ed
@@ -104,23 +108,24 @@ struct airfe_ctx {
   bool has_sp = false, has_lg = false;
   uint8_t* pl_stage = nullptr;   // staging of airfe_assign_points_to_lines / airfe_match_lines
   size_t pl_bytes = 0;
-  uint8_t* pl_scratch = nullptr; // scratch of their *_batch_dev forms (counts, bit rows, vote matrices)
-  size_t pl_scratch_bytes = 0;
+  uint8_t *pl_scratch = nullptr, *ml_scratch = nullptr;   // scratch of airfe_assign_points_to_lines_batch_dev (counts) / airfe_match_lines_batch_dev (bit rows, row maxima): one each
+  size_t pl_scratch_bytes = 0, ml_scratch_bytes = 0;
+  hipStream_t pl_scratch_stream = nullptr, ml_scratch_stream = nullptr;   // the stream each was last used on (synchronised before the block is replaced)
   bool nms_map_valid = true;     // heat_nms holds the last batch's NMS'd maps (large batches skip writing them)
   bool force_nms_map = false;    // the batched PLNet path reads junction scores from them: written at every batch size while set
   int Lmax = 1;                  // images the line-path arena holds (= Dmax)
   bool desc_normalised = false;  // dense descriptor map currently holds F.normalize'd rows (only after the inspection hook)
-  int gemm_small_max = 4096, gemm8_min = 16000, gemmr_min = 8192, gemmr_wgs = 256;   // GemmArgs::small_max / g8_min / gr_min / gr_wgs (AIRFE_SMALL_MAX_M, AIRFE_GEMM8_MIN_M, AIRFE_GEMMR_MIN_M, AIRFE_GEMMR_WGS)
-  int block_min = 0;             // tokens from which the fused LightGlue block is used (AIRFE_BLOCK_MIN_M).  Round 4: with 32- / 64-token passes for small
+  int gemm_small_max = 4096, gemm8_min = 16000, gemmr_min = 8192, gemmr_wgs = 256;   // GemmArgs::small_max / g8_min / gr_min / gr_wgs (airfe_tuning::gemm_small_max_m, gemm8_min_m, gemmr_min_m, gemmr_wgs)
+  int block_min = 0;             // tokens from which the fused LightGlue block is used (airfe_tuning::block_min_m).  Round 4: with 32- / 64-token passes for small
                                  // token counts the fused kernel wins at EVERY size (profiles/r04_lg_small_batch_sweep.txt: 1 pair 0.70 vs 0.78 ms, 4 pairs 0.75 vs 1.20);
                                  // with 112- / 128-token passes only (rounds 1-3) the four separate launches were quicker below 3200 tokens
-  bool qkv_pair = true;          // q|k and v of a layer in one streaming launch (AIRFE_QKV_PAIR=0: two launches)
-  int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, AIRFE_FUSE_LG_BLOCK=0/1 forces
-  int sg_kenc_gemm = -1;         // AIRFE_SG_KENC_GEMM=0/1: SuperGlue keypoint encoder's large layers as scalar loops / GEMMs (default: by token count)
+  bool qkv_pair = true;          // q|k and v of a layer in one streaming launch (airfe_tuning::qkv_pair = 0: two launches)
+  int fuse_lg_block = -1;        // LightGlue out-proj + FFN + residual as one kernel: -1 by token count, airfe_tuning::fuse_lg_block = 0 / 1 forces
+  int sg_kenc_gemm = -1;         // airfe_tuning::sg_kenc_gemm = 0 / 1: SuperGlue keypoint encoder's large layers as scalar loops / GEMMs (default: by token count)
   bool desc_dense_valid = true;  // c->desc holds the dense map of the last batch (else: the gather GEMM's rows)
   int last_B = 0;
   int* desc_idx = nullptr;       // row list of the descriptor head's gather GEMM
-  bool fold_qkv = true;          // AIRFE_FOLD_QKV=0: q | k | v projections as launches of their own (A/B runs)
+  bool fold_qkv = true;          // airfe_tuning::fold_qkv = 0: q | k | v projections as launches of their own (A/B runs)
 
   // detector weights
   float *c1a_w = nullptr, *c1a_b = nullptr;
@@ -153,8 +158,8 @@ struct airfe_ctx {
   uint8_t* kf_blk = nullptr; size_t kf_bytes = 0;   // airfe_stereo_keyframe's device block (grows on demand)
   uint8_t *tk_blk = nullptr, *ref_blk = nullptr; size_t tk_bytes = 0, ref_bytes = 0;   // airfe_track_frame: outputs; the last keyframe's features
   int ref_n = -1;
-  int kf_spec_lines = 1024, kf_spec_juncs = 512;   // line / junction rows airfe_stereo_keyframe copies back before it knows the counts (AIRFE_KF_SPEC_ROWS)
-  bool kf_graph_on = false;                         // AIRFE_KF_GRAPH
+  int kf_spec_lines = 1024, kf_spec_juncs = 512;   // line / junction rows airfe_stereo_keyframe copies back before it knows the counts (airfe_tuning::kf_spec_rows)
+  bool kf_graph_on = false;                         // airfe_tuning::kf_graph
   KfGraph kf_graph;
   float *st_feat0 = nullptr, *st_feat1 = nullptr, *st_score = nullptr;
   int *st_n0 = nullptr, *st_n1 = nullptr, *st_nm = nullptr;
@@ -247,9 +252,12 @@ static const char* kStageNames[ST_COUNT] = {
   "preprocess", "conv1_fused", "conv3x3_cin64", "conv3x3_cin128", "head_gemm", "head_eltwise", "simple_nms", "select_topk",
   "sample_desc", "lg_prepare", "lg_gemm", "lg_attention", "lg_ln_gelu", "lg_assign", "plnet_s0_decode", "plnet_stage1", "plnet_filter", "line_assoc", "rectify", "bow"};
 
+void note_launch(airfe_ctx* c, int stage);      // airfe.hip
+void fail_launch_now(hipStream_t st);            // airfe.hip: a deliberately invalid launch (airfe_debug_fail_next_launch)
 struct ProfScope {
-  airfe_ctx* c; hipStream_t st; bool on; airfe_ctx::Mark m;
-  ProfScope(airfe_ctx* c_, int stage, hipStream_t st_, double flops, double bytes) : c(c_), st(st_), on((c_->prof_mask >> stage) & 1u) {
+  airfe_ctx* c; hipStream_t st; bool on; int stage; airfe_ctx::Mark m;
+  ProfScope(airfe_ctx* c_, int stage_, hipStream_t st_, double flops, double bytes) : c(c_), st(st_), on((c_->prof_mask >> stage_) & 1u), stage(stage_) {
+    if (c->fail_stage == stage) { c->fail_stage = -1; fail_launch_now(st); }
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;
@@ -261,9 +269,10 @@ struct ProfScope {
     (void)hipEventRecord(m.a, st);
   }
   ~ProfScope() {
+    if (c->cfg.check_launches) note_launch(c, stage);      // the launches of this stage: reported by launch_status() with the stage's name
     if (!on) return;
     (void)hipEventRecord(m.b, st);
-    c->marks.push_back(m);
+    try { c->marks.push_back(m); } catch (...) { c->ev_pool.clear(); }      // (a destructor must not throw; the events leak rather than the process die)
   }
 };
 
@@ -280,6 +289,10 @@ namespace airfe_host {
   } while (0)
 
 int fail(airfe_ctx* c, const std::string& m);
+int fail_noexcept(airfe_ctx* c, const char* what, const char* detail) noexcept;   // for the catch blocks at the C boundary
+// 0 when no launch failed since the last report; else the context's error = "<stage>: kernel launch failed: <hip error>" and 1.  With
+// cfg.check_launches every stage's launches are looked at as the stage ends (ProfScope); without it this is one hipGetLastError().
+int launch_status(airfe_ctx* c);
 
 template <class T>
 T* dalloc(airfe_ctx* c, size_t n, bool zero = true) {
@@ -318,8 +331,8 @@ bool make_linear(airfe_ctx* c, const float* W, const float* bias, int K, int N, 
                  const std::function<int(int)>* src_row = nullptr, const std::function<int(int)>* src_col = nullptr);
 // ---- airfe_detect.hip
 int ensure_tables(airfe_ctx* c, int h, int w);
-void run_conv(airfe_ctx* c, const ConvW& w, const uint16_t* x, uint16_t* y, int B, int H, int W, int pool, int out_pad, int relu, hipStream_t st);
-void dense_desc_head(airfe_ctx* c, int B, hipStream_t st);
+int run_conv(airfe_ctx* c, const ConvW& w, const uint16_t* x, uint16_t* y, int B, int H, int W, int pool, int out_pad, hipStream_t st);
+int dense_desc_head(airfe_ctx* c, int B, hipStream_t st);
 int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int Bs, int h, int w, int stride, size_t img_stride,
                 float* d_feat, float* d_feat1, int cap, int* d_n, int* d_n1, hipStream_t st);
 int detect_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat, int cap, int* d_n, hipStream_t st);
@@ -329,7 +342,7 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
 // ---- airfe_match.hip
 void trace(airfe_ctx* c, hipStream_t st, const char* what, size_t li, const char* blk, const void* p, size_t words, unsigned unit_words);
 int trace_finish(airfe_ctx* c, hipStream_t st);
-void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1, const uint16_t* x2, int ld2, int M, int epi, int act, void* out,
+int run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1, const uint16_t* x2, int ld2, int M, int epi, int act, void* out,
                 int ldo, hipStream_t st, bool trans = false, void* out2 = nullptr, float* x32 = nullptr, const float* rc = nullptr, const float* rs = nullptr);
 void reset_slack_rows(airfe_ctx* c, int M, hipStream_t st);
 struct LgSecondPair { const float *f0, *f1; const int *n0, *n1; };      // a second pair for a B = 1 call (same ld / kp_off / normalize): outputs of pair 1 follow pair 0's

@@ -51,8 +51,7 @@ int lightglue_dev_f32(airfe_ctx* c, const float* f0, const int* n0, const float*
   }
   launch_lg_assign(c->simbuf, c->zbuf, c->lens, B, Np, mcap, 0.1f, c->rowlse, c->collse, scores_out, c->rowarg, c->rowval, c->colarg, d_idx,
                    d_score, d_nmatch, st);
-  HIPCHK(c, hipGetLastError());
-  return 0;
+  return launch_status(c);
 }
 
 // airfe_debug_trace: checksum `words` 32-bit words of p in units of unit_words (slot = one call; no-op unless tracing)
@@ -78,22 +77,25 @@ int trace_finish(airfe_ctx* c, hipStream_t st) {
     HIPCHK(c, hipMemcpyAsync(c->trace_off, c->trace_off_h.data(), c->trace_off_h.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
     launch_trace_digest(c->trace_tab, c->trace_off, (int)c->trace_slots.size(), c->trace_dig, st);
   }
-  HIPCHK(c, hipGetLastError());
-  return 0;
+  return launch_status(c);
 }
 #define TRACE_HALT do { if (c->trace_halt) return trace_finish(c, st); } while (0)
 
-void run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1, const uint16_t* x2, int ld2, int M,
-                int epi, int act, void* out, int ldo, hipStream_t st, bool trans, void* out2,
-                float* x32, const float* rc, const float* rs) {
+// (the matrix launches below return the launch status of their stage under cfg.check_launches, 0 otherwise: lightglue_dev / superglue_dev look once more at their end)
+#define STAGE_RC(c) ((c)->cfg.check_launches ? launch_status(c) : 0)
+#define RUN(x) do { if (x) return 1; } while (0)
+
+int run_linear(airfe_ctx* c, const LinW& w, const uint16_t* x1, int ld1, int K1, const uint16_t* x2, int ld2, int M,
+               int epi, int act, void* out, int ldo, hipStream_t st, bool trans, void* out2,
+               float* x32, const float* rc, const float* rs) {
   GemmArgs g;
   g.X1 = x1; g.ld1 = ld1; g.K1 = K1; g.X2 = x2; g.ld2 = ld2;
   g.Wp = w.w; g.bias = w.b; g.M = M; g.N = w.N; g.cb_total = w.cbt;
   g.epi = epi; g.act = act; g.out = out; g.out2 = out2; g.ldo = ldo; g.x32 = x32;
   g.rot_cos = rc; g.rot_sin = rs; g.Np = c->Np; g.H = 4;
   g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-  ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * w.K * w.N, (double)M * (w.K + w.N) * 2 + (double)w.K * w.N * 2);
-  launch_gemm(c->mprec, w.K, trans, g, st);
+  { ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * w.K * w.N, (double)M * (w.K + w.N) * 2 + (double)w.K * w.N * 2); launch_gemm(c->mprec, w.K, trans, g, st); }
+  return STAGE_RC(c);
 }
 
 void run_attention(airfe_ctx* c, int prec, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, const int* lens, int S,
@@ -107,7 +109,7 @@ void run_attention(airfe_ctx* c, int prec, const uint16_t* Q, const uint16_t* K,
 // The attention inputs of one layer: head-major q|k (`qk`, rotary when rc != nullptr; q -> qout, k -> kout, or both roles in qout
 // for the cross block's shared projection) and transposed V (`v`).  One streaming launch where kernels_gemmr.hip applies (large
 // token counts), else the two linears separately — same arithmetic either way.
-void run_qkv(airfe_ctx* c, const LinW& qk, const LinW& v, int M, void* qout, void* kout, const float* rc, const float* rs, hipStream_t st) {
+int run_qkv(airfe_ctx* c, const LinW& qk, const LinW& v, int M, void* qout, void* kout, const float* rc, const float* rs, hipStream_t st) {
   GemmArgs a, b;
   a.X1 = c->xb; a.ld1 = 256; a.K1 = 256; a.Wp = qk.w; a.bias = qk.b; a.M = M; a.N = qk.N; a.cb_total = qk.cbt;
   a.epi = EPI_HEADS; a.out = qout; a.out2 = kout; a.rot_cos = rc; a.rot_sin = rs; a.Np = c->Np; a.H = 4;
@@ -115,16 +117,15 @@ void run_qkv(airfe_ctx* c, const LinW& qk, const LinW& v, int M, void* qout, voi
   b.epi = EPI_HEADS_T; b.out = c->vtb; b.Np = c->Np; b.H = 4;
   a.gr_wgs = b.gr_wgs = c->gemmr_wgs;
   if (c->qkv_pair && M >= c->gemmr_min && qk.K == 256 && v.K == 256 && gemmr_pair_applicable(a, b)) {
-    ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * 256.0 * (qk.N + v.N), (double)M * (256 + qk.N + v.N) * 2 + 256.0 * (qk.N + v.N) * 2);
-    launch_gemmr_pair(c->mprec, a, b, st);
-    return;
+    { ProfScope ps(c, ST_LG_GEMM, st, 2.0 * M * 256.0 * (qk.N + v.N), (double)M * (256 + qk.N + v.N) * 2 + 256.0 * (qk.N + v.N) * 2); launch_gemmr_pair(c->mprec, a, b, st); }
+    return STAGE_RC(c);
   }
-  run_linear(c, qk, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS, ACT_NONE, qout, 0, st, false, kout, nullptr, rc, rs);
-  run_linear(c, v, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
+  RUN(run_linear(c, qk, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS, ACT_NONE, qout, 0, st, false, kout, nullptr, rc, rs));
+  return run_linear(c, v, c->xb, 256, 256, nullptr, 0, M, EPI_HEADS_T, ACT_NONE, c->vtb, 0, st, true);
 }
 
 // out-proj + FFN + residual of one block as ONE kernel (kernels_lgblockf.hip); flops/bytes are the algorithmic ones
-void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st, int relu = 0,
+int lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st, int relu = 0,
                const LinW* nqk = nullptr, const LinW* nv = nullptr, bool rotary = false) {
   LgBlockFArgs a;
   a.relu = relu;
@@ -136,7 +137,7 @@ void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, co
   // spread the same rows over 4x / 2x as many workgroups as long as that is still ONE round
   if (M <= 256 * 32) a.tokens_per_wg = 32;
   else if (M <= 256 * 64) a.tokens_per_wg = 64;
-  if (c->lgb_tokens > 0) a.tokens_per_wg = c->lgb_tokens;          // AIRFE_LGB_TOKENS (measurement switch)
+  if (c->lgb_tokens > 0) a.tokens_per_wg = c->lgb_tokens;          // airfe_tuning::lgb_tokens (measurement switch)
   double fl = 2.0 * M * (256.0 * 256 + 512.0 * 512 + 512.0 * 256), by = (double)M * (512 + 512 + 1024 + 512 + 1024) + 917504.0;
   if (nqk && nv) {            // the next attention layer's projections ride along (kernels_lgblockf.hip, FOLD)
     a.nqk_w = nqk->w; a.nqk_b = nqk->b; a.nqk_n = nqk->N; a.nv_w = nv->w; a.nv_b = nv->b;
@@ -145,14 +146,14 @@ void lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, co
     fl += 2.0 * M * 256.0 * (nqk->N + nv->N);
     by += (double)M * (nqk->N + nv->N) * 2 + 256.0 * (nqk->N + nv->N) * 2;
   }
-  ProfScope ps(c, ST_LG_GEMM, st, fl, by);
-  launch_lg_blockf(c->mprec, a, st);
+  { ProfScope ps(c, ST_LG_GEMM, st, fl, by); launch_lg_blockf(c->mprec, a, st); }
+  return STAGE_RC(c);
 }
 
-void lg_ffn(airfe_ctx* c, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st) {
-  run_linear(c, f0, c->xb, 256, 256, c->msg, 256, M, EPI_STORE, ACT_NONE, c->hb, 512, st);
+int lg_ffn(airfe_ctx* c, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st) {
+  RUN(run_linear(c, f0, c->xb, 256, 256, c->msg, 256, M, EPI_STORE, ACT_NONE, c->hb, 512, st));
   { ProfScope ps(c, ST_LG_LNGELU, st, 0, (double)M * 2048); launch_ln_gelu(c->mprec, c->hb, g, b, M, st); }
-  run_linear(c, f3, c->hb, 512, 512, nullptr, 0, M, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
+  return run_linear(c, f3, c->hb, 512, 512, nullptr, 0, M, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
 }
 
 // The surplus rows behind the last real token (alloc_matcher_arena's slack) go through every block like real ones: their residual
@@ -171,10 +172,11 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   if (!c->has_lg) return fail(c, "LightGlue weights were not loaded (cfg.lightglue_pack)");
   if (B < 1 || B > c->Pmax) return fail(c, "pair batch exceeds cfg.max_batch / 2");
   if (cap > c->Np) return fail(c, "feature capacity exceeds the matcher arena (max_keypoints)");
+  // (the second pair was looked at only behind the fp32 dispatch, which dropped it silently)
+  if (x2 && (B != 1 || c->Pmax < 2 || c->mprec == 2)) return fail(c, "lightglue: a second pair needs B = 1, max_batch >= 2 and fp16 / bf16 (matcher_precision)");
   if (c->mprec == 2) return lightglue_dev_f32(c, f0, n0, f1, n1, B, cap, ld, kp_off, normalize, d_idx, d_score, mcap, d_nmatch, scores_out, st);
   LgPrepArgs pa;
   if (x2) {                                      // the stereo and the temporal pair of one keyframe as a batch of two
-    if (B != 1 || c->Pmax < 2 || c->mprec == 2) return fail(c, "lightglue: a second pair needs B = 1, max_batch >= 2 and fp16 / bf16");
     pa.f0x = x2->f0; pa.f1x = x2->f1; pa.n0x = x2->n0; pa.n1x = x2->n1;
     B = 2;
   }
@@ -223,71 +225,79 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
     const LgLayer& l = c->lg[li];
     const LgLayer* nl = li + 1 < c->lg.size() ? &c->lg[li + 1] : nullptr;
     // ---- self block
-    if (!fold_s || li == 0) { run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, c->rot_cos, c->rot_sin, st); tr_qkv(li, "self.qkv", true); }
+    if (!fold_s || li == 0) { RUN(run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, c->rot_cos, c->rot_sin, st)); tr_qkv(li, "self.qkv", true); }
     TRACE_HALT;
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); run_attention(c, c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, 0, 0.125f, st); }
+    RUN(STAGE_RC(c));
     trace(c, st, "o", li, "self.attn", c->ob, Mw, 2048);
     TRACE_HALT;
     if (fused_block) {
-      lg_blockf(c, l.out, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st, 0, fold_c ? &l.cqk : nullptr, fold_c ? &l.cv : nullptr, false);
+      RUN(lg_blockf(c, l.out, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st, 0, fold_c ? &l.cqk : nullptr, fold_c ? &l.cv : nullptr, false));
       tr_x(li, "self.block");
       TRACE_HALT;
       if (fold_c) tr_qkv(li, "self.block", false);
       TRACE_HALT;
     } else {
-      run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
+      RUN(run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st));
       trace(c, st, "msg", li, "self.out", c->msg, Mw, 2048);
       TRACE_HALT;
-      lg_ffn(c, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st);
+      RUN(lg_ffn(c, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st));
       tr_x(li, "self.ffn");
       TRACE_HALT;
     }
     // ---- cross block (one shared projection for q and k; the two sides swap roles)
-    if (!fold_c) { run_qkv(c, l.cqk, l.cv, Mg, c->qb, nullptr, nullptr, nullptr, st); tr_qkv(li, "cross.qkv", false); }
+    if (!fold_c) { RUN(run_qkv(c, l.cqk, l.cv, Mg, c->qb, nullptr, nullptr, nullptr, st)); tr_qkv(li, "cross.qkv", false); }
     TRACE_HALT;
     { ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048); run_attention(c, c->mprec, c->qb, c->qb, c->vtb, c->ob, c->lens, S, 4, Np, 1, 0.125f, st); }
+    RUN(STAGE_RC(c));
     trace(c, st, "o", li, "cross.attn", c->ob, Mw, 2048);
     TRACE_HALT;
     if (fused_block) {
       const bool fn = fold_s && nl;
-      lg_blockf(c, l.cout, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st, 0, fn ? &nl->qk : nullptr, fn ? &nl->v : nullptr, true);
+      RUN(lg_blockf(c, l.cout, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st, 0, fn ? &nl->qk : nullptr, fn ? &nl->v : nullptr, true));
       tr_x(li, "cross.block");
       TRACE_HALT;
       if (fn) tr_qkv(li, "cross.block", true);
       TRACE_HALT;
     } else {
-      run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
+      RUN(run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st));
       trace(c, st, "msg", li, "cross.out", c->msg, Mw, 2048);
       TRACE_HALT;
-      lg_ffn(c, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st);
+      RUN(lg_ffn(c, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st));
       tr_x(li, "cross.ffn");
       TRACE_HALT;
     }
   }
   const size_t LF = c->lg.size();
-  run_linear(c, c->lg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
+  RUN(run_linear(c, c->lg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st));
   trace(c, st, "md", LF, "final", c->mdb, Mw, 2048);
   if (slack_words) trace(c, st, "x32slack", LF, "final", c->x32 + (size_t)M * 256, slack_words, 4096);
   TRACE_HALT;
-  ProfScope ps(c, ST_LG_ASSIGN, st, 2.0 * B * Np * (double)Np * 256, (double)B * Np * Np * 4 * 6);
-  launch_rowdot256(c->x32, c->lg_mw, c->lg_mb, c->zbuf, M, st);
-  trace(c, st, "z", LF, "final", c->zbuf, (size_t)M, 16);
-  TRACE_HALT;
-  launch_sim(c->mprec, c->mdb, c->simbuf, B, Np, st);
-  trace(c, st, "sim", LF, "final", c->simbuf, (size_t)B * Np * Np, 16u * (unsigned)Np);
-  TRACE_HALT;
-  launch_lg_assign(c->simbuf, c->zbuf, c->lens, B, Np, mcap, 0.1f, c->rowlse, c->collse, scores_out, c->rowarg, c->rowval,
-                   c->colarg, d_idx, d_score, d_nmatch, st);
-  trace(c, st, "rowlse", LF, "assign", c->rowlse, (size_t)B * Np, (unsigned)Np);
-  TRACE_HALT;
-  trace(c, st, "collse", LF, "assign", c->collse, (size_t)B * Np, (unsigned)Np);
-  TRACE_HALT;
-  trace(c, st, "rowval", LF, "assign", c->rowval, (size_t)B * Np, (unsigned)Np);
-  TRACE_HALT;
-  trace(c, st, "rowarg", LF, "assign", c->rowarg, (size_t)B * Np, (unsigned)Np);
-  TRACE_HALT;
-  trace(c, st, "colarg", LF, "assign", c->colarg, (size_t)B * Np, (unsigned)Np);
-  TRACE_HALT;
+  // the assignment tail in a scope of its own: its stage's launch status is noted before trace_finish looks at it
+  const int tail = [&]() -> int {
+    ProfScope ps(c, ST_LG_ASSIGN, st, 2.0 * B * Np * (double)Np * 256, (double)B * Np * Np * 4 * 6);
+#define TAIL_HALT do { if (c->trace_halt) return 2; } while (0)
+    launch_rowdot256(c->x32, c->lg_mw, c->lg_mb, c->zbuf, M, st);
+    trace(c, st, "z", LF, "final", c->zbuf, (size_t)M, 16);
+    TAIL_HALT;
+    launch_sim(c->mprec, c->mdb, c->simbuf, B, Np, st);
+    trace(c, st, "sim", LF, "final", c->simbuf, (size_t)B * Np * Np, 16u * (unsigned)Np);
+    TAIL_HALT;
+    launch_lg_assign(c->simbuf, c->zbuf, c->lens, B, Np, mcap, 0.1f, c->rowlse, c->collse, scores_out, c->rowarg, c->rowval,
+                     c->colarg, d_idx, d_score, d_nmatch, st);
+    trace(c, st, "rowlse", LF, "assign", c->rowlse, (size_t)B * Np, (unsigned)Np);
+    TAIL_HALT;
+    trace(c, st, "collse", LF, "assign", c->collse, (size_t)B * Np, (unsigned)Np);
+    TAIL_HALT;
+    trace(c, st, "rowval", LF, "assign", c->rowval, (size_t)B * Np, (unsigned)Np);
+    TAIL_HALT;
+    trace(c, st, "rowarg", LF, "assign", c->rowarg, (size_t)B * Np, (unsigned)Np);
+    TAIL_HALT;
+    trace(c, st, "colarg", LF, "assign", c->colarg, (size_t)B * Np, (unsigned)Np);
+    return 0;
+#undef TAIL_HALT
+  }();
+  (void)tail;
   return trace_finish(c, st);
 }
 
@@ -311,34 +321,33 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
       HIPCHK(c, hipMemsetAsync(c->msg + (size_t)M * 128, 0, (size_t)(Mg - M) * 128 * 2, st));
       HIPCHK(c, hipMemsetAsync(c->x32 + (size_t)M * 256, 0, (size_t)(Mg - M) * 256 * 4, st));
     }
-    run_linear(c, c->sg_k3, c->msg, 128, 128, nullptr, 0, Mg, EPI_STORE, ACT_RELU, c->hb, 256, st);
-    run_linear(c, c->sg_k4, c->hb, 256, 256, nullptr, 0, Mg, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
+    RUN(run_linear(c, c->sg_k3, c->msg, 128, 128, nullptr, 0, Mg, EPI_STORE, ACT_RELU, c->hb, 256, st));
+    RUN(run_linear(c, c->sg_k4, c->hb, 256, 256, nullptr, 0, Mg, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32));
   }
   const bool fused_block = c->fuse_lg_block == 1 || (c->fuse_lg_block < 0 && Mg >= c->block_min);
   int li = 0;
   for (const SgLayer& l : c->sg) {
     const int cross = li & 1;      // names = ['self','cross'] * 9
     ++li;
-    run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, nullptr, nullptr, st);
+    RUN(run_qkv(c, l.qk, l.v, Mg, c->qb, c->kb, nullptr, nullptr, st));
     {
       ProfScope ps(c, ST_LG_ATTENTION, st, 4.0 * S * Np * (double)Np * 256, (double)M * 2048);
       run_attention(c, c->mprec, c->qb, c->kb, c->vtb, c->ob, c->lens, S, 4, Np, cross, 0.125f, st);
     }
     if (fused_block) {          // merge + mlp.0 + ReLU + mlp.3 + residual as ONE kernel (the LightGlue block kernel with ReLU for LN + GELU)
-      lg_blockf(c, l.merge, l.mlp0, nullptr, nullptr, l.mlp3, Mg, st, 1);
+      RUN(lg_blockf(c, l.merge, l.mlp0, nullptr, nullptr, l.mlp3, Mg, st, 1));
       continue;
     }
-    run_linear(c, l.merge, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st);
-    run_linear(c, l.mlp0, c->xb, 256, 256, c->msg, 256, Mg, EPI_STORE, ACT_RELU, c->hb, 512, st);
-    run_linear(c, l.mlp3, c->hb, 512, 512, nullptr, 0, Mg, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
+    RUN(run_linear(c, l.merge, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st));
+    RUN(run_linear(c, l.mlp0, c->xb, 256, 256, c->msg, 256, Mg, EPI_STORE, ACT_RELU, c->hb, 512, st));
+    RUN(run_linear(c, l.mlp3, c->hb, 512, 512, nullptr, 0, Mg, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32));
   }
-  run_linear(c, c->sg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st);
+  RUN(run_linear(c, c->sg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st));
   launch_sim(c->mprec, c->mdb, c->simbuf, B, Np, st);
   launch_sg_sinkhorn(c->simbuf, c->lens, B, Np, c->Lz, c->sg_alpha, c->cfg.sinkhorn_iters, c->sg_u, c->sg_v, c->sg_Z, c->sg_cnt, c->sg_cnt + (size_t)c->Pmax * 16, c->sg_xch, st);
   launch_sg_decode(c->sg_Z, c->lens, B, Np, c->Lz, 0.2f, c->sg_idx0, c->sg_max0, c->sg_idx1, c->sg_out0, c->sg_out1, c->sg_ms0,
                    c->sg_ms1, st);
-  HIPCHK(c, hipGetLastError());
-  return 0;
+  return launch_status(c);
 }
 
 

@@ -294,7 +294,7 @@ struct MlArgs {
   double min_x_diff = 0, max_x_diff = 0, max_y_diff = 0;
   const float *feat0 = nullptr, *feat1 = nullptr;
   unsigned *bits0 = nullptr, *bits1 = nullptr;      // scratch [B][capL][W]
-  int *vote = nullptr, *row_loc = nullptr;          // scratch [B][capL][capL], [B][capL]
+  int* row_loc = nullptr;                           // scratch [B][capL]
   int* line_matches = nullptr;        // [B][capL]
 };
 void launch_match_lines(const MlArgs& a, int B, hipStream_t st);

@@ -1390,7 +1390,8 @@ __global__ __launch_bounds__(256) void ml_bits_kernel(MlArgs a, int side) {
   // one WAVE per line (4 lines per workgroup), a lane per 32-match word; lines dealt out with the grid's stride
   for (int l = blockIdx.x * 4 + (threadIdx.x >> 6); l < L; l += gridDim.x * 4) {
   unsigned* bits = (side ? a.bits1 : a.bits0) + ((size_t)b * a.capL + l) * a.W;
-  const int rb = row_ptr[l], re = row_ptr[l + 1];
+  // (clamped to the relation's capacity: after an overflowed AssignPointsToLines — d_total > capE — row_ptr runs past the entries that were written)
+  const int rb = min(row_ptr[l], a.capE), re = min(row_ptr[l + 1], a.capE);
   for (int w = threadIdx.x & 63; w < a.W; w += 64) {
     unsigned word = 0;
     for (int k = 0; k < 32; ++k) {
@@ -1432,7 +1433,6 @@ __global__ __launch_bounds__(256) void ml_vote_rowmax_kernel(MlArgs a) {
   __shared__ int sv[256], si[256];
   const int b = blockIdx.y;
   const int L0 = min(a.nlines0[b], a.capL), L1 = min(a.nlines1[b], a.capL);
-  int* vote = a.vote + (size_t)b * a.capL * a.capL;
   for (int l0 = blockIdx.x; l0 < L0; l0 += gridDim.x) {          // (L0 is workgroup-uniform: every thread takes the same trips, barriers are safe)
     const unsigned* r0 = a.bits0 + ((size_t)b * a.capL + l0) * a.W;
     int bv = -1, bi = 0x7fffffff;
@@ -1440,7 +1440,6 @@ __global__ __launch_bounds__(256) void ml_vote_rowmax_kernel(MlArgs a) {
       const unsigned* r1 = a.bits1 + ((size_t)b * a.capL + l1) * a.W;
       int v = 0;
       for (int w = 0; w < a.W; ++w) v += __popc(r0[w] & r1[w]);
-      vote[(size_t)l0 * a.capL + l1] = v;
       if (v > bv) { bv = v; bi = l1; }                           // l1 ascends within a thread: strict > keeps the first
     }
     ml_first_max(bv, bi, sv, si);
@@ -1453,13 +1452,17 @@ __global__ __launch_bounds__(256) void ml_colmax_kernel(MlArgs a) {
   const int b = blockIdx.y;
   const int L0 = min(a.nlines0[b], a.capL), L1 = min(a.nlines1[b], a.capL);
   if (L0 == 0 || a.npts0[b] == 0 || a.npts1[b] == 0) return;                      // src/line_processor.cc:132
-  const int* vote = a.vote + (size_t)b * a.capL * a.capL;
   const int* row_ptr0 = a.row_ptr0 + (size_t)b * (a.capL + 1);
   const int* row_ptr1 = a.row_ptr1 + (size_t)b * (a.capL + 1);
   for (int j = blockIdx.x; j < L1; j += gridDim.x) {
     int bv = -1, bi = 0x7fffffff;
+    // (the votes of column j again from the bit rows — W words per entry — instead of a [capL][capL] matrix per frame: that matrix was 256 MB of scratch
+    // at 64 frames x 1024 line slots and grew with capL^2)
+    const unsigned* r1 = a.bits1 + ((size_t)b * a.capL + j) * a.W;
     for (int i = threadIdx.x; i < L0; i += blockDim.x) {
-      const int v = vote[(size_t)i * a.capL + j];
+      const unsigned* r0 = a.bits0 + ((size_t)b * a.capL + i) * a.W;
+      int v = 0;
+      for (int w = 0; w < a.W; ++w) v += __popc(r0[w] & r1[w]);
       if (v > bv) { bv = v; bi = i; }
     }
     ml_first_max(bv, bi, sv, si);

@@ -4,7 +4,8 @@
  * replaces (paths under the AirSLAM checkout).  Plain pointers and sizes only; no C++/torch types.
  *
  * Conventions
- *   - return value: 0 = ok, non-zero = failure (airfe_last_error() gives the text); never throws.
+ *   - return value: 0 = ok, non-zero = failure (airfe_last_error() gives the text); never throws: every entry point catches C++ exceptions
+ *     (allocation failures of its host-side bookkeeping included) at the boundary and reports them as a failure.
  *   - one ctx = one HIP stream = one calling thread (the reference wrappers are not re-entrant either:
  *     include/plnet.h:38-63, include/light_glue.h:39-47).
  *   - feature rows are 259 contiguous floats [score, x, y, d0..d255]: byte-identical to one COLUMN of the
@@ -27,6 +28,27 @@ extern "C" {
 #define AIRFE_INTERNAL_SIZE 512 /* reference resizes every image to 512x512: src/plnet.cpp:17-18,258 */
 
 typedef struct airfe_ctx airfe_ctx;
+
+/* Every field: -1 = the library's default / automatic choice.  None of these changes a result beyond what the tests state (most forms are bit-identical). */
+typedef struct airfe_tuning {
+  int fuse_lg_block;     /* LightGlue / SuperGlue out-projection + FFN + residual as one kernel: 0 / 1 force, -1 by token count */
+  int gemm_small_max_m;  /* rows up to which the no-LDS GEMM is used */
+  int gemm8_min_m;       /* rows from which the 8-wave tiled GEMM is used */
+  int gemmr_min_m;       /* rows from which the streaming (DMA ring) q|k|v projection is used */
+  int gemmr_wgs;         /* its persistent workgroups (tests lower it so that a small batch wraps the ring) */
+  int qkv_pair;          /* q|k and v of a layer in one streaming launch (1) or two (0) */
+  int block_min_m;       /* tokens from which the fused block is used when fuse_lg_block = -1 */
+  int lgb_tokens;        /* tokens per workgroup of the fused block: 32 / 64 / 112 / 128 */
+  int sg_kenc_gemm;      /* SuperGlue keypoint encoder's large layers as GEMMs (1) or scalar loops (0) */
+  int fold_qkv;          /* the next attention layer's projections inside the fused block (1) or as launches of their own (0) */
+  int overlap_lines;     /* PLNet line path on a second stream beside the matcher (1) or behind it (0) */
+  int kf_graph;          /* airfe_stereo_keyframe replays a captured hipGraph (1); default 0 (measured: <= 1 %) */
+  int kf_spec_rows;      /* line / junction rows airfe_stereo_keyframe copies back before it knows the counts */
+  int fuse_dec;          /* PLNet stage-0: 17-channel head + decode in one pass (1) or two (0) */
+  int assign_fused;      /* LightGlue assignment: log-sum-exp / arg-max partials taken in the similarity tiles (1; no similarity matrix in HBM)
+                            or the round-2 form: similarity matrix + four passes over it (0) */
+  int reserved[8];       /* must be -1 */
+} airfe_tuning;
 
 /* Mirrors the knobs of PLNetConfig / SuperPointConfig / PointMatcherConfig (include/read_configs.h:9-103). */
 typedef struct airfe_cfg {
@@ -54,9 +76,17 @@ typedef struct airfe_cfg {
   int matcher_precision;       /* storage type of the LightGlue / SuperGlue tokens and weights: 1 = fp16 (default: the reference builds
                                   both matcher engines with BuilderFlag::kFP16, light_glue.cpp:115, super_glue.cpp:132; measured 8x
                                   closer to the fp32 oracle than bf16), 0 = bf16, 2 = fp32 (LightGlue only), -1 = same as `precision` */
+  int line_precision;          /* operand type of the PLNet stage-1 LOI head's matrix products (src/plnet.cpp:468-514): 2 = fp32 operands (f32-input MFMA;
+                                  the default), 1 = fp16 operands with fp32 accumulation — what the reference's own stage-1 engine runs
+                                  (BuilderFlag::kFP16, src/plnet.cpp:216); DESIGN.md has the measured cost in flipped lines with the real weights */
+  int check_launches;          /* 1 = hipGetLastError() behind every stage's launches: a failed launch is reported by the call that made it, with
+                                  the stage's name (tests run with it); 0 = once per pipeline (default) */
+  const airfe_tuning* tuning;       /* kernel-selection overrides (NULL = the library's own choices): A/B measurements and tests that must reach every
+                                  kernel form.  Read once by airfe_create; the library never reads the environment. */
 } airfe_cfg;
 
 void airfe_default_cfg(airfe_cfg* cfg);
+void airfe_default_tuning(airfe_tuning* t);      /* every field -1 */
 
 /* ≙ the build() calls made by FeatureDetector / PointMatcher constructors
  *   (src/feature_detector.cc:7-34, src/point_matcher.cc:6-37): loads + packs weights, allocates the

@@ -40,6 +40,10 @@ int airfe_debug_preprocess(airfe_ctx* ctx, const uint8_t* gray, int h, int w, in
 int airfe_debug_conv3x3(airfe_ctx* ctx, const float* x, int B, int cin, int H, int W, const float* w, const float* b,
                         int cout, int pool, float* y);
 int airfe_debug_gemm(airfe_ctx* ctx, const float* x, int M, int K, const float* w, const float* b, int N, int relu, float* y);
+/* error-path test of cfg.check_launches: the NEXT group of launches of profiling stage `stage` (airfe_profile_stage_name's index) is preceded by one
+ * deliberately invalid launch (4096 threads per workgroup), so that the entry that makes it must fail with "<stage name>: kernel launch failed: ..." —
+ * with check_launches = 0 the same failure surfaces at the pipeline's end without the stage.  -1 disarms. */
+int airfe_debug_fail_next_launch(airfe_ctx* ctx, int stage);
 /* fault hunting (tools/experiments/matcher_trace.py): position-dependent 64-bit checksums of the LightGlue forward's state behind EVERY launch
  * (src/light_glue.cpp:120-170 is one opaque engine call; here it is ~60 launches) — residual stream, token shadow, q / k / v^T, attention
  * output, descriptors, similarity, assignment vectors — in units of 16 token rows (v^T: one feature row).  airfe_debug_trace(ctx, 1) switches it on

@@ -40,23 +40,13 @@ def cosine_dist(a: np.ndarray, b: np.ndarray) -> np.ndarray:
 _CTX = {}
 
 
-def context(kind: str, env=None, **cfg):
-    """Cached airfe contexts (weight packing + arena allocation is not free).  `env` = {AIRFE_*: value} read by
-    airfe_create only (kernel-selection switches), restored afterwards."""
-    import os
+def context(kind: str, tuning=None, **cfg):
+    """Cached airfe contexts (weight packing + arena allocation is not free).  `tuning` = {airfe_tuning field: value}: the kernel-selection
+    overrides airfe_create reads (include/airfe.h; the library reads no environment variables)."""
     from airslam_amd import api, weights
-    key = (kind, tuple(sorted((env or {}).items())), tuple(sorted(cfg.items())))
+    key = (kind, tuple(sorted((tuning or {}).items())), tuple(sorted(cfg.items())))
     if key not in _CTX:
         sp = weights.synthetic_superpoint(1234) if "sp" in kind else None
         lg = weights.synthetic_lightglue(1234) if "lg" in kind else None
-        old = {k: os.environ.get(k) for k in (env or {})}
-        os.environ.update(env or {})
-        try:
-            _CTX[key] = (api.Context(superpoint=sp, lightglue=lg, **cfg), sp, lg)
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+        _CTX[key] = (api.Context(superpoint=sp, lightglue=lg, tuning=tuning, check_launches=1, **cfg), sp, lg)
     return _CTX[key]

@@ -75,3 +75,34 @@ def test_weight_pack_roundtrip(tmp_path):
     assert sum(v.size for v in w.values()) == 1300865          # SURVEY.md C.1
     lg = weights.synthetic_lightglue(7)
     weights.check_spec(lg, weights.lightglue_spec())
+
+
+def test_library_reads_no_environment():
+    """VERDICT r04 #8: kernel selection of the shipped library must not depend on the process environment — the switches live in airfe_tuning."""
+    csrc = os.path.join(ROOT, "airslam_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f"{f} reads the environment"
+
+
+def test_every_c_entry_catches_exceptions():
+    """include/airfe.h promises "never throws": every extern "C" function that can reach host-side C++ (std::vector / std::string growth) is a
+    function-try-block ending in AIRFE_CATCH."""
+    src = open(os.path.join(ROOT, "airslam_amd", "csrc", "airfe.hip")).read()
+    body = src[src.index('extern "C" {'):]
+    trivial = {"airfe_profile_stages", "airfe_has_line_branch", "airfe_debug_trace_slots"}      # one expression on plain ints / pointers
+    defs = re.findall(r"^int (airfe_[a-z0-9_]+)\([^;{]*?\)\s*(try)?\s*\{", body, flags=re.M | re.S)
+    assert len(defs) >= 45
+    missing = [n for n, t in defs if not t and n not in trivial]
+    assert not missing, f"no function-try-block: {missing}"
+    assert body.count("} AIRFE_CATCH(") == sum(1 for _, t in defs if t)
+    declared = {n for n in _header_symbols() if n not in ("airfe_default_cfg", "airfe_default_tuning", "airfe_destroy", "airfe_last_error", "airfe_profile_stage_name")}
+    assert declared == {n for n, _ in defs}, declared ^ {n for n, _ in defs}
+
+
+def test_default_tuning_is_all_minus_one(libpath):
+    from airslam_amd import _lib
+    t = _lib.Tuning()
+    _lib.lib().airfe_default_tuning(C.byref(t))
+    assert all(getattr(t, n) == -1 for n, _ in _lib.Tuning._fields_ if n != "reserved") and list(t.reserved) == [-1] * 8
+    assert C.sizeof(_lib.Tuning) == 4 * 23

@@ -38,7 +38,7 @@ def test_conv3x3(cin, cout, pool, B, H, W, prec):
 
 # launch_gemm picks the kernel by row count: M <= 4096 gemm_small_kernel (no LDS), M >= 16000 and M % 256 == 0 gemm8_kernel
 # (kernels_gemm8.hip), otherwise gemm_kernel.  "staged" moves the thresholds so that the same shapes run through the other two.
-GEMM_POLICIES = {"default": {}, "staged": {"AIRFE_SMALL_MAX_M": "0", "AIRFE_GEMM8_MIN_M": "4096"}}
+GEMM_POLICIES = {"default": {}, "staged": {"gemm_small_max_m": 0, "gemm8_min_m": 4096}}
 
 
 @pytest.mark.parametrize("prec", [1, 0], ids=["fp16", "bf16"])
@@ -49,7 +49,7 @@ GEMM_POLICIES = {"default": {}, "staged": {"AIRFE_SMALL_MAX_M": "0", "AIRFE_GEMM
                                         (128, 320, 8192, False), (256, 512, 4224, False), (256, 512, 16384, False),
                                         (512, 256, 16640, True)])
 def test_gemm(K, N, M, relu, policy, prec):
-    ctx, _, _ = context("sp", env=GEMM_POLICIES[policy], precision=prec)
+    ctx, _, _ = context("sp", tuning=GEMM_POLICIES[policy], precision=prec)
     rng = np.random.default_rng(K + N + M)
     x = to_2byte(rng.normal(size=(M, K)).astype(np.float32), prec)
     w = to_2byte((rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32), prec)

@@ -84,8 +84,8 @@ def test_needs_an_arena_of_two_images():
     ctx.close()
 
 
-def test_graph_replay_gives_the_same_bits(monkeypatch):
-    """AIRFE_KF_GRAPH=1: call 1 runs plainly, call 2 captures the queue as a hipGraph, later calls replay it — on other images, with other entries of the same
+def test_graph_replay_gives_the_same_bits():
+    """airfe_tuning::kf_graph = 1: call 1 runs plainly, call 2 captures the queue as a hipGraph, later calls replay it — on other images, with other entries of the same
     context in between (their host-side flags must not leak into the replay, nor the replay's into them)."""
     W, H = 752, 480
     pairs = [synth.stereo_pair(H, W, 1000 + i) for i in range(3)]
@@ -93,8 +93,7 @@ def test_graph_replay_gives_the_same_bits(monkeypatch):
     want = [plain.stereo_keyframe(*p) for p in pairs]
     want_pts = plain.detect_points(pairs[1][0])
     plain.close()
-    monkeypatch.setenv("AIRFE_KF_GRAPH", "1")
-    ctx = _ctx(W, H)
+    ctx = _ctx(W, H, tuning={"kf_graph": 1})
     for i in range(7):
         got = ctx.stereo_keyframe(*pairs[i % 3])
         for key in want[i % 3]:
@@ -179,17 +178,16 @@ def test_one_call_entries_are_deterministic_over_many_calls():
     ctx.close()
 
 
-def test_rows_beyond_the_speculative_copy_take_the_second_round_trip(monkeypatch):
+def test_rows_beyond_the_speculative_copy_take_the_second_round_trip():
     """the entry copies the first 1024 line rows per image and 512 junction rows back before it knows the counts; more than that (here: more than 64,
-    AIRFE_KF_SPEC_ROWS) is fetched in a second round trip — same results either way"""
+    airfe_tuning::kf_spec_rows) is fetched in a second round trip — same results either way"""
     W, H = 752, 480
     left, right = synth.stereo_pair(H, W, 1003)
     ctx = _ctx(W, H)
     want = ctx.stereo_keyframe(left, right)
     ctx.close()
     assert len(want["linesL"]) > 64 and len(want["juncL"]) > 64
-    monkeypatch.setenv("AIRFE_KF_SPEC_ROWS", "64")
-    ctx = _ctx(W, H)
+    ctx = _ctx(W, H, tuning={"kf_spec_rows": 64})
     for _ in range(2):
         got = ctx.stereo_keyframe(left, right)
         for key in want:

@@ -60,20 +60,20 @@ def _check_against_oracle(name, s, ref, idx, sc, tol, min_matches):
 
 
 # A context picks the LightGlue block form by token count (fused lg_blockf_kernel from 3200 tokens, four launches below);
-# AIRFE_FUSE_LG_BLOCK forces either, so that both forms meet the oracle at every size.
-FORMS = [{"AIRFE_FUSE_LG_BLOCK": "1"}, {"AIRFE_FUSE_LG_BLOCK": "0"}]
+# airfe_tuning::fuse_lg_block forces either, so that both forms meet the oracle at every size.
+FORMS = [{"fuse_lg_block": 1}, {"fuse_lg_block": 0}]
 
 
 @pytest.mark.parametrize("mprec", [1, 0], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("env", FORMS, ids=["fused_block", "four_launches"])
 @pytest.mark.parametrize("n0,n1,min_matches", [(400, 400, 150), (317, 400, 110), (64, 65, 20), (1, 5, 0), (2, 1, 0)])
 def test_lightglue_scores_vs_oracle(n0, n1, min_matches, env, mprec):
-    ctx, _, lg = context("lg", env=env, max_batch=4, matcher_precision=mprec)
+    ctx, _, lg = context("lg", tuning=env, max_batch=4, matcher_precision=mprec)
     _, _, a, b = _pair(n0, n1, n0 * 3 + n1)
     s = ctx.lightglue_scores(a, b)
     ref = ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
     idx, sc = ctx.match_lightglue(a, b)
-    _check_against_oracle(f"lg_scores_{n0}_{n1}_{'fused' if env['AIRFE_FUSE_LG_BLOCK'] == '1' else 'split'}_{'fp16' if mprec else 'bf16'}",
+    _check_against_oracle(f"lg_scores_{n0}_{n1}_{'fused' if env['fuse_lg_block'] == 1 else 'split'}_{'fp16' if mprec else 'bf16'}",
                           s, ref, idx, sc, TOL[mprec], min_matches)
 
 
@@ -150,10 +150,10 @@ def test_matching_points_early_out():
 # large-batch kernels are exercised at a size the oracle-free comparison below finishes quickly
 # (gemmr with 24 persistent workgroups instead of 256: 200 token tiles / 8 per feature group = 25 tiles per workgroup, so the
 # 6- and 8-slot DMA rings wrap several times, as they do at 64 pairs on 256 workgroups)
-BIG_GEMMS = {"gemm8": {"AIRFE_GEMM8_MIN_M": "4096", "AIRFE_GEMMR_MIN_M": "1000000000"},
-             "gemmr": {"AIRFE_GEMM8_MIN_M": "4096", "AIRFE_GEMMR_MIN_M": "1024"},
-             "gemmr_ring_wrap": {"AIRFE_GEMM8_MIN_M": "4096", "AIRFE_GEMMR_MIN_M": "1024", "AIRFE_GEMMR_WGS": "24"},
-             "gemmr_two_launches": {"AIRFE_GEMM8_MIN_M": "4096", "AIRFE_GEMMR_MIN_M": "1024", "AIRFE_GEMMR_WGS": "24", "AIRFE_QKV_PAIR": "0"}}
+BIG_GEMMS = {"gemm8": {"gemm8_min_m": 4096, "gemmr_min_m": 1000000000},
+             "gemmr": {"gemm8_min_m": 4096, "gemmr_min_m": 1024},
+             "gemmr_ring_wrap": {"gemm8_min_m": 4096, "gemmr_min_m": 1024, "gemmr_wgs": 24},
+             "gemmr_two_launches": {"gemm8_min_m": 4096, "gemmr_min_m": 1024, "gemmr_wgs": 24, "qkv_pair": 0}}
 
 
 @pytest.mark.parametrize("big", list(BIG_GEMMS))
@@ -165,7 +165,7 @@ def test_large_batch_uses_gemm8_and_agrees_with_single_pair_path(env, big):
     changes the rounding points)."""
     import torch
     from airslam_amd import api
-    ctx, _, lg = context("lg", env=dict(env, **BIG_GEMMS[big]), max_batch=8)
+    ctx, _, lg = context("lg", tuning=dict(env, **BIG_GEMMS[big]), max_batch=8)
     B = 8
     pairs = [_pair(400 - 7 * i, 390 - 11 * i, 40 + i) for i in range(B)]
     f0 = torch.zeros((B, 400, 259)); f1 = torch.zeros((B, 400, 259))
@@ -194,7 +194,7 @@ def test_block_form_switch_by_token_count_keeps_the_matches():
     to bf16 noise and the match sets almost entirely."""
     import torch
     from airslam_amd import api
-    ctx, _, lg = context("lg", env={"AIRFE_BLOCK_MIN_M": "4096"}, max_batch=8)
+    ctx, _, lg = context("lg", tuning={"block_min_m": 4096}, max_batch=8)
     B = 8
     pairs = [_pair(400 - 7 * i, 390 - 11 * i, 140 + i) for i in range(B)]
     f0 = torch.zeros((B, 400, 259)); f1 = torch.zeros((B, 400, 259))
@@ -269,29 +269,29 @@ def test_bench_size_matcher_batch_repeats_its_distinct_pairs():
         np.testing.assert_array_equal(osc[i, :m], rsc[j, :m])
 
 
-@pytest.mark.parametrize("env", [{"AIRFE_FUSE_LG_BLOCK": "1", "AIRFE_GEMMR_MIN_M": "512"}, {"AIRFE_FUSE_LG_BLOCK": "0"}],
+@pytest.mark.parametrize("env", [{"fuse_lg_block": 1, "gemmr_min_m": 512}, {"fuse_lg_block": 0}],
                          ids=["fused_block_gemmr", "four_launches"])
 def test_lightglue_bf16_storage(env):
     """matcher_precision = 0 (bf16 operands, fp32 accumulate) through the same kernels: the PBF16 instantiations of lg_blockf_kernel,
     gemmr_kernel / gemmr_pair_kernel and gemm_small_kernel (the default matcher storage is fp16, tested above).  Three fewer mantissa
     bits: ~8x the score error; the match set still has to be the oracle's outside the rows the oracle decides within that error."""
-    ctx, _, lg = context("lg", env=env, max_batch=4, matcher_precision=0)
+    ctx, _, lg = context("lg", tuning=env, max_batch=4, matcher_precision=0)
     _, _, a, b = _pair(400, 371, 4242)
     s = ctx.lightglue_scores(a, b)
     ref = ref_nets.lightglue_forward(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
     idx, sc = ctx.match_lightglue(a, b)
-    _check_against_oracle(f"lg_bf16_{'fused' if env['AIRFE_FUSE_LG_BLOCK'] == '1' else 'split'}", s, ref, idx, sc, TOL[0], 150)
+    _check_against_oracle(f"lg_bf16_{'fused' if env['fuse_lg_block'] == 1 else 'split'}", s, ref, idx, sc, TOL[0], 150)
 
 
 def test_folded_projections_give_the_same_bits():
     """The fused block computes the NEXT attention layer's q | k | v projections from its own result (kernels_lgblockf.hip, FOLD);
-    AIRFE_FOLD_QKV=0 runs them as launches of their own (gemmr_pair / the tiled kernels).  Same fragments, same K order, bias after
+    airfe_tuning::fold_qkv = 0 runs them as launches of their own (gemmr_pair / the tiled kernels).  Same fragments, same K order, bias after
     the sum, same rotary: the matches AND the scores must be bit-identical, at a size with a ragged last pass (8 pairs x 400 rows =
     6400 tokens = 57.1 passes of 112) and with short sequences (rows beyond a sequence's length are computed, stored and masked)."""
     import torch
     outs = []
-    for fold in ("1", "0"):
-        ctx, _, lg = context("lg", env={"AIRFE_FUSE_LG_BLOCK": "1", "AIRFE_FOLD_QKV": fold}, max_batch=8)
+    for fold in (1, 0):
+        ctx, _, lg = context("lg", tuning={"fuse_lg_block": 1, "fold_qkv": fold}, max_batch=8)
         B = 8
         pairs = [_pair(400 - 31 * i, 390 - 17 * i, 240 + i) for i in range(B)]
         f0 = torch.zeros((B, 400, 259)); f1 = torch.zeros((B, 400, 259))
@@ -347,11 +347,11 @@ def test_slack_rows_are_reset_on_every_call():
 def test_fused_block_tile_sizes_give_the_same_bits():
     """lg_blockf picks 32-token passes up to 8192 tokens, 64 up to 16384, else 112 / 128 (round 4: the batch-1 .. batch-16 calls), and the small tiles
     keep all weight slabs of a GEMM in flight.  A token's arithmetic does not depend on the tile it sits in: every tile size must give the SAME BITS
-    (AIRFE_LGB_TOKENS forces one)."""
+    (airfe_tuning::lgb_tokens forces one)."""
     _, _, a, b = _pair(400, 317, 11)
     ref = None
-    for tokens in ("32", "64", "112", "128"):
-        ctx, _, _ = context("lg", env={"AIRFE_FUSE_LG_BLOCK": "1", "AIRFE_LGB_TOKENS": tokens}, max_batch=4)
+    for tokens in (32, 64, 112, 128):
+        ctx, _, _ = context("lg", tuning={"fuse_lg_block": 1, "lgb_tokens": tokens}, max_batch=4)
         s = ctx.lightglue_scores(a, b)
         idx, sc = ctx.match_lightglue(a, b)
         if ref is None:

@@ -117,12 +117,11 @@ def _check_superglue(name, ctx, w, f0, f1, layers, iters, tol, min_valid):
 @pytest.mark.parametrize("n0,n1,layers,iters,min_valid,fused", [(300, 280, 4, 20, 100, 0), (64, 65, 18, 100, 20, 0), (1, 3, 2, 5, 0, 0),
                                                                  (400, 400, 18, 100, 150, 0), (400, 400, 18, 100, 150, 1),
                                                                  (300, 280, 4, 20, 100, 1), (1, 3, 2, 5, 0, 1)])
-def test_superglue_vs_oracle(n0, n1, layers, iters, min_valid, fused, monkeypatch):
+def test_superglue_vs_oracle(n0, n1, layers, iters, min_valid, fused):
     # fused = the propagation block (merge, mlp.0 + ReLU, mlp.3, residual) as the one-kernel form large batches use
-    monkeypatch.setenv("AIRFE_FUSE_LG_BLOCK", str(fused))
-    monkeypatch.setenv("AIRFE_SG_KENC_GEMM", str(fused))       # ... and the keypoint encoder's large layers as GEMMs (the large-batch form)
     w = weights.synthetic_superglue(1234, n_layers=layers)
-    ctx = api.Context(superglue=w, matcher=1, max_batch=2, sinkhorn_iters=iters)
+    # ... and the keypoint encoder's large layers as GEMMs (the large-batch form)
+    ctx = api.Context(superglue=w, matcher=1, max_batch=2, sinkhorn_iters=iters, tuning={"fuse_lg_block": fused, "sg_kenc_gemm": fused}, check_launches=1)
     _, _, f0, f1 = _sg_pair(n0, n1, n0 * 3 + n1)
     z = _check_superglue(f"sg_{n0}_{n1}_{layers}_{'fused' if fused else 'split'}", ctx, w, f0, f1, layers, iters, 0.05, min_valid)
     # marginals: exp(Z) rows/cols sum to the prescribed masses after `iters` iterations (column step is last)

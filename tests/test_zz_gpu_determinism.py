@@ -72,20 +72,19 @@ def test_folded_projections_are_deterministic():
     no single-shot parity test sees.)"""
     import hashlib
     _, _, a, b = _pair(400, 400, 1600)
-    ref_ctx, _, _ = context("lg", env={"AIRFE_FUSE_LG_BLOCK": "1", "AIRFE_FOLD_QKV": "0"}, max_batch=4)
+    ref_ctx, _, _ = context("lg", tuning={"fuse_lg_block": 1, "fold_qkv": 0}, max_batch=4)
     ref = hashlib.md5(ref_ctx.lightglue_scores(a, b).tobytes()).hexdigest()
-    ctx, _, _ = context("lg", env={"AIRFE_FUSE_LG_BLOCK": "1", "AIRFE_FOLD_QKV": "1"}, max_batch=4)
+    ctx, _, _ = context("lg", tuning={"fuse_lg_block": 1, "fold_qkv": 1}, max_batch=4)
     seen = {hashlib.md5(ctx.lightglue_scores(a, b).tobytes()).hexdigest() for _ in range(150)}
     assert seen == {ref}
 
 
 @pytest.mark.parametrize("fused", [0, 1])
-def test_superglue_is_deterministic(fused, monkeypatch):
+def test_superglue_is_deterministic(fused):
     """60 forward passes (GNN, register-resident cooperative Sinkhorn with its inter-workgroup rendezvous, decode): one result."""
     import hashlib
-    monkeypatch.setenv("AIRFE_FUSE_LG_BLOCK", str(fused))
     w = weights.synthetic_superglue(1234, n_layers=18)
-    ctx = api.Context(superglue=w, matcher=1, max_batch=2, sinkhorn_iters=100)
+    ctx = api.Context(superglue=w, matcher=1, max_batch=2, sinkhorn_iters=100, tuning={"fuse_lg_block": fused})
     _, _, f0, f1 = _sg_pair(400, 380, 77)
     seen = {hashlib.md5(ctx.superglue_scores(f0, f1).tobytes()).hexdigest() for _ in range(60)}
     assert len(seen) == 1
@@ -93,7 +92,7 @@ def test_superglue_is_deterministic(fused, monkeypatch):
 
 
 @pytest.mark.parametrize("overlap", [1, 0], ids=["line_path_beside_the_matcher", "one_stream"])
-def test_keyframe_step_is_deterministic_at_the_bench_size(overlap, monkeypatch):
+def test_keyframe_step_is_deterministic_at_the_bench_size(overlap):
     """64 stereo pairs through airfe_stereo_plnet_batch_dev (the default bench step), 500 times in each stream arrangement — the line path
     on the context's second stream beside the matcher (the default) and everything on one stream: every output equals the first run's bit
     for bit.  History: round 2 ended red here (1 run of 150 with different match scores); round 3 traced it with per-launch state checksums
@@ -101,10 +100,9 @@ def test_keyframe_step_is_deterministic_at_the_bench_size(overlap, monkeypatch):
     packed-math instruction form that is banned since (tests/test_no_scratch_cpu.py::test_no_packed_f32_cross_half_selects).  Before that the
     stage-1 kernel's hand-placed `s_waitcnt` gave a different line set in ~1 % of the steps.  A single-shot parity test sees neither."""
     import torch
-    monkeypatch.setenv("AIRFE_OVERLAP_LINES", str(overlap))
     B = 64
     ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(GOLDEN, "plnet_s1.airfe"),
-                      lightglue=weights.synthetic_lightglue(1234), max_batch=B, enc_chunk=64)
+                      lightglue=weights.synthetic_lightglue(1234), max_batch=B, enc_chunk=64, tuning={"overlap_lines": overlap})
     ls, rs = synth.stereo_batch(B, 480, 752, 1000)
     L, R = torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda()
     z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device="cuda")

@@ -5,6 +5,6 @@ from gpu_common import context
 from test_gpu_lightglue import _pair
 _, _, a, b = _pair(400, 400, 1600)
 for fold in ("0", "1"):
-    ctx, _, lg = context("lg", env={"AIRFE_FUSE_LG_BLOCK": "1", "AIRFE_FOLD_QKV": fold}, max_batch=4)
+    ctx, _, lg = context("lg", tuning={"fuse_lg_block": 1, "fold_qkv": fold}, max_batch=4)
     c = collections.Counter(hashlib.md5(ctx.lightglue_scores(a, b).tobytes()).hexdigest()[:6] for _ in range(400))
     print("fold", fold, "distinct results in 400 runs:", len(c), c.most_common(3))
