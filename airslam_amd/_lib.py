@@ -58,6 +58,9 @@ SIGNATURES = {
                                                 C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "airfe_track_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
                                     C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "airfe_promote_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int,
+                                      C.POINTER(C.c_int)]),
+    "airfe_adopt_reference": (C.c_int, [C.c_void_p]),
     "airfe_match_lightglue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_int, C.POINTER(C.c_int)]),
     "airfe_match_superglue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,

@@ -260,6 +260,25 @@ class Context:
                                             idx.ctypes.data, sc.ctypes.data, cap, C.byref(nm)), "airfe_track_frame")
         return feat[:n.value], idx[:nm.value], sc[:nm.value]
 
+    def promote_frame(self, right: np.ndarray):
+        """The promotion of map_builder.cc:104-108 for the frame of the last track_frame call (airfe_promote_frame): Detect(right) + MatchingPoints(left, right)
+        with the left rows still on the device -> (featR [n,259], idx [m,2] (left, right), score [m])."""
+        right = np.asarray(right)
+        if right.ndim != 2 or right.dtype != np.uint8 or right.size == 0:
+            raise AirfeError("empty image")
+        if right.strides[1] != 1 or right.strides[0] < right.shape[1]:
+            right = np.ascontiguousarray(right)
+        cap = self.np_rows
+        feat, idx, sc = np.empty((cap, FEAT), np.float32), np.empty((cap, 2), np.int32), np.empty((cap,), np.float32)
+        n, nm = C.c_int(0), C.c_int(0)
+        self._chk(self._l.airfe_promote_frame(self._h, right.ctypes.data, right.shape[0], right.shape[1], right.strides[0], feat.ctypes.data, cap, C.byref(n),
+                                              idx.ctypes.data, sc.ctypes.data, cap, C.byref(nm)), "airfe_promote_frame")
+        return feat[:n.value], idx[:nm.value], sc[:nm.value]
+
+    def adopt_reference(self):
+        """`_last_keyframe_feature = frame` for a promoted frame: the last track_frame's rows become the reference, on the device (airfe_adopt_reference)."""
+        self._chk(self._l.airfe_adopt_reference(self._h), "airfe_adopt_reference")
+
     def debug_plnet_stage0(self):
         """The on-device stage-0 line branch of the last detected image: dict in synth.plnet_stage0_lines' layout + jloc / joff."""
         n = 3 * 128 * 128

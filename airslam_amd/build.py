@@ -17,6 +17,21 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in ("kernels_lg.hip", "kernels_img.hip", "kernels_s0.hip", "kernels_f32.hip")}
 
 
+def csrc_sha() -> str:
+    """sha256 over the kernel / host sources of libairfe.so (csrc/*.hip, csrc/*.h, include/airfe*.h), in name order: the identity of the code a profile was
+    taken on.  tools/pmc_summary.py and tools/pmc_traffic.py stamp it into profiles/rNN_*.json; bench.py refuses counter-derived numbers whose stamp differs from
+    the tree it runs on (`roofline.counters_age`) — the GPU box has no .git to ask."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files += [os.path.join(HERE, "..", "include", "airfe.h"), os.path.join(HERE, "..", "include", "airfe_debug.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True

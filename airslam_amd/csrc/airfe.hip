@@ -1150,6 +1150,7 @@ int airfe_track_frame(airfe_ctx* c, const uint8_t* gray, int h, int w, int strid
   const int Np = c->cfg.max_keypoints;
   if (ref_feat && (n_ref < 0 || n_ref > Np)) return fail(c, "track_frame: reference keypoint count exceeds max_keypoints");
   *n = 0; *nmatch = 0;
+  c->tk_n = -1;
   hipStream_t st = c->stream;
   const size_t fb = (size_t)Np * AIRFE_FEAT_DIM * 4, early = 64 + fb, late = early + 64;
   // device block: [counts | new rows | idx | score] and the reference block [count | reference rows] (kept from call to call)
@@ -1190,6 +1191,7 @@ int airfe_track_frame(airfe_ctx* c, const uint8_t* gray, int h, int w, int strid
   *n = nn;
   HIPCHK(c, hipStreamSynchronize(st));
   drain.armed = false;
+  c->tk_n = nn;                                                      // (airfe_promote_frame / airfe_adopt_reference work on these rows)
   if (nn < 1 || c->ref_n < 1) return 0;                              // point_matcher.cc:53-55
   const int nm = std::min(reinterpret_cast<const int*>(c->pin + early)[2], Np);
   if (nm > 0) {
@@ -1197,6 +1199,71 @@ int airfe_track_frame(airfe_ctx* c, const uint8_t* gray, int h, int w, int strid
     memcpy(match_score, c->pin + late + (size_t)Np * 8, (size_t)nm * 4);
   }
   *nmatch = nm;
+  return 0;
+} AIRFE_CATCH(c)
+
+// The promotion of map_builder.cc:104-108 (see include/airfe.h): Detect(right) + MatchingPoints(left, right) with the left rows of the last
+// airfe_track_frame still on the device; the right rows come home on the side stream while LightGlue runs (the queue of airfe_track_frame).
+int airfe_promote_frame(airfe_ctx* c, const uint8_t* right, int h, int w, int stride, float* featR, int cap, int* nR, int32_t* match_idx,
+                        float* match_score, int mcap, int* nmatch) try {
+  AIRFE_ENTER(c);
+  if (!right || h < 1 || w < 1) return fail(c, "empty image");
+  if (stride < w) return fail(c, "image stride smaller than its width");
+  if (!featR || !nR || !match_idx || !match_score || !nmatch) return fail(c, "promote_frame: bad argument");
+  if (cap < c->cfg.max_keypoints || mcap < c->cfg.max_keypoints) return fail(c, "feature / match capacity < max_keypoints");
+  if (!c->has_lg) return fail(c, "promote_frame: LightGlue weights were not loaded (cfg.lightglue_pack)");
+  if (c->mprec == 2 || c->prec == 2) return fail(c, "promote_frame runs in fp16 / bf16");
+  if (c->tk_n < 0 || !c->tk_blk) return fail(c, "promote_frame: no airfe_track_frame preceded it (the left features live on the device since that call)");
+  const int Np = c->cfg.max_keypoints;
+  *nR = 0; *nmatch = 0;
+  hipStream_t st = c->stream;
+  const size_t fb = (size_t)Np * AIRFE_FEAT_DIM * 4, early = 64 + fb, late = early + 64;
+  if (ensure_block(c, c->pr_blk, c->pr_bytes, 64 + fb + (size_t)Np * 12)) return 1;
+  int* cnt = reinterpret_cast<int*>(c->pr_blk);                       // {n_right, -, nmatch}
+  float* d_right = reinterpret_cast<float*>(c->pr_blk + 64);
+  int32_t* d_idx = reinterpret_cast<int32_t*>(c->pr_blk + 64 + fb);
+  float* d_sc = reinterpret_cast<float*>(c->pr_blk + 64 + fb + (size_t)Np * 8);
+  const int* d_nleft = reinterpret_cast<const int*>(c->tk_blk);
+  const float* d_left = reinterpret_cast<const float*>(c->tk_blk + 64);
+  const size_t ib = (size_t)(h - 1) * stride + w;
+  if (ensure_stage_img(c, (size_t)h * stride)) return 1;
+  if (ensure_pin(c, std::max(ib, late + (size_t)Np * 12))) return 1;
+  memcpy(c->pin, right, ib);
+  DrainOnError drain{c, true};
+  HIPCHK(c, hipMemsetAsync(cnt, 0, 64, st));
+  HIPCHK(c, hipMemcpyAsync(c->st_img, c->pin, ib, hipMemcpyHostToDevice, st));
+  if (detect_dev(c, c->st_img, 1, h, w, stride, (size_t)h * stride, d_right, Np, cnt, st)) return 1;
+  HIPCHK(c, hipEventRecord(c->ev_fork, st));
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+  HIPCHK(c, hipMemcpyAsync(c->pin, c->pr_blk, early, hipMemcpyDeviceToHost, c->stream2));
+  HIPCHK(c, hipEventRecord(c->ev_feat, c->stream2));
+  if (lightglue_dev(c, d_left, d_nleft, d_right, cnt, 1, Np, AIRFE_FEAT_DIM, 1, 1, d_idx, d_sc, Np, cnt + 2, nullptr, st)) return 1;
+  HIPCHK(c, hipMemcpyAsync(c->pin + early, cnt, 64, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(c->pin + late, d_idx, (size_t)Np * 12, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipEventSynchronize(c->ev_feat));
+  const int nn = std::min(*reinterpret_cast<const int*>(c->pin), Np);
+  if (nn > 0) memcpy(featR, c->pin + 64, (size_t)nn * AIRFE_FEAT_DIM * 4);
+  *nR = nn;
+  HIPCHK(c, hipStreamSynchronize(st));
+  drain.armed = false;
+  if (nn < 1 || c->tk_n < 1) return 0;                               // point_matcher.cc:53-55
+  const int nm = std::min(reinterpret_cast<const int*>(c->pin + early)[2], Np);
+  if (nm > 0) {
+    memcpy(match_idx, c->pin + late, (size_t)nm * 8);
+    memcpy(match_score, c->pin + late + (size_t)Np * 8, (size_t)nm * 4);
+  }
+  *nmatch = nm;
+  return 0;
+} AIRFE_CATCH(c)
+
+int airfe_adopt_reference(airfe_ctx* c) try {
+  AIRFE_ENTER(c);
+  if (c->tk_n < 0 || !c->tk_blk) return fail(c, "adopt_reference: no airfe_track_frame preceded it");
+  const size_t fb = (size_t)c->cfg.max_keypoints * AIRFE_FEAT_DIM * 4;
+  if (ensure_block(c, c->ref_blk, c->ref_bytes, 64 + fb)) return 1;
+  // [count | rows] have the same layout in both blocks (the count's word 0; words 1.. of the header are scratch of the entries)
+  HIPCHK(c, hipMemcpyAsync(c->ref_blk, c->tk_blk, 64 + (size_t)std::max(c->tk_n, 0) * AIRFE_FEAT_DIM * 4, hipMemcpyDeviceToDevice, c->stream));
+  c->ref_n = c->tk_n;
   return 0;
 } AIRFE_CATCH(c)
 

@@ -158,6 +158,8 @@ struct airfe_ctx {
   uint8_t* kf_blk = nullptr; size_t kf_bytes = 0;   // airfe_stereo_keyframe's device block (grows on demand)
   uint8_t *tk_blk = nullptr, *ref_blk = nullptr; size_t tk_bytes = 0, ref_bytes = 0;   // airfe_track_frame: outputs; the last keyframe's features
   int ref_n = -1;
+  int tk_n = -1;                                    // keypoints of the last airfe_track_frame's frame (its rows are still in tk_blk); -1: none
+  uint8_t* pr_blk = nullptr; size_t pr_bytes = 0;   // airfe_promote_frame: [counts | right rows | idx | score]
   int kf_spec_lines = 1024, kf_spec_juncs = 512;   // line / junction rows airfe_stereo_keyframe copies back before it knows the counts (airfe_tuning::kf_spec_rows)
   bool kf_graph_on = false;                         // airfe_tuning::kf_graph
   KfGraph kf_graph;

@@ -16,7 +16,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("AIRFE_DIST_FORCE_INIT")) and not dist.is_initialized():      # (FORCE_INIT: a process group of one rank, tests only)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -32,11 +32,12 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def gather_matches(idx: torch.Tensor, score: torch.Tensor, nmatch: torch.Tensor, dst: int = 0):
+def gather_matches(idx: torch.Tensor, score: torch.Tensor, nmatch: torch.Tensor, dst: int = 0, force: bool = False):
     """idx [B,cap,2] int32, score [B,cap] f32, nmatch [B] int32 on every rank -> on `dst`:
     (idx [W*B,cap,2], score [W*B,cap], nmatch [W*B]) in rank order; None elsewhere.
-    One packed buffer per rank => a single gather collective per step (latency-bound payload)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    One packed buffer per rank => a single gather collective per step (latency-bound payload).
+    force: go through the collective even in a group of ONE rank (tests/test_gpu_rccl.py: the only way to put RCCL under this code on a 1-GPU box)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return idx, score, nmatch
     b, cap, _ = idx.shape
     packed = torch.cat([idx.reshape(b, cap * 2).to(torch.int32), score.view(torch.int32).reshape(b, cap),
@@ -53,8 +54,8 @@ def gather_matches(idx: torch.Tensor, score: torch.Tensor, nmatch: torch.Tensor,
     return gi, gs, gn
 
 
-def max_over_ranks(x: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def max_over_ranks(x: float, device, force: bool = False) -> float:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return x
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

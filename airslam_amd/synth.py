@@ -62,6 +62,13 @@ def stereo_sequence(n: int, h: int, w: int, seed: int, scene_len: int = 40):
         yield np.roll(l0, (2 * j, 3 * j), axis=(0, 1)), np.roll(r0, (2 * j, 3 * j), axis=(0, 1))
 
 
+def stereo_sequence_arrays(args):
+    """(n, h, w, seed, scene_len) -> (left [n,h,w], right [n,h,w]) uint8: stereo_sequence as two stacks (a picklable job for a process pool)."""
+    n, h, w, seed, scene_len = args
+    fr = list(stereo_sequence(n, h, w, seed, scene_len))
+    return np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr])
+
+
 def plnet_stage0_lines(seed: int, n_lines: int = 400, fh: int = 128, fw: int = 128, jn: int = 300):
     """Stand-in for the line-branch outputs of plnet_s0.onnx.
     Shapes/dtypes follow the contract read off src/plnet.cpp:453-507; the VALUES are synthetic."""

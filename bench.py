@@ -32,6 +32,26 @@ def latest_profile(suffix):
     return sorted(c)[-1] if c else None
 
 
+def counter_profile(suffix):
+    """(document, path, age) of the newest committed profiles/rNN_<suffix>: age = {"profile", "profile_csrc_sha", "tree_csrc_sha", "stale"} — counters measured on other
+    kernel sources than the ones this process runs are NOT reported (document = None): a number from an older kernel must never ride on a changed one."""
+    from airslam_amd.build import csrc_sha
+    pf = latest_profile(suffix)
+    if not pf:
+        return None, None, None
+    with open(pf) as fh:
+        doc = json.load(fh)
+    now = csrc_sha()
+    age = {"profile": "profiles/" + os.path.basename(pf), "profile_csrc_sha": doc.get("csrc_sha"), "tree_csrc_sha": now, "stale": doc.get("csrc_sha") != now}
+    return (None if age["stale"] else doc), pf, age
+
+
+# which roof a stage is priced against (SURVEY.md 8(d) table): matrix stages by their algorithmic FLOPs against the dense 2-byte MFMA peak, the rest by
+# their algorithmic bytes against the HBM peak; plnet_stage1 runs f32-input MFMA (157 TFLOP/s) unless cfg.line_precision = 1
+STAGE_BOUND = {"conv1_fused": "mfma", "conv3x3_cin64": "mfma", "conv3x3_cin128": "mfma", "head_gemm": "mfma", "lg_gemm": "mfma", "lg_attention": "mfma"}
+PEAK_MFMA_F32_TFLOPS = 157.0
+
+
 DOMINANT_STAGE = "conv1_fused"   # the dominant KERNEL (conv64r_kernel<POOL, FUSE1A>: conv1a + conv1b + pool, ~21 % of a step) is a stage of
                                 # its own: its launches keep their HIP events inside the timed region
 PEAK_MFMA_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROARCH.md chip table
@@ -178,6 +198,131 @@ def latency_b1(args, rank, world, local, dev):
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
+
+
+def seq_workload(args, rank, world, local, dev):
+    """--workload seq: BASELINE.json configs[3] — per rank S stereo SEQUENCES of --frames frames (synth.stereo_sequence, seeds 10 + rank * S + s), driven exactly as
+    MapBuilder::ExtractFeatureThread drives the front end (src/map_builder.cc:83-141 with the shipped use_superpoint: 1): PLNet stereo keyframes, SuperPoint-only
+    normal frames matched against the last keyframe, promotions (airslam_amd/seq.py).  S = 1 runs the one-call host entries (latency regime); S > 1 batches the S
+    sequences of a time-step through the device-resident entries.  Every K = 8 frames the temporal match lists go to rank 0 in one collective on a side stream.
+    A step = one time-step = one frame of each of the S sequences; value = frames/s of the whole job."""
+    from airslam_amd import api, seq, synth, weights
+    from airslam_amd import dist as adist
+    H, W, K = args.height, args.width, args.max_keypoints
+    frames = args.frames if args.steps_given is None else args.warmup + args.steps_given
+    warm = min(args.warmup, frames - 1)
+    scene_len, KG = args.scene_len, 8
+    sweep = sorted(set([args.sequences] + ([1, 4, 8, 16] if args.sweep else [])))
+    Smax = max(sweep)
+    import multiprocessing as mp
+    jobs = [(frames, H, W, 10 + rank * Smax + s_, scene_len) for s_ in range(Smax)]
+    with mp.get_context("spawn").Pool(min(Smax, os.cpu_count() or 1)) as pool:     # (2.6 s per 200-frame sequence on one core)
+        arrs = pool.map(synth.stereo_sequence_arrays, jobs)
+    Lh = np.stack([a[0] for a in arrs], 1)                 # [frames][Smax][H][W]
+    Rh = np.stack([a[1] for a in arrs], 1)
+    Ld, Rd = torch.from_numpy(Lh).to(dev), torch.from_numpy(Rh).to(dev)          # resident in HBM before the clock starts (Smax x frames x 0.72 MB)
+    s1_path = os.path.join(ROOT, "tests", "golden", "plnet_s1.airfe")
+    lg = weights.synthetic_lightglue(1234)
+    pol = seq.KeyframeConfig(image_width=W, image_height=H, tracking_point_rate=args.tracking_point_rate)
+    prec, mprec = (1 if args.dtype == "fp16" else 0), (1 if args.matcher_dtype == "fp16" else 0)
+
+    def run(S):
+        common = dict(device=local, precision=prec, matcher_precision=mprec, max_keypoints=K, image_width=W, image_height=H)
+        kf = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=s1_path, lightglue=lg, max_batch=max(S, 2), enc_chunk=max(min(2 * S, args.chunk), 2), **common)
+        nf = api.Context(superpoint=weights.synthetic_superpoint(1234), lightglue=lg, max_batch=max(S, 2), enc_chunk=max(min(S, args.chunk), 2), **common)
+        gat = seq.MatchGatherer(KG, S, K, dev)
+        results, lat, pending = [], [], []
+        if S == 1:
+            fe = seq.SequenceFrontEnd(kf, nf, pol)
+
+            def step(t):
+                r = fe.step(Lh[t, 0], Rh[t, 0])          # host images in, host matrices out: the batch-1 API takes host buffers (PCIe included)
+                if r.matches_idx is not None:
+                    m = len(r.matches_idx)
+                    idx = torch.zeros((1, K, 2), dtype=torch.int32); sc = torch.zeros((1, K)); idx[0, :m] = torch.from_numpy(r.matches_idx); sc[0, :m] = torch.from_numpy(r.matches_score)
+                    h = gat.add(idx.to(dev, non_blocking=True), sc.to(dev, non_blocking=True), torch.tensor([m], dtype=torch.int32).to(dev, non_blocking=True))
+                    if h is not None:
+                        pending.append(h)
+                return [r]
+        else:
+            bs = seq.BatchedSequences(kf, nf, S, pol, device=dev)
+
+            def step(t):
+                rs = bs.step(Ld[t, :S], Rd[t, :S])
+                tset = [i for i in range(S) if rs[i].matches_idx is not None]
+                if tset:                                   # (device tensors of this step's temporal matches, rows in tset order; the others count 0)
+                    h = gat.add(bs.tidx[:len(tset)], bs.tsc[:len(tset)], bs.tnm[:len(tset)], stream=bs.stream)
+                    if h is not None:
+                        pending.append(h)
+                return rs
+
+        def barrier():
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize(dev)
+        for t in range(warm):
+            results.append(step(t))
+        barrier()
+        t0 = time.perf_counter()
+        for t in range(warm, frames):
+            ta = time.perf_counter()
+            results.append(step(t))
+            lat.append(time.perf_counter() - ta)
+        for h in pending:
+            h.result()
+        barrier()
+        dt = adist.max_over_ranks(time.perf_counter() - t0, dev)
+        kf.close(); nf.close()
+        flat = [r for rs in results[warm:] for r in rs]
+        a = np.asarray(lat) * 1e3
+        return dict(S=S, dt=dt, frames_per_s=S * (frames - warm) * world / dt, ms_per_step=dt / (frames - warm) * 1e3,
+                    latency_ms={"p50": float(np.percentile(a, 50)), "p99": float(np.percentile(a, 99)), "mean": float(a.mean()), "max": float(a.max())},
+                    schedule={"frames": len(flat), "keyframe_candidates": sum(r.candidate for r in flat), "keyframes": sum(r.frame_type != seq.NORMAL for r in flat),
+                              "promotions": sum(r.promoted for r in flat), "normal_frames": sum(r.frame_type == seq.NORMAL for r in flat),
+                              "temporal_matches_mean": float(np.mean([len(r.matches_idx) for r in flat if r.matches_idx is not None] or [0])),
+                              "stereo_matches_mean": float(np.mean([len(r.stereo_idx) for r in flat if r.stereo_idx is not None] or [0])),
+                              "lines_mean_keyframe_left": float(np.mean([len(r.lines_left) for r in flat if r.lines_left is not None] or [0]))},
+                    gathers=gat.gathers, results=results)
+
+    runs = {S: run(S) for S in sweep}
+    head = runs[args.sequences]
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_pairs > 0:
+        # the oracle's restatement of the same loop on sequence 0's first frames (bounded: ~20 frames of fp32 PyTorch-CPU + numpy), taking its own decisions
+        from oracle import ref_seq
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        chain = ref_seq.Chain(weights.synthetic_plnet_s0(1234), weights.synthetic_superpoint(1234), weights.load_pack(s1_path), lg, W, H, K,
+                              policy=dict(tracking_point_rate=args.tracking_point_rate))
+        nfr = min(args.cpu_pairs + 2, frames)
+        ts, types = [], []
+        for t in range(nfr):
+            ta = time.perf_counter()
+            o = chain.step(Lh[t, 0], Rh[t, 0])
+            ts.append(time.perf_counter() - ta); types.append(o["frame_type"])
+        dev_types = [rs[0].frame_type for rs in head["results"][:nfr]]
+        cpu = dict(value=(nfr - 2) / sum(ts[2:]), unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                   sample=f"frames 2..{nfr - 1} of sequence 0 ({sum(ts[2:]):.1f} s; frames 0-1 warm the thread pool): oracle/ref_seq.Chain — fp32 PyTorch-CPU networks + numpy "
+                          f"post-processing, the same loop taking its own keyframe decisions",
+                   same_schedule_as_gpu=(types == dev_types), frame_types_cpu=types, frame_types_gpu=dev_types)
+    if rank == 0:
+        out = {"metric": "stereo sequence frames/sec (BASELINE configs[3]: per sequence PLNet stereo keyframes + SuperPoint-only normal frames matched against the last keyframe "
+                         "+ promotions, map_builder.cc:83-141 with use_superpoint: 1)",
+               "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": frames - warm, "warmup": warm, "ms_per_step": head["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": args.dtype if args.dtype == args.matcher_dtype else f"{args.dtype} (encoder) + {args.matcher_dtype} (matcher), fp32 accumulate",
+               "data": "synthetic", "latency_ms_per_time_step": head["latency_ms"],
+               "config": {"workload": f"{args.sequences} synthetic {W}x{H} stereo sequence(s) per GPU x {frames} frames (seeds 10 + rank * S + s, a new scene every {scene_len} frames, "
+                                      f"2-3 px pan per frame), images resident in HBM" + (" and in host memory (S = 1 goes through the batch-1 host entries: PCIe included)" if args.sequences == 1 else "")
+                                      + f"; keyframe policy = AddKeyframeCheck of vo_euroc.yaml with tracking_point_rate {args.tracking_point_rate} (the synthetic matcher weights match ~35 % "
+                                      f"of the keypoints; 0.65 would make every second frame a keyframe); max_keypoints={K}; seeded synthetic weights except PLNet stage 1 (real)",
+                          "sequences_per_gpu": args.sequences, "frames": frames, "gather_every_frames": KG, "gathers": head["gathers"], "schedule": head["schedule"],
+                          "driver": "airslam_amd.seq.SequenceFrontEnd (one-call host entries)" if args.sequences == 1 else "airslam_amd.seq.BatchedSequences (*_batch_dev entries)"},
+               "sweep": {str(S): {"frames_per_s": r["frames_per_s"], "ms_per_time_step": r["ms_per_step"], "latency_ms": r["latency_ms"], "schedule": r["schedule"]} for S, r in runs.items()},
+               "roofline": None, "cpu_baseline": cpu, "collective": args.collective}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def side_workloads(args, rank, world, local, dev):
@@ -338,7 +483,7 @@ def side_workloads(args, rank, world, local, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE under a launcher, else 1")
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; --workload seq: --frames minus the warm-up)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
     ap.add_argument("--height", type=int, default=480)
@@ -353,13 +498,20 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=20, help="CPU-baseline sample size (0 = skip)")
     ap.add_argument("--matcher", default="lightglue", choices=["lightglue", "superglue"],
                     help="superglue: 18-layer GNN + 100 Sinkhorn iterations (BASELINE configs[4]: --width 1280 --height 720 --max-keypoints 1024)")
-    ap.add_argument("--detector", default="plnet", choices=["superpoint", "plnet"],
+    ap.add_argument("--detector", default=None, choices=["superpoint", "plnet"],
                     help="plnet (default): PLNet::infer on both images (points + line branch + stage 1 + line filter, junctions on the left), the "
-                         "reference's keyframe step; superpoint: the point-only step")
+                         "reference's keyframe step; superpoint: the point-only step (the default of --workload track: what a normal frame runs with the "
+                         "shipped use_superpoint: 1, feature_detector.cc:36-41)")
+    ap.add_argument("--sequences", type=int, default=8, help="--workload seq: sequences per GPU (1 = the one-call host entries, > 1 = lock-step batches)")
+    ap.add_argument("--frames", type=int, default=200, help="--workload seq: frames per sequence")
+    ap.add_argument("--scene-len", type=int, default=40, help="--workload seq: frames per synthetic scene (a scene change forces a promotion)")
+    ap.add_argument("--sweep", action="store_true", help="--workload seq: also run S = 1, 4, 8, 16")
+    ap.add_argument("--tracking-point-rate", type=float, default=0.25, help="--workload seq: AddKeyframeCheck's tracking_point_rate (yaml: 0.65; see the workload text)")
     ap.add_argument("--plnet-host", action="store_true", help="PLNet + matcher through the batch-1 HOST API instead (PCIe and one sync per call included)")
-    ap.add_argument("--workload", default="stereo", choices=["stereo", "track", "loop", "frontend", "b1"],
-                    help="track: the NORMAL-frame step of the VO loop (map_builder.cc:94-101: Detect(left, features) = PLNet points + lines on the new "
-                         "frame, then MatchingPoints(last_keyframe, frame)); loop: matcher only, replaying a map file's feature records (loop closure, "
+    ap.add_argument("--workload", default="stereo", choices=["stereo", "track", "loop", "frontend", "b1", "seq"],
+                    help="seq: BASELINE configs[3] — whole stereo SEQUENCES driven as map_builder.cc:83-141 drives the front end (airslam_amd/seq.py); "
+                         "track: the NORMAL-frame step of the VO loop (map_builder.cc:94-101: Detect(left, features) — SuperPoint with the shipped use_superpoint: 1, "
+                         "--detector plnet for the use_superpoint: 0 form — then MatchingPoints(last_keyframe, frame)); loop: matcher only, replaying a map file's feature records (loop closure, "
                          "map_refiner.cc:213-230); b1: LATENCY of one stereo keyframe through the batch-1 host API, as the SLAM loop calls it (map_builder.cc:83-109): "
                          "p50 / p99 over --steps pairs, PLNet + LightGlue, host images in, host matrices out; frontend: the WHOLE per-keyframe front end, device-resident — rectify both raw images (camera.cc:161-182), "
                          "the stereo step, AssignPointsToLines on both frames + MatchLines with the stereo band (frame.cc:125,147-184), BoW words of the "
@@ -367,6 +519,11 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--stage-steps", type=int, default=3, help="extra untimed steps for the per-stage table")
     args = ap.parse_args()
+    args.steps_given = args.steps
+    if args.steps is None:
+        args.steps = 200
+    if args.detector is None:
+        args.detector = "superpoint" if args.workload == "track" else "plnet"
     gpus_given = args.gpus is not None
     if not gpus_given:               # `torchrun --nproc-per-node=8 bench.py` without --gpus: the launcher's world size is the answer
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
@@ -402,6 +559,8 @@ def main():
         raise SystemExit("--workload track runs the device-resident PLNet / SuperPoint + LightGlue path")
     if args.workload == "b1":
         return latency_b1(args, rank, world, local, dev)
+    if args.workload == "seq":
+        return seq_workload(args, rank, world, local, dev)
     if args.plnet_host or args.matcher == "superglue" or args.workload == "loop":
         return side_workloads(args, rank, world, local, dev)
 
@@ -585,18 +744,16 @@ def main():
         if dom:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
             traffic, tsrc = None, None
-            tf = latest_profile("hbm_traffic.json")
-            if tf:      # measured in separate --pmc passes (never together with other tracing), see profiles/README.md
-                with open(tf) as fh:
-                    rec = json.load(fh).get("conv1_fused", {})
+            tdoc, tf, tage = counter_profile("hbm_traffic.json")
+            if tdoc:      # measured in separate --pmc passes (never together with other tracing), see profiles/README.md
+                rec = tdoc.get("conv1_fused", {})
                 if rec.get("hbm_bytes_per_launch") and rec.get("images_per_launch"):      # per image x the images one launch covers in THIS run
                     traffic = rec["hbm_bytes_per_launch"] / rec["images_per_launch"] * (2.0 * B * args.steps / max(dom["launches"], 1))
                 tsrc = "profiles/" + os.path.basename(tf) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch of that kernel, scaled to this run's images per launch)"
             util, usrc = None, None
-            pf = latest_profile("pmc_summary.json")
-            if pf:      # counter-derived MFMA utilisation of the encoder kernels (separate --pmc pass, tools/pmc_summary.py)
-                with open(pf) as fh:
-                    ks = json.load(fh)["kernels"]
+            pdoc, pf, page = counter_profile("pmc_summary.json")
+            if pdoc:      # counter-derived MFMA utilisation of the encoder kernels (separate --pmc pass, tools/pmc_summary.py)
+                ks = pdoc["kernels"]
                 enc = {k: v for k, v in ks.items() if ("conv64r_kernel" in k or "conv128r_kernel" in k) and "mfma_util" in v}
                 wsum = sum(v["counters_per_launch"]["GRBM_GUI_ACTIVE"] * v["launches_sampled"] for v in enc.values())
                 if wsum > 0:
@@ -608,7 +765,11 @@ def main():
                                "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
                                "traffic": traffic, "traffic_source": tsrc,
                                "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1), "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
-                               "launches": dom["launches"]}
+                               "launches": dom["launches"],
+                               # `achieved` / `frac` are measured live in THIS run (HIP events on the launch stream); `traffic` and `mfma_util_counters` come from
+                               # committed rocprofv3 PMC passes and are reported ONLY when those passes were taken on the kernel sources this process runs:
+                               "counters_age": {"traffic": tage, "mfma_util": page,
+                                                "rule": "profile_csrc_sha == tree_csrc_sha (sha256 over csrc/*.hip, csrc/*.h, include/airfe*.h), else null"}}
         if stages:
             tot = sum(s["ms"] for s in stages.values())
             out["stages_note"] = f"separate untimed pass of {args.stage_steps} steps with every stage bracketed by events"
@@ -616,6 +777,18 @@ def main():
                                  "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] else None,
                                  "algo_gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
                              for k, v in stages.items() if v["launches"]}
+            for k, v in out["stages"].items():      # each stage against its own roof (algorithmic FLOPs or bytes of the stage / its event time / the peak)
+                if STAGE_BOUND.get(k) == "mfma" and v["tflops"]:
+                    v["bound"], v["frac"] = "mfma", v["tflops"] / PEAK_MFMA_TFLOPS
+                elif k == "plnet_stage1":
+                    v["bound"], v["frac"] = "hbm (gathers) / f32 mfma", None
+                elif v["algo_gbs"]:
+                    v["bound"], v["frac"] = "hbm", v["algo_gbs"] / PEAK_HBM_GBS
+            if out.get("roofline"):
+                # the WHOLE step against the matrix peak: algorithmic FLOPs of every matrix stage of one step / the timed ms_per_step / peak
+                fl_step = sum(v["flops"] for v in stages.values()) / args.stage_steps
+                out["roofline"]["step_frac"] = fl_step / (ms_step * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS
+                out["roofline"]["step_gflop"] = fl_step / 1e9
         if world == 1 and args.cpu_pairs > 0 and not track and not frontend:
             out["cpu_baseline"] = cpu_baseline(sp, lg, H, W, args.cpu_pairs, K, s1=weights.load_pack(s1_path) if plnet else None,
                                                gpu_nmatch=nm.cpu().numpy())

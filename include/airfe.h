@@ -153,6 +153,16 @@ int airfe_stereo_keyframe_tracked(airfe_ctx* ctx, const uint8_t* left, const uin
 int airfe_track_frame(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int stride, const float* ref_feat, int n_ref, float* feat, int cap, int* n,
                       int32_t* match_idx, float* match_score, int mcap, int* nmatch);
 
+/* PROMOTION of the frame of the last airfe_track_frame — src/map_builder.cc:104-108: AddKeyframeCheck wants the normal frame as a keyframe, so the
+ * feature thread runs Detect(image_right_rect, right_features) + MatchingPoints(left_features, right_features, stereo_matches, false) on it — as one queue:
+ * the left features are the rows airfe_track_frame left on the device.  featR / *nR = the right image's features, match_idx [mcap][2] = (left, right).
+ * Same bits as airfe_detect_points + airfe_match_lightglue on NormalizeKeypoints'ed rows.  Fails when no airfe_track_frame preceded it in this context. */
+int airfe_promote_frame(airfe_ctx* ctx, const uint8_t* right, int h, int w, int stride, float* featR, int cap, int* nR, int32_t* match_idx,
+                        float* match_score, int mcap, int* nmatch);
+/* ≙ `_last_keyframe_feature = frame` (src/map_builder.cc:139-141) for a promoted frame: the rows of the last airfe_track_frame become the reference of the
+ * following airfe_track_frame / airfe_stereo_keyframe_tracked calls (ref_feat == NULL) by a device-side copy — nothing crosses PCIe. */
+int airfe_adopt_reference(airfe_ctx* ctx);
+
 /* ≙ SuperPointLightGlue::infer (src/light_glue.cpp:120-170).  f0/f1: [n][258] rows = (x,y already normalised by
  *   PointMatcher::NormalizeKeypoints, d0..d255) — the contiguous temporary Eigen makes for bottomRows(258)
  *   at src/point_matcher.cc:67.  idx: [cap][2] (row-major, ascending in idx0), score = exp(log score). */

@@ -37,6 +37,20 @@ def test_default_workload_line():
     assert rf["bound"] in ("mfma", "hbm") and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
     assert 0.0 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert rf["traffic"] is None or rf["traffic"] > 0
+    # the line audits itself: the whole step against the matrix peak, every stage against its own roof, and counter-derived numbers only
+    # from profiles taken on the kernel sources this run executes
+    assert 0.0 < rf["step_frac"] < rf["frac"] < 1.0 and rf["step_gflop"] > 100 * 8          # >= 112 GFLOP per pair
+    for k in ("lg_gemm", "lg_attention", "conv3x3_cin64", "conv3x3_cin128"):
+        assert d["stages"][k]["bound"] == "mfma" and 0.0 < d["stages"][k]["frac"] < 1.0
+    assert d["stages"]["simple_nms"]["bound"] == "hbm" and 0.0 < d["stages"]["simple_nms"]["frac"] < 1.0
+    from airslam_amd.build import csrc_sha
+    for what, val in (("traffic", rf["traffic"]), ("mfma_util", rf["mfma_util_counters"])):
+        age = rf["counters_age"][what]
+        if age is None:
+            assert val is None
+            continue
+        assert age["tree_csrc_sha"] == csrc_sha() and age["stale"] == (age["profile_csrc_sha"] != age["tree_csrc_sha"])
+        assert (val is None) == age["stale"], f"{what}: a counter-derived number must be reported exactly when its profile was taken on this tree's kernels"
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "pairs/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
 
@@ -54,11 +68,31 @@ def test_side_workload_lines(args):
 
 
 def test_track_workload_line():
-    """the normal-frame step (map_builder.cc:94-101): 1x PLNet (points + lines) on the new frame + LightGlue against the last keyframe"""
+    """the normal-frame step (map_builder.cc:94-101) — by default what the shipped configs run on a normal frame: SuperPoint (use_superpoint: 1,
+    feature_detector.cc:36-41) + LightGlue against the last keyframe; --detector plnet is the use_superpoint: 0 form (points + lines)"""
     d = _run("--workload", "track", "--pairs", "8", "--steps", "3", "--warmup", "1")
-    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["value"] > 0 and "tracked frames" in d["metric"]
-    assert d["config"]["matches_mean"] > 50 and d["config"]["lines_mean"] >= 50 and "junctions_mean_left" not in d["config"]
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["value"] > 0 and "tracked frames" in d["metric"] and "SuperPoint" in d["metric"]
+    assert d["config"]["detector"] == "superpoint" and d["config"]["matches_mean"] > 50 and "lines_mean" not in d["config"]
+    d = _run("--workload", "track", "--detector", "plnet", "--pairs", "8", "--steps", "3", "--warmup", "1")
+    assert d["config"]["matches_mean"] > 50 and d["config"]["lines_mean"] >= 50 and "junctions_mean_left" not in d["config"] and "PLNet" in d["metric"]
     assert d["cpu_baseline"] is None if "cpu_baseline" in d else True
+
+
+def test_seq_workload_line():
+    """--workload seq (BASELINE configs[3]): S sequences driven as map_builder.cc:83-141 drives the front end — a short run of the batched driver and of the
+    one-call driver; the schedule contains keyframes, normal frames and (scenes of 10 frames) promotions"""
+    d = _run("--workload", "seq", "--sequences", "3", "--frames", "34", "--warmup", "2", "--scene-len", "10", "--cpu-pairs", "3")
+    assert d["unit"] == "frames/s" and d["steps"] == 32 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["value"] > 0
+    assert abs(d["value"] - 3 * 32 / (d["ms_per_step"] * 32 * 1e-3)) <= 1e-6 * d["value"]
+    sch = d["config"]["schedule"]
+    assert sch["frames"] == 3 * 32 and sch["keyframes"] >= 3 and sch["promotions"] >= 3 and sch["normal_frames"] >= 60 and sch["temporal_matches_mean"] >= 40
+    assert d["config"]["gather_every_frames"] == 8 and d["config"]["gathers"] == 4 and "BatchedSequences" in d["config"]["driver"]
+    lat = d["latency_ms_per_time_step"]
+    assert 0 < lat["p50"] <= lat["p99"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0
+    d1 = _run("--workload", "seq", "--sequences", "1", "--frames", "24", "--warmup", "2", "--scene-len", "10", "--cpu-pairs", "0")
+    assert "SequenceFrontEnd" in d1["config"]["driver"] and d1["config"]["schedule"]["frames"] == 22 and d1["value"] > 0
 
 
 def test_gpus_2_launches_two_ranks_itself(monkeypatch):

@@ -13,8 +13,12 @@ GRBM_GUI_ACTIVE is reported summed over the 8 XCDs; it is divided by 8 here (che
 import collections
 import json
 import re
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from airslam_amd.build import csrc_sha  # noqa: E402
 
 SIMDS = 1024
 XCDS = 8
@@ -64,7 +68,8 @@ def main(out_path, *dbs):
                     e["frac_" + nm] = c[nm] / c["SQ_WAVE_CYCLES"]
         if c.get("SQ_INSTS_MFMA") and c.get("SQ_INSTS_VALU"):
             e["valu_per_mfma"] = (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]) / c["SQ_INSTS_MFMA"]
-    doc = {"source": "rocprofv3 --pmc ... --kernel-trace (PMC passes only, never with other tracing); tools/pmc_summary.py",
+    doc = {"csrc_sha": csrc_sha(),       # the sources these counters were measured on (bench.py: roofline.counters_age)
+           "source": "rocprofv3 --pmc ... --kernel-trace (PMC passes only, never with other tracing); tools/pmc_summary.py",
            "derived": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); frac_* = share of SQ_WAVE_CYCLES",
            "kernels": kernels}
     with open(out_path, "w") as fh:

@@ -7,8 +7,12 @@ so it is doubled; WRITE_SIZE is taken as is (it matched the algorithmic output b
 import collections
 import json
 import re
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from airslam_amd.build import csrc_sha  # noqa: E402
 
 
 def per_kernel(db, counter):
@@ -36,7 +40,8 @@ def main(db_f, db_w, out, images_per_launch=128):
     dom = [v for k, v in kernels.items() if "conv64r_kernel" in k and re.search(r"conv64r_kernel<[^>]*,\s*true,\s*true", k)]   # <POOL, FUSE1A>
     nd = sum(v["launches_sampled"] for v in dom)
     totd = sum((v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches_sampled"] for v in dom)
-    doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
+    doc = {"csrc_sha": csrc_sha(),       # the sources these counters were measured on (bench.py: roofline.counters_age)
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
                      "`python bench.py --steps 2 --warmup 1 --pairs 64 --cpu-pairs 0 --no-profile`; tools/pmc_traffic.py",
            "units": "FETCH_SIZE/WRITE_SIZE are KiB; bytes = KiB*1024; FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B, "
                     "MI355X_MICROARCH.md 'HBM'); WRITE_SIZE taken as is",
