@@ -178,6 +178,7 @@ struct airfe_ctx {
   uint16_t *xb = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *ob = nullptr, *msg = nullptr, *hb = nullptr,
            *mdb = nullptr;
   int *lens = nullptr, *rowarg = nullptr, *colarg = nullptr;
+  float *lg_part = nullptr, *lg_argpart = nullptr;   // [Pmax][2][tiles][Np] float2 each: launch_lg_assign_fused
   bool has_arena = false;
 
   // SuperGlue

@@ -427,9 +427,11 @@ int alloc_matcher_arena(airfe_ctx* c) {
   c->rowval = dalloc<float>(c, (size_t)c->Pmax * Np);
   c->rowarg = dalloc<int>(c, (size_t)c->Pmax * Np);
   c->colarg = dalloc<int>(c, (size_t)c->Pmax * Np);
+  c->lg_part = dalloc<float>(c, lg_assign_part_floats(c->Pmax, Np));          // per-tile (max, sum exp) / (max, arg) partials of the fused assignment
+  c->lg_argpart = dalloc<float>(c, lg_assign_part_floats(c->Pmax, Np));
   if (!c->x32 || !c->xb || !c->qb || !c->kb || !c->vtb || !c->ob || !c->msg || !c->hb || !c->mdb || !c->rot_cos ||
       !c->rot_sin || !c->zbuf || !c->lens || !c->simbuf || !c->rowlse || !c->collse || !c->rowval || !c->rowarg ||
-      !c->colarg || !c->st_scores_full)
+      !c->colarg || !c->st_scores_full || !c->lg_part || !c->lg_argpart)
     return fail(c, "device allocation failed (matcher arena)");
   c->has_arena = true;
   return 0;

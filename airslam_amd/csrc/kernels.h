@@ -170,6 +170,12 @@ void launch_lg_assign(const float* sim, const float* z, const int* lens, int B, 
 // fault hunting (airfe_debug_trace): checksums of `units` units of `unit_words` 32-bit words each; per-slot digests
 void launch_trace_hash(const void* p, unsigned unit_words, unsigned units, unsigned long long* out, hipStream_t st);
 void launch_trace_digest(const unsigned long long* tab, const unsigned* off, int slots, unsigned long long* dig, hipStream_t st);
+// the same assignment WITHOUT the similarity matrix in HBM (kernels_lg.hip "assignment without the similarity matrix"): part / argpart = lg_assign_part_floats()
+// floats each; sim_out / scores_out only for the trace and the inspection hooks
+size_t lg_assign_part_floats(int B, int Np);
+void launch_lg_assign_fused(int prec, const uint16_t* md, const float* z, const int* lens, int B, int Np, int cap, float thr, float* part, float* argpart,
+                            float* rowlse, float* collse, float* sim_out, float* scores_out, int* rowarg, float* rowval, int* colarg, int32_t* idx,
+                            float* score, int* nmatch, hipStream_t st);
 void launch_lg_filter_scores(const float* scores, const int* lens, int B, int Np, int cap, float thr, int* rowarg, float* rowval,
                              int* colarg, int32_t* idx, float* score, int* nmatch, hipStream_t st);
 

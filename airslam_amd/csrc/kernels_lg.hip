@@ -407,6 +407,275 @@ void launch_lg_filter_scores(const float* scores, const int* lens, int B, int Np
   hipLaunchKernelGGL(lg_filter_kernel, dim3(B), dim3(1024), 0, st, lens, Np, cap, thr, rowarg, rowval, colarg, idx, score, nmatch);
 }
 
+// =============================================================================== assignment without the similarity matrix (round 5)
+// The round-2 tail wrote sim [B][Np][Np] (41 MB per 64 pairs) and read it back FOUR times (row / column log-sum-exp, row / column arg-max: 243 MB per step,
+// profiles/r04_hbm_traffic.txt).  Here the 64 x 64 similarity tile a wave holds in its MFMA accumulators is reduced where it is:
+//   launch 1 (lg_sim_lse_kernel):  per tile, per row the (max, sum exp) over the tile's valid columns and per column over its valid rows -> partials
+//                                  [B][2][nT][Np] float2 (nT = tiles per side: 7 at Np = 400) — 2.9 MB instead of 41;
+//   launch 2 (lg_sim_arg_kernel):  the tile AGAIN (same fragments, same K order: the same bits — 256-deep products from L2-resident descriptors are cheaper than
+//                                  a trip through HBM), the tiles' partials folded into rowlse / collse by each wave for its own 64 rows and columns, the
+//                                  log-assignment score of light_glue.cpp's engine tail, and per tile the first maximum of every row and column -> [B][2][nT][Np];
+//   launch 3 (lg_filter_fused_kernel): per pair the nT partial maxima folded (ties -> lowest index, like the reference's strict '>' scan), then filter_matches
+//                                  (src/light_glue.cpp:214-266) exactly as lg_filter_kernel does it.
+// Three dependent launches where large batches had six and small ones four.  The log-sum-exp is now a sum of per-tile sums instead of one 64-strided sum per
+// wave, and its exponentials are the hardware's (v_exp_f32 through __expf: 128 per lane and tile): scores move in the last bits against the round-2 form (bounded by the tests' 0.05 gate against the fp32 oracle; match sets identical), and they are
+// reproducible run to run (fixed order everywhere).  `scores_out` / `sim_out` (inspection hooks, the trace) are written only when asked for.
+struct LgTile {                                  // what both launches need of a tile: its accumulators and where it sits
+  f32x4 acc[4][4];
+  int i0, j0, b, lane, l15, g;
+};
+
+template <class P>
+__device__ __forceinline__ bool lg_tile_sim(const uint16_t* __restrict__ md, int Np, LgTile& t) {
+  t.b = blockIdx.z; t.lane = threadIdx.x & 63; t.l15 = t.lane & 15; t.g = t.lane >> 4;
+  const int wave = threadIdx.x >> 6;
+  t.i0 = (blockIdx.x * 4 + wave) * 64; t.j0 = blockIdx.y * 64;
+  if (t.i0 >= Np) return false;
+  const uint16_t* A = md + ((size_t)(2 * t.b) * Np + t.i0 + t.l15) * 256;
+  const uint16_t* Bm = md + ((size_t)(2 * t.b + 1) * Np + t.j0 + t.l15) * 256;
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) t.acc[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {               // (the loop of sim_kernel, operand for operand: the two launches and the round-2 kernel agree bit for bit)
+    typename P::vec8 af[4], bf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      af[q] = (t.i0 + q * 16 < Np) ? __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(A + (size_t)q * 16 * 256 + ks * 32 + t.g * 8)) : typename P::vec8{};
+      bf[q] = (t.j0 + q * 16 < Np) ? __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(Bm + (size_t)q * 16 * 256 + ks * 32 + t.g * 8)) : typename P::vec8{};
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) t.acc[it][jt] = P::mfma(af[it], bf[jt], t.acc[it][jt]);
+  }
+  return true;
+}
+// lane (l15, g) holds rows it * 16 + g * 4 + r and columns jt * 16 + l15 of the tile: a row lives in the 16 lanes of one g, a column in the 4 lanes l15 + 16 g'
+__device__ __forceinline__ float grp16_max(float v) { v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4)); return fmaxf(v, __shfl_xor(v, 8)); }
+__device__ __forceinline__ float grp16_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v + __shfl_xor(v, 8); }
+__device__ __forceinline__ float grp4_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float grp4_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+
+template <class P>
+__global__ __launch_bounds__(256) void lg_sim_lse_kernel(const uint16_t* __restrict__ md, const int* __restrict__ lens, int Np, int nT,
+                                                         float2* __restrict__ part, float* __restrict__ sim_out) {
+  LgTile t;
+  if (!lg_tile_sim<P>(md, Np, t)) return;
+  const int n0 = lens[2 * t.b], n1 = lens[2 * t.b + 1];
+  float2* rpart = part + (((size_t)t.b * 2 + 0) * nT + blockIdx.y) * Np;              // row partials of tile column blockIdx.y
+  float2* cpart = part + (((size_t)t.b * 2 + 1) * nT + (t.i0 >> 6)) * Np;             // column partials of tile row i0 / 64
+  bool cv[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) cv[jt] = t.j0 + jt * 16 + t.l15 < n1;
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) mx = cv[jt] ? fmaxf(mx, t.acc[it][jt][r]) : mx;
+      mx = grp16_max(mx);
+      float sm = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) sm += cv[jt] ? __expf(t.acc[it][jt][r] - mx) : 0.f;
+      sm = grp16_sum(sm);
+      const int i = t.i0 + it * 16 + t.g * 4 + r;
+      if (t.l15 == 0 && i < n0) rpart[i] = make_float2(mx, sm);
+    }
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = (t.i0 + it * 16 + t.g * 4 + r < n0) ? fmaxf(mx, t.acc[it][jt][r]) : mx;
+    mx = grp4_max(mx);
+    float sm = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sm += (t.i0 + it * 16 + t.g * 4 + r < n0) ? __expf(t.acc[it][jt][r] - mx) : 0.f;
+    sm = grp4_sum(sm);
+    const int j = t.j0 + jt * 16 + t.l15;
+    if (t.g == 0 && j < n1) cpart[j] = make_float2(mx, sm);
+  }
+  if (sim_out) {                                   // (the trace and the round-2 consumers: the matrix as sim_kernel writes it)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if (t.i0 + it * 16 >= Np) continue;
+      float* out = sim_out + ((size_t)t.b * Np + t.i0 + it * 16) * Np + t.j0;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        if (t.j0 + jt * 16 >= Np) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(t.g * 4 + r) * Np + jt * 16 + t.l15] = t.acc[it][jt][r];
+      }
+    }
+  }
+}
+
+// the nT partial (max, sum exp) of one row / column -> its log-sum-exp (tiles in ascending order; an empty set gives -inf + log 0 = NaN like the round-2 form)
+__device__ __forceinline__ float lg_fold_lse(const float2* __restrict__ p, int nT, int Np, int k, int ntile_valid) {
+  float M = -INFINITY;
+  for (int q = 0; q < ntile_valid; ++q) M = fmaxf(M, p[(size_t)q * Np + k].x);
+  float s = 0.f;
+  for (int q = 0; q < ntile_valid; ++q) {
+    const float2 v = p[(size_t)q * Np + k];
+    s += v.y * __expf(v.x - M);
+  }
+  return M + logf(s);
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void lg_sim_arg_kernel(const uint16_t* __restrict__ md, const float* __restrict__ z, const int* __restrict__ lens, int Np, int nT,
+                                                         const float2* __restrict__ part, float* __restrict__ rowlse, float* __restrict__ collse,
+                                                         float2* __restrict__ argpart, float* __restrict__ scores_out) {
+  LgTile t;
+  if (!lg_tile_sim<P>(md, Np, t)) return;
+  const int n0 = lens[2 * t.b], n1 = lens[2 * t.b + 1];
+  // log-sum-exp of this wave's 64 rows (over ALL columns < n1) and 64 columns (over all rows < n0): lane l folds row i0 + l and column j0 + l
+  const int tr = (n0 + 63) >> 6, tc = (n1 + 63) >> 6;                // tiles that hold a valid row / column
+  float rl_own = 0.f, cl_own = 0.f;
+  if (t.i0 + t.lane < n0) rl_own = lg_fold_lse(part + ((size_t)t.b * 2 + 0) * nT * Np, nT, Np, t.i0 + t.lane, tc);
+  if (t.j0 + t.lane < n1) cl_own = lg_fold_lse(part + ((size_t)t.b * 2 + 1) * nT * Np, nT, Np, t.j0 + t.lane, tr);
+  if (blockIdx.y == 0 && t.i0 + t.lane < n0) rowlse[(size_t)t.b * Np + t.i0 + t.lane] = rl_own;         // (kept for the trace / inspection: one writer per value)
+  if (t.i0 == 0 && t.j0 + t.lane < n1) collse[(size_t)t.b * Np + t.j0 + t.lane] = cl_own;
+  const float c0_own = (t.i0 + t.lane < n0) ? z[(size_t)(2 * t.b) * Np + t.i0 + t.lane] : 0.f;
+  const float c1_own = (t.j0 + t.lane < n1) ? z[(size_t)(2 * t.b + 1) * Np + t.j0 + t.lane] : 0.f;
+  float cl[4], c1[4];
+  bool cv[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    cl[jt] = __shfl(cl_own, jt * 16 + t.l15);
+    c1[jt] = __shfl(c1_own, jt * 16 + t.l15);
+    cv[jt] = t.j0 + jt * 16 + t.l15 < n1;
+  }
+  float cbest[4];
+  int cbi[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) { cbest[jt] = -FLT_MAX; cbi[jt] = 0x7FFFFFFF; }
+  float2* rarg = argpart + (((size_t)t.b * 2 + 0) * nT + blockIdx.y) * Np;
+  float2* carg = argpart + (((size_t)t.b * 2 + 1) * nT + (t.i0 >> 6)) * Np;
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = it * 16 + t.g * 4 + r, i = t.i0 + row;
+      const float rl = __shfl(rl_own, row), c0 = __shfl(c0_own, row);
+      const bool rv = i < n0;
+      float best = -FLT_MAX;                       // light_glue.cpp:219: strict '>' from -FLT_MAX, columns ascending
+      int bj = 0x7FFFFFFF;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const float sc = lg_score(t.acc[it][jt][r], rl, cl[jt], c0, c1[jt]);
+        const int j = t.j0 + jt * 16 + t.l15;
+        if (rv && cv[jt]) {
+          if (scores_out) scores_out[((size_t)t.b * Np + i) * Np + j] = sc;
+          if (sc > best) { best = sc; bj = j; }
+          if (sc > cbest[jt]) { cbest[jt] = sc; cbi[jt] = i; }       // rows ascend with (it, r) for a fixed g
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {           // first maximum of the row over the tile's 64 columns
+        const float ob = __shfl_xor(best, o);
+        const int oj = __shfl_xor(bj, o);
+        if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+      }
+      if (t.l15 == 0 && rv) rarg[i] = make_float2(best, __int_as_float(bj));
+    }
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    float best = cbest[jt];
+    int bi = cbi[jt];
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {            // first maximum of the column over the tile's 64 rows
+      const float ob = __shfl_xor(best, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    const int j = t.j0 + jt * 16 + t.l15;
+    if (t.g == 0 && j < n1) carg[j] = make_float2(best, __int_as_float(bi));
+  }
+}
+
+// one 1024-thread workgroup per pair: the tiles' partial maxima folded (first maximum: larger value, then lower index), then lg_filter_kernel's body
+__global__ __launch_bounds__(1024) void lg_filter_fused_kernel(const int* __restrict__ lens, int Np, int nT, int cap, float thr, const float2* __restrict__ argpart,
+                                                               int* __restrict__ rowarg, float* __restrict__ rowval, int* __restrict__ colarg,
+                                                               int32_t* __restrict__ idx, float* __restrict__ score, int* __restrict__ nmatch) {
+  __shared__ unsigned wsum[16];
+  __shared__ int scol[1024];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n0 = lens[2 * b], n1 = lens[2 * b + 1];
+  const int tr = (n0 + 63) >> 6, tc = (n1 + 63) >> 6;
+  auto fold = [&](int side, int k, int ntile, float& best, int& bi) {
+    best = -FLT_MAX; bi = 0x7FFFFFFF;
+    const float2* p = argpart + ((size_t)b * 2 + side) * nT * Np;
+    for (int q = 0; q < ntile; ++q) {
+      const float2 v = p[(size_t)q * Np + k];
+      const int oi = __float_as_int(v.y);
+      if (v.x > best || (v.x == best && oi < bi)) { best = v.x; bi = oi; }
+    }
+  };
+  if (tid < n1) {
+    float cb; int ci;
+    fold(1, tid, tr, cb, ci);
+    scol[tid] = (ci == 0x7FFFFFFF) ? 0 : ci;
+    colarg[(size_t)b * Np + tid] = scol[tid];
+  }
+  bool ok = false;
+  int col = 0;
+  float e = 0.f;
+  float rb = 0.f; int rj = 0x7FFFFFFF;
+  if (tid < n0) {
+    fold(0, tid, tc, rb, rj);
+    // nothing above -FLT_MAX: row_max[row] keeps its value-initialised pair (0, 0.0f) (std::vector::resize, light_glue.cpp:217)
+    col = (rj == 0x7FFFFFFF) ? 0 : rj;
+    const float val = (rj == 0x7FFFFFFF) ? 0.f : rb;
+    rowarg[(size_t)b * Np + tid] = col;
+    rowval[(size_t)b * Np + tid] = val;
+    e = expf_like_glibc(val);
+  }
+  __syncthreads();
+  if (tid < n0 && n1 > 0) ok = (scol[col] == tid) && (e > thr);      // (col < n1 whenever n1 > 0; an empty second image has no matches: point_matcher.cc:53-55)
+  const unsigned long long bal = __ballot(ok);
+  const unsigned before = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wsum[wv] = __popcll(bal);
+  __syncthreads();
+  unsigned off = 0, tot = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wv) off += wsum[w];
+    tot += wsum[w];
+  }
+  const unsigned slot = off + before;
+  if (ok && slot < (unsigned)cap) {
+    idx[((size_t)b * cap + slot) * 2] = tid;
+    idx[((size_t)b * cap + slot) * 2 + 1] = col;
+    score[(size_t)b * cap + slot] = e;
+  }
+  if (tid == 0) nmatch[b] = min((int)tot, cap);
+}
+
+size_t lg_assign_part_floats(int B, int Np) { return (size_t)B * 2 * ((Np + 63) / 64) * Np * 2; }      // floats of ONE partial array (float2 per entry)
+
+void launch_lg_assign_fused(int prec, const uint16_t* md, const float* z, const int* lens, int B, int Np, int cap, float thr, float* part, float* argpart,
+                            float* rowlse, float* collse, float* sim_out, float* scores_out, int* rowarg, float* rowval, int* colarg, int32_t* idx,
+                            float* score, int* nmatch, hipStream_t st) {
+  const int nT = (Np + 63) / 64;
+  dim3 grid((Np + 255) / 256, nT, B);
+  float2* p2 = reinterpret_cast<float2*>(part);
+  float2* a2 = reinterpret_cast<float2*>(argpart);
+  if (prec == 1) {
+    hipLaunchKernelGGL(lg_sim_lse_kernel<PF16>, grid, dim3(256), 0, st, md, lens, Np, nT, p2, sim_out);
+    hipLaunchKernelGGL(lg_sim_arg_kernel<PF16>, grid, dim3(256), 0, st, md, z, lens, Np, nT, p2, rowlse, collse, a2, scores_out);
+  } else {
+    hipLaunchKernelGGL(lg_sim_lse_kernel<PBF16>, grid, dim3(256), 0, st, md, lens, Np, nT, p2, sim_out);
+    hipLaunchKernelGGL(lg_sim_arg_kernel<PBF16>, grid, dim3(256), 0, st, md, z, lens, Np, nT, p2, rowlse, collse, a2, scores_out);
+  }
+  hipLaunchKernelGGL(lg_filter_fused_kernel, dim3(B), dim3(1024), 0, st, lens, Np, nT, cap, thr, a2, rowarg, rowval, colarg, idx, score, nmatch);
+}
+
 // =============================================================================== fault hunting: state checksums
 // Position-dependent 64-bit checksum of every `unit_words`-word unit of a buffer (airfe_debug_trace): sums are commutative, so the result
 // does not depend on how the threads are scheduled.  One workgroup per unit.

@@ -279,7 +279,7 @@ def seq_workload(args, rank, world, local, dev):
         return dict(S=S, dt=dt, frames_per_s=S * (frames - warm) * world / dt, ms_per_step=dt / (frames - warm) * 1e3,
                     latency_ms={"p50": float(np.percentile(a, 50)), "p99": float(np.percentile(a, 99)), "mean": float(a.mean()), "max": float(a.max())},
                     schedule={"frames": len(flat), "keyframe_candidates": sum(r.candidate for r in flat), "keyframes": sum(r.frame_type != seq.NORMAL for r in flat),
-                              "promotions": sum(r.promoted for r in flat), "normal_frames": sum(r.frame_type == seq.NORMAL for r in flat),
+                              "promotions": sum(r.promoted for r in flat), "normal_frames": sum(r.frame_type == seq.NORMAL for r in flat), "dropped_before_init": sum(r.dropped for r in flat),
                               "temporal_matches_mean": float(np.mean([len(r.matches_idx) for r in flat if r.matches_idx is not None] or [0])),
                               "stereo_matches_mean": float(np.mean([len(r.stereo_idx) for r in flat if r.stereo_idx is not None] or [0])),
                               "lines_mean_keyframe_left": float(np.mean([len(r.lines_left) for r in flat if r.lines_left is not None] or [0]))},

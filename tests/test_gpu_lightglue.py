@@ -361,3 +361,52 @@ def test_fused_block_tile_sizes_give_the_same_bits():
             np.testing.assert_array_equal(s, ref[0])
             np.testing.assert_array_equal(idx, ref[1])
             np.testing.assert_array_equal(sc, ref[2])
+
+
+@pytest.mark.parametrize("n0,n1", [(400, 400), (317, 400), (64, 65), (1, 5), (2, 1), (1024, 777), (129, 63)])
+def test_assignment_without_the_similarity_matrix_keeps_the_matches(n0, n1):
+    """Round 5: log-sum-exp and arg-max partials are taken inside the similarity tiles (airfe_tuning::assign_fused = 1, the default; kernels_lg.hip) instead of
+    writing sim [B][Np][Np] and reading it four times.  The log-sum-exp is then a sum of per-tile sums with hardware exponentials: the scores may move in their
+    last bits against the round-2 form, the match LISTS may not (outside rows whose decision sits within 1e-4 of a boundary — none in these inputs), and the
+    scores the kernel hands out are the ones its own arg-max saw (filter_matches of them reproduces the list exactly)."""
+    _, _, a, b = _pair(n0, n1, 500 + n0 + n1)
+    K = 1024 if max(n0, n1) > 400 else 400
+    outs = []
+    for fused in (1, 0):
+        ctx, _, _ = context("lg", tuning={"assign_fused": fused}, max_batch=2, max_keypoints=K)
+        s = ctx.lightglue_scores(a, b)
+        idx, sc = ctx.match_lightglue(a, b)
+        didx, dsc = ref_post.filter_matches(s, 0.1)
+        np.testing.assert_array_equal(idx, didx)
+        np.testing.assert_allclose(sc, dsc, rtol=2e-6)
+        outs.append((s, idx, sc))
+    (s1, i1, c1), (s0, i0, c0) = outs
+    d = float(np.abs(s1 - s0)[np.isfinite(s0)].max()) if np.isfinite(s0).any() else 0.0
+    diag(f"lg_assign_fused_vs_matrix_{n0}_{n1}", max_score_diff=d, matches=len(i1), identical=bool(np.array_equal(i1, i0)))
+    assert d <= 2e-4
+    np.testing.assert_array_equal(i1, i0)
+    np.testing.assert_allclose(c1, c0, rtol=3e-4)
+
+
+def test_assignment_partials_cover_a_batch_of_ragged_pairs():
+    """8 pairs of different lengths in one call (tiles with no valid row / column, sequences shorter than a tile): the batch entry's lists equal the
+    single-pair calls' in both assignment forms."""
+    import torch
+    for fused in (1, 0):
+        ctx, _, _ = context("lg", tuning={"assign_fused": fused}, max_batch=8)
+        B = 8
+        lens = [(400, 400), (1, 400), (400, 1), (63, 65), (64, 64), (129, 200), (399, 17), (5, 5)]
+        pairs = [_pair(n0, n1, 900 + i) for i, (n0, n1) in enumerate(lens)]
+        f0 = torch.zeros((B, 400, 259)); f1 = torch.zeros((B, 400, 259))
+        n0t = torch.tensor([p[0].shape[0] for p in pairs], dtype=torch.int32); n1t = torch.tensor([p[1].shape[0] for p in pairs], dtype=torch.int32)
+        for i, p in enumerate(pairs):
+            f0[i, :p[0].shape[0]] = torch.from_numpy(p[0]); f1[i, :p[1].shape[0]] = torch.from_numpy(p[1])
+        idx = torch.zeros((B, 400, 2), dtype=torch.int32).cuda(); sc = torch.zeros((B, 400)).cuda(); nm = torch.zeros((B,), dtype=torch.int32).cuda()
+        ctx.match_lightglue_batch_dev(f0.cuda(), n0t.cuda(), f1.cuda(), n1t.cuda(), idx, sc, nm)
+        ctx.sync()
+        for i, p in enumerate(pairs):
+            want_idx, want_sc = ctx.match_lightglue(p[2], p[3])
+            k = int(nm[i])
+            assert k == len(want_idx), (fused, i, k, len(want_idx))
+            np.testing.assert_array_equal(idx[i, :k].cpu().numpy(), want_idx)
+            np.testing.assert_array_equal(sc[i, :k].cpu().numpy(), want_sc)

@@ -20,6 +20,7 @@ HOT = {
     "kernels_ext.hip": ["sg_sinkhorn_reg_kernel", "plnet_s1_kernel", "s1_junc_proj_kernel"],
     "kernels_s0.hip": ["s0_j2l_grid_kernel", "s0_decode_kernel"],
     "kernels_nms512.hip": ["nms512_kernel"],
+    "kernels_lg.hip": ["lg_sim_lse_kernel", "lg_sim_arg_kernel"],
 }
 
 
