@@ -23,13 +23,18 @@ int fail_noexcept(airfe_ctx* c, const char* what, const char* detail) noexcept {
 }
 
 int launch_status(airfe_ctx* c) {
+  std::string m;
   if (c->launch_err.empty()) {
     const hipError_t e = hipGetLastError();
     if (e == hipSuccess) return 0;
-    return fail(c, std::string("kernel launch failed: ") + hipGetErrorString(e));
+    m = std::string("kernel launch failed: ") + hipGetErrorString(e);
+  } else {
+    m.swap(c->launch_err);
   }
-  std::string m;
-  m.swap(c->launch_err);
+  // an error path: whatever the call had queued before the failed launch (uploads from the pinned block, kernels on either stream) is drained, so that the
+  // next call starts from an idle context
+  (void)hipDeviceSynchronize();
+  (void)hipGetLastError();
   return fail(c, m);
 }
 

@@ -260,7 +260,7 @@ void fail_launch_now(hipStream_t st);            // airfe.hip: a deliberately in
 struct ProfScope {
   airfe_ctx* c; hipStream_t st; bool on; int stage; airfe_ctx::Mark m;
   ProfScope(airfe_ctx* c_, int stage_, hipStream_t st_, double flops, double bytes) : c(c_), st(st_), on((c_->prof_mask >> stage_) & 1u), stage(stage_) {
-    if (c->fail_stage == stage) { c->fail_stage = -1; fail_launch_now(st); }
+    if (c->fail_stage == stage) { c->fail_stage = -1; fail_launch_now(st); if (c->cfg.check_launches) note_launch(c, stage); }
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;

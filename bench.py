@@ -118,7 +118,7 @@ def latency_b1(args, rank, world, local, dev):
     ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234) if plnet else weights.synthetic_superpoint(1234),
                       plnet_s1=os.path.join(root, "tests", "golden", "plnet_s1.airfe") if plnet else None,
                       device=local, precision=1 if args.dtype == "fp16" else 0, matcher_precision=1 if args.matcher_dtype == "fp16" else 0,
-                      max_batch=2, enc_chunk=2, max_keypoints=K, image_width=W, image_height=H, matcher=1 if sg else 0,
+                      max_batch=2, enc_chunk=2, max_keypoints=K, image_width=W, image_height=H, matcher=1 if sg else 0, tuning=args.tuning,
                       **(dict(superglue=mw) if sg else dict(lightglue=mw)))
     det, pm = api.FeatureDetector(ctx), api.PointMatcher(ctx, W, H, 1 if sg else 0)
     pairs = [synth.stereo_pair(H, W, 1000 + i) for i in range(8)]
@@ -227,7 +227,7 @@ def seq_workload(args, rank, world, local, dev):
     prec, mprec = (1 if args.dtype == "fp16" else 0), (1 if args.matcher_dtype == "fp16" else 0)
 
     def run(S):
-        common = dict(device=local, precision=prec, matcher_precision=mprec, max_keypoints=K, image_width=W, image_height=H)
+        common = dict(device=local, precision=prec, matcher_precision=mprec, max_keypoints=K, image_width=W, image_height=H, tuning=args.tuning)
         kf = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=s1_path, lightglue=lg, max_batch=max(S, 2), enc_chunk=max(min(2 * S, args.chunk), 2), **common)
         nf = api.Context(superpoint=weights.synthetic_superpoint(1234), lightglue=lg, max_batch=max(S, 2), enc_chunk=max(min(S, args.chunk), 2), **common)
         gat = seq.MatchGatherer(KG, S, K, dev)
@@ -337,7 +337,7 @@ def side_workloads(args, rank, world, local, dev):
     mprec = 1 if args.matcher_dtype == "fp16" else 0
     sg = args.matcher == "superglue"
     cfg = dict(device=local, precision=prec, matcher_precision=mprec, max_batch=B, enc_chunk=min(args.chunk, B), max_keypoints=K,
-               image_width=W, image_height=H, matcher=1 if sg else 0)
+               image_width=W, image_height=H, matcher=1 if sg else 0, tuning=args.tuning)
     mw = weights.synthetic_superglue(1234) if sg else weights.synthetic_lightglue(1234)
     mkw = dict(superglue=mw) if sg else dict(lightglue=mw)
     n_match = [0.0]
@@ -516,9 +516,11 @@ def main():
                          "p50 / p99 over --steps pairs, PLNet + LightGlue, host images in, host matrices out; frontend: the WHOLE per-keyframe front end, device-resident — rectify both raw images (camera.cc:161-182), "
                          "the stereo step, AssignPointsToLines on both frames + MatchLines with the stereo band (frame.cc:125,147-184), BoW words of the "
                          "left features (bow/database.cc:57-89)")
+    ap.add_argument("--tuning", default="", help="airfe_tuning overrides for A/B runs, e.g. assign_fused=0,overlap_lines=0 (include/airfe.h)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--stage-steps", type=int, default=3, help="extra untimed steps for the per-stage table")
     args = ap.parse_args()
+    args.tuning = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tuning.split(",") if kv} or None
     args.steps_given = args.steps
     if args.steps is None:
         args.steps = 200
@@ -570,7 +572,7 @@ def main():
     lg = weights.synthetic_lightglue(1234)
     ctx = api.Context(superpoint=sp, lightglue=lg, plnet_s1=s1_path if plnet else None, device=local, precision=1 if args.dtype == "fp16" else 0,
                       matcher_precision=1 if args.matcher_dtype == "fp16" else 0, max_batch=B,
-                      enc_chunk=args.chunk, max_keypoints=K, image_width=W, image_height=H)
+                      enc_chunk=args.chunk, max_keypoints=K, image_width=W, image_height=H, tuning=args.tuning)
 
     ls, rs = synth.stereo_batch(B, H, W, 1000 + rank)
     L, R = torch.from_numpy(ls).to(dev), torch.from_numpy(rs).to(dev)
@@ -713,6 +715,8 @@ def main():
                        "matches_mean": float(nm.float().mean()), "detector": args.detector},
             "collective": args.collective,
         }
+        if args.tuning:
+            out["config"]["tuning"] = args.tuning
         if track:
             out["config"]["workload"] = (f"{B} synthetic {W}x{H} uint8 frames per step per GPU, resident in HBM, each matched against its last keyframe's "
                                          f"features (map_builder.cc:94-101); max_keypoints={K}; seeded synthetic weights (reference ONNX files are absent)")
