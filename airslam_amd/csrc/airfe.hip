@@ -38,6 +38,17 @@ int launch_status(airfe_ctx* c) {
   return fail(c, m);
 }
 
+int saturation_status(airfe_ctx* c) {
+  if (!c->sat_host) return 0;
+  const int v0 = reinterpret_cast<volatile int*>(c->sat_host)[0], v1 = reinterpret_cast<volatile int*>(c->sat_host)[1];
+  if (!v0 && !v1) return 0;
+  c->sat_host[0] = c->sat_host[1] = 0;
+  return fail(c, std::string("the detector's 2-byte activations left the ") + (c->prec == 1 ? "fp16" : "bf16") + " range (" + (v0 ? "non-finite score logits" : "") +
+                     (v0 && v1 ? ", " : "") + (v1 ? "non-finite descriptors" : "") +
+                     "): no keypoints are returned for this call.  Re-pack the detector weights with airslam_amd.weights.fold_activation_scales "
+                     "(tools/onnx_to_pack.py does it: exact power-of-two rescaling between layers) or run cfg.precision = 2");
+}
+
 }  // namespace airfe_host
 
 void note_launch(airfe_ctx* c, int stage) {
@@ -234,9 +245,14 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) try {
   if (!rc && cfg->plnet_s1_pack) rc = load_plnet_s1(c, cfg->plnet_s1_pack);
   if (!rc) {
     const size_t capf = (size_t)c->Np * AIRFE_FEAT_DIM;
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->sat_host), 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&c->sat_flag), c->sat_host, 0) != hipSuccess)
+      c->sat_flag = nullptr;
+    else
+      memset(c->sat_host, 0, 64);
     c->io_in = dalloc<uint8_t>(c, 64 + 2 * capf * 4);
     c->io_out = dalloc<uint8_t>(c, 64 + (size_t)c->Np * 12);
-    if (!c->io_in || !c->io_out) rc = fail(c, "device allocation failed (staging)");
+    if (!c->io_in || !c->io_out || !c->sat_flag) rc = fail(c, "device allocation failed (staging)");
     else {
       c->st_n0 = reinterpret_cast<int*>(c->io_in);
       c->st_n1 = c->st_n0 + 1;
@@ -266,6 +282,7 @@ void airfe_destroy(airfe_ctx* c) {
   c->kf_graph.reset();
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
+  if (c->sat_host) (void)hipHostFree(c->sat_host);
   for (auto& m : c->marks) { (void)hipEventDestroy(m.a); (void)hipEventDestroy(m.b); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -358,12 +375,14 @@ static int sinkhorn_failed(airfe_ctx* c);
 int airfe_sync(airfe_ctx* c) try {
   AIRFE_ENTER(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return sinkhorn_failed(c);         // (the batch entry points are asynchronous: a Sinkhorn time-out of an earlier call surfaces here)
+  if (saturation_status(c)) return 1;                     // (the batch entry points are asynchronous: an activation overflow of an earlier call surfaces here)
+  return sinkhorn_failed(c);         // (... and a Sinkhorn time-out)
 } AIRFE_CATCH(c)
 
 int airfe_superglue_status(airfe_ctx* c, void* stream) try {
   AIRFE_ENTER(c);
   HIPCHK(c, hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+  if (saturation_status(c)) return 1;
   return sinkhorn_failed(c);
 } AIRFE_CATCH(c)
 
@@ -383,6 +402,7 @@ int airfe_detect_points(airfe_ctx* c, const uint8_t* gray, int h, int w, int str
   if (ensure_pin(c, out_bytes)) return 1;
   HIPCHK(c, hipMemcpyAsync(c->pin, c->io_in, out_bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (saturation_status(c)) return 1;
   const int nn = std::min(*reinterpret_cast<const int*>(c->pin), c->cfg.max_keypoints);
   if (nn > 0) memcpy(feat, c->pin + 64, (size_t)nn * AIRFE_FEAT_DIM * 4);
   *n = nn;
@@ -489,6 +509,7 @@ int airfe_rectify_detect_points(airfe_ctx* c, int side, const uint8_t* raw, int 
   }
   if (rect_out) HIPCHK(c, hipMemcpyAsync(rect_out, c->st_rect, (size_t)h * w, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (feat && saturation_status(c)) return 1;
   if (feat && nn > 0) HIPCHK(c, hipMemcpy(feat, c->st_feat0, (size_t)nn * AIRFE_FEAT_DIM * 4, hipMemcpyDeviceToHost));
   if (n) *n = nn;
   return 0;
@@ -819,6 +840,7 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
     HIPCHK(c, hipMemcpyAsync(cnt + 2, njf_d, 4, hipMemcpyDeviceToHost, st));
   }
   HIPCHK(c, hipStreamSynchronize(st));
+  if (saturation_status(c)) return 1;
   const int nn = std::min(*reinterpret_cast<const int*>(c->pin), c->cfg.max_keypoints);
   if (nn > 0) memcpy(feat, c->pin + 64, (size_t)nn * AIRFE_FEAT_DIM * 4);
   *n = nn;
@@ -1081,6 +1103,7 @@ static int stereo_keyframe_impl(airfe_ctx* c, const uint8_t* left, const uint8_t
   if (n1 > 0) memcpy(featR, c->pin + 64 + fb, (size_t)n1 * AIRFE_FEAT_DIM * 4);
   *nL = n0; *nR = n1;
   if (!replay) HIPCHK(c, hipStreamSynchronize(st));
+  if (saturation_status(c)) { *nL = *nR = 0; return 1; }
   const int* hc = reinterpret_cast<const int*>(c->pin + early);
   const int nl0 = hc[2], nl1 = hc[3], nm = std::min(hc[10], Np), nj = hc[5];
   const int fl0 = hc[6], fl1 = hc[7], fj = hc[8];
@@ -1196,6 +1219,7 @@ int airfe_track_frame(airfe_ctx* c, const uint8_t* gray, int h, int w, int strid
   *n = nn;
   HIPCHK(c, hipStreamSynchronize(st));
   drain.armed = false;
+  if (saturation_status(c)) { *n = 0; return 1; }
   c->tk_n = nn;                                                      // (airfe_promote_frame / airfe_adopt_reference work on these rows)
   if (nn < 1 || c->ref_n < 1) return 0;                              // point_matcher.cc:53-55
   const int nm = std::min(reinterpret_cast<const int*>(c->pin + early)[2], Np);
@@ -1251,6 +1275,7 @@ int airfe_promote_frame(airfe_ctx* c, const uint8_t* right, int h, int w, int st
   *nR = nn;
   HIPCHK(c, hipStreamSynchronize(st));
   drain.armed = false;
+  if (saturation_status(c)) { *nR = 0; return 1; }
   if (nn < 1 || c->tk_n < 1) return 0;                               // point_matcher.cc:53-55
   const int nm = std::min(reinterpret_cast<const int*>(c->pin + early)[2], Np);
   if (nm > 0) {

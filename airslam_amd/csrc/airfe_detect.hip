@@ -143,7 +143,7 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
       g.M = cells; g.N = 65; g.cb_total = c->cPb.cbt; g.epi = EPI_STORE_F32; g.out = c->logits; g.ldo = 72;
       g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
       // soft-max + depth-to-space in the GEMM's epilogue, at EVERY batch size (one summation order): no logits in memory
-      g.epi = EPI_SOFTMAX_D2S; g.out = c->heat; g.d2s_hc = R / 8; g.d2s_wc = R / 8;
+      g.epi = EPI_SOFTMAX_D2S; g.out = c->heat; g.d2s_hc = R / 8; g.d2s_wc = R / 8; g.flag = c->sat_flag;
       ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 65, (double)cells * (512 + 256));
       launch_gemm8(c->prec, 256, false, g, st);
     }
@@ -197,10 +197,10 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
     ProfScope ps(c, ST_SAMPLE, st, 0, (double)Bh * c->cfg.max_keypoints * (4096 + 1036));
     if (sparse_desc)
       launch_sample_desc(c->desc + (size_t)b0 * cap * 4 * 256, Bh, R / 8, R / 8, half ? d_feat1 : d_feat, half ? d_n1 : d_n, cap, (float)w / (float)R,
-                         (float)h / (float)R, 1, st, 1);
+                         (float)h / (float)R, 1, st, 1, c->sat_flag);
     else
       launch_sample_desc(c->desc + (size_t)b0 * (R / 8) * (R / 8) * 256, Bh, R / 8, R / 8, half ? d_feat1 : d_feat, half ? d_n1 : d_n, cap,
-                         (float)w / (float)R, (float)h / (float)R, c->desc_normalised ? 0 : 1, st);
+                         (float)w / (float)R, (float)h / (float)R, c->desc_normalised ? 0 : 1, st, 0, c->sat_flag);
   }
   return launch_status(c);
 }

@@ -85,6 +85,8 @@ struct airfe_ctx {
   std::string err;
   std::string launch_err;        // cfg.check_launches: the first failed launch since the last report, with its stage's name (launch_status())
   int fail_stage = -1;           // airfe_debug_fail_next_launch: the next ProfScope of this stage makes a deliberately invalid launch first (tests)
+  int *sat_host = nullptr, *sat_flag = nullptr;   // two words of host-mapped, coherent memory (and their device address): [0] = non-finite detector logits, [1] = non-finite
+                                 // sampled descriptor — written by the head / sampling kernels only when the 2-byte activations overflowed, read by the host after its synchronisation: no copy
   bool fuse_dec = true;          // airfe_tuning::fuse_dec
   int assign_fused = 1;          // airfe_tuning::assign_fused
   hipStream_t stream = nullptr;
@@ -296,6 +298,9 @@ int fail_noexcept(airfe_ctx* c, const char* what, const char* detail) noexcept; 
 // 0 when no launch failed since the last report; else the context's error = "<stage>: kernel launch failed: <hip error>" and 1.  With
 // cfg.check_launches every stage's launches are looked at as the stage ends (ProfScope); without it this is one hipGetLastError().
 int launch_status(airfe_ctx* c);
+// Reads and clears the detector's saturation words (after the caller's synchronisation): non-zero -> the context's error says that the 2-byte activations left the
+// fp16 / bf16 range and 1 is returned — never keypoints of a poisoned score map.
+int saturation_status(airfe_ctx* c);
 
 template <class T>
 T* dalloc(airfe_ctx* c, size_t n, bool zero = true) {

@@ -42,6 +42,7 @@ struct GemmArgs {
   int gr_wgs = 256;              // its persistent workgroups (tests lower it so that a small batch wraps the DMA ring)
   const int* rowidx = nullptr;   // gemm8 only: row r of the GEMM reads X1 row rowidx[r] (a gather; [M] entries)
   int d2s_hc = 0, d2s_wc = 0;    // EPI_SOFTMAX_D2S: cells per image column / row
+  int* flag = nullptr;           // EPI_SOFTMAX_D2S: flag[0] = 1 when a cell's logits are not finite — the 2-byte activations upstream left their range
 };
 
 // out[M][N] = X[M][K] * W^T ; K in {128,256,512}; trans => EPI_HEADS_T (operand roles swapped)
@@ -126,8 +127,9 @@ void launch_select_list(const unsigned long long* cand, const int* cand_cnt, int
                         float* feat, int* n_out, hipStream_t st);
 // bilinear descriptor sampling + L2 norm (plnet.cpp:369-417), then x,y *= (w_scale,h_scale)
 //   desc fp32 [B][HC][WC][256]
+// flag (may be NULL): flag[1] = 1 when a sampled descriptor is not finite (2-byte activations upstream left their range)
 void launch_sample_desc(const float* desc, int B, int HC, int WC, float* feat, const int* n, int cap,
-                        float w_scale, float h_scale, int normalise, hipStream_t st, int compact = 0);
+                        float w_scale, float h_scale, int normalise, hipStream_t st, int compact = 0, int* flag = nullptr);
 // idx[(b * cap + k) * 4 + tap] = row (b0 + b) * HC * WC + cell of the dense head input that keypoint k of image b samples (k >= n[b]: 0):
 // the row list of the descriptor head's gather GEMM; compact = 1 in launch_sample_desc reads that GEMM's output
 void launch_desc_cells(const float* feat, const int* n, int cap, int B, int b0, int HC, int WC, int* idx, hipStream_t st);

@@ -237,7 +237,7 @@ static void gemm8_launch_t(int K, const GemmArgs& a, hipStream_t st) {
 template <class P>
 __global__ __launch_bounds__(256, 3) void head_softmax_d2s_kernel(const uint16_t* __restrict__ X /*[ncell][256]*/, const uint16_t* __restrict__ Wp,
                                                                   const float* __restrict__ bias /*[65..]*/, float* __restrict__ heat, int ntiles,
-                                                                  int hc, int wc) {
+                                                                  int hc, int wc, int* __restrict__ flag) {
   __shared__ __attribute__((aligned(16))) char wl[5 * 8 * 1024];      // [tile u][k-step][lane] 16-byte fragments
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
   {
@@ -310,6 +310,9 @@ __global__ __launch_bounds__(256, 3) void head_softmax_d2s_kernel(const uint16_t
       }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
+    // a cell whose logits are inf / NaN (its sum of exponentials is then not a finite number): the 2-byte activations upstream overflowed — the host entries turn
+    // the flag into an ERROR instead of handing out keypoints of a poisoned score map (one compare per cell; airfe.h "activation range")
+    if (flag && g == 0 && !(sum <= 3.0e38f)) *reinterpret_cast<volatile int*>(flag) = 1;      // (host-mapped word: written only when it happens)
     const float inv = 1.0f / sum;
     const int b = row / per, rem = row - b * per, cy = rem / wc, cx = rem - cy * wc;
     float* o = heat + ((size_t)b * hc * 8 + (size_t)cy * 8) * (wc * 8) + cx * 8;
@@ -331,8 +334,8 @@ void launch_gemm8(int prec, int K, bool trans, const GemmArgs& a, hipStream_t st
     }
     const int ntiles = a.M / 16;
     const int wgs = std::min((ntiles + 3) / 4, 256 * 4);      // persistent: four 4-wave workgroups per CU (40 KB of LDS each)
-    if (prec == 1) hipLaunchKernelGGL(head_softmax_d2s_kernel<PF16>, dim3(wgs), dim3(256), 0, st, a.X1, a.Wp, a.bias, reinterpret_cast<float*>(a.out), ntiles, a.d2s_hc, a.d2s_wc);
-    else hipLaunchKernelGGL(head_softmax_d2s_kernel<PBF16>, dim3(wgs), dim3(256), 0, st, a.X1, a.Wp, a.bias, reinterpret_cast<float*>(a.out), ntiles, a.d2s_hc, a.d2s_wc);
+    if (prec == 1) hipLaunchKernelGGL(head_softmax_d2s_kernel<PF16>, dim3(wgs), dim3(256), 0, st, a.X1, a.Wp, a.bias, reinterpret_cast<float*>(a.out), ntiles, a.d2s_hc, a.d2s_wc, a.flag);
+    else hipLaunchKernelGGL(head_softmax_d2s_kernel<PBF16>, dim3(wgs), dim3(256), 0, st, a.X1, a.Wp, a.bias, reinterpret_cast<float*>(a.out), ntiles, a.d2s_hc, a.d2s_wc, a.flag);
     return;
   }
   if (prec == 1) {

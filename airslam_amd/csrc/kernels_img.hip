@@ -1,6 +1,8 @@
 // airfe — image-side kernels: cv::resize-compatible pre-process, conv1a (Cin = 1), detector heads
 // (softmax-65 + depth-to-space, descriptor L2 norm, simple_nms), exact top-K keypoint selection and
 // bilinear descriptor sampling.  All HBM-bound; written for coalesced 16-byte lanes.
+#include <float.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -271,7 +273,7 @@ __global__ void desc_cells_kernel(const float* __restrict__ feat, const int* __r
 __global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restrict__ desc, int HC, int WC,
                                                           float* __restrict__ feat, const int* __restrict__ n, int cap,
                                                           float sx, float bx, float sy, float by, float w_scale,
-                                                          float h_scale, int normalise, int compact) {
+                                                          float h_scale, int normalise, int compact, int* __restrict__ flag) {
   const int b = blockIdx.y, k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (k >= n[b]) return;
   float* f = feat + ((size_t)b * cap + k) * 259;
@@ -313,6 +315,7 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restric
   }
   ss = wave_sum(ss);
   const float nrm = sqrtf(ss);
+  if (flag && lane == 0 && !(ss <= FLT_MAX)) *reinterpret_cast<volatile int*>(flag + 1) = 1;      // inf / NaN descriptor: the detector's 2-byte activations overflowed (airfe.h, "activation range")
   // Eigen (>= 3.3) colwise().normalize(): `if (squaredNorm() > 0) v /= sqrt(squaredNorm())` — a zero column stays zero, no NaN
 #pragma unroll
   for (int j = 0; j < 4; ++j) f[3 + lane * 4 + j] = (ss > 0.f) ? v[j] / nrm : v[j];
@@ -329,11 +332,11 @@ static void desc_grid_coeffs(int HC, int WC, float& sx, float& bx, float& sy, fl
 }
 
 void launch_sample_desc(const float* desc, int B, int HC, int WC, float* feat, const int* n, int cap, float w_scale,
-                        float h_scale, int normalise, hipStream_t st, int compact) {
+                        float h_scale, int normalise, hipStream_t st, int compact, int* flag) {
   float sx, bx, sy, by;
   desc_grid_coeffs(HC, WC, sx, bx, sy, by);
   hipLaunchKernelGGL(sample_desc_kernel, dim3((cap + 3) / 4, B), dim3(256), 0, st, desc, HC, WC, feat, n, cap, sx, bx,
-                     sy, by, w_scale, h_scale, normalise, compact);
+                     sy, by, w_scale, h_scale, normalise, compact, flag);
 }
 
 void launch_desc_cells(const float* feat, const int* n, int cap, int B, int b0, int HC, int WC, int* idx, hipStream_t st) {

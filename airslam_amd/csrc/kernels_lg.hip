@@ -452,55 +452,98 @@ __device__ __forceinline__ bool lg_tile_sim(const uint16_t* __restrict__ md, int
   }
   return true;
 }
-// lane (l15, g) holds rows it * 16 + g * 4 + r and columns jt * 16 + l15 of the tile: a row lives in the 16 lanes of one g, a column in the 4 lanes l15 + 16 g'
-__device__ __forceinline__ float grp16_max(float v) { v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4)); return fmaxf(v, __shfl_xor(v, 8)); }
-__device__ __forceinline__ float grp16_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v + __shfl_xor(v, 8); }
-__device__ __forceinline__ float grp4_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
-__device__ __forceinline__ float grp4_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+// lane (l15, g) holds rows it * 16 + g * 4 + r and columns jt * 16 + l15 of the tile: a row lives in the 16 lanes of one g, a column in the 4 lanes l15 + 16 g'.
+// Reductions are TRANSPOSING butterflies: with 16 per-row partials in each of a group's 16 lanes, step 1 exchanges 8 of them with lane ^ 8, step 2 four with lane ^ 4,
+// ... — 15 exchanges instead of the 64 of a value-by-value butterfly (the first build of these kernels: 0.17 ms per 64 pairs against the matrix form's 0.14,
+// profiles/r05_assign_ab.txt), and the group ends with lane l15 holding row (l15 >> 2, l15 & 3) complete: all 64 lanes store one row each.  Columns: 4 per lane, two
+// steps across the four g's, lane g ends with column jt = g.
+struct MS { float m, s; };                                   // a partial log-sum-exp: max and sum of exp(v - max)
+__device__ __forceinline__ MS ms_merge(MS a, MS b) {
+  const float m = fmaxf(a.m, b.m);
+  // (an empty side has m = -inf, s = 0: exp(-inf - m) = 0 unless both are empty, where 0 * exp(nan) must stay 0)
+  const float ea = a.s > 0.f ? a.s * __expf(a.m - m) : 0.f, eb = b.s > 0.f ? b.s * __expf(b.m - m) : 0.f;
+  return MS{m, ea + eb};
+}
+struct BA { float v; int i; };                               // a partial first maximum: value and index (ties -> lower index)
+__device__ __forceinline__ BA ba_merge(BA a, BA b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+__device__ __forceinline__ MS xchg(MS x, int mask) { return MS{__shfl_xor(x.m, mask), __shfl_xor(x.s, mask)}; }
+__device__ __forceinline__ BA xchg(BA x, int mask) { return BA{__shfl_xor(x.v, mask), __shfl_xor(x.i, mask)}; }
+__device__ __forceinline__ MS merge(MS a, MS b) { return ms_merge(a, b); }
+__device__ __forceinline__ BA merge(BA a, BA b) { return ba_merge(a, b); }
+// v[16] (index rho = it * 4 + r) in each of a group's 16 lanes -> the complete reduction of rho = l15 in lane l15
+// (one template instance per step: every register index is a compile-time constant — a runtime `half` put the arrays into scratch)
+template <int HALF, class T>
+__device__ __forceinline__ void reduce_step(T (&v)[16], int l15) {
+  const bool up = (l15 & HALF) != 0;
+#pragma unroll
+  for (int k = 0; k < HALF; ++k) {
+    const T send = up ? v[k] : v[k + HALF], keep = up ? v[k + HALF] : v[k];
+    v[k] = merge(keep, xchg(send, HALF));
+  }
+}
+template <class T>
+__device__ __forceinline__ T reduce_rows16(T (&v)[16], int l15) {
+  reduce_step<8>(v, l15);
+  reduce_step<4>(v, l15);
+  reduce_step<2>(v, l15);
+  reduce_step<1>(v, l15);
+  return v[0];
+}
+// v[4] (index jt) in each of the 4 lanes l15 + 16 g -> the complete reduction of jt = g in lane g
+template <class T>
+__device__ __forceinline__ T reduce_cols4(T (&v)[4], int g) {
+  {
+    const bool up = (g & 2) != 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const T send = up ? v[k] : v[k + 2], keep = up ? v[k + 2] : v[k];
+      v[k] = merge(keep, xchg(send, 32));
+    }
+  }
+  const bool up = (g & 1) != 0;
+  const T send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
+  return merge(keep, xchg(send, 16));
+}
 
 template <class P>
-__global__ __launch_bounds__(256) void lg_sim_lse_kernel(const uint16_t* __restrict__ md, const int* __restrict__ lens, int Np, int nT,
+__global__ __launch_bounds__(256, 2) void lg_sim_lse_kernel(const uint16_t* __restrict__ md, const int* __restrict__ lens, int Np, int nT,
                                                          float2* __restrict__ part, float* __restrict__ sim_out) {
   LgTile t;
   if (!lg_tile_sim<P>(md, Np, t)) return;
   const int n0 = lens[2 * t.b], n1 = lens[2 * t.b + 1];
   float2* rpart = part + (((size_t)t.b * 2 + 0) * nT + blockIdx.y) * Np;              // row partials of tile column blockIdx.y
   float2* cpart = part + (((size_t)t.b * 2 + 1) * nT + (t.i0 >> 6)) * Np;             // column partials of tile row i0 / 64
-  bool cv[4];
+  bool cv[4], rv[16];
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) cv[jt] = t.j0 + jt * 16 + t.l15 < n1;
 #pragma unroll
-  for (int it = 0; it < 4; ++it)
+  for (int q = 0; q < 16; ++q) rv[q] = t.i0 + (q >> 2) * 16 + t.g * 4 + (q & 3) < n0;
+  MS rows[16], cols[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float mx = -INFINITY;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) mx = cv[jt] ? fmaxf(mx, t.acc[it][jt][r]) : mx;
-      mx = grp16_max(mx);
-      float sm = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) sm += cv[jt] ? __expf(t.acc[it][jt][r] - mx) : 0.f;
-      sm = grp16_sum(sm);
-      const int i = t.i0 + it * 16 + t.g * 4 + r;
-      if (t.l15 == 0 && i < n0) rpart[i] = make_float2(mx, sm);
-    }
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
+  for (int q = 0; q < 16; ++q) {                             // this lane's 4 columns of row q
     float mx = -INFINITY;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mx = (t.i0 + it * 16 + t.g * 4 + r < n0) ? fmaxf(mx, t.acc[it][jt][r]) : mx;
-    mx = grp4_max(mx);
+    for (int jt = 0; jt < 4; ++jt) mx = cv[jt] ? fmaxf(mx, t.acc[q >> 2][jt][q & 3]) : mx;
     float sm = 0.f;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sm += (t.i0 + it * 16 + t.g * 4 + r < n0) ? __expf(t.acc[it][jt][r] - mx) : 0.f;
-    sm = grp4_sum(sm);
-    const int j = t.j0 + jt * 16 + t.l15;
-    if (t.g == 0 && j < n1) cpart[j] = make_float2(mx, sm);
+    for (int jt = 0; jt < 4; ++jt) sm += cv[jt] ? __expf(t.acc[q >> 2][jt][q & 3] - mx) : 0.f;
+    rows[q] = MS{mx, sm};
   }
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {                           // this lane's 16 rows of column jt
+    float mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) mx = rv[q] ? fmaxf(mx, t.acc[q >> 2][jt][q & 3]) : mx;
+    float sm = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sm += rv[q] ? __expf(t.acc[q >> 2][jt][q & 3] - mx) : 0.f;
+    cols[jt] = MS{mx, sm};
+  }
+  const MS rr = reduce_rows16(rows, t.l15);
+  const MS cc = reduce_cols4(cols, t.g);
+  const int i = t.i0 + (t.l15 >> 2) * 16 + t.g * 4 + (t.l15 & 3), j = t.j0 + t.g * 16 + t.l15;
+  if (i < n0) rpart[i] = make_float2(rr.m, rr.s);
+  if (j < n1) cpart[j] = make_float2(cc.m, cc.s);
   if (sim_out) {                                   // (the trace and the round-2 consumers: the matrix as sim_kernel writes it)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -516,88 +559,80 @@ __global__ __launch_bounds__(256) void lg_sim_lse_kernel(const uint16_t* __restr
   }
 }
 
-// the nT partial (max, sum exp) of one row / column -> its log-sum-exp (tiles in ascending order; an empty set gives -inf + log 0 = NaN like the round-2 form)
-__device__ __forceinline__ float lg_fold_lse(const float2* __restrict__ p, int nT, int Np, int k, int ntile_valid) {
-  float M = -INFINITY;
-  for (int q = 0; q < ntile_valid; ++q) M = fmaxf(M, p[(size_t)q * Np + k].x);
-  float s = 0.f;
-  for (int q = 0; q < ntile_valid; ++q) {
+// the partial (max, sum exp) of one row / column over its `ntile` valid tiles -> its log-sum-exp (tiles in ascending order; an empty set gives -inf like the round-2 form)
+__device__ __forceinline__ float lg_fold_lse(const float2* __restrict__ p, int Np, int k, int ntile) {
+  MS a{-INFINITY, 0.f};
+  for (int q = 0; q < ntile; ++q) {
     const float2 v = p[(size_t)q * Np + k];
-    s += v.y * __expf(v.x - M);
+    a = ms_merge(a, MS{v.x, v.y});
   }
-  return M + logf(s);
+  return a.m + logf(a.s);
 }
 
 template <class P>
-__global__ __launch_bounds__(256) void lg_sim_arg_kernel(const uint16_t* __restrict__ md, const float* __restrict__ z, const int* __restrict__ lens, int Np, int nT,
+__global__ __launch_bounds__(256, 2) void lg_sim_arg_kernel(const uint16_t* __restrict__ md, const float* __restrict__ z, const int* __restrict__ lens, int Np, int nT,
                                                          const float2* __restrict__ part, float* __restrict__ rowlse, float* __restrict__ collse,
                                                          float2* __restrict__ argpart, float* __restrict__ scores_out) {
+  __shared__ __attribute__((aligned(16))) float sv[4][4][64];         // per wave: rowlse, z0 of its 64 rows; collse, z1 of its 64 columns
   LgTile t;
   if (!lg_tile_sim<P>(md, Np, t)) return;
-  const int n0 = lens[2 * t.b], n1 = lens[2 * t.b + 1];
-  // log-sum-exp of this wave's 64 rows (over ALL columns < n1) and 64 columns (over all rows < n0): lane l folds row i0 + l and column j0 + l
+  const int n0 = lens[2 * t.b], n1 = lens[2 * t.b + 1], wave = threadIdx.x >> 6;
+  // log-sum-exp of this wave's 64 rows (over ALL columns < n1) and 64 columns (over all rows < n0): lane l folds row i0 + l and column j0 + l, the wave's LDS block
+  // hands them to the lanes that need them (wave-private: no workgroup barrier, a wave whose rows lie beyond Np has left already)
   const int tr = (n0 + 63) >> 6, tc = (n1 + 63) >> 6;                // tiles that hold a valid row / column
   float rl_own = 0.f, cl_own = 0.f;
-  if (t.i0 + t.lane < n0) rl_own = lg_fold_lse(part + ((size_t)t.b * 2 + 0) * nT * Np, nT, Np, t.i0 + t.lane, tc);
-  if (t.j0 + t.lane < n1) cl_own = lg_fold_lse(part + ((size_t)t.b * 2 + 1) * nT * Np, nT, Np, t.j0 + t.lane, tr);
+  if (t.i0 + t.lane < n0) rl_own = lg_fold_lse(part + ((size_t)t.b * 2 + 0) * nT * Np, Np, t.i0 + t.lane, tc);
+  if (t.j0 + t.lane < n1) cl_own = lg_fold_lse(part + ((size_t)t.b * 2 + 1) * nT * Np, Np, t.j0 + t.lane, tr);
   if (blockIdx.y == 0 && t.i0 + t.lane < n0) rowlse[(size_t)t.b * Np + t.i0 + t.lane] = rl_own;         // (kept for the trace / inspection: one writer per value)
   if (t.i0 == 0 && t.j0 + t.lane < n1) collse[(size_t)t.b * Np + t.j0 + t.lane] = cl_own;
-  const float c0_own = (t.i0 + t.lane < n0) ? z[(size_t)(2 * t.b) * Np + t.i0 + t.lane] : 0.f;
-  const float c1_own = (t.j0 + t.lane < n1) ? z[(size_t)(2 * t.b + 1) * Np + t.j0 + t.lane] : 0.f;
-  float cl[4], c1[4];
+  sv[wave][0][t.lane] = rl_own;
+  sv[wave][1][t.lane] = (t.i0 + t.lane < n0) ? z[(size_t)(2 * t.b) * Np + t.i0 + t.lane] : 0.f;
+  sv[wave][2][t.lane] = cl_own;
+  sv[wave][3][t.lane] = (t.j0 + t.lane < n1) ? z[(size_t)(2 * t.b + 1) * Np + t.j0 + t.lane] : 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float rl[16], c0[16], cl[4], c1[4];
   bool cv[4];
 #pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const float4 a = *reinterpret_cast<const float4*>(&sv[wave][0][it * 16 + t.g * 4]), b = *reinterpret_cast<const float4*>(&sv[wave][1][it * 16 + t.g * 4]);
+    rl[4 * it] = a.x; rl[4 * it + 1] = a.y; rl[4 * it + 2] = a.z; rl[4 * it + 3] = a.w;
+    c0[4 * it] = b.x; c0[4 * it + 1] = b.y; c0[4 * it + 2] = b.z; c0[4 * it + 3] = b.w;
+  }
+#pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
-    cl[jt] = __shfl(cl_own, jt * 16 + t.l15);
-    c1[jt] = __shfl(c1_own, jt * 16 + t.l15);
+    cl[jt] = sv[wave][2][jt * 16 + t.l15];
+    c1[jt] = sv[wave][3][jt * 16 + t.l15];
     cv[jt] = t.j0 + jt * 16 + t.l15 < n1;
   }
-  float cbest[4];
-  int cbi[4];
+  BA rows[16], cols[4];
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt) { cbest[jt] = -FLT_MAX; cbi[jt] = 0x7FFFFFFF; }
+  for (int jt = 0; jt < 4; ++jt) cols[jt] = BA{-FLT_MAX, 0x7FFFFFFF};
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int it = q >> 2, r = q & 3, i = t.i0 + it * 16 + t.g * 4 + r;
+    const bool rv = i < n0;
+    BA best{-FLT_MAX, 0x7FFFFFFF};                 // light_glue.cpp:219: strict '>' from -FLT_MAX, columns ascending
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const float sc = lg_score(t.acc[it][jt][r], rl[q], cl[jt], c0[q], c1[jt]);
+      const int j = t.j0 + jt * 16 + t.l15;
+      if (rv && cv[jt]) {
+        if (scores_out) scores_out[((size_t)t.b * Np + i) * Np + j] = sc;
+        if (sc > best.v) best = BA{sc, j};
+        if (sc > cols[jt].v) cols[jt] = BA{sc, i};                   // rows ascend with q for a fixed g
+      }
+    }
+    rows[q] = best;
+  }
+  const BA rr = reduce_rows16(rows, t.l15);        // first maximum of a row over the tile's 64 columns: lane l15 ends with row (l15 >> 2, l15 & 3)
+  const BA cc = reduce_cols4(cols, t.g);           // ... of a column over the tile's 64 rows: lane g ends with column jt = g
   float2* rarg = argpart + (((size_t)t.b * 2 + 0) * nT + blockIdx.y) * Np;
   float2* carg = argpart + (((size_t)t.b * 2 + 1) * nT + (t.i0 >> 6)) * Np;
-#pragma unroll
-  for (int it = 0; it < 4; ++it)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = it * 16 + t.g * 4 + r, i = t.i0 + row;
-      const float rl = __shfl(rl_own, row), c0 = __shfl(c0_own, row);
-      const bool rv = i < n0;
-      float best = -FLT_MAX;                       // light_glue.cpp:219: strict '>' from -FLT_MAX, columns ascending
-      int bj = 0x7FFFFFFF;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const float sc = lg_score(t.acc[it][jt][r], rl, cl[jt], c0, c1[jt]);
-        const int j = t.j0 + jt * 16 + t.l15;
-        if (rv && cv[jt]) {
-          if (scores_out) scores_out[((size_t)t.b * Np + i) * Np + j] = sc;
-          if (sc > best) { best = sc; bj = j; }
-          if (sc > cbest[jt]) { cbest[jt] = sc; cbi[jt] = i; }       // rows ascend with (it, r) for a fixed g
-        }
-      }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {           // first maximum of the row over the tile's 64 columns
-        const float ob = __shfl_xor(best, o);
-        const int oj = __shfl_xor(bj, o);
-        if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
-      }
-      if (t.l15 == 0 && rv) rarg[i] = make_float2(best, __int_as_float(bj));
-    }
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    float best = cbest[jt];
-    int bi = cbi[jt];
-#pragma unroll
-    for (int o = 16; o < 64; o <<= 1) {            // first maximum of the column over the tile's 64 rows
-      const float ob = __shfl_xor(best, o);
-      const int oi = __shfl_xor(bi, o);
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
-    const int j = t.j0 + jt * 16 + t.l15;
-    if (t.g == 0 && j < n1) carg[j] = make_float2(best, __int_as_float(bi));
-  }
+  const int i = t.i0 + (t.l15 >> 2) * 16 + t.g * 4 + (t.l15 & 3), j = t.j0 + t.g * 16 + t.l15;
+  if (i < n0) rarg[i] = make_float2(rr.v, __int_as_float(rr.i));
+  if (j < n1) carg[j] = make_float2(cc.v, __int_as_float(cc.i));
 }
 
 // one 1024-thread workgroup per pair: the tiles' partial maxima folded (first maximum: larger value, then lower index), then lg_filter_kernel's body

@@ -185,6 +185,76 @@ def _whiten_descriptor_head(w: Dict[str, np.ndarray], seed: int, lam: float = 1.
     w["convDb.bias"] = (A @ (w["convDb.bias"].astype(np.float64) - mean)).astype(np.float32)
 
 
+# --------------------------------------------------------------------------- fp16 activation range
+FP16_MAX = 65504.0
+ACT_TARGET = 2048.0      # where fold_activation_scales puts the calibration maximum of a layer it has to touch: 2^11, a factor 32 below the fp16 maximum
+
+_TRUNK = ("conv1a", "conv1b", None, "conv2a", "conv2b", None, "conv3a", "conv3b", None, "conv4a", "conv4b")
+
+
+def activation_maxima(w: Dict[str, np.ndarray], images=None, size: int = 512) -> Dict[str, float]:
+    """max |activation| behind every ReLU conv of the detector (trunk, convPa / convDa, line.conv1) over calibration images, fp32 on the CPU (torch as plumbing).
+    images: uint8 [h, w] arrays; default = three synthetic frames.  The network's 2-byte storage (cfg.precision 0 / 1) holds these values:
+    fp16 overflows to inf above 65504 (the reference builds its stage-0 engine with kTF32 — an 8-bit exponent — and the rest with kFP16, src/plnet.cpp:205,216)."""
+    import torch
+    import torch.nn.functional as Fn
+
+    from . import synth
+    if images is None:
+        images = [synth.gabor_image(480, 752, 4321 + i) for i in range(3)]
+    out: Dict[str, float] = {}
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(w[k], dtype=np.float32))
+    with torch.no_grad():
+        for img in images:
+            x = Fn.interpolate(torch.from_numpy(np.asarray(img, np.float32) / np.float32(255.0))[None, None], size=(size, size), mode="bilinear", align_corners=False)
+            taps = {}
+            for name in _TRUNK:
+                if name is None:
+                    x = Fn.max_pool2d(x, 2, 2)
+                    continue
+                x = Fn.relu(Fn.conv2d(x, t(name + ".weight"), t(name + ".bias"), padding=1))
+                taps[name] = x
+                out[name] = max(out.get(name, 0.0), float(x.abs().max()))
+            for name, src in (("convPa", "conv4b"), ("convDa", "conv4b"), ("line.conv1", "conv3a")):
+                if name + ".weight" in w:
+                    y = Fn.relu(Fn.conv2d(taps[src], t(name + ".weight"), t(name + ".bias"), padding=1))
+                    out[name] = max(out.get(name, 0.0), float(y.abs().max()))
+    return out
+
+
+def fold_activation_scales(w: Dict[str, np.ndarray], images=None, limit: float = ACT_TARGET, target: float = ACT_TARGET):
+    """Keep every 2-byte activation of the detector inside the fp16 range WITHOUT changing the function the network computes: a ReLU network is positively
+    homogeneous, so layer L may hand on c_L x its activations (c_L a power of two) if the next layer's weights are divided by c_L — power-of-two factors are exact in
+    fp32 and fp16 alike, max-pool commutes with them, and the factors are undone where the fp32 heads take over:
+        W_L' = W_L c_L / c_(L-1),  b_L' = b_L c_L         (trunk, convPa, convDa, line.conv1)
+        convPb' = convPb / c_Pa,  convDb' = convDb / c_Da,  line.head' = line.head / c_line.conv1      (biases unchanged: logits, descriptors, line maps as before)
+    c_L = 2^k is chosen from calibration maxima (activation_maxima): 1 while a layer's maximum is <= `limit` (a trained network: nothing is touched), else the power
+    of two that puts it at or below `target`.  -> (new pack, report {layer: (calibration max, c_L)}).  tools/onnx_to_pack.py applies it to every detector pack."""
+    mx = activation_maxima(w, images)
+    c: Dict[str, float] = {}
+    for name, m in mx.items():
+        c[name] = 1.0 if (m <= limit or not np.isfinite(m) or m <= 0) else float(2.0 ** np.floor(np.log2(target / m)))
+    return rescale_activations(w, c), {k: (mx[k], c[k]) for k in mx}
+
+
+def rescale_activations(w: Dict[str, np.ndarray], c: Dict[str, float]) -> Dict[str, np.ndarray]:
+    """The re-parameterisation behind fold_activation_scales: layer L hands on c[L] x its activations (powers of two; a layer absent from `c` keeps factor 1),
+    undone at the fp32 heads — the same function, other intermediate magnitudes.  (tests/ use it the other way round: factors ABOVE 1 make a healthy pack overflow.)"""
+    out = {k: np.array(v, dtype=np.float32, copy=True) for k, v in w.items()}
+    prev = {"conv1a": None, "conv1b": "conv1a", "conv2a": "conv1b", "conv2b": "conv2a", "conv3a": "conv2b", "conv3b": "conv3a", "conv4a": "conv3b", "conv4b": "conv4a",
+            "convPa": "conv4b", "convDa": "conv4b", "line.conv1": "conv3a"}
+    f = lambda k: float(c.get(k, 1.0)) if k else 1.0
+    for name, p in prev.items():
+        if name + ".weight" not in out:
+            continue
+        out[name + ".weight"] = (out[name + ".weight"] * np.float32(f(name) / f(p))).astype(np.float32)
+        out[name + ".bias"] = (out[name + ".bias"] * np.float32(f(name))).astype(np.float32)
+    for head, src in (("convPb", "convPa"), ("convDb", "convDa"), ("line.head", "line.conv1")):
+        if head + ".weight" in out:
+            out[head + ".weight"] = (out[head + ".weight"] / np.float32(f(src))).astype(np.float32)
+    return out
+
+
 _SP_CACHE: Dict[Tuple[int, bool], Dict[str, np.ndarray]] = {}
 
 

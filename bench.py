@@ -223,7 +223,7 @@ def seq_workload(args, rank, world, local, dev):
     Ld, Rd = torch.from_numpy(Lh).to(dev), torch.from_numpy(Rh).to(dev)          # resident in HBM before the clock starts (Smax x frames x 0.72 MB)
     s1_path = os.path.join(ROOT, "tests", "golden", "plnet_s1.airfe")
     lg = weights.synthetic_lightglue(1234)
-    pol = seq.KeyframeConfig(image_width=W, image_height=H, tracking_point_rate=args.tracking_point_rate)
+    pol = seq.KeyframeConfig(image_width=W, image_height=H, tracking_point_rate=args.tracking_point_rate, min_init_stereo_feature=args.min_init_stereo)
     prec, mprec = (1 if args.dtype == "fp16" else 0), (1 if args.matcher_dtype == "fp16" else 0)
 
     def run(S):
@@ -293,7 +293,7 @@ def seq_workload(args, rank, world, local, dev):
         from oracle import ref_seq
         torch.set_num_threads(min(os.cpu_count() or 1, 32))
         chain = ref_seq.Chain(weights.synthetic_plnet_s0(1234), weights.synthetic_superpoint(1234), weights.load_pack(s1_path), lg, W, H, K,
-                              policy=dict(tracking_point_rate=args.tracking_point_rate))
+                              policy=dict(tracking_point_rate=args.tracking_point_rate, min_init_stereo_feature=args.min_init_stereo))
         nfr = min(args.cpu_pairs + 2, frames)
         ts, types = [], []
         for t in range(nfr):
@@ -314,8 +314,9 @@ def seq_workload(args, rank, world, local, dev):
                "data": "synthetic", "latency_ms_per_time_step": head["latency_ms"],
                "config": {"workload": f"{args.sequences} synthetic {W}x{H} stereo sequence(s) per GPU x {frames} frames (seeds 10 + rank * S + s, a new scene every {scene_len} frames, "
                                       f"2-3 px pan per frame), images resident in HBM" + (" and in host memory (S = 1 goes through the batch-1 host entries: PCIe included)" if args.sequences == 1 else "")
-                                      + f"; keyframe policy = AddKeyframeCheck of vo_euroc.yaml with tracking_point_rate {args.tracking_point_rate} (the synthetic matcher weights match ~35 % "
-                                      f"of the keypoints; 0.65 would make every second frame a keyframe); max_keypoints={K}; seeded synthetic weights except PLNet stage 1 (real)",
+                                      + f"; keyframe policy = AddKeyframeCheck of vo_euroc.yaml with tracking_point_rate {args.tracking_point_rate} and min_init_stereo_feature {args.min_init_stereo} "
+                                      f"(the synthetic matcher weights match ~35 % of the keypoints; the yaml's 0.65 / 90 would make every second frame a keyframe candidate and leave "
+                                      f"some sequences uninitialised for a scene); max_keypoints={K}; seeded synthetic weights except PLNet stage 1 (real)",
                           "sequences_per_gpu": args.sequences, "frames": frames, "gather_every_frames": KG, "gathers": head["gathers"], "schedule": head["schedule"],
                           "driver": "airslam_amd.seq.SequenceFrontEnd (one-call host entries)" if args.sequences == 1 else "airslam_amd.seq.BatchedSequences (*_batch_dev entries)"},
                "sweep": {str(S): {"frames_per_s": r["frames_per_s"], "ms_per_time_step": r["ms_per_step"], "latency_ms": r["latency_ms"], "schedule": r["schedule"]} for S, r in runs.items()},
@@ -506,7 +507,9 @@ def main():
     ap.add_argument("--frames", type=int, default=200, help="--workload seq: frames per sequence")
     ap.add_argument("--scene-len", type=int, default=40, help="--workload seq: frames per synthetic scene (a scene change forces a promotion)")
     ap.add_argument("--sweep", action="store_true", help="--workload seq: also run S = 1, 4, 8, 16")
-    ap.add_argument("--tracking-point-rate", type=float, default=0.25, help="--workload seq: AddKeyframeCheck's tracking_point_rate (yaml: 0.65; see the workload text)")
+    ap.add_argument("--tracking-point-rate", type=float, default=0.2, help="--workload seq: AddKeyframeCheck's tracking_point_rate (yaml: 0.65; see the workload text)")
+    ap.add_argument("--min-init-stereo", type=int, default=60, help="--workload seq: min_init_stereo_feature (yaml: 90 of ~400 trained-matcher stereo matches; the synthetic "
+                                                                     "matcher finds ~130 per pair, of which some sequences keep 80-90 inside the camera's band: they would stay uninitialised for a whole scene)")
     ap.add_argument("--plnet-host", action="store_true", help="PLNet + matcher through the batch-1 HOST API instead (PCIe and one sync per call included)")
     ap.add_argument("--workload", default="stereo", choices=["stereo", "track", "loop", "frontend", "b1", "seq"],
                     help="seq: BASELINE configs[3] — whole stereo SEQUENCES driven as map_builder.cc:83-141 drives the front end (airslam_amd/seq.py); "

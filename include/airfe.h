@@ -11,6 +11,10 @@
  *   - feature rows are 259 contiguous floats [score, x, y, d0..d255]: byte-identical to one COLUMN of the
  *     reference's column-major Eigen::Matrix<float,259,Dynamic> (include/feature_detector.h:8-31), so the
  *     C++ shim does features.resize(259,n) + one memcpy.
+ *   - activation range: with 2-byte detector storage (cfg.precision 0 / 1) an activation above 65504 (fp16) overflows.  Weight packs made by tools/onnx_to_pack.py
+ *     are rescaled between layers by exact powers of two (airslam_amd.weights.fold_activation_scales) so that calibration maxima sit at <= 2048; if a frame still
+ *     drives the score logits or a sampled descriptor to inf / NaN, the host entries FAIL for that call (airfe_last_error says so) and the asynchronous *_dev
+ *     entries report it through airfe_sync / airfe_superglue_status — keypoints of a poisoned score map are never handed out.  cfg.precision = 2 has fp32 range.
  *   - *_dev entry points take DEVICE pointers and an optional hipStream_t (NULL = the ctx stream); they are
  *     asynchronous.  They have no reference counterpart (the reference is batch-1, host buffers only).
  */

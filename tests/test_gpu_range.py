@@ -1,0 +1,104 @@
+"""Storage ranges under hostile weights.
+(a) Detector: a pack whose 2-byte activations overflow fp16 must FAIL the call ("left the fp16 range"), never return keypoints of a poisoned score map; the same pack
+    after weights.fold_activation_scales (what tools/onnx_to_pack.py applies) must reproduce the oracle under the usual gates.
+(b) LightGlue: LayerNorm gains up to 10x, 30x outlier channels in ffn.0, a wider log-assignment range — fp16 error against the fp32 oracle next to the CPU emulation
+    of the device's rounding points (tools/lg_precision_bisect.py), match sets identical outside the rows the oracle decides within the measured error."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from airslam_amd import api, synth, weights
+from conftest import GOLDEN, ROOT
+from gpu_common import cosine_dist, diag
+from hostile import hostile_detector, hostile_lightglue
+
+pytestmark = pytest.mark.gpu
+
+
+def test_overflowing_activations_fail_the_call_instead_of_poisoning_it():
+    import torch
+    img = synth.gabor_image(480, 752, 7)
+    ctx = api.Context(superpoint=hostile_detector(), plnet_s1=os.path.join(GOLDEN, "plnet_s1.airfe"), lightglue=weights.synthetic_lightglue(1234, n_layers=2),
+                      max_batch=2, enc_chunk=2, precision=1)
+    with pytest.raises(api.AirfeError, match="left the fp16 range"):
+        ctx.detect_points(img)
+    with pytest.raises(api.AirfeError, match="left the fp16 range"):
+        ctx.detect_plnet(img, None, want_junctions=True)
+    left, right = synth.stereo_pair(480, 752, 1000)
+    with pytest.raises(api.AirfeError, match="left the fp16 range"):
+        ctx.stereo_keyframe(left, right)
+    # the asynchronous batch entry reports it at the next airfe_sync
+    L = torch.from_numpy(np.stack([img, img])).cuda()
+    feat = torch.zeros((2, 400, 259), device="cuda"); n = torch.zeros((2,), dtype=torch.int32, device="cuda")
+    ctx.detect_batch_dev(L, feat, n)
+    with pytest.raises(api.AirfeError, match="left the fp16 range"):
+        ctx.sync()
+    ctx.sync()                                                     # reported once, cleared
+    ctx.close()
+    # the fp32 mode has the range: same pack, the healthy network's keypoints (the re-parameterisation is exact in fp32)
+    c32 = api.Context(superpoint=hostile_detector(), max_batch=1, precision=2)
+    ref = api.Context(superpoint=weights.synthetic_plnet_s0(1234), max_batch=1, precision=2)
+    a, b = c32.detect_points(img), ref.detect_points(img)
+    assert a.shape == b.shape and a.shape[0] > 100
+    np.testing.assert_array_equal(a[:, 1:3], b[:, 1:3])
+    c32.close(); ref.close()
+
+
+def test_folded_scales_bring_the_hostile_detector_back_inside_the_gates():
+    from oracle import ref_nets, ref_post
+    hostile = hostile_detector()
+    folded, rep = weights.fold_activation_scales(hostile)
+    ctx = api.Context(superpoint=folded, max_batch=2, enc_chunk=2, precision=1)
+    img = synth.gabor_image(480, 752, 0)
+    feat = ctx.detect_points(img)
+    x, ws, hs = ref_post.process_image(img)
+    oh, od = ref_nets.superpoint_forward(hostile, x[None])         # the oracle runs the UNFOLDED pack: the function is the same
+    ref = ref_post.keypoints_decoder(ref_post.simple_nms(oh[0], 4), od[0], 0.004, 4, 400, ws, hs)
+    d2 = (feat[:, None, 1] / ws - ref[None, :, 1] / ws) ** 2 + (feat[:, None, 2] / hs - ref[None, :, 2] / hs) ** 2
+    near = d2.min(1) <= 1.0 + 1e-6
+    cd = cosine_dist(feat[near, 3:], ref[d2.argmin(1)[near], 3:])
+    heat, _, _ = ctx.detector_maps(1)
+    diag("range_folded_detector", factors=str({k: c for k, (m, c) in rep.items()}), calibration_max=str({k: round(m, 1) for k, (m, c) in rep.items()}),
+         n_dev=feat.shape[0], n_ref=ref.shape[0], frac_within_1px=near.mean(), desc_cos_max=cd.max(), heat_err_max=float(np.abs(heat[0] - oh[0]).max()))
+    assert feat.shape[0] > 100 and near.mean() >= 0.99 and cd.max() <= 1e-3
+    assert np.abs(heat[0] - oh[0]).max() <= 0.01 * oh.max() + 1e-3
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,kw", [("outlier_channels_30x", dict(outliers=8, outlier_gain=30.0)), ("layernorm_gains_to_3x", dict(ln_gain=3.0)),
+                                     ("layernorm_gains_to_10x", dict(ln_gain=10.0)), ("logit_range_x3", dict(logit_gain=3.0)),
+                                     ("all_three", dict(ln_gain=10.0, outliers=8, outlier_gain=30.0, logit_gain=3.0))])
+def test_lightglue_fp16_under_hostile_weight_statistics(name, kw):
+    from oracle import ref_nets, ref_post
+    from planted import decision_margins, fragile_rows, normalised, planted_pair
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lg_precision_bisect as bisect
+    w = hostile_lightglue(**kw)
+    f0, f1 = planted_pair(400, 400, 1600)
+    a, b = np.ascontiguousarray(normalised(f0)[:, 1:]), np.ascontiguousarray(normalised(f1)[:, 1:])
+    ka = (a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
+    ref = ref_nets.lightglue_forward(w, *ka)
+    emu = bisect.lightglue_forward_q(w, *ka, fmt="fp16")           # the device's ten rounding points, on the CPU
+    ctx = api.Context(lightglue=w, max_batch=2, matcher_precision=1, check_launches=1)
+    s = ctx.lightglue_scores(a, b)
+    idx, sc = ctx.match_lightglue(a, b)
+    ctx.close()
+    assert np.isfinite(s).all(), "fp16 storage overflowed inside the matcher"
+    near = ref > -20.0                                             # the entries a decision can depend on (the threshold is log 0.1 = -2.3)
+    err_all, err_near = float(np.abs(s - ref).max()), float(np.abs(s - ref)[near].max()) if near.any() else 0.0
+    emu_all, emu_near = float(np.abs(emu - ref).max()), float(np.abs(emu - ref)[near].max()) if near.any() else 0.0
+    ridx, _ = ref_post.filter_matches(ref, 0.1)
+    tol = max(0.05, err_near)
+    frag = fragile_rows(ref, tol)
+    dev = {tuple(p) for p in idx.tolist()}
+    rows = sorted({p[0] for p in dev ^ {tuple(q) for q in ridx}})
+    margins = decision_margins(ref)
+    diag(f"range_lg_{name}", score_range=[float(ref.min()), float(ref.max())], oracle_matches=len(ridx), device_matches=len(idx), err_max=err_all, err_max_near_decisions=err_near,
+         emulated_err_max=emu_all, emulated_err_near_decisions=emu_near, inside_the_0p05_gate=bool(err_near <= 0.05), fragile_rows=len(frag),
+         rows_decided_differently=len(rows), their_margins=[float(margins[r]) for r in rows])
+    assert {p for p in dev if p[0] not in frag} == {tuple(p) for p in ridx if p[0] not in frag}, "match sets differ outside the rows decided within the measured error"
+    assert all(margins[r] <= 2 * max(err_near, 1e-6) for r in rows), "a row decided differently has an oracle margin above twice the measured error"
+    assert err_all <= 3.0 * emu_all + 0.05 and err_near <= 3.0 * emu_near + 0.05, "the device is further from the oracle than its own rounding points explain"
+    assert len(frag) <= max(3, int(0.05 * max(len(ridx), 1)))

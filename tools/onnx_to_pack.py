@@ -151,6 +151,11 @@ def convert(kind: str, onnx_path: str, out_path: str) -> None:
         for name, shape, cands in missing:
             print(f"unplaced: {name} {shape} candidates={cands}", file=sys.stderr)
         raise SystemExit(f"{len(missing)} tensors could not be matched; write a name map for this export")
+    if kind in ("superpoint", "plnet_s0") and "conv1a.weight" in out:
+        # fp16 activation range (include/airfe.h "activation range"): layers whose calibration maxima exceed 2048 hand on a power-of-two fraction of their
+        # activations, undone at the fp32 heads — exact, and a no-op for a network whose activations are already small (every layer reports factor 1)
+        out, report = weights.fold_activation_scales(out)
+        print("activation maxima over the calibration frames -> power-of-two factors: " + ", ".join(f"{k} {m:.3g} x{c:g}" for k, (m, c) in report.items()))
     weights.save_pack(out_path, out)
     print(f"{out_path}: {len(out)} tensors, {sum(v.size for v in out.values())} parameters")
 
