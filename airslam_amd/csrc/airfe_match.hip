@@ -274,15 +274,16 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   if (slack_words) trace(c, st, "x32slack", LF, "final", c->x32 + (size_t)M * 256, slack_words, 4096);
   TRACE_HALT;
   // the assignment tail in a scope of its own: its stage's launch status is noted before trace_finish looks at it
+  const bool fused_assign = c->assign_fused == 1 || (c->assign_fused < 0 && B > 8);      // (measured both ways on one box: profiles/r05_assign_ab.txt)
   const int tail = [&]() -> int {
     // algorithmic: the similarity product (fused form: twice) and, round-2 form, the matrix written once and read four times / fused form, the descriptors + partials
-    ProfScope ps(c, ST_LG_ASSIGN, st, (c->assign_fused ? 4.0 : 2.0) * B * Np * (double)Np * 256,
-                 c->assign_fused ? (double)B * Np * (2.0 * 512 + 4.0 * 8 * ((Np + 63) / 64)) : (double)B * Np * Np * 4 * 6);
+    ProfScope ps(c, ST_LG_ASSIGN, st, (fused_assign ? 4.0 : 2.0) * B * Np * (double)Np * 256,
+                 fused_assign ? (double)B * Np * (2.0 * 512 + 4.0 * 8 * ((Np + 63) / 64)) : (double)B * Np * Np * 4 * 6);
 #define TAIL_HALT do { if (c->trace_halt) return 2; } while (0)
     launch_rowdot256(c->x32, c->lg_mw, c->lg_mb, c->zbuf, M, st);
     trace(c, st, "z", LF, "final", c->zbuf, (size_t)M, 16);
     TAIL_HALT;
-    if (c->assign_fused) {        // no similarity matrix in HBM: log-sum-exp and arg-max partials are taken in the similarity tiles (kernels_lg.hip)
+    if (fused_assign) {           // no similarity matrix in HBM: log-sum-exp and arg-max partials are taken in the similarity tiles (kernels_lg.hip)
       launch_lg_assign_fused(c->mprec, c->mdb, c->zbuf, c->lens, B, Np, mcap, 0.1f, c->lg_part, c->lg_argpart, c->rowlse, c->collse,
                              c->trace_on ? c->simbuf : nullptr, scores_out, c->rowarg, c->rowval, c->colarg, d_idx, d_score, d_nmatch, st);
       trace(c, st, "sim", LF, "final", c->simbuf, (size_t)B * Np * Np, 16u * (unsigned)Np);

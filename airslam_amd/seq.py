@@ -236,7 +236,9 @@ class BatchedSequences:
         self.pr, self.pnr = z(S, K, 259), z(S, dt=i32)
         self.pidx, self.psc, self.pnm = z(S, K, 2, dt=i32), z(S, K), z(S, dt=i32)
         self.stream = torch.cuda.Stream(device=dev)
+        self.stream_k = torch.cuda.Stream(device=dev)      # the keyframe candidates' PLNet batch runs here, beside the normal frames' SuperPoint batch on `stream`
         self.syncs = 0
+        self.t_queue = self.t_wait = self.t_host = 0.0      # where a time-step's wall time goes: queueing device work, waiting for it, the host side of the loop
         # pinned host twins of everything the host side of the loop reads: queued as asynchronous copies, read after ONE stream synchronisation
         self._pin = {k: torch.empty(getattr(self, k).shape, dtype=getattr(self, k).dtype).pin_memory() for k in (
             "cur", "cur_n", "kr", "knr", "klines", "knlines", "kjunc", "knjunc", "kidx", "ksc", "knm", "kfound", "tidx", "tsc", "tnm", "pr", "pnr", "pidx", "psc", "pnm")}
@@ -255,17 +257,24 @@ class BatchedSequences:
         kset = [i for i in range(S) if out[i].candidate]
         nset = [i for i in range(S) if not out[i].candidate]
         tset = [i for i in range(S) if self.states[i].init]
-        with t.cuda.stream(self.stream):
-            if kset:          # keyframe candidates: PLNet on both images + the stereo match, one batch (map_builder.cc:85-86)
+        import time as _time
+        t_a = _time.perf_counter()
+        if kset:              # keyframe candidates: PLNet on both images + the stereo match, one batch (map_builder.cc:85-86) — on its own stream, beside the
+            with t.cuda.stream(self.stream_k):             # normal frames' batch (the two contexts share nothing; they join before the temporal match)
+                self.stream_k.wait_stream(self.stream)     # (the previous step's reference update ran on `stream`)
                 nk, ks = len(kset), self._sel(kset)
                 Lk, Rk = L.index_select(0, ks), R.index_select(0, ks)
                 self.kf.stereo_plnet_batch_dev(Lk, Rk, self.kl[:nk], self.kr[:nk], self.knl[:nk], self.knr[:nk], self.klines[:2 * nk], self.knlines[:2 * nk],
-                                               self.kjunc[:nk], self.knjunc[:nk], self.kidx[:nk], self.ksc[:nk], self.knm[:nk], self.kfound[:3 * nk], stream=sh)
+                                               self.kjunc[:nk], self.knjunc[:nk], self.kidx[:nk], self.ksc[:nk], self.knm[:nk], self.kfound[:3 * nk],
+                                               stream=self.stream_k.cuda_stream)
                 self.cur.index_copy_(0, ks, self.kl[:nk]); self.cur_n.index_copy_(0, ks, self.knl[:nk])
+        with t.cuda.stream(self.stream):
             if nset:          # normal frames: SuperPoint on the left image, one batch (:94)
                 nn_, ns = len(nset), self._sel(nset)
                 self.nf.detect_batch_dev(L.index_select(0, ns), self.nfeat[:nn_], self.nn[:nn_], stream=sh)
                 self.cur.index_copy_(0, ns, self.nfeat[:nn_]); self.cur_n.index_copy_(0, ns, self.nn[:nn_])
+            if kset:
+                self.stream.wait_stream(self.stream_k)
             if tset:          # the temporal match of every initialised sequence, one LightGlue batch (:100-101)
                 nt, ts = len(tset), self._sel(tset)
                 self.tref[:nt] = self.ref.index_select(0, ts); self.tref_n[:nt] = self.ref_n.index_select(0, ts)
@@ -281,7 +290,9 @@ class BatchedSequences:
             if tset:
                 nt = len(tset)
                 h_t = [self._home(k, nt) for k in ("tidx", "tsc", "tnm")]
+        t_b = _time.perf_counter()
         self.stream.synchronize()
+        t_c = _time.perf_counter()
         self.syncs += 1
         for i in range(S):
             out[i].features_left = h_cur[i, :h_cur_n[i]].copy()
@@ -317,7 +328,10 @@ class BatchedSequences:
                 self.nf.match_lightglue_batch_dev(self.tcur[:npz], self.tcur_n[:npz], self.pr[:npz], self.pnr[:npz], self.pidx[:npz], self.psc[:npz], self.pnm[:npz],
                                                   stream=sh)
                 h_p = [self._home(k, npz) for k in ("pr", "pnr", "pidx", "psc", "pnm")]
+            t_p0 = _time.perf_counter()
             self.stream.synchronize()
+            self.t_wait += _time.perf_counter() - t_p0
+            t_c += _time.perf_counter() - t_p0             # (the promotion's wait is not host time)
             self.syncs += 1
             pr, pnr, pidx, psc, pnm = h_p
             for j, i in enumerate(pset):
@@ -339,6 +353,9 @@ class BatchedSequences:
             with t.cuda.stream(self.stream):
                 ks = self._sel(newkf)
                 self.ref.index_copy_(0, ks, self.cur.index_select(0, ks)); self.ref_n.index_copy_(0, ks, self.cur_n.index_select(0, ks))
+        self.t_queue += t_b - t_a
+        self.t_wait += t_c - t_b
+        self.t_host += _time.perf_counter() - t_c
         return out
 
 

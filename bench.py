@@ -223,7 +223,8 @@ def seq_workload(args, rank, world, local, dev):
     Ld, Rd = torch.from_numpy(Lh).to(dev), torch.from_numpy(Rh).to(dev)          # resident in HBM before the clock starts (Smax x frames x 0.72 MB)
     s1_path = os.path.join(ROOT, "tests", "golden", "plnet_s1.airfe")
     lg = weights.synthetic_lightglue(1234)
-    pol = seq.KeyframeConfig(image_width=W, image_height=H, tracking_point_rate=args.tracking_point_rate, min_init_stereo_feature=args.min_init_stereo)
+    pol = seq.KeyframeConfig(image_width=W, image_height=H, tracking_point_rate=args.tracking_point_rate, min_init_stereo_feature=args.min_init_stereo,
+                             min_num_match=args.min_num_match, max_num_match=max(80, args.min_num_match + 10))
     prec, mprec = (1 if args.dtype == "fp16" else 0), (1 if args.matcher_dtype == "fp16" else 0)
 
     def run(S):
@@ -283,7 +284,9 @@ def seq_workload(args, rank, world, local, dev):
                               "temporal_matches_mean": float(np.mean([len(r.matches_idx) for r in flat if r.matches_idx is not None] or [0])),
                               "stereo_matches_mean": float(np.mean([len(r.stereo_idx) for r in flat if r.stereo_idx is not None] or [0])),
                               "lines_mean_keyframe_left": float(np.mean([len(r.lines_left) for r in flat if r.lines_left is not None] or [0]))},
-                    gathers=gat.gathers, results=results)
+                    gathers=gat.gathers, results=results,
+                    wall_split_ms_per_step=(None if S == 1 else {"queue_device_work": bs.t_queue / frames * 1e3, "wait_for_device": bs.t_wait / frames * 1e3,
+                                                                 "host_side_of_the_loop": bs.t_host / frames * 1e3, "host_syncs": bs.syncs / frames}))
 
     runs = {S: run(S) for S in sweep}
     head = runs[args.sequences]
@@ -293,7 +296,8 @@ def seq_workload(args, rank, world, local, dev):
         from oracle import ref_seq
         torch.set_num_threads(min(os.cpu_count() or 1, 32))
         chain = ref_seq.Chain(weights.synthetic_plnet_s0(1234), weights.synthetic_superpoint(1234), weights.load_pack(s1_path), lg, W, H, K,
-                              policy=dict(tracking_point_rate=args.tracking_point_rate, min_init_stereo_feature=args.min_init_stereo))
+                              policy=dict(tracking_point_rate=args.tracking_point_rate, min_init_stereo_feature=args.min_init_stereo,
+                             min_num_match=args.min_num_match, max_num_match=max(80, args.min_num_match + 10)))
         nfr = min(args.cpu_pairs + 2, frames)
         ts, types = [], []
         for t in range(nfr):
@@ -319,7 +323,8 @@ def seq_workload(args, rank, world, local, dev):
                                       f"some sequences uninitialised for a scene); max_keypoints={K}; seeded synthetic weights except PLNet stage 1 (real)",
                           "sequences_per_gpu": args.sequences, "frames": frames, "gather_every_frames": KG, "gathers": head["gathers"], "schedule": head["schedule"],
                           "driver": "airslam_amd.seq.SequenceFrontEnd (one-call host entries)" if args.sequences == 1 else "airslam_amd.seq.BatchedSequences (*_batch_dev entries)"},
-               "sweep": {str(S): {"frames_per_s": r["frames_per_s"], "ms_per_time_step": r["ms_per_step"], "latency_ms": r["latency_ms"], "schedule": r["schedule"]} for S, r in runs.items()},
+               "sweep": {str(S): {"frames_per_s": r["frames_per_s"], "ms_per_time_step": r["ms_per_step"], "latency_ms": r["latency_ms"], "schedule": r["schedule"],
+                                   "wall_split_ms_per_step": r["wall_split_ms_per_step"]} for S, r in runs.items()},
                "roofline": None, "cpu_baseline": cpu, "collective": args.collective}
         print(json.dumps(out))
     if world > 1:
@@ -508,6 +513,7 @@ def main():
     ap.add_argument("--scene-len", type=int, default=40, help="--workload seq: frames per synthetic scene (a scene change forces a promotion)")
     ap.add_argument("--sweep", action="store_true", help="--workload seq: also run S = 1, 4, 8, 16")
     ap.add_argument("--tracking-point-rate", type=float, default=0.2, help="--workload seq: AddKeyframeCheck's tracking_point_rate (yaml: 0.65; see the workload text)")
+    ap.add_argument("--min-num-match", type=int, default=30, help="--workload seq: AddKeyframeCheck's min_num_match (yaml: 30; the tests raise it so that promotions happen)")
     ap.add_argument("--min-init-stereo", type=int, default=60, help="--workload seq: min_init_stereo_feature (yaml: 90 of ~400 trained-matcher stereo matches; the synthetic "
                                                                      "matcher finds ~130 per pair, of which some sequences keep 80-90 inside the camera's band: they would stay uninitialised for a whole scene)")
     ap.add_argument("--plnet-host", action="store_true", help="PLNet + matcher through the batch-1 HOST API instead (PCIe and one sync per call included)")

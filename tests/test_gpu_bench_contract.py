@@ -81,12 +81,12 @@ def test_track_workload_line():
 def test_seq_workload_line():
     """--workload seq (BASELINE configs[3]): S sequences driven as map_builder.cc:83-141 drives the front end — a short run of the batched driver and of the
     one-call driver; the schedule contains keyframes, normal frames and (scenes of 10 frames) promotions"""
-    d = _run("--workload", "seq", "--sequences", "3", "--frames", "34", "--warmup", "2", "--scene-len", "10", "--cpu-pairs", "3")
+    d = _run("--workload", "seq", "--sequences", "3", "--frames", "34", "--warmup", "2", "--scene-len", "10", "--cpu-pairs", "3", "--min-num-match", "100")
     assert d["unit"] == "frames/s" and d["steps"] == 32 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["value"] > 0
     assert abs(d["value"] - 3 * 32 / (d["ms_per_step"] * 32 * 1e-3)) <= 1e-6 * d["value"]
     sch = d["config"]["schedule"]
-    # (a scene change promotes only a frame that was NOT already a keyframe candidate: with candidates every few frames that is 1-3 of the 9 scene changes here)
-    assert sch["frames"] == 3 * 32 and sch["keyframes"] >= 6 and sch["promotions"] >= 1 and sch["normal_frames"] >= 48 and sch["temporal_matches_mean"] >= 40
+    # (--min-num-match 100: a normal frame whose temporal matches fall below 100 is promoted — the synthetic matcher finds 60-100 even across a scene change)
+    assert sch["frames"] == 3 * 32 and sch["keyframes"] >= 6 and sch["promotions"] >= 1 and sch["normal_frames"] >= 30 and sch["temporal_matches_mean"] >= 40
     assert sch["dropped_before_init"] == 0
     assert d["config"]["gather_every_frames"] == 8 and d["config"]["gathers"] == 4 and "BatchedSequences" in d["config"]["driver"]
     lat = d["latency_ms_per_time_step"]
