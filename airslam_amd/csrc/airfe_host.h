@@ -88,7 +88,7 @@ struct airfe_ctx {
   int *sat_host = nullptr, *sat_flag = nullptr;   // two words of host-mapped, coherent memory (and their device address): [0] = non-finite detector logits, [1] = non-finite
                                  // sampled descriptor — written by the head / sampling kernels only when the 2-byte activations overflowed, read by the host after its synchronisation: no copy
   bool fuse_dec = true;          // airfe_tuning::fuse_dec
-  int assign_fused = -1;         // airfe_tuning::assign_fused: -1 = by batch (fused above 8 pairs: at batch 1 the matrix form's two merged launches are 1 % quicker, profiles/r05_assign_ab.txt)
+  int assign_fused = 0;          // airfe_tuning::assign_fused (1: partials in the similarity tiles; measured -0.010 ms per 64-pair step, +0.012 ms per batch-1 keyframe: not the default, profiles/r05_assign_ab.txt)
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;         // airfe_stereo_plnet_batch_dev: the line branch runs here while the matcher runs on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_feat = nullptr;

@@ -274,7 +274,7 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   if (slack_words) trace(c, st, "x32slack", LF, "final", c->x32 + (size_t)M * 256, slack_words, 4096);
   TRACE_HALT;
   // the assignment tail in a scope of its own: its stage's launch status is noted before trace_finish looks at it
-  const bool fused_assign = c->assign_fused == 1 || (c->assign_fused < 0 && B > 8);      // (measured both ways on one box: profiles/r05_assign_ab.txt)
+  const bool fused_assign = c->assign_fused == 1;      // (measured both ways on one box: profiles/r05_assign_ab.txt; ONE form for every batch size: a pair's bits do not depend on the batch)
   const int tail = [&]() -> int {
     // algorithmic: the similarity product (fused form: twice) and, round-2 form, the matrix written once and read four times / fused form, the descriptors + partials
     ProfScope ps(c, ST_LG_ASSIGN, st, (fused_assign ? 4.0 : 2.0) * B * Np * (double)Np * 256,

@@ -210,7 +210,9 @@ class BatchedSequences:
     tensors [S, h, w] uint8 and returns S FrameResults whose arrays are the bytes SequenceFrontEnd returns for each sequence on its own."""
 
     def __init__(self, kf: api.Context, nf: api.Context, S: int, cfg: Optional[KeyframeConfig] = None, cap_lines: int = 1024, cap_junc: int = 1024,
-                 device=None):
+                 device=None, copy_results: bool = True):
+        """copy_results = False: the arrays of a step's FrameResults are VIEWS of pinned staging memory, valid until the end of the NEXT step (two staging sets
+        alternate) — a consumer that hands them on within a frame time saves S x 0.4 MB of host copies per step (1.6 ms at S = 16)."""
         import torch
         self.t = torch
         self.kf, self.nf, self.S, self.cfg = kf, nf, S, cfg or KeyframeConfig()
@@ -239,12 +241,29 @@ class BatchedSequences:
         self.stream_k = torch.cuda.Stream(device=dev)      # the keyframe candidates' PLNet batch runs here, beside the normal frames' SuperPoint batch on `stream`
         self.syncs = 0
         self.t_queue = self.t_wait = self.t_host = 0.0      # where a time-step's wall time goes: queueing device work, waiting for it, the host side of the loop
-        # pinned host twins of everything the host side of the loop reads: queued as asynchronous copies, read after ONE stream synchronisation
-        self._pin = {k: torch.empty(getattr(self, k).shape, dtype=getattr(self, k).dtype).pin_memory() for k in (
-            "cur", "cur_n", "kr", "knr", "klines", "knlines", "kjunc", "knjunc", "kidx", "ksc", "knm", "kfound", "tidx", "tsc", "tnm", "pr", "pnr", "pidx", "psc", "pnm")}
+        # pinned host twins of everything the host side of the loop reads (two sets in turn): queued as asynchronous copies, read after ONE stream synchronisation
+        names = ("cur", "cur_n", "kr", "knr", "klines", "knlines", "kjunc", "knjunc", "kidx", "ksc", "knm", "kfound", "tidx", "tsc", "tnm", "pr", "pnr", "pidx", "psc", "pnm")
+        self._pins = [{k: torch.empty(getattr(self, k).shape, dtype=getattr(self, k).dtype).pin_memory() for k in names} for _ in range(2)]
+        self._pin = self._pins[0]
+        self._flip = 0
+        self.copy_results = copy_results
+        self._own = (lambda a: a.copy()) if copy_results else (lambda a: a)
+        # the index lists of a step (which sequences take which branch) go up in ONE small copy from a pinned block
+        self._idx_h = torch.empty((6 * S,), dtype=torch.int64).pin_memory()
+        self._idx_d = torch.empty((6 * S,), dtype=torch.int64, device=dev)
 
-    def _sel(self, ids):
-        return self.t.tensor(ids, dtype=self.t.int64, device=self.dev)
+    def _upload_idx(self, lists, base=0):
+        """index lists -> device int64 slices (one asynchronous H2D on `stream`; the pinned block is free again: every step ends behind a synchronisation)"""
+        off, out = base, []
+        for ids in lists:
+            n = len(ids)
+            if n:
+                self._idx_h[off:off + n] = self.t.as_tensor(ids, dtype=self.t.int64)
+            out.append((off, n))
+            off += n
+        if off > base:
+            self._idx_d[base:off].copy_(self._idx_h[base:off], non_blocking=True)
+        return [self._idx_d[o:o + n] for o, n in out]
 
     def _home(self, name, n):
         """queue rows [0, n) of device tensor `name` into its pinned twin (asynchronous); the numpy view is valid after the stream synchronisation"""
@@ -259,10 +278,14 @@ class BatchedSequences:
         tset = [i for i in range(S) if self.states[i].init]
         import time as _time
         t_a = _time.perf_counter()
+        self._flip ^= 1
+        self._pin = self._pins[self._flip]
+        with t.cuda.stream(self.stream):
+            ks, ns, ts = self._upload_idx([kset, nset, tset])
         if kset:              # keyframe candidates: PLNet on both images + the stereo match, one batch (map_builder.cc:85-86) — on its own stream, beside the
             with t.cuda.stream(self.stream_k):             # normal frames' batch (the two contexts share nothing; they join before the temporal match)
                 self.stream_k.wait_stream(self.stream)     # (the previous step's reference update ran on `stream`)
-                nk, ks = len(kset), self._sel(kset)
+                nk = len(kset)
                 Lk, Rk = L.index_select(0, ks), R.index_select(0, ks)
                 self.kf.stereo_plnet_batch_dev(Lk, Rk, self.kl[:nk], self.kr[:nk], self.knl[:nk], self.knr[:nk], self.klines[:2 * nk], self.knlines[:2 * nk],
                                                self.kjunc[:nk], self.knjunc[:nk], self.kidx[:nk], self.ksc[:nk], self.knm[:nk], self.kfound[:3 * nk],
@@ -270,13 +293,13 @@ class BatchedSequences:
                 self.cur.index_copy_(0, ks, self.kl[:nk]); self.cur_n.index_copy_(0, ks, self.knl[:nk])
         with t.cuda.stream(self.stream):
             if nset:          # normal frames: SuperPoint on the left image, one batch (:94)
-                nn_, ns = len(nset), self._sel(nset)
+                nn_ = len(nset)
                 self.nf.detect_batch_dev(L.index_select(0, ns), self.nfeat[:nn_], self.nn[:nn_], stream=sh)
                 self.cur.index_copy_(0, ns, self.nfeat[:nn_]); self.cur_n.index_copy_(0, ns, self.nn[:nn_])
             if kset:
                 self.stream.wait_stream(self.stream_k)
             if tset:          # the temporal match of every initialised sequence, one LightGlue batch (:100-101)
-                nt, ts = len(tset), self._sel(tset)
+                nt = len(tset)
                 self.tref[:nt] = self.ref.index_select(0, ts); self.tref_n[:nt] = self.ref_n.index_select(0, ts)
                 self.tcur[:nt] = self.cur.index_select(0, ts); self.tcur_n[:nt] = self.cur_n.index_select(0, ts)
                 self.nf.match_lightglue_batch_dev(self.tref[:nt], self.tref_n[:nt], self.tcur[:nt], self.tcur_n[:nt], self.tidx[:nt], self.tsc[:nt], self.tnm[:nt],
@@ -295,7 +318,7 @@ class BatchedSequences:
         t_c = _time.perf_counter()
         self.syncs += 1
         for i in range(S):
-            out[i].features_left = h_cur[i, :h_cur_n[i]].copy()
+            out[i].features_left = self._own(h_cur[i, :h_cur_n[i]])
         if kset:
             kr, knr, kln, knl, kj, knj, kidx, ksc, knm, kfound = h_k
             nk = len(kset)
@@ -303,17 +326,17 @@ class BatchedSequences:
                 raise api.AirfeError("BatchedSequences: line / junction capacity overflow (cap_lines, cap_junc)")
             for j, i in enumerate(kset):
                 r = out[i]
-                r.features_right = kr[j, :knr[j]].copy()
-                r.lines_left, r.lines_right = kln[j, :knl[j]].copy(), kln[nk + j, :knl[nk + j]].copy()
-                r.junctions = kj[j, :knj[j]].copy()
+                r.features_right = self._own(kr[j, :knr[j]])
+                r.lines_left, r.lines_right = self._own(kln[j, :knl[j]]), self._own(kln[nk + j, :knl[nk + j]])
+                r.junctions = self._own(kj[j, :knj[j]])
                 m = int(knm[j]) if (len(r.features_left) and len(r.features_right)) else 0           # point_matcher.cc:53-55
-                r.stereo_idx, r.stereo_score = kidx[j, :m].copy(), ksc[j, :m].copy()
+                r.stereo_idx, r.stereo_score = self._own(kidx[j, :m]), self._own(ksc[j, :m])
                 r.good_stereo_point = good_stereo_points(cfg, r.features_left, r.features_right, r.stereo_idx)
         if tset:
             tidx, tsc, tnm = h_t
             for j, i in enumerate(tset):
                 m = int(tnm[j]) if (len(self.states[i].ref) and len(out[i].features_left)) else 0
-                out[i].matches_idx, out[i].matches_score = tidx[j, :m].copy(), tsc[j, :m].copy()
+                out[i].matches_idx, out[i].matches_score = self._own(tidx[j, :m]), self._own(tsc[j, :m])
         # decisions; promotions are collected first (they need a second device pass), then replayed
         pset = []
         for i in tset:
@@ -321,8 +344,9 @@ class BatchedSequences:
                 pset.append(i)
         promo = {}
         if pset:              # promotions: SuperPoint on the right image + the stereo match, one batch each (:104-108)
-            npz, ps = len(pset), self._sel(pset)
+            npz = len(pset)
             with t.cuda.stream(self.stream):
+                (ps,) = self._upload_idx([pset], base=3 * S)
                 self.nf.detect_batch_dev(R.index_select(0, ps), self.pr[:npz], self.pnr[:npz], stream=sh)
                 self.tcur[:npz] = self.cur.index_select(0, ps); self.tcur_n[:npz] = self.cur_n.index_select(0, ps)
                 self.nf.match_lightglue_batch_dev(self.tcur[:npz], self.tcur_n[:npz], self.pr[:npz], self.pnr[:npz], self.pidx[:npz], self.psc[:npz], self.pnm[:npz],
@@ -335,9 +359,9 @@ class BatchedSequences:
             self.syncs += 1
             pr, pnr, pidx, psc, pnm = h_p
             for j, i in enumerate(pset):
-                fr = pr[j, :pnr[j]].copy()
+                fr = self._own(pr[j, :pnr[j]])
                 m = int(pnm[j]) if (len(out[i].features_left) and len(fr)) else 0
-                promo[i] = (fr, pidx[j, :m].copy(), psc[j, :m].copy())
+                promo[i] = (fr, self._own(pidx[j, :m]), self._own(psc[j, :m]))
         newkf = []
         for i in range(S):
             r, stt = out[i], self.states[i]
@@ -349,9 +373,11 @@ class BatchedSequences:
             stt.decide(cfg, r, promote)
             if stt.ref is not before:
                 newkf.append(i)
+                if not self.copy_results:
+                    stt.ref = np.array(stt.ref)     # (the reference outlives the staging set its rows came back in)
         if newkf:             # `_last_keyframe_feature = frame`: on the device, the new keyframes' rows become the reference rows
             with t.cuda.stream(self.stream):
-                ks = self._sel(newkf)
+                (ks,) = self._upload_idx([newkf], base=4 * S)
                 self.ref.index_copy_(0, ks, self.cur.index_select(0, ks)); self.ref_n.index_copy_(0, ks, self.cur_n.index_select(0, ks))
         self.t_queue += t_b - t_a
         self.t_wait += t_c - t_b

@@ -246,7 +246,7 @@ def seq_workload(args, rank, world, local, dev):
                         pending.append(h)
                 return [r]
         else:
-            bs = seq.BatchedSequences(kf, nf, S, pol, device=dev)
+            bs = seq.BatchedSequences(kf, nf, S, pol, device=dev, copy_results=False)      # (results are read inside the step that made them)
 
             def step(t):
                 rs = bs.step(Ld[t, :S], Rd[t, :S])

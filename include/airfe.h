@@ -50,7 +50,7 @@ typedef struct airfe_tuning {
   int kf_spec_rows;      /* line / junction rows airfe_stereo_keyframe copies back before it knows the counts */
   int fuse_dec;          /* PLNet stage-0: 17-channel head + decode in one pass (1) or two (0) */
   int assign_fused;      /* LightGlue assignment: log-sum-exp / arg-max partials taken in the similarity tiles (1; no similarity matrix in HBM)
-                            or the round-2 form: similarity matrix + four passes over it (0); -1: fused above 8 pairs per call */
+                            or the round-2 form: similarity matrix + four passes over it (0, the default: the A/B is in profiles/r05_assign_ab.txt) */
   int reserved[8];       /* must be -1 */
 } airfe_tuning;
 

@@ -54,6 +54,17 @@ __global__ void check(int* bad) {
   atomicAdd(bad, b);
 }
 
+// which exchange of the DPP / permlane form differs from the portable one (bit i of *bad: step i of transpose32)
+__global__ void check_steps(int* bad) {
+  const int lane = threadIdx.x & 63;
+  float a[16], b[16];
+  int w = 0;
+#define STEP(I, RB, LB) for (int r = 0; r < 16; ++r) a[r] = b[r] = (float)(r * 64 + lane); xbit<RB, LB, 1>(a, lane); xbit<RB, LB, 2>(b, lane); for (int r = 0; r < 16; ++r) w |= (a[r] != b[r]) << I;
+  STEP(0, 3, 4) STEP(1, 2, 3) STEP(2, 1, 1) STEP(3, 0, 0)
+#undef STEP
+  atomicOr(bad, w);
+}
+
 template <int MODE>            // 0 = A (two products), 1 = B1, 2 = B2
 __global__ __launch_bounds__(256, 3) void probe(unsigned* sink, int iters) {
   const int lane = threadIdx.x & 63;
@@ -110,6 +121,13 @@ int main() {
   hipLaunchKernelGGL(check<2>, dim3(1), dim3(64), 0, 0, bad + 1);
   hipMemcpy(h, bad, 8, hipMemcpyDeviceToHost);
   printf("transpose check: portable form %s (%d wrong of 1024), DPP / permlane form %s (%d wrong)\n", h[0] ? "WRONG" : "ok", h[0], h[1] ? "WRONG" : "ok", h[1]);
+  if (h[1]) {
+    hipMemset(bad, 0, 4);
+    hipLaunchKernelGGL(check_steps, dim3(1), dim3(64), 0, 0, bad);
+    hipMemcpy(h, bad, 4, hipMemcpyDeviceToHost);
+    printf("  exchanges of the DPP / permlane form that differ from the portable one: %s%s%s%s (its time below is that of the instruction mix, not of a correct transpose)\n",
+           (h[0] & 1) ? "[lane bit 4: v_permlane16_swap] " : "", (h[0] & 2) ? "[lane bit 3: row_ror:8] " : "", (h[0] & 4) ? "[lane bit 1: quad_perm 2301] " : "", (h[0] & 8) ? "[lane bit 0: quad_perm 1032] " : "");
+  }
   const double a = run<0>(sink), b1 = run<1>(sink), b2 = run<2>(sink);
   printf("per 32x32 tile and SIMD (3 waves per SIMD, both directions' P packed to fp16):\n");
   printf("  A  two products (8 MFMA + 32 v_exp_f32 + 16 v_cvt_pk)                 %7.1f ns\n", a);
