@@ -205,6 +205,9 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) try {
   c->Np = (cfg->max_keypoints + 15) / 16 * 16;      // matcher rows per sequence: whole 16-token MFMA tiles, no further padding
   if (cfg->line_precision != 0 && cfg->line_precision != 1 && cfg->line_precision != 2) { return fail(nullptr, "airfe_create: line_precision must be 1 (fp16 operands) or 2 (fp32 operands)"); }
   if (c->cfg.line_precision == 0) c->cfg.line_precision = 2;
+  if (c->cfg.line_precision == 1)
+    return fail(nullptr, "airfe_create: line_precision = 1 (fp16 operands in PLNet stage 1, the reference's engine type) is not built: measured with the real weights it moves "
+                         "0.52 % of the kept lines across the 0.75 threshold (profiles/r05_s1_fp16_emulation.txt, DESIGN.md §3); stage 1 runs with fp32 operands");
   c->cfg.tuning = nullptr;                       // (the caller's struct need not outlive this call)
   if (const airfe_tuning* t = cfg->tuning) {     // kernel-selection overrides: -1 = keep the default
     for (int r : t->reserved)

@@ -21,7 +21,12 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":      # the rank's own GPU must be current BEFORE the communicator exists (else every rank's barrier lands on device 0)
+            dev = local % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(dev)
+            kw["device_id"] = torch.device("cuda", dev)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 

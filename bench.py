@@ -64,12 +64,12 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=
     `n_pairs` pairs (median of >= 20 after 3 warm-ups).  s1 (the stage-1 weights) selects the PLNet step: one trunk
     pass per image feeding the point heads AND the line branch, wireframe_matcher, stage 1, line filter, junctions on the left."""
     from airslam_amd import synth
-    from oracle import ref_chain, ref_nets, ref_post
+    from oracle import margins, ref_chain, ref_nets, ref_post
     torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads than this only adds sync overhead at batch 1
     # the SAME images rank 0 puts on the GPU (synth.stereo_batch(B, h, w, 1000)): its first n_pairs + warm pairs, ready before the clock
     ls, rs = synth.stereo_batch(n_pairs + warm, h, w, 1000)
     pairs = list(zip(ls, rs))
-    times, nmatch = [], []
+    times, nmatch, nfrag = [], [], []
     for i, (left, right) in enumerate(pairs):
         t0 = time.perf_counter()
         feats = []
@@ -89,6 +89,8 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=
             b = ref_post.normalize_keypoints(feats[1], w, h, 0.5)
             s = ref_nets.lightglue_forward(lg, a[:, 1:3], a[:, 3:], b[:, 1:3], b[:, 3:])
             k = len(ref_post.filter_matches(s, 0.1)[0])
+            if i >= warm:
+                nfrag.append(len(margins.fragile_rows(s, 0.05)))      # rows within 0.05 of a decision boundary: the share of matches a 2-byte matcher may legitimately flip
         if i >= warm:                                   # the first pairs warm the thread pool and the allocator
             times.append(time.perf_counter() - t0)
             nmatch.append(k)
@@ -99,6 +101,7 @@ def cpu_baseline(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=
         agree = dict(cpu_matches_mean=float(np.mean(nmatch)), gpu_matches_mean_same_pairs=float(g.mean()),
                      max_abs_count_diff=int(np.abs(g - np.asarray(nmatch)).max()))
     return dict(value=1.0 / med, unit="pairs/s", cores=torch.get_num_threads(), kind="port", same_pairs_as_gpu=agree,
+                fragile_share_of_matches=(float(sum(nfrag)) / max(sum(nmatch), 1)) if nfrag else None,     # (tests gate 6 %: tests/test_gpu_stereo.py)
                 sample=f"median of {n_pairs} synthetic {w}x{h} stereo pairs after {warm} warm-ups ({sum(times):.1f} s), fp32 PyTorch-CPU "
                        f"oracle + numpy post-processing ({'PLNet points + lines + junctions' if s1 is not None else 'SuperPoint'} + LightGlue), "
                        f"{float(np.mean(nmatch)):.0f} matches per pair")
@@ -124,6 +127,7 @@ def latency_b1(args, rank, world, local, dev):
     pairs = [synth.stereo_pair(H, W, 1000 + i) for i in range(8)]
     t_l, t_r, t_m, t_k, t_d2, t_m2, t_t1, t_t2, t_kt1, t_kt2, nmatch, nlines = [], [], [], [], [], [], [], [], [], [], [], []
     fused = plnet and not sg                                       # airfe_stereo_keyframe: the PLNet + LightGlue keyframe (map_builder.cc:85-86)
+    equal = True                                                   # the one- / two- / three-call forms return the same counts (reported on the line, not asserted: ADVICE r04)
     for i in range(args.warmup + args.steps):
         left, right = pairs[i % len(pairs)]
         acc = []
@@ -146,7 +150,7 @@ def latency_b1(args, rank, world, local, dev):
             t5 = time.perf_counter()
             n2, _ = pm.MatchingPoints(fl2, fr2)
             t6 = time.perf_counter()
-            assert len(k["idx"]) == n == n2 and len(k["linesL"]) == len(acc)
+            equal = equal and (len(k["idx"]) == n == n2 and len(k["linesL"]) == len(acc))
             # the normal-frame step (map_builder.cc:94-101): Detect(image, features) + MatchingPoints(last keyframe, features) — as two calls, as one
             t7 = time.perf_counter()
             if i % 8 == 0:
@@ -156,7 +160,7 @@ def latency_b1(args, rank, world, local, dev):
             t8 = time.perf_counter()
             _, tidx, _ = ctx.track_frame(right, ref_feat=kf_ref.T if i % 8 == 0 else None)           # its features go up once, then stay on the device
             t9 = time.perf_counter()
-            assert len(tidx) == nt
+            equal = equal and len(tidx) == nt
             # a keyframe candidate also runs the temporal match (map_builder.cc:96): one call with both pairs in ONE LightGlue forward, against
             # the one-call keyframe + a MatchingPoints call
             kt = ctx.stereo_keyframe(left, right, track=True)                               # (reference = the features uploaded above)
@@ -164,7 +168,7 @@ def latency_b1(args, rank, world, local, dev):
             k2 = ctx.stereo_keyframe(left, right)
             nt2, _ = pm.MatchingPoints(kf_ref, np.asfortranarray(k2["featL"].T))
             t11 = time.perf_counter()
-            assert len(kt["track_idx"]) == nt2 and len(kt["idx"]) == len(k2["idx"])
+            equal = equal and (len(kt["track_idx"]) == nt2 and len(kt["idx"]) == len(k2["idx"]))
         if i >= args.warmup:
             t_l.append(t1 - t0); t_r.append(t2 - t1); t_m.append(t3 - t2); nmatch.append(n); nlines.append(len(acc))
             if fused:
@@ -190,7 +194,7 @@ def latency_b1(args, rank, world, local, dev):
            "value": 1e3 / head, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype if args.dtype == args.matcher_dtype else f"{args.dtype} (encoder) + {args.matcher_dtype} (matcher), fp32 accumulate",
-           "data": "synthetic", "latency_ms": lat,
+           "data": "synthetic", "latency_ms": lat, "call_forms_agree": bool(equal),
            "config": {"workload": f"ONE synthetic {W}x{H} stereo pair per step through the batch-1 host API (airslam_amd.api over the C ABI's host-buffer entries), "
                                   f"max_keypoints={K}; seeded synthetic weights (reference ONNX files are absent)",
                       "matches_mean": float(np.mean(nmatch)), "lines_mean_left": float(np.mean(nlines)), "detector": args.detector, "matcher": args.matcher},
@@ -806,8 +810,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sp, lg, H, W, args.cpu_pairs, K, s1=weights.load_pack(s1_path) if plnet else None,
                                                gpu_nmatch=nm.cpu().numpy())
             cb = out["cpu_baseline"]["same_pairs_as_gpu"]
-            if cb and args.dtype == "fp16" and args.matcher_dtype == "fp16":       # a bench whose outputs drifted from the oracle's is not a bench
-                assert cb["max_abs_count_diff"] <= max(12, 0.15 * cb["cpu_matches_mean"]), f"GPU and CPU-oracle match counts disagree on the same pairs: {cb}"
+            if cb and args.dtype == "fp16" and args.matcher_dtype == "fp16":       # a bench whose outputs drifted from the oracle's says so ON the line (ADVICE r04:
+                out["cpu_baseline"]["parity_ok"] = bool(cb["max_abs_count_diff"] <= max(12, 0.15 * cb["cpu_matches_mean"]))      # an assert here lost the line)
+                if not out["cpu_baseline"]["parity_ok"]:
+                    print(f"bench.py: GPU and CPU-oracle match counts disagree on the same pairs: {cb}", file=sys.stderr)
         print(json.dumps(out))
     ctx.close()
     if world > 1:

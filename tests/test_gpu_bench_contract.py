@@ -53,6 +53,7 @@ def test_default_workload_line():
         assert (val is None) == age["stale"], f"{what}: a counter-derived number must be reported exactly when its profile was taken on this tree's kernels"
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "pairs/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+    assert cb.get("parity_ok", True) is True
 
 
 @pytest.mark.parametrize("args", [("--matcher", "superglue", "--pairs", "4"), ("--detector", "superpoint", "--pairs", "4"),
@@ -121,7 +122,7 @@ def test_frontend_workload_line():
 def test_b1_latency_line():
     """--workload b1: one stereo keyframe at a time through the batch-1 host API, latency percentiles"""
     d = _run("--workload", "b1", "--steps", "20", "--warmup", "3")
-    assert d["unit"] == "pairs/s" and d["steps"] == 20 and "latency" in d["metric"]
+    assert d["unit"] == "pairs/s" and d["steps"] == 20 and "latency" in d["metric"] and d["call_forms_agree"] is True
     lat = d["latency_ms"]
     assert lat["pair"]["p50"] > 0 and lat["pair"]["p99"] >= lat["pair"]["p50"] and abs(d["value"] - 1e3 / lat["pair"]["p50"]) < 1e-6 * d["value"]
     assert d["config"]["matches_mean"] > 50 and d["config"]["lines_mean_left"] >= 50

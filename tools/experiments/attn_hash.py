@@ -9,10 +9,13 @@ sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
 import torch
 from airslam_amd import api, synth, weights
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..' if 'experiments' in _os.path.abspath(__file__) else '.'))
+from tuning_env import tuning_from_env      # (tools/tuning_env.py: AIRFE_* environment -> airfe_tuning; the library itself reads no environment)
 from planted import normalised, planted_pair
 
 lg = weights.synthetic_lightglue(1234)
-ctx = api.Context(lightglue=lg, superpoint=weights.synthetic_superpoint(1234), max_batch=16, enc_chunk=16, max_keypoints=400)
+ctx = api.Context(tuning=tuning_from_env(), lightglue=lg, superpoint=weights.synthetic_superpoint(1234), max_batch=16, enc_chunk=16, max_keypoints=400)
 out = []
 for n0, n1 in [(400, 400), (317, 400), (64, 65), (33, 400), (400, 96), (129, 97)]:
     f0, f1 = planted_pair(n0, n1, 7 * n0 + n1)

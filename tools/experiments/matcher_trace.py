@@ -16,13 +16,16 @@ sys.path.insert(0, os.getcwd())
 import numpy as np
 import torch
 from airslam_amd import api, synth, weights
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..' if 'experiments' in _os.path.abspath(__file__) else '.'))
+from tuning_env import tuning_from_env      # (tools/tuning_env.py: AIRFE_* environment -> airfe_tuning; the library itself reads no environment)
 
 N1 = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 N2 = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 MODE = sys.argv[3] if len(sys.argv) > 3 else "stereo"
 B, K, H = 64, 400, 4
 dev = torch.device("cuda", 0)
-ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1="tests/golden/plnet_s1.airfe", lightglue=weights.synthetic_lightglue(1234),
+ctx = api.Context(tuning=tuning_from_env(), superpoint=weights.synthetic_plnet_s0(1234), plnet_s1="tests/golden/plnet_s1.airfe", lightglue=weights.synthetic_lightglue(1234),
                   max_batch=B, enc_chunk=64, max_keypoints=K)
 NP = ctx.np_rows
 ls, rs = synth.stereo_batch(B, 480, 752, 1000)

@@ -6,10 +6,13 @@ import sys
 sys.path.insert(0, os.getcwd())
 import torch
 from airslam_amd import api, synth, weights
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..' if 'experiments' in _os.path.abspath(__file__) else '.'))
+from tuning_env import tuning_from_env      # (tools/tuning_env.py: AIRFE_* environment -> airfe_tuning; the library itself reads no environment)
 
 B, K = 16, 400
 dev = torch.device("cuda", 0)
-ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1="tests/golden/plnet_s1.airfe", lightglue=weights.synthetic_lightglue(1234),
+ctx = api.Context(tuning=tuning_from_env(), superpoint=weights.synthetic_plnet_s0(1234), plnet_s1="tests/golden/plnet_s1.airfe", lightglue=weights.synthetic_lightglue(1234),
                   max_batch=B, enc_chunk=32, max_keypoints=K)
 ls, rs = synth.stereo_batch(B, 480, 752, 1000)
 L, R = torch.from_numpy(ls).to(dev), torch.from_numpy(rs).to(dev)

@@ -5,6 +5,9 @@ import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
 from airslam_amd import api, synth, weights
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..' if 'experiments' in _os.path.abspath(__file__) else '.'))
+from tuning_env import tuning_from_env      # (tools/tuning_env.py: AIRFE_* environment -> airfe_tuning; the library itself reads no environment)
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "plnet"
 B, K, H, W = 64, 400, 480, 752
@@ -15,10 +18,10 @@ z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=dev)
 
 def make(nb, lo):
     if mode == "plnet":
-        ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1="tests/golden/plnet_s1.airfe", lightglue=weights.synthetic_lightglue(1234),
+        ctx = api.Context(tuning=tuning_from_env(), superpoint=weights.synthetic_plnet_s0(1234), plnet_s1="tests/golden/plnet_s1.airfe", lightglue=weights.synthetic_lightglue(1234),
                           max_batch=nb, enc_chunk=64, max_keypoints=K)
     else:
-        ctx = api.Context(superpoint=weights.synthetic_superpoint(1234), lightglue=weights.synthetic_lightglue(1234), max_batch=nb, enc_chunk=64, max_keypoints=K)
+        ctx = api.Context(tuning=tuning_from_env(), superpoint=weights.synthetic_superpoint(1234), lightglue=weights.synthetic_lightglue(1234), max_batch=nb, enc_chunk=64, max_keypoints=K)
     L, R = torch.from_numpy(ls[lo:lo + nb]).to(dev), torch.from_numpy(rs[lo:lo + nb]).to(dev)
     bufs = dict(fl=z(nb, K, 259), fr=z(nb, K, 259), nl=z(nb, dt=torch.int32), nr=z(nb, dt=torch.int32), idx=z(nb, K, 2, dt=torch.int32), sc=z(nb, K),
                 nm=z(nb, dt=torch.int32), lines=z(2 * nb, 1024, 4, dt=torch.float64), nlines=z(2 * nb, dt=torch.int32), junc=z(nb, 1024, 259),

@@ -16,8 +16,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def child(pairs):
     import torch
     from airslam_amd import api, weights
+    import os as _os, sys as _sys
+    _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..' if 'experiments' in _os.path.abspath(__file__) else '.'))
+    from tuning_env import tuning_from_env      # (tools/tuning_env.py: AIRFE_* environment -> airfe_tuning; the library itself reads no environment)
     from planted import normalised, planted_pair
-    ctx = api.Context(lightglue=weights.synthetic_lightglue(1234), max_batch=2 * pairs, max_keypoints=400)
+    ctx = api.Context(tuning=tuning_from_env(), lightglue=weights.synthetic_lightglue(1234), max_batch=2 * pairs, max_keypoints=400)
     f0, f1 = planted_pair(400, 400, 3)
     a = torch.from_numpy(np.repeat(normalised(f0)[None], pairs, 0)).cuda(); b = torch.from_numpy(np.repeat(normalised(f1)[None], pairs, 0)).cuda()
     n = torch.full((pairs,), 400, dtype=torch.int32, device="cuda")
