@@ -216,7 +216,7 @@ def seq_workload(args, rank, world, local, dev):
     frames = args.frames if args.steps_given is None else args.warmup + args.steps_given
     warm = min(args.warmup, frames - 1)
     scene_len, KG = args.scene_len, 8
-    sweep = sorted(set([args.sequences] + ([1, 4, 8, 16] if args.sweep else [])))
+    sweep = sorted(set([args.sequences] + ([1, 4, 8, 16, 32] if args.sweep else [])))
     Smax = max(sweep)
     import multiprocessing as mp
     jobs = [(frames, H, W, 10 + rank * Smax + s_, scene_len) for s_ in range(Smax)]
@@ -515,7 +515,7 @@ def main():
     ap.add_argument("--sequences", type=int, default=8, help="--workload seq: sequences per GPU (1 = the one-call host entries, > 1 = lock-step batches)")
     ap.add_argument("--frames", type=int, default=200, help="--workload seq: frames per sequence")
     ap.add_argument("--scene-len", type=int, default=40, help="--workload seq: frames per synthetic scene (a scene change forces a promotion)")
-    ap.add_argument("--sweep", action="store_true", help="--workload seq: also run S = 1, 4, 8, 16")
+    ap.add_argument("--sweep", action="store_true", help="--workload seq: also run S = 1, 4, 8, 16, 32")
     ap.add_argument("--tracking-point-rate", type=float, default=0.2, help="--workload seq: AddKeyframeCheck's tracking_point_rate (yaml: 0.65; see the workload text)")
     ap.add_argument("--min-num-match", type=int, default=30, help="--workload seq: AddKeyframeCheck's min_num_match (yaml: 30; the tests raise it so that promotions happen)")
     ap.add_argument("--min-init-stereo", type=int, default=60, help="--workload seq: min_init_stereo_feature (yaml: 90 of ~400 trained-matcher stereo matches; the synthetic "

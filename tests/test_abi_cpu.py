@@ -106,3 +106,15 @@ def test_default_tuning_is_all_minus_one(libpath):
     _lib.lib().airfe_default_tuning(C.byref(t))
     assert all(getattr(t, n) == -1 for n, _ in _lib.Tuning._fields_ if n != "reserved") and list(t.reserved) == [-1] * 8
     assert C.sizeof(_lib.Tuning) == 4 * 23
+
+
+def test_committed_counter_profiles_were_taken_on_these_kernel_sources():
+    """`roofline.traffic` / `mfma_util_counters` on the bench line come from committed rocprofv3 PMC passes — they must be passes over THIS tree's
+    kernels (sha256 over csrc/*.hip, csrc/*.h, include/airfe*.h, stamped by tools/pmc_summary.py / tools/pmc_traffic.py).  bench.py drops stale ones (null +
+    counters_age.stale); this test keeps a commit from shipping them at all: change a kernel -> re-run tools/gpu_profile.sh."""
+    import glob
+    import json
+    from airslam_amd.build import csrc_sha
+    for suffix in ("pmc_summary.json", "hbm_traffic.json"):
+        newest = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)) if re.match(r"r\d\d_" + re.escape(suffix) + "$", os.path.basename(f)))[-1]
+        assert json.load(open(newest)).get("csrc_sha") == csrc_sha(), f"{os.path.basename(newest)} was measured on other kernel sources than this tree's"
