@@ -657,9 +657,14 @@ def main():
             ctx.stereo_plnet_batch_dev(L, R, fl, fr, nl, nr, lines, nlines, junc, njunc, idx, sc, nm, found, stream=sh)
         else:
             points_step()
-        if world > 1:
-            with torch.cuda.stream(stream):
-                adist.gather_matches(idx, sc, nm, dst=0)
+        if world > 1:          # the step's match lists to rank 0: copied on the compute stream, gathered on a SIDE stream behind an event —
+            gatherer.add(idx, sc, nm, stream=stream)      # the next step's kernels do not wait for the collective; barrier() drains it (torch.cuda.synchronize)
+
+    gatherer = None
+    if world > 1:
+        from airslam_amd import seq as aseq
+        gatherer = aseq.MatchGatherer(1, B, K, dev)
+        args.collective["per_step"] = "one packed gather of the match lists to rank 0 on a side stream behind an event (airslam_amd.seq.MatchGatherer, K = 1)"
 
     def barrier():
         torch.cuda.synchronize(dev)
