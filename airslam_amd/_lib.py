@@ -111,6 +111,7 @@ SIGNATURES = {
     "airfe_debug_sg_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "airfe_debug_plnet_stage0": (C.c_int, [C.c_void_p] + [C.c_void_p] * 10),
     "airfe_debug_plnet_s1": (C.c_int, [C.c_void_p, C.POINTER(Stage0), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "airfe_debug_plnet_s1_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "airfe_debug_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "airfe_debug_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_void_p]),

@@ -307,6 +307,14 @@ class Context:
                   "airfe_debug_plnet_s1")
         return la[:m2.value].copy(), sc[:m2.value].copy()
 
+    def debug_plnet_s1_last(self, cap: int = 45056):
+        """(lines_adjusted [m2, 4], scores_line [m2]) of image 0 of the last PLNet call, as the device path's stage-1 kernel left them"""
+        la = np.empty((cap, 4), np.float32)
+        sc = np.empty((cap,), np.float32)
+        m2 = C.c_int(0)
+        self._chk(self._l.airfe_debug_plnet_s1_last(self._h, la.ctypes.data, sc.ctypes.data, cap, C.byref(m2)), "airfe_debug_plnet_s1_last")
+        return la[:m2.value].copy(), sc[:m2.value].copy()
+
     def match_superglue(self, f0: np.ndarray, f1: np.ndarray):
         """f0/f1: [n, 259] rows (score, normalised x, y, desc) -> (indices0, indices1, mscores0, mscores1)."""
         f0 = np.ascontiguousarray(f0, dtype=np.float32)

@@ -203,11 +203,12 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) try {
   c->chunk = std::min(std::max(cfg->enc_chunk, 1), c->Bmax);
   c->Pmax = c->Bmax;
   c->Np = (cfg->max_keypoints + 15) / 16 * 16;      // matcher rows per sequence: whole 16-token MFMA tiles, no further padding
-  if (cfg->line_precision != 0 && cfg->line_precision != 1 && cfg->line_precision != 2) { return fail(nullptr, "airfe_create: line_precision must be 1 (fp16 operands) or 2 (fp32 operands)"); }
+  if (cfg->line_precision < 0 || cfg->line_precision > 3) { return fail(nullptr, "airfe_create: line_precision must be 2 (fp32 operands, f32-input MFMA) or 3 (fp32 operands as fp16 pairs on the 2-byte MFMA)"); }
   if (c->cfg.line_precision == 0) c->cfg.line_precision = 2;
   if (c->cfg.line_precision == 1)
-    return fail(nullptr, "airfe_create: line_precision = 1 (fp16 operands in PLNet stage 1, the reference's engine type) is not built: measured with the real weights it moves "
-                         "0.52 % of the kept lines across the 0.75 threshold (profiles/r05_s1_fp16_emulation.txt, DESIGN.md §3); stage 1 runs with fp32 operands");
+    return fail(nullptr, "airfe_create: line_precision = 1 (plain fp16 operands in PLNet stage 1) is refused: measured with the real weights it moves 0.5-0.9 % of the kept "
+                         "lines across the 0.75 threshold (profiles/r05_s1_fp16_emulation.txt); line_precision = 3 runs the same products on the 2-byte matrix pipe "
+                         "with fp16 (hi, lo) operand pairs and keeps the lines");
   c->cfg.tuning = nullptr;                       // (the caller's struct need not outlive this call)
   if (const airfe_tuning* t = cfg->tuning) {     // kernel-selection overrides: -1 = keep the default
     for (int r : t->reserved)
@@ -1349,6 +1350,21 @@ int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* line
   int cnt[2] = {0, 0};
   HIPCHK(c, hipMemcpyAsync(cnt, c->wf_counts, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
+  const int k = std::min(cnt[1], cap);
+  if (k > 0) {
+    HIPCHK(c, hipMemcpy(lines_adjusted, c->s1_la, (size_t)k * 16, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(scores_line, c->s1_sc, (size_t)k * 4, hipMemcpyDeviceToHost));
+  }
+  *m2 = k;
+  return 0;
+} AIRFE_CATCH(c)
+
+int airfe_debug_plnet_s1_last(airfe_ctx* c, float* lines_adjusted, float* scores_line, int cap, int* m2) try {
+  if (c && enter_device(c)) return 1;
+  if (!c || !c->has_s1 || !lines_adjusted || !scores_line || !m2) return fail(c, "debug_plnet_s1_last: stage-1 not loaded / bad argument");
+  HIPCHK(c, hipDeviceSynchronize());
+  int cnt[2] = {0, 0};
+  HIPCHK(c, hipMemcpy(cnt, c->wf_counts, 8, hipMemcpyDeviceToHost));
   const int k = std::min(cnt[1], cap);
   if (k > 0) {
     HIPCHK(c, hipMemcpy(lines_adjusted, c->s1_la, (size_t)k * 16, hipMemcpyDeviceToHost));

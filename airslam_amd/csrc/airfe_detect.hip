@@ -309,8 +309,12 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
     } else {
       launch_s1_junc_proj(d + SG_JUNCS, c->l_head, (size_t)128 * 128 * 160, 160, nullptr, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, st);
     }
-    launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, nullptr, 0, c->s1_jfeat, c->l_ta8, d + SG_THIN,
-                    d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
+    if (c->cfg.line_precision == 3)      // the four dense layers on the 2-byte matrix pipe, operands as fp16 (hi, lo) pairs: fp32-accurate (kernels_ext.hip)
+      launch_plnet_s1h(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, c->s1_jfeat, c->l_ta8, c->s1_wsplit, c->s1_w, c->s1_la, c->s1_sc,
+                       KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
+    else
+      launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, nullptr, 0, c->s1_jfeat, c->l_ta8, d + SG_THIN,
+                      d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
   }
   }
   ProfScope ps(c, ST_PL_FILTER, st, 0, (double)nb * R * R);

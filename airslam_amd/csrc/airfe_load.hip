@@ -522,6 +522,25 @@ int load_plnet_s1(airfe_ctx* c, const char* path) {
     c->s1_w[2 * i] = upload_transposed(c, *w, ls[i].n, ls[i].k, S1_WPAD);
     c->s1_w[2 * i + 1] = dupload(c, b->data);
   }
+  // the same four matrices as fp16 (hi, lo) planes for the 2-byte matrix pipe (cfg.line_precision = 3, kernels_ext.hip plnet_s1h_kernel): [2][128][K], fc2.0 only
+  // in its 240 thin / aux columns (its 256 LOI columns are applied per junction in fp32: s1_junc_proj_kernel); lo = fp16((w - hi) * 2^11)
+  {
+    struct S { const char* name; int k0, k; } ss[4] = {{"fc2.0", 256, 240}, {"fc2_res.0", 0, 240}, {"fc2.2", 0, 128}, {"fc2.4", 0, 128}};
+    for (int i = 0; i < 4; ++i) {
+      const Tensor* w = need(p, std::string(ss[i].name) + ".weight", err);
+      const int ld = (int)w->data.size() / 128, K = ss[i].k;
+      std::vector<uint16_t> t((size_t)2 * 128 * K);
+      for (int n = 0; n < 128; ++n)
+        for (int k = 0; k < K; ++k) {
+          const float v = w->data[(size_t)n * ld + ss[i].k0 + k];
+          const uint16_t hi = f2h(v);
+          t[(size_t)n * K + k] = hi;
+          t[(size_t)128 * K + (size_t)n * K + k] = f2h((v - h2f(hi)) * 2048.0f);
+        }
+      c->s1_wsplit[i] = dupload(c, t);
+      if (!c->s1_wsplit[i]) return fail(c, "device allocation failed (plnet_s1 split weights)");
+    }
+  }
   const Tensor *wh = need(p, "fc2_head.weight", err), *bh = need(p, "fc2_head.bias", err), *tt = need(p, "sample_t", err);
   if (!wh || !bh || !tt || wh->data.size() != 256 || tt->data.size() != 30) return fail(c, err.empty() ? "plnet_s1 head: unexpected shape" : err);
   c->s1_w[8] = dupload(c, wh->data);

@@ -202,6 +202,11 @@ void launch_plnet_s1(const float* juncs, const float* lines_pred, const int* kee
                      const int* counts, const float* loi, size_t loi_img, const float* proj, const float* ta8, const float* thin,
                      const float* aux, const float* const* w, float* lines_adjusted, float* scores_line, int keep_cap, int line_cap, int B,
                      size_t stage_stride, hipStream_t st);
+// the device path of launch_plnet_s1 (proj + ta8) with the dense layers on the 2-byte matrix pipe, operands as fp16 (hi, lo) pairs (cfg.line_precision = 3):
+// wsplit[4] = the [2][128][K] fp16 planes of fc2.0's thin / aux columns, fc2_res.0, fc2.2, fc2.4 (airfe_load.hip); w = the fp32 set (biases, head, sample_t)
+void launch_plnet_s1h(const float* juncs, const float* lines_pred, const int* keep, const int* pairs, const int* rep, const int* counts, const float* proj,
+                      const float* ta8, const uint16_t* const* wsplit, const float* const* w, float* lines_adjusted, float* scores_line, int keep_cap,
+                      int line_cap, int B, size_t stage_stride, hipStream_t st);
 // la [B][line_cap][4], sc [B][line_cap], lines_out [B][capL][4], nlines [B] (<= capL), nfound [B] or nullptr; jmap [nj][R*R] (zeroed by the
 // caller): the first nj images write their junction maps
 void launch_line_filter(const float* la, const float* sc, const int* counts, int border, float line_thr, float len_thr,

@@ -542,6 +542,250 @@ extern "C" int airfe_dbg_s1(unsigned long long* out, int reset) {
 namespace airfe {
 #endif
 
+// =============================================================================== stage 1 on the 2-byte matrix pipe, fp32-accurate (round 5)
+// The f32-input MFMA above runs at the f32 VECTOR rate (157 TFLOP/s: 368 MFMAs of 64 cycles per wave and 32-line tile, half of the kernel's time).  The reference
+// runs this engine in FP16 (src/plnet.cpp:216); plain fp16 operands move 0.5-0.9 % of the kept lines across the 0.75 threshold with the real weights
+// (profiles/r05_s1_fp16_emulation.txt).  Here every fp32 operand is a PAIR of fp16 values — hi = fp16(v), lo = fp16((v - hi) * 2^11): 22 bits of mantissa, lo
+// scaled so that it is never a denormal — and every product three v_mfma_f32_32x32x16_f16 with fp32 accumulation:
+//     W x  =  hi_W hi_x  +  2^-11 (hi_W lo_x + lo_W hi_x)          (the lo_W lo_x term, 2^-22 relative, is dropped)
+// 138 MFMAs of 32 cycles per wave and tile instead of 368 of 64 (5.3x less matrix time), scores within 2e-6 of the fp32 chain and NO candidate across the threshold
+// in the emulation.  The exactness argument: hi_W hi_x is a product of two 11-bit significands — exact in the fp32 accumulator; so are the two cross terms; what
+// differs from the f32 MFMA is the summation order (as between any two GEMM kernels) and the dropped 2^-22 term.
+// (Compiles to 128 registers at four workgroups per CU with 64 bytes of scratch per lane: a dozen tile-loop-INVARIANT values — table pointers, lane offsets —
+// stored once in the prologue and reloaded at four places per tile, outside the MFMA loops; uncapped it takes 141 registers = three workgroups per CU.)
+// Layouts: weights [2 planes (hi, lo)][128 features][K] fp16 (a lane's A fragment = 8 consecutive k of ONE feature: one 16-byte buffer load); activations in LDS
+// [line][K + pad] fp16, hi plane and lo plane (a lane's B fragment = 8 consecutive k of one line: one ds_read_b128).  Accumulator layout = the f32 kernel's.
+constexpr int S1H_XP = 264;              // halves per line of the x tile (240 + pad)
+constexpr int S1H_HP = 136;              // halves per line of a hidden tile (128 + pad; a multiple of 8: every line starts on a 16-byte boundary for ds_read_b128)
+constexpr float S1H_LO = 2048.0f, S1H_LO_INV = 1.0f / 2048.0f;
+
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4v;
+__device__ __forceinline__ f32x16 mfma_32x32x16h(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void s1h_split(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)((v - (float)hi) * S1H_LO);
+}
+
+template <int K>
+struct S1Wh {                              // the (hi, lo) planes of one layer as a buffer resource: [2][128][K] fp16
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ explicit S1Wh(const uint16_t* w) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(w), 0, 2 * 128 * K * 2, 0x00020000)) {}
+  __device__ __forceinline__ f16x8 ld(unsigned lane_off, unsigned soff) const {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, soff, 0));
+  }
+};
+
+// acc (+)= W[f0 + .., 0:K] x[0:K, line]; bias != nullptr: acc starts from the bias (else from what the caller put there)
+template <int K>
+__device__ __forceinline__ void s1h_dense(const uint16_t* __restrict__ w /*[2][128][K]*/, const float* bias /*LDS or nullptr*/, const uint16_t* xh /*LDS*/,
+                                          const uint16_t* xl, int xp, f32x16& acc, int f0, int lane) {
+  constexpr int STEPS = K / 16, D = 3;     // 16 k per step; D steps of weights in flight
+  static_assert(K % 16 == 0, "K must be a multiple of 16");
+  const int i = lane & 31, kk = lane >> 5;
+  const S1Wh<K> W(w);
+  const unsigned lb = (unsigned)((f0 + i) * K + 8 * kk) * 2u;
+  constexpr unsigned PLANE = 128u * K * 2u;
+  if (bias) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias[f0 + 8 * (r >> 2) + 4 * kk + (r & 3)];
+  }
+  f32x16 lo;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lo[r] = 0.f;
+  const uint16_t* bh = xh + i * xp + 8 * kk;
+  const uint16_t* bl = xl + i * xp + 8 * kk;
+  f16x8 wh[D], wl[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < STEPS) { wh[d] = W.ld(lb, (unsigned)d * 32u); wl[d] = W.ld(lb, PLANE + (unsigned)d * 32u); }
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const f16x8 ah = wh[s % D], al = wl[s % D];
+    const f16x8 xhv = *reinterpret_cast<const f16x8*>(bh + s * 16), xlv = *reinterpret_cast<const f16x8*>(bl + s * 16);
+    acc = mfma_32x32x16h(ah, xhv, acc);
+    lo = mfma_32x32x16h(ah, xlv, lo);
+    lo = mfma_32x32x16h(al, xhv, lo);
+    __builtin_amdgcn_sched_barrier(0);     // the refill stays behind the MFMAs that read the slot, and no later step's loads are hoisted above this one (registers)
+    if (s + D < STEPS) { wh[s % D] = W.ld(lb, (unsigned)(s + D) * 32u); wl[s % D] = W.ld(lb, PLANE + (unsigned)(s + D) * 32u); }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = fmaf(lo[r], S1H_LO_INV, acc[r]);
+}
+
+struct S1WeightsH {
+  const uint16_t *w0, *wr, *w2, *w4;     // (hi, lo) planes: fc2.0's thin / aux columns [128][240], fc2_res.0 [128][240], fc2.2 and fc2.4 [128][128]
+  const float *b0, *br, *b2, *b4, *wh, *bh, *tt;
+};
+
+// The device path of plnet_s1_kernel<true> (junction projections + pixel-major thin / aux) with the four dense layers on the 2-byte matrix pipe.  Same tile walk,
+// same header prefetch, same sampler, same head; what changes is the activation tiles' layout ([line][k] fp16 pairs instead of [k][line] fp32) and s1h_dense.
+__global__ __launch_bounds__(256, 4) void plnet_s1h_kernel(const float* __restrict__ juncs, const float* __restrict__ lines_pred, const int* __restrict__ keep,
+                                                           const int* __restrict__ pairs, const int* __restrict__ rep, const int* __restrict__ counts, S1Loi loi,
+                                                           S1WeightsH w, float* __restrict__ lines_adjusted, float* __restrict__ scores_line, int keep_cap,
+                                                           int line_cap, size_t stage_stride) {
+  // one block, three uses in turn: x tile (hi | lo) [2][32][264] halves = 33792 B; hidden tiles h0 (hi | lo), h1 (hi | lo) [4][32][136] halves = 34816 B; the last
+  // layer's fp32 output [128][33] over h0's place
+  constexpr int XS_HALVES = 4 * S1_LT * S1H_HP > 2 * S1_LT * S1H_XP ? 4 * S1_LT * S1H_HP : 2 * S1_LT * S1H_XP;
+  __shared__ __attribute__((aligned(16))) uint16_t xs[XS_HALVES];
+  __shared__ __attribute__((aligned(16))) float la[S1_LT][4], li[S1_LT][4];
+  __shared__ int lj[S1_LT][2];
+  __shared__ float zh[S1_LT][2];
+  __shared__ float tts[32];
+  __shared__ float bs[4][128];
+  __shared__ float whs[2][128];
+  uint16_t* xh = xs;
+  uint16_t* xl = xs + S1_LT * S1H_XP;
+  uint16_t* h0h = xs;
+  uint16_t* h0l = xs + S1_LT * S1H_HP;
+  uint16_t* h1h = xs + 2 * S1_LT * S1H_HP;
+  uint16_t* h1l = xs + 3 * S1_LT * S1H_HP;
+  float* hf = reinterpret_cast<float*>(xs);              // [128][S1_LP] fp32 = 16896 B: inside h0's two planes
+  static_assert(128 * S1_LP * 4 <= 2 * S1_LT * S1H_HP * 2 && S1H_XP % 8 == 0 && S1H_HP % 8 == 0, "the head's input must fit h0's two planes; rows must start on 16-byte boundaries");
+  {
+    const size_t img = blockIdx.y;
+    juncs += img * stage_stride; lines_pred += img * stage_stride;
+    keep += img * keep_cap; pairs += img * line_cap * 2; rep += img * line_cap; counts += img * LINE_CNT_LD;
+    lines_adjusted += img * line_cap * 4; scores_line += img * line_cap;
+    loi.jfeat += img * loi.jn * 256; loi.ta8 += img * 128 * 128 * 8;
+  }
+  const int m2 = counts[1];
+  const int tid = threadIdx.x, n = tid & 127, g0 = (tid >> 7) * (S1_LT / 2);
+  const int lane = tid & 63, f0 = (tid >> 6) * 32, col = lane & 31, rb = 4 * (lane >> 5);
+  if (tid < 30) tts[tid] = w.tt[tid];
+  if (tid < 128) { bs[0][tid] = w.b0[tid]; bs[1][tid] = w.br[tid]; bs[2][tid] = w.b2[tid]; bs[3][tid] = w.b4[tid]; whs[0][tid] = w.wh[tid]; whs[1][tid] = w.wh[128 + tid]; }
+  const int hl = tid >> 2, hc = tid & 3;
+  int h_j = 0, h_k = 0;
+  float h_v = 0.f, h_li = 0.f;
+  auto header_l1 = [&](int l0n) {
+    if (tid < S1_LT * 4 && l0n < m2) {
+      const int u = min(l0n + hl, m2 - 1);
+      h_j = pairs[u * 2 + (hc >> 1)];
+      h_k = rep[u];
+    }
+  };
+  auto header_l2 = [&](int l0n) {
+    if (tid < S1_LT * 4 && l0n < m2) {
+      h_v = juncs[h_j * 2 + (hc & 1)];
+      h_k = keep[h_k];
+    }
+  };
+  auto header_l3 = [&](int l0n) {
+    if (tid < S1_LT * 4 && l0n < m2) h_li = lines_pred[(size_t)h_k * 4 + hc];
+  };
+  auto header_put = [&](int l0n) {
+    if (tid < S1_LT * 4 && l0n < m2) {
+      la[hl][hc] = h_v;
+      li[hl][hc] = h_li;
+      if ((hc & 1) == 0) lj[hl][hc >> 1] = h_j;
+      if (l0n + hl < m2) lines_adjusted[(size_t)(l0n + hl) * 4 + hc] = h_v;
+    }
+  };
+  // this lane's 4 consecutive features of a hidden layer (accumulator registers 4 q4 .. 4 q4 + 3) of line `col`, as hi | lo halves
+  auto put_hidden = [&](uint16_t* ph, uint16_t* pl, const f32x16& v, bool relu) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      _Float16 hh[4], ll[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s1h_split(relu ? fmaxf(v[4 * q4 + e], 0.f) : v[4 * q4 + e], hh[e], ll[e]);
+      const int off = col * S1H_HP + f0 + 8 * q4 + rb;
+      *reinterpret_cast<uint2*>(ph + off) = __builtin_bit_cast(uint2, f16x4v{hh[0], hh[1], hh[2], hh[3]});
+      *reinterpret_cast<uint2*>(pl + off) = __builtin_bit_cast(uint2, f16x4v{ll[0], ll[1], ll[2], ll[3]});
+    }
+  };
+  const int l_first = blockIdx.x * S1_LT, l_step = gridDim.x * S1_LT;
+  header_l1(l_first); header_l2(l_first); header_l3(l_first);
+  for (int l0 = l_first; l0 < m2; l0 += l_step) {
+    __syncthreads();                                                       // the previous tile is done with xs, zh
+    header_put(l0);
+    __syncthreads();
+    header_l1(l0 + l_step);
+    {
+      // thin / aux taps exactly as plnet_s1_kernel<true> takes them (same bil_setup / bil_eval: the same fp32 values), stored as fp16 pairs at [line][k]
+      constexpr int ITEMS = (S1_LT / 2) * 60, SB = S1_SB;
+      constexpr int ROUNDS = (ITEMS + SB * 128 - 1) / (SB * 128);
+#pragma unroll 1
+      for (int rnd = 0; rnd < ROUNDS; ++rnd) {
+        BilTap bt[SB];
+        float4 a00[SB], a10[SB], a01[SB], a11[SB];
+        int dst[SB];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+          const int it = min(n + (rnd * SB + q) * 128, ITEMS - 1);
+          const int lq = it / 60, rr = it - lq * 60, kind = rr >= 30, j = rr - 30 * kind, l = g0 + lq;
+          const float t = tts[j], t1 = 1.0f - t;
+          const float4 e = *reinterpret_cast<const float4*>(kind ? li[l] : la[l]);
+          bt[q] = bil_setup(128, 128, e.x * t + e.z * t1, e.y * t + e.w * t1);
+          const float4* hp = reinterpret_cast<const float4*>(loi.ta8) + kind;
+          a00[q] = hp[bt[q].i00 * 2]; a10[q] = hp[bt[q].i10 * 2]; a01[q] = hp[bt[q].i01 * 2]; a11[q] = hp[bt[q].i11 * 2];
+          dst[q] = l * S1H_XP + 120 * kind + j;
+        }
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+          const float v00[4] = {a00[q].x, a00[q].y, a00[q].z, a00[q].w}, v10[4] = {a10[q].x, a10[q].y, a10[q].z, a10[q].w};
+          const float v01[4] = {a01[q].x, a01[q].y, a01[q].z, a01[q].w}, v11[4] = {a11[q].x, a11[q].y, a11[q].z, a11[q].w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            _Float16 hh, ll;
+            s1h_split(bil_eval(v00[c], v10[c], v01[c], v11[c], bt[q]), hh, ll);
+            xh[dst[q] + 30 * c] = __builtin_bit_cast(uint16_t, hh);
+            xl[dst[q] + 30 * c] = __builtin_bit_cast(uint16_t, ll);
+          }
+        }
+      }
+    }
+    header_l2(l0 + l_step);
+    __syncthreads();
+    f32x16 o, r;
+    {
+      // b0 + W0[:, 0:128] . loi(j1) + W0[:, 128:256] . loi(j2) (fp32, s1_junc_proj_kernel), then the 240 thin / aux columns on the matrix pipe
+      const float4* p1 = reinterpret_cast<const float4*>(loi.jfeat + (size_t)lj[col][0] * 256 + f0 + rb);
+      const float4* p2 = reinterpret_cast<const float4*>(loi.jfeat + (size_t)lj[col][1] * 256 + 128 + f0 + rb);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 u = p1[2 * q4], v = p2[2 * q4];
+        const float* bb = &bs[0][f0 + 8 * q4 + rb];
+        o[4 * q4] = bb[0] + u.x + v.x; o[4 * q4 + 1] = bb[1] + u.y + v.y; o[4 * q4 + 2] = bb[2] + u.z + v.z; o[4 * q4 + 3] = bb[3] + u.w + v.w;
+      }
+    }
+    s1h_dense<240>(w.w0, nullptr, xh, xl, S1H_XP, o, f0, lane);
+    header_l3(l0 + l_step);
+    s1h_dense<240>(w.wr, bs[1], xh, xl, S1H_XP, r, f0, lane);
+    __syncthreads();                                                       // every wave is done with the x tile
+    put_hidden(h0h, h0l, o, true);
+    __syncthreads();
+    s1h_dense<128>(w.w2, bs[2], h0h, h0l, S1H_HP, o, f0, lane);
+    put_hidden(h1h, h1l, o, true);                                         // (h1 does not overlap h0: no barrier between the last read of h0 and this)
+    __syncthreads();
+    s1h_dense<128>(w.w4, bs[3], h1h, h1l, S1H_HP, o, f0, lane);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) hf[(f0 + 8 * (q >> 2) + rb + (q & 3)) * S1_LP + col] = o[q] + fmaxf(r[q], 0.f);   // over h0 (last read before the previous barrier)
+    __syncthreads();
+    if (tid < S1_LT * 2) {
+      const int l = tid >> 1, c = tid & 1;
+      float z = w.bh[c];
+      for (int k = 0; k < 128; ++k) z = fmaf(whs[c][k], hf[k * S1_LP + l], z);
+      zh[l][c] = z;
+    }
+    __syncthreads();
+    if (tid < S1_LT && l0 + tid < m2) {
+      const float z0 = zh[tid][0], z1 = zh[tid][1], m = fmaxf(z0, z1);
+      const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+      scores_line[l0 + tid] = e1 / (e0 + e1);
+    }
+  }
+}
+
+void launch_plnet_s1h(const float* juncs, const float* lines_pred, const int* keep, const int* pairs, const int* rep, const int* counts, const float* proj,
+                      const float* ta8, const uint16_t* const* wsplit /*w0 wr w2 w4*/, const float* const* w, float* lines_adjusted, float* scores_line, int keep_cap,
+                      int line_cap, int B, size_t stage_stride, hipStream_t st) {
+  S1WeightsH sw{wsplit[0], wsplit[1], wsplit[2], wsplit[3], w[1], w[7], w[3], w[5], w[8], w[9], w[10]};
+  S1Loi sl{nullptr, 0, 128 * 128, 1, proj, 300, ta8};
+  const int gx = B == 1 ? 512 : (B <= 8 ? 128 : 64);
+  hipLaunchKernelGGL(plnet_s1h_kernel, dim3(gx, B), dim3(256), 0, st, juncs, lines_pred, keep, pairs, rep, counts, sl, sw, lines_adjusted, scores_line, keep_cap,
+                     line_cap, stage_stride);
+}
+
 // proj != nullptr (the device path): [B][300][256] junction projections (launch_s1_junc_proj) + ta8 [B][128*128][8] thin | aux pixel-major
 // (launch_s0_decode); loi / thin / aux are not used.  proj == nullptr: the contract's CHW tensors — loi [128][128*128] (one image: loi_img
 // = 0), thin / aux the stage's CHW planes — all 496 features per line.

@@ -529,6 +529,8 @@ def main():
                          "p50 / p99 over --steps pairs, PLNet + LightGlue, host images in, host matrices out; frontend: the WHOLE per-keyframe front end, device-resident — rectify both raw images (camera.cc:161-182), "
                          "the stereo step, AssignPointsToLines on both frames + MatchLines with the stereo band (frame.cc:125,147-184), BoW words of the "
                          "left features (bow/database.cc:57-89)")
+    ap.add_argument("--line-precision", type=int, default=0, choices=[0, 2, 3], help="PLNet stage 1: 2 = f32-input MFMA, 3 = fp16 (hi, lo) operand pairs on the 2-byte MFMA "
+                                                                                     "(the same lines); 0 = the library's default")
     ap.add_argument("--tuning", default="", help="airfe_tuning overrides for A/B runs, e.g. assign_fused=0,overlap_lines=0 (include/airfe.h)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--stage-steps", type=int, default=3, help="extra untimed steps for the per-stage table")
@@ -585,7 +587,7 @@ def main():
     lg = weights.synthetic_lightglue(1234)
     ctx = api.Context(superpoint=sp, lightglue=lg, plnet_s1=s1_path if plnet else None, device=local, precision=1 if args.dtype == "fp16" else 0,
                       matcher_precision=1 if args.matcher_dtype == "fp16" else 0, max_batch=B,
-                      enc_chunk=args.chunk, max_keypoints=K, image_width=W, image_height=H, tuning=args.tuning)
+                      enc_chunk=args.chunk, max_keypoints=K, image_width=W, image_height=H, tuning=args.tuning, line_precision=args.line_precision)
 
     ls, rs = synth.stereo_batch(B, H, W, 1000 + rank)
     L, R = torch.from_numpy(ls).to(dev), torch.from_numpy(rs).to(dev)
@@ -735,6 +737,8 @@ def main():
         }
         if args.tuning:
             out["config"]["tuning"] = args.tuning
+        if plnet:
+            out["config"]["line_precision"] = args.line_precision or "library default (include/airfe.h)"
         if track:
             out["config"]["workload"] = (f"{B} synthetic {W}x{H} uint8 frames per step per GPU, resident in HBM, each matched against its last keyframe's "
                                          f"features (map_builder.cc:94-101); max_keypoints={K}; seeded synthetic weights (reference ONNX files are absent)")

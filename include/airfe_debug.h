@@ -35,6 +35,9 @@ int airfe_debug_plnet_j2l(airfe_ctx* ctx, int fast, float* iskeep, float* idx_mi
 /* wireframe_matcher + stage-1 LOI head alone: lines_adjusted [cap][4], scores_line [cap], *m2 = unique lines */
 int airfe_debug_plnet_s1(airfe_ctx* ctx, const airfe_plnet_stage0* stage0, float* lines_adjusted, float* scores_line,
                          int cap, int* m2);
+/* the stage-1 outputs of image 0 of the LAST PLNet call as the line path left them on the device (the device path's own kernel: cfg.line_precision decides which):
+ * lines_adjusted [cap][4], scores_line [cap], *m2 = unique candidate lines */
+int airfe_debug_plnet_s1_last(airfe_ctx* ctx, float* lines_adjusted, float* scores_line, int cap, int* m2);
 /* the pre-process alone (cv::resize + /255, src/plnet.cpp:246-270): HOST gray image -> HOST fp32 [512][512] */
 int airfe_debug_preprocess(airfe_ctx* ctx, const uint8_t* gray, int h, int w, int stride, float* out);
 int airfe_debug_conv3x3(airfe_ctx* ctx, const float* x, int B, int cin, int H, int W, const float* w, const float* b,

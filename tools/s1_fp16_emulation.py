@@ -21,6 +21,29 @@ def h16(t):
     return t.to(torch.float16).to(torch.float32)
 
 
+def s1_scores_split(w, x, pta):
+    """`cfg.line_precision = 3` as the kernel computes it: every operand as a (hi, lo) PAIR of fp16 values (hi = fp16(v), lo = fp16(v - hi): 22 bits of mantissa),
+    every product as three fp16 MFMAs hi.hi + hi.lo + lo.hi with fp32 accumulation (the lo.lo term, 2^-22 relative, is dropped); junction projections (the 256 LOI
+    columns of fc2.0) stay fp32 scalar arithmetic."""
+    def sp(v):
+        hi = h16(v)
+        return hi, h16(v - hi)
+
+    def lin(name, v, keep32_cols=0):
+        W, b = torch.from_numpy(w[name + ".weight"]), torch.from_numpy(w[name + ".bias"])
+        y = b.clone().expand(v.shape[0], -1).clone()
+        if keep32_cols:
+            y = y + v[:, :keep32_cols] @ W[:, :keep32_cols].t()
+            v, W = v[:, keep32_cols:], W[:, keep32_cols:]
+        vh, vl = sp(v)
+        Wh, Wl = sp(W)
+        return y + vh @ Wh.t() + vh @ Wl.t() + vl @ Wh.t()
+    h = lin("fc2.4", torch.relu(lin("fc2.2", torch.relu(lin("fc2.0", x, 256)))))
+    h = h + torch.relu(lin("fc2_res.0", pta))
+    W, b = torch.from_numpy(w["fc2_head.weight"]), torch.from_numpy(w["fc2_head.bias"])
+    return torch.softmax(h @ W.t() + b, -1)[:, 1].numpy()
+
+
 def s1_scores(w, x, pta, half, proj_f32=False):
     """x [M,496] fp32 features -> scores_line; half: operands through fp16.  proj_f32: the 256 LOI columns of fc2.0 stay fp32 (the device applies them once
     per junction in fp32: s1_junc_proj_kernel)"""
@@ -63,6 +86,7 @@ if __name__ == "__main__":
     print("stage-1 weights: max |w| per layer", {k: float(np.abs(v).max()) for k, v in S1.items() if k.endswith("weight")})
     tot = dict(lines=0, flipped=0, flipped_p=0, cand=0)
     worst = 0.0
+    split_tot = [0, 0.0]
     for seed in seeds:
         img = synth.gabor_image(480, 752, seed)
         ref = ref_chain.plnet_infer(sp, S1, img)
@@ -81,9 +105,15 @@ if __name__ == "__main__":
             out[name] = dict(score_err_max=float(err.max()), score_err_mean=float(err.mean()), lines_fp32=len(l32), lines_fp16=len(l16), candidates=len(sc32),
                              score_flips=len(flips), flip_margins=[round(float(abs(sc32[i] - 0.75)), 5) for i in flips],
                              flips_beyond_2x_err=int(sum(abs(sc32[i] - 0.75) > 2 * err.max() for i in flips)), x_absmax=float(x.abs().max()))
+        scs = s1_scores_split(S1, x, pta)
+        es = np.abs(scs - sc32)
+        out["split_fp16_pairs"] = dict(score_err_max=float(es.max()), score_flips=int(((scs > 0.75) != (sc32 > 0.75)).sum()),
+                                       lines=len(ref_post.line_filter(la, scs, 4, 0.75, 50.0)[0]))
+        split_tot[0] += out["split_fp16_pairs"]["score_flips"]; split_tot[1] = max(split_tot[1], out["split_fp16_pairs"]["score_err_max"])
         print(f"seed {seed}: " + "; ".join(f"{k}: {v}" for k, v in out.items()))
         o = out["fp16_lines_fp32_junctions"]
         tot["lines"] += o["lines_fp32"]; tot["flipped"] += abs(o["lines_fp16"] - o["lines_fp32"]) ; tot["flipped_p"] += o["score_flips"]; tot["cand"] += o["candidates"]
         worst = max(worst, o["score_err_max"])
     print(f"SUMMARY fp16 operands (junction projections fp32): {tot['flipped_p']} of {tot['cand']} candidates change side of the 0.75 threshold "
           f"({tot['lines']} lines kept in fp32: {100.0 * tot['flipped_p'] / max(tot['lines'], 1):.2f} %), largest score error {worst:.5f}")
+    print(f"SUMMARY split fp16 pairs (hi.hi + hi.lo + lo.hi on the 2-byte matrix pipe, fp32 accumulate): {split_tot[0]} candidates change side, largest score error {split_tot[1]:.2e}")
