@@ -155,7 +155,7 @@ void airfe_default_cfg(airfe_cfg* cfg) {
   cfg->image_height = 480;
   cfg->sinkhorn_iters = 100;
   cfg->matcher_precision = 1;      // fp16, what the reference builds its matcher engines with (light_glue.cpp:115, super_glue.cpp:132)
-  cfg->line_precision = 2;         // fp32 operands in stage 1 (the reference's engine: fp16, plnet.cpp:216 — selectable)
+  cfg->line_precision = 0;         // stage 1: fp32 operands as fp16 (hi, lo) pairs on the 2-byte matrix pipe; f32-input MFMA in fp32 mode (include/airfe.h)
   cfg->check_launches = 0;
   cfg->tuning = nullptr;
 }
@@ -204,7 +204,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) try {
   c->Pmax = c->Bmax;
   c->Np = (cfg->max_keypoints + 15) / 16 * 16;      // matcher rows per sequence: whole 16-token MFMA tiles, no further padding
   if (cfg->line_precision < 0 || cfg->line_precision > 3) { return fail(nullptr, "airfe_create: line_precision must be 2 (fp32 operands, f32-input MFMA) or 3 (fp32 operands as fp16 pairs on the 2-byte MFMA)"); }
-  if (c->cfg.line_precision == 0) c->cfg.line_precision = 2;
+  if (c->cfg.line_precision == 0) c->cfg.line_precision = c->prec == 2 ? 2 : 3;      // fp32 mode: every product of the path on f32 operands
   if (c->cfg.line_precision == 1)
     return fail(nullptr, "airfe_create: line_precision = 1 (plain fp16 operands in PLNet stage 1) is refused: measured with the real weights it moves 0.5-0.9 % of the kept "
                          "lines across the 0.75 threshold (profiles/r05_s1_fp16_emulation.txt); line_precision = 3 runs the same products on the 2-byte matrix pipe "
@@ -1344,7 +1344,7 @@ int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* line
   if (upload_stage0(c, s0, st)) return 1;
   float* d = c->s0_stage;
   launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, KEEP_CAP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
-                   c->wf_counts, 1, SG_STRIDE, st);
+                   c->wf_counts, d + SG_JUNCS, d + SG_LP, c->s1_la, c->wf_prop, 1, SG_STRIDE, st);
   launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, c->s0_loi, 0, nullptr, nullptr, d + SG_THIN, d + SG_AUX,
                   c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, 1, SG_STRIDE, st);
   int cnt[2] = {0, 0};

@@ -291,7 +291,7 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
   {
   ProfScope ps(c, ST_PL_STAGE1, st, 0, (double)nb * 49152 * 12);
   launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
-                   c->wf_counts, nb, SG_STRIDE, s4);
+                   c->wf_counts, d + SG_JUNCS, d + SG_LP, c->s1_la, c->wf_prop, nb, SG_STRIDE, s4);
   if (loi_chw) {                    // host-supplied contract tensors: all 496 features per line from the CHW blocks
     launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, loi_chw, 0, nullptr, nullptr, d + SG_THIN, d + SG_AUX,
                     c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
@@ -305,13 +305,13 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
       g.X1 = c->l_feat; g.ld1 = 128; g.K1 = 128; g.Wp = c->cLh_loi.w; g.bias = c->cLh_loi.b; g.rowidx = c->l_ridx;
       g.M = Mp; g.N = 128; g.cb_total = c->cLh_loi.cbt; g.epi = EPI_STORE_F32; g.out = c->l_lrows; g.ldo = 128;
       launch_gemm8(c->prec, 128, false, g, s5);
-      launch_s1_junc_proj(d + SG_JUNCS, nullptr, 0, 0, c->l_lrows, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, s5);
+      if (c->cfg.line_precision == 3) launch_s1h_junc_proj(d + SG_JUNCS, c->l_lrows, 300, c->s1_wsplit[4], c->s1_wsplit[5], c->s1_jfeat, nb, SG_STRIDE, s5);
+      else launch_s1_junc_proj(d + SG_JUNCS, nullptr, 0, 0, c->l_lrows, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, s5);
     } else {
       launch_s1_junc_proj(d + SG_JUNCS, c->l_head, (size_t)128 * 128 * 160, 160, nullptr, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, st);
     }
     if (c->cfg.line_precision == 3)      // the four dense layers on the 2-byte matrix pipe, operands as fp16 (hi, lo) pairs: fp32-accurate (kernels_ext.hip)
-      launch_plnet_s1h(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, c->s1_jfeat, c->l_ta8, c->s1_wsplit, c->s1_w, c->s1_la, c->s1_sc,
-                       KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);
+      launch_plnet_s1h(c->wf_pairs, c->wf_counts, c->s1_jfeat, c->l_ta8, c->s1_wsplit, c->s1_w, c->s1_la, c->wf_prop, c->s1_sc, LINE_CAP, nb, st);
     else
       launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, nullptr, 0, c->s1_jfeat, c->l_ta8, d + SG_THIN,
                       d + SG_AUX, c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);

@@ -225,8 +225,9 @@ struct airfe_ctx {
   // PLNet stage 1 + line path
   bool has_s1 = false;
   const float* s1_w[11] = {nullptr};
-  const uint16_t* s1_wsplit[4] = {nullptr};   // fc2.0 (thin / aux columns), fc2_res.0, fc2.2, fc2.4 as fp16 (hi, lo) planes: plnet_s1h_kernel
+  const uint16_t* s1_wsplit[6] = {nullptr};   // fc2.0 (thin / aux columns), fc2_res.0, fc2.2, fc2.4, fc2.0's LOI columns of end point 1 / 2 as fp16 (hi, lo) planes
   int *wf_table = nullptr, *wf_keep = nullptr, *wf_pairs = nullptr, *wf_rep = nullptr, *wf_counts = nullptr;
+  float* wf_prop = nullptr;                    // [L][LINE_CAP][4]: lines_pred of every unique line's first proposal (wireframe_kernel -> plnet_s1h_kernel)
   float *s1_la = nullptr, *s1_sc = nullptr, *s1_jfeat = nullptr /*[Lmax][300][256]*/, *s0_stage = nullptr /*[Lmax][SG_STRIDE]*/, *s0_loi = nullptr /*CHW [128][128][128], one image*/,
         *junc_feat = nullptr;
   unsigned char* jmap = nullptr;

@@ -525,17 +525,19 @@ int load_plnet_s1(airfe_ctx* c, const char* path) {
   // the same four matrices as fp16 (hi, lo) planes for the 2-byte matrix pipe (cfg.line_precision = 3, kernels_ext.hip plnet_s1h_kernel): [2][128][K], fc2.0 only
   // in its 240 thin / aux columns (its 256 LOI columns are applied per junction in fp32: s1_junc_proj_kernel); lo = fp16((w - hi) * 2^11)
   {
-    struct S { const char* name; int k0, k; } ss[4] = {{"fc2.0", 256, 240}, {"fc2_res.0", 0, 240}, {"fc2.2", 0, 128}, {"fc2.4", 0, 128}};
-    for (int i = 0; i < 4; ++i) {
+    struct S { const char* name; int k0, k; } ss[6] = {{"fc2.0", 256, 240}, {"fc2_res.0", 0, 240}, {"fc2.2", 0, 128}, {"fc2.4", 0, 128},
+                                                     {"fc2.0", 0, 128}, {"fc2.0", 128, 128}};      // [4], [5]: the LOI columns of the two end points (s1h_junc_proj_kernel)
+    for (int i = 0; i < 6; ++i) {
       const Tensor* w = need(p, std::string(ss[i].name) + ".weight", err);
       const int ld = (int)w->data.size() / 128, K = ss[i].k;
-      std::vector<uint16_t> t((size_t)2 * 128 * K);
+      std::vector<uint16_t> t((size_t)2 * 128 * K);      // fragment order (kernels_ext.hip, S1Wh): [feature block n / 32][step k / 16][hi | lo][lane = 32 (k % 16 / 8) + n % 32][k % 8]
       for (int n = 0; n < 128; ++n)
         for (int k = 0; k < K; ++k) {
           const float v = w->data[(size_t)n * ld + ss[i].k0 + k];
           const uint16_t hi = f2h(v);
-          t[(size_t)n * K + k] = hi;
-          t[(size_t)128 * K + (size_t)n * K + k] = f2h((v - h2f(hi)) * 2048.0f);
+          const size_t at = ((size_t)((n >> 5) * (K / 16) + (k >> 4)) * 2 * 64 + (size_t)(32 * ((k >> 3) & 1) + (n & 31))) * 8 + (k & 7);
+          t[at] = hi;
+          t[at + 512] = f2h((v - h2f(hi)) * 2048.0f);
         }
       c->s1_wsplit[i] = dupload(c, t);
       if (!c->s1_wsplit[i]) return fail(c, "device allocation failed (plnet_s1 split weights)");
@@ -552,6 +554,7 @@ int load_plnet_s1(airfe_ctx* c, const char* path) {
   c->wf_keep = dalloc<int>(c, L * KEEP_CAP);
   c->wf_pairs = dalloc<int>(c, L * LINE_CAP * 2);
   c->wf_rep = dalloc<int>(c, L * LINE_CAP);
+  c->wf_prop = dalloc<float>(c, L * LINE_CAP * 4);
   c->wf_counts = dalloc<int>(c, L * LINE_CNT_LD);      // per image: M1, M2, then the per-workgroup counts of wf_count_kernel
   c->s1_la = dalloc<float>(c, L * LINE_CAP * 4);
   c->s1_sc = dalloc<float>(c, L * LINE_CAP);
@@ -564,7 +567,7 @@ int load_plnet_s1(airfe_ctx* c, const char* path) {
   c->d_njunc = dalloc<int>(c, L * (2 + 64));
   c->junc_feat = dalloc<float>(c, (size_t)JUNC_CAP * AIRFE_FEAT_DIM);
   for (int i = 0; i < 11; ++i) if (!c->s1_w[i]) return fail(c, "device allocation failed (plnet_s1 weights)");
-  if (!c->wf_table || !c->wf_keep || !c->wf_pairs || !c->wf_rep || !c->wf_counts || !c->s1_la || !c->s1_sc || !c->s1_jfeat || !c->s0_stage || !c->s0_loi ||
+  if (!c->wf_table || !c->wf_keep || !c->wf_pairs || !c->wf_rep || !c->wf_prop || !c->wf_counts || !c->s1_la || !c->s1_sc || !c->s1_jfeat || !c->s0_stage || !c->s0_loi ||
       !c->jmap || !c->d_lines || !c->d_nlines || !c->d_njunc || !c->junc_feat)
     return fail(c, "device allocation failed (line path arena)");
   c->has_s1 = true;

@@ -186,8 +186,10 @@ void launch_lg_filter_scores(const float* scores, const int* lens, int B, int Np
 // pointers into its stage block, image b's are b * stage_stride floats further; work lists and outputs are dense per image.
 constexpr int LINE_CNT_LD = 64;       // ints of `counts` per image: [0] M1 kept proposals, [1] M2 unique lines, [2 .. 50) scratch
 // table: [B][jn*jn] ints pre-filled with INT_MAX (left clean by the kernel); keep [B][cap], pairs [B][line_cap][2], rep [B][line_cap]
+// head4 / prop4 [B][line_cap][4] or both nullptr: per unique line (juncs[max], juncs[min]) = stage 1's lines_adjusted, and lines_pred of its first proposal
 void launch_wireframe(const float* iskeep, const float* imin, const float* imax, int n, int jn, int* table, int* keep,
-                      int* pairs, int* rep, int cap, int line_cap, int* counts, int B, size_t stage_stride, hipStream_t st);
+                      int* pairs, int* rep, int cap, int line_cap, int* counts, const float* juncs, const float* lines_pred, float* head4, float* prop4, int B,
+                      size_t stage_stride, hipStream_t st);
 // w: 11 device pointers {W0t[496][128], b0, W2t, b2, W4t, b4, Wrt[240][128], br, Wh[2][128], bh, t[30]}; every transposed table is followed by
 // S1_WPAD readable rows (the kernel's weight prefetch runs past the last row)
 constexpr int S1_WPAD = 128;
@@ -203,10 +205,13 @@ void launch_plnet_s1(const float* juncs, const float* lines_pred, const int* kee
                      const float* aux, const float* const* w, float* lines_adjusted, float* scores_line, int keep_cap, int line_cap, int B,
                      size_t stage_stride, hipStream_t st);
 // the device path of launch_plnet_s1 (proj + ta8) with the dense layers on the 2-byte matrix pipe, operands as fp16 (hi, lo) pairs (cfg.line_precision = 3):
-// wsplit[4] = the [2][128][K] fp16 planes of fc2.0's thin / aux columns, fc2_res.0, fc2.2, fc2.4 (airfe_load.hip); w = the fp32 set (biases, head, sample_t)
-void launch_plnet_s1h(const float* juncs, const float* lines_pred, const int* keep, const int* pairs, const int* rep, const int* counts, const float* proj,
-                      const float* ta8, const uint16_t* const* wsplit, const float* const* w, float* lines_adjusted, float* scores_line, int keep_cap,
-                      int line_cap, int B, size_t stage_stride, hipStream_t st);
+// wsplit[4] = the fp16 (hi, lo) fragments of fc2.0's thin / aux columns, fc2_res.0, fc2.2, fc2.4 (airfe_load.hip); w = the fp32 set (biases, head, sample_t);
+// lines_adjusted / prop4 = launch_wireframe's head4 / prop4
+void launch_plnet_s1h(const int* pairs, const int* counts, const float* proj, const float* ta8, const uint16_t* const* wsplit, const float* const* w,
+                      const float* lines_adjusted, const float* prop4, float* scores_line, int line_cap, int B, hipStream_t st);
+// launch_s1_junc_proj's gather form (lrows) on the same pipe: wa / wb = the (hi, lo) planes [2][128][128] of fc2.0's columns 0..127 / 128..255
+void launch_s1h_junc_proj(const float* juncs, const float* lrows, int jn, const uint16_t* wa, const uint16_t* wb, float* proj, int B, size_t stage_stride,
+                          hipStream_t st);
 // la [B][line_cap][4], sc [B][line_cap], lines_out [B][capL][4], nlines [B] (<= capL), nfound [B] or nullptr; jmap [nj][R*R] (zeroed by the
 // caller): the first nj images write their junction maps
 void launch_line_filter(const float* la, const float* sc, const int* counts, int border, float line_thr, float len_thr,

@@ -87,38 +87,106 @@ __global__ __launch_bounds__(256) void wf_emit_kernel(const float* __restrict__ 
   }
 }
 
+// head4 / prop4 [B][line_cap][4] (nullable together): per unique line the two junctions' coordinates (max, min: = stage 1's lines_adjusted) and the first proposal's four
+// numbers — what stage 1 otherwise fetches through pairs -> juncs and rep -> keep -> lines_pred, three dependent loads deep at the head of every one of its tiles.
+constexpr int WF_RC = 8;                 // rounds of 64 per wave kept in registers: <= 16 * 8 * 64 = 8192 kept proposals take the short path
 __global__ __launch_bounds__(1024) void wireframe_kernel(const float* __restrict__ imin, const float* __restrict__ imax, int jn, int* table,
                                                          const int* __restrict__ keep, int* __restrict__ pairs, int* __restrict__ rep,
-                                                         int cap, int line_cap, int* __restrict__ counts, size_t stage_stride) {
+                                                         int cap, int line_cap, int* __restrict__ counts, const float* __restrict__ juncs,
+                                                         const float* __restrict__ lines_pred, float* __restrict__ head4, float* __restrict__ prop4,
+                                                         size_t stage_stride) {
   __shared__ unsigned wcnt[16];
   {
     const size_t img = blockIdx.y;
     imin += img * stage_stride; imax += img * stage_stride;
     table += img * jn * jn; keep += img * cap; pairs += img * line_cap * 2; rep += img * line_cap; counts += img * LINE_CNT_LD;
+    if (head4) { juncs += img * stage_stride; lines_pred += img * stage_stride; head4 += img * line_cap * 4; prop4 += img * line_cap * 4; }
   }
   const int* wg_counts = counts + 2;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   unsigned m1 = 0;
   for (int w = 0; w < WF_WGS; ++w) m1 += (unsigned)wg_counts[w];
   m1 = min(m1, (unsigned)cap);
+  // unique line `pos` = proposal keep[k] = i between junctions a < b
+  auto emit = [&](unsigned pos, int k, int i, int a, int b) {
+    if (pos >= (unsigned)line_cap) return;
+    rep[pos] = k;
+    pairs[pos * 2] = b;           // (max, min): plnet.cpp:301
+    pairs[pos * 2 + 1] = a;
+    if (head4) {
+      const float2 jb = *reinterpret_cast<const float2*>(juncs + b * 2), ja = *reinterpret_cast<const float2*>(juncs + a * 2);
+      *reinterpret_cast<float4*>(head4 + (size_t)pos * 4) = make_float4(jb.x, jb.y, ja.x, ja.y);
+      *reinterpret_cast<float4*>(prop4 + (size_t)pos * 4) = *reinterpret_cast<const float4*>(lines_pred + (size_t)i * 4);
+    }
+  };
+  // every wave owns a contiguous 16th of keep[0 .. m1) and walks it 64 at a time (first-seen order = keep order: positions by ballot + popcount)
+  const int seg2 = ((int)m1 + 15) / 16, t_lo = wv * seg2, t_hi = min(t_lo + seg2, (int)m1);
+  if (m1 <= 16u * WF_RC * 64u) {
+    // the short path: a lane's proposals stay in registers through all four phases — keep -> (imin, imax) is fetched once instead of four times, and the rounds of
+    // a phase issue together (the kernel is one workgroup per image: its time is its chain of dependent loads)
+    int ci[WF_RC], ca[WF_RC], cb[WF_RC];
+    unsigned ok = 0, first = 0;
+#pragma unroll
+    for (int r = 0; r < WF_RC; ++r) {
+      const int k = t_lo + r * 64 + lane;
+      ci[r] = k < t_hi ? keep[k] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < WF_RC; ++r) {
+      ca[r] = ci[r] >= 0 ? (int)imin[ci[r]] : -1;
+      cb[r] = ci[r] >= 0 ? (int)imax[ci[r]] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < WF_RC; ++r)
+      if (ca[r] >= 0 && ca[r] < jn && cb[r] >= 0 && cb[r] < jn) {
+        ok |= 1u << r;
+        atomicMin(&table[ca[r] * jn + cb[r]], t_lo + r * 64 + lane);
+      }
+    __syncthreads();
+    unsigned wc2 = 0;
+#pragma unroll
+    for (int r = 0; r < WF_RC; ++r) {
+      const bool f = ((ok >> r) & 1u) && __hip_atomic_load(&table[ca[r] * jn + cb[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t_lo + r * 64 + lane;
+      first |= (unsigned)f << r;
+      wc2 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(f));
+    }
+    if (lane == 0) wcnt[wv] = wc2;
+    __syncthreads();                    // (also: every read of the table is done)
+    unsigned off2 = 0, m2 = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < wv) off2 += wcnt[w];
+      m2 += wcnt[w];
+    }
+#pragma unroll
+    for (int r = 0; r < WF_RC; ++r) {
+      const bool f = (first >> r) & 1u;
+      const unsigned long long mk = __builtin_amdgcn_ballot_w64(f);
+      if (f) emit(off2 + __builtin_popcountll(mk & ((1ull << lane) - 1ull)), t_lo + r * 64 + lane, ci[r], ca[r], cb[r]);
+      off2 += __builtin_popcountll(mk);
+    }
+#pragma unroll
+    for (int r = 0; r < WF_RC; ++r)     // leave the table clean for the next call
+      if ((ok >> r) & 1u) table[ca[r] * jn + cb[r]] = 0x7FFFFFFF;
+    if (tid == 0) { counts[0] = (int)m1; counts[1] = (int)min(m2, (unsigned)line_cap); }
+    return;
+  }
   for (unsigned k = tid; k < m1; k += 1024) {
     const int i = keep[k];
     const int a = (int)imin[i], b = (int)imax[i];
     if (a >= 0 && a < jn && b >= 0 && b < jn) atomicMin(&table[a * jn + b], (int)k);
   }
   __syncthreads();
-  // the first proposal of every unique pair, in keep order: the wave-segment walk over keep[0 .. m1)
-  const int seg2 = ((int)m1 + 15) / 16, t_lo = wv * seg2, t_hi = min(t_lo + seg2, (int)m1);
-  auto first_of_pair = [&](int k, int& a, int& b) {
-    const int i = keep[k];
+  // the first proposal of every unique pair, in keep order
+  auto first_of_pair = [&](int k, int& i, int& a, int& b) {
+    i = keep[k];
     a = (int)imin[i]; b = (int)imax[i];
     return (a >= 0 && a < jn && b >= 0 && b < jn) && __hip_atomic_load(&table[a * jn + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k;
   };
   unsigned wc2 = 0;
   for (int base = t_lo; base < t_hi; base += 64) {
     const int k = base + lane;
-    int a, b;
-    wc2 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(k < t_hi && first_of_pair(k, a, b)));
+    int i, a, b;
+    wc2 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(k < t_hi && first_of_pair(k, i, a, b)));
   }
   if (lane == 0) wcnt[wv] = wc2;
   __syncthreads();
@@ -129,17 +197,10 @@ __global__ __launch_bounds__(1024) void wireframe_kernel(const float* __restrict
   }
   for (int base = t_lo; base < t_hi; base += 64) {
     const int k = base + lane;
-    int a = 0, b = 0;
-    const bool f = k < t_hi && first_of_pair(k, a, b);
+    int i = 0, a = 0, b = 0;
+    const bool f = k < t_hi && first_of_pair(k, i, a, b);
     const unsigned long long mk = __builtin_amdgcn_ballot_w64(f);
-    if (f) {
-      const unsigned pos = off2 + __builtin_popcountll(mk & ((1ull << lane) - 1ull));
-      if (pos < (unsigned)line_cap) {
-        rep[pos] = k;
-        pairs[pos * 2] = b;           // (max, min): plnet.cpp:301
-        pairs[pos * 2 + 1] = a;
-      }
-    }
+    if (f) emit(off2 + __builtin_popcountll(mk & ((1ull << lane) - 1ull)), k, i, a, b);
     off2 += __builtin_popcountll(mk);
   }
   __syncthreads();
@@ -154,11 +215,12 @@ __global__ __launch_bounds__(1024) void wireframe_kernel(const float* __restrict
 // counts: LINE_CNT_LD ints per image — [0] M1, [1] M2, [2 .. 2 + WF_WGS) scratch (per-workgroup counts);
 // table [B][jn * jn] (0x7FFFFFFF everywhere), keep [B][cap], pairs [B][line_cap][2], rep [B][line_cap]
 void launch_wireframe(const float* iskeep, const float* imin, const float* imax, int n, int jn, int* table, int* keep,
-                      int* pairs, int* rep, int cap, int line_cap, int* counts, int B, size_t stage_stride, hipStream_t st) {
+                      int* pairs, int* rep, int cap, int line_cap, int* counts, const float* juncs, const float* lines_pred, float* head4, float* prop4, int B,
+                      size_t stage_stride, hipStream_t st) {
   hipLaunchKernelGGL(wf_count_kernel, dim3(WF_WGS, B), dim3(256), 0, st, iskeep, n, counts, stage_stride);
   hipLaunchKernelGGL(wf_emit_kernel, dim3(WF_WGS, B), dim3(256), 0, st, iskeep, n, counts, keep, cap, stage_stride);
-  hipLaunchKernelGGL(wireframe_kernel, dim3(1, B), dim3(1024), 0, st, imin, imax, jn, table, keep, pairs, rep, cap, line_cap, counts,
-                     stage_stride);
+  hipLaunchKernelGGL(wireframe_kernel, dim3(1, B), dim3(1024), 0, st, imin, imax, jn, table, keep, pairs, rep, cap, line_cap, counts, juncs, lines_pred,
+                     head4 && prop4 ? head4 : nullptr, prop4, stage_stride);
 }
 
 // =============================================================================== stage-1 LOI head
@@ -553,7 +615,8 @@ namespace airfe {
 // differs from the f32 MFMA is the summation order (as between any two GEMM kernels) and the dropped 2^-22 term.
 // (Compiles to 128 registers at four workgroups per CU with 64 bytes of scratch per lane: a dozen tile-loop-INVARIANT values — table pointers, lane offsets —
 // stored once in the prologue and reloaded at four places per tile, outside the MFMA loops; uncapped it takes 141 registers = three workgroups per CU.)
-// Layouts: weights [2 planes (hi, lo)][128 features][K] fp16 (a lane's A fragment = 8 consecutive k of ONE feature: one 16-byte buffer load); activations in LDS
+// Layouts: weights in FRAGMENT order [4 feature blocks][K / 16][hi | lo][64 lanes][8] fp16 (a lane's A fragment = 8 consecutive k of one feature: one 16-byte buffer
+// load, a wave's = 1 KB in a row; airfe_load.hip writes them); activations in LDS
 // [line][K + pad] fp16, hi plane and lo plane (a lane's B fragment = 8 consecutive k of one line: one ds_read_b128).  Accumulator layout = the f32 kernel's.
 constexpr int S1H_XP = 264;              // halves per line of the x tile (240 + pad)
 constexpr int S1H_HP = 136;              // halves per line of a hidden tile (128 + pad; a multiple of 8: every line starts on a 16-byte boundary for ds_read_b128)
@@ -567,7 +630,7 @@ __device__ __forceinline__ void s1h_split(float v, _Float16& hi, _Float16& lo) {
 }
 
 template <int K>
-struct S1Wh {                              // the (hi, lo) planes of one layer as a buffer resource: [2][128][K] fp16
+struct S1Wh {                              // the (hi, lo) fragments of one layer as a buffer resource: [4 feature blocks][K / 16 steps][2 planes][64 lanes][8] fp16
   __amdgpu_buffer_rsrc_t r;
   __device__ __forceinline__ explicit S1Wh(const uint16_t* w) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(w), 0, 2 * 128 * K * 2, 0x00020000)) {}
   __device__ __forceinline__ f16x8 ld(unsigned lane_off, unsigned soff) const {
@@ -577,14 +640,15 @@ struct S1Wh {                              // the (hi, lo) planes of one layer a
 
 // acc (+)= W[f0 + .., 0:K] x[0:K, line]; bias != nullptr: acc starts from the bias (else from what the caller put there)
 template <int K>
-__device__ __forceinline__ void s1h_dense(const uint16_t* __restrict__ w /*[2][128][K]*/, const float* bias /*LDS or nullptr*/, const uint16_t* xh /*LDS*/,
+__device__ __forceinline__ void s1h_dense(const uint16_t* __restrict__ w /*fragment order, see S1Wh*/, const float* bias /*LDS or nullptr*/, const uint16_t* xh /*LDS*/,
                                           const uint16_t* xl, int xp, f32x16& acc, int f0, int lane) {
   constexpr int STEPS = K / 16, D = 3;     // 16 k per step; D steps of weights in flight
   static_assert(K % 16 == 0, "K must be a multiple of 16");
   const int i = lane & 31, kk = lane >> 5;
   const S1Wh<K> W(w);
-  const unsigned lb = (unsigned)((f0 + i) * K + 8 * kk) * 2u;
-  constexpr unsigned PLANE = 128u * K * 2u;
+  // a wave's A fragments of one step are 2 KB in a row (hi | lo), every 128-byte line of them used in full by ONE instruction: with the row-major [feature][k] layout a
+  // load touched 32 lines for 32 bytes each, and the other 96 bytes had to survive three steps in a vector cache that 16 waves stream through
+  const unsigned lb = (unsigned)lane * 16u, wb = (unsigned)__builtin_amdgcn_readfirstlane(f0 >> 5) * (STEPS * 2048u);
   if (bias) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = bias[f0 + 8 * (r >> 2) + 4 * kk + (r & 3)];
@@ -597,7 +661,7 @@ __device__ __forceinline__ void s1h_dense(const uint16_t* __restrict__ w /*[2][1
   f16x8 wh[D], wl[D];
 #pragma unroll
   for (int d = 0; d < D; ++d)
-    if (d < STEPS) { wh[d] = W.ld(lb, (unsigned)d * 32u); wl[d] = W.ld(lb, PLANE + (unsigned)d * 32u); }
+    if (d < STEPS) { wh[d] = W.ld(lb, wb + (unsigned)d * 2048u); wl[d] = W.ld(lb, wb + (unsigned)d * 2048u + 1024u); }
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     const f16x8 ah = wh[s % D], al = wl[s % D];
@@ -606,7 +670,7 @@ __device__ __forceinline__ void s1h_dense(const uint16_t* __restrict__ w /*[2][1
     lo = mfma_32x32x16h(ah, xlv, lo);
     lo = mfma_32x32x16h(al, xhv, lo);
     __builtin_amdgcn_sched_barrier(0);     // the refill stays behind the MFMAs that read the slot, and no later step's loads are hoisted above this one (registers)
-    if (s + D < STEPS) { wh[s % D] = W.ld(lb, (unsigned)(s + D) * 32u); wl[s % D] = W.ld(lb, PLANE + (unsigned)(s + D) * 32u); }
+    if (s + D < STEPS) { wh[s % D] = W.ld(lb, wb + (unsigned)(s + D) * 2048u); wl[s % D] = W.ld(lb, wb + (unsigned)(s + D) * 2048u + 1024u); }
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
@@ -620,17 +684,15 @@ struct S1WeightsH {
 
 // The device path of plnet_s1_kernel<true> (junction projections + pixel-major thin / aux) with the four dense layers on the 2-byte matrix pipe.  Same tile walk,
 // same header prefetch, same sampler, same head; what changes is the activation tiles' layout ([line][k] fp16 pairs instead of [k][line] fp32) and s1h_dense.
-__global__ __launch_bounds__(256, 4) void plnet_s1h_kernel(const float* __restrict__ juncs, const float* __restrict__ lines_pred, const int* __restrict__ keep,
-                                                           const int* __restrict__ pairs, const int* __restrict__ rep, const int* __restrict__ counts, S1Loi loi,
-                                                           S1WeightsH w, float* __restrict__ lines_adjusted, float* __restrict__ scores_line, int keep_cap,
-                                                           int line_cap, size_t stage_stride) {
-  // one block, three uses in turn: x tile (hi | lo) [2][32][264] halves = 33792 B; hidden tiles h0 (hi | lo), h1 (hi | lo) [4][32][136] halves = 34816 B; the last
-  // layer's fp32 output [128][33] over h0's place
+__global__ __launch_bounds__(256, 4) void plnet_s1h_kernel(const int* __restrict__ pairs, const int* __restrict__ counts, S1Loi loi, S1WeightsH w,
+                                                           const float* __restrict__ lines_adjusted, const float* __restrict__ prop4,
+                                                           float* __restrict__ scores_line, int line_cap) {
+  // one block, two uses in turn: x tile (hi | lo) [2][32][264] halves = 33792 B; hidden tiles h0 (hi | lo), h1 (hi | lo) [4][32][136] halves = 34816 B
   constexpr int XS_HALVES = 4 * S1_LT * S1H_HP > 2 * S1_LT * S1H_XP ? 4 * S1_LT * S1H_HP : 2 * S1_LT * S1H_XP;
   __shared__ __attribute__((aligned(16))) uint16_t xs[XS_HALVES];
   __shared__ __attribute__((aligned(16))) float la[S1_LT][4], li[S1_LT][4];
   __shared__ int lj[S1_LT][2];
-  __shared__ float zh[S1_LT][2];
+  __shared__ float zp[4][2][S1_LT];                        // the 2-way head's partial sums per wave
   __shared__ float tts[32];
   __shared__ float bs[4][128];
   __shared__ float whs[2][128];
@@ -640,45 +702,38 @@ __global__ __launch_bounds__(256, 4) void plnet_s1h_kernel(const float* __restri
   uint16_t* h0l = xs + S1_LT * S1H_HP;
   uint16_t* h1h = xs + 2 * S1_LT * S1H_HP;
   uint16_t* h1l = xs + 3 * S1_LT * S1H_HP;
-  float* hf = reinterpret_cast<float*>(xs);              // [128][S1_LP] fp32 = 16896 B: inside h0's two planes
-  static_assert(128 * S1_LP * 4 <= 2 * S1_LT * S1H_HP * 2 && S1H_XP % 8 == 0 && S1H_HP % 8 == 0, "the head's input must fit h0's two planes; rows must start on 16-byte boundaries");
+  static_assert(S1H_XP % 8 == 0 && S1H_HP % 8 == 0, "rows must start on 16-byte boundaries");
   {
     const size_t img = blockIdx.y;
-    juncs += img * stage_stride; lines_pred += img * stage_stride;
-    keep += img * keep_cap; pairs += img * line_cap * 2; rep += img * line_cap; counts += img * LINE_CNT_LD;
-    lines_adjusted += img * line_cap * 4; scores_line += img * line_cap;
+    pairs += img * line_cap * 2; counts += img * LINE_CNT_LD;
+    lines_adjusted += img * line_cap * 4; prop4 += img * line_cap * 4; scores_line += img * line_cap;
     loi.jfeat += img * loi.jn * 256; loi.ta8 += img * 128 * 128 * 8;
   }
   const int m2 = counts[1];
   const int tid = threadIdx.x, n = tid & 127, g0 = (tid >> 7) * (S1_LT / 2);
   const int lane = tid & 63, f0 = (tid >> 6) * 32, col = lane & 31, rb = 4 * (lane >> 5);
-  if (tid < 30) tts[tid] = w.tt[tid];
-  if (tid < 128) { bs[0][tid] = w.b0[tid]; bs[1][tid] = w.br[tid]; bs[2][tid] = w.b2[tid]; bs[3][tid] = w.b4[tid]; whs[0][tid] = w.wh[tid]; whs[1][tid] = w.wh[128 + tid]; }
-  const int hl = tid >> 2, hc = tid & 3;
-  int h_j = 0, h_k = 0;
-  float h_v = 0.f, h_li = 0.f;
-  auto header_l1 = [&](int l0n) {
-    if (tid < S1_LT * 4 && l0n < m2) {
-      const int u = min(l0n + hl, m2 - 1);
-      h_j = pairs[u * 2 + (hc >> 1)];
-      h_k = rep[u];
+  // a tile's header — per line the two junctions (= lines_adjusted), the first proposal's four numbers, the junction indices — is three 16 / 16 / 8-byte records the
+  // wireframe kernel wrote (the f32 kernel walks pairs -> juncs and rep -> keep -> lines_pred: three dependent loads deep, after the line count): fetched WITHOUT
+  // waiting for the line count, rows past it zeroed when they go to LDS (junction 0 at the origin: in range for every gather, never stored)
+  const int hl = tid & 31, hk = tid >> 5;
+  float4 h_v = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto header_ld = [&](int l0n) {
+    if (tid < 96) {
+      const size_t u = (size_t)min(l0n + hl, line_cap - 1);
+      if (hk == 0) h_v = *reinterpret_cast<const float4*>(lines_adjusted + u * 4);
+      else if (hk == 1) h_v = *reinterpret_cast<const float4*>(prop4 + u * 4);
+      else {
+        const int2 pr = *reinterpret_cast<const int2*>(pairs + u * 2);
+        h_v = make_float4(__int_as_float(pr.x), __int_as_float(pr.y), 0.f, 0.f);
+      }
     }
-  };
-  auto header_l2 = [&](int l0n) {
-    if (tid < S1_LT * 4 && l0n < m2) {
-      h_v = juncs[h_j * 2 + (hc & 1)];
-      h_k = keep[h_k];
-    }
-  };
-  auto header_l3 = [&](int l0n) {
-    if (tid < S1_LT * 4 && l0n < m2) h_li = lines_pred[(size_t)h_k * 4 + hc];
   };
   auto header_put = [&](int l0n) {
-    if (tid < S1_LT * 4 && l0n < m2) {
-      la[hl][hc] = h_v;
-      li[hl][hc] = h_li;
-      if ((hc & 1) == 0) lj[hl][hc >> 1] = h_j;
-      if (l0n + hl < m2) lines_adjusted[(size_t)(l0n + hl) * 4 + hc] = h_v;
+    if (tid < 96) {
+      const float4 v = l0n + hl < m2 ? h_v : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (hk == 0) *reinterpret_cast<float4*>(la[hl]) = v;
+      else if (hk == 1) *reinterpret_cast<float4*>(li[hl]) = v;
+      else { lj[hl][0] = __float_as_int(v.x); lj[hl][1] = __float_as_int(v.y); }
     }
   };
   // this lane's 4 consecutive features of a hidden layer (accumulator registers 4 q4 .. 4 q4 + 3) of line `col`, as hi | lo halves
@@ -693,13 +748,23 @@ __global__ __launch_bounds__(256, 4) void plnet_s1h_kernel(const float* __restri
       *reinterpret_cast<uint2*>(pl + off) = __builtin_bit_cast(uint2, f16x4v{ll[0], ll[1], ll[2], ll[3]});
     }
   };
+#ifdef S1_TIMING
+  long long tacc[11] = {0}, tp_ = wall_clock64();
+#endif
   const int l_first = blockIdx.x * S1_LT, l_step = gridDim.x * S1_LT;
-  header_l1(l_first); header_l2(l_first); header_l3(l_first);
+  header_ld(l_first);
+  if (l_first >= m2) return;                               // the grid is sized for the densest image the arena admits: most of its workgroups have no tile
+  if (tid < 30) tts[tid] = w.tt[tid];
+  if (tid < 128) { bs[0][tid] = w.b0[tid]; bs[1][tid] = w.br[tid]; bs[2][tid] = w.b2[tid]; bs[3][tid] = w.b4[tid]; whs[0][tid] = w.wh[tid]; whs[1][tid] = w.wh[128 + tid]; }
   for (int l0 = l_first; l0 < m2; l0 += l_step) {
-    __syncthreads();                                                       // the previous tile is done with xs, zh
+    __syncthreads();                                                       // the previous tile is done with xs, zp
+#ifdef S1_TIMING
+    if (l0 == l_first) { S1_T(10) } else { S1_T(0) }                       // [10]: the prologue (tables to LDS, the first tile's three dependent header loads)
+#endif
     header_put(l0);
     __syncthreads();
-    header_l1(l0 + l_step);
+    if (l0 + l_step < m2) header_ld(l0 + l_step);
+    S1_T(1)
     {
       // thin / aux taps exactly as plnet_s1_kernel<true> takes them (same bil_setup / bil_eval: the same fp32 values), stored as fp16 pairs at [line][k]
       constexpr int ITEMS = (S1_LT / 2) * 60, SB = S1_SB;
@@ -734,8 +799,9 @@ __global__ __launch_bounds__(256, 4) void plnet_s1h_kernel(const float* __restri
         }
       }
     }
-    header_l2(l0 + l_step);
+    S1_T(2)
     __syncthreads();
+    S1_T(3)
     f32x16 o, r;
     {
       // b0 + W0[:, 0:128] . loi(j1) + W0[:, 128:256] . loi(j2) (fp32, s1_junc_proj_kernel), then the 240 thin / aux columns on the matrix pipe
@@ -749,41 +815,98 @@ __global__ __launch_bounds__(256, 4) void plnet_s1h_kernel(const float* __restri
       }
     }
     s1h_dense<240>(w.w0, nullptr, xh, xl, S1H_XP, o, f0, lane);
-    header_l3(l0 + l_step);
+    S1_T(4)
     s1h_dense<240>(w.wr, bs[1], xh, xl, S1H_XP, r, f0, lane);
+    S1_T(5)
     __syncthreads();                                                       // every wave is done with the x tile
+    S1_T(6)
     put_hidden(h0h, h0l, o, true);
     __syncthreads();
     s1h_dense<128>(w.w2, bs[2], h0h, h0l, S1H_HP, o, f0, lane);
     put_hidden(h1h, h1l, o, true);                                         // (h1 does not overlap h0: no barrier between the last read of h0 and this)
     __syncthreads();
     s1h_dense<128>(w.w4, bs[3], h1h, h1l, S1H_HP, o, f0, lane);
+    S1_T(7)
+    // the 2-way head on the accumulators: this lane's 16 features of line `col`, then the other half of the wave (features + 4), then the four waves through LDS
+    // (the f32 kernel writes the layer to LDS and lets 64 threads walk its 128 features: one more barrier and a 128-step chain per tile)
+    {
+      float z0 = 0.f, z1 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) hf[(f0 + 8 * (q >> 2) + rb + (q & 3)) * S1_LP + col] = o[q] + fmaxf(r[q], 0.f);   // over h0 (last read before the previous barrier)
-    __syncthreads();
-    if (tid < S1_LT * 2) {
-      const int l = tid >> 1, c = tid & 1;
-      float z = w.bh[c];
-      for (int k = 0; k < 128; ++k) z = fmaf(whs[c][k], hf[k * S1_LP + l], z);
-      zh[l][c] = z;
+      for (int q = 0; q < 16; ++q) {
+        const int f = f0 + 8 * (q >> 2) + rb + (q & 3);
+        const float v = o[q] + fmaxf(r[q], 0.f);
+        z0 = fmaf(whs[0][f], v, z0);
+        z1 = fmaf(whs[1][f], v, z1);
+      }
+      z0 += __shfl_xor(z0, 32);
+      z1 += __shfl_xor(z1, 32);
+      if (lane < 32) { zp[tid >> 6][0][col] = z0; zp[tid >> 6][1][col] = z1; }
     }
     __syncthreads();
     if (tid < S1_LT && l0 + tid < m2) {
-      const float z0 = zh[tid][0], z1 = zh[tid][1], m = fmaxf(z0, z1);
+      const float z0 = w.bh[0] + ((zp[0][0][tid] + zp[1][0][tid]) + (zp[2][0][tid] + zp[3][0][tid]));
+      const float z1 = w.bh[1] + ((zp[0][1][tid] + zp[1][1][tid]) + (zp[2][1][tid] + zp[3][1][tid]));
+      const float m = fmaxf(z0, z1);
       const float e0 = expf(z0 - m), e1 = expf(z1 - m);
       scores_line[l0 + tid] = e1 / (e0 + e1);
     }
+    S1_T(8)
+#ifdef S1_TIMING
+    if (tid == 0) tacc[9] += 1;
+#endif
   }
+#ifdef S1_TIMING
+  if (tid == 0) for (int i = 0; i < 11; ++i) atomicAdd(&s1_dbg[i], (unsigned long long)tacc[i]);
+#endif
 }
 
-void launch_plnet_s1h(const float* juncs, const float* lines_pred, const int* keep, const int* pairs, const int* rep, const int* counts, const float* proj,
-                      const float* ta8, const uint16_t* const* wsplit /*w0 wr w2 w4*/, const float* const* w, float* lines_adjusted, float* scores_line, int keep_cap,
-                      int line_cap, int B, size_t stage_stride, hipStream_t st) {
+// The junction projections proj[b][j][0:128] = W0[:, 0:128] . loi(j), [128:256] = W0[:, 128:256] . loi(j) (see s1_junc_proj_kernel) on the same pipe: tiles of 32
+// junctions, the LOI features of a junction combined from its four tap rows exactly as s1_junc_proj_kernel does (bil_eval), split into fp16 pairs, two 128-deep
+// products per tile.  103 us of scalar multiply-adds per 128 images -> a handful of MFMAs per junction tile.
+__global__ __launch_bounds__(256, 4) void s1h_junc_proj_kernel(const float* __restrict__ juncs, const float* __restrict__ lrows, int jn, const uint16_t* __restrict__ wa,
+                                                               const uint16_t* __restrict__ wb, float* __restrict__ proj, size_t stage_stride) {
+  __shared__ __attribute__((aligned(16))) uint16_t xs[2 * S1_LT * S1H_HP];
+  uint16_t* xh = xs;
+  uint16_t* xl = xs + S1_LT * S1H_HP;
+  const int tid = threadIdx.x, n = tid & 127, half = tid >> 7, lane = tid & 63, f0 = (tid >> 6) * 32, col = lane & 31, rb = 4 * (lane >> 5);
+  const size_t img = blockIdx.y;
+  const int j0 = blockIdx.x * S1_LT;
+  const float* jp = juncs + img * stage_stride;
+#pragma unroll 4
+  for (int q = half; q < S1_LT; q += 2) {
+    const int j = min(j0 + q, jn - 1);
+    const BilTap bt = bil_setup(128, 128, jp[j * 2], jp[j * 2 + 1]);
+    const float* rr = lrows + ((img * jn + j) * 4) * 128 + n;
+    _Float16 hh, ll;
+    s1h_split(bil_eval(rr[0], rr[128], rr[256], rr[384], bt), hh, ll);
+    xh[q * S1H_HP + n] = __builtin_bit_cast(uint16_t, hh);
+    xl[q * S1H_HP + n] = __builtin_bit_cast(uint16_t, ll);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    s1h_dense<128>(h ? wb : wa, nullptr, xh, xl, S1H_HP, acc, f0, lane);
+    if (j0 + col < jn) {
+      float* o = proj + (img * jn + j0 + col) * 256 + h * 128 + f0 + rb;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<float4*>(o + 8 * q4) = make_float4(acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]);
+    }
+  }
+}
+void launch_s1h_junc_proj(const float* juncs, const float* lrows, int jn, const uint16_t* wa, const uint16_t* wb, float* proj, int B, size_t stage_stride,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(s1h_junc_proj_kernel, dim3((jn + S1_LT - 1) / S1_LT, B), dim3(256), 0, st, juncs, lrows, jn, wa, wb, proj, stage_stride);
+}
+
+void launch_plnet_s1h(const int* pairs, const int* counts, const float* proj, const float* ta8, const uint16_t* const* wsplit /*w0 wr w2 w4*/, const float* const* w,
+                      const float* lines_adjusted, const float* prop4, float* scores_line, int line_cap, int B, hipStream_t st) {
   S1WeightsH sw{wsplit[0], wsplit[1], wsplit[2], wsplit[3], w[1], w[7], w[3], w[5], w[8], w[9], w[10]};
   S1Loi sl{nullptr, 0, 128 * 128, 1, proj, 300, ta8};
   const int gx = B == 1 ? 512 : (B <= 8 ? 128 : 64);
-  hipLaunchKernelGGL(plnet_s1h_kernel, dim3(gx, B), dim3(256), 0, st, juncs, lines_pred, keep, pairs, rep, counts, sl, sw, lines_adjusted, scores_line, keep_cap,
-                     line_cap, stage_stride);
+  hipLaunchKernelGGL(plnet_s1h_kernel, dim3(gx, B), dim3(256), 0, st, pairs, counts, sl, sw, lines_adjusted, prop4, scores_line, line_cap);
 }
 
 // proj != nullptr (the device path): [B][300][256] junction projections (launch_s1_junc_proj) + ta8 [B][128*128][8] thin | aux pixel-major

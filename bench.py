@@ -47,7 +47,7 @@ def counter_profile(suffix):
 
 
 # which roof a stage is priced against: matrix stages by their algorithmic FLOPs against the dense 2-byte MFMA peak, the rest by
-# their algorithmic bytes against the HBM peak; plnet_stage1 runs f32-input MFMA (157 TFLOP/s) unless cfg.line_precision = 1
+# their algorithmic bytes against the HBM peak; plnet_stage1 is a chain of gathers and a small MLP on the 2-byte MFMA (cfg.line_precision = 3): latency-bound, no single roof
 STAGE_BOUND = {"conv1_fused": "mfma", "conv3x3_cin64": "mfma", "conv3x3_cin128": "mfma", "head_gemm": "mfma", "lg_gemm": "mfma", "lg_attention": "mfma"}
 PEAK_MFMA_F32_TFLOPS = 157.0
 
@@ -529,8 +529,8 @@ def main():
                          "p50 / p99 over --steps pairs, PLNet + LightGlue, host images in, host matrices out; frontend: the WHOLE per-keyframe front end, device-resident — rectify both raw images (camera.cc:161-182), "
                          "the stereo step, AssignPointsToLines on both frames + MatchLines with the stereo band (frame.cc:125,147-184), BoW words of the "
                          "left features (bow/database.cc:57-89)")
-    ap.add_argument("--line-precision", type=int, default=0, choices=[0, 2, 3], help="PLNet stage 1: 2 = f32-input MFMA, 3 = fp16 (hi, lo) operand pairs on the 2-byte MFMA "
-                                                                                     "(the same lines); 0 = the library's default")
+    ap.add_argument("--line-precision", type=int, default=0, choices=[0, 2, 3], help="PLNet stage 1: 3 = fp16 (hi, lo) operand pairs on the 2-byte MFMA, 2 = f32-input MFMA "
+                                                                                     "(the same lines); 0 = the library's default (3)")
     ap.add_argument("--tuning", default="", help="airfe_tuning overrides for A/B runs, e.g. assign_fused=0,overlap_lines=0 (include/airfe.h)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--stage-steps", type=int, default=3, help="extra untimed steps for the per-stage table")
@@ -807,7 +807,7 @@ def main():
                 if STAGE_BOUND.get(k) == "mfma" and v["tflops"]:
                     v["bound"], v["frac"] = "mfma", v["tflops"] / PEAK_MFMA_TFLOPS
                 elif k == "plnet_stage1":
-                    v["bound"], v["frac"] = "hbm (gathers) / f32 mfma", None
+                    v["bound"], v["frac"] = "latency (gather chains + a 4-layer MLP per 32-line tile: DESIGN.md 3)", None
                 elif v["algo_gbs"]:
                     v["bound"], v["frac"] = "hbm", v["algo_gbs"] / PEAK_HBM_GBS
             if out.get("roofline"):

@@ -81,12 +81,13 @@ typedef struct airfe_cfg {
                                   both matcher engines with BuilderFlag::kFP16, light_glue.cpp:115, super_glue.cpp:132; measured 8x
                                   closer to the fp32 oracle than bf16), 0 = bf16, 2 = fp32 (LightGlue only), -1 = same as `precision` */
   int line_precision;          /* how the PLNet stage-1 LOI head's matrix products (src/plnet.cpp:468-514) are computed on the device path:
-                                  2 = fp32 operands on the f32-input MFMA (157 TFLOP/s);
-                                  3 = fp32 operands as PAIRS of fp16 values on the 2-byte MFMA (hi.hi + hi.lo + lo.hi, fp32 accumulation): the same lines
-                                      (scores within 2e-6), a fifth of the matrix time — what lets this engine run on the pipe the reference runs it on
+                                  3 = fp32 operands as PAIRS of fp16 values on the 2-byte MFMA (hi.hi + hi.lo + lo.hi, fp32 accumulation): the lines of the
+                                      fp32 chain (scores within 2e-6, no candidate across the 0.75 threshold), on the pipe the reference runs this engine on
                                       (BuilderFlag::kFP16, src/plnet.cpp:216) without its rounding;
+                                  2 = fp32 operands on the f32-input MFMA (157 TFLOP/s): the same lines, 1.8x the stage's time;
                                   1 = plain fp16 operands, REFUSED: emulated with the real weights it moves 0.5-0.9 % of the kept lines across the 0.75
-                                      threshold (profiles/r05_s1_fp16_emulation.txt).  0 = the library's default */
+                                      threshold (profiles/r05_s1_fp16_emulation.txt);
+                                  0 = default: 3, and 2 in fp32 mode (precision = 2) */
   int check_launches;          /* 1 = hipGetLastError() behind every stage's launches: a failed launch is reported by the call that made it, with
                                   the stage's name (tests run with it); 0 = once per pipeline (default) */
   const airfe_tuning* tuning;       /* kernel-selection overrides (NULL = the library's own choices): A/B measurements and tests that must reach every
