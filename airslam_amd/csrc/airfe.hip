@@ -795,6 +795,7 @@ int airfe_has_line_branch(const airfe_ctx* c) { return c && c->has_s0 && c->has_
 
 // caller-supplied stage-0 tensors (golden / known-answer tests of everything downstream) -> stage slot 0 + the CHW LOI block
 static int upload_stage0(airfe_ctx* c, const airfe_plnet_stage0* s0, hipStream_t st) {
+  c->wf_counted = false;               // host tensors: nothing has counted their kept proposals
   const size_t NP = KEEP_CAP;
   float* d = c->s0_stage;
   HIPCHK(c, hipMemcpyAsync(d + SG_JUNCS, s0->juncs_pred, 600 * 4, hipMemcpyHostToDevice, st));
@@ -1344,7 +1345,7 @@ int airfe_debug_plnet_s1(airfe_ctx* c, const airfe_plnet_stage0* s0, float* line
   if (upload_stage0(c, s0, st)) return 1;
   float* d = c->s0_stage;
   launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, KEEP_CAP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
-                   c->wf_counts, d + SG_JUNCS, d + SG_LP, c->s1_la, c->wf_prop, 1, SG_STRIDE, st);
+                   c->wf_counts, false, d + SG_JUNCS, d + SG_LP, c->s1_la, c->wf_prop, 1, SG_STRIDE, st);
   launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, c->s0_loi, 0, nullptr, nullptr, d + SG_THIN, d + SG_AUX,
                   c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, 1, SG_STRIDE, st);
   int cnt[2] = {0, 0};

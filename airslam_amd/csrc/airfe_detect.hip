@@ -238,7 +238,7 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
     if (run_conv(c, c->cL1, c->a3a + (size_t)i0 * (F + 2) * (F + 2) * 128, c->l_feat, nb, F, F, 0, 0, st)) return 1;
     if (!fused && c->fuse_dec) {        // the 17-channel head and its decode in one pass over the line features (kernels_s0.hip)
       ProfScope ps(c, ST_PL_DECODE, st, 2.0 * nb * F * F * 128 * 17, (double)nb * F * F * (256 + 92));
-      launch_s0_head_decode(c->prec, c->l_feat, c->cLh_dec.w, c->cLh_dec.b, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, c->l_ta8, nb, SG_STRIDE,
+      launch_s0_head_decode(c->prec, c->l_feat, c->cLh_dec.w, c->cLh_dec.b, d + SG_LP, c->l_jloc, nullptr, c->l_joff, c->l_ta8, nb, SG_STRIDE,
                             st);
       head_done = true;
     } else {
@@ -258,17 +258,17 @@ int line_branch_dev(airfe_ctx* c, hipStream_t st, int i0, int nb, bool chw) {
   if (head_done) {
     // (lines_pred, jloc, jnms, joff and the pixel-major thin | aux are already there)
   } else if (fused)
-    launch_s0_decode(c->l_head, 160, 128, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, chw ? c->s0_loi : nullptr, c->l_ta8, nb,
+    launch_s0_decode(c->l_head, 160, 128, d + SG_LP, c->l_jloc, nullptr, c->l_joff, d + SG_THIN, d + SG_AUX, chw ? c->s0_loi : nullptr, c->l_ta8, nb,
                      SG_STRIDE, st);
   else
-    launch_s0_decode(c->l_dec, 32, 0, d + SG_LP, c->l_jloc, c->l_jnms, c->l_joff, d + SG_THIN, d + SG_AUX, nullptr, c->l_ta8, nb, SG_STRIDE, st);
-  // get_junctions: top-300 of the suppressed junction map (score descending, raster ascending on ties)
+    launch_s0_decode(c->l_dec, 32, 0, d + SG_LP, c->l_jloc, nullptr, c->l_joff, d + SG_THIN, d + SG_AUX, nullptr, c->l_ta8, nb, SG_STRIDE, st);
+  // get_junctions: top-300 of the 3x3-suppressed junction map (score descending, raster ascending on ties)
   const int ccap = F * F;
   hipStream_t s3 = st;
-  launch_candidates(c->l_jnms, nb, F, F, 1e-30f, 0, c->l_cand, c->l_cand_cnt, ccap, s3);
+  launch_candidates_nms3(c->l_jloc, nb, F, F, 1e-30f, c->l_cand, c->l_cand_cnt, ccap, s3);      // non_maximum_suppression (3x3) inside the compaction
   launch_select_list(c->l_cand, c->l_cand_cnt, ccap, nb, F, 300, 320, c->l_sel, c->l_nsel, s3);
   launch_s0_juncs(c->l_sel, c->l_nsel, c->l_joff, d + SG_JUNCS, 300, 320, nb, SG_STRIDE, s3);
-  launch_s0_j2l(d + SG_LP, d + SG_JUNCS, 300, NP, 10.0f, d + SG_KEEP, d + SG_MIN, d + SG_MAX, nb, SG_STRIDE, chw ? 1 : 0, s3);
+  c->wf_counted = launch_s0_j2l(d + SG_LP, d + SG_JUNCS, 300, NP, 10.0f, d + SG_KEEP, d + SG_MIN, d + SG_MAX, c->wf_counts, nb, SG_STRIDE, chw ? 1 : 0, s3);
   }
   return launch_status(c);
 }
@@ -291,7 +291,8 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
   {
   ProfScope ps(c, ST_PL_STAGE1, st, 0, (double)nb * 49152 * 12);
   launch_wireframe(d + SG_KEEP, d + SG_MIN, d + SG_MAX, NP, 300, c->wf_table, c->wf_keep, c->wf_pairs, c->wf_rep, KEEP_CAP, LINE_CAP,
-                   c->wf_counts, d + SG_JUNCS, d + SG_LP, c->s1_la, c->wf_prop, nb, SG_STRIDE, s4);
+                   c->wf_counts, c->wf_counted, d + SG_JUNCS, d + SG_LP, c->s1_la, c->wf_prop, nb, SG_STRIDE, s4);
+  c->wf_counted = false;
   if (loi_chw) {                    // host-supplied contract tensors: all 496 features per line from the CHW blocks
     launch_plnet_s1(d + SG_JUNCS, d + SG_LP, c->wf_keep, c->wf_pairs, c->wf_rep, c->wf_counts, loi_chw, 0, nullptr, nullptr, d + SG_THIN, d + SG_AUX,
                     c->s1_w, c->s1_la, c->s1_sc, KEEP_CAP, LINE_CAP, nb, SG_STRIDE, st);

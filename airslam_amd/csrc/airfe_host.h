@@ -218,7 +218,7 @@ struct airfe_ctx {
   int* l_ridx = nullptr;         // [Lmax * 1200 (+ pad)]: tap rows of the junctions
   float* l_lrows = nullptr;      // [Lmax * 1200 (+ pad)][128]: LOI features of those rows
   uint16_t* l_feat = nullptr;    // [Lmax][128*128][128] 2-byte
-  float *l_ta8 = nullptr /*[Lmax][128*128][8] thin | aux pixel-major*/, *l_head = nullptr, *l_jloc = nullptr, *l_jnms = nullptr, *l_joff = nullptr, *l_sel = nullptr;
+  float *l_ta8 = nullptr /*[Lmax][128*128][8] thin | aux pixel-major*/, *l_head = nullptr, *l_jloc = nullptr, *l_joff = nullptr, *l_sel = nullptr;
   int* l_nsel = nullptr;
   unsigned long long* l_cand = nullptr;   // [Lmax][128*128] junction candidates (its own list: the line branch may run beside the point branch's tail)
   int* l_cand_cnt = nullptr;
@@ -227,6 +227,7 @@ struct airfe_ctx {
   const float* s1_w[11] = {nullptr};
   const uint16_t* s1_wsplit[6] = {nullptr};   // fc2.0 (thin / aux columns), fc2_res.0, fc2.2, fc2.4, fc2.0's LOI columns of end point 1 / 2 as fp16 (hi, lo) planes
   int *wf_table = nullptr, *wf_keep = nullptr, *wf_pairs = nullptr, *wf_rep = nullptr, *wf_counts = nullptr;
+  bool wf_counted = false;                     // the stage block's per-workgroup keep counts are in wf_counts (launch_s0_j2l wrote them): launch_wireframe skips its count pass
   float* wf_prop = nullptr;                    // [L][LINE_CAP][4]: lines_pred of every unique line's first proposal (wireframe_kernel -> plnet_s1h_kernel)
   float *s1_la = nullptr, *s1_sc = nullptr, *s1_jfeat = nullptr /*[Lmax][300][256]*/, *s0_stage = nullptr /*[Lmax][SG_STRIDE]*/, *s0_loi = nullptr /*CHW [128][128][128], one image*/,
         *junc_feat = nullptr;

@@ -330,14 +330,13 @@ int load_superpoint(airfe_ctx* c, const char* path) {
     c->l_ridx = dalloc<int>(c, (size_t)c->Lmax * 1200 + 256);
     c->l_lrows = dalloc<float>(c, ((size_t)c->Lmax * 1200 + 256) * 128);
     c->l_jloc = dalloc<float>(c, npx);
-    c->l_jnms = dalloc<float>(c, npx);
     c->l_joff = dalloc<float>(c, 2 * npx);
     c->l_ta8 = dalloc<float>(c, 8 * npx);
     c->l_sel = dalloc<float>(c, (size_t)c->Lmax * 320 * AIRFE_FEAT_DIM);
     c->l_nsel = dalloc<int>(c, c->Lmax);
     c->l_cand = dalloc<unsigned long long>(c, (size_t)c->Lmax * 128 * 128, false);
     c->l_cand_cnt = dalloc<int>(c, c->Lmax);
-    if (!c->l_feat || !c->l_ta8 || !c->l_head || !c->l_dec || !c->l_ridx || !c->l_lrows || !c->l_jloc || !c->l_jnms || !c->l_joff || !c->l_sel || !c->l_nsel || !c->l_cand || !c->l_cand_cnt)
+    if (!c->l_feat || !c->l_ta8 || !c->l_head || !c->l_dec || !c->l_ridx || !c->l_lrows || !c->l_jloc || !c->l_joff || !c->l_sel || !c->l_nsel || !c->l_cand || !c->l_cand_cnt)
       return fail(c, "device allocation failed (line branch arena)");
     c->has_s0 = true;
   }

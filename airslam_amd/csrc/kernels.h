@@ -121,6 +121,8 @@ void launch_nms512_candidates(const float* heat, float* out, void* planes, int B
 // candidates from a finished map (NMS off, or radius != 4 through the multi-pass launch_simple_nms)
 void launch_candidates(const float* heat, int B, int H, int W, float thr, int border, unsigned long long* cand,
                        int* cand_cnt, int cand_cap, hipStream_t st);
+// the same (border 0) over the 3x3-suppressed map a * (a == max3x3(a)) of `heat`, taken on the fly (PLNet's junction map)
+void launch_candidates_nms3(const float* heat, int B, int H, int W, float thr, unsigned long long* cand, int* cand_cnt, int cand_cap, hipStream_t st);
 // exact top-K (score desc, raster asc) / raster order when count <= K, on the candidate list
 //   feat [B][cap][259] rows: score,x,y written (x,y in 512-space, unscaled); n_out [B]
 void launch_select_list(const unsigned long long* cand, const int* cand_cnt, int cand_cap, int B, int W, int topk, int cap,
@@ -185,11 +187,12 @@ void launch_lg_filter_scores(const float* scores, const int* lens, int B, int Np
 // Every launcher takes B images per launch (one per grid row).  iskeep / imin / imax / juncs / lines_pred / thin / aux are IMAGE 0's
 // pointers into its stage block, image b's are b * stage_stride floats further; work lists and outputs are dense per image.
 constexpr int LINE_CNT_LD = 64;       // ints of `counts` per image: [0] M1 kept proposals, [1] M2 unique lines, [2 .. 50) scratch
+constexpr int WF_WGS = 48;            // workgroups that build the raster-ordered list of kept proposals (one contiguous run each)
 // table: [B][jn*jn] ints pre-filled with INT_MAX (left clean by the kernel); keep [B][cap], pairs [B][line_cap][2], rep [B][line_cap]
-// head4 / prop4 [B][line_cap][4] or both nullptr: per unique line (juncs[max], juncs[min]) = stage 1's lines_adjusted, and lines_pred of its first proposal
+// counted: the per-workgroup counts are already in `counts` (launch_s0_j2l); head4 / prop4 [B][line_cap][4] or both nullptr: per unique line (juncs[max], juncs[min]) = stage 1's lines_adjusted, and lines_pred of its first proposal
 void launch_wireframe(const float* iskeep, const float* imin, const float* imax, int n, int jn, int* table, int* keep,
-                      int* pairs, int* rep, int cap, int line_cap, int* counts, const float* juncs, const float* lines_pred, float* head4, float* prop4, int B,
-                      size_t stage_stride, hipStream_t st);
+                      int* pairs, int* rep, int cap, int line_cap, int* counts, bool counted, const float* juncs, const float* lines_pred, float* head4,
+                      float* prop4, int B, size_t stage_stride, hipStream_t st);
 // w: 11 device pointers {W0t[496][128], b0, W2t, b2, W4t, b4, Wrt[240][128], br, Wh[2][128], bh, t[30]}; every transposed table is followed by
 // S1_WPAD readable rows (the kernel's weight prefetch runs past the last row)
 constexpr int S1_WPAD = 128;
@@ -262,7 +265,8 @@ void launch_s0_juncs(const float* sel, const int* n_sel, const float* joff, floa
 // HAWP wireframe_matcher: nearest junctions of both endpoints of n proposals -> iskeep, idx_junc_to_end_min / _max (floats).
 // exact_all = 0: iskeep exact everywhere, min / max exact where iskeep > 0 (all that plnet.cpp:272-307 reads), by a cell search;
 // exact_all = 1: the contract's tensors in full (every proposal against every junction)
-void launch_s0_j2l(const float* lines_pred, const float* juncs, int jn, int n, float thr, float* iskeep, float* imin, float* imax,
+// counts != nullptr: [B][LINE_CNT_LD], and the return value says whether the kernel left launch_wireframe's per-workgroup counts there (counted = true)
+bool launch_s0_j2l(const float* lines_pred, const float* juncs, int jn, int n, float thr, float* iskeep, float* imin, float* imax, int* counts,
                    int B, size_t stage_stride, int exact_all, hipStream_t st);
 
 // ---- SuperGlue ----------------------------------------------------------------------------------------------

@@ -39,7 +39,6 @@ __device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* w
 // — ONE workgroup walking the 49152-entry map was latency-bound at 47 us per frame), the unique pairs by one workgroup over that list.
 // Every kernel of the line path takes one image per grid row (blockIdx.y): iskeep / imin / imax / juncs / lines_pred / thin / aux are
 // image 0's pointers into its stage block (image b: + b * stage_stride floats), the work lists are dense per image.
-constexpr int WF_WGS = 48;
 
 __global__ __launch_bounds__(256) void wf_count_kernel(const float* __restrict__ iskeep, int n, int* __restrict__ counts, size_t stage_stride) {
   __shared__ int wsum[4];
@@ -215,9 +214,9 @@ __global__ __launch_bounds__(1024) void wireframe_kernel(const float* __restrict
 // counts: LINE_CNT_LD ints per image — [0] M1, [1] M2, [2 .. 2 + WF_WGS) scratch (per-workgroup counts);
 // table [B][jn * jn] (0x7FFFFFFF everywhere), keep [B][cap], pairs [B][line_cap][2], rep [B][line_cap]
 void launch_wireframe(const float* iskeep, const float* imin, const float* imax, int n, int jn, int* table, int* keep,
-                      int* pairs, int* rep, int cap, int line_cap, int* counts, const float* juncs, const float* lines_pred, float* head4, float* prop4, int B,
-                      size_t stage_stride, hipStream_t st) {
-  hipLaunchKernelGGL(wf_count_kernel, dim3(WF_WGS, B), dim3(256), 0, st, iskeep, n, counts, stage_stride);
+                      int* pairs, int* rep, int cap, int line_cap, int* counts, bool counted, const float* juncs, const float* lines_pred, float* head4,
+                      float* prop4, int B, size_t stage_stride, hipStream_t st) {
+  if (!counted) hipLaunchKernelGGL(wf_count_kernel, dim3(WF_WGS, B), dim3(256), 0, st, iskeep, n, counts, stage_stride);
   hipLaunchKernelGGL(wf_emit_kernel, dim3(WF_WGS, B), dim3(256), 0, st, iskeep, n, counts, keep, cap, stage_stride);
   hipLaunchKernelGGL(wireframe_kernel, dim3(1, B), dim3(1024), 0, st, imin, imax, jn, table, keep, pairs, rep, cap, line_cap, counts, juncs, lines_pred,
                      head4 && prop4 ? head4 : nullptr, prop4, stage_stride);

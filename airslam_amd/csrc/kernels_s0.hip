@@ -245,7 +245,7 @@ static_assert(J2L_CELLS % 256 == 0, "cells are dealt out evenly over the 256 thr
 
 __global__ __launch_bounds__(256) void s0_j2l_grid_kernel(const float* __restrict__ lines_pred, const float* __restrict__ juncs, int jn, int n,
                                                           float thr, float* __restrict__ iskeep, float* __restrict__ imin,
-                                                          float* __restrict__ imax, size_t stage_stride) {
+                                                          float* __restrict__ imax, int* __restrict__ wg_counts, size_t stage_stride) {
   __shared__ float2 sxy[320];
   __shared__ int sj[320];
   __shared__ int cs[J2L_CELLS + 4], fill[J2L_CELLS];
@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void s0_j2l_grid_kernel(const float* __restric
         if (d < best || (d == best && j < bi)) { best = d; bi = j; }
       }
   };
+  int kept = 0;
   for (int r = 0; r < J2L_PT; ++r) {
     const int p = (blockIdx.x * J2L_PT + r) * 256 + t;
     if (p >= n) break;
@@ -320,9 +321,19 @@ __global__ __launch_bounds__(256) void s0_j2l_grid_kernel(const float* __restric
     nearest(l.x, l.y, c1, i1);
     nearest(l.z, l.w, c2, i2);
     const int lo = min(i1, i2), hi = max(i1, i2);
-    iskeep[p] = (lo < hi && c1 < thr && c2 < thr) ? 1.0f : 0.0f;
+    const bool k = lo < hi && c1 < thr && c2 < thr;
+    kept += k;
+    iskeep[p] = k ? 1.0f : 0.0f;
     imin[p] = (float)lo;
     imax[p] = (float)hi;
+  }
+  // the kept proposals of this workgroup's run of 256 * J2L_PT: the count wf_count_kernel would take over the same run (launch_wireframe's first launch)
+  if (wg_counts) {
+    kept = (int)wave_sum((float)kept);
+    __syncthreads();                    // (wtot's earlier readers)
+    if ((t & 63) == 0) wtot[t >> 6] = kept;
+    __syncthreads();
+    if (t == 0) wg_counts[(size_t)blockIdx.y * LINE_CNT_LD + 2 + blockIdx.x] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
   }
 }
 
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(256) void s0_j2l_grid_kernel(const float* __restric
 void launch_s0_decode(const float* head, int ld, int off, float* lines_pred, float* jloc, float* jnms, float* joff, float* thin, float* aux,
                       float* loi, float* ta8, int B, size_t stage_stride, hipStream_t st) {
   hipLaunchKernelGGL(s0_decode_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, head, lines_pred, jloc, joff, thin, aux, ta8, stage_stride, ld, off);
-  hipLaunchKernelGGL(s0_jnms_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, jloc, jnms);
+  if (jnms) hipLaunchKernelGGL(s0_jnms_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, jloc, jnms);      // (nullptr: the caller takes the candidates with launch_candidates_nms3)
   if (loi) hipLaunchKernelGGL(s0_loi_chw_kernel, dim3(S0_NPX / 32), dim3(256), 0, st, head, loi);
 }
 // X [B * 128*128][128] line features (2-byte), Wp / bias: the packed 17-channel head (its first 64-feature block); jnms = 3x3 NMS of jloc
@@ -345,20 +356,24 @@ void launch_s0_head_decode(int prec, const uint16_t* X, const uint16_t* Wp, cons
     hipLaunchKernelGGL(s0_head_decode_kernel<PF16>, dim3(wgs), dim3(256), 0, st, X, Wp, bias, ntiles, lines_pred, jloc, joff, ta8, stage_stride);
   else
     hipLaunchKernelGGL(s0_head_decode_kernel<PBF16>, dim3(wgs), dim3(256), 0, st, X, Wp, bias, ntiles, lines_pred, jloc, joff, ta8, stage_stride);
-  hipLaunchKernelGGL(s0_jnms_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, jloc, jnms);
+  if (jnms) hipLaunchKernelGGL(s0_jnms_kernel, dim3(S0_NPX / 256, B), dim3(256), 0, st, jloc, jnms);      // (nullptr: the caller takes the candidates with launch_candidates_nms3)
 }
 void launch_s0_juncs(const float* sel, const int* n_sel, const float* joff, float* juncs, int jn, int sel_cap, int B, size_t stage_stride,
                      hipStream_t st) {
   hipLaunchKernelGGL(s0_juncs_kernel, dim3((jn + 63) / 64, B), dim3(64), 0, st, sel, n_sel, joff, juncs, jn, sel_cap, stage_stride);
 }
-void launch_s0_j2l(const float* lines_pred, const float* juncs, int jn, int n, float thr, float* iskeep, float* imin, float* imax,
+bool launch_s0_j2l(const float* lines_pred, const float* juncs, int jn, int n, float thr, float* iskeep, float* imin, float* imax, int* counts,
                    int B, size_t stage_stride, int exact_all, hipStream_t st) {
-  if (exact_all || thr >= (float)(J2L_CELL * J2L_CELL - 1) || jn > 320)
+  if (exact_all || thr >= (float)(J2L_CELL * J2L_CELL - 1) || jn > 320) {
     hipLaunchKernelGGL(s0_j2l_kernel, dim3((n + 255) / 256, B), dim3(256), 0, st, lines_pred, juncs, jn, n, thr, iskeep, imin, imax,
                        stage_stride);
-  else
-    hipLaunchKernelGGL(s0_j2l_grid_kernel, dim3((n + 256 * J2L_PT - 1) / (256 * J2L_PT), B), dim3(256), 0, st, lines_pred, juncs, jn, n, thr,
-                       iskeep, imin, imax, stage_stride);
+    return false;
+  }
+  const int wgs = (n + 256 * J2L_PT - 1) / (256 * J2L_PT);
+  const bool counted = counts && wgs == WF_WGS && n % WF_WGS == 0 && n / WF_WGS == 256 * J2L_PT;      // the wireframe list's runs are this kernel's
+  hipLaunchKernelGGL(s0_j2l_grid_kernel, dim3(wgs, B), dim3(256), 0, st, lines_pred, juncs, jn, n, thr, iskeep, imin, imax, counted ? counts : nullptr,
+                     stage_stride);
+  return counted;
 }
 
 }  // namespace airfe

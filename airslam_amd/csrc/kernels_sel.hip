@@ -52,6 +52,50 @@ __global__ __launch_bounds__(256) void candidates_kernel(const float* __restrict
   }
 }
 
+// candidates_kernel over a * (a == max_pool2d(a, 3, stride 1, padding 1)) (HAWP's non_maximum_suppression, kernels_s0.hip s0_jnms_kernel) without the suppressed
+// map in between: one launch and 2 x 64 KB per image less on the junction path
+__global__ __launch_bounds__(256) void candidates_nms3_kernel(const float* __restrict__ heat, int H, int W, float thr, u64* __restrict__ cand,
+                                                              int* __restrict__ cand_cnt, int cand_cap) {
+  __shared__ u64 lkeys[1024];
+  __shared__ int lcnt[2];
+  const int b = blockIdx.y, N = H * W;
+  const float* hm = heat + (size_t)b * N;
+  for (int s0 = blockIdx.x * 1024; s0 < N; s0 += gridDim.x * 1024) {
+    if (threadIdx.x == 0) lcnt[0] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = s0 + k * 256 + threadIdx.x;
+      if (i < N) {
+        const int y = i / W, x = i - y * W;
+        const float a = hm[i];
+        float m = a;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx, yy = y + dy;
+            if (xx >= 0 && xx < W && yy >= 0 && yy < H) m = fmaxf(m, hm[yy * W + xx]);
+          }
+        const float v = (a == m) ? a : 0.f;
+        if (!(v < thr)) lkeys[atomicAdd(&lcnt[0], 1)] = make_key(v, i);
+      }
+    }
+    __syncthreads();
+    const int n = lcnt[0];
+    if (threadIdx.x == 0 && n > 0) lcnt[1] = atomicAdd(&cand_cnt[b], n);
+    __syncthreads();
+    const int base = lcnt[1];
+    for (int i = threadIdx.x; i < n; i += 256)
+      if (base + i < cand_cap) cand[(size_t)b * cand_cap + base + i] = lkeys[i];
+    __syncthreads();
+  }
+}
+void launch_candidates_nms3(const float* heat, int B, int H, int W, float thr, u64* cand, int* cand_cnt, int cand_cap, hipStream_t st) {
+  (void)hipMemsetAsync(cand_cnt, 0, (size_t)B * sizeof(int), st);
+  hipLaunchKernelGGL(candidates_nms3_kernel, dim3(64, B), dim3(256), 0, st, heat, H, W, thr, cand, cand_cnt, cand_cap);
+}
+
 void launch_candidates(const float* heat, int B, int H, int W, float thr, int border, u64* cand, int* cand_cnt, int cand_cap,
                        hipStream_t st) {
   (void)hipMemsetAsync(cand_cnt, 0, (size_t)B * sizeof(int), st);
