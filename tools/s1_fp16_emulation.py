@@ -22,23 +22,19 @@ def h16(t):
 
 
 def s1_scores_split(w, x, pta):
-    """`cfg.line_precision = 3` as the kernel computes it: every operand as a (hi, lo) PAIR of fp16 values (hi = fp16(v), lo = fp16(v - hi): 22 bits of mantissa),
-    every product as three fp16 MFMAs hi.hi + hi.lo + lo.hi with fp32 accumulation (the lo.lo term, 2^-22 relative, is dropped); junction projections (the 256 LOI
-    columns of fc2.0) stay fp32 scalar arithmetic."""
+    """`cfg.line_precision = 3` as the kernels compute it (plnet_s1h_kernel, s1h_junc_proj_kernel): every operand as a (hi, lo) PAIR of fp16 values
+    (hi = fp16(v), lo = fp16((v - hi) * 2^11): 22 bits of mantissa, lo never a denormal), every product as three fp16 MFMAs hi.hi + 2^-11 (hi.lo + lo.hi) with fp32
+    accumulation (the lo.lo term, 2^-22 relative, is dropped) — the junction projections (the 256 LOI columns of fc2.0) included."""
     def sp(v):
         hi = h16(v)
-        return hi, h16(v - hi)
+        return hi, h16((v - hi) * 2048.0)
 
-    def lin(name, v, keep32_cols=0):
+    def lin(name, v):
         W, b = torch.from_numpy(w[name + ".weight"]), torch.from_numpy(w[name + ".bias"])
-        y = b.clone().expand(v.shape[0], -1).clone()
-        if keep32_cols:
-            y = y + v[:, :keep32_cols] @ W[:, :keep32_cols].t()
-            v, W = v[:, keep32_cols:], W[:, keep32_cols:]
         vh, vl = sp(v)
         Wh, Wl = sp(W)
-        return y + vh @ Wh.t() + vh @ Wl.t() + vl @ Wh.t()
-    h = lin("fc2.4", torch.relu(lin("fc2.2", torch.relu(lin("fc2.0", x, 256)))))
+        return b + vh @ Wh.t() + (vh @ Wl.t() + vl @ Wh.t()) * (1.0 / 2048.0)
+    h = lin("fc2.4", torch.relu(lin("fc2.2", torch.relu(lin("fc2.0", x)))))
     h = h + torch.relu(lin("fc2_res.0", pta))
     W, b = torch.from_numpy(w["fc2_head.weight"]), torch.from_numpy(w["fc2_head.bias"])
     return torch.softmax(h @ W.t() + b, -1)[:, 1].numpy()
