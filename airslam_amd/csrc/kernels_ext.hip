@@ -802,21 +802,25 @@ __global__ __launch_bounds__(256, 4) void plnet_s1h_kernel(const int* __restrict
     __syncthreads();
     S1_T(3)
     f32x16 o, r;
+    // the junction terms of layer 0 — b0 + W0[:, 0:128] . loi(j1) + W0[:, 128:256] . loi(j2), per junction by s1h_junc_proj_kernel — are two gathered rows per line:
+    // asked for here, used after the residual layer (which needs nothing of them) has covered their latency
+    float4 ju[4], jv[4];
     {
-      // b0 + W0[:, 0:128] . loi(j1) + W0[:, 128:256] . loi(j2) (fp32, s1_junc_proj_kernel), then the 240 thin / aux columns on the matrix pipe
       const float4* p1 = reinterpret_cast<const float4*>(loi.jfeat + (size_t)lj[col][0] * 256 + f0 + rb);
       const float4* p2 = reinterpret_cast<const float4*>(loi.jfeat + (size_t)lj[col][1] * 256 + 128 + f0 + rb);
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const float4 u = p1[2 * q4], v = p2[2 * q4];
-        const float* bb = &bs[0][f0 + 8 * q4 + rb];
-        o[4 * q4] = bb[0] + u.x + v.x; o[4 * q4 + 1] = bb[1] + u.y + v.y; o[4 * q4 + 2] = bb[2] + u.z + v.z; o[4 * q4 + 3] = bb[3] + u.w + v.w;
-      }
+      for (int q4 = 0; q4 < 4; ++q4) { ju[q4] = p1[2 * q4]; jv[q4] = p2[2 * q4]; }
+    }
+    s1h_dense<240>(w.wr, bs[1], xh, xl, S1H_XP, r, f0, lane);
+    S1_T(5)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float* bb = &bs[0][f0 + 8 * q4 + rb];
+      o[4 * q4] = bb[0] + ju[q4].x + jv[q4].x; o[4 * q4 + 1] = bb[1] + ju[q4].y + jv[q4].y;
+      o[4 * q4 + 2] = bb[2] + ju[q4].z + jv[q4].z; o[4 * q4 + 3] = bb[3] + ju[q4].w + jv[q4].w;
     }
     s1h_dense<240>(w.w0, nullptr, xh, xl, S1H_XP, o, f0, lane);
     S1_T(4)
-    s1h_dense<240>(w.wr, bs[1], xh, xl, S1H_XP, r, f0, lane);
-    S1_T(5)
     __syncthreads();                                                       // every wave is done with the x tile
     S1_T(6)
     put_hidden(h0h, h0l, o, true);

@@ -17,7 +17,7 @@ HOT = {
     "kernels_conv64r.hip": ["conv64r_kernel"],
     "kernels_conv128r.hip": ["conv128r_kernel"],
     "kernels_gemmr.hip": ["gemmr_kernel", "gemmr_pair_kernel"],
-    "kernels_ext.hip": ["sg_sinkhorn_reg_kernel", "plnet_s1_kernel", "s1_junc_proj_kernel"],
+    "kernels_ext.hip": ["sg_sinkhorn_reg_kernel", "plnet_s1_kernel", "s1_junc_proj_kernel", "s1h_junc_proj_kernel"],
     "kernels_s0.hip": ["s0_j2l_grid_kernel", "s0_decode_kernel"],
     "kernels_nms512.hip": ["nms512_kernel"],
     "kernels_lg.hip": ["lg_sim_lse_kernel", "lg_sim_arg_kernel"],
@@ -77,6 +77,26 @@ def test_hot_kernels_use_no_scratch():
                 seen += 1
                 assert u.get("ScratchSize [bytes/lane]", 0) == 0 and u.get("VGPRs Spill", 0) == 0, (src, name, u)
     assert seen >= 10          # the template instantiations were actually found
+
+
+def test_split_stage1_kernel_spills_only_outside_its_matrix_loops():
+    """plnet_s1h_kernel is capped at 128 registers (four workgroups per CU) and keeps a handful of tile-loop-INVARIANT values in scratch — stored once in the prologue,
+    reloaded between phases.  That is by design (kernels_ext.hip); what must not happen is a scratch access inside a layer's MFMA run."""
+    _compile_all()
+    u = [v for k, v in _usage("kernels_ext.hip").items() if "plnet_s1h_kernel" in k]
+    assert len(u) == 1 and u[0].get("ScratchSize [bytes/lane]", 0) <= 64, u
+    isa = _compile("kernels_ext.hip")[1]
+    body = isa[isa.index("plnet_s1h_kernel"):]
+    body = body[:body.index("s_endpgm")].splitlines()
+    mf = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_f16" in l]
+    sc = [i for i, l in enumerate(body) if re.search(r"\bscratch_(load|store)", l)]
+    assert len(mf) == 138 and len(sc) <= 16, (len(mf), len(sc))
+    # the four layers are runs of MFMAs separated by barriers: no scratch access between the first and last MFMA of a run
+    barriers = [i for i, l in enumerate(body) if "s_barrier" in l]
+    for a, b in zip([0] + barriers, barriers + [len(body)]):
+        run = [i for i in mf if a <= i < b]
+        if run:
+            assert not [i for i in sc if run[0] <= i <= run[-1]], ("scratch access inside an MFMA run", a, b)
 
 
 def test_no_packed_f32_cross_half_selects():

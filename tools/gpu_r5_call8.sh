@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round 5: stage 1 on fp16 (hi, lo) pairs, second cut (2-way head on the accumulators, junction projections on the same pipe): parity, A B A B, phase timing, kernel trace.
 cd "$(dirname "$0")/.."
-OUT=gpurun_out/r05k; mkdir -p $OUT
+OUT=gpurun_out/r05n; mkdir -p $OUT
 timeout 900 python -m pytest tests/test_gpu_stage1_split.py tests/test_gpu_plnet_batch.py tests/test_gpu_lines.py tests/test_gpu_ref_pin.py tests/test_gpu_plnet_s0.py -q -m gpu > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest.log | cut -c1-400
-for lp in 2 3 2 3; do
+for lp in 3 3; do
   timeout 300 python bench.py --steps 60 --warmup 5 --cpu-pairs 0 --line-precision $lp > $OUT/bench_lp$lp.json 2> $OUT/bench_lp$lp.err
   python - <<PY
 import json
