@@ -161,6 +161,32 @@ bool make_linear_named(airfe_ctx* c, const Pack& p, const std::string& name, int
   return make_linear(c, w->data.data(), b->data.data(), K, N, out, scale);
 }
 
+// airfe_tuning::fold_out_proj.  A block computes  h = W1 cat(x, msg) + b1  with  msg = Wo a + bo  (a = the attention output) and nothing between the two
+// linear maps, so  h = W1x x + (W1m Wo) a + (b1 + W1m bo):  the layer is packed as ONE 512 -> 512 linear over cat(x, a) and the 256 x 256 out-projection
+// (LightGlue self_attn.out_proj / cross_attn.to_out, light_glue's exported graph; SuperGlue attn.merge) is never run.  Products summed in double in a fixed
+// order and rounded once to fp32 before the 2-byte packing; `wo_col` = the column order of Wo the caller's attention output has (SuperGlue: head-major).
+bool make_ffn0_folded(airfe_ctx* c, const Tensor& w1, const Tensor& b1, const Tensor& wo, const Tensor& bo, LinW& out, std::string& err,
+                      const std::function<int(int)>* wo_col = nullptr) {
+  if (w1.data.size() != 512 * 512 || b1.data.size() != 512 || wo.data.size() != 256 * 256 || bo.data.size() != 256) { err = "fold_out_proj: unexpected shape"; return false; }
+  std::vector<float> W((size_t)512 * 512), B(512);
+  std::vector<double> row(256);
+  for (int n = 0; n < 512; ++n) {
+    const float* w1n = &w1.data[(size_t)n * 512];
+    memcpy(&W[(size_t)n * 512], w1n, 256 * sizeof(float));
+    std::fill(row.begin(), row.end(), 0.0);
+    double bacc = b1.data[n];
+    for (int j = 0; j < 256; ++j) {
+      const double m = w1n[256 + j];
+      bacc += m * bo.data[j];
+      const float* woj = &wo.data[(size_t)j * 256];
+      for (int k = 0; k < 256; ++k) row[k] += m * woj[k];
+    }
+    for (int k = 0; k < 256; ++k) W[(size_t)n * 512 + 256 + k] = (float)row[wo_col ? (*wo_col)(k) : k];
+    B[n] = (float)bacc;
+  }
+  return make_linear(c, W.data(), B.data(), 512, 512, out, 1.f);
+}
+
 // OpenCV resize() INTER_LINEAR coefficient table (imgproc/src/resize.cpp) -> [d][4] = s0, s1, a0, a1
 std::vector<int> resize_table(int dsize, int ssize) {
   std::vector<int> t((size_t)dsize * 4);
@@ -372,11 +398,19 @@ int load_lightglue(airfe_ctx* c, const char* path) {
     ok = ok && make_linear(c, wqkv->data.data(), bqkv->data.data(), 256, 512, l.qk, ATT_QK_FOLD, &qk_row);
     ok = ok && make_linear(c, wqkv->data.data(), bqkv->data.data(), 256, 256, l.v, 1.f, &v_row);
     ok = ok && make_linear_named(c, p, s + ".out_proj", 256, 256, l.out, err);
+    if (c->fold_out) {         // (l.out / l.cout stay packed: nothing runs them in this context, airfe_debug hooks may)
+      const Tensor *w1 = need(p, s + ".ffn.0.weight", err), *b1f = need(p, s + ".ffn.0.bias", err), *wo = need(p, s + ".out_proj.weight", err), *bo = need(p, s + ".out_proj.bias", err);
+      ok = ok && w1 && b1f && wo && bo && make_ffn0_folded(c, *w1, *b1f, *wo, *bo, l.ffn0, err);
+    } else
     ok = ok && make_linear_named(c, p, s + ".ffn.0", 512, 512, l.ffn0, err);
     ok = ok && make_linear_named(c, p, s + ".ffn.3", 512, 256, l.ffn3, err);
     ok = ok && make_linear_named(c, p, x + ".to_qk", 256, 256, l.cqk, err, ATT_QK_FOLD);
     ok = ok && make_linear_named(c, p, x + ".to_v", 256, 256, l.cv, err);
     ok = ok && make_linear_named(c, p, x + ".to_out", 256, 256, l.cout, err);
+    if (c->fold_out) {
+      const Tensor *w1 = need(p, x + ".ffn.0.weight", err), *b1f = need(p, x + ".ffn.0.bias", err), *wo = need(p, x + ".to_out.weight", err), *bo = need(p, x + ".to_out.bias", err);
+      ok = ok && w1 && b1f && wo && bo && make_ffn0_folded(c, *w1, *b1f, *wo, *bo, l.cffn0, err);
+    } else
     ok = ok && make_linear_named(c, p, x + ".ffn.0", 512, 512, l.cffn0, err);
     ok = ok && make_linear_named(c, p, x + ".ffn.3", 512, 256, l.cffn3, err);
     const Tensor *g1 = need(p, s + ".ffn.1.weight", err), *b1 = need(p, s + ".ffn.1.bias", err);
@@ -485,6 +519,10 @@ int load_superglue(airfe_ctx* c, const char* path) {
     ok = ok && make_linear(c, wqk.data(), bqk.data(), 256, 512, l.qk, ATT_QK_FOLD);
     ok = ok && make_linear(c, wv->data.data(), bv->data.data(), 256, 256, l.v, 1.f, &hm);
     ok = ok && make_linear(c, wm->data.data(), bm->data.data(), 256, 256, l.merge, 1.f, nullptr, &hm);
+    if (c->fold_out) {
+      const Tensor *w1 = need(p, g + ".mlp.0.weight", err), *b1f = need(p, g + ".mlp.0.bias", err);
+      ok = ok && w1 && b1f && make_ffn0_folded(c, *w1, *b1f, *wm, *bm, l.mlp0, err, &hm);
+    } else
     ok = ok && make_linear_named(c, p, g + ".mlp.0", 512, 512, l.mlp0, err);
     ok = ok && make_linear_named(c, p, g + ".mlp.3", 512, 256, l.mlp3, err);
   }

@@ -131,6 +131,7 @@ int lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, con
   a.relu = relu;
   a.attn = c->ob; a.xb = c->xb; a.x32 = c->x32; a.wo = out.w; a.w1 = f0.w; a.w2 = f3.w;
   a.bo = out.b; a.b1 = f0.b; a.gamma = g; a.beta = b; a.b2 = f3.b; a.M = M;
+  if (c->fold_out) { a.wo = nullptr; a.bo = nullptr; }       // the out-projection lives inside f0 (airfe_load.hip, make_ffn0_folded): the kernel's ffn.0 reads cat(x, attn)
   // one workgroup per CU and pass: ceil(M / T) workgroups run in rounds of 256, a round lasts ~T — take the T with the smaller product
   a.tokens_per_wg = ((M + 111) / 112 + 255) / 256 * 112 < ((M + 127) / 128 + 255) / 256 * 128 ? 112 : 128;
   // small token counts (the batch-1 calls of the SLAM loop: 800 tokens): 112-token passes would occupy 8 of the 256 CUs — 32- / 64-token passes
@@ -138,7 +139,8 @@ int lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, con
   if (M <= 256 * 32) a.tokens_per_wg = 32;
   else if (M <= 256 * 64) a.tokens_per_wg = 64;
   if (c->lgb_tokens > 0) a.tokens_per_wg = c->lgb_tokens;          // airfe_tuning::lgb_tokens (measurement switch)
-  double fl = 2.0 * M * (256.0 * 256 + 512.0 * 512 + 512.0 * 256), by = (double)M * (512 + 512 + 1024 + 512 + 1024) + 917504.0;
+  // (algorithmic = what this context's packed network asks for: with the out-projection folded into ffn.0 its 2 * 256 * 256 FLOPs per token do not exist)
+  double fl = 2.0 * M * ((c->fold_out ? 0.0 : 256.0 * 256) + 512.0 * 512 + 512.0 * 256), by = (double)M * (512 + 512 + 1024 + 512 + 1024) + (c->fold_out ? 786432.0 : 917504.0);
   if (nqk && nv) {            // the next attention layer's projections ride along (kernels_lgblockf.hip, FOLD)
     a.nqk_w = nqk->w; a.nqk_b = nqk->b; a.nqk_n = nqk->N; a.nv_w = nv->w; a.nv_b = nv->b;
     a.rot_cos = rotary ? c->rot_cos : nullptr; a.rot_sin = rotary ? c->rot_sin : nullptr;
@@ -151,7 +153,7 @@ int lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, con
 }
 
 int lg_ffn(airfe_ctx* c, const LinW& f0, const float* g, const float* b, const LinW& f3, int M, hipStream_t st) {
-  RUN(run_linear(c, f0, c->xb, 256, 256, c->msg, 256, M, EPI_STORE, ACT_NONE, c->hb, 512, st));
+  RUN(run_linear(c, f0, c->xb, 256, 256, c->fold_out ? c->ob : c->msg, 256, M, EPI_STORE, ACT_NONE, c->hb, 512, st));      // fold_out: cat(x, attention output)
   { ProfScope ps(c, ST_LG_LNGELU, st, 0, (double)M * 2048); launch_ln_gelu(c->mprec, c->hb, g, b, M, st); }
   return run_linear(c, f3, c->hb, 512, 512, nullptr, 0, M, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32);
 }
@@ -238,9 +240,11 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
       if (fold_c) tr_qkv(li, "self.block", false);
       TRACE_HALT;
     } else {
-      RUN(run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st));
-      trace(c, st, "msg", li, "self.out", c->msg, Mw, 2048);
-      TRACE_HALT;
+      if (!c->fold_out) {
+        RUN(run_linear(c, l.out, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st));
+        trace(c, st, "msg", li, "self.out", c->msg, Mw, 2048);
+        TRACE_HALT;
+      }
       RUN(lg_ffn(c, l.ffn0, l.ln_g, l.ln_b, l.ffn3, Mg, st));
       tr_x(li, "self.ffn");
       TRACE_HALT;
@@ -260,9 +264,11 @@ int lightglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
       if (fn) tr_qkv(li, "cross.block", true);
       TRACE_HALT;
     } else {
-      RUN(run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st));
-      trace(c, st, "msg", li, "cross.out", c->msg, Mw, 2048);
-      TRACE_HALT;
+      if (!c->fold_out) {
+        RUN(run_linear(c, l.cout, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st));
+        trace(c, st, "msg", li, "cross.out", c->msg, Mw, 2048);
+        TRACE_HALT;
+      }
       RUN(lg_ffn(c, l.cffn0, l.cln_g, l.cln_b, l.cffn3, Mg, st));
       tr_x(li, "cross.ffn");
       TRACE_HALT;
@@ -348,8 +354,8 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
       RUN(lg_blockf(c, l.merge, l.mlp0, nullptr, nullptr, l.mlp3, Mg, st, 1));
       continue;
     }
-    RUN(run_linear(c, l.merge, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st));
-    RUN(run_linear(c, l.mlp0, c->xb, 256, 256, c->msg, 256, Mg, EPI_STORE, ACT_RELU, c->hb, 512, st));
+    if (!c->fold_out) RUN(run_linear(c, l.merge, c->ob, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->msg, 256, st));
+    RUN(run_linear(c, l.mlp0, c->xb, 256, 256, c->fold_out ? c->ob : c->msg, 256, Mg, EPI_STORE, ACT_RELU, c->hb, 512, st));
     RUN(run_linear(c, l.mlp3, c->hb, 512, 512, nullptr, 0, Mg, EPI_RESID, ACT_NONE, c->xb, 256, st, false, nullptr, c->x32));
   }
   RUN(run_linear(c, c->sg_final, c->xb, 256, 256, nullptr, 0, Mg, EPI_STORE, ACT_NONE, c->mdb, 256, st));

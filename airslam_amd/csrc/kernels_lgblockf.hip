@@ -236,7 +236,10 @@ struct LfLane {                       // per-lane constants of the whole kernel
 // one launch less per layer): 1 = the cross block's shared q/k projection (256 features, head-major) + V (transposed); 2 = the self block's
 // q | k (512 features, rotary) + V.  Same fragments, same K order, bias after the sum and the same rotary code as gemmr_body
 // (kernels_gemmr.hip) / the tiled kernels: the three forms give the same bits.
-template <class P, int NMT, bool RELU, int FOLD>
+// FOLDO = the out-projection is already inside W1's message half (airfe_tuning::fold_out_proj, airfe_load.hip make_ffn0_folded): ffn.0 reads cat(x, attn) — the
+// attn tile sits in R1 where msg would be, the x tile in R0, both in flight when the pass starts — and the 256 x 256 GEMM, the msg pack, one barrier and the
+// mid-GEMM wait for the x tile are gone.
+template <class P, int NMT, bool RELU, int FOLD, bool FOLDO>
 __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const LfLane& L, int row0) {
   const int lane = L.lane, wave = L.wave, l15 = L.l15, g = L.g, wf = L.wf, cb = L.cb, tp = L.tp, fo0 = L.fo0, fo1 = L.fo1;
 #ifdef LF_TIMING
@@ -244,10 +247,15 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   if (wave == 0 && lane == 0) atomicAdd(&lf_dbg[L.tb + 15], 1ull);
 #endif
   typename P::vec8 c2[2][2], c4[4][2];                            // A fragments in flight: 32-feature GEMMs / the 64-feature one
-  lf_first<P, 2>(c2, L.wob + fo0, L.wob + fo1);
-  f32x4 bo2[2], b14[4];                                           // biases of the first two GEMMs: fetched with the attn tile
+  [[maybe_unused]] f32x4 bo2[2];
+  f32x4 b14[4];                                                   // biases of the first two GEMMs: fetched with the attn tile
+  if constexpr (FOLDO) {
+    lf_first<P, 4>(c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1);
+  } else {
+    lf_first<P, 2>(c2, L.wob + fo0, L.wob + fo1);
 #pragma unroll
-  for (int u = 0; u < 2; ++u) bo2[u] = *reinterpret_cast<const f32x4*>(a.bo + cb * 64 + tp * 32 + g * 8 + u * 4);
+    for (int u = 0; u < 2; ++u) bo2[u] = *reinterpret_cast<const f32x4*>(a.bo + cb * 64 + tp * 32 + g * 8 + u * 4);
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) b14[t] = *reinterpret_cast<const f32x4*>(a.b1 + wf * 64 + (t >> 1) * 32 + g * 8 + (t & 1) * 4);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -255,7 +263,8 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   LF_T(0)
 
   // ---- msg = Wo attn + bo -> R1
-  {
+  if constexpr (!FOLDO) {
+    {
     f32x4 acc[2][NMT];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -274,8 +283,9 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
       }
       *reinterpret_cast<uint4*>(smem + LF_R1 + (m * 16 + l15) * 512 + ((piece ^ l15) << 4)) = pack8<P>(v);
     }
+    }
+    __syncthreads();                                              // msg complete, attn dead
   }
-  __syncthreads();                                                // msg complete, attn dead
   LF_T(1)
 
   // ---- h = W1 cat(x, msg) + b1: the msg half first; the x tile's DMA into R0 is issued behind the msg half's LAST weight
@@ -285,12 +295,18 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int m = 0; m < NMT; ++m) h[t][m] = b14[t];
-  lf_mma<P, 4, NMT>(h, c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R1, 512, l15, g,
-                    [&](int s) { if (s == 3) lf_stage_rows(a.xb, row0, NMT, LF_R0, wave, lane); });
-  LF_T(2)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  LF_T(3)
+  if constexpr (FOLDO) {                                          // the attention half (R1 holds the attn tile itself); the x tile landed with it
+    lf_mma<P, 4, NMT>(h, c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R1, 512, l15, g);
+    LF_T(2)
+    LF_T(3)
+  } else {
+    lf_mma<P, 4, NMT>(h, c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R1, 512, l15, g,
+                      [&](int s) { if (s == 3) lf_stage_rows(a.xb, row0, NMT, LF_R0, wave, lane); });
+    LF_T(2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    LF_T(3)
+  }
   lf_mma<P, 4, NMT>(h, c4, L.w1b + fo0, L.w1b + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R0, 512, l15, g);
 
   // LayerNorm scale / shift of this wave's 64 features: fetched now, used after the next barrier
@@ -509,7 +525,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   }
 }
 
-template <class P, int NMT, bool RELU, int FOLD>
+template <class P, int NMT, bool RELU, int FOLD, bool FOLDO>
 __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -531,27 +547,35 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
   L.w2b = reinterpret_cast<const char*>(a.w2) + (size_t)L.cb * 8 * SLAB_BYTES + 2 * L.tp * 2048;
 
   const int row0 = blockIdx.x * (16 * NMT);
-  lf_stage_rows(a.attn, row0, NMT, LF_R0, L.wave, L.lane);
+  lf_stage_rows(a.attn, row0, NMT, FOLDO ? LF_R1 : LF_R0, L.wave, L.lane);
+  if constexpr (FOLDO) lf_stage_rows(a.xb, row0, NMT, LF_R0, L.wave, L.lane);
 #ifdef LF_TIMING
   L.tb = 0;
 #endif
-  lf_pass<P, NMT, RELU, FOLD>(a, smem, L, row0);
+  lf_pass<P, NMT, RELU, FOLD, FOLDO>(a, smem, L, row0);
 #ifdef LF_TWICE
   __syncthreads();
   L.tb = 16;
-  lf_stage_rows(a.attn, row0, NMT, LF_R0, L.wave, L.lane);
-  lf_pass<P, NMT, RELU, FOLD>(a, smem, L, row0);
+  lf_stage_rows(a.attn, row0, NMT, FOLDO ? LF_R1 : LF_R0, L.wave, L.lane);
+  if constexpr (FOLDO) lf_stage_rows(a.xb, row0, NMT, LF_R0, L.wave, L.lane);
+  lf_pass<P, NMT, RELU, FOLD, FOLDO>(a, smem, L, row0);
 #endif
 }
 
-template <class P, int NMT, bool RELU, int FOLD = 0>
-static void launch_f(const LgBlockFArgs& a, hipStream_t st) {
+template <class P, int NMT, bool RELU, int FOLD, bool FOLDO>
+static void launch_fo(const LgBlockFArgs& a, hipStream_t st) {
   static PerDeviceOnce attr_once;
-  auto kfn = lg_blockf_kernel<P, NMT, RELU, FOLD>;
+  auto kfn = lg_blockf_kernel<P, NMT, RELU, FOLD, FOLDO>;
   if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS);
   }
   hipLaunchKernelGGL(kfn, dim3((unsigned)((a.M + 16 * NMT - 1) / (16 * NMT))), dim3(512), LF_LDS, st, a);
+}
+
+template <class P, int NMT, bool RELU, int FOLD = 0>
+static void launch_f(const LgBlockFArgs& a, hipStream_t st) {
+  if (a.wo) launch_fo<P, NMT, RELU, FOLD, false>(a, st);
+  else launch_fo<P, NMT, RELU, FOLD, true>(a, st);          // the out-projection is inside w1 (airfe_tuning::fold_out_proj)
 }
 
 // Tokens per workgroup: one workgroup fits a CU (136 KiB of LDS), so a launch is ceil(M / tokens) workgroups in rounds of 256.

@@ -338,6 +338,39 @@ def synthetic_superglue(seed: int = 1234, n_layers: int = SG_LAYERS, structured:
     return w
 
 
+def _fold_pair(w1: np.ndarray, b1: np.ndarray, wo: np.ndarray, bo: np.ndarray):
+    """ffn.0 over cat(x, Wo a + bo)  ==  ffn.0' over cat(x, a):  W1' = [W1x | W1m Wo], b1' = b1 + W1m bo.  Sums in float64 in the order the loader uses
+    (airslam_amd/csrc/airfe_load.hip make_ffn0_folded: j ascending), rounded once to fp32 — the same bits as the library's own fold."""
+    w1m = w1[:, 256:].astype(np.float64)
+    acc = np.zeros((512, 256), np.float64)
+    bacc = b1.astype(np.float64).copy()
+    wo64, bo64 = wo.astype(np.float64), bo.astype(np.float64)
+    for j in range(256):
+        acc += w1m[:, j:j + 1] * wo64[j:j + 1, :]
+        bacc += w1m[:, j] * bo64[j]
+    return np.concatenate([w1[:, :256], acc.astype(np.float32)], 1).astype(np.float32), bacc.astype(np.float32)
+
+
+def fold_out_proj(w: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """The pack with every attention out-projection (LightGlue self_attn.out_proj / cross_attn.to_out, SuperGlue attn.merge) multiplied into the message half of
+    the ffn.0 / mlp.0 that follows it, and the out-projection itself replaced by the identity: the SAME function (two linear maps with nothing between them), and
+    what `airfe_tuning::fold_out_proj` (the default) does inside the library when it packs the weights.  With the identity as out-projection the message a 2-byte
+    context computes IS the attention output, so `fold_out_proj = 0` on this pack and `fold_out_proj = 1` on the original must give the same bits
+    (tests/test_gpu_lightglue.py) — the test that pins the loader's fold."""
+    o = dict(w)
+    eye, zero = np.eye(256, dtype=np.float32), np.zeros(256, np.float32)
+    for k in list(w):
+        for out, f0 in ((".self_attn.out_proj", ".self_attn.ffn.0"), (".cross_attn.to_out", ".cross_attn.ffn.0"), (".attn.merge", ".mlp.0")):
+            if k.endswith(out + ".weight"):
+                pre = k[: -len(out + ".weight")]
+                o[pre + f0 + ".weight"], o[pre + f0 + ".bias"] = _fold_pair(w[pre + f0 + ".weight"].reshape(512, 512), w[pre + f0 + ".bias"],
+                                                                           w[k].reshape(256, 256), w[pre + out + ".bias"])
+                o[pre + f0 + ".weight"] = o[pre + f0 + ".weight"].reshape(w[pre + f0 + ".weight"].shape)
+                o[k] = eye.reshape(w[k].shape).copy()
+                o[pre + out + ".bias"] = zero.copy()
+    return o
+
+
 def synthetic_plnet_s1(seed: int = 1234) -> Dict[str, np.ndarray]:
     w = synthetic(plnet_s1_spec(), seed + 30)
     w["sample_t"] = linspace_t()

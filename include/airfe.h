@@ -51,7 +51,11 @@ typedef struct airfe_tuning {
   int fuse_dec;          /* PLNet stage-0: 17-channel head + decode in one pass (1) or two (0) */
   int assign_fused;      /* LightGlue assignment: log-sum-exp / arg-max partials taken in the similarity tiles (1; no similarity matrix in HBM)
                             or the round-2 form: similarity matrix + four passes over it (0, the default: the A/B is in profiles/r05_assign_ab.txt) */
-  int reserved[8];       /* must be -1 */
+  int fold_out_proj;     /* LightGlue / SuperGlue: the attention out-projection (out_proj / to_out / merge) multiplied into the message half of ffn.0 / mlp.0 when
+                            the weights are packed — two linear maps with nothing between them are one: W1m (Wo a + bo) = (W1m Wo) a + W1m bo — so a block runs
+                            ffn.0 on cat(x, attention output) and the 256x256 GEMM, its barrier and its message tile are gone (1, the default for fp16 / bf16);
+                            0: the out-projection as a GEMM of its own (the round 1-4 form; profiles/r05_fold_out_ab.txt) */
+  int reserved[7];       /* must be -1 */
 } airfe_tuning;
 
 /* Mirrors the knobs of PLNetConfig / SuperPointConfig / PointMatcherConfig (include/read_configs.h:9-103). */

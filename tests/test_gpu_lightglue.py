@@ -314,6 +314,44 @@ def test_folded_projections_give_the_same_bits():
         np.testing.assert_array_equal(sc_a[i, :nm_a[i]], sc_b[i, :nm_b[i]])
 
 
+@pytest.mark.parametrize("form", [{"fuse_lg_block": 1}, {"fuse_lg_block": 1, "lgb_tokens": 32}, {"fuse_lg_block": 0}], ids=["fused112", "fused32", "split"])
+def test_out_projection_folded_into_ffn0_gives_the_bits_of_the_identity_form(form):
+    """airfe_tuning::fold_out_proj (the default): the loader multiplies out_proj / to_out into the message half of ffn.0 (airfe_load.hip make_ffn0_folded) and
+    the block runs ffn.0 on cat(x, attention output).  Pinned two ways: (1) every oracle test of this file runs the folded form (the default) against the fp32
+    oracle of the ORIGINAL weights; (2) here: weights.fold_out_proj is the same fold in Python with the out-projection replaced by the identity — a context that
+    still runs the out-projection GEMM (fold_out_proj = 0) on THAT pack computes msg = I a = a exactly, so it must return the bits of the folded context on the
+    original pack: same packed ffn.0 slabs (the loader's fold == the Python fold, bit for bit) and the same K order in the kernel."""
+    import torch
+    from airslam_amd import api, weights
+    w = weights.synthetic_lightglue(1234)
+    outs = []
+    for pack, fold in ((w, 1), (weights.fold_out_proj(w), 0)):
+        ctx = api.Context(lightglue=pack, max_batch=8, tuning=dict(form, fold_out_proj=fold), check_launches=1)
+        B = 8
+        pairs = [_pair(400 - 31 * i, 390 - 17 * i, 640 + i) for i in range(B)]
+        f0 = torch.zeros((B, 400, 259)); f1 = torch.zeros((B, 400, 259))
+        n0 = torch.tensor([p[0].shape[0] for p in pairs], dtype=torch.int32)
+        n1 = torch.tensor([p[1].shape[0] for p in pairs], dtype=torch.int32)
+        for i, (a, b, _, _) in enumerate(pairs):
+            f0[i, :a.shape[0]] = torch.from_numpy(a); f1[i, :b.shape[0]] = torch.from_numpy(b)
+        f0, f1, n0, n1 = f0.cuda(), f1.cuda(), n0.cuda(), n1.cuda()
+        idx = torch.zeros((B, 400, 2), dtype=torch.int32, device="cuda")
+        sc = torch.zeros((B, 400), dtype=torch.float32, device="cuda")
+        nm = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        ctx.match_lightglue_batch_dev(f0, n0, f1, n1, idx, sc, nm)
+        ctx.sync()
+        a0, b0 = pairs[0][2], pairs[0][3]
+        outs.append((nm.cpu().numpy().copy(), idx.cpu().numpy().copy(), sc.cpu().numpy().copy(), ctx.lightglue_scores(a0, b0).copy()))
+        ctx.close()
+    (nm_a, idx_a, sc_a, s_a), (nm_b, idx_b, sc_b, s_b) = outs
+    assert nm_a.min() >= 50
+    np.testing.assert_array_equal(nm_a, nm_b)
+    for i in range(len(nm_a)):
+        np.testing.assert_array_equal(idx_a[i, :nm_a[i]], idx_b[i, :nm_b[i]])
+        np.testing.assert_array_equal(sc_a[i, :nm_a[i]], sc_b[i, :nm_b[i]])
+    np.testing.assert_array_equal(s_a, s_b)                  # the whole log-assignment matrix of pair 0, batch-1 path (32-token passes)
+
+
 def test_slack_rows_are_reset_on_every_call():
     """the matcher arena's surplus token rows behind the last sequence go through every block like real tokens; their
     residual stream must start from ZERO on every call (it used to keep growing from call to call on the 2-byte path — NaN in the last pair after

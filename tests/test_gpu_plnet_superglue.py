@@ -130,6 +130,22 @@ def test_superglue_vs_oracle(n0, n1, layers, iters, min_valid, fused):
     ctx.close()
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+def test_superglue_merge_folded_into_mlp0_gives_the_bits_of_the_identity_form(fused):
+    """airfe_tuning::fold_out_proj for SuperGlue: attn.merge (whose input channels the loader permutes to the head-major order of the attention output) multiplied
+    into the message half of mlp.0.  Same pin as tests/test_gpu_lightglue.py: the Python fold with merge = identity, run WITH the merge GEMM, must give the bits
+    of the library's fold on the original pack — which holds only if the loader applied the channel permutation to the folded columns correctly."""
+    w = weights.synthetic_superglue(1234, n_layers=4)
+    _, _, na, nb = _sg_pair(300, 280, 77)
+    zs = []
+    for pack, fold in ((w, 1), (weights.fold_out_proj(w), 0)):
+        ctx = api.Context(superglue=pack, matcher=1, max_batch=2, sinkhorn_iters=20, tuning={"fuse_lg_block": fused, "sg_kenc_gemm": fused, "fold_out_proj": fold}, check_launches=1)
+        zs.append(ctx.superglue_scores(na, nb).copy())
+        ctx.close()
+    assert np.isfinite(zs[0]).all()
+    np.testing.assert_array_equal(zs[0], zs[1])
+
+
 @pytest.mark.parametrize("name", ["ties_threshold_inf_row", "all_minus_inf", "all_equal_below", "all_equal_above",
                                   "random_with_floor_nan", "single", "one_row"])
 def test_decode_kernels_on_hand_built_scores(name):

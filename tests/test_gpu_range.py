@@ -77,7 +77,9 @@ def test_lightglue_fp16_under_hostile_weight_statistics(name, kw):
     a, b = np.ascontiguousarray(normalised(f0)[:, 1:]), np.ascontiguousarray(normalised(f1)[:, 1:])
     ka = (a[:, :2], a[:, 2:], b[:, :2], b[:, 2:])
     ref = ref_nets.lightglue_forward(w, *ka)
-    emu = bisect.lightglue_forward_q(w, *ka, fmt="fp16")           # the device's ten rounding points, on the CPU
+    from airslam_amd import weights as _weights
+    # the device's rounding points on the CPU, on the network the context actually packs (fold_out_proj: out_proj / to_out inside ffn.0, no rounded message)
+    emu = bisect.lightglue_forward_q(_weights.fold_out_proj(w), *ka, fmt="fp16")
     ctx = api.Context(lightglue=w, max_batch=2, matcher_precision=1, check_launches=1)
     s = ctx.lightglue_scores(a, b)
     idx, sc = ctx.match_lightglue(a, b)

@@ -211,3 +211,27 @@ def test_cpu_sinkhorn_of_the_reference():
     rng = np.random.default_rng(5)
     s = rng.normal(0, 1, (12, 9)).astype(np.float32)
     np.testing.assert_allclose(ref_post.log_optimal_transport(s, 2.3457, 20), ref_lib.log_optimal_transport(s, 2.3457, 20), atol=2e-5, rtol=0)
+
+
+def test_fold_out_proj_is_the_same_function():
+    """weights.fold_out_proj (the Python twin of the loader's fold, airfe_tuning::fold_out_proj): out_proj / to_out / merge multiplied into the message half of
+    ffn.0 / mlp.0 and replaced by the identity.  Two linear maps with nothing between them are one: the fp32 oracle must not see the difference."""
+    import numpy as np
+    from airslam_amd import weights
+    from oracle import ref_nets
+    from planted import normalised, planted_pair
+    f0, f1 = planted_pair(90, 80, 3)
+    a, b = normalised(f0)[:, 1:], normalised(f1)[:, 1:]
+    w = weights.synthetic_lightglue(1234, n_layers=3)
+    f = weights.fold_out_proj(w)
+    assert np.array_equal(f["transformers.0.self_attn.out_proj.weight"], np.eye(256, dtype=np.float32)) and not f["transformers.1.cross_attn.to_out.bias"].any()
+    assert np.array_equal(f["transformers.2.self_attn.ffn.0.weight"][:, :256], w["transformers.2.self_attn.ffn.0.weight"][:, :256])      # the x half is untouched
+    s0 = ref_nets.lightglue_forward(w, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:], n_layers=3)
+    s1 = ref_nets.lightglue_forward(f, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:], n_layers=3)
+    assert np.abs(s0 - s1).max() <= 1e-4 * max(1.0, np.abs(s0).max())
+    g0, g1 = normalised(f0, 752, 480, 0.7), normalised(f1, 752, 480, 0.7)
+    sg = weights.synthetic_superglue(1234, n_layers=4)
+    fs = weights.fold_out_proj(sg)
+    z0 = ref_nets.superglue_forward(sg, g0[:, 1:3], g0[:, 0], g0[:, 3:], g1[:, 1:3], g1[:, 0], g1[:, 3:], n_layers=4, iters=20)
+    z1 = ref_nets.superglue_forward(fs, g0[:, 1:3], g0[:, 0], g0[:, 3:], g1[:, 1:3], g1[:, 0], g1[:, 3:], n_layers=4, iters=20)
+    assert np.abs(z0 - z1).max() <= 1e-4 * max(1.0, np.abs(z0).max())
