@@ -365,8 +365,21 @@ def fold_out_proj(w: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
                 pre = k[: -len(out + ".weight")]
                 o[pre + f0 + ".weight"], o[pre + f0 + ".bias"] = _fold_pair(w[pre + f0 + ".weight"].reshape(512, 512), w[pre + f0 + ".bias"],
                                                                            w[k].reshape(256, 256), w[pre + out + ".bias"])
-                o[pre + f0 + ".weight"] = o[pre + f0 + ".weight"].reshape(w[pre + f0 + ".weight"].shape)
-                o[k] = eye.reshape(w[k].shape).copy()
+                if out == ".attn.merge":
+                    # SuperGlue's attention output has the channel order c = d * 4 + h (MultiHeadedAttention's view(dim, heads)); the library keeps it head-major
+                    # (k = h * 64 + d) and permutes merge's input columns when it packs.  For the identity form to hand mlp.0 the library's own operand — the same
+                    # K order, hence the same bits — the stand-in for merge is the PERMUTATION that yields the head-major vector, and mlp.0's message
+                    # columns follow it: msg[j] = a[hm(j)], W1'[:, 256 + j] = (W1m Wm)[:, hm(j)] with hm(j) = (j & 63) * 4 + (j >> 6).  Still the same function.
+                    j = np.arange(256)
+                    hm = (j & 63) * 4 + (j >> 6)
+                    f = o[pre + f0 + ".weight"]
+                    o[pre + f0 + ".weight"] = np.concatenate([f[:, :256], f[:, 256:][:, hm]], 1)
+                    perm = np.zeros((256, 256), np.float32)
+                    perm[j, hm] = 1.0
+                    o[k] = perm.reshape(w[k].shape)
+                else:
+                    o[k] = eye.reshape(w[k].shape).copy()
+                o[pre + f0 + ".weight"] = np.ascontiguousarray(o[pre + f0 + ".weight"].reshape(w[pre + f0 + ".weight"].shape))
                 o[pre + out + ".bias"] = zero.copy()
     return o
 

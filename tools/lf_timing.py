@@ -11,7 +11,8 @@ subprocess.check_call(["cp", "airslam_amd/libairfe_T.so.tmp", "airslam_amd/libai
 import torch
 from airslam_amd import api, weights, _lib
 from planted import normalised, planted_pair
-names = ["wait: attn tile + first weights (launch start -> first barrier)", "out-proj (4 slabs) + msg pack + barrier", "ffn.0 msg half (4 slabs) + x-tile DMA issue",
+# (fold_out_proj, the default: no out-projection phase; the "msg half" is the attention half, under which the x tile lands)
+names = ["wait: attn tile + first weights (launch start -> first barrier)", "out-proj (4 slabs) + msg pack + barrier", "ffn.0 msg / attention half (4 slabs) + x-tile DMA issue",
          "wait: x tile + barrier", "ffn.0 x half (4 slabs) + LayerNorm partial sums", "barrier (sums)", "LayerNorm + GELU + pack, residual rows fetched",
          "barrier (h tile)", "ffn.3 (8 slabs) + residual + x stores", "2 barriers + x tile back into LDS", "folded q | k units (4 slabs each) + rotary + stores",
          "folded V unit (4 slabs, transposed) + stores"]
