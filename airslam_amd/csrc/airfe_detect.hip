@@ -190,7 +190,10 @@ int detect_dev2(airfe_ctx* c, const uint8_t* d_gray, const uint8_t* d_gray1, int
     g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b; g.rowidx = c->desc_idx;
     g.M = Mp; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
     ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * Mp * 256 * 256, (double)Mp * (512 + 1024));
-    launch_gemm8(c->prec, 256, false, g, st);
+    // large batches: the streaming kernel with gathered rows (kernels_gemmr.hip, GATHER) — the tiled 8-wave kernel ran this HBM-bound shape at 2.3 TB/s; the same bits
+    g.gr_wgs = c->gemmr_wgs;
+    if (c->desc_gather_stream && Mp >= c->gemmr_min && gemmr_gather_applicable(256, g)) launch_gemmr_gather(c->prec, g, st);
+    else launch_gemm8(c->prec, 256, false, g, st);
   }
   for (int half = 0; half < nhalf; ++half) {
     const int b0 = half * Bs;

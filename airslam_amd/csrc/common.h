@@ -20,11 +20,40 @@ struct PerDeviceOnce {
 };
 
 
-// `std::exp(float)` as the reference's host code computes it (glibc expf: correctly rounded in practice) for the two places where an exponential
-// becomes an OUTPUT or meets a THRESHOLD (filter_matches src/light_glue.cpp:248-249, decode src/super_glue.cpp:299,355).  OCML's expf is a 1-ulp
-// routine: beside the compiled reference (oracle/_ref, tests/test_gpu_ref_pin.py) it differed in the last bit of 7 % of the match scores.  The
-// double exponential rounded once gives glibc's bits; the call sites see at most 1024 values per pair.
-__device__ __forceinline__ float expf_like_glibc(float x) { return (float)exp((double)x); }
+// `std::exp(float)` as the reference's host code computes it, for the two places where an exponential becomes an OUTPUT or meets a THRESHOLD (filter_matches
+// src/light_glue.cpp:248-249, decode src/super_glue.cpp:299,355).  OCML's expf is a 1-ulp routine: beside the compiled reference (oracle/_ref,
+// tests/test_gpu_ref_pin.py) it differed in the last bit of 7 % of the match scores.  Rounds 3-4 used (float)exp((double)x) — the correctly rounded value — which
+// is what glibc returns "in practice" but not always: its expf has 0.502 ulp, and against the host's libm the correctly rounded value differs on 0.063 % of the
+// inputs (37902 of 6e7 sampled), i.e. on one of ~200 match scores in every eighth pair (round 5: it turned tests/test_gpu_ref_pin.py red the moment the scores
+// moved).  So this IS glibc's algorithm (glibc >= 2.27, sysdeps/ieee754/flt-32/e_expf.c with the exp2f_data table: x N / ln 2 = k + r by the 1.5 * 2^52 shift,
+// 2^(k / N) from a 32-entry table, a cubic in r, all in double) with the contractions of the FMA build x86-64 hosts select (__expf_fma: r = fma(InvLn2N, x, -k),
+// the only one of its fused operations that is visible in the results).  Verified on the CPU against glibc 2.35's expf on EVERY float (2 x 2139095041 values, 0
+// mismatches: tools/expf_glibc_check.c); double arithmetic on the device is IEEE, so the bits carry over.  The call sites see at most 1024 values per pair.
+__device__ __forceinline__ float expf_like_glibc(float x) {
+  constexpr unsigned long long T[32] = {
+      0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull,
+      0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull,
+      0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull,
+      0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+      0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+  constexpr double InvLn2N = 0x1.71547652b82fep+0 * 32, SHIFT = 0x1.8p+52;
+  constexpr double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+  if (x != x) return x + x;
+  if (x > 0x1.62e42ep6f) return __builtin_inff();                    // overflow
+  if (x < -0x1.9fe368p6f) return 0.0f;                               // below the smallest subnormal (also -inf)
+  const double xd = (double)x;
+  double kd = __builtin_fma(InvLn2N, xd, SHIFT);
+  const unsigned long long ki = __builtin_bit_cast(unsigned long long, kd);
+  kd -= SHIFT;
+  const double r = __builtin_fma(InvLn2N, xd, -kd);
+  const double s = __builtin_bit_cast(double, T[ki % 32] + (ki << 47));
+  const double z = __builtin_fma(C0, r, C1);
+  const double r2 = r * r;
+  double y = __builtin_fma(C2, r, 1.0);
+  y = __builtin_fma(z, r2, y);
+  const double ys = y * s;
+  return (float)ys;
+}
 
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -13,6 +13,11 @@
 // waits rely on loads retiring in order: "at most 2*(tiles still in flight behind the wanted one)" outstanding.
 // Rotary (self q|k): the cos / sin rows of a tile's tokens (2 x 4 KiB of fp32) ride the ring with it — one more DMA instruction per
 // wave and tile, six slots of 24 KiB instead of eight of 16 — and the epilogue rotates the accumulator pairs from LDS.
+// GATHER (round 5): the descriptor head over the SAMPLED cells of a large batch (airfe_detect.hip: four cells per keypoint, 204800 rows of convDa's map at 64 pairs)
+// is the same shape — K = 256, N = 256, HBM-bound (512 B in, 1024 B of fp32 out per row) — and ran in the tiled 8-wave kernel (gemm8, rowidx form) at 2.3 TB/s
+// with its waves parked 67 % of the time.  Here row r of a streamed tile comes from X1 row rowidx[r]: the indices of ALL of a workgroup's tiles go into LDS
+// before the loop (a compiler-visible global load inside the loop would drain the DMA ring, see below), a lane reads its row's index from there (lgkmcnt) and
+// the tile streams through the same ring; the epilogue stores fp32 rows (EPI_STORE_F32).  Same fragments, same K order, bias after the sum: the bits of gemm8.
 #include "common.h"
 #include "kernels.h"
 
@@ -35,8 +40,9 @@ __device__ __forceinline__ void gr_glds16(const void* gsrc, unsigned lds_off) {
 }
 
 // One workgroup's whole launch: 256-feature slice `group` of linear `a`, token tiles first, first + per_group, ...
-template <class P, bool TRANS, bool ROT>
+template <class P, bool TRANS, bool ROT, bool GATHER = false>
 __device__ __forceinline__ void gemmr_body(const GemmArgs& a, char* smem, int group, int first, int per_group, int ntiles) {
+  static_assert(!GATHER || (!TRANS && !ROT), "the gather form is the plain K = 256 linear with fp32 rows out");
   constexpr int GR_SLOT = GR_XBYTES + (ROT ? GR_RBYTES : 0);
   constexpr int GR_SLOTS = ROT ? 6 : 8;
   constexpr int PER = ROT ? 3 : 2;                                    // DMA instructions per wave and tile
@@ -65,16 +71,26 @@ __device__ __forceinline__ void gemmr_body(const GemmArgs& a, char* smem, int gr
     binit[u] = *reinterpret_cast<const f32x4*>(a.bias + cb * 64 + tp * 32 + g * 8 + u * 4);
     bt[u] = a.bias[cb * 64 + slab_row_to_feature((2 * tp + u) * 16 + l15)];
   }
+  // GATHER: the source rows of every tile this workgroup will stream, [n][32] behind the ring
+  [[maybe_unused]] int* idx_lds = reinterpret_cast<int*>(smem + GR_SLOTS * GR_SLOT);
+  if constexpr (GATHER) {
+    for (int e = tid; e < n * GR_TT; e += 512) idx_lds[e] = a.rowidx[(size_t)(first + (e >> 5) * per_group) * GR_TT + (e & 31)];
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (GATHER) __syncthreads();
 
-  // ---- DMA of tile `t` (32 rows x 512 B) into ring slot `slot`: 16 wave-instructions of 1 KiB, two per wave, two rows each
+  // ---- DMA of the workgroup's j-th tile (t = first + j per_group; 32 rows x 512 B) into ring slot `slot`: 16 wave-instructions of 1 KiB, two per wave, two rows each
   const int ld = a.ld1;
-  auto dma = [&](int t, int slot) {
+  auto dma = [&](int j, int slot) {
+    [[maybe_unused]] const int t = first + j * per_group;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int inst = wave * 2 + i;
       const int r = inst * 2 + (lane >> 5), pp = lane & 31;
-      gr_glds16(a.X1 + (size_t)(t * GR_TT + r) * ld + ((pp ^ (r & 15)) << 3), (unsigned)(slot * GR_SLOT + inst * 1024));
+      size_t srow;
+      if constexpr (GATHER) srow = (size_t)idx_lds[j * GR_TT + r];
+      else srow = (size_t)(t * GR_TT + r);
+      gr_glds16(a.X1 + srow * ld + ((pp ^ (r & 15)) << 3), (unsigned)(slot * GR_SLOT + inst * 1024));
     }
     if constexpr (ROT) {                                              // waves 0-3: cos rows, 4-7: sin rows; 8 rows of 128 B per instruction
       const float* src = (wave < 4 ? a.rot_cos : a.rot_sin) + ((size_t)t * GR_TT + (wave & 3) * 8) * 32 + lane * 4;
@@ -83,7 +99,7 @@ __device__ __forceinline__ void gemmr_body(const GemmArgs& a, char* smem, int gr
   };
 #pragma unroll
   for (int j = 0; j < GR_SLOTS; ++j)
-    if (j < n) dma(first + j * per_group, j);
+    if (j < n) dma(j, j);
   // tile 0 landed: at most PER * min(n - 1, GR_SLOTS - 1) younger DMA instructions may still be in flight
   if (n >= GR_SLOTS) gr_wait_vm<PER * (GR_SLOTS - 1)>();
   else gr_wait_vm<0>();
@@ -138,7 +154,11 @@ __device__ __forceinline__ void gemmr_body(const GemmArgs& a, char* smem, int gr
           const f32x4 cs = *reinterpret_cast<const f32x4*>(rt), sn = *reinterpret_cast<const f32x4*>(rt + GR_RBYTES / 2);
           rotate_pairs(v, cs, sn);
         }
-        if (a.epi == EPI_HEADS) {
+        if constexpr (GATHER) {                                       // EPI_STORE_F32: the lane's 8 features of output row `row` (dense row order, not the source's)
+          float* o = reinterpret_cast<float*>(a.out) + (size_t)row * a.ldo + co;
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else if (a.epi == EPI_HEADS) {
           const int s = row / a.Np, nn = row - s * a.Np;
           const int sel = co >> 8, cw = co & 255, h = cw >> 6, d = cw & 63;
           uint16_t* o = reinterpret_cast<uint16_t*>(sel ? a.out2 : a.out) + (((size_t)s * a.H + h) * a.Np + nn) * 64 + d;
@@ -162,7 +182,7 @@ __device__ __forceinline__ void gemmr_body(const GemmArgs& a, char* smem, int gr
       }
     }
     __syncthreads();                                                  // every wave is done with slot i and has its part of tile i+1
-    if (i + GR_SLOTS < n) dma(first + (i + GR_SLOTS) * per_group, slot);
+    if (i + GR_SLOTS < n) dma(i + GR_SLOTS, slot);
   }
 }
 
@@ -173,6 +193,12 @@ __global__ __launch_bounds__(512, 1) void gemmr_kernel(GemmArgs a, int ntiles, i
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int w = blockIdx.x;
   gemmr_body<P, TRANS, ROT>(a, smem, (w >> 3) % ngroups, (w & 7) + 8 * (w / (8 * ngroups)), gridDim.x / ngroups, ntiles);
+}
+
+template <class P>
+__global__ __launch_bounds__(512, 1) void gemmr_gather_kernel(GemmArgs a, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemmr_body<P, false, false, true>(a, smem, 0, blockIdx.x, gridDim.x, ntiles);
 }
 
 // q|k (or the cross block's shared qk) and v of one attention layer in ONE launch: the first ng_a feature groups belong to linear
@@ -211,6 +237,28 @@ static void gemmr_launch_t(const GemmArgs& a, hipStream_t st) {
   const int ngroups = a.cb_total / 4;
   const int nwg = std::max(a.gr_wgs / (8 * ngroups), 1) * (8 * ngroups);
   hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(512), LDS, st, a, a.M / GR_TT, ngroups);
+}
+
+// The gather form: y[r] = W x[rowidx[r]] + b as fp32 rows, K = N = 256 (the descriptor head over sampled cells).
+bool gemmr_gather_applicable(int K, const GemmArgs& a) {
+  return K == 256 && a.rowidx && !a.X2 && !a.rot_cos && a.act == ACT_NONE && a.cb_total == 4 && a.N == 256 && a.M % GR_TT == 0 && a.epi == EPI_STORE_F32 && a.ldo >= 256 &&
+         a.ld1 % 8 == 0 && (a.M / GR_TT + std::max(a.gr_wgs, 1) - 1) / std::max(a.gr_wgs, 1) <= 240;      // (the busiest workgroup's index list fits behind the ring)
+}
+
+void launch_gemmr_gather(int prec, const GemmArgs& a, hipStream_t st) {
+  const int ntiles = a.M / GR_TT;
+  const int nwg = std::max(std::min(a.gr_wgs, ntiles), 1);
+  const int nmax = (ntiles + nwg - 1) / nwg;                          // tiles of the busiest workgroup: its index list sits behind the ring
+  const int lds = 8 * GR_XBYTES + nmax * GR_TT * 4;
+  if (prec == 1) {
+    static PerDeviceOnce once;
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmr_gather_kernel<PF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(gemmr_gather_kernel<PF16>, dim3((unsigned)nwg), dim3(512), lds, st, a, ntiles);
+  } else {
+    static PerDeviceOnce once;
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmr_gather_kernel<PBF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(gemmr_gather_kernel<PBF16>, dim3((unsigned)nwg), dim3(512), lds, st, a, ntiles);
+  }
 }
 
 bool gemmr_applicable(int K, bool trans, const GemmArgs& a) {

@@ -221,31 +221,6 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
   }
 }
 
-// The MFMAs of ONE slab step of lf_mma's generic trip (slab index s of the B operand's K range), for callers that schedule the weight fetches themselves.
-template <class P, int NT, int NMT>
-__device__ __forceinline__ void lf_slab(f32x4 (&acc)[NT][NMT], const typename P::vec8 (&frag)[NT][2], const char* brow, int pitch, int s, int l15, int g) {
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int boff = (((s * 8 + h * 4 + g) ^ l15) << 4);
-#pragma unroll
-    for (int mb = 0; mb < NMT; mb += 4) {
-      typename P::vec8 bf[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (mb + j < NMT) bf[j] = lds_frag<P>(brow, boff + (mb + j) * 16 * pitch);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (mb + j < NMT) acc[t][mb + j] = P::mfma(frag[t][h], bf[j], acc[t][mb + j]);
-    }
-  }
-}
-
-#ifndef LF_XOVERLAP
-#define LF_XOVERLAP 1
-#endif
-
 struct LfLane {                       // per-lane constants of the whole kernel
   int lane, wave, l15, g, wf, cb, tp, fo0, fo1;
 #ifdef LF_TIMING
@@ -263,7 +238,9 @@ struct LfLane {                       // per-lane constants of the whole kernel
 // (kernels_gemmr.hip) / the tiled kernels: the three forms give the same bits.
 // FOLDO = the out-projection is already inside W1's message half (airfe_tuning::fold_out_proj, airfe_load.hip make_ffn0_folded): ffn.0 reads cat(x, attn) — the
 // attn tile sits in R1 where msg would be, the x tile in R0, both in flight when the pass starts — and the 256 x 256 GEMM, the msg pack, one barrier and the
-// mid-GEMM wait for the x tile are gone.
+// mid-GEMM wait for the x tile are gone.  (Letting the x tile land UNDER the attention half — its DMA issued last, two slabs of weights ahead so that no
+// counted wait catches it — measured the same, 1.84 / 1.87 against 1.87 / 1.87 ms of lg_gemm: the first barrier comes ~5 us after the launch whether it waits
+// for two tiles or for one tile and 128 KB of weights, profiles/r05_fold_out_ab.txt; not kept.)
 template <class P, int NMT, bool RELU, int FOLD, bool FOLDO>
 __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const LfLane& L, int row0) {
   const int lane = L.lane, wave = L.wave, l15 = L.l15, g = L.g, wf = L.wf, cb = L.cb, tp = L.tp, fo0 = L.fo0, fo1 = L.fo1;
@@ -274,15 +251,8 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   typename P::vec8 c2[2][2], c4[4][2];                            // A fragments in flight: 32-feature GEMMs / the 64-feature one
   [[maybe_unused]] f32x4 bo2[2];
   f32x4 b14[4];                                                   // biases of the first two GEMMs: fetched with the attn tile
-  // XOV (FOLDO, 112-token passes): with every CU of the chip starting a pass at the same moment the two tiles arrive at ~11 bytes per cycle and CU — a burst at
-  // the HBM roof, 4-5 us for 114 KB — and only the attn tile is needed first.  So the x tile's DMA goes out LAST, the first barrier does not wait for it
-  // (its DMA is issued as that wait ends), and the attention half of ffn.0 starts with TWO slabs of weights already in registers: its first two slab steps
-  // need no wait, and the wait of the third — for a fetch issued behind the DMA, vmcnt retires in order — finds the x tile landed.
-  constexpr bool XOV = FOLDO && NMT == 7 && LF_XOVERLAP;
-  [[maybe_unused]] typename P::vec8 c4b[4][2];
   if constexpr (FOLDO) {
     lf_first<P, 4>(c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1);
-    if constexpr (XOV) lf_first<P, 4>(c4b, L.w1b + 5 * SLAB_BYTES + fo0, L.w1b + 5 * SLAB_BYTES + fo1);
   } else {
     lf_first<P, 2>(c2, L.wob + fo0, L.wob + fo1);
 #pragma unroll
@@ -290,16 +260,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) b14[t] = *reinterpret_cast<const f32x4*>(a.b1 + wf * 64 + (t >> 1) * 32 + g * 8 + (t & 1) * 4);
-  if constexpr (XOV) {
-    // The wait is the BUILTIN and comes BEFORE the DMA: hipcc's wait-count pass does not see the DMAs inside the asm strings, so a counted wait it inserts
-    // for one of its own loads is too strict by the DMAs in flight behind that load (first build: `vmcnt(10)` ahead of the first MFMA = five of the seven
-    // pieces of the x tile).  This way it knows that everything it has requested is here and inserts no wait until slab 2's.
-    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): attn tile, two slabs of weights, biases
-    __builtin_amdgcn_sched_barrier(0);
-    lf_stage_rows(a.xb, row0, NMT, LF_R0, wave, lane);            // 7 DMA instructions per wave: they land under the attention half's first two slab steps
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   LF_T(0)
 
@@ -336,32 +297,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int m = 0; m < NMT; ++m) h[t][m] = b14[t];
-  if constexpr (XOV) {                                            // the attention half under which the x tile lands: slabs 0, 1 are here, 2, 3 and the x half's first follow
-    const char* wa0 = L.w1b + 4 * SLAB_BYTES + fo0;
-    const char* wa1 = L.w1b + 4 * SLAB_BYTES + fo1;
-    const char* brow = smem + LF_R1 + l15 * 512;
-    typename P::vec8 nx[4][2];
-    lf_first<P, 4>(nx, wa0 + 2 * SLAB_BYTES, wa1 + 2 * SLAB_BYTES);
-    __builtin_amdgcn_sched_barrier(0);
-    lf_slab<P, 4, NMT>(h, c4, brow, 512, 0, l15, g);
-    lf_first<P, 4>(c4, wa0 + 3 * SLAB_BYTES, wa1 + 3 * SLAB_BYTES);
-    __builtin_amdgcn_sched_barrier(0);
-    lf_slab<P, 4, NMT>(h, c4b, brow, 512, 1, l15, g);
-    lf_first<P, 4>(c4b, L.w1b + fo0, L.w1b + fo1);                // the x half's first slab
-    __builtin_amdgcn_sched_barrier(0);
-    lf_slab<P, 4, NMT>(h, nx, brow, 512, 2, l15, g);              // (its fragments were requested behind the x tile's DMA: they are here => so is the tile)
-    __builtin_amdgcn_sched_barrier(0);
-    lf_slab<P, 4, NMT>(h, c4, brow, 512, 3, l15, g);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      c4[t][0] = c4b[t][0];
-      c4[t][1] = c4b[t][1];
-    }
-    LF_T(2)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                              // every wave's pieces of the x tile
-    LF_T(3)
-  } else if constexpr (FOLDO) {                                   // the attention half (R1 holds the attn tile itself); the x tile landed with it
+  if constexpr (FOLDO) {                                          // the attention half (R1 holds the attn tile itself); the x tile landed with it
     lf_mma<P, 4, NMT>(h, c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R1, 512, l15, g);
     LF_T(2)
     LF_T(3)
@@ -613,9 +549,8 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
   L.w2b = reinterpret_cast<const char*>(a.w2) + (size_t)L.cb * 8 * SLAB_BYTES + 2 * L.tp * 2048;
 
   const int row0 = blockIdx.x * (16 * NMT);
-  constexpr bool XOV = FOLDO && NMT == 7 && LF_XOVERLAP;           // (lf_pass issues the x tile's DMA itself, behind its first weight fetches)
   lf_stage_rows(a.attn, row0, NMT, FOLDO ? LF_R1 : LF_R0, L.wave, L.lane);
-  if constexpr (FOLDO && !XOV) lf_stage_rows(a.xb, row0, NMT, LF_R0, L.wave, L.lane);
+  if constexpr (FOLDO) lf_stage_rows(a.xb, row0, NMT, LF_R0, L.wave, L.lane);
 #ifdef LF_TIMING
   L.tb = 0;
 #endif
@@ -624,7 +559,7 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
   __syncthreads();
   L.tb = 16;
   lf_stage_rows(a.attn, row0, NMT, FOLDO ? LF_R1 : LF_R0, L.wave, L.lane);
-  if constexpr (FOLDO && !XOV) lf_stage_rows(a.xb, row0, NMT, LF_R0, L.wave, L.lane);
+  if constexpr (FOLDO) lf_stage_rows(a.xb, row0, NMT, LF_R0, L.wave, L.lane);
   lf_pass<P, NMT, RELU, FOLD, FOLDO>(a, smem, L, row0);
 #endif
 }

@@ -363,12 +363,33 @@ def normalize_keypoints(feat: np.ndarray, width: int, height: int, scale: float)
 _FLT_MAX = np.finfo(np.float32).max
 
 
+def _libm_expf():
+    import ctypes
+    import ctypes.util
+    lib = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    lib.expf.restype = ctypes.c_float
+    lib.expf.argtypes = [ctypes.c_float]
+    return lib.expf
+
+
+_LIBM_EXPF = None
+
+
 def _expf(x: np.ndarray) -> np.ndarray:
-    """`std::exp(float)` = glibc's expf (src/light_glue.cpp:248, src/super_glue.cpp:299): correctly rounded in practice (< 0.502 ulp), which numpy's
-    own float32 exp is not (it is a 1-ulp SIMD routine: it decides `exp(s) > threshold` differently one ulp beside log(threshold)).  The double
-    exponential rounded once to float32 reproduces glibc bit for bit on every value tests/test_ref_pin_cpu.py feeds both."""
-    with np.errstate(over="ignore", under="ignore", invalid="ignore"):
-        return np.exp(np.asarray(x, F).astype(np.float64)).astype(F)
+    """`std::exp(float)` (src/light_glue.cpp:248, src/super_glue.cpp:299) = glibc's expf — called, not restated: this file runs on the host whose libm the
+    compiled reference (oracle/_ref) links, so the oracle's exponential IS the reference's.  (numpy's float32 exp is a 1-ulp SIMD routine that decides
+    `exp(s) > threshold` differently one ulp beside log(threshold); the double exponential rounded once — what this function returned in rounds 3-4 — is the
+    correctly rounded value, which glibc's 0.502-ulp routine misses on 0.063 % of the inputs: tools/expf_glibc_check.c.  The device restates glibc's algorithm
+    operation by operation, airslam_amd/csrc/common.h expf_like_glibc, verified against this libm on every float.)"""
+    global _LIBM_EXPF
+    if _LIBM_EXPF is None:
+        _LIBM_EXPF = _libm_expf()
+    a = np.asarray(x, F)                                  # (np.ascontiguousarray would turn a scalar into a 1-element vector)
+    out = np.empty(a.shape, F)
+    fi, fo = np.ascontiguousarray(a).reshape(-1), out.reshape(-1)
+    for i in range(fi.size):                                # (at most ~1e3 values per pair: the row maxima / the kept matches)
+        fo[i] = _LIBM_EXPF(float(fi[i]))
+    return out[()] if out.ndim == 0 else out
 
 
 def _first_max_above_floor(m: np.ndarray, axis: int):

@@ -137,6 +137,34 @@ def test_batch_dev_equals_host_path():
         np.testing.assert_array_equal(feat[b, :ref.shape[0]].cpu().numpy(), ref)
 
 
+def test_descriptor_head_streaming_gather_gives_the_bits_of_the_tiled_kernel():
+    """Round 5: at large batches the descriptor head over the sampled cells (four per keypoint) runs in the streaming GEMM with gathered source rows
+    (kernels_gemmr.hip GATHER; from gemmr_min_m rows on) instead of the tiled 8-wave kernel's gather form.  Same fragments, same K order, bias after the sum:
+    feature rows (score, x, y, 256 descriptor floats) must be bit-identical — and equal to the batch-1 host path, whose descriptors come from the DENSE map.
+    gemmr_wgs = 16 makes every workgroup stream many tiles (the DMA ring wraps, the index list behind the ring is long)."""
+    import torch
+    from airslam_amd import api, weights
+    B = 10
+    ls, _ = synth.stereo_batch(B, 480, 752, 23)
+    g = torch.from_numpy(ls).cuda()
+    outs = []
+    for tun in ({"desc_gather_stream": 1}, {"desc_gather_stream": 1, "gemmr_wgs": 16}, {"desc_gather_stream": 0}):
+        ctx = api.Context(superpoint=weights.synthetic_superpoint(1234), max_batch=B, enc_chunk=B, max_keypoints=400, tuning=tun, check_launches=1)
+        feat = torch.zeros((B, 400, 259), dtype=torch.float32, device="cuda")
+        n = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        ctx.detect_batch_dev(g, feat, n)
+        ctx.sync()
+        outs.append((n.cpu().numpy().copy(), feat.cpu().numpy().copy()))
+        if tun == {"desc_gather_stream": 1}:
+            ref0 = ctx.detect_points(ls[0])                           # batch 1: dense descriptor map + sampler
+        ctx.close()
+    assert outs[0][0].min() >= 200                                    # B * 400 * 4 = 16000 rows >= gemmr_min_m = 8192: the streaming form ran
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0][0], o[0])
+        np.testing.assert_array_equal(outs[0][1], o[1])
+    np.testing.assert_array_equal(outs[0][1][0, :ref0.shape[0]], ref0)
+
+
 def test_empty_image_is_an_error_like_the_reference():
     from airslam_amd import api
     ctx, _, _ = context("sp", **CFG)

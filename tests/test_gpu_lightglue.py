@@ -352,6 +352,32 @@ def test_out_projection_folded_into_ffn0_gives_the_bits_of_the_identity_form(for
     np.testing.assert_array_equal(s_a, s_b)                  # the whole log-assignment matrix of pair 0, batch-1 path (32-token passes)
 
 
+def test_match_scores_are_glibc_expf_bit_for_bit():
+    """The match score the reference returns is `std::exp(score)` on the host (src/light_glue.cpp:248): glibc's expf, a 0.502-ulp routine — NOT the correctly
+    rounded value (they differ on 0.063 % of all inputs, tools/expf_glibc_check.c), which is what the device computed in rounds 3-4 and what made the
+    exact-equality pin against the compiled reference a coin that happened to fall right (tests/test_gpu_ref_pin.py: ~200 scores per pair).  The device now
+    restates glibc's algorithm operation by operation (common.h expf_like_glibc); here ~20000 scores over the whole range a kept match can have,
+    (log 0.1, 0], against the host's libm, bit for bit (the old form would miss about a dozen of them)."""
+    from airslam_amd import api, weights
+    ctx = api.Context(lightglue=weights.synthetic_lightglue(1234, n_layers=1), max_batch=2, max_keypoints=1024)
+    rng = np.random.default_rng(5)
+    n, total = 1024, 0
+    for rep in range(20):
+        s = np.full((n, n), -50.0, np.float32)
+        v = (-rng.uniform(0.0, 2.30, n)).astype(np.float32)
+        if rep == 0:
+            v[:8] = np.float32([0.0, -0.0, -1e-8, -2.3025851, -2.302585, -1.0, -0.6931472, -1.4012985e-45])      # exact 1, the threshold's neighbours, a subnormal argument
+        perm = rng.permutation(n)
+        s[np.arange(n), perm] = v                                   # one mutual maximum per row and column
+        idx, sc = ctx.debug_lg_filter(s)
+        assert len(idx) >= n - 4 and np.array_equal(idx[:, 1], perm[idx[:, 0]])
+        want = ref_post._expf(v[idx[:, 0]])
+        np.testing.assert_array_equal(sc.view(np.uint32), np.asarray(want, np.float32).view(np.uint32))
+        total += len(idx)
+    assert total >= 20000
+    ctx.close()
+
+
 def test_slack_rows_are_reset_on_every_call():
     """the matcher arena's surplus token rows behind the last sequence go through every block like real tokens; their
     residual stream must start from ZERO on every call (it used to keep growing from call to call on the 2-byte path — NaN in the last pair after

@@ -1,0 +1,54 @@
+/* The restatement of glibc's expf that airslam_amd/csrc/common.h (expf_like_glibc) and oracle/ref_post.py (_expf) use, against the host's libm on EVERY float:
+ *     gcc -O2 -mfma -ffp-contract=off -o /tmp/expf_check tools/expf_glibc_check.c -lm && (/tmp/expf_check 0 & /tmp/expf_check 1 & wait)
+ * glibc 2.35 on an FMA-capable x86-64 (this image): "negative floats: n=2139095041 mismatches=0", "positive floats: n=2139095041 mismatches=0" (about 90 s).
+ * The one contraction that is visible in the results is r = fma(InvLn2N, x, -k): without it 5 of 4e7 sampled inputs differ in the last bit; the correctly rounded
+ * value (float)exp((double)x) differs on 0.063 % of the inputs. */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+static const uint64_t T[32] = {
+0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51,
+0x3fef72b83c7d517b, 0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1,
+0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d,
+0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585,
+0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13,
+0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
+0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069,
+0x3fef5818dcfba487, 0x3fef7c97337b9b5f, 0x3fefa4afa2a490da, 0x3fefd0765b6e4540};
+static inline uint64_t asu(double d){uint64_t u; memcpy(&u,&d,8); return u;}
+static inline double asd(uint64_t u){double d; memcpy(&d,&u,8); return d;}
+static inline float my_expf(float x) {
+  const double InvLn2N = 0x1.71547652b82fep+0 * 32, SHIFT = 0x1.8p+52;
+  const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+  if (x != x) return x + x;
+  if (x > 0x1.62e42ep6f) return INFINITY;
+  if (x < -0x1.9fe368p6f) return 0.0f;
+  double xd = (double)x;
+  double kd = fma(InvLn2N, xd, SHIFT);
+  uint64_t ki = asu(kd);
+  kd -= SHIFT;
+  double r = fma(InvLn2N, xd, -kd);
+  uint64_t t = T[ki % 32];
+  t += ki << (52 - 5);
+  double s = asd(t);
+  double zz = fma(C0, r, C1);
+  double r2 = r * r;
+  double y = fma(C2, r, 1.0);
+  y = fma(zz, r2, y);
+  return (float)(y * s);
+}
+int main(int argc, char** argv) {
+  /* every float of the sign / range given: argv[1] = 0 (negative, incl. -0 .. -inf) or 1 (positive) */
+  int pos = argc > 1 && argv[1][0] == '1';
+  uint64_t bad = 0, n = 0;
+  for (uint32_t u = 0; u <= 0x7f800000u; ++u) {
+    uint32_t b = u | (pos ? 0u : 0x80000000u);
+    float x; memcpy(&x, &b, 4);
+    float ref = expf(x), a = my_expf(x);
+    n++;
+    if (memcmp(&a, &ref, 4) != 0) { if (bad < 5) printf("x=%a ref=%a mine=%a\n", x, ref, a); bad++; }
+  }
+  printf("%s floats: n=%lu mismatches=%lu\n", pos ? "positive" : "negative", n, bad);
+  return 0;
+}

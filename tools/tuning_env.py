@@ -5,7 +5,7 @@ import os
 NAMES = {"AIRFE_FUSE_LG_BLOCK": "fuse_lg_block", "AIRFE_SMALL_MAX_M": "gemm_small_max_m", "AIRFE_GEMM8_MIN_M": "gemm8_min_m", "AIRFE_GEMMR_MIN_M": "gemmr_min_m",
          "AIRFE_GEMMR_WGS": "gemmr_wgs", "AIRFE_QKV_PAIR": "qkv_pair", "AIRFE_BLOCK_MIN_M": "block_min_m", "AIRFE_LGB_TOKENS": "lgb_tokens", "AIRFE_SG_KENC_GEMM": "sg_kenc_gemm",
          "AIRFE_FOLD_QKV": "fold_qkv", "AIRFE_OVERLAP_LINES": "overlap_lines", "AIRFE_KF_GRAPH": "kf_graph", "AIRFE_KF_SPEC_ROWS": "kf_spec_rows", "AIRFE_FUSE_DEC": "fuse_dec",
-         "AIRFE_ASSIGN_FUSED": "assign_fused", "AIRFE_FOLD_OUT_PROJ": "fold_out_proj"}
+         "AIRFE_ASSIGN_FUSED": "assign_fused", "AIRFE_FOLD_OUT_PROJ": "fold_out_proj", "AIRFE_DESC_GATHER_STREAM": "desc_gather_stream"}
 
 
 def tuning_from_env():
