@@ -16,7 +16,7 @@ HOT = {
     "kernels_lgblockf.hip": ["lg_blockf_kernel"],
     "kernels_conv64r.hip": ["conv64r_kernel"],
     "kernels_conv128r.hip": ["conv128r_kernel"],
-    "kernels_gemmr.hip": ["gemmr_kernel", "gemmr_pair_kernel"],
+    "kernels_gemmr.hip": ["gemmr_kernel", "gemmr_pair_kernel", "gemmr_gather_kernel"],
     "kernels_ext.hip": ["sg_sinkhorn_reg_kernel", "plnet_s1_kernel", "s1_junc_proj_kernel", "s1h_junc_proj_kernel"],
     "kernels_s0.hip": ["s0_j2l_grid_kernel", "s0_decode_kernel"],
     "kernels_nms512.hip": ["nms512_kernel"],
