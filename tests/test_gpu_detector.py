@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 CFG = dict(max_batch=4, enc_chunk=2)
 
 
-@pytest.mark.parametrize("h,w,seed", [(480, 752, 0), (480, 640, 2), (720, 1280, 3), (512, 512, 4), (100, 131, 5)])
+# (three kernels behind one entry: four output rows per workgroup for 4-byte-aligned rows up to 2048 pixels — every camera of the reference's configs —, one row per
+#  workgroup up to 4096 (the 2560-wide case), per pixel for unaligned rows (the 131-wide case))
+@pytest.mark.parametrize("h,w,seed", [(480, 752, 0), (480, 640, 2), (720, 1280, 3), (512, 512, 4), (100, 131, 5), (1440, 2560, 6), (1080, 2048, 7)])
 def test_preprocess_bit_exact(h, w, seed):
     ctx, _, _ = context("sp", **CFG)
     img = synth.gabor_image(h, w, seed)
