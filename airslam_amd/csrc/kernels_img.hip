@@ -67,7 +67,10 @@ __global__ __launch_bounds__(256) void preprocess_rows_kernel(const uint8_t* __r
 // tap table + LUT -> store) run by 512 x B tiny workgroups: 48 us for 64 images = 1.9 TB/s with its waves parked 81 % of the time.  Here the eight source
 // rows of four output rows are requested together, the tap table entry of a column is read once for the four rows and the 1 KB LUT sits in LDS.  Same
 // integer arithmetic, same bits.
-constexpr int PRE_R = 4, PRE_R_MAX_W = 2048;
+#ifndef AIRFE_PRE_R
+#define AIRFE_PRE_R 4
+#endif
+constexpr int PRE_R = AIRFE_PRE_R, PRE_R_MAX_W = 2048;
 __global__ __launch_bounds__(256) void preprocess_rows4_kernel(const uint8_t* __restrict__ src, int stride, size_t img_stride, int w,
                                                                const int4* __restrict__ xtab, const int4* __restrict__ ytab,
                                                                const float* __restrict__ lut, float* __restrict__ out, int RH, int RW) {
