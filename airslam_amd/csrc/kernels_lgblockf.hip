@@ -121,16 +121,13 @@ __device__ __forceinline__ void lf_first(typename P::vec8 (&cur)[NT][2], const c
 
 struct LfNoHook { __device__ __forceinline__ void operator()(int) const {} };
 
-// LF_DEPTH2: bit 0 = the 32-feature GEMMs (NT = 2), bit 1 = the 64-feature one (NT = 4) of the large token tiles keep TWO slabs of weights in flight (see lf_mma)
-#ifndef LF_DEPTH2
-#define LF_DEPTH2 0
-#endif
 
 // acc[t][m] += W(tiles t of this wave, slabs 0..nslab-1) x B(token tiles m < NMT): w0 / w1 = this lane's fragment address in
 // slab 0, tile 0 for the two 32-wide halves of the slab's 64-wide K chunk; tile t at +2048 t, slab s at +8192 s.  `cur` holds
 // slab 0 on entry; the next slab's fragments are fetched while the current one feeds 2 NT NMT MFMAs, and during the last slab
 // the fetch goes to n0 / n1 (the first slab of whatever this wave multiplies next), which `cur` holds on exit.  (Fetching two
-// or three slabs ahead for the 32-feature GEMMs measured no faster on the whole block.)
+// or three slabs ahead for the 32-feature GEMMs measured no faster on the whole block — round 1, and again in round 5 at the kernel level under rocprofv3: a rolled
+// two-slab form of this loop for the 112-token passes, 114.9 / 116.6 us against 114.5 / 114.3, profiles/r05_probe_blockf_depth2.txt.)
 template <class P, int NT, int NMT, class Hook = LfNoHook, bool SWAP = false>
 __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (&cur)[NT][2], const char* w0, const char* w1, int nslab,
                                        const char* n0, const char* n1, const char* breg, int pitch, int l15, int g, Hook hook = Hook()) {
@@ -183,59 +180,6 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
         if (s + 1 + AHEAD <= nslab) fetch(s + 1 + AHEAD, ring[s % AHEAD]);
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
-    return;
-  }
-  if constexpr ((NT == 2 && (LF_DEPTH2 & 1)) || (NT == 4 && (LF_DEPTH2 & 2))) {
-    // Two slabs in flight, rolled: a slab step of a 32-feature GEMM is 28 MFMAs = 0.19 us of matrix pipe per wave (0.37 us for the two waves of a SIMD), an L2
-    // round trip under load 0.5-0.8 us — one slab ahead, every step ends in a wait.  Two steps per trip so that the buffers alternate without a third copy.
-    // Same MFMAs in the same order: the same bits.  (nslab is 4 or 8.)
-    typename P::vec8 na[NT][2], nb[NT][2];
-    auto fetch = [&](int k, typename P::vec8 (&dst)[NT][2]) {
-      const char* p0 = k == nslab ? n0 : w0 + k * SLAB_BYTES;
-      const char* p1 = k == nslab ? n1 : w1 + k * SLAB_BYTES;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        dst[t][0] = lf_ldg<P>(p0 + t * 2048);
-        dst[t][1] = lf_ldg<P>(p1 + t * 2048);
-      }
-    };
-    auto step = [&](int s) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int boff = (((s * 8 + h * 4 + g) ^ l15) << 4);
-#pragma unroll
-        for (int mb = 0; mb < NMT; mb += 4) {
-          typename P::vec8 bf[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (mb + j < NMT) bf[j] = lds_frag<P>(brow, boff + (mb + j) * 16 * pitch);
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (mb + j < NMT) {
-                if constexpr (SWAP) acc[t][mb + j] = P::mfma(bf[j], cur[t][h], acc[t][mb + j]);
-                else acc[t][mb + j] = P::mfma(cur[t][h], bf[j], acc[t][mb + j]);
-              }
-        }
-      }
-    };
-    fetch(1, na);
-#pragma unroll 1
-    for (int s = 0; s < nslab; s += 2) {
-      fetch(s + 2 <= nslab ? s + 2 : nslab, nb);        // (s + 2 <= nslab always holds: nslab is even)
-      hook(s);
-      __builtin_amdgcn_sched_barrier(0);
-      step(s);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) { cur[t][0] = na[t][0]; cur[t][1] = na[t][1]; }
-      if (s + 3 <= nslab) fetch(s + 3, na);
-      hook(s + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      step(s + 1);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) { cur[t][0] = nb[t][0]; cur[t][1] = nb[t][1]; }
     }
     return;
   }
