@@ -57,6 +57,9 @@ __device__ __forceinline__ void att_glds16(const void* sbase, unsigned voff, uns
                : "memory");
 }
 
+#ifndef ATT_RETRY_LOOP
+#define ATT_RETRY_LOOP 1
+#endif
 constexpr float ATT_PSUM_MAX = 16384.0f;   // a lane's partial row sum above this sends the tile through the re-centring path
 
 // The soft-max scale is NOT applied here: sqrt(scale * log2 e) is folded into the packed q and k projection weights
@@ -187,60 +190,76 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
       };
       float ps0, ps1;
       auto exps = [&]() {                                // p = 2^(s - m) in place + the lane's partial row sum
-        ps0 = 0.f; ps1 = 0.f;
+        // (the two partial sums as ONE float pair added in the accumulators' own order: written as two scalars, hipcc's SLP pass paired them the other way
+        //  round, put every second exponential into the "wrong" register of its pair and moved sixteen values back per tile)
+        f32x2 ps = {0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           st0[r] = __builtin_amdgcn_exp2f(st0[r]);
           st0[r + 1] = __builtin_amdgcn_exp2f(st0[r + 1]);
-          ps0 += st0[r];
-          ps1 += st0[r + 1];
+          ps += f32x2{st0[r], st0[r + 1]};
         }
         if (two) {
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             st1[r] = __builtin_amdgcn_exp2f(st1[r]);
             st1[r + 1] = __builtin_amdgcn_exp2f(st1[r + 1]);
-            ps0 += st1[r];
-            ps1 += st1[r + 1];
+            ps += f32x2{st1[r], st1[r + 1]};
           }
         }
+        ps0 = ps.x; ps1 = ps.y;
       };
+      auto recentre_tile = [&]() {                         // the shift from the tile's explicit row maximum: scores -> scores - max, accumulators rescaled
+        float mx = max3f(st0[0], st0[1], st0[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = max3f(mx, st0[r], st0[r + 1]);
+        mx = fmaxf(mx, st0[15]);
+        if (two) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) mx = max3f(mx, st1[r], st1[r + 1]);
+        }
+        mx = pair_max(mx);                               // finite: every tile that is run holds at least one real key
+        if (kt > 0) {                                    // (nothing accumulated yet on the first tile)
+          const float alpha = __builtin_amdgcn_exp2f(-mx);
+          l_i *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+        m_i += mx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          cinit[r] = -m_i;
+          st0[r] -= mx;
+        }
+        if (two) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st1[r] -= mx;
+        }
+      };
+#if ATT_RETRY_LOOP
       bool recentre = (kt == 0);                         // the first tile fixes the shift from its explicit row maximum
       for (;;) {                                         // (one copy of the tile's code: a tile that overflows simply goes round again)
         scores();
-        if (recentre) {
-          float mx = max3f(st0[0], st0[1], st0[2]);
-#pragma unroll
-          for (int r = 3; r < 15; r += 2) mx = max3f(mx, st0[r], st0[r + 1]);
-          mx = fmaxf(mx, st0[15]);
-          if (two) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) mx = max3f(mx, st1[r], st1[r + 1]);
-          }
-          mx = pair_max(mx);                             // finite: every tile that is run holds at least one real key
-          if (kt > 0) {                                  // (nothing accumulated yet on the first tile)
-            const float alpha = __builtin_amdgcn_exp2f(-mx);
-            l_i *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-          }
-          m_i += mx;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            cinit[r] = -m_i;
-            st0[r] -= mx;
-          }
-          if (two) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st1[r] -= mx;
-          }
-        }
+        if (recentre) recentre_tile();
         exps();
         if (recentre || !__any(!(ps0 + ps1 <= ATT_PSUM_MAX))) break;      // (the negated compare also catches inf / NaN sums)
         recentre = true;
       }
+#else
+      // Straight line (round 5): as a loop ("a tile that overflows simply goes round again") the score registers were loop-carried, and hipcc moved the second
+      // sub-tile's sixteen probabilities from where v_exp_f32 put them back into the loop's registers — 14 v_mov_b32 per tile on a kernel that is bound by its
+      // issue slots.  The rare second round is now a second copy of the code.
+      scores();
+      if (kt == 0) recentre_tile();                      // the first tile fixes the shift from its explicit row maximum
+      exps();
+      if (kt != 0 && __any(!(ps0 + ps1 <= ATT_PSUM_MAX))) {               // (the negated compare also catches inf / NaN sums)
+        scores();
+        recentre_tile();
+        exps();
+      }
+#endif
       l_i += ps0 + ps1;
       typename P::vec8 pf[4];
 #pragma unroll
