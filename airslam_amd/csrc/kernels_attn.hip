@@ -58,7 +58,7 @@ __device__ __forceinline__ void att_glds16(const void* sbase, unsigned voff, uns
 }
 
 #ifndef ATT_RETRY_LOOP
-#define ATT_RETRY_LOOP 1
+#define ATT_RETRY_LOOP 0
 #endif
 constexpr float ATT_PSUM_MAX = 16384.0f;   // a lane's partial row sum above this sends the tile through the re-centring path
 
