@@ -121,17 +121,15 @@ __device__ __forceinline__ void lf_first(typename P::vec8 (&cur)[NT][2], const c
 
 struct LfNoHook { __device__ __forceinline__ void operator()(int) const {} };
 
-#ifndef LF_PINGPONG
-#define LF_PINGPONG 1
-#endif
-
 
 // acc[t][m] += W(tiles t of this wave, slabs 0..nslab-1) x B(token tiles m < NMT): w0 / w1 = this lane's fragment address in
 // slab 0, tile 0 for the two 32-wide halves of the slab's 64-wide K chunk; tile t at +2048 t, slab s at +8192 s.  `cur` holds
 // slab 0 on entry; the next slab's fragments are fetched while the current one feeds 2 NT NMT MFMAs, and during the last slab
 // the fetch goes to n0 / n1 (the first slab of whatever this wave multiplies next), which `cur` holds on exit.  (Fetching two
 // or three slabs ahead for the 32-feature GEMMs measured no faster on the whole block — round 1, and again in round 5 at the kernel level under rocprofv3: a rolled
-// two-slab form of this loop for the 112-token passes, 114.9 / 116.6 us against 114.5 / 114.3, profiles/r05_probe_blockf_depth2.txt.)
+// two-slab form of this loop for the 112-token passes, 114.9 / 116.6 us against 114.5 / 114.3, profiles/r05_probe_blockf_depth2.txt.  Nor do the `cur = nxt`
+// register moves that end a trip cost anything measurable: two steps per trip with the fragment sets changing roles — VALU : MFMA inside the loops 0.25 instead
+// of 0.6-0.9 — ran 121.6 / 121.3 us against 118.3 / 123.0 on one box, same file.)
 template <class P, int NT, int NMT, class Hook = LfNoHook, bool SWAP = false>
 __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (&cur)[NT][2], const char* w0, const char* w1, int nslab,
                                        const char* n0, const char* n1, const char* breg, int pitch, int l15, int g, Hook hook = Hook()) {
@@ -187,20 +185,19 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
     }
     return;
   }
-  // Two slab steps per trip with the two fragment sets changing roles (round 5): as one step per trip the trip ended in `cur = nxt`, sixteen (NT = 2) or
-  // thirty-two register moves per 28-112 MFMAs on a SIMD whose issue slots are what the MFMAs compete for (LF_PINGPONG = 0: that form).  nslab is 4 or 8.
-  // Same loads, same MFMAs in the same order: the same bits.
   typename P::vec8 nxt[NT][2];
-  auto fetch = [&](int k, typename P::vec8 (&dst)[NT][2]) {
-    const char* p0 = k == nslab ? n0 : w0 + k * SLAB_BYTES;
-    const char* p1 = k == nslab ? n1 : w1 + k * SLAB_BYTES;
+#pragma unroll 1
+  for (int s = 0; s < nslab; ++s) {
+    const bool last = s + 1 == nslab;
+    const char* p0 = last ? n0 : w0 + (s + 1) * SLAB_BYTES;
+    const char* p1 = last ? n1 : w1 + (s + 1) * SLAB_BYTES;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      dst[t][0] = lf_ldg<P>(p0 + t * 2048);
-      dst[t][1] = lf_ldg<P>(p1 + t * 2048);
+      nxt[t][0] = lf_ldg<P>(p0 + t * 2048);
+      nxt[t][1] = lf_ldg<P>(p1 + t * 2048);
     }
-  };
-  auto step = [&](int s, const typename P::vec8 (&frag)[NT][2]) {
+    hook(s);                                // vector-memory work that must queue BEHIND this trip's prefetch (vmcnt retires in order)
+    __builtin_amdgcn_sched_barrier(0);      // keep the whole prefetch at the top of the trip (hipcc sinks loads towards their use)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int boff = (((s * 8 + h * 4 + g) ^ l15) << 4);
@@ -215,40 +212,17 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (mb + j < NMT) {
-              if constexpr (SWAP) acc[t][mb + j] = P::mfma(bf[j], frag[t][h], acc[t][mb + j]);     // tokens x features: the transposed-V form
-              else acc[t][mb + j] = P::mfma(frag[t][h], bf[j], acc[t][mb + j]);
+              if constexpr (SWAP) acc[t][mb + j] = P::mfma(bf[j], cur[t][h], acc[t][mb + j]);     // tokens x features: the transposed-V form
+              else acc[t][mb + j] = P::mfma(cur[t][h], bf[j], acc[t][mb + j]);
             }
       }
     }
-  };
-#if LF_PINGPONG
-#pragma unroll 1
-  for (int s = 0; s < nslab; s += 2) {
-    fetch(s + 1, nxt);
-    hook(s);                                // vector-memory work that must queue BEHIND this trip's prefetch (vmcnt retires in order)
-    __builtin_amdgcn_sched_barrier(0);      // keep the whole prefetch at the top of the step (hipcc sinks loads towards their use)
-    step(s, cur);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(s + 2, cur);                      // (s + 2 == nslab: the first slab of whatever this wave multiplies next)
-    hook(s + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    step(s + 1, nxt);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#else
-#pragma unroll 1
-  for (int s = 0; s < nslab; ++s) {
-    fetch(s + 1, nxt);
-    hook(s);
-    __builtin_amdgcn_sched_barrier(0);
-    step(s, cur);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       cur[t][0] = nxt[t][0];
       cur[t][1] = nxt[t][1];
     }
   }
-#endif
 }
 
 struct LfLane {                       // per-lane constants of the whole kernel
