@@ -73,6 +73,28 @@ __device__ __forceinline__ f32x2 lf_gelu2(f32x2 y) {
   r = r * x + 0.15690208971500397f;
   return y * (t * r + 0.5f);
 }
+// Four pairs at once, one Horner level at a time (round 5).  Evaluated pair by pair the polynomial is ONE dependent chain of 13 packed operations: hipcc, short of
+// registers in this phase, emits exactly that — every v_pk_fma_f32 waits for the one before it and is followed by the wait state the hazard asks for (533 s_nop in
+// the LayerNorm + GELU phase of a 112-token pass).  Level by level over four independent pairs the dependent operations are four instructions apart.  The same
+// operations per element: the same bits.
+__device__ __forceinline__ void lf_gelu2x4(f32x2 (&y)[4]) {
+  f32x2 t[4], x[4], r[4];
+#define LF_G4(expr) _Pragma("unroll") for (int k = 0; k < 4; ++k) { expr; } __builtin_amdgcn_sched_barrier(0);
+  LF_G4((t[k] = f32x2{__builtin_amdgcn_fmed3f(y[k].x, -4.5f, 4.5f), __builtin_amdgcn_fmed3f(y[k].y, -4.5f, 4.5f)}))
+  LF_G4(x[k] = t[k] * t[k])
+  LF_G4(x[k] = x[k] * (2.0f / 20.25f) - 1.0f)
+  LF_G4(r[k] = x[k] * 0.0031705170404165983f - 0.009152771905064583f)
+  LF_G4(r[k] = r[k] * x[k] + 0.012448843568563461f)
+  LF_G4(r[k] = r[k] * x[k] - 0.016971856355667114f)
+  LF_G4(r[k] = r[k] * x[k] + 0.027542514726519585f)
+  LF_G4(r[k] = r[k] * x[k] - 0.040475402027368546f)
+  LF_G4(r[k] = r[k] * x[k] + 0.05482625961303711f)
+  LF_G4(r[k] = r[k] * x[k] - 0.07717858254909515f)
+  LF_G4(r[k] = r[k] * x[k] + 0.15690208971500397f)
+  LF_G4(r[k] = t[k] * r[k] + 0.5f)
+  LF_G4(y[k] = y[k] * r[k])
+#undef LF_G4
+}
 #else
 __device__ __forceinline__ f32x2 lf_gelu2(f32x2 y) {
   const f32x2 a = __builtin_elementwise_abs(y);
@@ -90,6 +112,10 @@ __device__ __forceinline__ f32x2 lf_gelu2(f32x2 y) {
   const f32x2 p = (x * x) * -1.4426950408889634f + r;
   const f32x2 q = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
   return __builtin_elementwise_max(y, f32x2{0.f, 0.f}) - (x * 0.70710678118654752f) * q;
+}
+__device__ __forceinline__ void lf_gelu2x4(f32x2 (&y)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) y[k] = lf_gelu2(y[k]);
 }
 #endif
 
@@ -120,6 +146,10 @@ __device__ __forceinline__ void lf_first(typename P::vec8 (&cur)[NT][2], const c
 }
 
 struct LfNoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+#ifndef LF_GELU_X4
+#define LF_GELU_X4 1
+#endif
 
 
 // acc[t][m] += W(tiles t of this wave, slabs 0..nslab-1) x B(token tiles m < NMT): w0 / w1 = this lane's fragment address in
@@ -396,6 +426,20 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
       for (int m = 0; m < NMT; ++m) {
         const f32x2 rs = {rstd[m], rstd[m]}, nm = {nmr[m], nmr[m]};
         float v[8];
+#if LF_GELU_X4
+        f32x2 y[4];                                                // the four feature pairs of this token tile: (tile 2q, e = 0), (2q, 2), (2q + 1, 0), (2q + 1, 2)
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          y[e >> 1] = (f32x2{h[2 * q][m][e], h[2 * q][m][e + 1]} * rs + nm) * f32x2{g0[e], g0[e + 1]} + f32x2{be0[e], be0[e + 1]};
+          y[2 + (e >> 1)] = (f32x2{h[2 * q + 1][m][e], h[2 * q + 1][m][e + 1]} * rs + nm) * f32x2{g1[e], g1[e + 1]} + f32x2{be1[e], be1[e + 1]};
+        }
+        lf_gelu2x4(y);
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          v[e] = y[e >> 1].x; v[e + 1] = y[e >> 1].y;
+          v[4 + e] = y[2 + (e >> 1)].x; v[5 + e] = y[2 + (e >> 1)].y;
+        }
+#else
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
           const f32x2 y0 = (f32x2{h[2 * q][m][e], h[2 * q][m][e + 1]} * rs + nm) * f32x2{g0[e], g0[e + 1]} + f32x2{be0[e], be0[e + 1]};
@@ -404,6 +448,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
           v[e] = o0.x; v[e + 1] = o0.y;
           v[4 + e] = o1.x; v[5 + e] = o1.y;
         }
+#endif
         *reinterpret_cast<uint4*>(smem + (m * 16 + l15) * 1024 + ((piece ^ l15) << 4)) = pack8<P>(v);
       }
       }
