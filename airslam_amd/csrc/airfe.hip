@@ -199,6 +199,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) try {
   c->prec = cfg->precision;
   c->mprec = cfg->matcher_precision < 0 ? cfg->precision : cfg->matcher_precision;
   c->pack_prec = c->prec;
+  if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess) c->n_cu = 0;
   c->Bmax = std::max(cfg->max_batch, 1);
   c->chunk = std::min(std::max(cfg->enc_chunk, 1), c->Bmax);
   c->Pmax = c->Bmax;

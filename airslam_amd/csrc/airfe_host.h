@@ -127,6 +127,7 @@ struct airfe_ctx {
   bool desc_dense_valid = true;  // c->desc holds the dense map of the last batch (else: the gather GEMM's rows)
   int last_B = 0;
   int* desc_idx = nullptr;       // row list of the descriptor head's gather GEMM
+  int n_cu = 0;                  // compute units of cfg.device (hipDeviceAttributeMultiprocessorCount): the fused block's two-round split
   bool fold_qkv = true;          // airfe_tuning::fold_qkv = 0: q | k | v projections as launches of their own (A/B runs)
   bool desc_gather_stream = true;   // airfe_tuning::desc_gather_stream = 0: the descriptor head over sampled cells in the tiled kernel (gemm8) at every size (A/B, bit-identity test)
   bool fold_out = true;          // airfe_tuning::fold_out_proj: out_proj / to_out / merge multiplied into the message half of ffn.0 / mlp.0 at pack time (2-byte matcher only);

@@ -139,6 +139,8 @@ int lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, con
   if (M <= 256 * 32) a.tokens_per_wg = 32;
   else if (M <= 256 * 64) a.tokens_per_wg = 64;
   if (c->lgb_tokens > 0) a.tokens_per_wg = c->lgb_tokens;          // airfe_tuning::lgb_tokens (measurement switch)
+  a.mixed = c->lgb_tokens <= 0;                                     // the library's own choice: a second round of 6-tile passes where that balances the CUs (lgb_tokens = 112 forces uniform passes)
+  a.n_cu = c->n_cu;
   // (algorithmic = what this context's packed network asks for: with the out-projection folded into ffn.0 its 2 * 256 * 256 FLOPs per token do not exist)
   double fl = 2.0 * M * ((c->fold_out ? 0.0 : 256.0 * 256) + 512.0 * 512 + 512.0 * 256), by = (double)M * (512 + 512 + 1024 + 512 + 1024) + (c->fold_out ? 786432.0 : 917504.0);
   if (nqk && nv) {            // the next attention layer's projections ride along (kernels_lgblockf.hip, FOLD)

@@ -68,6 +68,7 @@ struct LgBlockFArgs {
   const float *bo, *b1, *gamma, *beta, *b2;
   int M;                     // tokens, multiple of 128
   int tokens_per_wg = 128;   // 128 or 112 (see launch_lg_blockf)
+  int mixed = 0, n_cu = 0;   // mixed = 1 (with tokens_per_wg = 112 and the folded out-projection): one round of 7-tile passes on n_cu CUs, then 6-tile passes (kernels_lgblockf.hip)
   int relu = 0;              // 1: ReLU instead of LayerNorm + GELU (the SuperGlue block; gamma / beta unused)
   // the NEXT attention layer's projections, computed from the block's result (nqk_w == nullptr: none).  nqk_n = 512: q | k with rotary
   // (rows 0..255 -> q_out, 256..511 -> k_out), 256: the cross block's shared projection (-> q_out); nv: V, stored transposed.

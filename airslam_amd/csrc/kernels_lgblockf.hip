@@ -576,11 +576,8 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   }
 }
 
-template <class P, int NMT, bool RELU, int FOLD, bool FOLDO>
-__global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void lf_lane_init(const LgBlockFArgs& a, LfLane& L) {
   const int tid = threadIdx.x;
-  LfLane L;
   L.lane = tid & 63;
   L.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   L.l15 = L.lane & 15;
@@ -596,7 +593,13 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
   L.wob = reinterpret_cast<const char*>(a.wo) + (size_t)L.cb * 4 * SLAB_BYTES + 2 * L.tp * 2048;
   L.w1b = reinterpret_cast<const char*>(a.w1) + (size_t)L.wf * 8 * SLAB_BYTES;
   L.w2b = reinterpret_cast<const char*>(a.w2) + (size_t)L.cb * 8 * SLAB_BYTES + 2 * L.tp * 2048;
+}
 
+template <class P, int NMT, bool RELU, int FOLD, bool FOLDO>
+__global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  LfLane L;
+  lf_lane_init(a, L);
   const int row0 = blockIdx.x * (16 * NMT);
   lf_stage_rows(a.attn, row0, NMT, FOLDO ? LF_R1 : LF_R0, L.wave, L.lane);
   if constexpr (FOLDO) lf_stage_rows(a.xb, row0, NMT, LF_R0, L.wave, L.lane);
@@ -611,6 +614,45 @@ __global__ __launch_bounds__(512, 1) void lg_blockf_kernel(LgBlockFArgs a) {
   if constexpr (FOLDO) lf_stage_rows(a.xb, row0, NMT, LF_R0, L.wave, L.lane);
   lf_pass<P, NMT, RELU, FOLD, FOLDO>(a, smem, L, row0);
 #endif
+}
+
+// Two rounds of unequal passes (round 5).  A launch over 51200 tokens in 112-token passes is 458 workgroups on 256 CUs: 202 CUs run two passes = 14 token tiles,
+// 54 run one, and the launch lasts as long as the 14.  At full load a pass costs in proportion to its tiles (128- against 112-token passes: 127 against 113 us per
+// launch), so the first n7 workgroups — one per CU — take 7 tiles and the rest 6: every CU runs 13.  Which pass a token rides in changes nothing about its result
+// (tests/test_gpu_lightglue.py: the tile sizes give the same bits).  The 6-tile passes may run up to 95 rows past M (arena slack, like the 111 of the uniform form).
+template <class P, bool RELU, int FOLD>
+__global__ __launch_bounds__(512, 1) void lg_blockf_mixed_kernel(LgBlockFArgs a, int n7) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  LfLane L;
+  lf_lane_init(a, L);
+#ifdef LF_TIMING
+  L.tb = 0;
+#endif
+  if ((int)blockIdx.x < n7) {
+    const int row0 = blockIdx.x * 112;
+    lf_stage_rows(a.attn, row0, 7, LF_R1, L.wave, L.lane);
+    lf_stage_rows(a.xb, row0, 7, LF_R0, L.wave, L.lane);
+    lf_pass<P, 7, RELU, FOLD, true>(a, smem, L, row0);
+  } else {
+    const int row0 = n7 * 112 + ((int)blockIdx.x - n7) * 96;
+    lf_stage_rows(a.attn, row0, 6, LF_R1, L.wave, L.lane);
+    lf_stage_rows(a.xb, row0, 6, LF_R0, L.wave, L.lane);
+    lf_pass<P, 6, RELU, FOLD, true>(a, smem, L, row0);
+  }
+}
+
+template <class P, bool RELU, int FOLD>
+static bool launch_mixed(const LgBlockFArgs& a, hipStream_t st) {
+  const int tiles = (a.M + 15) / 16, W = a.n_cu;
+  if (!a.mixed || a.wo || W <= 0 || tiles <= 7 * W || tiles > 13 * W) return false;      // (folded out-projection only; one full round of 7-tile passes + at most one of 6)
+  const int n7 = W, n6 = (tiles - 7 * W + 5) / 6;
+  static PerDeviceOnce attr_once;
+  auto kfn = lg_blockf_mixed_kernel<P, RELU, FOLD>;
+  if (attr_once.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS);
+  }
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(n7 + n6)), dim3(512), LF_LDS, st, a, n7);
+  return true;
 }
 
 template <class P, int NMT, bool RELU, int FOLD, bool FOLDO>
@@ -637,7 +679,7 @@ static void launch_nmt(const LgBlockFArgs& a, hipStream_t st) {
   switch (a.tokens_per_wg) {
     case 32: launch_f<P, 2, RELU, FOLD>(a, st); break;      // small token counts (batch 1: 800 tokens = 25 workgroups instead of 7)
     case 64: launch_f<P, 4, RELU, FOLD>(a, st); break;
-    case 112: launch_f<P, 7, RELU, FOLD>(a, st); break;
+    case 112: if (!launch_mixed<P, RELU, FOLD>(a, st)) launch_f<P, 7, RELU, FOLD>(a, st); break;
     default: launch_f<P, 8, RELU, FOLD>(a, st); break;
   }
 }

@@ -352,6 +352,39 @@ def test_out_projection_folded_into_ffn0_gives_the_bits_of_the_identity_form(for
     np.testing.assert_array_equal(s_a, s_b)                  # the whole log-assignment matrix of pair 0, batch-1 path (32-token passes)
 
 
+def test_two_round_pass_split_gives_the_bits_of_uniform_passes():
+    """Round 5: when a launch of the fused block would be one full round of 112-token passes plus a partial second round, the second round runs 96-token passes so
+    that every CU gets 13 token tiles instead of 14 or 7 (kernels_lgblockf.hip lg_blockf_mixed_kernel; the library's own choice, `lgb_tokens = 112` forces uniform
+    passes).  Which pass a token rides in must not change its result: 40 pairs (32000 tokens = 256 passes of 7 tiles + 36 of 6, the last one ragged) both ways."""
+    import torch
+    from airslam_amd import api, weights
+    B = 40
+    pairs = [_pair(400 - 7 * (i % 9), 396 - 5 * (i % 7), 900 + i) for i in range(B)]
+    f0 = torch.zeros((B, 400, 259)); f1 = torch.zeros((B, 400, 259))
+    n0 = torch.tensor([p[0].shape[0] for p in pairs], dtype=torch.int32)
+    n1 = torch.tensor([p[1].shape[0] for p in pairs], dtype=torch.int32)
+    for i, (a, b, _, _) in enumerate(pairs):
+        f0[i, :a.shape[0]] = torch.from_numpy(a); f1[i, :b.shape[0]] = torch.from_numpy(b)
+    f0, f1, n0, n1 = f0.cuda(), f1.cuda(), n0.cuda(), n1.cuda()
+    outs = []
+    for tun in (None, {"lgb_tokens": 112}):
+        ctx = api.Context(lightglue=weights.synthetic_lightglue(1234), max_batch=B, tuning=tun, check_launches=1)
+        idx = torch.zeros((B, 400, 2), dtype=torch.int32, device="cuda")
+        sc = torch.zeros((B, 400), dtype=torch.float32, device="cuda")
+        nm = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        for _ in range(2):                                   # (twice: the slack rows a ragged last pass writes must not leak into the next call)
+            ctx.match_lightglue_batch_dev(f0, n0, f1, n1, idx, sc, nm)
+        ctx.sync()
+        outs.append((nm.cpu().numpy().copy(), idx.cpu().numpy().copy(), sc.cpu().numpy().copy()))
+        ctx.close()
+    (nm_a, idx_a, sc_a), (nm_b, idx_b, sc_b) = outs
+    assert nm_a.min() >= 50
+    np.testing.assert_array_equal(nm_a, nm_b)
+    for i in range(B):
+        np.testing.assert_array_equal(idx_a[i, :nm_a[i]], idx_b[i, :nm_b[i]])
+        np.testing.assert_array_equal(sc_a[i, :nm_a[i]], sc_b[i, :nm_b[i]])
+
+
 def test_match_scores_are_glibc_expf_bit_for_bit():
     """The match score the reference returns is `std::exp(score)` on the host (src/light_glue.cpp:248): glibc's expf, a 0.502-ulp routine — NOT the correctly
     rounded value (they differ on 0.063 % of all inputs, tools/expf_glibc_check.c), which is what the device computed in rounds 3-4 and what made the

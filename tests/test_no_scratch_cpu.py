@@ -13,7 +13,7 @@ CSRC = os.path.join(ROOT, "airslam_amd", "csrc")
 # file -> kernel-name fragments that must compile without scratch
 HOT = {
     "kernels_attn.hip": ["attention32_kernel"],
-    "kernels_lgblockf.hip": ["lg_blockf_kernel"],
+    "kernels_lgblockf.hip": ["lg_blockf_kernel", "lg_blockf_mixed_kernel"],
     "kernels_conv64r.hip": ["conv64r_kernel"],
     "kernels_conv128r.hip": ["conv128r_kernel"],
     "kernels_gemmr.hip": ["gemmr_kernel", "gemmr_pair_kernel", "gemmr_gather_kernel"],
