@@ -279,3 +279,29 @@ def test_match_lines_matrix_cross_check():
                 want[i] = j
         assert rp.match_lines(rel0, rel1, matches, N0, N1) == want
         assert any(w >= 0 for w in want)
+
+
+def test_glibc_expf_restatement_equals_the_hosts_libm(tmp_path):
+    """`std::exp(float)` of the reference's host code (src/light_glue.cpp:248, src/super_glue.cpp:299) is glibc's expf; the device restates its algorithm
+    (airslam_amd/csrc/common.h expf_like_glibc), and tools/expf_glibc_check.c is that restatement in C, compared with the host's libm.  Every 257th float of both
+    signs here (16.6 million values, 0 mismatches expected; the whole range: the tool without a stride, ~90 s) — on a host whose libm selects another build of expf
+    (no FMA) this test says so instead of letting the GPU pin drift.  Also: the oracle's _expf IS libm's."""
+    import ctypes
+    import os
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "expf_check")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "expf_glibc_check.c")
+    subprocess.run([gcc, "-O2", "-mfma", "-ffp-contract=off", "-o", exe, src, "-lm"], check=True)
+    for sign in ("0", "1"):
+        out = subprocess.run([exe, sign, "257"], check=True, capture_output=True, text=True).stdout
+        assert "mismatches=0" in out and "n=8323328" in out, out
+    x = np.float32([-2.3025851, -0.6931472, -1e-8, 0.0, -17.5, -103.0, 88.0])
+    libm = ctypes.CDLL("libm.so.6")
+    libm.expf.restype = ctypes.c_float
+    libm.expf.argtypes = [ctypes.c_float]
+    want = np.float32([libm.expf(float(v)) for v in x])
+    assert np.array_equal(np.asarray(rp._expf(x), np.float32).view(np.uint32), want.view(np.uint32))
