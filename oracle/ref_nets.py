@@ -4,12 +4,16 @@ PyTorch-CPU fp32 restatement of the network bodies the reference executes throug
 TensorRT engines built from ONNX files (call sites src/plnet.cpp:233,510;
 src/super_point.cpp:133; src/light_glue.cpp:159; src/super_glue.cpp:185).
 
-PARITY UNPINNED for SuperPoint / LightGlue / SuperGlue: their ONNX files are absent
-from /root/reference (.MISSING_LARGE_BLOBS), onnxruntime is not installed, and the
-reference has no tests.  The bodies below restate the PUBLISHED architectures
-(SuperPoint v1 — DeTone et al.; LightGlue — Lindenberger et al., cvg/LightGlue
-lightglue.py; SuperGlue — Sarlin et al., magicleap/SuperGluePretrainedNetwork), with
-tensor names/shapes anchored on the reference's bindings.
+SuperPoint / LightGlue / SuperGlue: their ONNX files are absent from /root/reference (.MISSING_LARGE_BLOBS), onnxruntime is
+not installed, and the reference has no tests.  The bodies below restate the PUBLISHED architectures (SuperPoint v1 — DeTone et
+al.; LightGlue — Lindenberger et al., cvg/LightGlue lightglue.py; SuperGlue — Sarlin et al., magicleap/
+SuperGluePretrainedNetwork), with tensor names/shapes anchored on the reference's bindings, and are
+PINNED TO INDEPENDENT IMPLEMENTATIONS: Hugging Face transformers 5.15.0's ports of the same three networks, loaded with the same
+seeded weights (oracle/hf_pin.py holds the layout mappings), agree with the functions below — SuperPoint's suppressed score map
+and dense descriptors bit for bit, LightGlue's log-assignment within 1.1e-4 on a range of 52, SuperGlue's optimal-transport
+matrix within 3.4e-5 on a range of 65 (tests/test_oracle_hf_pin_cpu.py; the HIP library against HF directly:
+tests/test_gpu_hf_pin.py).  What stays unpinned is the stage-0 LINE head of PLNet (plnet_s0_lines: plnet_s0.onnx is absent and
+no second implementation of it exists here).
 The PLNet stage-1 head IS pinned: see oracle/onnx_run.py (real graph + weights).
 
 All functions take a dict name -> np.ndarray (airslam_amd.weights naming) so that

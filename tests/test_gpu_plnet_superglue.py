@@ -80,9 +80,11 @@ def _sg_pair(n0, n1, seed, w=752, h=480):
     return f0, f1, normalised(f0, w, h, 0.7), normalised(f1, w, h, 0.7)
 
 
-def _check_superglue(name, ctx, w, f0, f1, layers, iters, tol, min_valid):
+def _check_superglue(name, ctx, w, f0, f1, layers, iters, tol, min_valid, ref=None):
+    """`ref` = the [N0+1, N1+1] matrix to compare with (tests/test_gpu_hf_pin.py passes Hugging Face's); default: the fp32 oracle's."""
     z = ctx.superglue_scores(f0, f1)
-    ref = ref_nets.superglue_forward(w, f0[:, 1:3], f0[:, 0], f0[:, 3:], f1[:, 1:3], f1[:, 0], f1[:, 3:], n_layers=layers, iters=iters)
+    if ref is None:
+        ref = ref_nets.superglue_forward(w, f0[:, 1:3], f0[:, 0], f0[:, 3:], f1[:, 1:3], f1[:, 0], f1[:, 3:], n_layers=layers, iters=iters)
     n0, n1 = f0.shape[0], f1.shape[0]
     err = np.abs(z - ref)
     i0, i1, m0, m1 = ctx.match_superglue(f0, f1)
