@@ -34,8 +34,34 @@ class Stage0(C.Structure):
         "loi_features", "loi_features_thin", "loi_features_aux")]
 
 
-# name -> (restype, argtypes); every symbol include/airfe.h declares
+class SeqPolicy(C.Structure):
+    """airfe_seq_policy (include/airfe_seq.h)"""
+    _fields_ = [("min_init_stereo_feature", C.c_int), ("min_num_match", C.c_int), ("max_num_match", C.c_int), ("tracking_point_rate", C.c_float),
+                ("tracking_parallax_rate", C.c_float), ("min_x_diff", C.c_double), ("max_x_diff", C.c_double), ("max_y_diff", C.c_double),
+                ("image_width", C.c_int), ("image_height", C.c_int)]
+
+
+class SeqFrame(C.Structure):
+    """airfe_seq_frame (include/airfe_seq.h)"""
+    _fields_ = ([(n, C.c_int) for n in ("frame_type", "candidate", "promoted", "dropped", "enough_match", "good_stereo_point", "n_left", "n_right", "n_lines_left",
+                                        "n_lines_right", "n_junctions", "n_stereo", "n_matches")] + [("_pad", C.c_int)]
+                + [(n, C.c_void_p) for n in ("features_left", "features_right", "lines_left", "lines_right", "junctions", "stereo_idx", "stereo_score", "matches_idx",
+                                             "matches_score")])
+
+
+# name -> (restype, argtypes); every symbol include/*.h declares
 SIGNATURES = {
+    "airfe_seq_default_policy": (None, [C.POINTER(SeqPolicy)]),
+    "airfe_seq_add_keyframe_check": (C.c_int, [C.POINTER(SeqPolicy), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "airfe_seq_good_stereo_points": (C.c_int, [C.POINTER(SeqPolicy), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "airfe_seq_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(SeqPolicy), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "airfe_seq_destroy": (None, [C.c_void_p]),
+    "airfe_seq_last_error": (C.c_char_p, [C.c_void_p]),
+    "airfe_seq_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t]),
+    "airfe_seq_end": (C.c_int, [C.c_void_p, C.POINTER(SeqFrame)]),
+    "airfe_seq_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(SeqFrame)]),
+    "airfe_seq_stream": (C.c_void_p, [C.c_void_p]),
+    "airfe_seq_wall_split": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "airfe_default_cfg": (None, [C.POINTER(Cfg)]),
     "airfe_default_tuning": (None, [C.POINTER(Tuning)]),
     "airfe_debug_fail_next_launch": (C.c_int, [C.c_void_p, C.c_int]),

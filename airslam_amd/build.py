@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libairfe.so")
-SOURCES = ["airfe.hip", "airfe_load.hip", "airfe_detect.hip", "airfe_match.hip", "kernels_mm.hip", "kernels_conv64r.hip", "kernels_conv128r.hip", "kernels_gemm8.hip", "kernels_gemmr.hip", "kernels_img.hip", "kernels_sel.hip", "kernels_nms512.hip", "kernels_lg.hip", "kernels_attn.hip", "kernels_lgblockf.hip", "kernels_ext.hip", "kernels_s0.hip", "kernels_f32.hip"]
+SOURCES = ["airfe.hip", "airfe_seq.hip", "airfe_load.hip", "airfe_detect.hip", "airfe_match.hip", "kernels_mm.hip", "kernels_conv64r.hip", "kernels_conv128r.hip", "kernels_gemm8.hip", "kernels_gemmr.hip", "kernels_img.hip", "kernels_sel.hip", "kernels_nms512.hip", "kernels_lg.hip", "kernels_attn.hip", "kernels_lgblockf.hip", "kernels_ext.hip", "kernels_s0.hip", "kernels_f32.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # Per-file flags.  -fno-slp-vectorize: the SLP vectoriser packs incidental scalar fp32 arithmetic of these (latency- / HBM-bound) kernels into
 # v_pk_*_f32 with cross-half `op_sel` selections — the instruction form behind round 2's irreproducible rotary element (common.h, rotate_pairs;
@@ -24,7 +24,7 @@ def csrc_sha() -> str:
     import hashlib
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
-    files += [os.path.join(HERE, "..", "include", "airfe.h"), os.path.join(HERE, "..", "include", "airfe_debug.h")]
+    files += [os.path.join(HERE, "..", "include", h) for h in ("airfe.h", "airfe_debug.h", "airfe_seq.h")]
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
@@ -44,8 +44,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
-    headers.append(os.path.join(HERE, "..", "include", "airfe.h"))
-    headers.append(os.path.join(HERE, "..", "include", "airfe_debug.h"))
+    headers += [os.path.join(HERE, "..", "include", h) for h in ("airfe.h", "airfe_debug.h", "airfe_seq.h")]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = []
     jobs = []

@@ -111,8 +111,14 @@ int ensure_pin(airfe_ctx* c, size_t bytes) {
 // A host entry that returns with an error AFTER it queued work must not leave that work in flight: the next call memcpy's into the pinned block a
 // pending D2H may still write, and reference rows that were only partly uploaded must not be matched against.  Armed once queueing starts,
 // disarmed on success.
+// A host entry reports the overflow of ITS OWN call: a saturation word an earlier asynchronous *_batch_dev call left behind (whose caller never asked: airfe_sync /
+// airfe_superglue_status) must not fail a later healthy call with a stale "left the fp16 range" (ADVICE r05).  Cleared where a host entry starts queueing.
+inline void clear_saturation(airfe_ctx* c) {
+  if (c->sat_host) c->sat_host[0] = c->sat_host[1] = 0;
+}
 struct DrainOnError {
   airfe_ctx* c; bool armed = false, ref_uploaded = false;
+  explicit DrainOnError(airfe_ctx* c_, bool armed_ = false) : c(c_), armed(armed_) { clear_saturation(c_); }
   ~DrainOnError() {
     if (!armed) return;
     (void)hipStreamSynchronize(c->stream);
@@ -128,6 +134,7 @@ int upload_image(airfe_ctx* c, const uint8_t* gray, int h, int w, int stride) {
   if (ensure_stage_img(c, (size_t)h * stride)) return 1;
   // through the pinned block: a pageable hipMemcpyAsync is staged by the runtime in chunks, synchronously (measured: 2.4x the time)
   if (ensure_pin(c, bytes)) return 1;
+  clear_saturation(c);
   memcpy(c->pin, gray, bytes);
   HIPCHK(c, hipMemcpyAsync(c->st_img, c->pin, bytes, hipMemcpyHostToDevice, c->stream));
   return 0;
@@ -1111,6 +1118,7 @@ static int stereo_keyframe_impl(airfe_ctx* c, const uint8_t* left, const uint8_t
   if (n1 > 0) memcpy(featR, c->pin + 64 + fb, (size_t)n1 * AIRFE_FEAT_DIM * 4);
   *nL = n0; *nR = n1;
   if (!replay) HIPCHK(c, hipStreamSynchronize(st));
+  drain.ref_uploaded = false;           // (the stream is idle: an uploaded reference is whole whatever is reported below — as airfe_track_frame does)
   if (saturation_status(c)) { *nL = *nR = 0; return 1; }
   const int* hc = reinterpret_cast<const int*>(c->pin + early);
   const int nl0 = hc[2], nl1 = hc[3], nm = std::min(hc[10], Np), nj = hc[5];

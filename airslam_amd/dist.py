@@ -65,3 +65,31 @@ def max_over_ranks(x: float, device, force: bool = False) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_over_ranks(x: float, device, force: bool = False) -> List[float]:
+    """every rank's value of `x`, in rank order, on every rank (one all_gather of a double)"""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+        return [float(x)]
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]
+
+
+def pin_rank_to_cores(local: int, n_local: int) -> Optional[List[int]]:
+    """One process per GPU queues hundreds of launches per step from its own host thread: give local rank `local` of `n_local` its own contiguous share of the
+    cores this process may run on (os.sched_setaffinity), so that eight ranks do not migrate over each other's cores.  -> the cores chosen, or None where the
+    platform has no affinity call / there are fewer cores than ranks (nothing is changed then)."""
+    if not hasattr(os, "sched_getaffinity") or n_local <= 1:
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    if len(cores) < n_local:
+        return None
+    per = len(cores) // n_local
+    mine = cores[local * per:(local + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine

@@ -15,13 +15,17 @@ What the reference runs per frame is `MapBuilder::ExtractFeatureThread`, src/map
         a NORMAL frame with result 0 is promoted: Detect(right) + MatchingPoints(left, right)                (:104-108)
     `_last_keyframe_feature = frame` for every frame that is not a normal one (:139-141)
 
-Two drivers of the same loop, with identical per-frame outputs (tests/test_gpu_seq.py):
+Three drivers of the same loop, with identical per-frame outputs (tests/test_gpu_seq.py):
   * `SequenceFrontEnd`  — ONE sequence through the batch-1 host entries, one call per branch: airfe_stereo_keyframe[_tracked] (PLNet x2 + stereo match
     [+ temporal match in the same LightGlue forward]), airfe_track_frame (SuperPoint + temporal match, the reference rows resident on the device),
     airfe_promote_frame (+ airfe_adopt_reference).  The regime AirSLAM itself runs in: latency per frame.
   * `BatchedSequences`  — S independent sequences in lock-step through the device-resident *_batch_dev entries: per time-step the sequences are grouped by
     branch (keyframe candidates -> one PLNet stereo batch, the rest -> one SuperPoint batch; all temporal matches -> one LightGlue batch; promotions -> one
     more detector + matcher batch), one host synchronisation per decision point.  The regime of a server replaying many sequences: frames/s.
+  * `NativeSequences`   — the same lock-step schedule driven from C++ (include/airfe_seq.h, csrc/airfe_seq.hip: the reference's caller is C++ too): the host side
+    of a time-step is two C calls, every gather / scatter / result copy of the step is one copy-job launch, and only the valid rows cross PCIe.
+    `NativePipeline` runs two such drivers (two groups of sequences, each with its own contexts) half a step apart, so that the device works on one group
+    while the host decides for the other.
 
 The keyframe POLICY (AddKeyframeCheck, Frame::AddRightFeatures' stereo count) is the caller's, not the path's: it is restated here (file:line on every
 function) only so that the loop can run without the SLAM back end.  Not restated: the F-matrix RANSAC behind MatchingPoints(..., true)
@@ -317,6 +321,8 @@ class BatchedSequences:
         self.stream.synchronize()
         t_c = _time.perf_counter()
         self.syncs += 1
+        # the asynchronous entries report through their contexts (an fp16 overflow of a detector: never keypoints of a poisoned score map): ask both
+        self.kf.sync(); self.nf.sync()
         for i in range(S):
             out[i].features_left = self._own(h_cur[i, :h_cur_n[i]])
         if kset:
@@ -357,6 +363,7 @@ class BatchedSequences:
             self.t_wait += _time.perf_counter() - t_p0
             t_c += _time.perf_counter() - t_p0             # (the promotion's wait is not host time)
             self.syncs += 1
+            self.nf.sync()
             pr, pnr, pidx, psc, pnm = h_p
             for j, i in enumerate(pset):
                 fr = self._own(pr[j, :pnr[j]])
@@ -385,34 +392,211 @@ class BatchedSequences:
         return out
 
 
+class NativeSequences:
+    """S sequences in lock-step through the C++ driver (include/airfe_seq.h).  `step(L, R)` = BatchedSequences.step with the same results (views of the
+    driver's pinned staging memory, valid until the end of the next step unless copy_results); `begin` / `end_raw` are the two halves for pipelined use,
+    `raw` the ctypes array of airfe_seq_frame records of the last step (what a C++ caller would read)."""
+
+    def __init__(self, kf: api.Context, nf: api.Context, S: int, cfg: Optional[KeyframeConfig] = None, cap_lines: int = 1024, cap_junc: int = 1024,
+                 device=None, copy_results: bool = True, temporal_buffers: bool = False):
+        import ctypes as C
+        from . import _lib
+        self._C, self._l = C, _lib.lib()
+        self.kf, self.nf, self.S, self.cfg = kf, nf, S, cfg or KeyframeConfig()
+        self.K = nf.max_keypoints
+        c = self.cfg
+        pol = _lib.SeqPolicy(c.min_init_stereo_feature, c.min_num_match, c.max_num_match, c.tracking_point_rate, c.tracking_parallax_rate, c.min_x_diff, c.max_x_diff,
+                             c.max_y_diff, c.image_width, c.image_height)
+        self.tidx = self.tsc = self.tnm = None
+        ptrs = (None, None, None)
+        if temporal_buffers:         # the temporal match lists stay on the device in caller-owned tensors (MatchGatherer forwards them)
+            import torch
+            dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+            self.tidx = torch.zeros((S, self.K, 2), dtype=torch.int32, device=dev)
+            self.tsc = torch.zeros((S, self.K), dtype=torch.float32, device=dev)
+            self.tnm = torch.zeros((S,), dtype=torch.int32, device=dev)
+            ptrs = (self.tidx.data_ptr(), self.tsc.data_ptr(), self.tnm.data_ptr())
+        h = C.c_void_p()
+        if self._l.airfe_seq_create(kf._h, nf._h, S, C.byref(pol), cap_lines, cap_junc, ptrs[0], ptrs[1], ptrs[2], C.byref(h)):
+            raise api.AirfeError("airfe_seq_create: " + (self._l.airfe_seq_last_error(None) or b"").decode())
+        self._h = h
+        self.raw = (_lib.SeqFrame * S)()
+        self.copy_results = copy_results
+        self.stream_ptr = self._l.airfe_seq_stream(self._h)
+        self._ext_stream = None
+
+    @property
+    def stream(self):
+        """the driver's stream as a torch stream (for ordering a forwarder of the temporal buffers behind it)"""
+        if self._ext_stream is None:
+            import torch
+            self._ext_stream = torch.cuda.ExternalStream(self.stream_ptr)
+        return self._ext_stream
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.airfe_seq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            raise api.AirfeError(f"{what}: {(self._l.airfe_seq_last_error(self._h) or b'').decode()}")
+
+    def begin(self, L, R):
+        """L, R: [S, h, w] uint8 device tensors (contiguous rows)"""
+        assert L.shape[0] == self.S and R.shape == L.shape and L.stride(2) == 1 and R.stride() == L.stride()
+        self._chk(self._l.airfe_seq_begin(self._h, L.data_ptr(), R.data_ptr(), L.shape[1], L.shape[2], L.stride(1), L.stride(0)), "airfe_seq_begin")
+
+    def end_raw(self):
+        self._chk(self._l.airfe_seq_end(self._h, self.raw), "airfe_seq_end")
+        return self.raw
+
+    def step_raw(self, L, R):
+        assert L.shape[0] == self.S and R.shape == L.shape and L.stride(2) == 1 and R.stride() == L.stride()
+        self._chk(self._l.airfe_seq_step(self._h, L.data_ptr(), R.data_ptr(), L.shape[1], L.shape[2], L.stride(1), L.stride(0), self.raw), "airfe_seq_step")
+        return self.raw
+
+    def results(self) -> List[FrameResult]:
+        """the last step's records as FrameResults"""
+        C = self._C
+        own = (lambda a: a.copy()) if self.copy_results else (lambda a: a)
+
+        def arr(ptr, n, cols, ct, dt):
+            if n < 0 or not ptr:
+                return None
+            if n == 0:
+                return np.zeros((0, cols) if cols else (0,), dt)
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n * max(cols, 1),)).view(dt)
+            return own(a.reshape(n, cols) if cols else a)
+        out = []
+        for r in self.raw:
+            fr = FrameResult(frame_type=r.frame_type, candidate=bool(r.candidate), promoted=bool(r.promoted), dropped=bool(r.dropped), enough_match=r.enough_match,
+                             good_stereo_point=r.good_stereo_point)
+            fr.features_left = arr(r.features_left, r.n_left, 259, C.c_float, np.float32)
+            fr.features_right = arr(r.features_right, r.n_right, 259, C.c_float, np.float32)
+            fr.lines_left = arr(r.lines_left, r.n_lines_left, 4, C.c_double, np.float64)
+            fr.lines_right = arr(r.lines_right, r.n_lines_right, 4, C.c_double, np.float64)
+            fr.junctions = arr(r.junctions, r.n_junctions, 259, C.c_float, np.float32)
+            fr.stereo_idx = arr(r.stereo_idx, r.n_stereo, 2, C.c_int32, np.int32)
+            fr.stereo_score = arr(r.stereo_score, r.n_stereo, 0, C.c_float, np.float32)
+            fr.matches_idx = arr(r.matches_idx, r.n_matches, 2, C.c_int32, np.int32)
+            fr.matches_score = arr(r.matches_score, r.n_matches, 0, C.c_float, np.float32)
+            out.append(fr)
+        return out
+
+    def step(self, L, R) -> List[FrameResult]:
+        self.step_raw(L, R)
+        return self.results()
+
+    def counts(self):
+        """the integer fields of the last step's records as one [S, 13] array (schedule statistics without building FrameResults)"""
+        a = np.frombuffer(self.raw, dtype=np.uint8).reshape(self.S, -1)
+        return a[:, :52].copy().view(np.int32)
+
+    def wall_split(self):
+        """-> dict(queue_s, wait_s, host_s, host_syncs, steps) since the last call"""
+        C = self._C
+        q, w, h, n, st = C.c_double(), C.c_double(), C.c_double(), C.c_int(), C.c_int()
+        self._chk(self._l.airfe_seq_wall_split(self._h, C.byref(q), C.byref(w), C.byref(h), C.byref(n), C.byref(st)), "airfe_seq_wall_split")
+        return dict(queue_s=q.value, wait_s=w.value, host_s=h.value, host_syncs=n.value, steps=st.value)
+
+
+COUNT_FIELDS = ("frame_type", "candidate", "promoted", "dropped", "enough_match", "good_stereo_point", "n_left", "n_right", "n_lines_left", "n_lines_right",
+                "n_junctions", "n_stereo", "n_matches")
+
+
+class NativePipeline:
+    """G groups of sequences (one NativeSequences each, with its own pair of contexts), half a step apart: begin(A) begin(B) | end(A) begin(A) end(B) begin(B) | ...
+    — while the host takes group A's decisions and queues its next time-step, the device works on group B's.  `step(L, R)` takes the images of ALL sequences of a
+    time-step ([S_total, h, w], group g owns rows [g * S, (g + 1) * S)) and returns the records of the time-step BEFORE (one step of latency: the pipeline's price);
+    `flush()` returns the last ones."""
+
+    def __init__(self, groups: List[NativeSequences]):
+        self.g = groups
+        self.S = groups[0].S
+        assert all(x.S == self.S for x in groups)
+        self._primed = False
+
+    def _slices(self, L, R):
+        S = self.S
+        return [(L[i * S:(i + 1) * S], R[i * S:(i + 1) * S]) for i in range(len(self.g))]
+
+    def step(self, L, R):
+        sl = self._slices(L, R)
+        if not self._primed:
+            for x, (l, r) in zip(self.g, sl):
+                x.begin(l, r)
+            self._primed = True
+            return None
+        out = []
+        for x, (l, r) in zip(self.g, sl):
+            out.append(x.end_raw())
+            self.on_group_done(x)
+            x.begin(l, r)
+        return out
+
+    def on_group_done(self, x):
+        """hook: called after a group's end, before its next begin (the temporal buffers of that group are complete and not yet overwritten)"""
+
+    def flush(self):
+        if not self._primed:
+            return None
+        out = []
+        for x in self.g:
+            out.append(x.end_raw())
+            self.on_group_done(x)
+        self._primed = False
+        return out
+
+
 class MatchGatherer:
     """SURVEY.md 8(e) / BASELINE configs[3]: every K frames the ranks' temporal match lists go to rank 0 in ONE collective (airslam_amd.dist.gather_matches:
     a padded [K * S][cap * 3 + 1] int32 buffer per rank), issued on a SIDE stream behind an event so that the next frames' kernels do not wait for it.
     `add(idx, score, n)` takes one time-step's [S, cap, 2] / [S, cap] / [S] tensors (device or CPU); the K-th call starts the gather and returns a handle whose
     `.result()` is rank 0's (idx, score, n) — [world * K * S, ...] in (rank, frame, sequence) order — or None on the other ranks."""
 
-    def __init__(self, K: int, S: int, cap: int, device, dst: int = 0):
+    def __init__(self, K: int, S: int, cap: int, device, dst: int = 0, buffers: int = 1):
+        """buffers: sets of (idx, score, n) filled in turn, each with the event of the gather that last read it — with one set and K = 1 every add() waits for the
+        previous collective before it refills the set; with two the compute stream only ever waits for the collective before the last one."""
         import torch
         self.t, self.K, self.S, self.cap, self.dst, self.dev = torch, K, S, cap, dst, device
-        self.idx = torch.zeros((K * S, cap, 2), dtype=torch.int32, device=device)
-        self.score = torch.zeros((K * S, cap), dtype=torch.float32, device=device)
-        self.n = torch.zeros((K * S,), dtype=torch.int32, device=device)
+        self.sets = [dict(idx=torch.zeros((K * S, cap, 2), dtype=torch.int32, device=device), score=torch.zeros((K * S, cap), dtype=torch.float32, device=device),
+                          n=torch.zeros((K * S,), dtype=torch.int32, device=device), last=None) for _ in range(max(1, buffers))]
+        self.cur = 0
         self.fill = 0
         self.gathers = 0
         self.cuda = torch.device(device).type == "cuda"
         self.side = torch.cuda.Stream(device=device) if self.cuda else None
-        self._last = None
+
+    @property
+    def idx(self):
+        return self.sets[self.cur]["idx"]
+
+    @property
+    def score(self):
+        return self.sets[self.cur]["score"]
+
+    @property
+    def n(self):
+        return self.sets[self.cur]["n"]
 
     def add(self, idx, score, n, stream=None):
         t, S, k = self.t, self.S, self.fill
+        b = self.sets[self.cur]
         ctxm = t.cuda.stream(stream) if (self.cuda and stream is not None) else _Null()
         with ctxm:
-            if k == 0 and self._last is not None and self.cuda:      # the buffers are about to be refilled: the previous gather must have read them
-                (stream or t.cuda.current_stream(self.dev)).wait_event(self._last)
+            if k == 0 and b["last"] is not None and self.cuda:      # the set is about to be refilled: the gather that last read it must be done
+                (stream or t.cuda.current_stream(self.dev)).wait_event(b["last"])
             rows = slice(k * S, k * S + idx.shape[0])
-            self.idx[rows] = idx; self.score[rows] = score; self.n[rows] = n
+            b["idx"][rows] = idx; b["score"][rows] = score; b["n"][rows] = n
             if idx.shape[0] < S:
-                self.n[k * S + idx.shape[0]:(k + 1) * S] = 0
+                b["n"][k * S + idx.shape[0]:(k + 1) * S] = 0
         self.fill += 1
         if self.fill < self.K:
             return None
@@ -423,16 +607,18 @@ class MatchGatherer:
         from . import dist as adist
         t = self.t
         self.gathers += 1
+        b = self.sets[self.cur]
+        self.cur = (self.cur + 1) % len(self.sets)
         if not self.cuda:
-            out = adist.gather_matches(self.idx, self.score, self.n, dst=self.dst)
+            out = adist.gather_matches(b["idx"], b["score"], b["n"], dst=self.dst)
             return _Done(out)
         ev = t.cuda.Event()
         ev.record(stream or t.cuda.current_stream(self.dev))
         with t.cuda.stream(self.side):
             self.side.wait_event(ev)
-            out = adist.gather_matches(self.idx, self.score, self.n, dst=self.dst)
-            self._last = t.cuda.Event()
-            self._last.record(self.side)
+            out = adist.gather_matches(b["idx"], b["score"], b["n"], dst=self.dst)
+            b["last"] = t.cuda.Event()
+            b["last"].record(self.side)
         return _Done(out, self.side)
 
 

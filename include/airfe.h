@@ -89,7 +89,9 @@ typedef struct airfe_cfg {
   int line_precision;          /* how the PLNet stage-1 LOI head's matrix products (src/plnet.cpp:468-514) are computed on the device path:
                                   3 = fp32 operands as PAIRS of fp16 values on the 2-byte MFMA (hi.hi + hi.lo + lo.hi, fp32 accumulation): the lines of the
                                       fp32 chain (scores within 2e-6, no candidate across the 0.75 threshold), on the pipe the reference runs this engine on
-                                      (BuilderFlag::kFP16, src/plnet.cpp:216) without its rounding;
+                                      (BuilderFlag::kFP16, src/plnet.cpp:216) without its rounding.  Range: the operands (LOI / thin / aux samples, hidden
+                                      activations) are clamped to +-65504 before the split — the real head's stay below 64; a value beyond fp16's range enters
+                                      as +-65504 instead of turning a line's score into NaN;
                                   2 = fp32 operands on the f32-input MFMA (157 TFLOP/s): the same lines, 1.8x the stage's time;
                                   1 = plain fp16 operands, REFUSED: emulated with the real weights it moves 0.5-0.9 % of the kept lines across the 0.75
                                       threshold (profiles/r05_s1_fp16_emulation.txt);

@@ -21,7 +21,8 @@ def _header_symbols(name=None):
 
 
 def test_debug_hooks_are_not_in_the_product_header():
-    assert not [n for n in _header_symbols("airfe.h") if n.startswith("airfe_debug_")]
+    assert not [n for n in _header_symbols("airfe.h") + _header_symbols("airfe_seq.h") if n.startswith("airfe_debug_")]
+    assert all(n.startswith("airfe_seq_") for n in _header_symbols("airfe_seq.h"))
     assert all(n.startswith("airfe_debug_") for n in _header_symbols("airfe_debug.h"))
 
 
@@ -86,18 +87,23 @@ def test_library_reads_no_environment():
 
 
 def test_every_c_entry_catches_exceptions():
-    """include/airfe.h promises "never throws": every extern "C" function that can reach host-side C++ (std::vector / std::string growth) is a
-    function-try-block ending in AIRFE_CATCH."""
-    src = open(os.path.join(ROOT, "airslam_amd", "csrc", "airfe.hip")).read()
-    body = src[src.index('extern "C" {'):]
+    """include/airfe.h and include/airfe_seq.h promise "never throws": every extern "C" function that can reach host-side C++ (std::vector / std::string growth) is
+    a function-try-block ending in AIRFE_CATCH (csrc/airfe.hip) / SEQ_CATCH or a catch-all (csrc/airfe_seq.hip)."""
     trivial = {"airfe_profile_stages", "airfe_has_line_branch", "airfe_debug_trace_slots"}      # one expression on plain ints / pointers
-    defs = re.findall(r"^int (airfe_[a-z0-9_]+)\([^;{]*?\)\s*(try)?\s*\{", body, flags=re.M | re.S)
-    assert len(defs) >= 45
-    missing = [n for n, t in defs if not t and n not in trivial]
-    assert not missing, f"no function-try-block: {missing}"
-    assert body.count("} AIRFE_CATCH(") == sum(1 for _, t in defs if t)
-    declared = {n for n in _header_symbols() if n not in ("airfe_default_cfg", "airfe_default_tuning", "airfe_destroy", "airfe_last_error", "airfe_profile_stage_name")}
-    assert declared == {n for n, _ in defs}, declared ^ {n for n, _ in defs}
+    found = set()
+    for fname, catch, least in (("airfe.hip", "} AIRFE_CATCH(", 45), ("airfe_seq.hip", "} SEQ_CATCH(", 5)):
+        src = open(os.path.join(ROOT, "airslam_amd", "csrc", fname)).read()
+        body = src[src.index('extern "C" {'):]
+        defs = re.findall(r"^int (airfe_[a-z0-9_]+)\([^;{]*?\)\s*(try)?\s*\{", body, flags=re.M | re.S)
+        assert len(defs) >= least
+        missing = [n for n, t in defs if not t and n not in trivial]
+        assert not missing, f"{fname}: no function-try-block: {missing}"
+        assert body.count(catch) + body.count("} catch (...) { return -1; }") == sum(1 for _, t in defs if t), fname
+        found |= {n for n, _ in defs}
+    not_int = ("airfe_default_cfg", "airfe_default_tuning", "airfe_destroy", "airfe_last_error", "airfe_profile_stage_name", "airfe_seq_default_policy", "airfe_seq_destroy",
+               "airfe_seq_last_error", "airfe_seq_stream")
+    declared = {n for n in _header_symbols() if n not in not_int}
+    assert declared == found, declared ^ found
 
 
 def test_default_tuning_is_all_minus_one(libpath):

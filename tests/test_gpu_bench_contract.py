@@ -54,6 +54,19 @@ def test_default_workload_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "pairs/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
     assert cb.get("parity_ok", True) is True
+    # the same step host to host rides along (pinned host images in, everything the step produced back in pinned host memory, copies on their own streams)
+    hh = d["host_to_host"]
+    assert hh["pairs_per_s"] > 0 and hh["h2d_bytes_per_step"] == 2 * 8 * 752 * 480 and hh["d2h_bytes_per_step"] > 2 * 8 * 400 * 259 * 4 and hh["matches_mean_last_step"] > 50
+    assert abs(hh["ratio_to_resident"] - hh["pairs_per_s"] / d["value"]) < 1e-9
+    assert len(d["host"]["queue_ms_per_step_per_rank"]) == 1 and 0 < d["host"]["queue_ms_per_step_per_rank"][0] < d["ms_per_step"] * 1.5
+
+
+def test_io_host_line():
+    """--io host: `value` = the host-to-host rate (anchor: the reference copies in and out inside every infer(), src/plnet.cpp:231,237), the resident rate beside it"""
+    d = _run("--pairs", "8", "--steps", "3", "--warmup", "1", "--cpu-pairs", "0", "--io", "host", "--io-steps", "6")
+    assert d["value"] == d["host_to_host"]["pairs_per_s"] and d["steps"] == 6 and d["value_resident"] > 0 and "HOST memory" in d["config"]["workload"]
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["host_to_host"]["pcie_gbs"]["h2d"] > 0 and d["host_to_host"]["pcie_gbs"]["d2h"] > 0
 
 
 @pytest.mark.parametrize("args", [("--matcher", "superglue", "--pairs", "4"), ("--detector", "superpoint", "--pairs", "4"),
@@ -89,11 +102,22 @@ def test_seq_workload_line():
     # (--min-num-match 100: a normal frame whose temporal matches fall below 100 is promoted — the synthetic matcher finds 60-100 even across a scene change)
     assert sch["frames"] == 3 * 32 and sch["keyframes"] >= 6 and sch["promotions"] >= 1 and sch["normal_frames"] >= 30 and sch["temporal_matches_mean"] >= 40
     assert sch["dropped_before_init"] == 0
-    assert d["config"]["gather_every_frames"] == 8 and d["config"]["gathers"] == 4 and "BatchedSequences" in d["config"]["driver"]
+    # default driver: the C++ lock-step loop (include/airfe_seq.h); 3 sequences = one group
+    assert d["config"]["gather_every_frames"] == 8 and d["config"]["gathers"] == 4 and "airfe_seq.h" in d["config"]["driver"] and d["config"]["groups"] == 1
     lat = d["latency_ms_per_time_step"]
     assert 0 < lat["p50"] <= lat["p99"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and 0.0 < rf["step_frac"] < rf["frac"] < 1.0 and rf["step_gflop"] > 50
+    ws = d["host"]["wall_split_ms_per_step"]
+    assert ws["host_syncs"] >= 1.0 and ws["queue_device_work"] > 0 and ws["wait_for_device"] > 0 and ws["host_side_of_the_loop"] >= 0
+    # the same frames through round 5's Python driver and through two pipelined groups of the C++ one: the same schedule
+    dp = _run("--workload", "seq", "--sequences", "4", "--frames", "34", "--warmup", "2", "--scene-len", "10", "--cpu-pairs", "0", "--min-num-match", "100", "--seq-driver", "python")
+    dn = _run("--workload", "seq", "--sequences", "4", "--frames", "34", "--warmup", "2", "--scene-len", "10", "--cpu-pairs", "0", "--min-num-match", "100")
+    assert "BatchedSequences" in dp["config"]["driver"] and dn["config"]["groups"] == 2 and "NativePipeline" in dn["config"]["driver"]
+    assert dp["config"]["schedule"] == dn["config"]["schedule"]
+    assert dn["config"]["gathers"] == 2 * 4
     d1 = _run("--workload", "seq", "--sequences", "1", "--frames", "24", "--warmup", "2", "--scene-len", "10", "--cpu-pairs", "0")
     assert "SequenceFrontEnd" in d1["config"]["driver"] and d1["config"]["schedule"]["frames"] == 22 and d1["value"] > 0
 
@@ -107,6 +131,23 @@ def test_gpus_2_launches_two_ranks_itself(monkeypatch):
     d = _run("--gpus", "2", "--pairs", "4", "--steps", "2", "--warmup", "1", "--cpu-pairs", "0", "--no-profile")
     assert d["n_gpus"] == 2 and d["collective"]["ranks"] == 2 and d["collective"]["backend"] == "gloo"
     assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_two_ranks_on_one_host_do_not_slow_each_other_s_queueing(monkeypatch):
+    """Host-side readiness for the 8-rank run: one process per GPU queues a few hundred launches per step from one host thread; every local
+    rank is given its own share of the cores (airslam_amd.dist.pin_rank_to_cores) and the line carries each rank's queueing time per step.  Two ranks on this
+    box (sharing GPU 0 over gloo — the device time doubles, the HOST time must not): each rank's queue_ms_per_step within 25 % + 0.15 ms of the one-rank run's
+    (10 % is the target on an idle box; the slack is for a shared CI host)."""
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    common = ("--pairs", "16", "--steps", "12", "--warmup", "3", "--cpu-pairs", "0", "--no-profile", "--io-steps", "0")
+    one = _run("--gpus", "1", *common)
+    monkeypatch.setenv("AIRFE_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("AIRFE_ONE_DEVICE", "1")
+    two = _run("--gpus", "2", *common)
+    q1, q2 = one["host"]["queue_ms_per_step_per_rank"], two["host"]["queue_ms_per_step_per_rank"]
+    assert len(q1) == 1 and len(q2) == 2
+    assert max(q2) <= 1.25 * q1[0] + 0.15 + 0.3, (q1, q2)          # (+0.3 ms: the per-step gather's Python, which the one-rank run does not have)
+    assert two["host"]["cores_of_rank0"] is None or len(two["host"]["cores_of_rank0"]) >= 1
 
 
 def test_frontend_workload_line():

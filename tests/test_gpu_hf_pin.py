@@ -78,7 +78,7 @@ def test_lightglue_scores_vs_hf(n0, n1, seed):
     hf = GOLD[f"lg_{n0}_{n1}_{seed}"]
     hp = _live()
     if hp is not None:
-        np.testing.assert_allclose(hp.lightglue_scores(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:]), hf, atol=2e-4, rtol=0)
+        np.testing.assert_allclose(hp.lightglue_scores(lg, a[:, :2], a[:, 2:], b[:, :2], b[:, 2:]), hf, atol=5e-4, rtol=0)      # live modules on THIS host (other core count: other summation order inside torch) against the committed run
     s = ctx.lightglue_scores(a, b)
     idx, sc = ctx.match_lightglue(a, b)
     _check_against_oracle(f"hf_lightglue_{n0}_{n1}", s, hf[:-1, :-1], idx, sc, 0.05, min(n0, n1) // 3 if min(n0, n1) > 8 else 0)
@@ -92,6 +92,6 @@ def test_superglue_scores_vs_hf(n0, n1, seed):
     hf = GOLD[f"sg_{n0}_{n1}_{seed}"]
     hp = _live()
     if hp is not None:
-        np.testing.assert_allclose(hp.superglue_scores(w, a[:, 1:3], a[:, 0], a[:, 3:], b[:, 1:3], b[:, 0], b[:, 3:]), hf, atol=2e-4, rtol=0)
+        np.testing.assert_allclose(hp.superglue_scores(w, a[:, 1:3], a[:, 0], a[:, 3:], b[:, 1:3], b[:, 0], b[:, 3:]), hf, atol=5e-4, rtol=0)      # live modules on THIS host (other core count: other summation order inside torch) against the committed run
     _check_superglue(f"hf_superglue_{n0}_{n1}", ctx, w, a, b, 18, 100, 0.05, min(n0, n1) // 3 if min(n0, n1) > 8 else 0, ref=hf)
     ctx.close()

@@ -392,6 +392,8 @@ def test_match_scores_are_glibc_expf_bit_for_bit():
     restates glibc's algorithm operation by operation (common.h expf_like_glibc); here ~20000 scores over the whole range a kept match can have,
     (log 0.1, 0], against the host's libm, bit for bit (the old form would miss about a dozen of them)."""
     from airslam_amd import api, weights
+    from conftest import skip_unless_host_expf_is_glibc
+    skip_unless_host_expf_is_glibc()
     ctx = api.Context(lightglue=weights.synthetic_lightglue(1234, n_layers=1), max_batch=2, max_keypoints=1024)
     rng = np.random.default_rng(5)
     n, total = 1024, 0
@@ -462,8 +464,8 @@ def test_fused_block_tile_sizes_give_the_same_bits():
 
 @pytest.mark.parametrize("n0,n1", [(400, 400), (317, 400), (64, 65), (1, 5), (2, 1), (1024, 777), (129, 63)])
 def test_assignment_without_the_similarity_matrix_keeps_the_matches(n0, n1):
-    """Round 5: log-sum-exp and arg-max partials are taken inside the similarity tiles (airfe_tuning::assign_fused = 1, the default; kernels_lg.hip) instead of
-    writing sim [B][Np][Np] and reading it four times.  The log-sum-exp is then a sum of per-tile sums with hardware exponentials: the scores may move in their
+    """Round 5: log-sum-exp and arg-max partials are taken inside the similarity tiles (airfe_tuning::assign_fused = 1; kernels_lg.hip) instead of
+    writing sim [B][Np][Np] and reading it four times (selectable; the library default is assign_fused = 0: profiles/r05_assign_ab.txt).  The log-sum-exp is then a sum of per-tile sums with hardware exponentials: the scores may move in their
     last bits against the round-2 form, the match LISTS may not (outside rows whose decision sits within 1e-4 of a boundary — none in these inputs), and the
     scores the kernel hands out are the ones its own arg-max saw (filter_matches of them reproduces the list exactly)."""
     _, _, a, b = _pair(n0, n1, 500 + n0 + n1)

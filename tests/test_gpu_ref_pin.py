@@ -136,7 +136,11 @@ def test_matching_points_equals_the_reference_on_the_devices_own_scores(tmp_path
     assert cnt >= 50 and rcnt == cnt
     np.testing.assert_array_equal(q, np.array([m[0] for m in matches], np.int32))
     np.testing.assert_array_equal(t, np.array([m[1] for m in matches], np.int32))
-    np.testing.assert_array_equal(d, np.array([m[2] for m in matches], np.float32))       # 1 - exp(score): the device's exp == glibc's expf here
+    from conftest import host_expf_is_the_restated_glibc_routine
+    if host_expf_is_the_restated_glibc_routine():          # (the compiled reference links THIS host's libm; on another expf build the distances are within an ulp, not equal)
+        np.testing.assert_array_equal(d, np.array([m[2] for m in matches], np.float32))   # 1 - exp(score): the device's exp == glibc's expf here
+    else:
+        np.testing.assert_allclose(d, np.array([m[2] for m in matches], np.float32), atol=2e-7, rtol=0)
     fed = calls[0][1]                                                                       # NormalizeKeypoints + process_input of the reference
     np.testing.assert_array_equal(fed["keypoints_0"][0], n0[1:3].T)
     np.testing.assert_array_equal(fed["keypoints_1"][0], n1[1:3].T)

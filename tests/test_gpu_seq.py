@@ -73,6 +73,127 @@ def test_batched_sequences_equal_the_single_call_path():
     assert min(m["temporal_matches_mean"] for m in summ) >= 40
 
 
+def _run_batched(S, N, seqs, cfg):
+    import torch
+    kfb, nfb = _contexts(S)
+    bs = seq.BatchedSequences(kfb, nfb, S, cfg)
+    out = []
+    for t in range(N):
+        L = torch.from_numpy(np.stack([seqs[s][t][0] for s in range(S)])).cuda()
+        R = torch.from_numpy(np.stack([seqs[s][t][1] for s in range(S)])).cuda()
+        out.append(bs.step(L, R))
+    kfb.close(); nfb.close()
+    return out
+
+
+def test_native_driver_equals_the_python_driver():
+    """include/airfe_seq.h (the lock-step loop in C++: csrc/airfe_seq.hip) against airslam_amd.seq.BatchedSequences on the same 3 x 36 frames: every field and every
+    array of the 108 results byte-equal, incl. promotions and the schedule; one host synchronisation per decision point; the temporal match lists left on the
+    device in the caller's tensors are the ones in the records."""
+    import torch
+    S, N = 3, 36
+    cfg = seq.KeyframeConfig(**POLICY)
+    seqs = [_frames(N, 10 + s, 12) for s in range(S)]
+    want = _run_batched(S, N, seqs, cfg)
+    kf, nf = _contexts(S)
+    ns = seq.NativeSequences(kf, nf, S, cfg, temporal_buffers=True)
+    bad, promos, kfs = {}, 0, 0
+    for t in range(N):
+        L = torch.from_numpy(np.stack([seqs[s][t][0] for s in range(S)])).cuda()
+        R = torch.from_numpy(np.stack([seqs[s][t][1] for s in range(S)])).cuda()
+        got = ns.step(L, R)
+        for s, r in enumerate(got):
+            d = r.same_as(want[t][s])
+            if d:
+                bad[(s, t)] = d
+            promos += r.promoted; kfs += r.frame_type != seq.NORMAL
+        tset = [s for s in range(S) if got[s].matches_idx is not None]
+        torch.cuda.synchronize()
+        for j, s in enumerate(tset):          # row j of the device-side temporal buffers = the j-th initialised sequence
+            m = len(got[s].matches_idx)
+            if len(want[t][s].features_left):
+                assert int(ns.tnm[j]) == m or m == 0
+            np.testing.assert_array_equal(ns.tidx[j, :m].cpu().numpy(), got[s].matches_idx)
+            np.testing.assert_array_equal(ns.tsc[j, :m].cpu().numpy(), got[s].matches_score)
+        c = ns.counts()
+        assert [int(x) for x in c[:, 0]] == [r.frame_type for r in got] and [int(x) for x in c[:, 12]] == [len(r.matches_idx) if r.matches_idx is not None else -1 for r in got]
+    ws = ns.wall_split()
+    ns.close(); kf.close(); nf.close()
+    diag("seq_native_vs_python", differing=str(dict(list(bad.items())[:5])), promotions=promos, keyframes=kfs, host_syncs_per_step=ws["host_syncs"] / N,
+         queue_ms_per_step=ws["queue_s"] / N * 1e3, wait_ms_per_step=ws["wait_s"] / N * 1e3, host_ms_per_step=ws["host_s"] / N * 1e3)
+    assert not bad, f"{len(bad)} (sequence, frame) results differ: {dict(list(bad.items())[:5])}"
+    assert promos >= 2 and kfs >= 3 * S
+    assert ws["steps"] == N and ws["host_syncs"] == N + sum(1 for t in range(N) if any(r.promoted for r in want[t]))
+
+
+def test_native_pipeline_of_two_groups_equals_the_python_driver():
+    """Two NativeSequences (2 + 2 sequences, each group with its own contexts) half a step apart (seq.NativePipeline): the records of every (sequence, frame) are the
+    bytes the Python driver returns for the 4 sequences in one group — batch composition and the pipelining change nothing."""
+    import torch
+    S, N = 4, 30
+    cfg = seq.KeyframeConfig(**POLICY)
+    seqs = [_frames(N, 20 + s, 10) for s in range(S)]
+    want = _run_batched(S, N, seqs, cfg)
+    ctxs = [_contexts(2), _contexts(2)]
+    groups = [seq.NativeSequences(k, n, 2, cfg) for k, n in ctxs]
+    pipe = seq.NativePipeline(groups)
+    bad = {}
+
+    def check(t, recs):
+        for g, x in enumerate(groups):
+            for j, r in enumerate(x.results()):
+                d = r.same_as(want[t][2 * g + j])
+                if d:
+                    bad[(2 * g + j, t)] = d
+    done = 0
+    for t in range(N):
+        L = torch.from_numpy(np.stack([seqs[s][t][0] for s in range(S)])).cuda()
+        R = torch.from_numpy(np.stack([seqs[s][t][1] for s in range(S)])).cuda()
+        # (results() reads the group's LAST record array: check each group right after its end, through the hook)
+        seen = []
+        pipe.on_group_done = lambda x, seen=seen: seen.append((groups.index(x), x.results()))
+        pipe.step(L, R)
+        for g, res in seen:
+            for j, r in enumerate(res):
+                d = r.same_as(want[t - 1][2 * g + j])
+                if d:
+                    bad[(2 * g + j, t - 1)] = d
+            done += len(res)
+    seen = []
+    pipe.on_group_done = lambda x, seen=seen: seen.append((groups.index(x), x.results()))
+    pipe.flush()
+    for g, res in seen:
+        for j, r in enumerate(res):
+            d = r.same_as(want[N - 1][2 * g + j])
+            if d:
+                bad[(2 * g + j, N - 1)] = d
+        done += len(res)
+    for x in groups:
+        x.close()
+    for k, n in ctxs:
+        k.close(); n.close()
+    assert done == S * N
+    assert not bad, f"{len(bad)} (sequence, frame) results differ: {dict(list(bad.items())[:5])}"
+
+
+def test_native_driver_refuses_bad_arguments_and_reports_overflow():
+    import torch
+    cfg = seq.KeyframeConfig(**POLICY)
+    kf, nf = _contexts(2)
+    with pytest.raises(api.AirfeError, match="max_batch"):
+        seq.NativeSequences(kf, nf, 3, cfg)
+    with pytest.raises(api.AirfeError, match="line branch"):
+        seq.NativeSequences(nf, nf, 2, cfg)
+    ns = seq.NativeSequences(kf, nf, 2, cfg, cap_lines=8)          # far fewer rows than a synthetic frame's ~200 lines
+    fr = _frames(1, 10, 12)[0]
+    L = torch.from_numpy(np.stack([fr[0], fr[0]])).cuda(); R = torch.from_numpy(np.stack([fr[1], fr[1]])).cuda()
+    with pytest.raises(api.AirfeError, match="line capacity overflow"):
+        ns.step(L, R)
+    with pytest.raises(api.AirfeError, match="no time-step in flight"):
+        ns.end_raw()
+    ns.close(); kf.close(); nf.close()
+
+
 def test_promote_and_adopt_equal_detect_plus_match():
     """airfe_promote_frame ≙ map_builder.cc:104-108 = Detect(right) + MatchingPoints(left, right) with the left rows of the last airfe_track_frame still on the
     device; airfe_adopt_reference makes those rows the reference of the following airfe_track_frame calls."""

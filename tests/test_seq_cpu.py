@@ -172,3 +172,47 @@ def test_gather_every_8_frames_gloo_world2():
                     assert n[row] == want
                     assert (idx[row, :want, 0] == np.arange(want) + 1000 * rank + t).all() and (idx[row, :want, 1] == s).all()
                     assert np.allclose(sc[row, :want], 0.5 + 0.01 * t)
+
+
+def test_native_policy_functions_equal_the_python_driver_and_the_oracle():
+    """include/airfe_seq.h: airfe_seq_add_keyframe_check / airfe_seq_good_stereo_points (what the C++ lock-step driver decides with; pure host functions, no GPU)
+    against airslam_amd.seq's Python forms and the oracle's independent restatement (oracle/ref_seq.py) of src/map_builder.cc:429-466 and src/frame.cc:141-172 —
+    on random frames whose match counts and ratios straddle every threshold of the policy."""
+    import ctypes as C
+    from airslam_amd import _lib
+    from oracle import ref_seq
+    lib = _lib.lib()
+    rng = np.random.default_rng(5)
+    seen_akc, seen_good = set(), 0
+    for trial in range(400):
+        cfg = seq.KeyframeConfig(min_num_match=int(rng.integers(5, 40)), max_num_match=int(rng.integers(40, 90)), tracking_point_rate=float(rng.choice([0.2, 0.35, 0.65])),
+                                 tracking_parallax_rate=float(rng.choice([0.005, 0.02, 0.1])))
+        pol = _lib.SeqPolicy(cfg.min_init_stereo_feature, cfg.min_num_match, cfg.max_num_match, cfg.tracking_point_rate, cfg.tracking_parallax_rate, cfg.min_x_diff,
+                             cfg.max_x_diff, cfg.max_y_diff, cfg.image_width, cfg.image_height)
+        n0, n1 = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        f0 = rng.uniform(0, 1, (n0, 259)).astype(np.float32); f1 = rng.uniform(0, 1, (n1, 259)).astype(np.float32)
+        f0[:, 1] = rng.uniform(0, W, n0); f0[:, 2] = rng.uniform(0, H, n0)
+        m = int(rng.integers(0, min(n0, n1) + 1))
+        idx = np.stack([rng.permutation(n0)[:m], rng.permutation(n1)[:m]], 1).astype(np.int32)
+        spread = float(rng.choice([0.5, 3.0, 30.0, 150.0]))             # matched keypoints move by about this many pixels: parallax below / above the threshold
+        f1[:, 1] = rng.uniform(0, W, n1); f1[:, 2] = rng.uniform(0, H, n1)
+        f1[idx[:, 1], 1] = f0[idx[:, 0], 1] - rng.uniform(0.2, 1.0, m).astype(np.float32) * np.float32(spread)
+        f1[idx[:, 1], 2] = f0[idx[:, 0], 2] + rng.normal(0, 2.5, m).astype(np.float32)
+        got = lib.airfe_seq_add_keyframe_check(C.byref(pol), f0.ctypes.data, n0, f1.ctypes.data, n1, idx.ctypes.data, m)
+        want = seq.add_keyframe_check(cfg, f0, f1, idx)
+        orc = ref_seq.add_keyframe_check(f0, f1, idx, cfg.min_num_match, cfg.max_num_match, cfg.tracking_point_rate, cfg.tracking_parallax_rate, W, H)
+        assert got == want == orc, (trial, got, want, orc, m, n0, n1)
+        seen_akc.add(got)
+        g = lib.airfe_seq_good_stereo_points(C.byref(pol), f0.ctypes.data, f1.ctypes.data, idx.ctypes.data, m)
+        assert g == seq.good_stereo_points(cfg, f0, f1, idx) == ref_seq.add_right_features_count(f0, f1, idx, cfg.min_x_diff, cfg.max_x_diff, cfg.max_y_diff), trial
+        seen_good += g > 0 and g < m
+    assert seen_akc == {0, 1, 2} and seen_good > 50
+    # the band's edges: |dx| exactly on min_x_diff / max_x_diff, dy exactly on max_y_diff (the comparisons are >, <, <=)
+    cfg = seq.KeyframeConfig()
+    pol = _lib.SeqPolicy(cfg.min_init_stereo_feature, cfg.min_num_match, cfg.max_num_match, cfg.tracking_point_rate, cfg.tracking_parallax_rate, 1.0, 200.0, 5.0, W, H)
+    fl = np.zeros((6, 259), np.float32); fr = np.zeros((6, 259), np.float32)
+    fl[:, 1] = 300; fl[:, 2] = 100
+    fr[:, 1] = [299, 298.5, 100, 99.5, 301.5, 250]; fr[:, 2] = [100, 105, 100, 95, 100, 105.5]
+    idx = np.stack([np.arange(6), np.arange(6)], 1).astype(np.int32)
+    assert lib.airfe_seq_good_stereo_points(C.byref(pol), fl.ctypes.data, fr.ctypes.data, idx.ctypes.data, 6) == seq.good_stereo_points(cfg, fl, fr, idx) == 1      # only row 1 (|dx| 1.5, dy 5): rows 0, 2, 3 sit ON the band, row 4 has a negative parallax, row 5 dy 5.5
+    assert lib.airfe_seq_add_keyframe_check(None, None, 0, None, 0, None, 0) == -1
