@@ -308,7 +308,10 @@ int line_tail_dev(airfe_ctx* c, int i0, int nb, const float* loi_chw, int h, int
       GemmArgs g;
       g.X1 = c->l_feat; g.ld1 = 128; g.K1 = 128; g.Wp = c->cLh_loi.w; g.bias = c->cLh_loi.b; g.rowidx = c->l_ridx;
       g.M = Mp; g.N = 128; g.cb_total = c->cLh_loi.cbt; g.epi = EPI_STORE_F32; g.out = c->l_lrows; g.ldo = 128;
-      launch_gemm8(c->prec, 128, false, g, s5);
+      g.gr_wgs = c->gemmr_wgs;
+      // large batches: the streaming kernel with gathered rows (kernels_gemmr.hip, K = N = 128 form) — the tiled kernel ran this HBM-bound shape at 0.8 TB/s; the same bits
+      if (c->desc_gather_stream && Mp >= c->gemmr_min && c->prec != 2 && gemmr_gather128_applicable(g)) launch_gemmr_gather128(c->prec, g, s5);
+      else launch_gemm8(c->prec, 128, false, g, s5);
       if (c->cfg.line_precision == 3) launch_s1h_junc_proj(d + SG_JUNCS, c->l_lrows, 300, c->s1_wsplit[4], c->s1_wsplit[5], c->s1_jfeat, nb, SG_STRIDE, s5);
       else launch_s1_junc_proj(d + SG_JUNCS, nullptr, 0, 0, c->l_lrows, 300, c->s1_w[0], c->s1_jfeat, nb, SG_STRIDE, s5);
     } else {

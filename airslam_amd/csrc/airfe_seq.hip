@@ -457,9 +457,13 @@ int airfe_seq_end(airfe_seq* s, airfe_seq_frame* out) try {
     r.features_left = G.cur + (size_t)i * K * AIRFE_FEAT_DIM;
   }
   for (int j = 0; j < 2 * nk; ++j)
-    if (h_kfound[j] > s->CL) return sfail(s, "airfe_seq: line capacity overflow (cap_lines)");
+    if (h_kfound[j] > s->CL || h_kfound[j] < 0)
+      return sfail(s, "airfe_seq: line capacity overflow (cap_lines): " + std::to_string(h_kfound[j]) + " lines in the " + (j < nk ? "left" : "right") + " image of sequence " +
+                          std::to_string(s->kset[j % nk]) + ", cap_lines = " + std::to_string(s->CL));
   for (int j = 0; j < nk; ++j)
-    if (h_kfound[2 * nk + j] > s->CJ) return sfail(s, "airfe_seq: junction capacity overflow (cap_junc)");
+    if (h_kfound[2 * nk + j] > s->CJ || h_kfound[2 * nk + j] < 0)
+      return sfail(s, "airfe_seq: junction capacity overflow (cap_junc): " + std::to_string(h_kfound[2 * nk + j]) + " junctions in sequence " + std::to_string(s->kset[j]) +
+                          ", cap_junc = " + std::to_string(s->CJ));
   for (int j = 0; j < nk; ++j) {
     airfe_seq_frame& r = out[s->kset[j]];
     r.candidate = 1;

@@ -54,6 +54,8 @@ bool gemmr_applicable(int K, bool trans, const GemmArgs& a);
 void launch_gemmr(int prec, bool trans, const GemmArgs& a, hipStream_t st);
 bool gemmr_gather_applicable(int K, const GemmArgs& a);          // y[r] = W x[rowidx[r]] + b, fp32 rows out, K = N = 256: the streaming kernel with gathered source rows
 void launch_gemmr_gather(int prec, const GemmArgs& a, hipStream_t st);
+bool gemmr_gather128_applicable(const GemmArgs& a);                    // ... and K = N = 128 (the LOI head at the junctions' tap rows)
+void launch_gemmr_gather128(int prec, const GemmArgs& a, hipStream_t st);
 // head-major q|k linear `a` + transposed-V linear `b` over the same rows in one launch
 bool gemmr_pair_applicable(const GemmArgs& a, const GemmArgs& b);
 void launch_gemmr_pair(int prec, const GemmArgs& a, const GemmArgs& b, hipStream_t st);

@@ -261,6 +261,118 @@ void launch_gemmr_gather(int prec, const GemmArgs& a, hipStream_t st) {
   }
 }
 
+// GATHER, K = N = 128 (round 6): the LOI head of the PLNet line branch at the junctions' tap rows (airfe_detect.hip line_tail_dev: 1200 rows per image, 153600 at
+// 64 pairs; 256 B in, 512 B of fp32 out per row: HBM work) ran in the tiled 8-wave kernel (gemm8, rowidx form) at 0.8 TB/s — two K chunks per 256-row tile are
+// all fill and drain.  The same streaming shape as above with the geometry of this head: a tile = 64 gathered rows of 256 B (16 KiB: the ring's slot), 16
+// wave-instructions of four rows each; wave w owns the 32 features (w & 3) of rows 32 (w >> 2) .. + 32 — 8 weight fragments in registers, 8 ds_read_b128 and
+// 16 MFMAs per tile.  Same fragments, same K order (four 32-wide steps, ascending), bias after the sum: the bits of gemm8.
+constexpr int G128_TT = 64;                        // rows per streamed tile
+template <class P>
+__global__ __launch_bounds__(512, 1) void gemmr_gather128_kernel(GemmArgs a, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SLOTS = 8, SLOT = G128_TT * 256, PER = 2;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int first = blockIdx.x, per_group = gridDim.x;
+  const int n = first < ntiles ? (ntiles - first + per_group - 1) / per_group : 0;
+  if (n == 0) return;
+  const int cb = (wave & 3) >> 1, tp = wave & 1, rh = wave >> 2;
+  typename P::vec8 wreg[2][4];
+  {
+    const int sw = (l15 >> 1) & 7;
+    const char* wb = reinterpret_cast<const char*>(a.Wp) + (size_t)cb * 2 * SLAB_BYTES + 2 * tp * 2048 + l15 * 128;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        wreg[u][ks] = __builtin_bit_cast(typename P::vec8, *reinterpret_cast<const uint4*>(
+            wb + u * 2048 + (ks >> 1) * SLAB_BYTES + ((((ks & 1) * 4 + g) ^ sw) << 4)));
+  }
+  f32x4 binit[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) binit[u] = *reinterpret_cast<const f32x4*>(a.bias + cb * 64 + tp * 32 + g * 8 + u * 4);
+  int* idx_lds = reinterpret_cast<int*>(smem + SLOTS * SLOT);
+  for (int e = tid; e < n * G128_TT; e += 512) idx_lds[e] = a.rowidx[(size_t)(first + (e >> 6) * per_group) * G128_TT + (e & 63)];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int ld = a.ld1;
+  auto dma = [&](int j, int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int inst = wave * 2 + i;
+      const int r = inst * 4 + (lane >> 4), pp = lane & 15;
+      const size_t srow = (size_t)idx_lds[j * G128_TT + r];
+      gr_glds16(a.X1 + srow * ld + ((pp ^ (r & 15)) << 3), (unsigned)(slot * SLOT + inst * 1024));
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < SLOTS; ++j)
+    if (j < n) dma(j, j);
+  if (n >= SLOTS) gr_wait_vm<PER * (SLOTS - 1)>();
+  else gr_wait_vm<0>();
+  __syncthreads();
+
+  for (int i = 0; i < n; ++i) {
+    const int t = first + i * per_group, slot = i & (SLOTS - 1);
+    const char* xs = smem + slot * SLOT + (rh * 32 + l15) * 256;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[u][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      typename P::vec8 bf[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) bf[m] = lds_frag<P>(xs, m * 16 * 256 + (((ks * 4 + g) ^ l15) << 4));
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[u][m] = P::mfma(wreg[u][ks], bf[m], acc[u][m]);
+    }
+    const int behind = n - 2 - i;
+    if (behind >= SLOTS - 2) gr_wait_vm<PER * (SLOTS - 2)>();
+    else if (behind == 5) gr_wait_vm<PER * 5>();
+    else if (behind == 4) gr_wait_vm<PER * 4>();
+    else if (behind == 3) gr_wait_vm<PER * 3>();
+    else if (behind == 2) gr_wait_vm<PER * 2>();
+    else if (behind == 1) gr_wait_vm<PER>();
+    else gr_wait_vm<0>();
+    const int co = cb * 64 + tp * 32 + g * 8;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int row = t * G128_TT + rh * 32 + m * 16 + l15;
+      float* o = reinterpret_cast<float*>(a.out) + (size_t)row * a.ldo + co;
+      *reinterpret_cast<float4*>(o) = make_float4(acc[0][m][0] + binit[0][0], acc[0][m][1] + binit[0][1], acc[0][m][2] + binit[0][2], acc[0][m][3] + binit[0][3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(acc[1][m][0] + binit[1][0], acc[1][m][1] + binit[1][1], acc[1][m][2] + binit[1][2], acc[1][m][3] + binit[1][3]);
+    }
+    __syncthreads();
+    if (i + SLOTS < n) dma(i + SLOTS, slot);
+  }
+}
+
+bool gemmr_gather128_applicable(const GemmArgs& a) {
+  return a.rowidx && !a.X2 && !a.rot_cos && a.act == ACT_NONE && a.cb_total == 2 && a.N == 128 && a.K1 == 128 && a.M % G128_TT == 0 && a.epi == EPI_STORE_F32 &&
+         a.ldo >= 128 && a.ld1 % 8 == 0 && (a.M / G128_TT + std::max(a.gr_wgs, 1) - 1) / std::max(a.gr_wgs, 1) <= 120;      // (the busiest workgroup's index list fits behind the ring)
+}
+
+void launch_gemmr_gather128(int prec, const GemmArgs& a, hipStream_t st) {
+  const int ntiles = a.M / G128_TT;
+  const int nwg = std::max(std::min(a.gr_wgs, ntiles), 1);
+  const int nmax = (ntiles + nwg - 1) / nwg;
+  const int lds = 8 * G128_TT * 256 + nmax * G128_TT * 4;
+  if (prec == 1) {
+    static PerDeviceOnce once;
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmr_gather128_kernel<PF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(gemmr_gather128_kernel<PF16>, dim3((unsigned)nwg), dim3(512), lds, st, a, ntiles);
+  } else {
+    static PerDeviceOnce once;
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmr_gather128_kernel<PBF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(gemmr_gather128_kernel<PBF16>, dim3((unsigned)nwg), dim3(512), lds, st, a, ntiles);
+  }
+}
+
 bool gemmr_applicable(int K, bool trans, const GemmArgs& a) {
   const int ng = a.cb_total / 4;
   return K == 256 && !a.X2 && (!a.rot_cos || (!trans && a.epi == EPI_HEADS)) && a.act == ACT_NONE && a.cb_total % 4 == 0 && (ng == 1 || ng == 2) && a.N == a.cb_total * 64 &&

@@ -106,16 +106,21 @@ class HostClock:
     """wall time the host spends inside a block (queueing device work), summed: `with clock: step()`"""
 
     def __init__(self):
-        self.s, self.n = 0.0, 0
+        self.s, self.cpu, self.n = 0.0, 0.0, 0
 
     def __enter__(self):
-        self._t = time.perf_counter()
+        self._t, self._c = time.perf_counter(), time.thread_time()
         return self
 
     def __exit__(self, *a):
         self.s += time.perf_counter() - self._t
+        self.cpu += time.thread_time() - self._c
         self.n += 1
         return False
 
     def ms(self):
         return self.s / max(self.n, 1) * 1e3
+
+    def cpu_ms(self):
+        """CPU time of the calling thread inside the block (a launch call that blocks on a full queue sleeps: wall time, not CPU time)"""
+        return self.cpu / max(self.n, 1) * 1e3

@@ -165,6 +165,7 @@ def run(args, rank, world, local, dev):
         elif S > 1:
             split = {"queue_device_work": bs.t_queue / frames * 1e3, "wait_for_device": bs.t_wait / frames * 1e3, "host_side_of_the_loop": bs.t_host / frames * 1e3,
                      "host_syncs": bs.syncs / frames}
+        n_gathers = sum(g.gathers for g in gats)
         # the matrix work of a time-step against the peak: a few more time-steps (frames wrap around) with every stage of every context bracketed by events
         roof = None
         if S > 1 and not args.no_profile and args.stage_steps > 0:
@@ -198,7 +199,7 @@ def run(args, rank, world, local, dev):
         timed_counts = counts[n_warm_records:n_warm_records + timed]
         a = np.asarray(lat) * 1e3
         return dict(S=S, dt=dt, latency_ms={"p50": float(np.percentile(a, 50)), "p99": float(np.percentile(a, 99)), "mean": float(a.mean()), "max": float(a.max())}, frames_per_s=S * timed * world / dt, ms_per_step=dt / timed * 1e3, host_ms_per_step=host.ms(),
-                    schedule=_schedule(np.concatenate(timed_counts)), gathers=sum(g.gathers for g in gats), counts=counts, wall_split_ms_per_step=split, roofline=roof,
+                    schedule=_schedule(np.concatenate(timed_counts)), gathers=n_gathers, counts=counts, wall_split_ms_per_step=split, roofline=roof,
                     driver=driver, groups=G)
 
     runs = {S: run_S(S) for S in sweep}
@@ -222,7 +223,8 @@ def run(args, rank, world, local, dev):
                                 f"some sequences uninitialised for a scene); max_keypoints={K}; seeded synthetic weights except PLNet stage 1 (real)",
                     "sequences_per_gpu": args.sequences, "frames": frames, "gather_every_frames": KG, "gathers": head["gathers"], "schedule": head["schedule"],
                     "driver": head["driver"], "groups": head["groups"]},
-            host={"python_ms_per_time_step_per_rank": host_ms, "wall_split_ms_per_step": head["wall_split_ms_per_step"], "cores_of_rank0": args.cores},
+            host={"python_ms_per_time_step_per_rank": host_ms, "wall_split_ms_per_step": head["wall_split_ms_per_step"],
+                  "cores_of_rank0": [args.cores[0], args.cores[-1]] if args.cores else None},
             latency_ms_per_time_step=head["latency_ms"],
             sweep={str(S): {"frames_per_s": r["frames_per_s"], "ms_per_time_step": r["ms_per_step"], "latency_ms": r["latency_ms"], "schedule": r["schedule"], "driver": r["driver"],
                             "wall_split_ms_per_step": r["wall_split_ms_per_step"], "step_frac": r["roofline"] and r["roofline"]["step_frac"]} for S, r in runs.items()},

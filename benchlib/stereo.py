@@ -183,6 +183,9 @@ def run(args, rank, world, local, dev):
     ctx.profile(False)
     dt = adist.max_over_ranks(dt, dev)
     host_ms = adist.all_over_ranks(host.ms(), dev)            # per rank: wall time the host spends queueing one step (the rest of a step it is free)
+    host_cpu_ms = adist.all_over_ranks(host.cpu_ms(), dev)    # ... and the CPU time of that (a launch that blocks on a full queue is wall time only)
+    first_core = adist.all_over_ranks(float(args.cores[0]) if args.cores else -1.0, dev)
+    n_cores = adist.all_over_ranks(float(len(args.cores)) if args.cores else 0.0, dev)
     stages = {}
     if not args.no_profile and args.stage_steps > 0:          # every rank takes part: a step contains the match gather when world > 1
         ctx.profile(True)
@@ -233,8 +236,11 @@ def run(args, rank, world, local, dev):
                           "2-byte type inside the north-star tolerances (descriptors 4e-4 cosine, LightGlue 0.03 of 0.05); bf16 FAILS them (2e-2 cosine, "
                           "0.25 log-assignment: DESIGN.md §1) and is selectable with --dtype bf16 --matcher-dtype bf16 only as a non-compliant speed run"),
             collective=args.collective)
-        out["host"] = {"queue_ms_per_step_per_rank": host_ms, "cores_of_rank0": args.cores,
-                       "note": "wall time the host thread spends queueing one step's launches (the entries are asynchronous); the device needs ms_per_step for them"}
+        out["host"] = {"queue_ms_per_step_per_rank": host_ms, "queue_cpu_ms_per_step_per_rank": host_cpu_ms,
+                       "cores_per_rank": [[int(f), int(f) + int(n) - 1] if n else None for f, n in zip(first_core, n_cores)],
+                       "note": "wall / CPU time the host thread spends queueing one step's launches (the entries are asynchronous; a launch call that finds the queue "
+                               "full waits: wall time only); the device needs ms_per_step for them.  cores_per_rank: [first, last] core of each rank's own share "
+                               "(os.sched_setaffinity by local rank), null = not pinned"}
         if io_host:
             out["value_resident"] = resident
             out["ms_per_step_resident"] = ms_step

@@ -60,6 +60,26 @@ def test_plnet_batch_equals_single_image_calls(B, J):
         assert min(c[2] for c in counts[:J]) >= 50
 
 
+@pytest.mark.parametrize("wgs", [256, 8], ids=["one_tile_per_workgroup", "ring_wraps"])
+def test_loi_head_streaming_gather_gives_the_bits_of_the_tiled_kernel(wgs):
+    """Round 6: the LOI head at the junctions' tap rows (K = N = 128, 1200 gathered rows per image) streams through gemmr_gather128_kernel from 8192 rows on
+    (kernels_gemmr.hip); airfe_tuning::desc_gather_stream = 0 keeps the tiled gemm8 kernel.  Same fragments, same K order, bias after the sum: every line of 8
+    images byte-equal — also with 8 persistent workgroups, where each streams 19 tiles through its 8-slot ring."""
+    import torch
+    imgs = torch.from_numpy(_images(8, 21)).cuda()
+    outs = []
+    for tun in ({"desc_gather_stream": 1, "gemmr_wgs": wgs}, {"desc_gather_stream": 0}):
+        ctx = api.Context(superpoint=weights.synthetic_plnet_s0(1234), plnet_s1=os.path.join(GOLDEN, "plnet_s1.airfe"), max_batch=8, enc_chunk=4, tuning=tun, check_launches=1)
+        o = _buffers(torch, 8, 0)
+        ctx.detect_plnet_batch_dev(imgs, o["feat"], o["n"], o["lines"], o["nlines"], None, None, o["found"])
+        ctx.sync()
+        outs.append({k: o[k].cpu().numpy().copy() for k in ("feat", "n", "lines", "nlines", "found")})
+        ctx.close()
+    assert outs[0]["nlines"].min() >= 100
+    for k in outs[0]:
+        np.testing.assert_array_equal(outs[0][k], outs[1][k])
+
+
 def test_plnet_batch_reports_overflow_and_is_deterministic():
     import torch
     ctx = _ctx()
