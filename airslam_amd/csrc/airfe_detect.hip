@@ -77,7 +77,13 @@ int dense_desc_head(airfe_ctx* c, int B, hipStream_t st) {
   g.X1 = c->aDa; g.ld1 = 256; g.K1 = 256; g.Wp = c->cDb.w; g.bias = c->cDb.b;
   g.M = cells; g.N = 256; g.cb_total = c->cDb.cbt; g.epi = EPI_STORE_F32; g.out = c->desc; g.ldo = 256;
   g.small_max = c->gemm_small_max; g.g8_min = c->gemm8_min; g.gr_min = c->gemmr_min; g.gr_wgs = c->gemmr_wgs;
-  { ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024)); launch_gemm(c->prec, 256, false, g, st); }
+  {
+    ProfScope ps(c, ST_HEAD_GEMM, st, 2.0 * cells * 256 * 256, (double)cells * (512 + 1024));
+    // large batches (round 6): 512 B in and 1 KB of fp32 out per cell is HBM work — the tiled kernel ran it at 1.8 TB/s (225 us per 64 images); the streaming kernel's
+    // identity-index form (kernels_gemmr.hip) has the same fragments, K order and bias placement: the same bits
+    if (c->desc_gather_stream && cells >= c->gemmr_min && gemmr_gather_applicable(256, g)) launch_gemmr_gather(c->prec, g, st);
+    else launch_gemm(c->prec, 256, false, g, st);
+  }
   // F.normalize of the dense map is applied lazily: sample_desc_kernel normalises just the 4 taps each keypoint reads
   // (same operations, same bits) — a dense pass moved 8 MB/image to serve 400 x 4 cell reads.
   c->desc_normalised = false;

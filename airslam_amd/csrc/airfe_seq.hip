@@ -315,6 +315,9 @@ int airfe_seq_create(airfe_ctx* kf, airfe_ctx* nf, int S, const airfe_seq_policy
   SEQ_HIP(s, hipHostMalloc(reinterpret_cast<void**>(&s->jobs_h), (size_t)s->job_slots * s->job_cap * sizeof(SeqJob), hipHostMallocMapped | hipHostMallocCoherent));
   SEQ_HIP(s, hipHostGetDevicePointer(reinterpret_cast<void**>(&s->jobs_d), s->jobs_h, 0));
   s->jl.reserve(s->job_cap);
+  // seq_dalloc clears its blocks with hipMemset on the NULL stream; the driver's streams are non-blocking (they do not order against it): nothing of the driver
+  // may run before those clears have finished
+  SEQ_HIP(s, hipDeviceSynchronize());
   *out = g.release();
   return 0;
 } SEQ_CATCH(nullptr)
@@ -348,6 +351,7 @@ int airfe_seq_begin(airfe_seq* s, const uint8_t* d_left, const uint8_t* d_right,
     s->imgL = seq_dalloc<uint8_t>(s, (size_t)2 * S * ibytes);
     s->imgR = seq_dalloc<uint8_t>(s, (size_t)2 * S * ibytes);
     if (!s->imgL || !s->imgR) return sfail(s, "airfe_seq_begin: device allocation failed (images)");
+    SEQ_HIP(s, hipDeviceSynchronize());      // (the blocks' clears ran on the NULL stream: see airfe_seq_create — a gather queued now must not be overtaken by them)
     s->img_cap = ibytes;
   }
   s->h = h; s->w = w; s->stride = stride; s->img_stride = img_stride; s->R_step = d_right;

@@ -73,8 +73,11 @@ __device__ __forceinline__ void gemmr_body(const GemmArgs& a, char* smem, int gr
   }
   // GATHER: the source rows of every tile this workgroup will stream, [n][32] behind the ring
   [[maybe_unused]] int* idx_lds = reinterpret_cast<int*>(smem + GR_SLOTS * GR_SLOT);
-  if constexpr (GATHER) {
-    for (int e = tid; e < n * GR_TT; e += 512) idx_lds[e] = a.rowidx[(size_t)(first + (e >> 5) * per_group) * GR_TT + (e & 31)];
+  if constexpr (GATHER) {       // (a.rowidx == nullptr: the identity — every row in order, fp32 rows out: the DENSE descriptor head of the junction images)
+    for (int e = tid; e < n * GR_TT; e += 512) {
+      const int r = (first + (e >> 5) * per_group) * GR_TT + (e & 31);
+      idx_lds[e] = a.rowidx ? a.rowidx[r] : r;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (GATHER) __syncthreads();
@@ -241,7 +244,7 @@ static void gemmr_launch_t(const GemmArgs& a, hipStream_t st) {
 
 // The gather form: y[r] = W x[rowidx[r]] + b as fp32 rows, K = N = 256 (the descriptor head over sampled cells).
 bool gemmr_gather_applicable(int K, const GemmArgs& a) {
-  return K == 256 && a.rowidx && !a.X2 && !a.rot_cos && a.act == ACT_NONE && a.cb_total == 4 && a.N == 256 && a.M % GR_TT == 0 && a.epi == EPI_STORE_F32 && a.ldo >= 256 &&
+  return K == 256 && !a.X2 && !a.rot_cos && a.act == ACT_NONE && a.cb_total == 4 && a.N == 256 && a.M % GR_TT == 0 && a.epi == EPI_STORE_F32 && a.ldo >= 256 &&
          a.ld1 % 8 == 0 && (a.M / GR_TT + std::max(a.gr_wgs, 1) - 1) / std::max(a.gr_wgs, 1) <= 240;      // (the busiest workgroup's index list fits behind the ring)
 }
 
