@@ -20,6 +20,20 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifdef ATT_TIMING   // per-phase shader-clock timers of every ACTIVE wave (tools/att_timing.py; a measurement build, never the shipped library).  s_memtime ticks =
+// shader cycles; each reading is consumed only after the tile's barrier, so that no s_waitcnt of its own sits between the phases it separates.
+__device__ unsigned long long att_dbg[32];
+extern "C" void airfe_dbg_att(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[32] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(att_dbg), z, sizeof(z)); }
+  else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(att_dbg), 32 * sizeof(unsigned long long));
+}
+#define ATT_NOW(v) { __builtin_amdgcn_sched_barrier(0); v = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#define ATT_ADD(i, d) { if (lane == 0) atomicAdd(&att_dbg[i], (unsigned long long)(d)); }
+#else
+#define ATT_NOW(v)
+#define ATT_ADD(i, d)
+#endif
+
 namespace airfe {
 
 
@@ -75,6 +89,10 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
                                                           const uint16_t* __restrict__ Vt, uint16_t* __restrict__ O,
                                                           const int* __restrict__ lens, int H, int Np, int cross, int nqb) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+#ifdef ATT_TIMING
+  unsigned long long t_start, t_a, t_b, t_c, t_d, t_e, t_f, t_g;
+  ATT_NOW(t_start)
+#endif
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: it forms the LDS address M0 carries for the DMA
   // XCD-aware workgroup -> (sequence, head, query block) map: the nqb query blocks of one (sequence, head) re-read its K and V,
@@ -141,7 +159,12 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
   const int krow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
   const int ksw = swz128(krow), fsw = swz128(l31);
 
+#ifdef ATT_TIMING
+  ATT_NOW(t_g)
+  if (active) { ATT_ADD(0, t_g - t_start) ATT_ADD(15, 1) }
+#endif
   for (int kt = 0; kt < nkv; ++kt) {
+    ATT_NOW(t_a)
     if (kt + 1 < nkv) dma_tile(kt + 1, (kt + 1) & 1);
     const char* kb = smem + (kt & 1) * 16384;
     const char* vb = kb + 8192;
@@ -252,14 +275,23 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
       // sub-tile's sixteen probabilities from where v_exp_f32 put them back into the loop's registers — 14 v_mov_b32 per tile on a kernel that is bound by its
       // issue slots.  The rare second round is now a second copy of the code.
       scores();
+#ifdef ATT_TIMING
+      ATT_NOW(t_b)                                       // K fragments read, QK^T chains issued
+      { float w_; asm volatile("v_mov_b32 %0, %1" : "=v"(w_) : "v"(two ? st1[15] : st0[15])); asm volatile("" :: "v"(w_)); }
+      ATT_NOW(t_c)                                       // ... and complete (the move waits for the last accumulator)
+#endif
       if (kt == 0) recentre_tile();                      // the first tile fixes the shift from its explicit row maximum
       exps();
       if (kt != 0 && __any(!(ps0 + ps1 <= ATT_PSUM_MAX))) {               // (the negated compare also catches inf / NaN sums)
         scores();
         recentre_tile();
         exps();
+#ifdef ATT_TIMING
+        ATT_ADD(14, 1)
+#endif
       }
 #endif
+      ATT_NOW(t_d)                                       // probabilities + partial row sums
       l_i += ps0 + ps1;
       typename P::vec8 pf[4];
 #pragma unroll
@@ -305,8 +337,16 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
         }
       }
     }
+    ATT_NOW(t_e)                                         // P packed, V fragments read, PV chains issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of tile kt + 1 have landed ...
+    ATT_NOW(t_f)
     __syncthreads();                                     // ... and so have everyone else's; buffer kt & 1 is free again
+#ifdef ATT_TIMING
+    ATT_NOW(t_g)
+    if (active) {
+      ATT_ADD(1, t_b - t_a) ATT_ADD(2, t_c - t_b) ATT_ADD(3, t_d - t_c) ATT_ADD(4, t_e - t_d) ATT_ADD(5, t_f - t_e) ATT_ADD(6, t_g - t_f) ATT_ADD(13, 1)
+    }
+#endif
   }
 
   if (!active) return;
@@ -330,6 +370,11 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
       if (q < Np) *reinterpret_cast<uint4*>(orow + dt * 32 + (hh ? go : ge) * 8) = v;
     }
   }
+#ifdef ATT_TIMING
+  ATT_NOW(t_a)
+  ATT_ADD(7, t_a - t_g)
+  ATT_ADD(8, t_a - t_start)
+#endif
 }
 
 void launch_attention32(int prec, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, uint16_t* O, const int* lens,

@@ -35,6 +35,16 @@ extern "C" void airfe_dbg_lf(unsigned long long* out, int reset) {
 #else
 #define LF_T(i)
 #endif
+#ifdef LF_TIMING2   // one level below LF_TIMING (tools/lf_timing2.py; a measurement build): inside the K loop of ONE GEMM of a pass — ffn.0's x half, 4 slabs of 64-feature
+// tiles — the shader-clock time of every wave between: trip start | weight prefetch issued | this trip's weights landed (vmcnt) | per 4-tile group: B fragments requested
+// (ds_read_b128) | landed (lgkmcnt(0)) | MFMAs issued | register moves.  The two forced waits replace the compiler's counted ones (a measurement build).
+__device__ unsigned long long lf2_dbg[16];
+extern "C" void airfe_dbg_lf2(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(lf2_dbg), z, sizeof(z)); }
+  else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lf2_dbg), 16 * sizeof(unsigned long long));
+}
+#define LF2_NOW(v) { __builtin_amdgcn_sched_barrier(0); v = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#endif
 
 namespace airfe {
 
@@ -160,7 +170,7 @@ struct LfNoHook { __device__ __forceinline__ void operator()(int) const {} };
 // two-slab form of this loop for the 112-token passes, 114.9 / 116.6 us against 114.5 / 114.3, profiles/r05_probe_blockf_depth2.txt.  Nor do the `cur = nxt`
 // register moves that end a trip cost anything measurable: two steps per trip with the fragment sets changing roles — VALU : MFMA inside the loops 0.25 instead
 // of 0.6-0.9 — ran 121.6 / 121.3 us against 118.3 / 123.0 on one box, same file.)
-template <class P, int NT, int NMT, class Hook = LfNoHook, bool SWAP = false>
+template <class P, int NT, int NMT, class Hook = LfNoHook, bool SWAP = false, bool TIMED = false>
 __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (&cur)[NT][2], const char* w0, const char* w1, int nslab,
                                        const char* n0, const char* n1, const char* breg, int pitch, int l15, int g, Hook hook = Hook()) {
   const char* brow = breg + l15 * pitch;
@@ -216,8 +226,15 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
     return;
   }
   typename P::vec8 nxt[NT][2];
+#ifdef LF_TIMING2
+  [[maybe_unused]] unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0;
+  [[maybe_unused]] unsigned long long a_pref = 0, a_vm = 0, a_rd = 0, a_lgkm = 0, a_mma = 0, a_mov = 0, a_trips = 0;
+#endif
 #pragma unroll 1
   for (int s = 0; s < nslab; ++s) {
+#ifdef LF_TIMING2
+    if constexpr (TIMED) LF2_NOW(q0)
+#endif
     const bool last = s + 1 == nslab;
     const char* p0 = last ? n0 : w0 + (s + 1) * SLAB_BYTES;
     const char* p1 = last ? n1 : w1 + (s + 1) * SLAB_BYTES;
@@ -228,15 +245,33 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
     }
     hook(s);                                // vector-memory work that must queue BEHIND this trip's prefetch (vmcnt retires in order)
     __builtin_amdgcn_sched_barrier(0);      // keep the whole prefetch at the top of the trip (hipcc sinks loads towards their use)
+#ifdef LF_TIMING2
+    if constexpr (TIMED) {
+      LF2_NOW(q1)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NT) : "memory");      // this trip's A fragments (requested one trip ago) have landed
+      LF2_NOW(q2)
+      a_pref += q1 - q0; a_vm += q2 - q1;
+    }
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int boff = (((s * 8 + h * 4 + g) ^ l15) << 4);
 #pragma unroll
       for (int mb = 0; mb < NMT; mb += 4) {
+#ifdef LF_TIMING2
+        if constexpr (TIMED) LF2_NOW(q3)
+#endif
         typename P::vec8 bf[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (mb + j < NMT) bf[j] = lds_frag<P>(brow, boff + (mb + j) * 16 * pitch);
+#ifdef LF_TIMING2
+        if constexpr (TIMED) {
+          LF2_NOW(q4)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          LF2_NOW(q5)
+        }
+#endif
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -245,6 +280,12 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
               if constexpr (SWAP) acc[t][mb + j] = P::mfma(bf[j], cur[t][h], acc[t][mb + j]);     // tokens x features: the transposed-V form
               else acc[t][mb + j] = P::mfma(cur[t][h], bf[j], acc[t][mb + j]);
             }
+#ifdef LF_TIMING2
+        if constexpr (TIMED) {
+          LF2_NOW(q6)
+          a_rd += q4 - q3; a_lgkm += q5 - q4; a_mma += q6 - q5;
+        }
+#endif
       }
     }
 #pragma unroll
@@ -252,7 +293,22 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
       cur[t][0] = nxt[t][0];
       cur[t][1] = nxt[t][1];
     }
+#ifdef LF_TIMING2
+    if constexpr (TIMED) {
+      LF2_NOW(q1)
+      a_mov += q1 - q6; a_trips += 1;
+    }
+#endif
   }
+#ifdef LF_TIMING2
+  if constexpr (TIMED) {
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&lf2_dbg[0], a_pref); atomicAdd(&lf2_dbg[1], a_vm); atomicAdd(&lf2_dbg[2], a_rd); atomicAdd(&lf2_dbg[3], a_lgkm); atomicAdd(&lf2_dbg[4], a_mma);
+      atomicAdd(&lf2_dbg[5], a_mov); atomicAdd(&lf2_dbg[6], a_trips); atomicAdd(&lf2_dbg[7], (unsigned long long)(2 * ((NMT + 3) / 4)) * a_trips);
+      atomicAdd(&lf2_dbg[8], (unsigned long long)(2 * NT * NMT) * a_trips);      // MFMAs issued
+    }
+  }
+#endif
 }
 
 struct LfLane {                       // per-lane constants of the whole kernel
@@ -343,7 +399,11 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
     __syncthreads();
     LF_T(3)
   }
+#ifdef LF_TIMING2
+  lf_mma<P, 4, NMT, LfNoHook, false, true>(h, c4, L.w1b + fo0, L.w1b + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R0, 512, l15, g);
+#else
   lf_mma<P, 4, NMT>(h, c4, L.w1b + fo0, L.w1b + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R0, 512, l15, g);
+#endif
 
   // LayerNorm scale / shift of this wave's 64 features: fetched now, used after the next barrier
   [[maybe_unused]] f32x4 gam[2][2], bet[2][2];

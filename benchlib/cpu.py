@@ -7,16 +7,17 @@ import numpy as np
 import torch
 
 
-def stereo(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=0.75, line_length_threshold=50.0, gpu_nmatch=None):
+def stereo(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=0.75, line_length_threshold=50.0, gpu_nmatch=None, sg=None, seed=1000):
     """The CPU oracle (PyTorch-CPU fp32 networks + numpy restatement of the reference's C++ post-processing) timed on
     the host cores, on a bounded sample of the same workload: `warm` untimed pairs, then the MEDIAN per-pair time of
     `n_pairs` pairs (median of >= 20 after 3 warm-ups).  s1 (the stage-1 weights) selects the PLNet step: one trunk
-    pass per image feeding the point heads AND the line branch, wireframe_matcher, stage 1, line filter, junctions on the left."""
+    pass per image feeding the point heads AND the line branch, wireframe_matcher, stage 1, line filter, junctions on the left.  sg (SuperGlue weights): the matcher
+    is SuperGlue (18 layers, 100 Sinkhorn iterations, decode at 0.2: BASELINE configs[4]) instead of LightGlue."""
     from airslam_amd import synth
     from oracle import margins, ref_chain, ref_nets, ref_post
     torch.set_num_threads(min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 32))   # more threads than this only adds sync overhead at batch 1
     # the SAME images rank 0 puts on the GPU (synth.stereo_batch(B, h, w, 1000)): its first n_pairs + warm pairs, ready before the clock
-    ls, rs = synth.stereo_batch(n_pairs + warm, h, w, 1000)
+    ls, rs = synth.stereo_batch(n_pairs + warm, h, w, seed)
     pairs = list(zip(ls, rs))
     times, nmatch, nfrag = [], [], []
     for i, (left, right) in enumerate(pairs):
@@ -33,7 +34,12 @@ def stereo(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=0.75, 
             feats.append(ref_chain.plnet_infer(sp, s1, img, want_junctions=side == 0, top_k=max_kp, line_threshold=line_threshold,
                                                line_length_threshold=line_length_threshold)["features"])
         k = 0
-        if feats[0].shape[0] and feats[1].shape[0]:
+        if sg is not None and feats[0].shape[0] and feats[1].shape[0]:
+            a = ref_post.normalize_keypoints(feats[0], w, h, 0.7)
+            b = ref_post.normalize_keypoints(feats[1], w, h, 0.7)
+            z = ref_nets.superglue_forward(sg, a[:, 1:3], a[:, 0], a[:, 3:], b[:, 1:3], b[:, 0], b[:, 3:])
+            k = int((ref_post.superglue_decode(z, 0.2)[0] >= 0).sum())
+        elif feats[0].shape[0] and feats[1].shape[0]:
             a = ref_post.normalize_keypoints(feats[0], w, h, 0.5)
             b = ref_post.normalize_keypoints(feats[1], w, h, 0.5)
             s = ref_nets.lightglue_forward(lg, a[:, 1:3], a[:, 3:], b[:, 1:3], b[:, 3:])
@@ -52,7 +58,7 @@ def stereo(sp, lg, h, w, n_pairs, max_kp, warm=3, s1=None, line_threshold=0.75, 
     return dict(value=1.0 / med, unit="pairs/s", cores=torch.get_num_threads(), kind="port", same_pairs_as_gpu=agree,
                 fragile_share_of_matches=(float(sum(nfrag)) / max(sum(nmatch), 1)) if nfrag else None,     # (tests gate 6 %: tests/test_gpu_stereo.py)
                 sample=f"median of {n_pairs} synthetic {w}x{h} stereo pairs after {warm} warm-ups ({sum(times):.1f} s), fp32 PyTorch-CPU "
-                       f"oracle + numpy post-processing ({'PLNet points + lines + junctions' if s1 is not None else 'SuperPoint'} + LightGlue), "
+                       f"oracle + numpy post-processing ({'PLNet points + lines + junctions' if s1 is not None else 'SuperPoint'} + {'SuperGlue' if sg is not None else 'LightGlue'}), "
                        f"{float(np.mean(nmatch)):.0f} matches per pair")
 
 

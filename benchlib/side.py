@@ -139,6 +139,11 @@ def run(args, rank, world, local, dev):
                 out["roofline"] = {"bound": "mfma", "mfma_util_counters": util, "mfma_util_source": usrc, "kernel": "all bracketed matrix stages of one step (algorithmic FLOPs / their event time)",
                                    "achieved": ach, "peak": cm.PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / cm.PEAK_MFMA_TFLOPS, "traffic": None,
                                    "step_frac": fl_tot / (ms_step * 1e-3) / 1e12 / cm.PEAK_MFMA_TFLOPS, "step_gflop": fl_tot / 1e9, "counters_age": {"mfma_util": page}}
+        if world == 1 and args.cpu_pairs > 0 and args.workload == "stereo" and not args.plnet_host:
+            from . import cpu
+            gm = (i0 >= 0).sum(1).cpu().numpy() if sg else nm.cpu().numpy()
+            out["cpu_baseline"] = cpu.stereo(weights.synthetic_superpoint(1234), None if sg else mw, H, W, min(args.cpu_pairs, 6), K, warm=1, sg=mw if sg else None,
+                                             gpu_nmatch=gm, seed=1000 + rank)
         print(json.dumps(out))
     ctx.close()
     if world > 1:

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Measurement builds of libairfe.so (never shipped; *.so.tmp is git-ignored but travels with gpurun):
+#   airslam_amd/libairfe_T.so.tmp    -DLF_TIMING    per-phase timers of the LightGlue block   (tools/lf_timing.py)
+#   airslam_amd/libairfe_T2.so.tmp   -DLF_TIMING2   inside the K loop of the block's ffn.0    (tools/lf_timing2.py)
+#   airslam_amd/libairfe_AT.so.tmp   -DATT_TIMING   per-phase timers of attention32_kernel    (tools/att_timing.py)
+set -e
+cd "$(dirname "$0")/.."
+python -m airslam_amd.build > /dev/null
+B=airslam_amd/csrc/build
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+others() { ls $B/*.o | grep -v "/$1.o"; }
+hipcc $FL -DLF_TIMING -c airslam_amd/csrc/kernels_lgblockf.hip -o /tmp/lf_T.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_T.so.tmp /tmp/lf_T.o $(others kernels_lgblockf)
+hipcc $FL -DLF_TIMING2 -c airslam_amd/csrc/kernels_lgblockf.hip -o /tmp/lf_T2.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_T2.so.tmp /tmp/lf_T2.o $(others kernels_lgblockf)
+hipcc $FL -DATT_TIMING -c airslam_amd/csrc/kernels_attn.hip -o /tmp/att_T.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_AT.so.tmp /tmp/att_T.o $(others kernels_attn)
+ls -la airslam_amd/*.so.tmp
