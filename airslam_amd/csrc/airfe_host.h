@@ -42,7 +42,7 @@ typedef std::map<std::string, Tensor> Pack;
 constexpr float ATT_QK_FOLD = 0.42466090014400953f;
 
 struct ConvW { uint16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; };
-struct LinW { uint16_t* w = nullptr; float* b = nullptr; int K = 0, N = 0, cbt = 0; };
+struct LinW { uint16_t* w = nullptr; float* b = nullptr; int K = 0, N = 0, cbt = 0; uint16_t* wf = nullptr; /* the same weights in MFMA fragment order (make_linear) */ };
 struct LgLayer {
   LinW qk, v, out, ffn0, ffn3, cqk, cv, cout, cffn0, cffn3;
   float *ln_g = nullptr, *ln_b = nullptr, *cln_g = nullptr, *cln_b = nullptr;

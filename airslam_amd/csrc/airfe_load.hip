@@ -149,7 +149,25 @@ bool make_linear(airfe_ctx* c, const float* W, const float* bias, int K, int N, 
   out.K = Kp;
   out.N = N;
   out.cbt = cbt;
-  return out.w && out.b;
+  // the same bytes in FRAGMENT order for kernels that load A fragments straight from global memory (kernels_lgblockf.hip): [16-row tile T][slab s][32-wide half h]
+  // [lane = g * 16 + l15][16 B] — a wave's load is 1 KB in a row instead of 16 bytes out of each of 16 lines (the slab image is laid out for LDS)
+  {
+    const int NS = Kp / 64;
+    std::vector<uint16_t> fr(slabs.size());
+    for (int T = 0; T < cbp * 4; ++T)
+      for (int sl = 0; sl < NS; ++sl) {
+        const uint16_t* slab = slabs.data() + ((size_t)(T >> 2) * NS + sl) * (SLAB_BYTES / 2);
+        for (int h = 0; h < 2; ++h)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int l15 = lane & 15, g = lane >> 4, rr = (T & 3) * 16 + l15;
+            const int byte = rr * 128 + (((h * 4 + g) ^ ((rr >> 1) & 7)) << 4);
+            uint16_t* dst = fr.data() + (((size_t)T * NS + sl) * 2 + h) * 512 + (size_t)lane * 8;
+            for (int e = 0; e < 8; ++e) dst[e] = slab[(byte >> 1) + e];
+          }
+      }
+    out.wf = dupload(c, fr);
+  }
+  return out.w && out.b && out.wf;
 }
 
 bool make_linear_named(airfe_ctx* c, const Pack& p, const std::string& name, int K, int N, LinW& out, std::string& err,

@@ -129,7 +129,8 @@ int lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, con
                const LinW* nqk = nullptr, const LinW* nv = nullptr, bool rotary = false) {
   LgBlockFArgs a;
   a.relu = relu;
-  a.attn = c->ob; a.xb = c->xb; a.x32 = c->x32; a.wo = out.w; a.w1 = f0.w; a.w2 = f3.w;
+  const bool fr = lg_blockf_frag_weights();                   // the block kernel reads its A fragments from global memory: weights in fragment order (LinW::wf)
+  a.attn = c->ob; a.xb = c->xb; a.x32 = c->x32; a.wo = fr ? out.wf : out.w; a.w1 = fr ? f0.wf : f0.w; a.w2 = fr ? f3.wf : f3.w;
   a.bo = out.b; a.b1 = f0.b; a.gamma = g; a.beta = b; a.b2 = f3.b; a.M = M;
   if (c->fold_out) { a.wo = nullptr; a.bo = nullptr; }       // the out-projection lives inside f0 (airfe_load.hip, make_ffn0_folded): the kernel's ffn.0 reads cat(x, attn)
   // one workgroup per CU and pass: ceil(M / T) workgroups run in rounds of 256, a round lasts ~T — take the T with the smaller product
@@ -144,7 +145,7 @@ int lg_blockf(airfe_ctx* c, const LinW& out, const LinW& f0, const float* g, con
   // (algorithmic = what this context's packed network asks for: with the out-projection folded into ffn.0 its 2 * 256 * 256 FLOPs per token do not exist)
   double fl = 2.0 * M * ((c->fold_out ? 0.0 : 256.0 * 256) + 512.0 * 512 + 512.0 * 256), by = (double)M * (512 + 512 + 1024 + 512 + 1024) + (c->fold_out ? 786432.0 : 917504.0);
   if (nqk && nv) {            // the next attention layer's projections ride along (kernels_lgblockf.hip, FOLD)
-    a.nqk_w = nqk->w; a.nqk_b = nqk->b; a.nqk_n = nqk->N; a.nv_w = nv->w; a.nv_b = nv->b;
+    a.nqk_w = fr ? nqk->wf : nqk->w; a.nqk_b = nqk->b; a.nqk_n = nqk->N; a.nv_w = fr ? nv->wf : nv->w; a.nv_b = nv->b;
     a.rot_cos = rotary ? c->rot_cos : nullptr; a.rot_sin = rotary ? c->rot_sin : nullptr;
     a.q_out = c->qb; a.k_out = c->kb; a.vt_out = c->vtb; a.Np = c->Np; a.H = 4;
     fl += 2.0 * M * 256.0 * (nqk->N + nv->N);

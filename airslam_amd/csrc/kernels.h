@@ -66,7 +66,7 @@ struct LgBlockFArgs {
   const uint16_t* attn;      // [M][256]
   uint16_t* xb;              // [M][256], updated in place
   float* x32;                // [M][256], updated in place
-  const uint16_t *wo, *w1, *w2;                    // LinW::w of out-proj (256->256), ffn.0 (512->512), ffn.3 (512->256); wo == nullptr: the out-projection is inside w1's message half (fold_out_proj) and `attn` is ffn.0's second operand
+  const uint16_t *wo, *w1, *w2;                    // LinW::wf (fragment order; LinW::w when !lg_blockf_frag_weights()) of out-proj (256->256), ffn.0 (512->512), ffn.3 (512->256); wo == nullptr: the out-projection is inside w1's message half (fold_out_proj) and `attn` is ffn.0's second operand
   const float *bo, *b1, *gamma, *beta, *b2;
   int M;                     // tokens, multiple of 128
   int tokens_per_wg = 128;   // 128 or 112 (see launch_lg_blockf)
@@ -81,6 +81,7 @@ struct LgBlockFArgs {
   uint16_t *q_out = nullptr, *k_out = nullptr, *vt_out = nullptr;
 };
 void launch_lg_blockf(int prec, const LgBlockFArgs& a, hipStream_t st);
+bool lg_blockf_frag_weights();     // true: wo / w1 / w2 / nqk_w / nv_w are LinW::wf (fragment order), false: LinW::w (slab image)
 
 struct ConvArgs {
   const uint16_t* X = nullptr;  // [B][H+2][W+2][CIN], zero border

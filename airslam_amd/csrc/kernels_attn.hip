@@ -28,7 +28,7 @@ extern "C" void airfe_dbg_att(unsigned long long* out, int reset) {
   else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(att_dbg), 32 * sizeof(unsigned long long));
 }
 #define ATT_NOW(v) { __builtin_amdgcn_sched_barrier(0); v = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-#define ATT_ADD(i, d) { if (lane == 0) atomicAdd(&att_dbg[i], (unsigned long long)(d)); }
+#define ATT_ADD(i, d) { if (lane == 0) atomicAdd(&att_dbg[i], (unsigned long long)(d)); }      // (only behind the tile loop: an atomic per tile is vector-memory work the loop's own vmcnt waits would see)
 #else
 #define ATT_NOW(v)
 #define ATT_ADD(i, d)
@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
                                                           const int* __restrict__ lens, int H, int Np, int cross, int nqb) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
 #ifdef ATT_TIMING
-  unsigned long long t_start, t_a, t_b, t_c, t_d, t_e, t_f, t_g;
+  unsigned long long t_start, t_a, t_b, t_c, t_d, t_e, t_f, t_g, t_pro;
+  unsigned long long s_b = 0, s_c = 0, s_d = 0, s_e = 0, s_f = 0, s_g = 0, s_tiles = 0, s_retry = 0;
   ATT_NOW(t_start)
 #endif
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
 
 #ifdef ATT_TIMING
   ATT_NOW(t_g)
-  if (active) { ATT_ADD(0, t_g - t_start) ATT_ADD(15, 1) }
+  t_pro = t_g;
 #endif
   for (int kt = 0; kt < nkv; ++kt) {
     ATT_NOW(t_a)
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
         recentre_tile();
         exps();
 #ifdef ATT_TIMING
-        ATT_ADD(14, 1)
+        s_retry += 1;
 #endif
       }
 #endif
@@ -343,9 +344,7 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
     __syncthreads();                                     // ... and so have everyone else's; buffer kt & 1 is free again
 #ifdef ATT_TIMING
     ATT_NOW(t_g)
-    if (active) {
-      ATT_ADD(1, t_b - t_a) ATT_ADD(2, t_c - t_b) ATT_ADD(3, t_d - t_c) ATT_ADD(4, t_e - t_d) ATT_ADD(5, t_f - t_e) ATT_ADD(6, t_g - t_f) ATT_ADD(13, 1)
-    }
+    if (active) { s_b += t_b - t_a; s_c += t_c - t_b; s_d += t_d - t_c; s_e += t_e - t_d; s_f += t_f - t_e; s_g += t_g - t_f; s_tiles += 1; }
 #endif
   }
 
@@ -372,6 +371,8 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
   }
 #ifdef ATT_TIMING
   ATT_NOW(t_a)
+  ATT_ADD(0, t_pro - t_start) ATT_ADD(15, 1)
+  ATT_ADD(1, s_b) ATT_ADD(2, s_c) ATT_ADD(3, s_d) ATT_ADD(4, s_e) ATT_ADD(5, s_f) ATT_ADD(6, s_g) ATT_ADD(13, s_tiles) ATT_ADD(14, s_retry)
   ATT_ADD(7, t_a - t_g)
   ATT_ADD(8, t_a - t_start)
 #endif

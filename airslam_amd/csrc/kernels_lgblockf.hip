@@ -51,6 +51,23 @@ namespace airfe {
 constexpr int LF_R0 = 0, LF_R1 = 65536, LF_ST = 131072;
 constexpr int LF_LDS = LF_ST + 8 * 128 * 8;
 
+// WEIGHT LAYOUT (round 6).  The A fragments come straight from global memory: one 16-byte load per lane, tile and 32-wide K half.  In the packed SLAB image
+// (LinW::w: [64 rows][64 k], 128-byte rows, swizzled — the image the LDS-staged kernels want) lane (l15, g) of such a load reads row l15, 16-byte piece g: the 16
+// lanes of a quarter-wave touch 16 DIFFERENT 128-byte lines, 16 bytes of each, and the four quarter-waves touch the same 16 lines again — 64 tag look-ups for 1 KB.
+// The timers inside the K loop (LF_TIMING2, profiles/r06_att_blockf.txt) put 72 % of a trip into ISSUING its eight loads: ~67 cycles per load, the vector
+// memory path of the CU saturated by look-ups, not by bytes.  LinW::wf is the same bytes in FRAGMENT order — [16-row tile T][slab s][half h][lane][16 B]:
+// a wave's load is 1 KB in a row, eight whole lines.  LF_FRAG = 0 keeps the slab image (A/B builds).
+#ifndef LF_FRAG
+#define LF_FRAG 1
+#endif
+constexpr int LF_SS = LF_FRAG ? 2048 : SLAB_BYTES;                               // bytes from a tile's slab s to its slab s + 1
+constexpr int lf_ts(int K) { return LF_FRAG ? (K / 64) * 2048 : 2048; }         // bytes from tile T to tile T + 1 of a linear with K inputs
+constexpr int LF_TS256 = lf_ts(256), LF_TS512 = lf_ts(512);
+// byte offset of (64-feature block cb, tile t0 of it, slab 0) in the weights of a linear with K inputs
+__device__ __forceinline__ size_t lf_woff(int K, int cb, int t0) {
+  return LF_FRAG ? (size_t)(cb * 4 + t0) * (K / 64) * 2048 : (size_t)cb * (K / 64) * SLAB_BYTES + (size_t)t0 * 2048;
+}
+
 __device__ __forceinline__ void lf_glds16(const void* gsrc, unsigned lds_off) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -146,12 +163,12 @@ __device__ __forceinline__ typename P::vec8 lf_ldg(const char* p) {
 
 // The first slab's A fragments of a GEMM: issued ahead of the phase that precedes it (barrier, pack, GELU), so that a GEMM
 // never starts by waiting one L2 round trip.
-template <class P, int NT>
+template <class P, int NT, int TS>
 __device__ __forceinline__ void lf_first(typename P::vec8 (&cur)[NT][2], const char* w0, const char* w1) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    cur[t][0] = lf_ldg<P>(w0 + t * 2048);
-    cur[t][1] = lf_ldg<P>(w1 + t * 2048);
+    cur[t][0] = lf_ldg<P>(w0 + t * TS);
+    cur[t][1] = lf_ldg<P>(w1 + t * TS);
   }
 }
 
@@ -170,7 +187,8 @@ struct LfNoHook { __device__ __forceinline__ void operator()(int) const {} };
 // two-slab form of this loop for the 112-token passes, 114.9 / 116.6 us against 114.5 / 114.3, profiles/r05_probe_blockf_depth2.txt.  Nor do the `cur = nxt`
 // register moves that end a trip cost anything measurable: two steps per trip with the fragment sets changing roles — VALU : MFMA inside the loops 0.25 instead
 // of 0.6-0.9 — ran 121.6 / 121.3 us against 118.3 / 123.0 on one box, same file.)
-template <class P, int NT, int NMT, class Hook = LfNoHook, bool SWAP = false, bool TIMED = false>
+// TS / TSN: tile stride of this linear's weights / of the linear whose first slab is prefetched during the last trip (n0 / n1).
+template <class P, int NT, int NMT, int TS, int TSN, class Hook = LfNoHook, bool SWAP = false, bool TIMED = false>
 __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (&cur)[NT][2], const char* w0, const char* w1, int nslab,
                                        const char* n0, const char* n1, const char* breg, int pitch, int l15, int g, Hook hook = Hook()) {
   const char* brow = breg + l15 * pitch;
@@ -182,12 +200,13 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
     // at the back edge: r04 probe 1 measured no gain from that form), then consumed in order.  Same MFMAs in the same order: bit-identical.
     typename P::vec8 ring[8][NT][2];
     auto fetch = [&](int k, typename P::vec8 (&dst)[NT][2]) {
-      const char* p0 = k == nslab ? n0 : w0 + k * SLAB_BYTES;
-      const char* p1 = k == nslab ? n1 : w1 + k * SLAB_BYTES;
+      const char* p0 = k == nslab ? n0 : w0 + k * LF_SS;
+      const char* p1 = k == nslab ? n1 : w1 + k * LF_SS;
+      const int ts = k == nslab ? TSN : TS;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        dst[t][0] = lf_ldg<P>(p0 + t * 2048);
-        dst[t][1] = lf_ldg<P>(p1 + t * 2048);
+        dst[t][0] = lf_ldg<P>(p0 + t * ts);
+        dst[t][1] = lf_ldg<P>(p1 + t * ts);
       }
     };
     constexpr int AHEAD = (NT == 4 ? 4 : 8) / (NMT > 2 ? 2 : 1);   // 32-token tiles: 4 slabs of the 64-feature GEMM (128 registers) / all 8 of a 32-feature one in flight; 64-token tiles: half (registers)
@@ -236,12 +255,21 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
     if constexpr (TIMED) LF2_NOW(q0)
 #endif
     const bool last = s + 1 == nslab;
-    const char* p0 = last ? n0 : w0 + (s + 1) * SLAB_BYTES;
-    const char* p1 = last ? n1 : w1 + (s + 1) * SLAB_BYTES;
+    const char* p0 = last ? n0 : w0 + (s + 1) * LF_SS;
+    const char* p1 = last ? n1 : w1 + (s + 1) * LF_SS;
+    if constexpr (TS == TSN) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      nxt[t][0] = lf_ldg<P>(p0 + t * 2048);
-      nxt[t][1] = lf_ldg<P>(p1 + t * 2048);
+      for (int t = 0; t < NT; ++t) {
+        nxt[t][0] = lf_ldg<P>(p0 + t * TS);
+        nxt[t][1] = lf_ldg<P>(p1 + t * TS);
+      }
+    } else {
+      const int ts = last ? TSN : TS;                      // (wave-uniform)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        nxt[t][0] = lf_ldg<P>(p0 + t * ts);
+        nxt[t][1] = lf_ldg<P>(p1 + t * ts);
+      }
     }
     hook(s);                                // vector-memory work that must queue BEHIND this trip's prefetch (vmcnt retires in order)
     __builtin_amdgcn_sched_barrier(0);      // keep the whole prefetch at the top of the trip (hipcc sinks loads towards their use)
@@ -342,9 +370,9 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   [[maybe_unused]] f32x4 bo2[2];
   f32x4 b14[4];                                                   // biases of the first two GEMMs: fetched with the attn tile
   if constexpr (FOLDO) {
-    lf_first<P, 4>(c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1);
+    lf_first<P, 4, LF_TS512>(c4, L.w1b + 4 * LF_SS + fo0, L.w1b + 4 * LF_SS + fo1);
   } else {
-    lf_first<P, 2>(c2, L.wob + fo0, L.wob + fo1);
+    lf_first<P, 2, LF_TS256>(c2, L.wob + fo0, L.wob + fo1);
 #pragma unroll
     for (int u = 0; u < 2; ++u) bo2[u] = *reinterpret_cast<const f32x4*>(a.bo + cb * 64 + tp * 32 + g * 8 + u * 4);
   }
@@ -362,8 +390,8 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int m = 0; m < NMT; ++m) acc[u][m] = bo2[u];
-    lf_mma<P, 2, NMT>(acc, c2, L.wob + fo0, L.wob + fo1, 4, L.wob + fo0, L.wob + fo1, smem + LF_R0, 512, l15, g);
-    lf_first<P, 4>(c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1);  // lands while msg is packed and the barrier drains
+    lf_mma<P, 2, NMT, LF_TS256, LF_TS256>(acc, c2, L.wob + fo0, L.wob + fo1, 4, L.wob + fo0, L.wob + fo1, smem + LF_R0, 512, l15, g);
+    lf_first<P, 4, LF_TS512>(c4, L.w1b + 4 * LF_SS + fo0, L.w1b + 4 * LF_SS + fo1);  // lands while msg is packed and the barrier drains
     const int piece = cb * 8 + tp * 4 + g;
 #pragma unroll
     for (int m = 0; m < NMT; ++m) {
@@ -388,21 +416,22 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
 #pragma unroll
     for (int m = 0; m < NMT; ++m) h[t][m] = b14[t];
   if constexpr (FOLDO) {                                          // the attention half (R1 holds the attn tile itself); the x tile landed with it
-    lf_mma<P, 4, NMT>(h, c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R1, 512, l15, g);
+    lf_mma<P, 4, NMT, LF_TS512, LF_TS512>(h, c4, L.w1b + 4 * LF_SS + fo0, L.w1b + 4 * LF_SS + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R1, 512, l15, g);
     LF_T(2)
     LF_T(3)
   } else {
-    lf_mma<P, 4, NMT>(h, c4, L.w1b + 4 * SLAB_BYTES + fo0, L.w1b + 4 * SLAB_BYTES + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R1, 512, l15, g,
-                      [&](int s) { if (s == 3) lf_stage_rows(a.xb, row0, NMT, LF_R0, wave, lane); });
+    auto xhook = [&](int s) { if (s == 3) lf_stage_rows(a.xb, row0, NMT, LF_R0, wave, lane); };
+    lf_mma<P, 4, NMT, LF_TS512, LF_TS512, decltype(xhook)>(h, c4, L.w1b + 4 * LF_SS + fo0, L.w1b + 4 * LF_SS + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R1, 512, l15, g,
+                                                             xhook);
     LF_T(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     LF_T(3)
   }
 #ifdef LF_TIMING2
-  lf_mma<P, 4, NMT, LfNoHook, false, true>(h, c4, L.w1b + fo0, L.w1b + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R0, 512, l15, g);
+  lf_mma<P, 4, NMT, LF_TS512, LF_TS512, LfNoHook, false, true>(h, c4, L.w1b + fo0, L.w1b + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R0, 512, l15, g);
 #else
-  lf_mma<P, 4, NMT>(h, c4, L.w1b + fo0, L.w1b + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R0, 512, l15, g);
+  lf_mma<P, 4, NMT, LF_TS512, LF_TS512>(h, c4, L.w1b + fo0, L.w1b + fo1, 4, L.w1b + fo0, L.w1b + fo1, smem + LF_R0, 512, l15, g);
 #endif
 
   // LayerNorm scale / shift of this wave's 64 features: fetched now, used after the next barrier
@@ -443,7 +472,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
   float* xr0 = a.x32 + (size_t)(row0 + l15) * 256 + co;
   float4 r0[NMT], r1[NMT];
   constexpr bool EARLY_W2 = NMT < 8;                              // (128-token passes are a few registers short: they fetch them after the GELU)
-  if constexpr (EARLY_W2) lf_first<P, 2>(c2, L.w2b + fo0, L.w2b + fo1);
+  if constexpr (EARLY_W2) lf_first<P, 2, LF_TS512>(c2, L.w2b + fo0, L.w2b + fo1);
   f32x4 b22[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) b22[u] = *reinterpret_cast<const f32x4*>(a.b2 + co + u * 4);
@@ -522,7 +551,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
       }
     }
   }
-  if constexpr (!EARLY_W2) lf_first<P, 2>(c2, L.w2b + fo0, L.w2b + fo1);
+  if constexpr (!EARLY_W2) lf_first<P, 2, LF_TS512>(c2, L.w2b + fo0, L.w2b + fo1);
   LF_T(6)
   __syncthreads();
   LF_T(7)
@@ -536,8 +565,8 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int m = 0; m < NMT; ++m) acc[u][m] = b22[u];
-    const char* nq = FOLD ? reinterpret_cast<const char*>(a.nqk_w) + (size_t)cb * 4 * SLAB_BYTES + 2 * tp * 2048 : L.w2b;   // FOLD: first unit = q/k unit wf
-    lf_mma<P, 2, NMT>(acc, c2, L.w2b + fo0, L.w2b + fo1, 8, nq + fo0, nq + fo1, smem, 1024, l15, g);
+    const char* nq = FOLD ? reinterpret_cast<const char*>(a.nqk_w) + lf_woff(256, cb, 2 * tp) : L.w2b;   // FOLD: first unit = q/k unit wf
+    lf_mma<P, 2, NMT, LF_TS512, (FOLD ? LF_TS256 : LF_TS512)>(acc, c2, L.w2b + fo0, L.w2b + fo1, 8, nq + fo0, nq + fo1, smem, 1024, l15, g);
 #pragma unroll
     for (int m = 0; m < NMT; ++m) {
       const size_t row = (size_t)(row0 + m * 16 + l15);
@@ -569,12 +598,12 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
     const int H = a.H, Np = a.Np;
     // q / k units: 32 features each, (cb', tp') = (id >> 1, id & 1); this wave takes id = wf (and wf + 8 of the 512-feature q | k)
     constexpr int NQ = FOLD == 2 ? 2 : 1;
-    const char* vbase = reinterpret_cast<const char*>(a.nv_w) + (size_t)cb * 4 * SLAB_BYTES + 2 * tp * 2048;
+    const char* vbase = reinterpret_cast<const char*>(a.nv_w) + lf_woff(256, cb, 2 * tp);
 #pragma unroll
     for (int qu = 0; qu < NQ; ++qu) {
       const int cbq = cb + 4 * qu;
-      const char* wq = reinterpret_cast<const char*>(a.nqk_w) + (size_t)cbq * 4 * SLAB_BYTES + 2 * tp * 2048;
-      const char* nx = (qu + 1 < NQ) ? reinterpret_cast<const char*>(a.nqk_w) + (size_t)(cbq + 4) * 4 * SLAB_BYTES + 2 * tp * 2048 : vbase;
+      const char* wq = reinterpret_cast<const char*>(a.nqk_w) + lf_woff(256, cbq, 2 * tp);
+      const char* nx = (qu + 1 < NQ) ? reinterpret_cast<const char*>(a.nqk_w) + lf_woff(256, cbq + 4, 2 * tp) : vbase;
       const int cq = cbq * 64 + tp * 32 + g * 8;                  // this lane's 8 features of the projection
       f32x4 bq[2];
 #pragma unroll
@@ -584,7 +613,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int m = 0; m < NMT; ++m) acc[u][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      lf_mma<P, 2, NMT>(acc, c2, wq + fo0, wq + fo1, 4, nx + fo0, nx + fo1, smem + LF_R0, 512, l15, g);
+      lf_mma<P, 2, NMT, LF_TS256, LF_TS256>(acc, c2, wq + fo0, wq + fo1, 4, nx + fo0, nx + fo1, smem + LF_R0, 512, l15, g);
       const int sel = cq >> 8, hh = (cq & 255) >> 6, d = cq & 63;
       uint16_t* ob = sel ? a.k_out : a.q_out;
 #pragma unroll
@@ -618,7 +647,7 @@ __device__ __forceinline__ void lf_pass(const LgBlockFArgs& a, char* smem, const
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int m = 0; m < NMT; ++m) acc[u][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      lf_mma<P, 2, NMT, LfNoHook, true>(acc, c2, vbase + fo0, vbase + fo1, 4, vbase + fo0, vbase + fo1, smem + LF_R0, 512, l15, g);
+      lf_mma<P, 2, NMT, LF_TS256, LF_TS256, LfNoHook, true>(acc, c2, vbase + fo0, vbase + fo1, 4, vbase + fo0, vbase + fo1, smem + LF_R0, 512, l15, g);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int cv = cb * 64 + slab_row_to_feature((2 * tp + u) * 16 + l15);
@@ -642,17 +671,22 @@ __device__ __forceinline__ void lf_lane_init(const LgBlockFArgs& a, LfLane& L) {
   L.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   L.l15 = L.lane & 15;
   L.g = L.lane >> 4;
-  const int sw = (L.l15 >> 1) & 7;                                // swz128 of this lane's slab row (same for every tile)
-  L.fo0 = L.l15 * 128 + ((L.g ^ sw) << 4);
-  L.fo1 = L.l15 * 128 + (((4 + L.g) ^ sw) << 4);
+  if (LF_FRAG) {                                                  // fragment order: a lane's 16 bytes at lane * 16, the second 32-wide half 1 KB on
+    L.fo0 = L.lane * 16;
+    L.fo1 = L.lane * 16 + 1024;
+  } else {
+    const int sw = (L.l15 >> 1) & 7;                              // swz128 of this lane's slab row (same for every tile)
+    L.fo0 = L.l15 * 128 + ((L.g ^ sw) << 4);
+    L.fo1 = L.l15 * 128 + (((4 + L.g) ^ sw) << 4);
+  }
   // Which feature block a wave owns rotates with the workgroup (among the workgroups of one XCD: blockIdx / 8), so that the
   // 32 CUs of an XCD do not all ask its L2 for the same weight lines at the same moment.  Numerics do not depend on it.
   L.wf = (L.wave + (blockIdx.x >> 3)) & 7;
   L.cb = L.wf >> 1;                                               // 256-feature GEMMs: wave = 32 features (one tile pair)
   L.tp = L.wf & 1;
-  L.wob = reinterpret_cast<const char*>(a.wo) + (size_t)L.cb * 4 * SLAB_BYTES + 2 * L.tp * 2048;
-  L.w1b = reinterpret_cast<const char*>(a.w1) + (size_t)L.wf * 8 * SLAB_BYTES;
-  L.w2b = reinterpret_cast<const char*>(a.w2) + (size_t)L.cb * 8 * SLAB_BYTES + 2 * L.tp * 2048;
+  L.wob = reinterpret_cast<const char*>(a.wo) + lf_woff(256, L.cb, 2 * L.tp);
+  L.w1b = reinterpret_cast<const char*>(a.w1) + lf_woff(512, L.wf, 0);
+  L.w2b = reinterpret_cast<const char*>(a.w2) + lf_woff(512, L.cb, 2 * L.tp);
 }
 
 template <class P, int NMT, bool RELU, int FOLD, bool FOLDO>
@@ -743,6 +777,8 @@ static void launch_nmt(const LgBlockFArgs& a, hipStream_t st) {
     default: launch_f<P, 8, RELU, FOLD>(a, st); break;
   }
 }
+
+bool lg_blockf_frag_weights() { return LF_FRAG != 0; }
 
 void launch_lg_blockf(int prec, const LgBlockFArgs& a, hipStream_t st) {
   if (a.relu) {

@@ -3,6 +3,7 @@
 #   airslam_amd/libairfe_T.so.tmp    -DLF_TIMING    per-phase timers of the LightGlue block   (tools/lf_timing.py)
 #   airslam_amd/libairfe_T2.so.tmp   -DLF_TIMING2   inside the K loop of the block's ffn.0    (tools/lf_timing2.py)
 #   airslam_amd/libairfe_AT.so.tmp   -DATT_TIMING   per-phase timers of attention32_kernel    (tools/att_timing.py)
+#   airslam_amd/libairfe_F0.so.tmp   -DLF_FRAG=0    the block kernel on the slab image (A/B against the fragment-order weights: tools/gpu_ab_lib.sh)
 set -e
 cd "$(dirname "$0")/.."
 python -m airslam_amd.build > /dev/null
@@ -15,4 +16,7 @@ hipcc $FL -DLF_TIMING2 -c airslam_amd/csrc/kernels_lgblockf.hip -o /tmp/lf_T2.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_T2.so.tmp /tmp/lf_T2.o $(others kernels_lgblockf)
 hipcc $FL -DATT_TIMING -c airslam_amd/csrc/kernels_attn.hip -o /tmp/att_T.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_AT.so.tmp /tmp/att_T.o $(others kernels_attn)
+# A/B build: the block kernel reading the slab image (round 5's layout) instead of the fragment-order copy
+hipcc $FL -DLF_FRAG=0 -c airslam_amd/csrc/kernels_lgblockf.hip -o /tmp/lf_F0.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_F0.so.tmp /tmp/lf_F0.o $(others kernels_lgblockf)
 ls -la airslam_amd/*.so.tmp
