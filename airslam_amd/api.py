@@ -506,6 +506,20 @@ class Context:
         self._chk(self._l.airfe_bow_transform_dev(self._h, feat_t.data_ptr(), n, word_t.data_ptr(), weight_t.data_ptr(), self._stream(stream)),
                   "airfe_bow_transform_dev")
 
+    def copy_rows_plan(self, jobs):
+        """jobs: [(src tensor / pointer, dst tensor / pointer, count tensor (int32, one element) / pointer / None, row_bytes, cap rows)] -> a reusable plan for
+        copy_rows_dev (the five host arrays of airfe_copy_rows_dev, built once: the buffers of a pipeline do not move)"""
+        ptr = lambda x: 0 if x is None else (int(x) if isinstance(x, int) else x.data_ptr())
+        n = len(jobs)
+        return dict(n=n, src=np.array([ptr(j[0]) for j in jobs], np.uint64), dst=np.array([ptr(j[1]) for j in jobs], np.uint64),
+                    cnt=np.array([ptr(j[2]) for j in jobs], np.uint64), rb=np.array([j[3] for j in jobs], np.uint32), cap=np.array([j[4] for j in jobs], np.uint32),
+                    keep=jobs)
+
+    def copy_rows_dev(self, plan, stream=None):
+        """airfe_copy_rows_dev: the valid rows of every job of `plan` in one launch on `stream` (asynchronous)"""
+        self._chk(self._l.airfe_copy_rows_dev(self._h, plan["n"], plan["src"].ctypes.data, plan["dst"].ctypes.data, plan["cnt"].ctypes.data, plan["rb"].ctypes.data,
+                                              plan["cap"].ctypes.data, self._stream(stream)), "airfe_copy_rows_dev")
+
     def _stream(self, stream):
         # the ctx runs on its own non-blocking stream: order it after whatever torch queued on ITS streams
         if stream is None:

@@ -297,6 +297,7 @@ void airfe_destroy(airfe_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->sat_host) (void)hipHostFree(c->sat_host);
+  if (c->copy_ring) (void)hipHostFree(c->copy_ring);
   for (auto& m : c->marks) { (void)hipEventDestroy(m.a); (void)hipEventDestroy(m.b); }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -130,6 +130,9 @@ int sfail_noexcept(airfe_seq* s, const char* what, const char* detail) noexcept 
 #define SEQ_CATCH(s)                                                                       \
   catch (const std::exception& e_) { return sfail_noexcept((s), __func__, e_.what()); }    \
   catch (...) { return sfail_noexcept((s), __func__, nullptr); }
+#define AIRFE_CATCH(c)                                                                                 \
+  catch (const std::exception& e_) { return airfe_host::fail_noexcept((c), __func__, e_.what()); }    \
+  catch (...) { return airfe_host::fail_noexcept((c), __func__, nullptr); }
 #define SEQ_HIP(s, expr)                                                                   \
   do {                                                                                     \
     hipError_t e_ = (expr);                                                                \
@@ -220,6 +223,39 @@ void airfe_seq_default_policy(airfe_seq_policy* p) {
   if (!p) return;
   *p = airfe_seq_policy{90, 30, 80, 0.65f, 0.1f, 1.0, 200.0, 5.0, 752, 480};
 }
+
+// ---- the copy kernel on its own (include/airfe.h): valid rows of device buffers -> device or host-mapped memory, one launch
+int airfe_copy_rows_dev(airfe_ctx* c, int njobs, const void* const* src, void* const* dst, const int* const* cnt, const uint32_t* row_bytes, const uint32_t* cap,
+                        void* stream) try {
+  if (!c) return 1;
+  int d = -1;
+  if (!(hipGetDevice(&d) == hipSuccess && d == c->cfg.device) && hipSetDevice(c->cfg.device) != hipSuccess) return fail(c, "hipSetDevice(cfg.device) failed");
+  if (njobs < 0 || (njobs > 0 && (!src || !dst || !row_bytes || !cap))) return fail(c, "airfe_copy_rows_dev: bad argument");
+  if (njobs == 0) return 0;
+  constexpr int SLOTS = 8;
+  if (njobs > c->copy_ring_cap) {               // (grows by replacement; launches that still read the old ring are drained first)
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->copy_ring) (void)hipHostFree(c->copy_ring);
+    c->copy_ring = nullptr; c->copy_ring_cap = 0;
+    const int capn = std::max(njobs, 512);
+    HIPCHK(c, hipHostMalloc(&c->copy_ring, (size_t)SLOTS * capn * sizeof(SeqJob), hipHostMallocMapped | hipHostMallocCoherent));
+    c->copy_ring_cap = capn; c->copy_ring_slot = 0;
+  }
+  SeqJob* slot = reinterpret_cast<SeqJob*>(c->copy_ring) + (size_t)c->copy_ring_slot * c->copy_ring_cap;
+  c->copy_ring_slot = (c->copy_ring_slot + 1) % SLOTS;      // a slot is rewritten 8 launches later: the caller synchronises its stream more often than that (documented)
+  size_t big = 0;
+  for (int j = 0; j < njobs; ++j) {
+    if (!src[j] || !dst[j] || row_bytes[j] % 4) return fail(c, "airfe_copy_rows_dev: null pointer or a row size that is not a multiple of 4");
+    slot[j] = SeqJob{src[j], dst[j], cnt ? cnt[j] : nullptr, row_bytes[j], cap[j]};
+    big = std::max(big, (size_t)cap[j] * row_bytes[j]);
+  }
+  void* dp = nullptr;
+  HIPCHK(c, hipHostGetDevicePointer(&dp, slot, 0));
+  const int chunks = (int)std::min<size_t>(16, std::max<size_t>(1, big / 32768));
+  hipLaunchKernelGGL(seq_copy_jobs_kernel, dim3(njobs, chunks), dim3(256), 0, stream ? (hipStream_t)stream : c->stream, reinterpret_cast<const SeqJob*>(dp));
+  HIPCHK(c, hipGetLastError());
+  return 0;
+} AIRFE_CATCH(c)
 
 int airfe_seq_add_keyframe_check(const airfe_seq_policy* p, const float* ref_feat, int ref_n, const float* cur_feat, int cur_n, const int32_t* idx, int m) try {
   if (!p || m < 0 || ref_n < 0 || cur_n < 0 || (m > 0 && (!ref_feat || !cur_feat || !idx))) return -1;

@@ -16,32 +16,47 @@ from . import common as cm
 
 
 def host_to_host(ctx, dev, ls, rs, B, H, W, K, CL, CJ, steps, warm, world):
-    """Steady state of: H2D of the step's 2 B images (copy-in stream) -> airfe_stereo_plnet_batch_dev (compute stream) -> D2H of what the step produced (copy-out
-    stream) — the counts first, then, once the host has them, the rows up to the largest count of the batch (the junction buffer alone is 68 MB at its capacity of
-    1024 rows per image for ~150 junctions) — with two buffer sets in flight: while step i computes, the host finishes step i - 1's copies and consumes step
-    i - 2's results.  -> dict(pairs_per_s, ms_per_step, bytes, GB/s)."""
+    """Steady state of: H2D of the step's 2 B images (copy-in stream) -> airfe_stereo_plnet_batch_dev (compute stream) -> airfe_copy_rows_dev (copy-out stream): ONE
+    launch that writes the counts and the VALID feature / match / line / junction rows of the step straight into pinned host memory (the junction buffer alone is
+    68 MB at its capacity of 1024 rows per image for ~150 junctions) — with two buffer sets in flight: while step i computes, step i - 1's rows cross PCIe and the
+    host takes step i - 2's results.  -> dict(pairs_per_s, ms_per_step, bytes, GB/s)."""
     from airslam_amd import dist as adist
     Lp, Rp = torch.from_numpy(ls).pin_memory(), torch.from_numpy(rs).pin_memory()
     s_in, s_cmp, s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
     z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=dev)
     i32 = torch.int32
-    COUNTS = ("nl", "nr", "nm", "nlines", "njunc", "found")
     sets = []
     for _ in range(2):
         d = dict(fl=z(B, K, 259), fr=z(B, K, 259), nl=z(B, dt=i32), nr=z(B, dt=i32), idx=z(B, K, 2, dt=i32), sc=z(B, K), nm=z(B, dt=i32),
                  lines=z(2 * B, CL, 4, dt=torch.float64), nlines=z(2 * B, dt=i32), junc=z(B, CJ, 259), njunc=z(B, dt=i32), found=z(3 * B, dt=i32))
-        h = {k: torch.empty(v.shape, dtype=v.dtype).pin_memory() for k, v in d.items()}
+        h = {k: torch.zeros(v.shape, dtype=v.dtype).pin_memory() for k, v in d.items()}
+        jobs = [(d[k], h[k], None, 4, d[k].numel()) for k in ("nl", "nr", "nm", "nlines", "njunc", "found")]
+        for b in range(B):
+            jobs += [(d["fl"][b], h["fl"][b], d["nl"][b:b + 1], 1036, K), (d["fr"][b], h["fr"][b], d["nr"][b:b + 1], 1036, K),
+                     (d["idx"][b], h["idx"][b], d["nm"][b:b + 1], 8, K), (d["sc"][b], h["sc"][b], d["nm"][b:b + 1], 4, K),
+                     (d["junc"][b], h["junc"][b], d["njunc"][b:b + 1], 1036, CJ)]
+        for b in range(2 * B):
+            jobs.append((d["lines"][b], h["lines"][b], d["nlines"][b:b + 1], 32, CL))
         sets.append(dict(L=torch.empty((B, H, W), dtype=torch.uint8, device=dev), R=torch.empty((B, H, W), dtype=torch.uint8, device=dev), d=d, h=h,
-                         ev_in=torch.cuda.Event(), ev_done=torch.cuda.Event(), ev_cnt=torch.cuda.Event(), ev_out=torch.cuda.Event()))
+                         plan=ctx.copy_rows_plan(jobs), ev_in=torch.cuda.Event(), ev_done=torch.cuda.Event(), ev_out=torch.cuda.Event()))
     bytes_in = 2 * B * H * W
     moved = {"d2h": 0, "consumed_matches": 0}
 
-    def queue(i):
+    def take(st):
+        """the consumer: step i - 2's results are in the pinned block (here: the counts are read, the rows' bytes tallied)"""
+        h = st["h"]
+        fnd = h["found"]
+        if int(fnd[:2 * B].max()) > CL or int(fnd[2 * B:].max()) > CJ:
+            raise SystemExit("bench: line / junction capacity overflow")
+        moved["consumed_matches"] += int(h["nm"].sum())
+        moved["d2h"] += (int(h["nl"].sum()) + int(h["nr"].sum()) + int(h["njunc"].sum())) * 1036 + int(h["nm"].sum()) * 12 + int(h["nlines"].sum()) * 32 + 4 * (8 * B)
+
+    def one(i):
         st = sets[i % 2]
         if i >= 2:
-            st["ev_out"].synchronize()                       # the consumer takes step i - 2's results from the pinned block (here: reads a count)
-            moved["consumed_matches"] += int(st["h"]["nm"][0])
-            s_in.wait_event(st["ev_done"])                   # ... and step i - 2's kernels have read this set's images
+            st["ev_out"].synchronize()
+            take(st)
+            s_in.wait_event(st["ev_done"])                   # step i - 2's kernels have read this set's images
         with torch.cuda.stream(s_in):
             st["L"].copy_(Lp, non_blocking=True); st["R"].copy_(Rp, non_blocking=True)
             st["ev_in"].record(s_in)
@@ -52,53 +67,29 @@ def host_to_host(ctx, dev, ls, rs, B, H, W, K, CL, CJ, steps, warm, world):
         ctx.stereo_plnet_batch_dev(st["L"], st["R"], d["fl"], d["fr"], d["nl"], d["nr"], d["lines"], d["nlines"], d["junc"], d["njunc"], d["idx"], d["sc"], d["nm"],
                                    d["found"], stream=s_cmp.cuda_stream)
         st["ev_done"].record(s_cmp)
-
-    def finish(j):
-        """step j's results to the host: the counts, then (the host knows them) the valid rows"""
-        st = sets[j % 2]
-        d, h = st["d"], st["h"]
         s_out.wait_event(st["ev_done"])
-        with torch.cuda.stream(s_out):
-            for k in COUNTS:
-                h[k].copy_(d[k], non_blocking=True)
-            st["ev_cnt"].record(s_out)
-        st["ev_cnt"].synchronize()
-        fnd = h["found"]
-        if int(fnd[:2 * B].max()) > CL or int(fnd[2 * B:].max()) > CJ:
-            raise SystemExit("bench: line / junction capacity overflow")
-        mk, mm = max(int(h["nl"].max()), int(h["nr"].max()), 1), max(int(h["nm"].max()), 1)
-        ml, mj = max(int(h["nlines"].max()), 1), max(int(h["njunc"].max()), 1)
-        with torch.cuda.stream(s_out):
-            for k, n in (("fl", mk), ("fr", mk), ("idx", mm), ("sc", mm), ("lines", ml), ("junc", mj)):
-                h[k][:, :n].copy_(d[k][:, :n], non_blocking=True)
-                moved["d2h"] += d[k][:, :n].numel() * d[k].element_size()
-            st["ev_out"].record(s_out)
-        moved["d2h"] += sum(d[k].numel() * 4 for k in COUNTS)
-
-    def one(i, first):
-        queue(i)
-        if i > first:
-            finish(i - 1)
+        ctx.copy_rows_dev(st["plan"], stream=s_out.cuda_stream)
+        st["ev_out"].record(s_out)
 
     for i in range(warm):
-        one(i, 0)
-    finish(warm - 1) if warm else None
+        one(i)
     cm.barrier(dev, world)
     moved["d2h"] = 0
     t0 = time.perf_counter()
     for i in range(warm, warm + steps):
-        one(i, warm)
-    finish(warm + steps - 1)
+        one(i)
     cm.barrier(dev, world)
     dt = adist.max_over_ranks(time.perf_counter() - t0, dev)
+    for j in (warm + steps - 2, warm + steps - 1):           # (the last two steps' rows, for the byte count: their copies are complete behind the barrier)
+        take(sets[j % 2])
     hlast = sets[(warm + steps - 1) % 2]["h"]
     bytes_out = moved["d2h"] / steps
     return dict(pairs_per_s=B * steps * world / dt, ms_per_step=dt / steps * 1e3, steps=steps,
                 h2d_bytes_per_step=bytes_in, d2h_bytes_per_step=bytes_out, pcie_gbs={"h2d": bytes_in * steps / dt / 1e9, "d2h": bytes_out * steps / dt / 1e9},
                 matches_mean_last_step=float(hlast["nm"].float().mean()), lines_mean_last_step=float(hlast["nlines"].float().mean()),
-                what=(f"pinned host images -> H2D ({bytes_in / 1e6:.1f} MB per step, copy-in stream) -> the same step (compute stream) -> D2H of the counts, then of the "
-                      f"feature / match / line / junction rows up to the largest count of the batch ({bytes_out / 1e6:.1f} MB per step, copy-out stream) -> pinned host "
-                      f"memory; two buffer sets in flight: while step i computes, the host finishes step i - 1's copies and takes step i - 2's results"))
+                what=(f"pinned host images -> H2D ({bytes_in / 1e6:.1f} MB per step, copy-in stream) -> the same step (compute stream) -> airfe_copy_rows_dev: one launch "
+                      f"that writes the counts and the valid feature / match / line / junction rows into pinned host memory ({bytes_out / 1e6:.1f} MB per step, copy-out "
+                      f"stream); two buffer sets in flight: while step i computes, step i - 1's rows cross PCIe and the host takes step i - 2's results"))
 
 
 def run(args, rank, world, local, dev):

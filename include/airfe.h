@@ -285,6 +285,13 @@ int airfe_match_lines_batch_dev(airfe_ctx* ctx, const int32_t* d_row_ptr0, const
                                 const int32_t* d_row_ptr1, const int32_t* d_pt_idx1, const int* d_nlines1, const int* d_n1, int capL, int capE,
                                 const int32_t* d_matches, const int* d_nmatch, int mcap, int B, const double* filter3, const float* d_feat0,
                                 const float* d_feat1, int cap, int32_t* d_line_matches, void* stream);
+/* NEW (no reference counterpart: the reference copies whole bindings back inside every infer(), src/plnet.cpp:237, buffers.h:237-417): the VALID rows of device
+ * result buffers to wherever a kernel can write — device memory or host-mapped pinned memory (hipHostMalloc) — in ONE launch on `stream`.  Job j copies
+ * min(*cnt[j], cap[j]) rows (cnt[j] == NULL: cap[j] rows) of row_bytes[j] bytes (a multiple of 4) from src[j] to dst[j]; the counts are read on the device, so the
+ * caller needs no synchronisation to learn them first, and only the rows that exist cross PCIe (a batch entry's junction buffer is 1 MB per image at its capacity for
+ * ~150 rows of 1 KB).  The five arrays are HOST arrays of njobs entries, read before the call returns.  Asynchronous: the copies are complete when `stream` is. */
+int airfe_copy_rows_dev(airfe_ctx* ctx, int njobs, const void* const* src, void* const* dst, const int* const* cnt, const uint32_t* row_bytes,
+                        const uint32_t* cap, void* stream);
 /* synchronises the context's own stream; also reports (once) a Sinkhorn rendezvous time-out of an earlier SuperGlue call */
 int airfe_sync(airfe_ctx* ctx);
 /* SuperGlue's error channel for callers of the asynchronous *_dev entries who synchronise their OWN stream: synchronises `stream` (the one the
