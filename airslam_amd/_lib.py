@@ -13,7 +13,7 @@ class Tuning(C.Structure):
     """airfe_tuning (include/airfe.h): kernel-selection overrides, -1 = the library's choice"""
     _fields_ = [(n, C.c_int) for n in (
         "fuse_lg_block", "gemm_small_max_m", "gemm8_min_m", "gemmr_min_m", "gemmr_wgs", "qkv_pair", "block_min_m", "lgb_tokens", "sg_kenc_gemm",
-        "fold_qkv", "overlap_lines", "kf_graph", "kf_spec_rows", "fuse_dec", "assign_fused", "fold_out_proj", "desc_gather_stream")] + [("reserved", C.c_int * 6)]
+        "fold_qkv", "overlap_lines", "kf_graph", "kf_spec_rows", "fuse_dec", "assign_fused", "fold_out_proj", "desc_gather_stream", "copy_wgs")] + [("reserved", C.c_int * 5)]
 
 
 class Cfg(C.Structure):

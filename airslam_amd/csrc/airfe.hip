@@ -241,6 +241,7 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) try {
     if (t->assign_fused >= 0) c->assign_fused = t->assign_fused != 0 ? 1 : 0;
     if (t->fold_out_proj >= 0) c->fold_out = t->fold_out_proj != 0;
     if (t->desc_gather_stream >= 0) c->desc_gather_stream = t->desc_gather_stream != 0;
+    if (t->copy_wgs > 0) c->copy_wgs = t->copy_wgs;
   }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||

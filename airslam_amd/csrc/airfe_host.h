@@ -86,7 +86,7 @@ struct airfe_ctx {
   std::string launch_err;        // cfg.check_launches: the first failed launch since the last report, with its stage's name (launch_status())
   int fail_stage = -1;           // airfe_debug_fail_next_launch: the next ProfScope of this stage makes a deliberately invalid launch first (tests)
   void* copy_ring = nullptr;     // airfe_copy_rows_dev: host-mapped ring of job lists (csrc/airfe_seq.hip)
-  int copy_ring_cap = 0, copy_ring_slot = 0;
+  int copy_ring_cap = 0, copy_ring_slot = 0, copy_wgs = 64;   // airfe_tuning::copy_wgs
   int *sat_host = nullptr, *sat_flag = nullptr;   // two words of host-mapped, coherent memory (and their device address): [0] = non-finite detector logits, [1] = non-finite
                                  // sampled descriptor — written by the head / sampling kernels only when the 2-byte activations overflowed, read by the host after its synchronisation: no copy
   bool fuse_dec = true;          // airfe_tuning::fuse_dec

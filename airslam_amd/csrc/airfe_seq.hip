@@ -19,32 +19,36 @@ struct SeqJob {
   uint32_t cap;
 };
 
-// grid (jobs, chunks): workgroup (j, c) copies every gridDim.y-th 1-KiB run of job j.  Sources and destinations are device memory or host-mapped pinned memory
-// (the packed results are written straight into the staging set the host reads after its synchronisation: only the valid rows cross PCIe).  The job list itself
-// is read from host-mapped memory.  All sizes are multiples of 4 bytes; 16-byte accesses where both addresses allow it.
-__global__ __launch_bounds__(256) void seq_copy_jobs_kernel(const SeqJob* __restrict__ jobs) {
-  const SeqJob j = jobs[blockIdx.x];
-  uint32_t rows = j.cap;
-  if (j.cnt) {
-    const int c = *j.cnt;
-    rows = c < 0 ? 0u : ((uint32_t)c < rows ? (uint32_t)c : rows);
-  }
-  const size_t bytes = (size_t)rows * j.row_bytes;
-  const char* s = reinterpret_cast<const char*>(j.src);
-  char* d = reinterpret_cast<char*>(j.dst);
-  if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
-    const size_t q = bytes / 16;
-    const uint4* s4 = reinterpret_cast<const uint4*>(s);
-    uint4* d4 = reinterpret_cast<uint4*>(d);
-    for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < q; i += (size_t)gridDim.y * 256) d4[i] = s4[i];
-    const size_t done = q * 16;
-    if (blockIdx.y == 0 && threadIdx.x < (bytes - done) / 4)
-      reinterpret_cast<uint32_t*>(d + done)[threadIdx.x] = reinterpret_cast<const uint32_t*>(s + done)[threadIdx.x];
-  } else {
-    const size_t q = bytes / 4;
-    const uint32_t* s1 = reinterpret_cast<const uint32_t*>(s);
-    uint32_t* d1 = reinterpret_cast<uint32_t*>(d);
-    for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < q; i += (size_t)gridDim.y * 256) d1[i] = s1[i];
+// Unit (j, c) = every `chunks`-th 4-KiB run of job j; a workgroup takes units blockIdx.x, blockIdx.x + gridDim.x, ...  (the grid is capped: copies into pinned host memory
+// are PCIe-bound — a few dozen workgroups keep enough stores in flight, thousands would sit on CUs that the next step's kernels want).  Sources and destinations are
+// device memory or host-mapped pinned memory (the packed results are written straight into the staging set the host reads after its synchronisation: only the valid
+// rows cross PCIe).  The job list itself is read from host-mapped memory.  All sizes are multiples of 4 bytes; 16-byte accesses where both addresses allow it.
+__global__ __launch_bounds__(256) void seq_copy_jobs_kernel(const SeqJob* __restrict__ jobs, int njobs, int chunks) {
+  for (int u = blockIdx.x; u < njobs * chunks; u += gridDim.x) {
+    const int ji = u / chunks, ck = u - ji * chunks;
+    const SeqJob j = jobs[ji];
+    uint32_t rows = j.cap;
+    if (j.cnt) {
+      const int c = *j.cnt;
+      rows = c < 0 ? 0u : ((uint32_t)c < rows ? (uint32_t)c : rows);
+    }
+    const size_t bytes = (size_t)rows * j.row_bytes;
+    const char* s = reinterpret_cast<const char*>(j.src);
+    char* d = reinterpret_cast<char*>(j.dst);
+    if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+      const size_t q = bytes / 16;
+      const uint4* s4 = reinterpret_cast<const uint4*>(s);
+      uint4* d4 = reinterpret_cast<uint4*>(d);
+      for (size_t i = (size_t)ck * 256 + threadIdx.x; i < q; i += (size_t)chunks * 256) d4[i] = s4[i];
+      const size_t done = q * 16;
+      if (ck == 0 && threadIdx.x < (bytes - done) / 4)
+        reinterpret_cast<uint32_t*>(d + done)[threadIdx.x] = reinterpret_cast<const uint32_t*>(s + done)[threadIdx.x];
+    } else {
+      const size_t q = bytes / 4;
+      const uint32_t* s1 = reinterpret_cast<const uint32_t*>(s);
+      uint32_t* d1 = reinterpret_cast<uint32_t*>(d);
+      for (size_t i = (size_t)ck * 256 + threadIdx.x; i < q; i += (size_t)chunks * 256) d1[i] = s1[i];
+    }
   }
 }
 
@@ -166,7 +170,7 @@ int launch_jobs(airfe_seq* s, hipStream_t st) {
   size_t big = 0;
   for (const SeqJob& j : s->jl) big = std::max(big, (size_t)j.cap * j.row_bytes);
   const int chunks = (int)std::min<size_t>(16, std::max<size_t>(1, big / 32768));
-  hipLaunchKernelGGL(seq_copy_jobs_kernel, dim3(n, chunks), dim3(256), 0, st, s->jobs_d + (size_t)slot * s->job_cap);
+  hipLaunchKernelGGL(seq_copy_jobs_kernel, dim3(std::min(n * chunks, 256)), dim3(256), 0, st, s->jobs_d + (size_t)slot * s->job_cap, n, chunks);
   s->jl.clear();
   SEQ_HIP(s, hipGetLastError());
   return 0;
@@ -252,7 +256,9 @@ int airfe_copy_rows_dev(airfe_ctx* c, int njobs, const void* const* src, void* c
   void* dp = nullptr;
   HIPCHK(c, hipHostGetDevicePointer(&dp, slot, 0));
   const int chunks = (int)std::min<size_t>(16, std::max<size_t>(1, big / 32768));
-  hipLaunchKernelGGL(seq_copy_jobs_kernel, dim3(njobs, chunks), dim3(256), 0, stream ? (hipStream_t)stream : c->stream, reinterpret_cast<const SeqJob*>(dp));
+  // at most 64 workgroups: a quarter of the CUs' slots at most while the copy waits on PCIe beside the next step's kernels (bench.py --io host)
+  hipLaunchKernelGGL(seq_copy_jobs_kernel, dim3(std::min(njobs * chunks, std::max(c->copy_wgs, 1))), dim3(256), 0, stream ? (hipStream_t)stream : c->stream, reinterpret_cast<const SeqJob*>(dp),
+                     njobs, chunks);
   HIPCHK(c, hipGetLastError());
   return 0;
 } AIRFE_CATCH(c)

@@ -56,8 +56,10 @@ typedef struct airfe_tuning {
                             ffn.0 on cat(x, attention output) and the 256x256 GEMM, its barrier and its message tile are gone (1, the default for fp16 / bf16);
                             0: the out-projection as a GEMM of its own (the round 1-4 form; profiles/r05_fold_out_ab.txt) */
   int desc_gather_stream;/* the descriptor head over the sampled cells of a large batch (>= gemmr_min_m rows) in the streaming kernel with gathered rows (1, default)
-                            or the tiled 8-wave kernel (0); the same bits (tests/test_gpu_detector.py) */
-  int reserved[6];       /* must be -1 */
+                            or the tiled 8-wave kernel (0); the same bits (tests/test_gpu_detector.py).  Round 6: also the LOI head at the junctions' tap rows
+                            (K = N = 128) and the dense descriptor head of the junction images */
+  int copy_wgs;          /* airfe_copy_rows_dev: workgroups of the copy kernel (default 64: PCIe-bound copies into pinned memory need stores in flight, not CUs) */
+  int reserved[5];       /* must be -1 */
 } airfe_tuning;
 
 /* Mirrors the knobs of PLNetConfig / SuperPointConfig / PointMatcherConfig (include/read_configs.h:9-103). */

@@ -111,7 +111,7 @@ def test_default_tuning_is_all_minus_one(libpath):
     from airslam_amd import _lib
     t = _lib.Tuning()
     _lib.lib().airfe_default_tuning(C.byref(t))
-    assert all(getattr(t, n) == -1 for n, _ in _lib.Tuning._fields_ if n != "reserved") and list(t.reserved) == [-1] * 6
+    assert all(getattr(t, n) == -1 for n, _ in _lib.Tuning._fields_ if n != "reserved") and list(t.reserved) == [-1] * 5
     assert C.sizeof(_lib.Tuning) == 4 * 23
 
 
