@@ -52,6 +52,7 @@ class SeqFrame(C.Structure):
 # name -> (restype, argtypes); every symbol include/*.h declares
 SIGNATURES = {
     "airfe_copy_rows_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "airfe_pack_rows_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "airfe_seq_default_policy": (None, [C.POINTER(SeqPolicy)]),
     "airfe_seq_add_keyframe_check": (C.c_int, [C.POINTER(SeqPolicy), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "airfe_seq_good_stereo_points": (C.c_int, [C.POINTER(SeqPolicy), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

@@ -509,7 +509,7 @@ class Context:
     def copy_rows_plan(self, jobs):
         """jobs: [(src tensor / pointer, dst tensor / pointer, count tensor (int32, one element) / pointer / None, row_bytes, cap rows)] -> a reusable plan for
         copy_rows_dev (the five host arrays of airfe_copy_rows_dev, built once: the buffers of a pipeline do not move)"""
-        ptr = lambda x: 0 if x is None else (int(x) if isinstance(x, int) else x.data_ptr())
+        ptr = lambda x: 0 if x is None else (int(x) if isinstance(x, int) else x.data_ptr())        # (dst None: a plan for pack_rows_dev only)
         n = len(jobs)
         return dict(n=n, src=np.array([ptr(j[0]) for j in jobs], np.uint64), dst=np.array([ptr(j[1]) for j in jobs], np.uint64),
                     cnt=np.array([ptr(j[2]) for j in jobs], np.uint64), rb=np.array([j[3] for j in jobs], np.uint32), cap=np.array([j[4] for j in jobs], np.uint32),
@@ -519,6 +519,13 @@ class Context:
         """airfe_copy_rows_dev: the valid rows of every job of `plan` in one launch on `stream` (asynchronous)"""
         self._chk(self._l.airfe_copy_rows_dev(self._h, plan["n"], plan["src"].ctypes.data, plan["dst"].ctypes.data, plan["cnt"].ctypes.data, plan["rb"].ctypes.data,
                                               plan["cap"].ctypes.data, self._stream(stream)), "airfe_copy_rows_dev")
+
+    def pack_rows_dev(self, plan, packed_t, offsets_t, stream=None):
+        """airfe_pack_rows_dev: the valid rows of every job of `plan` (its dst column is ignored) back to back into `packed_t` (device uint8), job j at
+        offsets_t[j], offsets_t[n] = bytes used (device int64 [n + 1]); two launches on `stream` (asynchronous)"""
+        assert offsets_t.numel() >= plan["n"] + 1
+        self._chk(self._l.airfe_pack_rows_dev(self._h, plan["n"], plan["src"].ctypes.data, plan["cnt"].ctypes.data, plan["rb"].ctypes.data, plan["cap"].ctypes.data,
+                                              packed_t.data_ptr(), offsets_t.data_ptr(), self._stream(stream)), "airfe_pack_rows_dev")
 
     def _stream(self, stream):
         # the ctx runs on its own non-blocking stream: order it after whatever torch queued on ITS streams

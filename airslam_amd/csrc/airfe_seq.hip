@@ -17,6 +17,7 @@ struct SeqJob {
   const int* cnt;
   uint32_t row_bytes;
   uint32_t cap;
+  const unsigned long long* off;      // != nullptr: the rows go to dst + *off (airfe_pack_rows_dev: offsets computed on the device from the counts)
 };
 
 // Unit (j, c) = every `chunks`-th 4-KiB run of job j; a workgroup takes units blockIdx.x, blockIdx.x + gridDim.x, ...  (the grid is capped: copies into pinned host memory
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256) void seq_copy_jobs_kernel(const SeqJob* __rest
     }
     const size_t bytes = (size_t)rows * j.row_bytes;
     const char* s = reinterpret_cast<const char*>(j.src);
-    char* d = reinterpret_cast<char*>(j.dst);
+    char* d = reinterpret_cast<char*>(j.dst) + (j.off ? *j.off : 0ull);
     if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
       const size_t q = bytes / 16;
       const uint4* s4 = reinterpret_cast<const uint4*>(s);
@@ -50,6 +51,32 @@ __global__ __launch_bounds__(256) void seq_copy_jobs_kernel(const SeqJob* __rest
       for (size_t i = (size_t)ck * 256 + threadIdx.x; i < q; i += (size_t)chunks * 256) d1[i] = s1[i];
     }
   }
+}
+
+// off[j] = where job j's rows start in the packed block (16-byte aligned), off[njobs] = the block's size: an exclusive scan of min(*cnt, cap) * row_bytes, one workgroup
+__global__ __launch_bounds__(256) void seq_offsets_kernel(const SeqJob* __restrict__ jobs, int njobs, unsigned long long* __restrict__ off) {
+  __shared__ unsigned long long part[256];
+  const int tid = threadIdx.x, per = (njobs + 255) / 256, j0 = tid * per, j1 = min(j0 + per, njobs);
+  auto size_of = [&](int ji) -> unsigned long long {
+    const SeqJob j = jobs[ji];
+    uint32_t rows = j.cap;
+    if (j.cnt) {
+      const int c = *j.cnt;
+      rows = c < 0 ? 0u : ((uint32_t)c < rows ? (uint32_t)c : rows);
+    }
+    return ((unsigned long long)rows * j.row_bytes + 15ull) & ~15ull;
+  };
+  unsigned long long sum = 0;
+  for (int ji = j0; ji < j1; ++ji) sum += size_of(ji);
+  part[tid] = sum;
+  __syncthreads();
+  unsigned long long base = 0;
+  for (int t = 0; t < tid; ++t) base += part[t];
+  for (int ji = j0; ji < j1; ++ji) {
+    off[ji] = base;
+    base += size_of(ji);
+  }
+  if (tid == 255) off[njobs] = base;
 }
 
 using clk = std::chrono::steady_clock;
@@ -176,7 +203,7 @@ int launch_jobs(airfe_seq* s, hipStream_t st) {
   return 0;
 }
 inline void job(airfe_seq* s, const void* src, void* dst, const int* cnt, size_t row_bytes, size_t cap) {
-  s->jl.push_back(SeqJob{src, dst, cnt, (uint32_t)row_bytes, (uint32_t)cap});
+  s->jl.push_back(SeqJob{src, dst, cnt, (uint32_t)row_bytes, (uint32_t)cap, nullptr});
 }
 
 // Frame::AddRightFeatures' count (src/frame.cc:141-172): stereo matches inside the camera's band whose signed parallax is inside it too
@@ -229,12 +256,11 @@ void airfe_seq_default_policy(airfe_seq_policy* p) {
 }
 
 // ---- the copy kernel on its own (include/airfe.h): valid rows of device buffers -> device or host-mapped memory, one launch
-int airfe_copy_rows_dev(airfe_ctx* c, int njobs, const void* const* src, void* const* dst, const int* const* cnt, const uint32_t* row_bytes, const uint32_t* cap,
-                        void* stream) try {
-  if (!c) return 1;
+static int copy_rows_impl(airfe_ctx* c, int njobs, const void* const* src, void* const* dst, void* d_packed, unsigned long long* d_off, const int* const* cnt,
+                          const uint32_t* row_bytes, const uint32_t* cap, void* stream, const char* who) {
   int d = -1;
   if (!(hipGetDevice(&d) == hipSuccess && d == c->cfg.device) && hipSetDevice(c->cfg.device) != hipSuccess) return fail(c, "hipSetDevice(cfg.device) failed");
-  if (njobs < 0 || (njobs > 0 && (!src || !dst || !row_bytes || !cap))) return fail(c, "airfe_copy_rows_dev: bad argument");
+  if (njobs < 0 || (njobs > 0 && (!src || !row_bytes || !cap || (!dst && !(d_packed && d_off))))) return fail(c, std::string(who) + ": bad argument");
   if (njobs == 0) return 0;
   constexpr int SLOTS = 8;
   if (njobs > c->copy_ring_cap) {               // (grows by replacement; launches that still read the old ring are drained first)
@@ -249,18 +275,35 @@ int airfe_copy_rows_dev(airfe_ctx* c, int njobs, const void* const* src, void* c
   c->copy_ring_slot = (c->copy_ring_slot + 1) % SLOTS;      // a slot is rewritten 8 launches later: the caller synchronises its stream more often than that (documented)
   size_t big = 0;
   for (int j = 0; j < njobs; ++j) {
-    if (!src[j] || !dst[j] || row_bytes[j] % 4) return fail(c, "airfe_copy_rows_dev: null pointer or a row size that is not a multiple of 4");
-    slot[j] = SeqJob{src[j], dst[j], cnt ? cnt[j] : nullptr, row_bytes[j], cap[j]};
+    if (!src[j] || (dst && !dst[j]) || row_bytes[j] % 4) return fail(c, std::string(who) + ": null pointer or a row size that is not a multiple of 4");
+    slot[j] = SeqJob{src[j], dst ? dst[j] : d_packed, cnt ? cnt[j] : nullptr, row_bytes[j], cap[j], dst ? nullptr : d_off + j};
     big = std::max(big, (size_t)cap[j] * row_bytes[j]);
   }
   void* dp = nullptr;
   HIPCHK(c, hipHostGetDevicePointer(&dp, slot, 0));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  if (!dst) hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const SeqJob*>(dp), njobs, d_off);
   const int chunks = (int)std::min<size_t>(16, std::max<size_t>(1, big / 32768));
-  // at most 64 workgroups: a quarter of the CUs' slots at most while the copy waits on PCIe beside the next step's kernels (bench.py --io host)
-  hipLaunchKernelGGL(seq_copy_jobs_kernel, dim3(std::min(njobs * chunks, std::max(c->copy_wgs, 1))), dim3(256), 0, stream ? (hipStream_t)stream : c->stream, reinterpret_cast<const SeqJob*>(dp),
-                     njobs, chunks);
+  // a capped grid: copies into pinned memory wait on PCIe — a few dozen workgroups keep enough stores in flight (tools/microbench/pcie_kernel_write.hip: 64 reach the
+  // 55 GB/s of the copy engines), thousands would sit on CUs beside the next step's kernels
+  hipLaunchKernelGGL(seq_copy_jobs_kernel, dim3(std::min(njobs * chunks, std::max(dst ? c->copy_wgs : 1024, 1))), dim3(256), 0, st, reinterpret_cast<const SeqJob*>(dp), njobs,
+                     chunks);
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+
+int airfe_copy_rows_dev(airfe_ctx* c, int njobs, const void* const* src, void* const* dst, const int* const* cnt, const uint32_t* row_bytes, const uint32_t* cap,
+                        void* stream) try {
+  if (!c) return 1;
+  if (njobs > 0 && !dst) return fail(c, "airfe_copy_rows_dev: bad argument");
+  return copy_rows_impl(c, njobs, src, dst, nullptr, nullptr, cnt, row_bytes, cap, stream, "airfe_copy_rows_dev");
+} AIRFE_CATCH(c)
+
+int airfe_pack_rows_dev(airfe_ctx* c, int njobs, const void* const* src, const int* const* cnt, const uint32_t* row_bytes, const uint32_t* cap, void* d_packed,
+                        unsigned long long* d_offsets, void* stream) try {
+  if (!c) return 1;
+  if (njobs > 0 && (!d_packed || !d_offsets)) return fail(c, "airfe_pack_rows_dev: bad argument");
+  return copy_rows_impl(c, njobs, src, nullptr, d_packed, d_offsets, cnt, row_bytes, cap, stream, "airfe_pack_rows_dev");
 } AIRFE_CATCH(c)
 
 int airfe_seq_add_keyframe_check(const airfe_seq_policy* p, const float* ref_feat, int ref_n, const float* cur_feat, int cur_n, const int32_t* idx, int m) try {

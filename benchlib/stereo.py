@@ -16,10 +16,11 @@ from . import common as cm
 
 
 def host_to_host(ctx, dev, ls, rs, B, H, W, K, CL, CJ, steps, warm, world):
-    """Steady state of: H2D of the step's 2 B images (copy-in stream) -> airfe_stereo_plnet_batch_dev (compute stream) -> airfe_copy_rows_dev (copy-out stream): ONE
-    launch that writes the counts and the VALID feature / match / line / junction rows of the step straight into pinned host memory (the junction buffer alone is
-    68 MB at its capacity of 1024 rows per image for ~150 junctions) — with two buffer sets in flight: while step i computes, step i - 1's rows cross PCIe and the
-    host takes step i - 2's results.  -> dict(pairs_per_s, ms_per_step, bytes, GB/s)."""
+    """Steady state of: H2D of the step's 2 B images (copy-in stream, copy engine) -> airfe_stereo_plnet_batch_dev + airfe_pack_rows_dev (compute stream: the counts
+    and the VALID feature / match / line / junction rows of the step back to back in one device block, offsets from a scan of the counts on the device) -> D2H of the
+    offsets, then — the host knows the size one step later — of the packed bytes (copy-out stream, copy engine) — with two buffer sets in flight: while step i
+    computes, the host finishes step i - 1's copies and takes step i - 2's results.  The junction buffer alone is 68 MB per step at its capacity of 1024 rows per
+    image for ~150 junctions: at capacity the step moves 125 MB back, packed 78 MB.  -> dict(pairs_per_s, ms_per_step, bytes, GB/s)."""
     from airslam_amd import dist as adist
     Lp, Rp = torch.from_numpy(ls).pin_memory(), torch.from_numpy(rs).pin_memory()
     s_in, s_cmp, s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
@@ -29,29 +30,31 @@ def host_to_host(ctx, dev, ls, rs, B, H, W, K, CL, CJ, steps, warm, world):
     for _ in range(2):
         d = dict(fl=z(B, K, 259), fr=z(B, K, 259), nl=z(B, dt=i32), nr=z(B, dt=i32), idx=z(B, K, 2, dt=i32), sc=z(B, K), nm=z(B, dt=i32),
                  lines=z(2 * B, CL, 4, dt=torch.float64), nlines=z(2 * B, dt=i32), junc=z(B, CJ, 259), njunc=z(B, dt=i32), found=z(3 * B, dt=i32))
-        h = {k: torch.zeros(v.shape, dtype=v.dtype).pin_memory() for k, v in d.items()}
-        jobs = [(d[k], h[k], None, 4, d[k].numel()) for k in ("nl", "nr", "nm", "nlines", "njunc", "found")]
+        jobs = [(d[k], None, None, 4, d[k].numel()) for k in ("nl", "nr", "nm", "nlines", "njunc", "found")]      # jobs 0-5: the count arrays themselves
         for b in range(B):
-            jobs += [(d["fl"][b], h["fl"][b], d["nl"][b:b + 1], 1036, K), (d["fr"][b], h["fr"][b], d["nr"][b:b + 1], 1036, K),
-                     (d["idx"][b], h["idx"][b], d["nm"][b:b + 1], 8, K), (d["sc"][b], h["sc"][b], d["nm"][b:b + 1], 4, K),
-                     (d["junc"][b], h["junc"][b], d["njunc"][b:b + 1], 1036, CJ)]
+            jobs += [(d["fl"][b], None, d["nl"][b:b + 1], 1036, K), (d["fr"][b], None, d["nr"][b:b + 1], 1036, K), (d["idx"][b], None, d["nm"][b:b + 1], 8, K),
+                     (d["sc"][b], None, d["nm"][b:b + 1], 4, K), (d["junc"][b], None, d["njunc"][b:b + 1], 1036, CJ)]
         for b in range(2 * B):
-            jobs.append((d["lines"][b], h["lines"][b], d["nlines"][b:b + 1], 32, CL))
-        sets.append(dict(L=torch.empty((B, H, W), dtype=torch.uint8, device=dev), R=torch.empty((B, H, W), dtype=torch.uint8, device=dev), d=d, h=h,
-                         plan=ctx.copy_rows_plan(jobs), ev_in=torch.cuda.Event(), ev_done=torch.cuda.Event(), ev_out=torch.cuda.Event()))
+            jobs.append((d["lines"][b], None, d["nlines"][b:b + 1], 32, CL))
+        cap_bytes = sum((j[3] * j[4] + 15) // 16 * 16 for j in jobs)
+        sets.append(dict(L=torch.empty((B, H, W), dtype=torch.uint8, device=dev), R=torch.empty((B, H, W), dtype=torch.uint8, device=dev), d=d,
+                         plan=ctx.copy_rows_plan(jobs), packed=torch.zeros((cap_bytes,), dtype=torch.uint8, device=dev),
+                         off=torch.zeros((len(jobs) + 1,), dtype=torch.int64, device=dev), h_packed=torch.zeros((cap_bytes,), dtype=torch.uint8).pin_memory(),
+                         h_off=torch.zeros((len(jobs) + 1,), dtype=torch.int64).pin_memory(),
+                         ev_in=torch.cuda.Event(), ev_done=torch.cuda.Event(), ev_cnt=torch.cuda.Event(), ev_out=torch.cuda.Event()))
     bytes_in = 2 * B * H * W
-    moved = {"d2h": 0, "consumed_matches": 0}
+    moved = {"d2h": 0, "matches": 0, "lines": 0}
 
     def take(st):
-        """the consumer: step i - 2's results are in the pinned block (here: the counts are read, the rows' bytes tallied)"""
-        h = st["h"]
-        fnd = h["found"]
+        """the consumer: step i - 2's packed rows are in the pinned block; job j's rows start at h_off[j] (jobs 0-5 are the count arrays)"""
+        off, hp = st["h_off"], st["h_packed"]
+        cnt = lambda j, n: hp[int(off[j]):int(off[j]) + 4 * n].view(torch.int32)
+        fnd = cnt(5, 3 * B)
         if int(fnd[:2 * B].max()) > CL or int(fnd[2 * B:].max()) > CJ:
             raise SystemExit("bench: line / junction capacity overflow")
-        moved["consumed_matches"] += int(h["nm"].sum())
-        moved["d2h"] += (int(h["nl"].sum()) + int(h["nr"].sum()) + int(h["njunc"].sum())) * 1036 + int(h["nm"].sum()) * 12 + int(h["nlines"].sum()) * 32 + 4 * (8 * B)
+        moved["matches"], moved["lines"] = float(cnt(2, B).float().mean()), float(cnt(3, 2 * B).float().mean())
 
-    def one(i):
+    def queue(i):
         st = sets[i % 2]
         if i >= 2:
             st["ev_out"].synchronize()
@@ -62,34 +65,52 @@ def host_to_host(ctx, dev, ls, rs, B, H, W, K, CL, CJ, steps, warm, world):
             st["ev_in"].record(s_in)
         s_cmp.wait_event(st["ev_in"])
         if i >= 2:
-            s_cmp.wait_event(st["ev_out"])
+            s_cmp.wait_event(st["ev_out"])                   # (the packed block of this set has left the device)
         d = st["d"]
         ctx.stereo_plnet_batch_dev(st["L"], st["R"], d["fl"], d["fr"], d["nl"], d["nr"], d["lines"], d["nlines"], d["junc"], d["njunc"], d["idx"], d["sc"], d["nm"],
                                    d["found"], stream=s_cmp.cuda_stream)
+        ctx.pack_rows_dev(st["plan"], st["packed"], st["off"], stream=s_cmp.cuda_stream)
         st["ev_done"].record(s_cmp)
         s_out.wait_event(st["ev_done"])
-        ctx.copy_rows_dev(st["plan"], stream=s_out.cuda_stream)
-        st["ev_out"].record(s_out)
+        with torch.cuda.stream(s_out):
+            st["h_off"].copy_(st["off"], non_blocking=True)
+            st["ev_cnt"].record(s_out)
+
+    def finish(j):
+        """step j's packed rows to the host: the host has the size now"""
+        st = sets[j % 2]
+        st["ev_cnt"].synchronize()
+        total = int(st["h_off"][-1])
+        with torch.cuda.stream(s_out):
+            st["h_packed"][:total].copy_(st["packed"][:total], non_blocking=True)
+            st["ev_out"].record(s_out)
+        moved["d2h"] += total + st["h_off"].numel() * 8
 
     for i in range(warm):
-        one(i)
+        queue(i)
+        if i > 0:
+            finish(i - 1)
+    if warm:
+        finish(warm - 1)
     cm.barrier(dev, world)
     moved["d2h"] = 0
     t0 = time.perf_counter()
     for i in range(warm, warm + steps):
-        one(i)
+        queue(i)
+        if i > warm:
+            finish(i - 1)
+    finish(warm + steps - 1)
     cm.barrier(dev, world)
     dt = adist.max_over_ranks(time.perf_counter() - t0, dev)
-    for j in (warm + steps - 2, warm + steps - 1):           # (the last two steps' rows, for the byte count: their copies are complete behind the barrier)
-        take(sets[j % 2])
-    hlast = sets[(warm + steps - 1) % 2]["h"]
+    take(sets[(warm + steps - 1) % 2])
     bytes_out = moved["d2h"] / steps
     return dict(pairs_per_s=B * steps * world / dt, ms_per_step=dt / steps * 1e3, steps=steps,
                 h2d_bytes_per_step=bytes_in, d2h_bytes_per_step=bytes_out, pcie_gbs={"h2d": bytes_in * steps / dt / 1e9, "d2h": bytes_out * steps / dt / 1e9},
-                matches_mean_last_step=float(hlast["nm"].float().mean()), lines_mean_last_step=float(hlast["nlines"].float().mean()),
-                what=(f"pinned host images -> H2D ({bytes_in / 1e6:.1f} MB per step, copy-in stream) -> the same step (compute stream) -> airfe_copy_rows_dev: one launch "
-                      f"that writes the counts and the valid feature / match / line / junction rows into pinned host memory ({bytes_out / 1e6:.1f} MB per step, copy-out "
-                      f"stream); two buffer sets in flight: while step i computes, step i - 1's rows cross PCIe and the host takes step i - 2's results"))
+                matches_mean_last_step=moved["matches"], lines_mean_last_step=moved["lines"],
+                what=(f"pinned host images -> H2D ({bytes_in / 1e6:.1f} MB per step, copy-in stream) -> the same step + airfe_pack_rows_dev (compute stream: counts and valid "
+                      f"feature / match / line / junction rows back to back in one device block) -> D2H of the offsets, then of the packed bytes ({bytes_out / 1e6:.1f} MB per "
+                      f"step, copy-out stream, copy engine) -> pinned host memory; two buffer sets in flight: while step i computes, the host finishes step i - 1's copies "
+                      f"and takes step i - 2's results"))
 
 
 def run(args, rank, world, local, dev):

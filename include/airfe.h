@@ -294,6 +294,14 @@ int airfe_match_lines_batch_dev(airfe_ctx* ctx, const int32_t* d_row_ptr0, const
  * ~150 rows of 1 KB).  The five arrays are HOST arrays of njobs entries, read before the call returns.  Asynchronous: the copies are complete when `stream` is. */
 int airfe_copy_rows_dev(airfe_ctx* ctx, int njobs, const void* const* src, void* const* dst, const int* const* cnt, const uint32_t* row_bytes,
                         const uint32_t* cap, void* stream);
+/* The same, packed: job j's valid rows go to d_packed + d_offsets[j] (16-byte aligned, jobs back to back in order), d_offsets[njobs] = the bytes used; the
+ * offsets are an exclusive scan of the counts taken ON THE DEVICE (two launches on `stream`).  d_packed (device) must hold the sum of the jobs' capacities rounded
+ * up to 16 bytes each; d_offsets (device) njobs + 1 entries.  For a consumer that wants the results of a large batch on the host through the copy ENGINES: read
+ * d_offsets (a few KB), then copy d_packed[0 .. d_offsets[njobs]) with hipMemcpyAsync — no kernel sits on the stream's hardware queue while the bytes cross PCIe
+ * (bench.py --io host: one kernel writing the rows into pinned memory itself reaches the same 55 GB/s but runs in line with the next step's kernels wherever the
+ * two streams share a hardware queue). */
+int airfe_pack_rows_dev(airfe_ctx* ctx, int njobs, const void* const* src, const int* const* cnt, const uint32_t* row_bytes, const uint32_t* cap, void* d_packed,
+                        unsigned long long* d_offsets, void* stream);
 /* synchronises the context's own stream; also reports (once) a Sinkhorn rendezvous time-out of an earlier SuperGlue call */
 int airfe_sync(airfe_ctx* ctx);
 /* SuperGlue's error channel for callers of the asynchronous *_dev entries who synchronise their OWN stream: synchronises `stream` (the one the

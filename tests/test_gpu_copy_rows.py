@@ -44,3 +44,30 @@ def test_copy_rows_to_pinned_and_device_memory():
     from airslam_amd import api
     with pytest.raises(api.AirfeError, match="multiple of 4"):
         ctx.copy_rows_dev(ctx.copy_rows_plan([(src[0], h_feat[0], None, 6, 1)]), stream=st.cuda_stream)
+
+
+def test_pack_rows_back_to_back_with_device_side_offsets():
+    """airfe_pack_rows_dev: the same jobs packed into ONE device block, job j at offsets[j] (16-byte aligned), offsets[n] = bytes used — the exclusive scan of the
+    counts is taken on the device (700 jobs: more than one per thread of the scan's workgroup)"""
+    import torch
+    ctx, _, _ = context("sp", max_batch=2, enc_chunk=2)
+    rng = np.random.default_rng(4)
+    n, cap = 700, 9
+    src = torch.from_numpy(rng.integers(0, 1 << 30, size=(n, cap, 7), dtype=np.int32)).cuda()          # rows of 28 bytes
+    cnt_np = rng.integers(-1, 12, size=n).astype(np.int32)
+    cnt = torch.from_numpy(cnt_np).cuda()
+    jobs = [(src[j], None, cnt[j:j + 1] if j % 5 else None, 28, cap) for j in range(n)]                # every fifth job: no count = its capacity
+    plan = ctx.copy_rows_plan(jobs)
+    packed = torch.full((n * ((cap * 28 + 15) // 16 * 16),), 255, dtype=torch.uint8).cuda()
+    off = torch.zeros((n + 1,), dtype=torch.int64).cuda()
+    st = torch.cuda.Stream()
+    ctx.pack_rows_dev(plan, packed, off, stream=st.cuda_stream)
+    st.synchronize()
+    o, p, s = off.cpu().numpy(), packed.cpu().numpy(), src.cpu().numpy()
+    pos = 0
+    for j in range(n):
+        rows = cap if j % 5 == 0 else int(np.clip(cnt_np[j], 0, cap))
+        assert o[j] == pos and pos % 16 == 0
+        np.testing.assert_array_equal(p[pos:pos + rows * 28].view(np.int32), s[j, :rows].reshape(-1))
+        pos += (rows * 28 + 15) // 16 * 16
+    assert o[n] == pos
