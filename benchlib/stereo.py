@@ -23,8 +23,8 @@ def host_to_host(ctx, dev, ls, rs, B, H, W, K, CL, CJ, steps, warm, world):
     image for ~150 junctions: at capacity the step moves 125 MB back, packed 78 MB.  -> dict(pairs_per_s, ms_per_step, bytes, GB/s)."""
     from airslam_amd import dist as adist
     Lp, Rp = torch.from_numpy(ls).pin_memory(), torch.from_numpy(rs).pin_memory()
-    s_in, s_cmp, s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
-    z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=dev)
+    s_in, s_cmp, s_out, s_cnt = (torch.cuda.Stream(device=dev) for _ in range(4))      # (the offsets of step i and the packed bytes of step i - 1 on streams of their own:
+    z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=dev)                # on one stream the second would queue behind the first's wait for step i)
     i32 = torch.int32
     sets = []
     for _ in range(2):
@@ -71,10 +71,10 @@ def host_to_host(ctx, dev, ls, rs, B, H, W, K, CL, CJ, steps, warm, world):
                                    d["found"], stream=s_cmp.cuda_stream)
         ctx.pack_rows_dev(st["plan"], st["packed"], st["off"], stream=s_cmp.cuda_stream)
         st["ev_done"].record(s_cmp)
-        s_out.wait_event(st["ev_done"])
-        with torch.cuda.stream(s_out):
+        s_cnt.wait_event(st["ev_done"])
+        with torch.cuda.stream(s_cnt):
             st["h_off"].copy_(st["off"], non_blocking=True)
-            st["ev_cnt"].record(s_out)
+            st["ev_cnt"].record(s_cnt)
 
     def finish(j):
         """step j's packed rows to the host: the host has the size now"""
