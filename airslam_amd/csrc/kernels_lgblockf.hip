@@ -257,6 +257,16 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
     const bool last = s + 1 == nslab;
     const char* p0 = last ? n0 : w0 + (s + 1) * LF_SS;
     const char* p1 = last ? n1 : w1 + (s + 1) * LF_SS;
+#ifdef LF_NOWEIGHTS      // diagnostic build (tools/build_timing_variants.sh): the K loop WITHOUT its weight stream (results are garbage) — the ceiling of any fix of that stream
+    if (true) {
+      (void)p0; (void)p1;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        nxt[t][0] = cur[t][0];
+        nxt[t][1] = cur[t][1];
+      }
+    } else
+#endif
     if constexpr (TS == TSN) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {

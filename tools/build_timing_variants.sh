@@ -19,4 +19,7 @@ hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_AT.so.tmp /tmp
 # A/B build: the block kernel reading the slab image (round 5's layout) instead of the fragment-order copy
 hipcc $FL -DLF_FRAG=0 -c airslam_amd/csrc/kernels_lgblockf.hip -o /tmp/lf_F0.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_F0.so.tmp /tmp/lf_F0.o $(others kernels_lgblockf)
+# diagnostic: the block kernel without the weight stream of its K loops (garbage results; kernel times only)
+hipcc $FL -DLF_NOWEIGHTS -c airslam_amd/csrc/kernels_lgblockf.hip -o /tmp/lf_NW.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_NW.so.tmp /tmp/lf_NW.o $(others kernels_lgblockf)
 ls -la airslam_amd/*.so.tmp
