@@ -166,8 +166,15 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
 #endif
   for (int kt = 0; kt < nkv; ++kt) {
     ATT_NOW(t_a)
+#ifdef ATT_NODMA       // diagnostic build (tools/build_timing_variants.sh): no K / V staging behind tile 0 (garbage results) — the ceiling of any fix of the staging traffic
+    if (false)
+#endif
     if (kt + 1 < nkv) dma_tile(kt + 1, (kt + 1) & 1);
+#ifdef ATT_NODMA
+    const char* kb = smem;                               // (tile 0's data every time: valid scores, no staging)
+#else
     const char* kb = smem + (kt & 1) * 16384;
+#endif
     const char* vb = kb + 8192;
     if (active) {
       const int left = len_kv - kt * 64;                 // keys left from this tile on (wave-uniform)

@@ -22,4 +22,7 @@ hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_F0.so.tmp /tmp
 # diagnostic: the block kernel without the weight stream of its K loops (garbage results; kernel times only)
 hipcc $FL -DLF_NOWEIGHTS -c airslam_amd/csrc/kernels_lgblockf.hip -o /tmp/lf_NW.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_NW.so.tmp /tmp/lf_NW.o $(others kernels_lgblockf)
+# diagnostic: attention without its K / V staging behind the first tile (garbage results; kernel times only)
+hipcc $FL -DATT_NODMA -c airslam_amd/csrc/kernels_attn.hip -o /tmp/att_ND.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_ND.so.tmp /tmp/att_ND.o $(others kernels_attn)
 ls -la airslam_amd/*.so.tmp
