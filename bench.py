@@ -71,6 +71,9 @@ def main():
                     help="stereo workload: `value` = the step with inputs resident in HBM (the contract's default) or host to host — pinned host images in, features / "
                          "lines / junctions / matches back in pinned host memory, PCIe on copy streams beside the compute stream (the resident rate rides along as value_resident)")
     ap.add_argument("--io-steps", type=int, default=20, help="steps of the host-to-host pass the default line reports beside the resident rate (0 = skip)")
+    ap.add_argument("--inflight", type=int, default=1, choices=[1, 2],
+                    help="stereo workload: steps in flight on the device — 2 = consecutive steps alternate between two contexts (own arena and stream), so that the matcher of "
+                         "step i runs beside the encoder of step i + 1")
     ap.add_argument("--seq-driver", default="native", choices=["native", "python"],
                     help="--workload seq, S > 1: the C++ lock-step driver (include/airfe_seq.h) or round 5's Python driver (airslam_amd.seq.BatchedSequences)")
     ap.add_argument("--groups", type=int, default=0, help="--workload seq, native driver: groups of sequences half a step apart (0 = 2 from 4 sequences on, else 1)")

@@ -140,7 +140,26 @@ def run(args, rank, world, local, dev):
     stream = torch.cuda.Stream(device=dev)
     sh = stream.cuda_stream
 
-    def points_step():
+    # --inflight 2: consecutive steps alternate between TWO contexts (own arena, own stream, own result buffers; the same resident images), so that two steps are
+    # in flight on the device: the matcher of step i runs beside the encoder of step i + 1.  A step stays one airfe_stereo_plnet_batch_dev call over `--pairs` pairs.
+    second = None
+    if args.inflight > 1:
+        if args.inflight != 2 or args.workload != "stereo":
+            raise SystemExit("--inflight: 1 or 2, stereo workload only")
+        c2 = api.Context(superpoint=sp, lightglue=lg, plnet_s1=cm.S1_PACK if plnet else None, device=local, precision=1 if args.dtype == "fp16" else 0,
+                         matcher_precision=1 if args.matcher_dtype == "fp16" else 0, max_batch=B,
+                         enc_chunk=args.chunk, max_keypoints=K, image_width=W, image_height=H, tuning=args.tuning, line_precision=args.line_precision)
+        second = dict(ctx=c2, stream=torch.cuda.Stream(device=dev), fl=torch.zeros_like(fl), fr=torch.zeros_like(fr), nl=torch.zeros_like(nl), nr=torch.zeros_like(nr),
+                      idx=torch.zeros_like(idx), sc=torch.zeros_like(sc), nm=torch.zeros_like(nm))
+        if plnet:
+            second.update(lines=torch.zeros_like(lines), nlines=torch.zeros_like(nlines), junc=torch.zeros_like(junc), njunc=torch.zeros_like(njunc), found=torch.zeros_like(found))
+    ctxs = [ctx] + ([second["ctx"]] if second else [])
+
+    def points_step(slot=0):
+        if slot:
+            b = second
+            b["ctx"].stereo_batch_dev(L, R, b["fl"], b["fr"], b["nl"], b["nr"], b["idx"], b["sc"], b["nm"], stream=b["stream"].cuda_stream)
+            return
         ctx.stereo_batch_dev(L, R, fl, fr, nl, nr, idx, sc, nm, stream=sh)
 
     frontend = args.workload == "frontend"
@@ -176,10 +195,21 @@ def run(args, rank, world, local, dev):
     if world > 1:
         from airslam_amd import seq as aseq
         gatherer = aseq.MatchGatherer(1, B, K, dev, buffers=2)
+        gatherer2 = aseq.MatchGatherer(1, B, K, dev, buffers=2) if second else None
         args.collective["per_step"] = ("one packed gather of the match lists to rank 0 on a side stream behind an event (airslam_amd.seq.MatchGatherer, K = 1, two buffer "
                                        "sets: the next step's kernels do not wait for the collective)")
 
-    def step():
+    def step(slot=0):
+        if slot:               # the second context's turn (--inflight 2)
+            b = second
+            if plnet:
+                b["ctx"].stereo_plnet_batch_dev(L, R, b["fl"], b["fr"], b["nl"], b["nr"], b["lines"], b["nlines"], b["junc"], b["njunc"], b["idx"], b["sc"], b["nm"], b["found"],
+                                                stream=b["stream"].cuda_stream)
+            else:
+                points_step(1)
+            if world > 1:
+                gatherer2.add(b["idx"], b["sc"], b["nm"], stream=b["stream"])
+            return
         if track:
             # Detect(image_left, features) on a normal frame = PLNet::infer(points + lines, no junctions: feature_detector.cc:36-60) on ONE
             # image, then MatchingPoints(features_last_keyframe, left_features) (map_builder.cc:94-101)
@@ -205,22 +235,27 @@ def run(args, rank, world, local, dev):
             gatherer.add(idx, sc, nm, stream=stream)      # barrier() drains it (torch.cuda.synchronize)
 
     torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup * len(ctxs)):
+        step(i % len(ctxs))
     cm.barrier(dev, world)
     # Timed region: only the dominant kernel's stage carries HIP events (on the launch stream); bracketing EVERY stage
     # costs ~8 % of a step, so the full per-stage table comes from a second, untimed pass below.
     if not args.no_profile:
-        ctx.profile(stages=[cm.DOMINANT_STAGE])
+        for c_ in ctxs:
+            c_.profile(stages=[cm.DOMINANT_STAGE])
     host = cm.HostClock()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         with host:
-            step()
+            step(i % len(ctxs))
     cm.barrier(dev, world)
     dt = time.perf_counter() - t0
-    dom = ctx.profile_read()[cm.DOMINANT_STAGE] if not args.no_profile else None
-    ctx.profile(False)
+    dom = None
+    if not args.no_profile:
+        doms = [c_.profile_read()[cm.DOMINANT_STAGE] for c_ in ctxs]
+        dom = {k: sum(d[k] for d in doms) for k in doms[0]}
+    for c_ in ctxs:
+        c_.profile(False)
     dt = adist.max_over_ranks(dt, dev)
     host_ms = adist.all_over_ranks(host.ms(), dev)            # per rank: wall time the host spends queueing one step (the rest of a step it is free)
     host_cpu_ms = adist.all_over_ranks(host.cpu_ms(), dev)    # ... and the CPU time of that (a launch that blocks on a full queue is wall time only)
@@ -241,9 +276,12 @@ def run(args, rank, world, local, dev):
         for _ in range(args.warmup):
             points_step()
         cm.barrier(dev, world)
+        if second:
+            points_step(1)
+            cm.barrier(dev, world)
         tp = time.perf_counter()
-        for _ in range(args.steps):
-            points_step()
+        for i in range(args.steps):
+            points_step(i % len(ctxs))
         cm.barrier(dev, world)
         points_only = B * args.steps * world / adist.max_over_ranks(time.perf_counter() - tp, dev)
         step()                         # (the counts reported below are the PLNet step's)
@@ -289,6 +327,13 @@ def run(args, rank, world, local, dev):
             out["host_to_host"] = dict(h2h, ratio_to_resident=h2h["pairs_per_s"] / resident)
         if args.tuning:
             out["config"]["tuning"] = args.tuning
+        out["config"]["steps_in_flight"] = len(ctxs)
+        if second:
+            out["config"]["steps_in_flight_note"] = ("consecutive steps alternate between two contexts (own arena, stream and result buffers; the same resident images): a step is "
+                                                     "still ONE airfe_stereo_plnet_batch_dev call over pairs_per_step_per_gpu pairs, and step i + 1 is queued while step i runs; the "
+                                                     "dominant kernel's launch duration is measured WITH the other step's kernels beside it")
+            if not (torch.equal(nm, second["nm"]) and torch.equal(idx, second["idx"])):
+                raise SystemExit("bench: the two contexts in flight returned different matches for the same pairs")
         if plnet:
             out["config"]["line_precision"] = args.line_precision or "library default (include/airfe.h)"
         if track:
@@ -356,5 +401,7 @@ def run(args, rank, world, local, dev):
                     print(f"bench.py: GPU and CPU-oracle match counts disagree on the same pairs: {cb}", file=sys.stderr)
         print(json.dumps(out))
     ctx.close()
+    if second:
+        second["ctx"].close()
     if world > 1:
         torch.distributed.destroy_process_group()
