@@ -196,8 +196,6 @@ int airfe_create(const airfe_cfg* cfg, airfe_ctx** out) try {
   if (cfg->precision < 0 || cfg->precision > 2) return fail(nullptr, "airfe_create: precision must be 0 (bf16), 1 (fp16) or 2 (fp32)");
   if (cfg->matcher_precision < -1 || cfg->matcher_precision > 2)
     return fail(nullptr, "airfe_create: matcher_precision must be -1 (= precision), 0 (bf16), 1 (fp16) or 2 (fp32)");
-  if ((cfg->matcher_precision == 2 || (cfg->matcher_precision < 0 && cfg->precision == 2)) && cfg->superglue_pack)
-    return fail(nullptr, "airfe_create: the fp32 mode covers SuperPoint / PLNet + LightGlue (BASELINE configs[1]); SuperGlue runs in fp16 / bf16");
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, "airfe_create: hipSetDevice failed");
   // (owned by a guard until the very end: an exception below — a weight pack that does not fit the host's memory, say — must not leak the arena)
   struct Guard { airfe_ctx* p; ~Guard() { if (p) airfe_destroy(p); } } guard{new airfe_ctx()};
@@ -885,7 +883,7 @@ int airfe_detect_plnet(airfe_ctx* c, const uint8_t* gray, int h, int w, int stri
 static int plnet_lines_batch(airfe_ctx* c, int B, int h, int w, double* d_lines, int capL, int* d_nlines, float* d_junc, int capJ,
                              int* d_njunc, int nj, int* d_found, hipStream_t st, int phase = 3) {
   if (!c->has_s0 || !c->has_s1) return fail(c, "the batched PLNet path needs the line branch (line.* in the detector pack) and cfg.plnet_s1_pack");
-  if (c->prec == 2) return fail(c, "the batched PLNet path runs in fp16 / bf16 (the fp32 mode is one image per call)");
+  if (c->prec == 2) return fail(c, "plnet_lines_batch is the 2-byte batch path (fp32 mode goes image by image: plnet_batch_f32)");
   if (B > c->Lmax) return fail(c, "batch exceeds the line-path arena");
   if (capL < 1 || !d_lines || !d_nlines) return fail(c, "detect_plnet_batch: no line output");
   if (nj < 0 || nj > B || (nj > 0 && (!d_junc || !d_njunc || capJ < 1))) return fail(c, "detect_plnet_batch: bad junction arguments");
@@ -903,11 +901,36 @@ static int plnet_lines_batch(airfe_ctx* c, int B, int h, int w, double* d_lines,
   return rc;
 }
 
+// The batched PLNet entries in fp32 mode (cfg.precision = 2, round 6): the same results through the one-image path, image by image — the fp32 line head works
+// from ONE image's fp32 conv3a activations (line_branch_dev's fused form), so every image runs encoder -> point branch -> line branch -> tail before the next
+// one starts.  A correctness mode: nothing here is batched for speed.  lfound / jfound: per image "found" counts (nullptr: the context's scratch words).
+static int plnet_batch_f32(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat, int cap, int* d_n,
+                           double* d_lines, int capL, int* d_nlines, float* d_junc, int capJ, int* d_njunc, int nj, int* lfound, int* jfound, hipStream_t st) {
+  if (!c->has_s0 || !c->has_s1) return fail(c, "the batched PLNet path needs the line branch (line.* in the detector pack) and cfg.plnet_s1_pack");
+  if (capL < 1 || !d_lines || !d_nlines) return fail(c, "detect_plnet_batch: no line output");
+  if (nj < 0 || nj > B || (nj > 0 && (!d_junc || !d_njunc || capJ < 1))) return fail(c, "detect_plnet_batch: bad junction arguments");
+  for (int b = 0; b < B; ++b) {
+    const bool jn = b < nj;
+    c->force_nms_map = jn;
+    const int rc = detect_dev(c, d_gray + (size_t)b * img_stride, 1, h, w, stride, img_stride, d_feat + (size_t)b * cap * AIRFE_FEAT_DIM, cap, d_n + b, st);
+    c->force_nms_map = false;
+    if (rc || line_branch_dev(c, st, 0, 1, false)) return 1;
+    if (line_tail_dev(c, 0, 1, nullptr, h, w, d_lines + (size_t)b * capL * 4, capL, d_nlines + b, lfound ? lfound + b : c->d_nlines + c->Lmax,
+                      jn ? d_junc + (size_t)b * capJ * AIRFE_FEAT_DIM : nullptr, capJ, jn ? d_njunc + b : nullptr, jn ? (jfound ? jfound + b : c->d_njunc + c->Lmax) : nullptr,
+                      jn ? 1 : 0, st, 3))
+      return 1;
+  }
+  return 0;
+}
+
 int airfe_detect_plnet_batch_dev(airfe_ctx* c, const uint8_t* d_gray, int B, int h, int w, int stride, size_t img_stride, float* d_feat,
                                  int cap, int* d_n, double* d_lines, int capL, int* d_nlines, float* d_junc, int capJ, int* d_njunc,
                                  int junction_images, int* d_found, void* stream) try {
   AIRFE_ENTER(c);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  if (c->prec == 2)
+    return plnet_batch_f32(c, d_gray, B, h, w, stride, img_stride, d_feat, cap, d_n, d_lines, capL, d_nlines, d_junc, capJ, d_njunc, junction_images, d_found,
+                           d_found ? d_found + B : nullptr, st);
   c->force_nms_map = junction_images > 0;         // junction scores are read from the NMS'd maps
   const int rc = detect_dev(c, d_gray, B, h, w, stride, img_stride, d_feat, cap, d_n, st);
   c->force_nms_map = false;
@@ -921,8 +944,20 @@ static int stereo_plnet_dev(airfe_ctx* c, const uint8_t* d_left, const uint8_t* 
                             int capL, int* d_nlines, float* d_juncL, int capJ, int* d_njuncL, int* d_found, int32_t* d_idx,
                             float* d_score, int mcap, int* d_nmatch, hipStream_t st, const std::function<int(hipStream_t)>* after_detect = nullptr,
                             const std::function<int(hipStream_t)>* after_lines = nullptr, const LgSecondPair* x2 = nullptr) {
-  if (!(c->prec != 2 && 2 * B <= c->Dmax))
-    return fail(c, "stereo_plnet_batch: needs the one-pass stereo detector (detector + LightGlue packs loaded, 2 B <= 2 max_batch, fp16 / bf16)");
+  if (c->prec == 2) {            // fp32 mode: image by image (plnet_batch_f32), then the matcher over the B pairs (fp32 too unless matcher_precision says otherwise)
+    if (x2) return fail(c, "stereo_plnet_batch: the second (temporal) pair rides in a 2-byte forward (precision fp16 / bf16)");
+    if (plnet_batch_f32(c, d_left, B, h, w, stride, img_stride, d_featL, cap, d_nL, d_lines, capL, d_nlines, d_juncL, capJ, d_njuncL, d_juncL ? B : 0, d_found,
+                        d_found ? d_found + 2 * B : nullptr, st) ||
+        plnet_batch_f32(c, d_right, B, h, w, stride, img_stride, d_featR, cap, d_nR, d_lines + (size_t)B * capL * 4, capL, d_nlines + B, nullptr, 0, nullptr, 0,
+                        d_found ? d_found + B : nullptr, nullptr, st))
+      return 1;
+    if (after_detect && (*after_detect)(st)) return 1;
+    if (after_lines && (*after_lines)(st)) return 1;
+    if (!d_idx) return 0;
+    return lightglue_dev(c, d_featL, d_nL, d_featR, d_nR, B, cap, AIRFE_FEAT_DIM, 1, 1, d_idx, d_score, mcap, d_nmatch, nullptr, st, nullptr);
+  }
+  if (!(2 * B <= c->Dmax))
+    return fail(c, "stereo_plnet_batch: needs the one-pass stereo detector (detector + LightGlue packs loaded, 2 B <= 2 max_batch)");
   // (With stage timers on anything behind the encoder the chains run one after the other: a stage's event pair must not span the other chain.)
   const uint32_t enc_only = (1u << ST_PREPROCESS) | (1u << ST_CONV1_FUSED) | (1u << ST_CONV3X3_C64);
   const bool overlap = c->overlap_lines && (c->prof_mask & ~enc_only) == 0;

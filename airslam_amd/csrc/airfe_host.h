@@ -208,8 +208,10 @@ struct airfe_ctx {
   struct F32Lin { float* w = nullptr; float* b = nullptr; int K = 0, N = 0; };
   struct F32LgLayer { F32Lin qkv, out, ffn0, ffn3, cqk, cv, cout, cffn0, cffn3; float *ln_g, *ln_b, *cln_g, *cln_b; };
   F32Conv f_c1b, f_c2a, f_c2b, f_c3a, f_c3b, f_c4a, f_c4b, f_cPa, f_cDa, f_cL1;
-  F32Lin f_cPb, f_cDb, f_cLh, f_lgfinal;
+  struct F32SgLayer { F32Lin qkv, merge, mlp0, mlp3; };      // SuperGlue GNN layer: q | k | v rows head-major, merge's input columns head-major
+  F32Lin f_cPb, f_cDb, f_cLh, f_lgfinal, f_sgfinal;
   std::vector<F32LgLayer> f_lg;
+  std::vector<F32SgLayer> f_sg;
   int f_B = 0;                   // images per pass of the fp32 encoder (its activations are 4 bytes: 2 images at a time)
   float *f1a = nullptr, *f1b = nullptr, *fp1 = nullptr, *f2a = nullptr, *f2b = nullptr, *fp2 = nullptr, *f3a = nullptr, *f3b = nullptr,
         *fp3 = nullptr, *f4a = nullptr, *f4b = nullptr, *fPa = nullptr, *fDa = nullptr, *fL1 = nullptr;

@@ -280,6 +280,8 @@ int load_superpoint_f32(airfe_ctx* c, const Pack& p) {
   return 0;
 }
 
+int alloc_matcher_arena_f32(airfe_ctx* c);
+
 int load_lightglue_f32(airfe_ctx* c, const Pack& p, int L) {
   std::string err;
   c->f_lg.resize(L);
@@ -302,11 +304,52 @@ int load_lightglue_f32(airfe_ctx* c, const Pack& p, int L) {
   }
   ok = ok && f32_lin_named(c, p, "log_assignment." + std::to_string(L - 1) + ".final_proj", 256, 256, c->f_lgfinal, err);
   if (!ok) return fail(c, err.empty() ? "device allocation failed while loading fp32 LightGlue weights" : err);
+  return alloc_matcher_arena_f32(c);
+}
+
+// the fp32 matcher's activations (LightGlue and SuperGlue share them: one matcher runs at a time)
+int alloc_matcher_arena_f32(airfe_ctx* c) {
+  if (c->m_qkv) return 0;
   const size_t M = (size_t)(2 * c->Pmax + 2 + 128 / c->Np) * c->Np + 256;
   c->m_qkv = dalloc<float>(c, M * 768); c->m_ctx = dalloc<float>(c, M * 256); c->m_msg = dalloc<float>(c, M * 256);
   c->m_h = dalloc<float>(c, M * 512); c->m_md = dalloc<float>(c, M * 256);
   if (!c->m_qkv || !c->m_ctx || !c->m_msg || !c->m_h || !c->m_md) return fail(c, "device allocation failed (fp32 matcher arena)");
   return 0;
+}
+
+// SuperGlue in fp32 (cfg.matcher_precision = 2): the GNN's linears as plain [N][K] fp32 matrices.  MultiHeadedAttention views its channels as
+// (dim, heads) — channel = d * 4 + h — while the attention kernel wants a head's 64 features side by side: the q / k / v ROWS and merge's input
+// COLUMNS are permuted to head-major here (the same permutation the 2-byte loader applies, load_superglue below), nothing else changes.
+int load_superglue_f32(airfe_ctx* c, const Pack& p, int L) {
+  std::string err;
+  const auto hm = [](int f) { return (f & 63) * 4 + (f >> 6); };
+  c->f_sg.resize(L);
+  bool ok = true;
+  for (int i = 0; i < L && ok; ++i) {
+    auto& l = c->f_sg[i];
+    const std::string g = "gnn.layers." + std::to_string(i);
+    const Tensor *w[3], *b[3];
+    for (int j = 0; j < 3; ++j) {
+      w[j] = need(p, g + ".attn.proj." + std::to_string(j) + ".weight", err);
+      b[j] = need(p, g + ".attn.proj." + std::to_string(j) + ".bias", err);
+      if (!w[j] || !b[j] || w[j]->data.size() != 256 * 256 || b[j]->data.size() != 256) { ok = false; break; }
+    }
+    const Tensor *wm = need(p, g + ".attn.merge.weight", err), *bm = need(p, g + ".attn.merge.bias", err);
+    if (!ok || !wm || !bm || wm->data.size() != 256 * 256 || bm->data.size() != 256) { ok = false; break; }
+    std::vector<float> wqkv((size_t)768 * 256), bqkv(768), wmp((size_t)256 * 256);
+    for (int j = 0; j < 3; ++j)
+      for (int f = 0; f < 256; ++f) {
+        memcpy(&wqkv[((size_t)j * 256 + f) * 256], &w[j]->data[(size_t)hm(f) * 256], 1024);
+        bqkv[j * 256 + f] = b[j]->data[hm(f)];
+      }
+    for (int n = 0; n < 256; ++n)
+      for (int f = 0; f < 256; ++f) wmp[(size_t)n * 256 + f] = wm->data[(size_t)n * 256 + hm(f)];
+    ok = f32_lin(c, wqkv.data(), bqkv.data(), 256, 768, l.qkv) && f32_lin(c, wmp.data(), bm->data.data(), 256, 256, l.merge) &&
+         f32_lin_named(c, p, g + ".mlp.0", 512, 512, l.mlp0, err) && f32_lin_named(c, p, g + ".mlp.3", 512, 256, l.mlp3, err);
+  }
+  ok = ok && f32_lin_named(c, p, "final_proj", 256, 256, c->f_sgfinal, err);
+  if (!ok) return fail(c, err.empty() ? "SuperGlue (fp32): unexpected shapes or device allocation failed" : err);
+  return alloc_matcher_arena_f32(c);
 }
 
 int load_superpoint(airfe_ctx* c, const char* path) {
@@ -497,7 +540,7 @@ float* upload_transposed(airfe_ctx* c, const Tensor& w, int N, int K, int pad_ro
 }
 
 int load_superglue(airfe_ctx* c, const char* path) {
-  c->pack_prec = c->mprec;
+  c->pack_prec = c->mprec == 2 ? 1 : c->mprec;
   Pack p;
   std::string err;
   if (!load_pack(path, p, err)) return fail(c, err);
@@ -561,6 +604,7 @@ int load_superglue(airfe_ctx* c, const char* path) {
   if (!c->sg_u || !c->sg_v || !c->sg_Z || !c->sg_max0 || !c->sg_ms0 || !c->sg_ms1 || !c->sg_idx0 || !c->sg_idx1 ||
       !c->sg_out0 || !c->sg_out1 || !c->sg_cnt || !c->sg_xch)
     return fail(c, "device allocation failed (SuperGlue arena)");
+  if (c->mprec == 2 && load_superglue_f32(c, p, L)) return 1;
   c->has_sg = true;
   return 0;
 }

@@ -54,6 +54,44 @@ int lightglue_dev_f32(airfe_ctx* c, const float* f0, const int* n0, const float*
   return launch_status(c);
 }
 
+// SuperGlue forward in fp32 (same call contract as superglue_dev; cfg.matcher_precision = 2): keypoint encoder as fp32 FMA loops (the prepare kernel's unsplit
+// form), per GNN layer q | k | v from ONE [768][256] projection with head-major rows, exact soft-max attention (self / cross alternate: names = ['self', 'cross'] * 9),
+// merge, mlp.0 on cat(x, message) + ReLU (BatchNorm is folded into mlp.0 in the pack), mlp.3 added to x; final_proj with d^-1/4 on both sides; the optimal-transport
+// tail (Sinkhorn in log space, decode) is the shared fp32 code.
+static int superglue_dev_f32(airfe_ctx* c, const float* f0, const int* n0, const float* f1, const int* n1, int B, int cap, int normalize, hipStream_t st) {
+  const int S = 2 * B, Np = c->Np, M = S * Np;
+  const float cx = (float)(c->cfg.image_width / 2), cy = (float)(c->cfg.image_height / 2);
+  const float linv = (float)(1.0 / std::max(c->cfg.image_width, c->cfg.image_height) * (double)0.7f);   // point_matcher.cc:58
+  reset_slack_rows(c, M, st);
+  launch_sg_prepare(1, f0, f1, n0, n1, AIRFE_FEAT_DIM, normalize, cx, cy, linv, c->sg_kenc, B, cap, Np, c->x32, c->xb, c->lens, nullptr, st);
+  auto lin = [&](const airfe_ctx::F32Lin& w, const float* x1, int ld1, int K1, const float* x2, int ld2, float* y, int ldy, int acc, int relu, float scale = 1.f) {
+    GemmF32Args g;
+    g.X1 = x1; g.ld1 = ld1; g.K1 = K1; g.X2 = x2; g.ld2 = ld2; g.W = w.w; g.bias = w.b; g.Y = y; g.ldy = ldy;
+    g.M = M; g.N = w.N; g.K = w.K; g.accumulate = acc; g.relu = relu; g.scale = scale;
+    launch_gemm_f32(g, st);
+  };
+  int li = 0;
+  for (const auto& l : c->f_sg) {
+    const int cross = li & 1;
+    ++li;
+    lin(l.qkv, c->x32, 256, 256, nullptr, 0, c->m_qkv, 768, 0, 0);
+    launch_attention_f32(c->m_qkv, 768, c->m_qkv + 256, 768, c->m_qkv + 512, 768, c->m_ctx, c->lens, S, 4, Np, cross, 0.125f, st);
+    lin(l.merge, c->m_ctx, 256, 256, nullptr, 0, c->m_msg, 256, 0, 0);
+    lin(l.mlp0, c->x32, 256, 256, c->m_msg, 256, c->m_h, 512, 0, 1);
+    lin(l.mlp3, c->m_h, 512, 512, nullptr, 0, c->x32, 256, 1, 0);
+  }
+  lin(c->f_sgfinal, c->x32, 256, 256, nullptr, 0, c->m_md, 256, 0, 0, 0.25f);      // scores / 256^.5 split over both sides
+  for (int b = 0; b < B; ++b) {                                                      // sim[b] = md[2b] . md[2b+1]^T
+    GemmF32Args g;
+    g.X1 = c->m_md + (size_t)(2 * b) * Np * 256; g.ld1 = 256; g.K1 = 256; g.K = 256; g.W = c->m_md + (size_t)(2 * b + 1) * Np * 256;
+    g.Y = c->simbuf + (size_t)b * Np * Np; g.ldy = Np; g.M = Np; g.N = Np;
+    launch_gemm_f32(g, st);
+  }
+  launch_sg_sinkhorn(c->simbuf, c->lens, B, Np, c->Lz, c->sg_alpha, c->cfg.sinkhorn_iters, c->sg_u, c->sg_v, c->sg_Z, c->sg_cnt, c->sg_cnt + (size_t)c->Pmax * 16, c->sg_xch, st);
+  launch_sg_decode(c->sg_Z, c->lens, B, Np, c->Lz, 0.2f, c->sg_idx0, c->sg_max0, c->sg_idx1, c->sg_out0, c->sg_out1, c->sg_ms0, c->sg_ms1, st);
+  return launch_status(c);
+}
+
 // airfe_debug_trace: checksum `words` 32-bit words of p in units of unit_words (slot = one call; no-op unless tracing)
 void trace(airfe_ctx* c, hipStream_t st, const char* what, size_t li, const char* blk, const void* p, size_t words, unsigned unit_words) {
   if (!c->trace_on) return;
@@ -326,6 +364,7 @@ int superglue_dev(airfe_ctx* c, const float* f0, const int* n0, const float* f1,
   if (!c->has_sg) return fail(c, "SuperGlue weights were not loaded (cfg.superglue_pack)");
   if (B < 1 || B > c->Pmax) return fail(c, "pair batch exceeds cfg.max_batch");
   if (cap > c->Np) return fail(c, "feature capacity exceeds the matcher arena (max_keypoints)");
+  if (c->mprec == 2) return superglue_dev_f32(c, f0, n0, f1, n1, B, cap, normalize, st);
   const int S = 2 * B, Np = c->Np, M = S * Np;
   const int Mg = (M + 127) / 128 * 128;
   const float cx = (float)(c->cfg.image_width / 2), cy = (float)(c->cfg.image_height / 2);

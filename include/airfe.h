@@ -87,7 +87,7 @@ typedef struct airfe_cfg {
   const char* superglue_pack;
   int matcher_precision;       /* storage type of the LightGlue / SuperGlue tokens and weights: 1 = fp16 (default: the reference builds
                                   both matcher engines with BuilderFlag::kFP16, light_glue.cpp:115, super_glue.cpp:132; measured 8x
-                                  closer to the fp32 oracle than bf16), 0 = bf16, 2 = fp32 (LightGlue only), -1 = same as `precision` */
+                                  closer to the fp32 oracle than bf16), 0 = bf16, 2 = fp32 (correctness mode, both matchers: f32-input MFMA GEMMs, exact soft-max), -1 = same as `precision` */
   int line_precision;          /* how the PLNet stage-1 LOI head's matrix products (src/plnet.cpp:468-514) are computed on the device path:
                                   3 = fp32 operands as PAIRS of fp16 values on the 2-byte MFMA (hi.hi + hi.lo + lo.hi, fp32 accumulation): the lines of the
                                       fp32 chain (scores within 2e-6, no candidate across the 0.75 threshold), on the pipe the reference runs this engine on

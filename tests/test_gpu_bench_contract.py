@@ -62,6 +62,14 @@ def test_default_workload_line():
     assert d["host"]["cores_per_rank"] == [None]       # one rank: nothing to share
 
 
+def test_two_steps_in_flight_line():
+    """--inflight 2: consecutive steps alternate between two contexts; the line says so, and the run itself checks that both contexts return the same matches"""
+    d = _run("--pairs", "8", "--steps", "4", "--warmup", "1", "--cpu-pairs", "0", "--io-steps", "0", "--inflight", "2")
+    assert d["config"]["steps_in_flight"] == 2 and "steps_in_flight_note" in d["config"] and d["steps"] == 4
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"] and d["config"]["matches_mean"] > 50
+    assert d["roofline"]["launches"] == 4 and 0.0 < d["roofline"]["frac"] < 1.0
+
+
 def test_io_host_line():
     """--io host: `value` = the host-to-host rate (anchor: the reference copies in and out inside every infer(), src/plnet.cpp:231,237), the resident rate beside it"""
     d = _run("--pairs", "8", "--steps", "3", "--warmup", "1", "--cpu-pairs", "0", "--io", "host", "--io-steps", "6")

@@ -66,6 +66,26 @@ def test_fp32_lightglue_scores_and_match_sets(n0, n1):
     assert len(ridx) >= 20
 
 
+@pytest.mark.parametrize("n0,n1,layers,iters,min_valid", [(300, 280, 4, 20, 100), (400, 400, 18, 100, 150), (64, 65, 18, 100, 20), (1, 3, 2, 5, 0)])
+def test_fp32_superglue_scores_and_match_sets(n0, n1, layers, iters, min_valid):
+    """matcher_precision = 2 with the SuperGlue pack (round 6): the GNN as f32-input MFMA GEMMs with exact soft-max attention, the keypoint encoder as fp32 FMA loops,
+    Sinkhorn + decode as always.  Against the fp32 oracle only the summation order differs: the optimal-transport matrix within 2e-3 (the 2-byte path: 1e-2 of a 5e-2
+    gate) and the oracle's matches."""
+    from test_gpu_plnet_superglue import _check_superglue, _sg_pair
+    w = weights.synthetic_superglue(1234, n_layers=layers)
+    ctx = api.Context(superglue=w, matcher=1, max_batch=2, sinkhorn_iters=iters, max_keypoints=400, precision=2, matcher_precision=2)
+    _, _, f0, f1 = _sg_pair(n0, n1, n0 * 7 + n1)
+    z = _check_superglue(f"fp32_sg_{n0}_{n1}_{layers}", ctx, w, f0, f1, layers, iters, 2e-3, min_valid)
+    ref = ref_nets.superglue_forward(w, f0[:, 1:3], f0[:, 0], f0[:, 3:], f1[:, 1:3], f1[:, 0], f1[:, 3:], n_layers=layers, iters=iters)
+    assert np.abs(z - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max() / 20)
+    # ... and the 2-byte default on the same pair stays an order of magnitude further away: the mode is what it says
+    if n0 >= 64:
+        c16 = api.Context(superglue=w, matcher=1, max_batch=2, sinkhorn_iters=iters, max_keypoints=400)
+        assert np.abs(c16.superglue_scores(f0, f1) - ref).max() > 3 * np.abs(z - ref).max()
+        c16.close()
+    ctx.close()
+
+
 def test_fp32_stereo_equals_the_all_oracle_chain():
     ctx, sp, lg = _ctx()
     left, right = synth.stereo_pair(480, 752, 3)
@@ -133,3 +153,48 @@ def test_fp32_sequence_every_output_vs_the_oracle():
         assert r["lines_l_ref"] >= 50 and r["lines_l_dev_hit"] >= 0.98 and r["lines_l_ref_hit"] >= 0.98 and r["lines_r_dev_hit"] >= 0.98 and r["lines_r_ref_hit"] >= 0.98
         assert r["junc_ref"] >= 30 and r["junc_within_1px"] >= 0.98 and abs(r["junc_dev"] - r["junc_ref"]) <= 0.02 * r["junc_ref"]
     assert sum(r["match_sets_identical"] for r in rows) >= 6                            # identical match sets on (nearly) every frame
+
+
+def test_fp32_batched_plnet_entries_equal_the_one_image_calls():
+    """Round 6: airfe_detect_plnet_batch_dev / airfe_stereo_plnet_batch_dev in fp32 mode run the one-image path image by image (airfe.hip plnet_batch_f32): every
+    feature row, line and junction byte-equal with airfe_detect_plnet per image, the matches those of the fp32 matcher on those features."""
+    import torch
+    ctx, _, _ = _ctx()
+    B, J, K = 3, 2, 400
+    imgs = np.stack([synth.gabor_image(480, 752, 8 + 3 * i) for i in range(B)])
+    z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device="cuda")
+    o = dict(feat=z(B, K, 259), n=z(B, dt=torch.int32), lines=z(B, 2048, 4, dt=torch.float64), nlines=z(B, dt=torch.int32), junc=z(J, 1024, 259),
+             njunc=z(J, dt=torch.int32), found=z(B + J, dt=torch.int32))
+    ctx.detect_plnet_batch_dev(torch.from_numpy(imgs).cuda(), o["feat"], o["n"], o["lines"], o["nlines"], o["junc"], o["njunc"], o["found"])
+    ctx.sync()
+    n, nl, nj, found = (o[k].cpu().numpy() for k in ("n", "nlines", "njunc", "found"))
+    for b in range(B):
+        feat, lines, junc = ctx.detect_plnet(imgs[b], None, want_junctions=b < J)
+        np.testing.assert_array_equal(o["feat"][b, :n[b]].cpu().numpy(), feat)
+        np.testing.assert_array_equal(o["lines"][b, :nl[b]].cpu().numpy(), lines)
+        assert n[b] == feat.shape[0] and nl[b] == lines.shape[0] >= 100 and found[b] == lines.shape[0]
+        if b < J:
+            assert nj[b] == junc.shape[0] >= 50 and found[B + b] == junc.shape[0]
+            np.testing.assert_array_equal(o["junc"][b, :nj[b]].cpu().numpy(), junc)
+    # the stereo entry: left = images 0, 1; right = images 1, 2
+    P = 2
+    L, R = torch.from_numpy(imgs[:P]).cuda(), torch.from_numpy(imgs[1:1 + P]).cuda()
+    s = dict(fl=z(P, K, 259), fr=z(P, K, 259), nl=z(P, dt=torch.int32), nr=z(P, dt=torch.int32), lines=z(2 * P, 2048, 4, dt=torch.float64), nlines=z(2 * P, dt=torch.int32),
+             junc=z(P, 1024, 259), njunc=z(P, dt=torch.int32), idx=z(P, K, 2, dt=torch.int32), sc=z(P, K), nm=z(P, dt=torch.int32), found=z(3 * P, dt=torch.int32))
+    ctx.stereo_plnet_batch_dev(L, R, s["fl"], s["fr"], s["nl"], s["nr"], s["lines"], s["nlines"], s["junc"], s["njunc"], s["idx"], s["sc"], s["nm"], s["found"])
+    ctx.sync()
+    h = {k: v.cpu().numpy() for k, v in s.items()}
+    for p in range(P):
+        fl, ll, jl = ctx.detect_plnet(imgs[p], None, want_junctions=True)
+        fr, lr, _ = ctx.detect_plnet(imgs[1 + p], None, want_junctions=False)
+        np.testing.assert_array_equal(h["fl"][p, :h["nl"][p]], fl)
+        np.testing.assert_array_equal(h["fr"][p, :h["nr"][p]], fr)
+        np.testing.assert_array_equal(h["lines"][p, :h["nlines"][p]], ll)
+        np.testing.assert_array_equal(h["lines"][P + p, :h["nlines"][P + p]], lr)
+        np.testing.assert_array_equal(h["junc"][p, :h["njunc"][p]], jl)
+        assert h["found"][p] == ll.shape[0] and h["found"][P + p] == lr.shape[0] and h["found"][2 * P + p] == jl.shape[0]
+        a, b_ = normalised(fl), normalised(fr)                  # PointMatcher::NormalizeKeypoints, then the host entry of the same fp32 matcher
+        idx, sc = ctx.match_lightglue(np.ascontiguousarray(a[:, 1:]), np.ascontiguousarray(b_[:, 1:]))
+        np.testing.assert_array_equal(h["idx"][p, :h["nm"][p]], idx)
+        np.testing.assert_array_equal(h["sc"][p, :h["nm"][p]], sc)
+    assert h["nm"][1] >= 5 or h["nm"][0] >= 5
