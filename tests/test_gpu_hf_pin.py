@@ -125,3 +125,31 @@ def test_superglue_fp32_scores_vs_hf(n0, n1, seed):
     z = _check_superglue(f"hf_superglue_fp32_{n0}_{n1}", ctx, w, a, b, 18, 100, 2e-3, min(n0, n1) // 3 if min(n0, n1) > 8 else 0, ref=hf)
     assert np.abs(z - hf).max() <= 2e-3
     ctx.close()
+
+
+@pytest.mark.parametrize("h,w,seed", hf_cases.SP_IMAGES)
+def test_superpoint_fp32_maps_vs_hf(h, w, seed):
+    """precision = 2: the dense score map at Hugging Face's suppressed maxima, the dense descriptors, and the keypoints the reference's detect_point takes from HF's
+    suppressed map — to summation order (the 2-byte default above: 1e-3 cosine / 99 % within 1 px)."""
+    ctx, sp, _ = context("sp", max_batch=2, enc_chunk=2, precision=2)
+    img, x = hf_cases.sp_input(h, w, seed)
+    feat = ctx.detect_points(img)
+    heat, nms, desc = ctx.detector_maps(1)
+    hf_nms = np.zeros((512, 512), np.float32)
+    hf_nms.reshape(-1)[GOLD[f"sp_{h}_{w}_{seed}_nms_idx"]] = GOLD[f"sp_{h}_{w}_{seed}_nms_val"]
+    st = hf_cases.DESC_STRIDE
+    hf_desc = GOLD[f"sp_{h}_{w}_{seed}_desc"]
+    cd = cosine_dist(desc[0][::st, ::st].reshape(-1, 256), hf_desc.transpose(1, 2, 0).reshape(-1, 256))
+    sup = hf_nms > 0
+    herr = np.abs(heat[0][sup] - hf_nms[sup])
+    # the device's own suppressed map has HF's support and values
+    nerr = np.abs(nms[0] - hf_nms).max()
+    ws, hs = np.float32(w / 512), np.float32(h / 512)
+    dummy = np.zeros((256, 64, 64), np.float32); dummy[0] = 1
+    ref = ref_post.keypoints_decoder(hf_nms, dummy, 0.004, 4, 400, ws, hs)
+    dev_xy = {(float(a), float(b)) for a, b in feat[:, 1:3]}
+    ref_xy = {(float(a), float(b)) for a, b in ref[:, 1:3]}
+    diag(f"hf_superpoint_fp32_{h}_{w}", desc_cos_max=cd.max(), heat_err_max=herr.max(), nms_err_max=nerr, heat_max=hf_nms.max(), n_dev=feat.shape[0], n_hf=ref.shape[0],
+         xy_sym_diff=len(dev_xy ^ ref_xy))
+    assert cd.max() <= 1e-5 and herr.max() <= 2e-5 * max(float(hf_nms.max()), 1.0) and nerr <= 2e-5 * max(float(hf_nms.max()), 1.0)
+    assert feat.shape[0] > 100 and len(dev_xy ^ ref_xy) <= 2          # the same keypoints but for a score tie at the top-K boundary
