@@ -245,6 +245,11 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
     return;
   }
   typename P::vec8 nxt[NT][2];
+#ifdef LF_NOLDS          // diagnostic build (tools/build_timing_variants.sh): the K loop WITHOUT its B-fragment reads from LDS — four fragments read once, reused by every group
+  typename P::vec8 bf0[4];          // (garbage results; kernel times only: the ceiling of any fix of the LDS side of the loop)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bf0[j] = lds_frag<P>(brow, ((g ^ l15) << 4) + j * 16 * pitch);
+#endif
 #ifdef LF_TIMING2
   [[maybe_unused]] unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0;
   [[maybe_unused]] unsigned long long a_pref = 0, a_vm = 0, a_rd = 0, a_lgkm = 0, a_mma = 0, a_mov = 0, a_trips = 0;
@@ -300,9 +305,15 @@ __device__ __forceinline__ void lf_mma(f32x4 (&acc)[NT][NMT], typename P::vec8 (
         if constexpr (TIMED) LF2_NOW(q3)
 #endif
         typename P::vec8 bf[4];
+#ifdef LF_NOLDS
+        (void)boff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = bf0[j];
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (mb + j < NMT) bf[j] = lds_frag<P>(brow, boff + (mb + j) * 16 * pitch);
+#endif
 #ifdef LF_TIMING2
         if constexpr (TIMED) {
           LF2_NOW(q4)

@@ -25,4 +25,9 @@ hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_NW.so.tmp /tmp
 # diagnostic: attention without its K / V staging behind the first tile (garbage results; kernel times only)
 hipcc $FL -DATT_NODMA -c airslam_amd/csrc/kernels_attn.hip -o /tmp/att_ND.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_ND.so.tmp /tmp/att_ND.o $(others kernels_attn)
+# diagnostic: the block kernel without the B-fragment reads of its K loops (NL), and without both streams (NB): garbage results; kernel times only
+hipcc $FL -DLF_NOLDS -c airslam_amd/csrc/kernels_lgblockf.hip -o /tmp/lf_NL.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_NL.so.tmp /tmp/lf_NL.o $(others kernels_lgblockf)
+hipcc $FL -DLF_NOLDS -DLF_NOWEIGHTS -c airslam_amd/csrc/kernels_lgblockf.hip -o /tmp/lf_NB.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_NB.so.tmp /tmp/lf_NB.o $(others kernels_lgblockf)
 ls -la airslam_amd/*.so.tmp
