@@ -424,6 +424,17 @@ class Context:
                                            y.ctypes.data), "airfe_debug_gemm")
         return y
 
+    def debug_attention(self, q, k, v, lens, cross=False):
+        """The matcher's flash attention alone (include/airfe_debug.h): q, k, v [S, H, n, 64] fp32 (scale and log2 e already inside q / k), lens [S] -> out [S, n, H * 64]."""
+        q = np.ascontiguousarray(q, np.float32); k = np.ascontiguousarray(k, np.float32); v = np.ascontiguousarray(v, np.float32)
+        lens = np.ascontiguousarray(lens, np.int32)
+        s, h, n, d = q.shape
+        assert d == 64 and k.shape == q.shape and v.shape == q.shape and lens.shape == (s,)
+        out = np.empty((s, n, h * 64), np.float32)
+        self._chk(self._l.airfe_debug_attention(self._h, q.ctypes.data, k.ctypes.data, v.ctypes.data, lens.ctypes.data, s, h, n, int(cross), out.ctypes.data),
+                  "airfe_debug_attention")
+        return out
+
     # ---------------------------------------------------------------- device-resident batch (torch plumbing)
     def detect_batch_dev(self, gray_t, feat_t, n_t, stream=None):
         b, h, w = gray_t.shape

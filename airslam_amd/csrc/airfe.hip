@@ -1606,4 +1606,45 @@ int airfe_debug_gemm(airfe_ctx* c, const float* x, int M, int K, const float* w,
   return rc;
 } AIRFE_CATCH(c)
 
+int airfe_debug_attention(airfe_ctx* c, const float* q, const float* k, const float* v, const int* lens, int S, int H, int n, int cross, float* out) try {
+  AIRFE_ENTER(c);
+  if (c->mprec == 2) return fail(c, "debug_attention drives the 2-byte kernel (matcher_precision fp16 / bf16)");
+  if (S < 1 || H < 1 || n < 1 || (S * H) % 8 != 0 || (cross && (S & 1))) return fail(c, "debug_attention: S * H must be a multiple of 8 (cross: S even)");
+  const int Np = (n + 15) / 16 * 16, prec = c->mprec;
+  const size_t rows = (size_t)S * H * Np + 128;                      // (+ slack: the last key tile reads up to 63 rows past a sequence)
+  std::vector<uint16_t> hq(rows * 64, 0), hk(rows * 64, 0), hvt(rows * 64, 0);
+  for (int s = 0; s < S; ++s)
+    for (int h = 0; h < H; ++h)
+      for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 64; ++d) {
+          const size_t src = (((size_t)s * H + h) * n + i) * 64 + d;
+          hq[(((size_t)s * H + h) * Np + i) * 64 + d] = cvt2(q[src], prec);
+          hk[(((size_t)s * H + h) * Np + i) * 64 + d] = cvt2(k[src], prec);
+          hvt[(((size_t)s * H + h) * 64 + d) * Np + i] = cvt2(v[src], prec);       // V^T [S][H][64][Np]
+        }
+  airfe_ctx tmp;   // only as an allocation list holder
+  uint16_t *dq = dupload(&tmp, hq), *dk = dupload(&tmp, hk), *dv = dupload(&tmp, hvt);
+  uint16_t* dout = dalloc<uint16_t>(&tmp, ((size_t)S * Np + 128) * H * 64);
+  std::vector<int> hl(lens, lens + S);
+  int* dl = dupload(&tmp, hl);
+  int rc = 0;
+  if (!dq || !dk || !dv || !dout || !dl) rc = fail(c, "debug_attention: allocation failed");
+  if (!rc) {
+    launch_attention32(prec, dq, dk, dv, dout, dl, S, H, Np, cross, c->stream);
+    if (hipStreamSynchronize(c->stream) != hipSuccess || launch_status(c)) rc = rc ? rc : fail(c, "debug_attention: kernel failed");
+  }
+  if (!rc) {
+    std::vector<uint16_t> ho((size_t)S * Np * H * 64);
+    (void)hipMemcpy(ho.data(), dout, ho.size() * 2, hipMemcpyDeviceToHost);
+    for (int s = 0; s < S; ++s)
+      for (int i = 0; i < n; ++i)
+        for (int f = 0; f < H * 64; ++f) {
+          const uint16_t u = ho[((size_t)s * Np + i) * H * 64 + f];
+          out[((size_t)s * n + i) * H * 64 + f] = back2(u, prec);
+        }
+  }
+  for (void* p : tmp.allocs) (void)hipFree(p);
+  return rc;
+} AIRFE_CATCH(c)
+
 }  // extern "C"

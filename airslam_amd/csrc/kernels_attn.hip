@@ -74,6 +74,14 @@ __device__ __forceinline__ void att_glds16(const void* sbase, unsigned voff, uns
 #ifndef ATT_RETRY_LOOP
 #define ATT_RETRY_LOOP 0
 #endif
+#ifndef ATT_SUBTILE        // 1: a tile runs as a pipeline of its two 32-key sub-tiles inside the wave (round 6: the same bits, measured no faster — 41.6 / 41.3 against 41.2 / 40.6 us,
+#define ATT_SUBTILE 0      // profiles/r06_attention_deletions.txt; kept as the tested alternative); 0 (default): exponentials of the whole tile, then its PV (rounds 3-6)
+#endif
+#ifdef ATT_NOEXP           // diagnostic build (garbage results; kernel times only): the soft-max without its exponentials (and without the overflow re-run they would trigger)
+#define ATT_EXP2(x) (x)
+#else
+#define ATT_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 constexpr float ATT_PSUM_MAX = 16384.0f;   // a lane's partial row sum above this sends the tile through the re-centring path
 
 // The soft-max scale is NOT applied here: sqrt(scale * log2 e) is folded into the packed q and k projection weights
@@ -219,6 +227,7 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
           }
         }
       };
+#if !ATT_SUBTILE
       float ps0, ps1;
       auto exps = [&]() {                                // p = 2^(s - m) in place + the lane's partial row sum
         // (the two partial sums as ONE float pair added in the accumulators' own order: written as two scalars, hipcc's SLP pass paired them the other way
@@ -226,20 +235,21 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
         f32x2 ps = {0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          st0[r] = __builtin_amdgcn_exp2f(st0[r]);
-          st0[r + 1] = __builtin_amdgcn_exp2f(st0[r + 1]);
+          st0[r] = ATT_EXP2(st0[r]);
+          st0[r + 1] = ATT_EXP2(st0[r + 1]);
           ps += f32x2{st0[r], st0[r + 1]};
         }
         if (two) {
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
-            st1[r] = __builtin_amdgcn_exp2f(st1[r]);
-            st1[r + 1] = __builtin_amdgcn_exp2f(st1[r + 1]);
+            st1[r] = ATT_EXP2(st1[r]);
+            st1[r + 1] = ATT_EXP2(st1[r + 1]);
             ps += f32x2{st1[r], st1[r + 1]};
           }
         }
         ps0 = ps.x; ps1 = ps.y;
       };
+#endif
       auto recentre_tile = [&]() {                         // the shift from the tile's explicit row maximum: scores -> scores - max, accumulators rescaled
         float mx = max3f(st0[0], st0[1], st0[2]);
 #pragma unroll
@@ -269,6 +279,7 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
           for (int r = 0; r < 16; ++r) st1[r] -= mx;
         }
       };
+#if !ATT_SUBTILE
 #if ATT_RETRY_LOOP
       bool recentre = (kt == 0);                         // the first tile fixes the shift from its explicit row maximum
       for (;;) {                                         // (one copy of the tile's code: a tile that overflows simply goes round again)
@@ -290,7 +301,11 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
 #endif
       if (kt == 0) recentre_tile();                      // the first tile fixes the shift from its explicit row maximum
       exps();
+#ifdef ATT_NOEXP
+      if (false) {
+#else
       if (kt != 0 && __any(!(ps0 + ps1 <= ATT_PSUM_MAX))) {               // (the negated compare also catches inf / NaN sums)
+#endif
         scores();
         recentre_tile();
         exps();
@@ -344,11 +359,127 @@ __global__ __launch_bounds__(256, OCC) void attention32_kernel(const uint16_t* _
           }
         }
       }
+#else
+      // ---- round 6: the tile as a pipeline of its two 32-key SUB-TILES inside the wave (tools/microbench/valu_rates.hip: this kernel is bound by the latency of each
+      // wave's serial chain scores -> exponentials -> PV, not by issue slots).  Order: all V^T fragments requested right behind the score chains (they take the K
+      // fragments' registers; their LDS latency passes under the exponentials), exponentials + pack of sub-tile 0, PV of sub-tile 0 ISSUED, then the exponentials of
+      // sub-tile 1 while those four MFMAs run, pack, PV of sub-tile 1.  Same operations on the same values in the same order per accumulator as the tile-at-once form
+      // (-DATT_SUBTILE=0): the same bits, except in a tile that re-centres — the unit of the online soft-max is now the sub-tile, and a re-centring never LOWERS the shift
+      // (rows of the wave that did not overflow keep theirs: alpha = 1).
+      f32x2 ps = {0.f, 0.f};                             // the lane's partial row sums of this tile (one float pair, added in the accumulators' own order)
+      auto exps_sub = [&](f32x16& st) {                  // p = 2^(s - m) in place, sums into ps
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          st[r] = __builtin_amdgcn_exp2f(st[r]);
+          st[r + 1] = __builtin_amdgcn_exp2f(st[r + 1]);
+          ps += f32x2{st[r], st[r + 1]};
+        }
+      };
+      auto rowmax = [&](const f32x16& st) {              // over the lane's 16 keys of the sub-tile and its partner lane's 16
+        float mx = max3f(st[0], st[1], st[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = max3f(mx, st[r], st[r + 1]);
+        return pair_max(fmaxf(mx, st[15]));
+      };
+      auto rescale = [&](float mx) {                     // the shift moves up by mx >= 0: everything accumulated so far shrinks by 2^-mx
+        const float alpha = __builtin_amdgcn_exp2f(-mx);
+        l_i *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        m_i += mx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cinit[r] = -m_i;
+        return alpha;
+      };
+      auto pack_sub = [&](const f32x16& st, typename P::vec8 (&pf)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float pv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pv[e] = st[8 * j + e];
+          pf[j] = __builtin_bit_cast(typename P::vec8, pack8<P>(pv));
+        }
+      };
+      scores();
+#ifdef ATT_TIMING
+      ATT_NOW(t_b)                                       // K fragments read, QK^T chains issued
+      ATT_NOW(t_c)
+#endif
+      typename P::vec8 vf[2][2];                         // V^T fragments of a sub-tile: [16-key step j4][32-row d tile dt]
+#pragma unroll
+      for (int j4 = 0; j4 < 2; ++j4)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) vf[j4][dt] = lds_frag<P>(vb, (dt * 32 + l31) * 128 + (((j4 * 2 + hh) ^ fsw) << 4));
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt == 0) recentre_tile();                      // the first tile fixes the shift from its explicit row maximum (both sub-tiles; nothing accumulated yet)
+      typename P::vec8 pf0[2], pf1[2];
+      // ---- sub-tile 0
+      exps_sub(st0);
+      if (kt != 0 && __any(!(ps.x + ps.y <= ATT_PSUM_MAX))) {     // (the negated compare also catches inf / NaN sums)
+        scores();                                        // st0 was exponentiated in place: both chains again (a rare path)
+        const float mx = fmaxf(rowmax(st0), 0.f);
+        rescale(mx);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st0[r] -= mx;
+        if (two) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st1[r] -= mx;
+        }
+        ps = f32x2{0.f, 0.f};
+        exps_sub(st0);
+#ifdef ATT_TIMING
+        s_retry += 1;
+#endif
+      }
+      pack_sub(st0, pf0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j4 = 0; j4 < 2; ++j4) {                   // O^T += V^T . P^T over the sub-tile's two 16-key steps, the two d tiles alternated
+        o[0] = Mfma32<P>::run(vf[j4][0], pf0[j4], o[0]);
+        o[1] = Mfma32<P>::run(vf[j4][1], pf0[j4], o[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- sub-tile 1: its V^T fragments are requested and its exponentials run while the four MFMAs above do
+      if (two) {
+#pragma unroll
+        for (int j4 = 0; j4 < 2; ++j4)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) vf[j4][dt] = lds_frag<P>(vb, (dt * 32 + l31) * 128 + ((((j4 + 2) * 2 + hh) ^ fsw) << 4));
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x2 ps_sub0 = ps;
+        exps_sub(st1);
+        if (__any(!(ps.x + ps.y <= ATT_PSUM_MAX))) {     // (the first tile cannot get here: its shift is the exact maximum, every p <= 1)
+          scores();                                      // (st0 comes back too; it is dead: sub-tile 0 is inside o and ps_sub0 already)
+          const float mx = fmaxf(rowmax(st1), 0.f);
+          const float alpha = rescale(mx);               // o holds sub-tile 0's PV under the old shift: it shrinks with the rest
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st1[r] -= mx;
+          ps = ps_sub0 * alpha;
+          exps_sub(st1);
+#ifdef ATT_TIMING
+          s_retry += 1;
+#endif
+        }
+        pack_sub(st1, pf1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j4 = 0; j4 < 2; ++j4) {
+          o[0] = Mfma32<P>::run(vf[j4][0], pf1[j4], o[0]);
+          o[1] = Mfma32<P>::run(vf[j4][1], pf1[j4], o[1]);
+        }
+      }
+      ATT_NOW(t_d)
+      l_i += ps.x + ps.y;
+#endif
     }
     ATT_NOW(t_e)                                         // P packed, V fragments read, PV chains issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of tile kt + 1 have landed ...
     ATT_NOW(t_f)
+#ifndef ATT_NOBAR      // diagnostic build (with ATT_NODMA; garbage results, kernel times only): the tile loop without its barrier — every wave at its own pace
     __syncthreads();                                     // ... and so have everyone else's; buffer kt & 1 is free again
+#endif
 #ifdef ATT_TIMING
     ATT_NOW(t_g)
     if (active) { s_b += t_b - t_a; s_c += t_c - t_b; s_d += t_d - t_c; s_e += t_e - t_d; s_f += t_f - t_e; s_g += t_g - t_f; s_tiles += 1; }

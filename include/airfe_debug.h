@@ -43,6 +43,11 @@ int airfe_debug_preprocess(airfe_ctx* ctx, const uint8_t* gray, int h, int w, in
 int airfe_debug_conv3x3(airfe_ctx* ctx, const float* x, int B, int cin, int H, int W, const float* w, const float* b,
                         int cout, int pool, float* y);
 int airfe_debug_gemm(airfe_ctx* ctx, const float* x, int M, int K, const float* w, const float* b, int N, int relu, float* y);
+/* the matcher's flash attention alone (kernels_attn.hip) on HOST fp32 tensors, rounded to the matcher's 2-byte type on the way in: q, k [S][H][n][64] with the
+ * soft-max scale and log2 e ALREADY inside (the kernel computes p = 2^(q.k - shift)), v [S][H][n][64], lens [S] (keys / queries beyond lens[s] are padding), cross:
+ * sequence s attends to sequence s ^ 1.  out [S][n][H*64] fp32.  n <= max_keypoints (rounded up to 16 inside); S * H a multiple of 8.  The way to drive the kernel's
+ * re-centring path (a tile whose partial row sums leave the 2-byte range) with hand-built logits. */
+int airfe_debug_attention(airfe_ctx* ctx, const float* q, const float* k, const float* v, const int* lens, int S, int H, int n, int cross, float* out);
 /* error-path test of cfg.check_launches: the NEXT group of launches of profiling stage `stage` (airfe_profile_stage_name's index) is preceded by one
  * deliberately invalid launch (4096 threads per workgroup), so that the entry that makes it must fail with "<stage name>: kernel launch failed: ..." —
  * with check_launches = 0 the same failure surfaces at the pipeline's end without the stage.  -1 disarms. */
