@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <mutex>
 
 namespace airfe {
 
@@ -9,13 +11,32 @@ namespace airfe {
 // instantiation instead of a `static bool` (two contexts on two devices in one process — cfg.device invites it — would have left the second
 // device's kernels without their dynamic-LDS limit).
 struct PerDeviceOnce {
-  bool done[64] = {};
-  bool first() {
+  // Thread-safe (round 6): two host threads driving two contexts may reach a kernel's FIRST launch together.  The one that gets here first runs the caller's
+  // `if (auto once = x.first()) { hipFuncSetAttribute(...) }` body while holding the lock (the token lives as long as the if statement); the other waits for it and then
+  // sees `done` — it can no longer launch a kernel whose dynamic-LDS limit is still being raised.  Behind the first use the fast path is one acquire load.
+  std::atomic<bool> done[64] = {};
+  std::mutex mu;
+  struct Token {
+    PerDeviceOnce* owner = nullptr;
+    int dev = 0;
+    bool yes = false;
+    std::unique_lock<std::mutex> lock;
+    Token() = default;
+    Token(Token&& o) noexcept : owner(o.owner), dev(o.dev), yes(o.yes), lock(std::move(o.lock)) { o.owner = nullptr; }
+    Token(const Token&) = delete;
+    Token& operator=(const Token&) = delete;
+    explicit operator bool() const { return yes; }
+    ~Token() { if (owner) owner->done[dev].store(true, std::memory_order_release); }      // (before the lock member lets go)
+  };
+  Token first() {
+    Token t;
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
-    if (done[d]) return false;
-    done[d] = true;
-    return true;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) { t.yes = true; return t; }      // (unknown device: set the attribute every time)
+    if (done[d].load(std::memory_order_acquire)) return t;
+    std::unique_lock<std::mutex> lk(mu);
+    if (done[d].load(std::memory_order_relaxed)) return t;
+    t.owner = this; t.dev = d; t.yes = true; t.lock = std::move(lk);
+    return t;
   }
 };
 

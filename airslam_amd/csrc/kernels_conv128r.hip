@@ -170,7 +170,7 @@ template <class P, bool POOL>
 static void conv128r_launch_t(const ConvArgs& a, hipStream_t st) {
   static PerDeviceOnce attr_once;
   auto kfn = conv128r_kernel<P, POOL>;
-  if (attr_once.first()) {
+  if (auto once_token = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, C128R_LDS);
   }
   const int tiles_x = a.W / 16, tiles_y = a.H / 8;

@@ -455,7 +455,7 @@ static void conv64r_launch_t(const ConvArgs& a, hipStream_t st) {
   constexpr int LDS = C64R_CONST_OFF + 4096 + 256;
   static PerDeviceOnce attr_once;
   auto kfn = conv64r_kernel<P, POOL, FUSE1A, RW>;
-  if (attr_once.first()) {
+  if (auto once_token = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
   const int tiles_x = a.W / 16, tiles_y = a.H / 16;

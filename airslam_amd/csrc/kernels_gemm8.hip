@@ -216,7 +216,7 @@ static void gemm8_launch_t(int K, const GemmArgs& a, hipStream_t st) {
   constexpr int LDS = 2 * G8_STAGE;
   static PerDeviceOnce attr_once;
   auto kfn = gemm8_kernel<P, TRANS>;
-  if (attr_once.first()) {
+  if (auto once_token = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
   const int mb = a.M / 256;

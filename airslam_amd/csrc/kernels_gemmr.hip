@@ -221,7 +221,7 @@ static void gemmr_pair_launch_t(const GemmArgs& a, const GemmArgs& b, hipStream_
   constexpr int LDS = ROT ? 6 * (GR_XBYTES + GR_RBYTES) : 8 * GR_XBYTES;
   static PerDeviceOnce attr_once;
   auto kfn = gemmr_pair_kernel<P, ROT>;
-  if (attr_once.first()) {
+  if (auto once_token = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
   const int ng_a = a.cb_total / 4, ngroups = ng_a + 1;
@@ -234,7 +234,7 @@ static void gemmr_launch_t(const GemmArgs& a, hipStream_t st) {
   constexpr int LDS = ROT ? 6 * (GR_XBYTES + GR_RBYTES) : 8 * GR_XBYTES;
   static PerDeviceOnce attr_once;
   auto kfn = gemmr_kernel<P, TRANS, ROT>;
-  if (attr_once.first()) {
+  if (auto once_token = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
   const int ngroups = a.cb_total / 4;
@@ -255,11 +255,11 @@ void launch_gemmr_gather(int prec, const GemmArgs& a, hipStream_t st) {
   const int lds = 8 * GR_XBYTES + nmax * GR_TT * 4;
   if (prec == 1) {
     static PerDeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmr_gather_kernel<PF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (auto once_token = once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmr_gather_kernel<PF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(gemmr_gather_kernel<PF16>, dim3((unsigned)nwg), dim3(512), lds, st, a, ntiles);
   } else {
     static PerDeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmr_gather_kernel<PBF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (auto once_token = once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmr_gather_kernel<PBF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(gemmr_gather_kernel<PBF16>, dim3((unsigned)nwg), dim3(512), lds, st, a, ntiles);
   }
 }
@@ -367,11 +367,11 @@ void launch_gemmr_gather128(int prec, const GemmArgs& a, hipStream_t st) {
   const int lds = 8 * G128_TT * 256 + nmax * G128_TT * 4;
   if (prec == 1) {
     static PerDeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmr_gather128_kernel<PF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (auto once_token = once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmr_gather128_kernel<PF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(gemmr_gather128_kernel<PF16>, dim3((unsigned)nwg), dim3(512), lds, st, a, ntiles);
   } else {
     static PerDeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmr_gather128_kernel<PBF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (auto once_token = once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmr_gather128_kernel<PBF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(gemmr_gather128_kernel<PBF16>, dim3((unsigned)nwg), dim3(512), lds, st, a, ntiles);
   }
 }

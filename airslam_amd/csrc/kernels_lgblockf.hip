@@ -763,7 +763,7 @@ static bool launch_mixed(const LgBlockFArgs& a, hipStream_t st) {
   const int n7 = W, n6 = (tiles - 7 * W + 5) / 6;
   static PerDeviceOnce attr_once;
   auto kfn = lg_blockf_mixed_kernel<P, RELU, FOLD>;
-  if (attr_once.first()) {
+  if (auto once_token = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS);
   }
   hipLaunchKernelGGL(kfn, dim3((unsigned)(n7 + n6)), dim3(512), LF_LDS, st, a, n7);
@@ -774,7 +774,7 @@ template <class P, int NMT, bool RELU, int FOLD, bool FOLDO>
 static void launch_fo(const LgBlockFArgs& a, hipStream_t st) {
   static PerDeviceOnce attr_once;
   auto kfn = lg_blockf_kernel<P, NMT, RELU, FOLD, FOLDO>;
-  if (attr_once.first()) {
+  if (auto once_token = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS);
   }
   hipLaunchKernelGGL(kfn, dim3((unsigned)((a.M + 16 * NMT - 1) / (16 * NMT))), dim3(512), LF_LDS, st, a);

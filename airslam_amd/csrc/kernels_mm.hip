@@ -159,7 +159,7 @@ static void conv_launch_t(const ConvArgs& a, hipStream_t st) {
   constexpr int LDS = (TH + 2) * 18 * CIN * 2 + 2 * SLAB_BYTES;
   static PerDeviceOnce attr_once;
   auto kfn = conv3x3_kernel<P, CIN, MR, POOL>;
-  if (attr_once.first()) {
+  if (auto once_token = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
   const int tiles_x = a.W / 16, tiles_y = a.H / TH;
@@ -372,7 +372,7 @@ static void gemm_launch_t(int K, const GemmArgs& a, hipStream_t st) {
   constexpr int LDS = 2 * 32768;
   static PerDeviceOnce attr_once;
   auto kfn = gemm_kernel<P, TRANS>;
-  if (attr_once.first()) {
+  if (auto once_token = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
   const int mb = a.M / 128;
