@@ -1610,6 +1610,9 @@ int airfe_debug_attention(airfe_ctx* c, const float* q, const float* k, const fl
   AIRFE_ENTER(c);
   if (c->mprec == 2) return fail(c, "debug_attention drives the 2-byte kernel (matcher_precision fp16 / bf16)");
   if (S < 1 || H < 1 || n < 1 || (S * H) % 8 != 0 || (cross && (S & 1))) return fail(c, "debug_attention: S * H must be a multiple of 8 (cross: S even)");
+  if (!q || !k || !v || !lens || !out) return fail(c, "debug_attention: null argument");
+  for (int s = 0; s < S; ++s)
+    if (lens[s] < 0 || lens[s] > n) return fail(c, "debug_attention: lens[s] must lie in 0 .. n");
   const int Np = (n + 15) / 16 * 16, prec = c->mprec;
   const size_t rows = (size_t)S * H * Np + 128;                      // (+ slack: the last key tile reads up to 63 rows past a sequence)
   std::vector<uint16_t> hq(rows * 64, 0), hk(rows * 64, 0), hvt(rows * 64, 0);
