@@ -30,8 +30,9 @@ hipcc $FL -DLF_NOLDS -c airslam_amd/csrc/kernels_lgblockf.hip -o /tmp/lf_NL.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_NL.so.tmp /tmp/lf_NL.o $(others kernels_lgblockf)
 hipcc $FL -DLF_NOLDS -DLF_NOWEIGHTS -c airslam_amd/csrc/kernels_lgblockf.hip -o /tmp/lf_NB.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_NB.so.tmp /tmp/lf_NB.o $(others kernels_lgblockf)
-# attention: the sub-tile pipeline (S1: a tested alternative, the same bits) and three more deletions (garbage results; kernel times only): no staging + no barrier, no exponentials, all three
-for v in "S1:-DATT_SUBTILE=1" "ANB:-DATT_NODMA -DATT_NOBAR" "ANE:-DATT_NOEXP" "ANA:-DATT_NODMA -DATT_NOBAR -DATT_NOEXP"; do
+# attention: the sub-tile pipeline (S1: a tested alternative, the same bits), three more deletions (garbage results; kernel times only): no staging + no barrier, no exponentials, all three;
+# workgroups that do nothing (EM) / only their prologue (PO); the prologue in rounds 3-5's order (QF)
+for v in "S1:-DATT_SUBTILE=1" "ANB:-DATT_NODMA -DATT_NOBAR" "ANE:-DATT_NOEXP" "ANA:-DATT_NODMA -DATT_NOBAR -DATT_NOEXP" "EM:-DATT_EMPTY" "PO:-DATT_PROLOGUE_ONLY" "QF:-DATT_Q_FIRST"; do
   n=${v%%:*}; f=${v#*:}
   hipcc $FL $f -c airslam_amd/csrc/kernels_attn.hip -o /tmp/att_$n.o
   hipcc --offload-arch=gfx950 -shared -fPIC -o airslam_amd/libairfe_$n.so.tmp /tmp/att_$n.o $(others kernels_attn)
